@@ -1,0 +1,238 @@
+"""Generate golden vectors by running the UNMODIFIED reference (zakuro-ai/asr, /root/reference) on CPU.
+
+Run in the build container only (the reference does not exist on the GPU box):
+
+    python tests/golden/make_golden.py
+
+Outputs (committed, data only — expected outputs, never reference source):
+    tests/golden/ctc.npz            torch.nn.CTCLoss (the reference's criterion) known answers
+    tests/golden/lengths.npz        get_seq_lens table, _collate_fn + fit() length recovery (A.5)
+    tests/golden/collate.npz        _collate_fn on a 3-sample batch
+    tests/golden/state_manifest.json  state_dict keys/shapes of the reference model (A.1)
+    tests/golden/model_<name>.npz   whole model: logits, loss, grads (sub-sampled), BN running
+                                    stats, 3 AdamW steps — reference statement sequence of
+                                    DeepSpeechTrainer.fit + backward + AdamW.step
+Inputs/weights are NOT stored: they are regenerated from integer hashes (tests/golden/det.py).
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import tempfile
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import det  # noqa: E402
+from _ref_shim import import_reference  # noqa: E402
+
+GRAD_STRIDE = 13
+GRAD_FULL_MAX = 4096
+
+
+def subsample(a: np.ndarray) -> np.ndarray:
+    f = a.reshape(-1)
+    return f if f.size <= GRAD_FULL_MAX else f[::GRAD_STRIDE]
+
+
+def audio_conf():
+    return SimpleNamespace(sample_rate=16000, window_size=0.02, window_stride=0.01, window="hamming",
+                           speed_volume_perturb=False, spec_augment=False, noise_dir=None,
+                           noise_prob=0.4, noise_levels=(0.0, 0.5))
+
+
+def label_csv(tmp, n):
+    import pandas as pd
+    chars = ["_", "'"] + list("abcdefghijklmnopqrstuvwxyz") + ["|"] + [chr(0x3041 + i) for i in range(100)]
+    path = os.path.join(tmp, f"labels{n}.csv")
+    pd.DataFrame({"label": chars[:n]}).to_csv(path, index=False)
+    return path
+
+
+MODELS = {
+    # name: (rnn, hidden, layers, classes, t_ins)
+    "gru_h32_l2": ("gru", 32, 2, 7, [40, 33, 21]),
+    "lstm_h24_l2": ("lstm", 24, 2, 7, [40, 33, 21]),
+    "gru_h48_l3": ("gru", 48, 3, 29, [90, 77, 64, 50, 31]),
+    "lstm_h40_l3": ("lstm", 40, 3, 29, [61, 61, 47, 22]),
+}
+
+
+def gen_ctc(out):
+    torch.manual_seed(0)
+    crit = torch.nn.CTCLoss(reduction="none")
+    cases = {}
+    # case A: all feasible, ragged, repeated labels
+    T, B, C = 12, 4, 7
+    logits = torch.from_numpy(det.unitvar((T, B, C), 11)).requires_grad_(True)
+    targets = torch.tensor([1, 1, 2, 3, 3, 3, 4, 5, 6, 6, 1, 2], dtype=torch.int32)
+    tl = torch.tensor([3, 4, 4, 1], dtype=torch.int32)
+    il = torch.tensor([12, 10, 9, 5], dtype=torch.int32)
+    lp = logits.log_softmax(2)
+    nll = crit(lp, targets, il, tl)
+    nll.sum().backward()
+    cases["a"] = dict(seed=11, T=T, B=B, C=C, targets=targets.numpy(), tl=tl.numpy(), il=il.numpy(),
+                      nll=nll.detach().numpy(), grad=logits.grad.numpy())
+    # case B: row 1 infeasible (needs 2*3-? frames: "1 1 1" needs 5 frames, only 3 given)
+    T, B, C = 9, 3, 5
+    logits = torch.from_numpy(det.unitvar((T, B, C), 12)).requires_grad_(True)
+    targets = torch.tensor([2, 3, 1, 1, 1, 4], dtype=torch.int32)
+    tl = torch.tensor([2, 3, 1], dtype=torch.int32)
+    il = torch.tensor([9, 3, 2], dtype=torch.int32)
+    lp = logits.log_softmax(2)
+    nll = crit(lp, targets, il, tl)
+    cases["b"] = dict(seed=12, T=T, B=B, C=C, targets=targets.numpy(), tl=tl.numpy(), il=il.numpy(),
+                      nll=nll.detach().numpy())
+    # case C: longer, C=29, U up to 10, including length-0 target
+    T, B, C = 50, 5, 29
+    logits = torch.from_numpy(det.unitvar((T, B, C), 13) * 2.0).requires_grad_(True)
+    tl = torch.tensor([10, 7, 5, 0, 3], dtype=torch.int32)
+    targets = torch.from_numpy(det.randint((int(tl.sum()),), 14, 1, C).astype(np.int32))
+    il = torch.tensor([50, 44, 30, 20, 7], dtype=torch.int32)
+    lp = logits.log_softmax(2)
+    nll = crit(lp, targets, il, tl)
+    nll.sum().backward()
+    cases["c"] = dict(seed=13, T=T, B=B, C=C, targets=targets.numpy(), tl=tl.numpy(), il=il.numpy(),
+                      nll=nll.detach().numpy(), grad=logits.grad.numpy(), scale=2.0)
+    flat = {}
+    for k, d in cases.items():
+        for kk, v in d.items():
+            flat[f"{k}_{kk}"] = np.asarray(v)
+    np.savez_compressed(os.path.join(out, "ctc.npz"), **flat)
+
+
+def gen_lengths(out, DeepSpeech, functional, tmp):
+    model = DeepSpeech(audio_conf=audio_conf(), decoder=None, label_path=label_csv(tmp, 7),
+                       rnn_type="nn.GRU", rnn_hidden_size=8, rnn_hidden_layers=1)
+    L = torch.arange(1, 2002, dtype=torch.int32)
+    seq = model.get_seq_lens(L).numpy().astype(np.int32)
+    rec = {}
+    for tmax in (201, 501, 1001, 1501, 2001):
+        tb = np.arange(1, tmax + 1)
+        pct = torch.zeros(tmax, dtype=torch.float32)
+        for i, t in enumerate(tb):
+            pct[i] = int(t) / float(tmax)          # functional.py:28
+        rec[f"rec_{tmax}"] = pct.mul_(int(tmax)).int().numpy()  # deepspeech_trainer.py:104
+    np.savez_compressed(os.path.join(out, "lengths.npz"), seq_lens=seq, **rec)
+
+    # _collate_fn example (functional.py:9-32)
+    specs = [torch.from_numpy(det.unitvar((161, t), 20 + i)) for i, t in enumerate((15, 20, 9))]
+    tr = [[4, 5], [1, 2, 3], [6]]
+    inputs, targets, pct, sizes = functional._collate_fn(list(zip(specs, tr)))
+    np.savez_compressed(os.path.join(out, "collate.npz"), inputs=inputs.numpy(), targets=targets.numpy(),
+                        pct=pct.numpy(), sizes=sizes.numpy())
+
+
+def gen_model(out, name, DeepSpeech, tmp):
+    rnn, hidden, layers, classes, t_ins = MODELS[name]
+    model = DeepSpeech(audio_conf=audio_conf(), decoder=None, label_path=label_csv(tmp, classes),
+                       rnn_type={"gru": "nn.GRU", "lstm": "nn.LSTM"}[rnn], rnn_hidden_size=hidden,
+                       rnn_hidden_layers=layers, bidirectional=True)
+    ref_sd = model.state_dict()
+    shapes = det.state_shapes(rnn, hidden, layers, classes)
+    assert list(shapes.keys()) == list(ref_sd.keys()), "state_dict key order/name mismatch"
+    for k, v in ref_sd.items():
+        assert tuple(v.shape) == tuple(shapes[k]), (k, v.shape, shapes[k])
+    weights = det.model_state(shapes, base_seed=0)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in weights.items()})
+    model.train()
+
+    x, targets, pct, tsz = det.batch(len(t_ins), t_ins, classes, seed=1)
+    inputs = torch.from_numpy(x)
+    targets = torch.from_numpy(targets)
+    tsz = torch.from_numpy(tsz)
+    criterion = torch.nn.CTCLoss(reduction="sum")
+    opt = torch.optim.AdamW(model.parameters(), lr=1.5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5)
+
+    taps = {}
+    hooks = [model.conv.register_forward_hook(lambda m, i, o: taps.__setitem__("act2", o[0].detach().clone()))]
+    for l, r in enumerate(model.rnns):
+        hooks.append(r.register_forward_hook(lambda m, i, o, l=l: taps.__setitem__(f"rnn{l}", o.detach().clone())))
+
+    rec = {}
+    losses = []
+    for step in range(3):
+        input_percentages = torch.from_numpy(pct.copy())
+        # ---- reference statement sequence: deepspeech_trainer.py:102-117 (fit) ----
+        input_sizes = input_percentages.mul_(int(inputs.size(3))).int()
+        o, output_sizes = model.forward(inputs, input_sizes)
+        o = o.transpose(0, 1)
+        float_out = o.float().log_softmax(2)
+        loss = criterion(float_out, targets, output_sizes, tsz)
+        loss = loss / inputs.size(0)
+        loss_value = loss.item()
+        # ---- deepspeech_trainer.py:86-95 ----
+        opt.zero_grad()
+        loss.backward()
+        if step == 0:
+            rec["input_sizes"] = input_sizes.numpy()
+            rec["output_sizes"] = output_sizes.numpy()
+            rec["logits"] = o.detach().transpose(0, 1).contiguous().numpy()   # (B,T,C)
+            for k, v in taps.items():
+                rec["tap_" + k] = subsample(v.numpy())
+                rec["tapnorm_" + k] = np.array(float(v.double().norm()))
+            for k, p in model.named_parameters():
+                g = p.grad.detach().numpy()
+                rec["grad_" + k] = subsample(g)
+                rec["gradnorm_" + k] = np.array(float(np.sqrt((g.astype(np.float64) ** 2).sum())))
+                rec["gradsum_" + k] = np.array(float(g.astype(np.float64).sum()))
+            for k, v in model.state_dict().items():
+                if "running_" in k:
+                    rec["buf_" + k] = v.numpy().copy()
+        opt.step()
+        losses.append(loss_value)
+    rec["losses"] = np.array(losses, dtype=np.float64)
+    for k, p in model.named_parameters():
+        w = p.detach().numpy()
+        rec["final_" + k] = subsample(w)
+    for h in hooks:
+        h.remove()
+    # eval-mode forward (softmax) after 3 steps, same inputs
+    model.eval()
+    with torch.no_grad():
+        input_percentages = torch.from_numpy(pct.copy())
+        input_sizes = input_percentages.mul_(int(inputs.size(3))).int()
+        o, _ = model.forward(inputs, input_sizes)
+    rec["eval_probs"] = o.numpy()
+    rec["cfg"] = np.array(json.dumps(dict(rnn=rnn, hidden=hidden, layers=layers, classes=classes, t_ins=t_ins)))
+    np.savez_compressed(os.path.join(out, f"model_{name}.npz"), **rec)
+    print(name, "losses", losses)
+
+
+def gen_manifest(out, DeepSpeech, tmp):
+    man = {}
+    for rnn, hidden, layers, classes in (("gru", 32, 2, 7), ("lstm", 24, 2, 7), ("gru", 768, 5, 29)):
+        model = DeepSpeech(audio_conf=audio_conf(), decoder=None, label_path=label_csv(tmp, classes),
+                           rnn_type={"gru": "nn.GRU", "lstm": "nn.LSTM"}[rnn], rnn_hidden_size=hidden,
+                           rnn_hidden_layers=layers, bidirectional=True)
+        sd = model.state_dict()
+        man[f"{rnn}_{hidden}x{layers}_c{classes}"] = {
+            "keys": {k: list(v.shape) for k, v in sd.items()},
+            "param_count": int(sum(p.numel() for p in model.parameters())),
+            "param_order": [k for k, _ in model.named_parameters()],
+        }
+    with open(os.path.join(out, "state_manifest.json"), "w") as f:
+        json.dump(man, f, indent=1)
+
+
+def main():
+    DeepSpeech, blocks, functional = import_reference()
+    torch.set_num_threads(4)
+    out = HERE
+    with tempfile.TemporaryDirectory() as tmp:
+        gen_ctc(out)
+        gen_lengths(out, DeepSpeech, functional, tmp)
+        gen_manifest(out, DeepSpeech, tmp)
+        for name in MODELS:
+            gen_model(out, name, DeepSpeech, tmp)
+    for f in sorted(os.listdir(out)):
+        if f.endswith((".npz", ".json")):
+            print(f, os.path.getsize(os.path.join(out, f)))
+
+
+if __name__ == "__main__":
+    main()
