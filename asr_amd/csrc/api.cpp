@@ -1,0 +1,28 @@
+// Error/version plumbing of the C-ABI (include/ds2hip.h).
+#include <stdarg.h>
+#include <stdio.h>
+#include "common.h"
+
+static thread_local char g_ds2_err[1024] = "";
+
+int ds2_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_ds2_err, sizeof(g_ds2_err), fmt, ap);
+  va_end(ap);
+  return -1;
+}
+
+extern "C" const char* ds2_last_error(void) { return g_ds2_err; }
+extern "C" const char* ds2_version(void) { return "ds2hip 0.1.0 (gfx950)"; }
+
+extern "C" int ds2_device_info(int* cu_count, int* wave_size, char* arch, int arch_len) {
+  hipDeviceProp_t p;
+  int dev = 0;
+  DS2_HIP(hipGetDevice(&dev));
+  DS2_HIP(hipGetDeviceProperties(&p, dev));
+  if (cu_count) *cu_count = p.multiProcessorCount;
+  if (wave_size) *wave_size = p.warpSize;
+  if (arch && arch_len > 0) snprintf(arch, arch_len, "%s", p.gcnArchName);
+  return 0;
+}

@@ -1,0 +1,50 @@
+// Common device/host helpers for libds2hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "ds2hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+int ds2_set_error(const char* fmt, ...);
+
+#define DS2_REQUIRE(cond, ...)                                    \
+  do {                                                            \
+    if (!(cond)) return ds2_set_error(__VA_ARGS__);               \
+  } while (0)
+
+#define DS2_LAUNCH_CHECK(name)                                                       \
+  do {                                                                               \
+    hipError_t e__ = hipGetLastError();                                              \
+    if (e__ != hipSuccess) return ds2_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+  } while (0)
+
+#define DS2_HIP(call)                                                                \
+  do {                                                                               \
+    hipError_t e__ = (call);                                                         \
+    if (e__ != hipSuccess) return ds2_set_error("%s failed: %s", #call, hipGetErrorString(e__)); \
+  } while (0)
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
+
+// wave64 reductions (all 64 lanes participate)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }

@@ -1,0 +1,520 @@
+// HBM-bound normalisation / reduction kernels of the DeepSpeech2 train step (fp32).
+//
+//   BatchNorm1d over (T*B, H) rows incl. padding rows   blocks.py:75,85-86 ; deepspeech.py:104
+//   BatchNorm2d + Hardtanh(0,20) + MaskConv time mask   deepspeech.py:62-66 ; blocks.py:48-55
+//   direction sum y = h_fwd + h_bwd                      blocks.py:92
+//   (B,C*D,T) <-> (T,B,C*D) collapse/transposes          deepspeech.py:135-137
+//
+// All reductions are two-stage and ORDERED (per-chunk fp32 partials -> fp64 finalize): results
+// are bit-reproducible run to run, no float atomics.  Every kernel is a coalesced stream:
+// 16-byte loads along the contiguous axis, wavefront shuffles + LDS for the in-block reduction.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ f32x4 ld4(const float* __restrict__ p, int valid, bool vec) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (valid >= 4 && vec) {
+    v = *reinterpret_cast<const f32x4*>(p);
+  } else {
+    if (valid > 0) v.x = p[0];
+    if (valid > 1) v.y = p[1];
+    if (valid > 2) v.z = p[2];
+    if (valid > 3) v.w = p[3];
+  }
+  return v;
+}
+__device__ __forceinline__ void st4(float* __restrict__ p, f32x4 v, int valid, bool vec) {
+  if (valid >= 4 && vec) {
+    *reinterpret_cast<f32x4*>(p) = v;
+  } else {
+    if (valid > 0) p[0] = v.x;
+    if (valid > 1) p[1] = v.y;
+    if (valid > 2) p[2] = v.z;
+    if (valid > 3) p[3] = v.w;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Column reductions over a row-major (M, H) matrix: two sums per column.
+//   MODE 0: x = X            ; s0 = sum x, s1 = sum x^2
+//   MODE 1: x = X + X2 -> Y  ; s0 = sum x, s1 = sum x^2            (direction sum + BN stats)
+//   MODE 2: s0 = sum dY, s1 = sum dY * (X - mean) * rstd            (BN backward sums; X2 = dY)
+// block = 256 threads: 16 column-quads (64 columns) x 16 row groups.  grid = (ceil(H/64), chunks)
+// ------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ X2,
+                                                         int ldx2, float* __restrict__ Y, int ldy, int M, int H,
+                                                         int rows_per_chunk, const float* __restrict__ mean,
+                                                         const float* __restrict__ var, float eps, float* __restrict__ part,
+                                                         int vec) {
+  __shared__ float red[16][64][2];
+  const int cq = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int c0 = blockIdx.x * 64 + cq * 4;
+  const int valid = H - c0;
+  const int rbeg = blockIdx.y * rows_per_chunk;
+  const int rend = min(M, rbeg + rows_per_chunk);
+  f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
+  f32x4 mu = {0, 0, 0, 0}, rs = {0, 0, 0, 0};
+  if (MODE == 2 && valid > 0) {
+    mu = ld4(mean + c0, valid, false);
+    f32x4 vv = ld4(var + c0, valid, false);
+    rs.x = rsqrtf(vv.x + eps); rs.y = rsqrtf(vv.y + eps); rs.z = rsqrtf(vv.z + eps); rs.w = rsqrtf(vv.w + eps);
+  }
+  if (valid > 0) {
+    for (int r = rbeg + rg; r < rend; r += 16) {
+      f32x4 x = ld4(X + (long long)r * ldx + c0, valid, vec);
+      if (MODE == 1) {
+        f32x4 x2 = ld4(X2 + (long long)r * ldx2 + c0, valid, vec);
+        x += x2;
+        st4(Y + (long long)r * ldy + c0, x, valid, vec);
+      }
+      if (MODE == 2) {
+        f32x4 dy = ld4(X2 + (long long)r * ldx2 + c0, valid, vec);
+        s0 += dy;
+        s1 += dy * ((x - mu) * rs);
+      } else {
+        s0 += x;
+        s1 += x * x;
+      }
+    }
+  }
+  red[rg][cq * 4 + 0][0] = s0.x; red[rg][cq * 4 + 0][1] = s1.x;
+  red[rg][cq * 4 + 1][0] = s0.y; red[rg][cq * 4 + 1][1] = s1.y;
+  red[rg][cq * 4 + 2][0] = s0.z; red[rg][cq * 4 + 2][1] = s1.z;
+  red[rg][cq * 4 + 3][0] = s0.w; red[rg][cq * 4 + 3][1] = s1.w;
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int c = threadIdx.x >> 1, w = threadIdx.x & 1;
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) s += red[g][c][w];
+    const int col = blockIdx.x * 64 + c;
+    if (col < H) part[((long long)blockIdx.y * H + col) * 2 + w] = s;
+  }
+}
+
+// finalize: sums over chunks in fp64.
+//   kind 0: out0 = mean, out1 = biased var; optional running stats update (momentum, unbiased var)
+//   kind 1: out0 = s0, out1 = s1 (raw sums)
+__global__ void col_finalize_kernel(const float* __restrict__ part, int chunks, int H, double count, int kind,
+                                    float* __restrict__ out0, float* __restrict__ out1, float* __restrict__ run_mean,
+                                    float* __restrict__ run_var, float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= H) return;
+  double a = 0.0, b = 0.0;
+  for (int k = 0; k < chunks; ++k) {
+    a += (double)part[((long long)k * H + c) * 2 + 0];
+    b += (double)part[((long long)k * H + c) * 2 + 1];
+  }
+  if (kind == 0) {
+    const double m = a / count;
+    double v = b / count - m * m;
+    if (v < 0.0) v = 0.0;
+    out0[c] = (float)m;
+    out1[c] = (float)v;
+    if (run_mean) {
+      const double unb = count > 1.0 ? v * count / (count - 1.0) : v;
+      run_mean[c] = (float)((1.0 - momentum) * (double)run_mean[c] + momentum * m);
+      run_var[c] = (float)((1.0 - momentum) * (double)run_var[c] + momentum * unb);
+    }
+  } else {
+    out0[c] = (float)a;
+    out1[c] = (float)b;
+  }
+}
+
+// Y = (X - mean) * rstd * gamma + beta        (M,H) elementwise
+__global__ __launch_bounds__(256) void bn1d_apply_kernel(const float* __restrict__ X, int ldx, float* __restrict__ Y, int ldy,
+                                                         int M, int H, const float* __restrict__ mean,
+                                                         const float* __restrict__ var, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps, int vec) {
+  const int hq = (H + 3) / 4;
+  const long long total = (long long)M * hq;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int r = i / hq, c0 = (i % hq) * 4;
+    const int valid = H - c0;
+    f32x4 x = ld4(X + (long long)r * ldx + c0, valid, vec);
+    f32x4 mu = ld4(mean + c0, valid, false), vv = ld4(var + c0, valid, false);
+    f32x4 g = ld4(gamma + c0, valid, false), b = ld4(beta + c0, valid, false);
+    f32x4 y;
+    y.x = (x.x - mu.x) * rsqrtf(vv.x + eps) * g.x + b.x;
+    y.y = (x.y - mu.y) * rsqrtf(vv.y + eps) * g.y + b.y;
+    y.z = (x.z - mu.z) * rsqrtf(vv.z + eps) * g.z + b.z;
+    y.w = (x.w - mu.w) * rsqrtf(vv.w + eps) * g.w + b.w;
+    st4(Y + (long long)r * ldy + c0, y, valid, vec);
+  }
+}
+
+// dX = gamma*rstd * (dY - s0/M - xhat * s1/M) ; dgamma = s1 ; dbeta = s0 (written by block 0)
+__global__ __launch_bounds__(256) void bn1d_bwd_apply_kernel(const float* __restrict__ dY, int lddy, const float* __restrict__ X,
+                                                             int ldx, float* __restrict__ dX, int lddx, int M, int H,
+                                                             const float* __restrict__ mean, const float* __restrict__ var,
+                                                             const float* __restrict__ gamma, const float* __restrict__ s0,
+                                                             const float* __restrict__ s1, float eps, float inv_count,
+                                                             int vec) {
+  const int hq = (H + 3) / 4;
+  const long long total = (long long)M * hq;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int r = i / hq, c0 = (i % hq) * 4;
+    const int valid = H - c0;
+    f32x4 dy = ld4(dY + (long long)r * lddy + c0, valid, vec);
+    f32x4 x = ld4(X + (long long)r * ldx + c0, valid, vec);
+    f32x4 mu = ld4(mean + c0, valid, false), vv = ld4(var + c0, valid, false), g = ld4(gamma + c0, valid, false);
+    f32x4 a = ld4(s0 + c0, valid, false), b = ld4(s1 + c0, valid, false);
+    f32x4 o;
+    float rs;
+    rs = rsqrtf(vv.x + eps); o.x = g.x * rs * (dy.x - a.x * inv_count - (x.x - mu.x) * rs * b.x * inv_count);
+    rs = rsqrtf(vv.y + eps); o.y = g.y * rs * (dy.y - a.y * inv_count - (x.y - mu.y) * rs * b.y * inv_count);
+    rs = rsqrtf(vv.z + eps); o.z = g.z * rs * (dy.z - a.z * inv_count - (x.z - mu.z) * rs * b.z * inv_count);
+    rs = rsqrtf(vv.w + eps); o.w = g.w * rs * (dy.w - a.w * inv_count - (x.w - mu.w) * rs * b.w * inv_count);
+    st4(dX + (long long)r * lddx + c0, o, valid, vec);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Channel reductions over (B, C, D, T) fp32 (T contiguous), masked by out_len[b].
+//   MODE 0: s0 = sum y, s1 = sum y^2    (y already masked to 0 beyond len: plain sums)
+//   MODE 1: dz = dA * [0 < z < 20] * [t < len],  z = (y-mean)*rstd*gamma+beta
+//           s0 = sum dz, s1 = sum dz * xhat
+// grid = (C, chunks) ; a chunk = a range of (b, d) rows ; block 256 threads stride over T with float4
+// ------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restrict__ Yraw, const float* __restrict__ dA, int Bn,
+                                                          int C, int D, int T, int rows_per_chunk,
+                                                          const int* __restrict__ lens, const float* __restrict__ mean,
+                                                          const float* __restrict__ var, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps, float* __restrict__ part) {
+  __shared__ float red[4][2];
+  const int c = blockIdx.x;
+  const int nrows = Bn * D;
+  const int rbeg = blockIdx.y * rows_per_chunk, rend = min(nrows, rbeg + rows_per_chunk);
+  float mu = 0.f, rs = 0.f, ga = 0.f, be = 0.f;
+  if (MODE == 1) { mu = mean[c]; rs = rsqrtf(var[c] + eps); ga = gamma[c]; be = beta[c]; }
+  float s0 = 0.f, s1 = 0.f;
+  const bool vec = (T % 4) == 0;
+  const int tq = (T + 3) / 4;
+  for (int row = rbeg; row < rend; ++row) {
+    const int b = row / D, d = row % D;
+    const long long base = (((long long)b * C + c) * D + d) * T;
+    const int len = (MODE == 1) ? min(lens[b], T) : T;
+    for (int q = threadIdx.x; q < tq; q += 256) {
+      const int t0 = q * 4;
+      const int valid = T - t0;
+      f32x4 y = ld4(Yraw + base + t0, valid, vec);
+      if (MODE == 0) {
+        s0 += y.x + y.y + y.z + y.w;
+        s1 += y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w;
+      } else {
+        f32x4 da = ld4(dA + base + t0, valid, vec);
+        float yy[4] = {y.x, y.y, y.z, y.w}, dd[4] = {da.x, da.y, da.z, da.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float xh = (yy[j] - mu) * rs;
+          const float z = xh * ga + be;
+          const float dz = (t0 + j < len && z > 0.f && z < 20.f) ? dd[j] : 0.f;
+          s0 += dz;
+          s1 += dz * xh;
+        }
+      }
+    }
+  }
+  s0 = wave_sum(s0);
+  s1 = wave_sum(s1);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[wave][0] = s0; red[wave][1] = s1; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    part[((long long)blockIdx.y * C + c) * 2 + threadIdx.x] = s;
+  }
+}
+
+// a = mask(clamp((y-mean)*rstd*gamma+beta, 0, 20))  on (B,C,D,T)
+__global__ __launch_bounds__(256) void bn2d_act_fwd_kernel(const float* __restrict__ Yraw, float* __restrict__ A, int Bn, int C, int D,
+                                                           int T, const int* __restrict__ lens, const float* __restrict__ mean,
+                                                           const float* __restrict__ var, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps) {
+  const int tq = (T + 3) / 4;
+  const long long total = (long long)Bn * C * D * tq;
+  const bool vec = (T % 4) == 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int q = i % tq;
+    const long long row = i / tq;                 // (b*C + c)*D + d
+    const int c = (row / D) % C, b = row / ((long long)C * D);
+    const int t0 = q * 4, valid = T - t0;
+    const int len = min(lens[b], T);
+    const float mu = mean[c], sc = rsqrtf(var[c] + eps) * gamma[c], be = beta[c];
+    f32x4 y = ld4(Yraw + row * T + t0, valid, vec);
+    f32x4 a;
+    a.x = (t0 + 0 < len) ? fminf(fmaxf((y.x - mu) * sc + be, 0.f), 20.f) : 0.f;
+    a.y = (t0 + 1 < len) ? fminf(fmaxf((y.y - mu) * sc + be, 0.f), 20.f) : 0.f;
+    a.z = (t0 + 2 < len) ? fminf(fmaxf((y.z - mu) * sc + be, 0.f), 20.f) : 0.f;
+    a.w = (t0 + 3 < len) ? fminf(fmaxf((y.w - mu) * sc + be, 0.f), 20.f) : 0.f;
+    st4(A + row * T + t0, a, valid, vec);
+  }
+}
+
+// dy = mask(gamma*rstd*(dz - s0/N - xhat*s1/N)), dz recomputed from dA, y
+__global__ __launch_bounds__(256) void bn2d_act_bwd_apply_kernel(const float* __restrict__ Yraw, const float* __restrict__ dA,
+                                                                 float* __restrict__ dY, int Bn, int C, int D, int T,
+                                                                 const int* __restrict__ lens, const float* __restrict__ mean,
+                                                                 const float* __restrict__ var, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, const float* __restrict__ s0,
+                                                                 const float* __restrict__ s1, float eps, float inv_count) {
+  const int tq = (T + 3) / 4;
+  const long long total = (long long)Bn * C * D * tq;
+  const bool vec = (T % 4) == 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int q = i % tq;
+    const long long row = i / tq;
+    const int c = (row / D) % C, b = row / ((long long)C * D);
+    const int t0 = q * 4, valid = T - t0;
+    const int len = min(lens[b], T);
+    const float mu = mean[c], rs = rsqrtf(var[c] + eps), ga = gamma[c], be = beta[c];
+    const float m0 = s0[c] * inv_count, m1 = s1[c] * inv_count;
+    f32x4 y = ld4(Yraw + row * T + t0, valid, vec);
+    f32x4 da = ld4(dA + row * T + t0, valid, vec);
+    float yy[4] = {y.x, y.y, y.z, y.w}, dd[4] = {da.x, da.y, da.z, da.w}, oo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float xh = (yy[j] - mu) * rs;
+      const float z = xh * ga + be;
+      const bool in = t0 + j < len;
+      const float dz = (in && z > 0.f && z < 20.f) ? dd[j] : 0.f;
+      oo[j] = in ? ga * rs * (dz - m0 - xh * m1) : 0.f;
+    }
+    f32x4 o = {oo[0], oo[1], oo[2], oo[3]};
+    st4(dY + row * T + t0, o, valid, vec);
+  }
+}
+
+// (B, F, T) -> (T, B, F)  [dir 0]   or   (T, B, F) -> (B, F, T)  [dir 1] ; 32x32 LDS tiles
+__global__ __launch_bounds__(256) void transpose_bft_kernel(const float* __restrict__ src, float* __restrict__ dst, int Bn, int F, int T,
+                                                            int dir) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int f0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // ty 0..7
+  if (dir == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f = f0 + ty + 8 * i, t = t0 + tx;
+      tile[ty + 8 * i][tx] = (f < F && t < T) ? src[((long long)b * F + f) * T + t] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int t = t0 + ty + 8 * i, f = f0 + tx;
+      if (f < F && t < T) dst[((long long)t * Bn + b) * F + f] = tile[tx][ty + 8 * i];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int t = t0 + ty + 8 * i, f = f0 + tx;
+      tile[ty + 8 * i][tx] = (f < F && t < T) ? src[((long long)t * Bn + b) * F + f] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f = f0 + ty + 8 * i, t = t0 + tx;
+      if (f < F && t < T) dst[((long long)b * F + f) * T + t] = tile[tx][ty + 8 * i];
+    }
+  }
+}
+
+// generic 2-D transpose: src (R, Cc) ld -> dst (Cc, R) ld ; batched via blockIdx.z
+__global__ __launch_bounds__(256) void transpose2d_kernel(const float* __restrict__ src, int lds_, long long ss, float* __restrict__ dst,
+                                                          int ldd, long long sd, int R, int Cc) {
+  __shared__ float tile[32][33];
+  src += (long long)blockIdx.z * ss;
+  dst += (long long)blockIdx.z * sd;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    tile[ty + 8 * i][tx] = (r < R && c < Cc) ? src[(long long)r * lds_ + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, r = r0 + tx;
+    if (r < R && c < Cc) dst[(long long)c * ldd + r] = tile[tx][ty + 8 * i];
+  }
+}
+
+int pick_chunks(int M, int colblocks, int min_rows) {
+  int chunks = 2048 / (colblocks > 0 ? colblocks : 1);
+  if (chunks < 1) chunks = 1;
+  const int maxc = ceil_div(M, min_rows);
+  if (chunks > maxc) chunks = maxc;
+  if (chunks < 1) chunks = 1;
+  return chunks;
+}
+
+}  // namespace
+
+// workspace: chunks * H * 2 floats, chunks <= 2048
+extern "C" size_t ds2_colreduce_workspace_bytes(int M, int H) { return (size_t)2048 * 2 * sizeof(float) * (size_t)(H > 64 ? H : 64); }
+
+static int col_reduce_launch(int mode, const float* X, int ldx, const float* X2, int ldx2, float* Y, int ldy, int M, int H,
+                             const float* mean, const float* var, float eps, int kind, float* out0, float* out1,
+                             float* run_mean, float* run_var, float momentum, void* ws, size_t ws_bytes, hipStream_t s) {
+  const int colblocks = ceil_div(H, 64);
+  const int chunks = pick_chunks(M, colblocks, 64);
+  const int rpc = ceil_div(M, chunks);
+  const int nch = ceil_div(M, rpc);
+  DS2_REQUIRE(ws && ws_bytes >= (size_t)nch * H * 2 * sizeof(float), "col_reduce: workspace too small");
+  int vec = (ldx % 4 == 0) && ((uintptr_t)X % 16 == 0);
+  if (X2) vec = vec && (ldx2 % 4 == 0) && ((uintptr_t)X2 % 16 == 0);
+  if (Y) vec = vec && (ldy % 4 == 0) && ((uintptr_t)Y % 16 == 0);
+  dim3 grid(colblocks, nch), block(256);
+  float* part = (float*)ws;
+  if (mode == 0) hipLaunchKernelGGL((col_reduce_kernel<0>), grid, block, 0, s, X, ldx, X2, ldx2, Y, ldy, M, H, rpc, mean, var, eps, part, vec);
+  else if (mode == 1) hipLaunchKernelGGL((col_reduce_kernel<1>), grid, block, 0, s, X, ldx, X2, ldx2, Y, ldy, M, H, rpc, mean, var, eps, part, vec);
+  else hipLaunchKernelGGL((col_reduce_kernel<2>), grid, block, 0, s, X, ldx, X2, ldx2, Y, ldy, M, H, rpc, mean, var, eps, part, vec);
+  DS2_LAUNCH_CHECK("col_reduce_kernel");
+  hipLaunchKernelGGL(col_finalize_kernel, dim3(ceil_div(H, 256)), dim3(256), 0, s, (const float*)part, nch, H, (double)M, kind,
+                     out0, out1, run_mean, run_var, momentum);
+  DS2_LAUNCH_CHECK("col_finalize_kernel");
+  return 0;
+}
+
+// mean/biased var per column of X (M,H); optional running-stat update (momentum, unbiased var).
+extern "C" int ds2_colstats_f32(const float* X, int ldx, int M, int H, float* mean, float* var, float* run_mean, float* run_var,
+                                float momentum, void* ws, size_t ws_bytes, void* stream) {
+  DS2_REQUIRE(X && mean && var && M > 0 && H > 0, "ds2_colstats_f32: bad args");
+  return col_reduce_launch(0, X, ldx, nullptr, 0, nullptr, 0, M, H, nullptr, nullptr, 0.f, 0, mean, var, run_mean, run_var,
+                           momentum, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// Y = Xa + Xb and column stats of Y in one pass (direction sum, blocks.py:92, fused with the next BN's statistics)
+extern "C" int ds2_add_colstats_f32(const float* Xa, int lda, const float* Xb, int ldb, float* Y, int ldy, int M, int H,
+                                    float* mean, float* var, float* run_mean, float* run_var, float momentum, void* ws,
+                                    size_t ws_bytes, void* stream) {
+  DS2_REQUIRE(Xa && Xb && Y && mean && var && M > 0 && H > 0, "ds2_add_colstats_f32: bad args");
+  return col_reduce_launch(1, Xa, lda, Xb, ldb, Y, ldy, M, H, nullptr, nullptr, 0.f, 0, mean, var, run_mean, run_var, momentum,
+                           ws, ws_bytes, (hipStream_t)stream);
+}
+
+// column sums: out0[c] = sum_r X[r][c]; out1[c] = sum_r X[r][c]^2
+extern "C" int ds2_colsum_f32(const float* X, int ldx, int M, int H, float* sum, float* sumsq, void* ws, size_t ws_bytes,
+                              void* stream) {
+  DS2_REQUIRE(X && sum && sumsq && M > 0 && H > 0, "ds2_colsum_f32: bad args");
+  return col_reduce_launch(0, X, ldx, nullptr, 0, nullptr, 0, M, H, nullptr, nullptr, 0.f, 1, sum, sumsq, nullptr, nullptr, 0.f,
+                           ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int ds2_bn1d_apply_f32(const float* X, int ldx, float* Y, int ldy, int M, int H, const float* mean, const float* var,
+                                  const float* gamma, const float* beta, float eps, void* stream) {
+  DS2_REQUIRE(X && Y && mean && var && gamma && beta, "ds2_bn1d_apply_f32: null pointer");
+  const int vec = (ldx % 4 == 0) && (ldy % 4 == 0) && ((uintptr_t)X % 16 == 0) && ((uintptr_t)Y % 16 == 0);
+  const long long total = (long long)M * ((H + 3) / 4);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(bn1d_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, X, ldx, Y, ldy, M, H, mean, var, gamma,
+                     beta, eps, vec);
+  DS2_LAUNCH_CHECK("bn1d_apply_kernel");
+  return 0;
+}
+
+// BatchNorm1d backward (training mode): dX, dgamma, dbeta from dY and the forward input X.
+extern "C" int ds2_bn1d_bwd_f32(const float* dY, int lddy, const float* X, int ldx, float* dX, int lddx, int M, int H,
+                                const float* mean, const float* var, const float* gamma, float eps, float* dgamma, float* dbeta,
+                                void* ws, size_t ws_bytes, void* stream) {
+  DS2_REQUIRE(dY && X && dX && mean && var && gamma && dgamma && dbeta, "ds2_bn1d_bwd_f32: null pointer");
+  int rc = col_reduce_launch(2, X, ldx, dY, lddy, nullptr, 0, M, H, mean, var, eps, 1, dbeta, dgamma, nullptr, nullptr, 0.f, ws,
+                             ws_bytes, (hipStream_t)stream);
+  if (rc) return rc;
+  const int vec = (ldx % 4 == 0) && (lddy % 4 == 0) && (lddx % 4 == 0) && ((uintptr_t)X % 16 == 0) &&
+                  ((uintptr_t)dY % 16 == 0) && ((uintptr_t)dX % 16 == 0);
+  const long long total = (long long)M * ((H + 3) / 4);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(bn1d_bwd_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dY, lddy, X, ldx, dX, lddx, M, H, mean,
+                     var, gamma, (const float*)dbeta, (const float*)dgamma, eps, 1.0f / (float)M, vec);
+  DS2_LAUNCH_CHECK("bn1d_bwd_apply_kernel");
+  return 0;
+}
+
+extern "C" size_t ds2_chanreduce_workspace_bytes(int C) { return (size_t)2048 * 2 * sizeof(float) * (size_t)(C > 1 ? C : 1); }
+
+static int chan_reduce_launch(int mode, const float* Y, const float* dA, int Bn, int C, int D, int T, const int* lens,
+                              const float* mean, const float* var, const float* gamma, const float* beta, float eps, int kind,
+                              float* out0, float* out1, float* run_mean, float* run_var, float momentum, void* ws,
+                              size_t ws_bytes, hipStream_t s) {
+  const int nrows = Bn * D;
+  int chunks = 2048 / C;
+  if (chunks < 1) chunks = 1;
+  if (chunks > nrows) chunks = nrows;
+  const int rpc = ceil_div(nrows, chunks);
+  const int nch = ceil_div(nrows, rpc);
+  DS2_REQUIRE(ws && ws_bytes >= (size_t)nch * C * 2 * sizeof(float), "chan_reduce: workspace too small");
+  float* part = (float*)ws;
+  dim3 grid(C, nch), block(256);
+  if (mode == 0) hipLaunchKernelGGL((chan_reduce_kernel<0>), grid, block, 0, s, Y, dA, Bn, C, D, T, rpc, lens, mean, var, gamma, beta, eps, part);
+  else hipLaunchKernelGGL((chan_reduce_kernel<1>), grid, block, 0, s, Y, dA, Bn, C, D, T, rpc, lens, mean, var, gamma, beta, eps, part);
+  DS2_LAUNCH_CHECK("chan_reduce_kernel");
+  hipLaunchKernelGGL(col_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, (const float*)part, nch, C,
+                     (double)Bn * D * T, kind, out0, out1, run_mean, run_var, momentum);
+  DS2_LAUNCH_CHECK("col_finalize_kernel");
+  return 0;
+}
+
+// per-channel batch statistics of the (already time-masked) conv output Y (B,C,D,T); count = B*D*T
+// (padding included).
+extern "C" int ds2_bn2d_stats_f32(const float* Y, int B, int C, int D, int T, float* mean, float* var, float* run_mean,
+                                  float* run_var, float momentum, void* ws, size_t ws_bytes, void* stream) {
+  DS2_REQUIRE(Y && mean && var, "ds2_bn2d_stats_f32: null pointer");
+  return chan_reduce_launch(0, Y, nullptr, B, C, D, T, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0, mean, var, run_mean,
+                            run_var, momentum, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// A = mask(hardtanh_{0,20}(BN(Y)))  (deepspeech.py:62-63 / 65-66 with blocks.py:48-55 masks)
+extern "C" int ds2_bn2d_act_fwd_f32(const float* Y, float* A, int B, int C, int D, int T, const int* lens_dev, const float* mean,
+                                    const float* var, const float* gamma, const float* beta, float eps, void* stream) {
+  DS2_REQUIRE(Y && A && lens_dev && mean && var && gamma && beta, "ds2_bn2d_act_fwd_f32: null pointer");
+  const long long total = (long long)B * C * D * ((T + 3) / 4);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(bn2d_act_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, Y, A, B, C, D, T, lens_dev, mean, var,
+                     gamma, beta, eps);
+  DS2_LAUNCH_CHECK("bn2d_act_fwd_kernel");
+  return 0;
+}
+
+// backward of mask∘hardtanh∘mask∘BN∘(mask): dY (masked), dgamma, dbeta from dA and the raw conv output Y
+extern "C" int ds2_bn2d_act_bwd_f32(const float* Y, const float* dA, float* dY, int B, int C, int D, int T, const int* lens_dev,
+                                    const float* mean, const float* var, const float* gamma, const float* beta, float eps,
+                                    float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream) {
+  DS2_REQUIRE(Y && dA && dY && lens_dev && mean && var && gamma && beta && dgamma && dbeta, "ds2_bn2d_act_bwd_f32: null pointer");
+  int rc = chan_reduce_launch(1, Y, dA, B, C, D, T, lens_dev, mean, var, gamma, beta, eps, 1, dbeta, dgamma, nullptr, nullptr,
+                              0.f, ws, ws_bytes, (hipStream_t)stream);
+  if (rc) return rc;
+  const long long total = (long long)B * C * D * ((T + 3) / 4);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(bn2d_act_bwd_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, Y, dA, dY, B, C, D, T, lens_dev,
+                     mean, var, gamma, beta, (const float*)dbeta, (const float*)dgamma, eps, 1.0f / ((float)B * D * T));
+  DS2_LAUNCH_CHECK("bn2d_act_bwd_apply_kernel");
+  return 0;
+}
+
+// dir 0: (B,F,T) -> (T,B,F)  (deepspeech.py:135-137 collapse) ; dir 1: inverse
+extern "C" int ds2_transpose_bft_f32(const float* src, float* dst, int B, int F, int T, int dir, void* stream) {
+  DS2_REQUIRE(src && dst && B > 0 && F > 0 && T > 0, "ds2_transpose_bft_f32: bad args");
+  dim3 grid(ceil_div(T, 32), ceil_div(F, 32), B);
+  hipLaunchKernelGGL(transpose_bft_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dst, B, F, T, dir);
+  DS2_LAUNCH_CHECK("transpose_bft_kernel");
+  return 0;
+}
+
+extern "C" int ds2_transpose2d_f32(const float* src, int ld_src, long long stride_src, float* dst, int ld_dst, long long stride_dst,
+                                   int R, int Cc, int batch, void* stream) {
+  DS2_REQUIRE(src && dst && R > 0 && Cc > 0 && batch > 0, "ds2_transpose2d_f32: bad args");
+  dim3 grid(ceil_div(Cc, 32), ceil_div(R, 32), batch);
+  hipLaunchKernelGGL(transpose2d_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, stride_src, dst, ld_dst, stride_dst, R, Cc);
+  DS2_LAUNCH_CHECK("transpose2d_kernel");
+  return 0;
+}

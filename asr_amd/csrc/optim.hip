@@ -1,0 +1,76 @@
+// Fused flat-buffer AdamW (decoupled weight decay), one launch for all parameters.
+// Same update as torch.optim.AdamW single-tensor path (trainers/__main__.py:41-47; hyper-parameters
+// asr_deepspeech/config.yml:41-47):  p *= 1 - lr*wd ; m,v EMA ; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+// HBM-bound: 16 B read + 12 B write per parameter... (p,g,m,v in; p,m,v out) = 28 B/param.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
+                                                    float wd, float bc1, float bc2_sqrt, float gscale) {
+  const long long n4 = n / 4;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    f32x4 pp = reinterpret_cast<f32x4*>(p)[i];
+    f32x4 gg = reinterpret_cast<const f32x4*>(g)[i] * gscale;
+    f32x4 mm = reinterpret_cast<f32x4*>(m)[i];
+    f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+    pp *= (1.f - lr * wd);
+    mm = b1 * mm + (1.f - b1) * gg;
+    vv = b2 * vv + (1.f - b2) * gg * gg;
+    f32x4 den;
+    den.x = sqrtf(vv.x) / bc2_sqrt + eps; den.y = sqrtf(vv.y) / bc2_sqrt + eps;
+    den.z = sqrtf(vv.z) / bc2_sqrt + eps; den.w = sqrtf(vv.w) / bc2_sqrt + eps;
+    pp -= (lr / bc1) * mm / den;
+    reinterpret_cast<f32x4*>(p)[i] = pp;
+    reinterpret_cast<f32x4*>(m)[i] = mm;
+    reinterpret_cast<f32x4*>(v)[i] = vv;
+  }
+  // tail
+  const long long tail0 = n4 * 4;
+  for (long long i = tail0 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float pp = p[i], gg = g[i] * gscale, mm = m[i], vv = v[i];
+    pp *= (1.f - lr * wd);
+    mm = b1 * mm + (1.f - b1) * gg;
+    vv = b2 * vv + (1.f - b2) * gg * gg;
+    pp -= (lr / bc1) * mm / (sqrtf(vv) / bc2_sqrt + eps);
+    p[i] = pp; m[i] = mm; v[i] = vv;
+  }
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, long long n, float s) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) x[i] *= s;
+}
+
+}  // namespace
+
+// step is 1-based.  grad_scale multiplies g on the fly (e.g. 1/world_size after an all-reduce SUM).
+extern "C" int ds2_adamw_f32(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                             float weight_decay, int step, float grad_scale, void* stream) {
+  DS2_REQUIRE(p && g && m && v && n >= 0 && step >= 1, "ds2_adamw_f32: bad args");
+  DS2_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0,
+              "ds2_adamw_f32: buffers must be 16-byte aligned");
+  if (n == 0) return 0;
+  const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  long long blocks = (n / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
+                     weight_decay, bc1, (float)sqrt(bc2), grad_scale);
+  DS2_LAUNCH_CHECK("adamw_kernel");
+  return 0;
+}
+
+extern "C" int ds2_scale_f32(float* x, long long n, float s, void* stream) {
+  DS2_REQUIRE(x && n >= 0, "ds2_scale_f32: bad args");
+  if (n == 0) return 0;
+  long long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(scale_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, s);
+  DS2_LAUNCH_CHECK("scale_kernel");
+  return 0;
+}

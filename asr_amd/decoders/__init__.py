@@ -1,0 +1,78 @@
+"""Greedy CTC decoder + WER/CER (host-side mirror of asr_deepspeech/decoders/{decoder,greedy_decoder}.py).
+Needed because `DeepSpeech.__init__` instantiates one (deepspeech.py:55); eval-only, not on the train step.
+The edit distance is a small pure-Python DP (the reference imports the `Levenshtein` C package)."""
+from __future__ import annotations
+
+import torch
+
+
+def _edit_distance(a, b) -> int:
+    if len(a) < len(b):
+        a, b = b, a
+    prev = list(range(len(b) + 1))
+    for i, ca in enumerate(a, 1):
+        cur = [i]
+        for j, cb in enumerate(b, 1):
+            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb)))
+        prev = cur
+    return prev[-1]
+
+
+class Decoder:
+    """decoder.py:4-72: labels is {char: index}; index 0 is the CTC blank."""
+
+    def __init__(self, labels, blank_index=0):
+        self.labels = labels
+        self.int_to_char = dict((i, c) for c, i in labels.items()) if isinstance(labels, dict) else dict(enumerate(labels))
+        self.blank_index = blank_index
+        space_index = len(self.int_to_char)
+        if isinstance(labels, dict) and " " in labels:
+            space_index = labels[" "]
+        self.space_index = space_index
+
+    def wer(self, s1, s2):
+        b = set(s1.split() + s2.split())
+        word2char = dict(zip(b, range(len(b))))
+        w1 = [chr(word2char[w]) for w in s1.split()]
+        w2 = [chr(word2char[w]) for w in s2.split()]
+        return _edit_distance(w1, w2)
+
+    def cer(self, s1, s2):
+        s1, s2 = s1.replace(" ", ""), s2.replace(" ", "")
+        return _edit_distance(s1, s2)
+
+    def decode(self, probs, sizes=None):
+        raise NotImplementedError
+
+
+class GreedyDecoder(Decoder):
+    """greedy_decoder.py:6-68: per-frame argmax, collapse repeats, drop blanks."""
+
+    def convert_to_strings(self, sequences, sizes=None, remove_repetitions=False, return_offsets=False):
+        strings, offsets = [], []
+        for x in range(len(sequences)):
+            seq_len = sizes[x] if sizes is not None else len(sequences[x])
+            string, string_offsets = self.process_string(sequences[x], seq_len, remove_repetitions)
+            strings.append([string])
+            if return_offsets:
+                offsets.append([string_offsets])
+        return (strings, offsets) if return_offsets else strings
+
+    def process_string(self, sequence, size, remove_repetitions=False):
+        string, offsets = "", []
+        seq = [int(v) for v in (sequence.tolist() if torch.is_tensor(sequence) else sequence)][: int(size)]
+        for i, idx in enumerate(seq):
+            char = self.int_to_char.get(idx, "")
+            if idx != self.blank_index:
+                if remove_repetitions and i != 0 and idx == seq[i - 1]:
+                    continue
+                string += " " if idx == self.space_index else char
+                offsets.append(i)
+        return string, torch.tensor(offsets, dtype=torch.int)
+
+    def decode(self, probs, sizes=None):
+        """probs (B,T,C) -> ([[str]], [[offsets]]) ; argmax is one device op, strings are built on host."""
+        max_probs = torch.argmax(probs, 2).cpu()
+        strings, offsets = self.convert_to_strings(max_probs.view(max_probs.size(0), max_probs.size(1)), sizes,
+                                                   remove_repetitions=True, return_offsets=True)
+        return strings, offsets

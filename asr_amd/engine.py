@@ -1,0 +1,219 @@
+"""Forward / backward orchestration of the DeepSpeech2 hot path over the libds2hip kernels.
+
+Mirrors, block for block, what autograd replays for the reference's
+`DeepSpeech.forward` (modules/deepspeech.py:130-149) — MaskConv conv stack (modules/blocks.py:42-56),
+L x BatchRNN (modules/blocks.py:84-93), fc block (modules/deepspeech.py:103-109) — but as an explicit
+schedule of HIP kernels with hand-derived backward passes, no torch compute ops on the path.
+
+`W` is a mapping {reference state_dict key -> fp32 GPU tensor} plus the zero-copy concatenated views
+`rnns.{l}.wih_cat (2GH, I)`, `rnns.{l}.whh_cat (2, GH, H)`, `rnns.{l}.bih_cat (2GH,)`,
+`rnns.{l}.bhh_cat (2, GH)` provided by `asr_amd.params.FlatParams` (forward and reverse direction
+weights are stored adjacently, so both directions run as ONE GEMM / ONE recurrence launch series).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib, ops
+
+Tensor = torch.Tensor
+
+
+@dataclass
+class ModelCfg:
+    rnn: str            # "gru" | "lstm"
+    hidden: int
+    layers: int
+    classes: int
+    freq: int = 161
+
+    @property
+    def gates(self) -> int:
+        return 3 if self.rnn == "gru" else 4
+
+
+@dataclass
+class LayerCtx:
+    xin: Optional[Tensor] = None     # (M, I) raw layer input (previous y) — BN backward needs it
+    xn: Optional[Tensor] = None      # (M, I) GEMM A operand (BN output, or the raw input for layer 0)
+    gx: Optional[Tensor] = None      # (M, 2GH) gates -> overwritten by dGx in backward
+    hbuf: Optional[Tensor] = None    # (M, 2H)
+    aux: Optional[Tensor] = None     # (M, 2H)
+    mean: Optional[Tensor] = None    # BN batch stats of this layer's INPUT (layers >= 1)
+    var: Optional[Tensor] = None
+
+
+@dataclass
+class Ctx:
+    B: int = 0
+    T: int = 0
+    D1: int = 0
+    D2: int = 0
+    x: Optional[Tensor] = None
+    lens_dev: Optional[Tensor] = None
+    y1: Optional[Tensor] = None
+    a1: Optional[Tensor] = None
+    y2: Optional[Tensor] = None
+    st1: tuple = ()
+    st2: tuple = ()
+    packs: tuple = ()
+    layers: List[LayerCtx] = field(default_factory=list)
+    y_last: Optional[Tensor] = None
+    fc_xn: Optional[Tensor] = None
+    fc_stats: tuple = ()
+
+
+def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, training: bool, save: bool = True):
+    """x (B,1,F,Tin) fp32 GPU; lens_dev int32 (B,) GPU = output frame counts.  Returns (logits (T,B,C), ctx)."""
+    if not x.is_cuda:
+        raise _lib.DS2LibraryError("asr_amd.engine.forward needs a GPU tensor: the MI355X kernels are the only implementation "
+                                   "(the CPU restatement lives in oracle/ and is test-only)")
+    x = x.contiguous().float()
+    B, _, F, Tin = x.shape
+    D1, D2, T = _lib.conv_dims(F, Tin)
+    G, H, L = cfg.gates, cfg.hidden, cfg.layers
+    M = T * B
+    ctx = Ctx(B=B, T=T, D1=D1, D2=D2, x=x, lens_dev=lens_dev)
+    cp = "conv.seq_module."
+
+    def run(name):
+        return (W[name + ".running_mean"], W[name + ".running_var"]) if training else (None, None)
+
+    # ---- conv stack -----------------------------------------------------------------------------
+    wpk1, wpk2, wpk2d = ops.conv_pack(W[cp + "0.weight"], W[cp + "3.weight"])
+    ctx.packs = (wpk2d,)
+    y1 = ops.conv1_fwd(x, wpk1, W[cp + "0.bias"], lens_dev)
+    if training:
+        m1, v1 = ops.bn2d_stats(y1, *run(cp + "1"))
+    else:
+        m1, v1 = W[cp + "1.running_mean"], W[cp + "1.running_var"]
+    a1 = ops.bn2d_act_fwd(y1, lens_dev, m1, v1, W[cp + "1.weight"], W[cp + "1.bias"])
+    y2 = ops.conv2_fwd(a1, wpk2, W[cp + "3.bias"], lens_dev)
+    if training:
+        m2, v2 = ops.bn2d_stats(y2, *run(cp + "4"))
+    else:
+        m2, v2 = W[cp + "4.running_mean"], W[cp + "4.running_var"]
+    a2 = ops.bn2d_act_fwd(y2, lens_dev, m2, v2, W[cp + "4.weight"], W[cp + "4.bias"])
+    xin = ops.transpose_bft(a2, B, 32 * D2, T, to_tbf=True).view(M, 32 * D2)   # (T*B, 1312), feature = c*D2 + d
+    del a2
+    if save:
+        ctx.y1, ctx.a1, ctx.y2, ctx.st1, ctx.st2 = y1, a1, y2, (m1, v1), (m2, v2)
+
+    # ---- recurrent stack ------------------------------------------------------------------------
+    mean = var = None
+    for l in range(L):
+        lc = LayerCtx()
+        if l > 0:
+            bp = f"rnns.{l}.batch_norm.module."
+            if not training:
+                mean, var = W[bp + "running_mean"], W[bp + "running_var"]
+            xn = ops.bn1d_apply(xin, mean, var, W[bp + "weight"], W[bp + "bias"])
+            lc.mean, lc.var = mean, var
+        else:
+            xn = xin
+        gx = ops.gemm(xn, W[f"rnns.{l}.wih_cat"], transB=True, bias=W[f"rnns.{l}.bih_cat"])      # (M, 2GH)
+        hbuf, aux = ops.rnn_fwd(G, gx, W[f"rnns.{l}.whh_cat"], W[f"rnns.{l}.bhh_cat"], lens_dev, T, B, H)
+        nxt = f"rnns.{l + 1}.batch_norm.module" if l + 1 < L else "fc.0.module.0"
+        y, mean, var = ops.add_colstats(hbuf[:, :H], hbuf[:, H:], *run(nxt))
+        if save:
+            lc.xin, lc.xn, lc.gx, lc.hbuf, lc.aux = xin, xn, gx, hbuf, aux
+            ctx.layers.append(lc)
+        xin = y
+
+    # ---- fc block -------------------------------------------------------------------------------
+    fp = "fc.0.module."
+    if not training:
+        mean, var = W[fp + "0.running_mean"], W[fp + "0.running_var"]
+    xn = ops.bn1d_apply(xin, mean, var, W[fp + "0.weight"], W[fp + "0.bias"])
+    logits = ops.gemm(xn, W[fp + "1.weight"], transB=True)                                        # (M, C)
+    if save:
+        ctx.y_last, ctx.fc_xn, ctx.fc_stats = xin, xn, (mean, var)
+    if training:
+        for name in ([cp + "1", cp + "4", fp + "0"] + [f"rnns.{l}.batch_norm.module" for l in range(1, L)]):
+            W[name + ".num_batches_tracked"] += 1
+    return logits.view(T, B, cfg.classes), ctx
+
+
+def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ctx, dlogits: Tensor, on_bucket=None):
+    """dlogits (T,B,C) contiguous.  Writes every parameter gradient into Gr[name] (same keys as W for
+    parameters, plus the *_cat views).  Consumes ctx (gate buffers are overwritten in place).
+    `on_bucket(name)` is called as soon as the gradients of 'fc', 'rnns.<l>', 'conv' are final (all
+    kernels enqueued) — the data-parallel reducer launches that bucket's RCCL all-reduce there, so
+    communication overlaps the rest of the backward pass."""
+    done = on_bucket if on_bucket is not None else (lambda name: None)
+    G, H, L, Cn = cfg.gates, cfg.hidden, cfg.layers, cfg.classes
+    B, T, D1, D2 = ctx.B, ctx.T, ctx.D1, ctx.D2
+    M = T * B
+    lens_dev = ctx.lens_dev
+    dl = dlogits.reshape(M, Cn)
+    fp = "fc.0.module."
+    # ---- fc -------------------------------------------------------------------------------------
+    ops.gemm(dl, ctx.fc_xn, transA=True, out=Gr[fp + "1.weight"])                                 # (C, H)
+    dxn = ops.gemm(dl, W[fp + "1.weight"])                                                        # (M, H)
+    mean, var = ctx.fc_stats
+    dy = ops.bn1d_bwd(dxn, ctx.y_last, mean, var, W[fp + "0.weight"], Gr[fp + "0.weight"], Gr[fp + "0.bias"])
+    del dxn
+    done("fc")
+    # ---- recurrent stack ------------------------------------------------------------------------
+    for l in range(L - 1, -1, -1):
+        lc = ctx.layers[l]
+        I = lc.xn.shape[1]
+        whhT = ops.transpose_batched(W[f"rnns.{l}.whh_cat"])                                      # (2, H, GH)
+        ops.rnn_bwd(G, dy, lc.gx, lc.aux, lc.hbuf, whhT, lens_dev, T, B, H)
+        dgx = lc.gx                                                                               # now dGx (M, 2GH)
+        # bias grads
+        dbih = Gr[f"rnns.{l}.bih_cat"]
+        dbih.copy_(ops.colsum(dgx))
+        dbhh = Gr[f"rnns.{l}.bhh_cat"]                                                            # (2, GH)
+        dbhh.copy_(dbih.view(2, G * H))
+        if G == 3:
+            dbhh[:, 2 * H:] = ops.colsum(lc.aux).view(2, H)
+        # dW_hh[dir] = sum_t dGh[t]^T h_prev[t]  (h_prev = h[t-1] fwd / h[t+1] reverse)
+        dwhh = Gr[f"rnns.{l}.whh_cat"]                                                            # (2, GH, H)
+        if T > 1:
+            K = (T - 1) * B
+            ldg, ldh = 2 * G * H, 2 * H
+            a0 = dgx.data_ptr() + 4 * (B * ldg)                 # dir 0: rows t >= 1
+            b0 = lc.hbuf.data_ptr()                             #        h[t-1]
+            a1 = dgx.data_ptr() + 4 * (G * H)                   # dir 1: rows t <= T-2, column block of dir 1
+            b1 = lc.hbuf.data_ptr() + 4 * (H + B * ldh)         #        h[t+1]
+            sA, sB = (a1 - a0) // 4, (b1 - b0) // 4
+            rows = 2 * H if G == 3 else 4 * H
+            ops.gemm_raw(True, False, rows, H, K, a0, ldg, sA, b0, ldh, sB, dwhh.data_ptr(), H, G * H * H, dgx.device, batch=2)
+            if G == 3:  # n-gate rows use d(hn) (aux) instead of dGx_n
+                x0 = lc.aux.data_ptr() + 4 * (B * ldh)
+                x1 = lc.aux.data_ptr() + 4 * H
+                ops.gemm_raw(True, False, H, H, K, x0, ldh, (x1 - x0) // 4, b0, ldh, sB, dwhh.data_ptr() + 4 * (2 * H * H), H,
+                             G * H * H, dgx.device, batch=2)
+        else:
+            dwhh.zero_()
+        # dW_ih (2GH, I) = dGx^T Xn ;  dXn = dGx W_ih
+        ops.gemm(dgx, lc.xn, transA=True, out=Gr[f"rnns.{l}.wih_cat"])
+        dxn = ops.gemm(dgx, W[f"rnns.{l}.wih_cat"])                                               # (M, I)
+        lc.gx = lc.aux = lc.hbuf = lc.xn = None
+        if l > 0:
+            bp = f"rnns.{l}.batch_norm.module."
+            dy = ops.bn1d_bwd(dxn, lc.xin, lc.mean, lc.var, W[bp + "weight"], Gr[bp + "weight"], Gr[bp + "bias"])
+        else:
+            dy = dxn
+        del dxn
+        done(f"rnns.{l}")
+    # ---- conv stack -----------------------------------------------------------------------------
+    cp = "conv.seq_module."
+    da2 = ops.transpose_bft(dy, B, 32 * D2, T, to_tbf=False).view(B, 32, D2, T)
+    m2, v2 = ctx.st2
+    dy2 = ops.bn2d_act_bwd(ctx.y2, da2, lens_dev, m2, v2, W[cp + "4.weight"], W[cp + "4.bias"], Gr[cp + "4.weight"], Gr[cp + "4.bias"])
+    del da2
+    Gr[cp + "3.bias"].copy_(ops.chan_sum(dy2))
+    ops.conv2_wgrad(ctx.a1, dy2, lens_dev, Gr[cp + "3.weight"])
+    da1 = ops.conv2_dgrad(dy2, ctx.packs[0], D1)
+    del dy2
+    m1, v1 = ctx.st1
+    dy1 = ops.bn2d_act_bwd(ctx.y1, da1, lens_dev, m1, v1, W[cp + "1.weight"], W[cp + "1.bias"], Gr[cp + "1.weight"], Gr[cp + "1.bias"])
+    del da1
+    Gr[cp + "0.bias"].copy_(ops.chan_sum(dy1))
+    ops.conv1_wgrad(ctx.x, dy1, lens_dev, Gr[cp + "0.weight"])
+    done("conv")

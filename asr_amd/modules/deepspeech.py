@@ -1,0 +1,218 @@
+"""`DeepSpeech` with the reference's constructor, `forward`, `get_seq_lens`, `get_loader`, eval
+`__call__`, `finetune_from` and state_dict keys (asr_deepspeech/modules/deepspeech.py:24-288), whose
+forward/backward run on the hand-written MI355X kernels (asr_amd/engine.py, libds2hip).
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Optional
+
+import torch
+from torch import nn
+
+from .. import _lib, engine
+from ..device import resolve_device
+from ..params import FlatParams
+from ..vars import resolve_rnn_type
+from .blocks import BatchRNN, InferenceBatchSoftmax, Lookahead, MaskConv, SequenceWise
+
+
+def _read_labels(label_path):
+    """deepspeech.py:48 — {char: row index} from the `label` column of labels.csv (row 0 = CTC blank)."""
+    import pandas as pd
+    return dict([(v, k) for k, v in pd.read_csv(label_path).to_dict()["label"].items()])
+
+
+class _DS2Function(torch.autograd.Function):
+    """Whole-network autograd node: forward = kernel schedule, backward = hand-derived schedule.
+    Parameters are passed as inputs so that `loss.backward()` populates `p.grad` like the reference."""
+
+    @staticmethod
+    def forward(ctx, model, x, lens_dev, *params):
+        W = model._flat.tensors(model)
+        logits, saved = engine.forward(W, model._cfg, x, lens_dev, training=model.training, save=True)
+        ctx.model, ctx.saved = model, saved
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        model = ctx.model
+        W = model._flat.tensors(model)
+        Gr = model._flat.tensors(model, grads=True)
+        engine.backward(W, Gr, model._cfg, ctx.saved, dlogits.contiguous(), on_bucket=model._on_bucket)
+        ctx.saved = None
+        grads = tuple(Gr[n] for n in model._param_names)
+        return (None, None, None) + grads
+
+
+class DeepSpeech(nn.Module):
+    def __init__(self, audio_conf, decoder, label_path, id="asr", rnn_type="nn.LSTM", rnn_hidden_size=768, rnn_hidden_layers=5,
+                 bidirectional=True, context=20, version="0.0.1", model_path=None, restart_from=None):
+        super().__init__()
+        self.version = version
+        self.id = id
+        self.decoder, self.audio_conf = decoder, audio_conf
+        self.context = context
+        self.rnn_hidden_size = rnn_hidden_size
+        self.rnn_hidden_layers = rnn_hidden_layers
+        self.rnn_type = resolve_rnn_type(rnn_type)
+        self.labels = _read_labels(label_path)
+        self.bidirectional = bidirectional
+        self.sample_rate = self.audio_conf.sample_rate
+        self.window_size = self.audio_conf.window_size
+        self.num_classes = len(self.labels)
+        self.model_path = model_path
+        self.build_network()
+        from ..decoders import GreedyDecoder
+        self.decoder = GreedyDecoder(self.labels)
+        self._flat: Optional[FlatParams] = None
+        self._on_bucket = None          # DP hook: called as each layer's gradients become final
+        self._param_names = [n for n, _ in self.named_parameters()]
+        kind = {nn.GRU: "gru", nn.LSTM: "lstm"}.get(self.rnn_type)
+        self._cfg = engine.ModelCfg(rnn=kind or "unsupported", hidden=rnn_hidden_size, layers=rnn_hidden_layers,
+                                    classes=self.num_classes, freq=int(math.floor(self.sample_rate * self.window_size / 2) + 1))
+
+    # -- structure (deepspeech.py:58-110) -----------------------------------------------------------
+    def build_network(self):
+        self.conv = MaskConv(nn.Sequential(
+            nn.Conv2d(1, 32, kernel_size=(41, 11), stride=(2, 2), padding=(20, 5)),
+            nn.BatchNorm2d(32),
+            nn.Hardtanh(0, 20, inplace=True),
+            nn.Conv2d(32, 32, kernel_size=(21, 11), stride=(2, 1), padding=(10, 5)),
+            nn.BatchNorm2d(32),
+            nn.Hardtanh(0, 20, inplace=True),
+        ))
+        f = int(math.floor((self.sample_rate * self.window_size) / 2) + 1)
+        f = int(math.floor(f + 2 * 20 - 41) / 2 + 1)
+        f = int(math.floor(f + 2 * 10 - 21) / 2 + 1)
+        rnn_input_size = f * 32
+        rnns = [("0", BatchRNN(rnn_input_size, self.rnn_hidden_size, rnn_type=self.rnn_type, bidirectional=self.bidirectional,
+                               batch_norm=False))]
+        for i in range(self.rnn_hidden_layers - 1):
+            rnns.append((str(i + 1), BatchRNN(self.rnn_hidden_size, self.rnn_hidden_size, rnn_type=self.rnn_type,
+                                              bidirectional=self.bidirectional)))
+        self.rnns = nn.Sequential(OrderedDict(rnns))
+        self.lookahead = (nn.Sequential(Lookahead(self.rnn_hidden_size, context=self.context), nn.Hardtanh(0, 20, inplace=True))
+                          if not self.bidirectional else None)
+        fully_connected = nn.Sequential(nn.BatchNorm1d(self.rnn_hidden_size),
+                                        nn.Linear(self.rnn_hidden_size, self.num_classes, bias=False))
+        self.fc = nn.Sequential(SequenceWise(fully_connected))
+        self.inference_softmax = InferenceBatchSoftmax()
+
+    # -- flat parameter storage -------------------------------------------------------------------
+    def _ensure_flat(self, device):
+        device = torch.device(device)
+        if self._flat is None or self._flat.device != device or not self._flat.owns(self):
+            old = self._flat
+            self._flat = FlatParams(self, self.rnn_hidden_layers, device)
+            for b_name, b in list(self.named_buffers()):
+                if b.device != device:
+                    mod, _, leaf = b_name.rpartition(".")
+                    setattr(self.get_submodule(mod), leaf, b.to(device))
+            del old
+        return self._flat
+
+    def flat_parameters(self):
+        """(flat params, flat grads) fp32 buffers — the fused optimizer / RCCL all-reduce operate on these."""
+        assert self._flat is not None, "call model.to(device) and run one forward (or _ensure_flat) first"
+        return self._flat.flat, self._flat.flat_grad
+
+    def finetune_from(self, model_path, nlayers=1):
+        """deepspeech.py:112-128: shape-checked partial load, then freeze all but the last n tensors."""
+        state_dict = self.state_dict()
+        loaded = torch.load(model_path, map_location="cpu")
+        loaded = loaded.get("state_dict", loaded) if isinstance(loaded, dict) else loaded
+        for k, v in loaded.items():
+            if k in state_dict and state_dict[k].shape == v.shape:
+                state_dict[k] = v
+            else:
+                print(k, state_dict.get(k, torch.empty(0)).shape, v.shape)
+        self.load_state_dict(state_dict)
+        print(f"finetune from {model_path} (last {nlayers} layers)")
+        if nlayers is not None:
+            for m in list(self.parameters())[:-nlayers]:
+                m.requires_grad = False
+
+    # -- forward (deepspeech.py:130-149) ----------------------------------------------------------
+    def forward(self, x: torch.Tensor, lengths: torch.Tensor):
+        lengths = torch.as_tensor(lengths).cpu().int()
+        output_lengths = self.get_seq_lens(lengths)
+        if not self.bidirectional or self._cfg.rnn == "unsupported":
+            raise NotImplementedError("only bidirectional GRU/LSTM DeepSpeech has MI355X kernels (DESIGN.md, out of scope)")
+        if not x.is_cuda:
+            raise _lib.DS2LibraryError(
+                "asr_amd.DeepSpeech.forward needs GPU input: the MI355X HIP kernels are the only implementation. "
+                "(The CPU restatement used for parity checks lives in oracle/ and is test infrastructure.)")
+        _lib.load()
+        self._ensure_flat(x.device)
+        lens_dev = output_lengths.to(x.device, non_blocking=True)
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if needs_grad:
+            params = [p for _, p in self.named_parameters()]
+            logits = _DS2Function.apply(self, x, lens_dev, *params)
+        else:
+            W = self._flat.tensors(self)
+            logits, _ = engine.forward(W, self._cfg, x, lens_dev, training=self.training, save=False)
+        out = logits.transpose(0, 1)            # (B,T,C) view, like the reference's x.transpose(0, 1)
+        out = self.inference_softmax(out)       # identity in train, HIP softmax in eval
+        return out, output_lengths
+
+    def get_loader(self, manifest, batch_size, num_workers, caching=False):
+        from ..data import get_loader
+        return get_loader(self.audio_conf, self.labels, manifest, batch_size, num_workers, caching=caching)
+
+    def get_seq_lens(self, input_length: torch.Tensor) -> torch.Tensor:
+        """deepspeech.py:275-288: true division per Conv2d on the time axis, one truncation at the end."""
+        seq_len = input_length
+        for m in self.conv.modules():
+            if isinstance(m, nn.modules.conv.Conv2d):
+                seq_len = (seq_len + 2 * m.padding[1] - m.dilation[1] * (m.kernel_size[1] - 1) - 1) / m.stride[1] + 1
+        return seq_len.int()
+
+    # -- evaluation loop (deepspeech.py:161-273) --------------------------------------------------
+    def evaluate(self, loader=None, manifest=None, batch_size=None, device="auto", num_workers=32, verbose=False, half=False,
+                 output_file=None, main_proc=True, **_unused):
+        device = resolve_device(device)
+        with torch.no_grad():
+            if loader is None:
+                loader, _ = self.get_loader(manifest=manifest, batch_size=batch_size, num_workers=num_workers)
+            decoder = self.decoder
+            self.eval()
+            self.to(device)
+            total_cer = total_wer = num_tokens = num_chars = 0
+            output_data = []
+            for data in loader:
+                inputs, targets, input_percentages, target_sizes = data
+                input_sizes = input_percentages.mul_(int(inputs.size(3))).int()
+                inputs = inputs.to(device)
+                split_targets, offset = [], 0
+                for size in target_sizes:
+                    split_targets.append(targets[offset:offset + size])
+                    offset += size
+                out, output_sizes = self.forward(inputs, input_sizes)
+                decoded_output, _ = decoder.decode(out, output_sizes)
+                target_strings = decoder.convert_to_strings(split_targets)
+                if output_file is not None:
+                    output_data.append((out.detach().cpu().numpy(), output_sizes.numpy(), target_strings))
+                for i in range(len(target_strings)):
+                    transcript, reference = decoded_output[i][0], target_strings[i][0]
+                    total_wer += decoder.wer(transcript, reference)
+                    total_cer += decoder.cer(transcript, reference)
+                    num_tokens += len(reference.split())
+                    num_chars += len(reference.replace(" ", ""))
+                    if verbose:
+                        print(f"Ref:{reference.lower()}\nHyp:{transcript.lower()}")
+            wer = float(total_wer) / max(num_tokens, 1)
+            cer = float(total_cer) / max(num_chars, 1)
+            if main_proc and output_file is not None:
+                with open(output_file, "w") as f:
+                    f.write(f"===== {wer * 100:.2f}/{cer * 100:.2f} =====\n")
+            return wer * 100, cer * 100, output_data
+
+    def __call__(self, *args, **kwargs):
+        """The reference overrides __call__ with its eval loop (deepspeech.py:161).  Keep that calling
+        convention (`model(loader=..., device=...)`) and fall through to nn.Module for tensors."""
+        if args and torch.is_tensor(args[0]):
+            return super().__call__(*args, **kwargs)
+        return self.evaluate(*args, **kwargs)

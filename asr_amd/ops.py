@@ -1,0 +1,343 @@
+"""Typed torch-tensor wrappers over the libds2hip C-ABI (device pointers + current HIP stream).
+
+PyTorch is plumbing here: it owns device memory (caching allocator), streams and RCCL; every FLOP of
+the DeepSpeech2 step is executed by the hand-written gfx950 kernels behind `asr_amd/_lib.py`.
+Nothing in this module has a CPU path: tensors must live on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+Tensor = torch.Tensor
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def _ptr(t: Optional[Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk_f32(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.DS2LibraryError("asr_amd kernels need GPU tensors (no CPU fallback exists)")
+        if t.dtype != torch.float32:
+            raise TypeError(f"expected float32 tensor, got {t.dtype}")
+
+
+def _ws(nbytes: int, device) -> Tensor:
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def _row_pitch(t: Tensor) -> int:
+    """pitch (elements) of a 2-D row-major (possibly column-sliced) view."""
+    assert t.dim() == 2 and t.stride(1) == 1, "need a row-major 2-D view"
+    return t.stride(0) if t.size(0) > 1 else max(t.stride(0), t.size(1))
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM
+# ------------------------------------------------------------------------------------------------
+def gemm_raw(transA: bool, transB: bool, M: int, N: int, K: int, A_ptr: int, lda: int, sA: int, B_ptr: int, ldb: int, sB: int,
+             C_ptr: int, ldc: int, sC: int, device, bias: Optional[Tensor] = None, accumulate: bool = False, batch: int = 1,
+             splitk: int = 0):
+    lib = _lib.load()
+    if splitk <= 0:
+        tiles = ((M + 127) // 128) * ((N + 127) // 128) * batch
+        splitk = 1
+        if tiles < 128 and K >= 1024:
+            splitk = max(1, min((384 + tiles - 1) // tiles, K // 256))
+    ws = None
+    wsb = 0
+    if splitk > 1:
+        wsb = lib.ds2_gemm_f32_workspace_bytes(M, N, batch, splitk)
+        ws = _ws(wsb, device)
+    _lib.check(lib.ds2_gemm_f32(int(transA), int(transB), M, N, K, A_ptr, lda, sA, B_ptr, ldb, sB, C_ptr, ldc, sC, _ptr(bias),
+                                int(accumulate), batch, splitk, _ptr(ws), wsb, _stream()), "ds2_gemm_f32")
+
+
+def gemm(A: Tensor, B: Tensor, transA: bool = False, transB: bool = False, bias: Optional[Tensor] = None,
+         out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    """out[M,N] (+)= op(A) @ op(B) (+ bias).  A, B, out: 2-D row-major views (column slices allowed)."""
+    _chk_f32(A, B, bias, out)
+    M, K = (A.size(1), A.size(0)) if transA else (A.size(0), A.size(1))
+    N = B.size(0) if transB else B.size(1)
+    Kb = B.size(1) if transB else B.size(0)
+    assert K == Kb, (A.shape, B.shape, transA, transB)
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    gemm_raw(transA, transB, M, N, K, A.data_ptr(), _row_pitch(A), 0, B.data_ptr(), _row_pitch(B), 0, out.data_ptr(),
+             _row_pitch(out), 0, A.device, bias, accumulate)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# BatchNorm1d family on (M, H)
+# ------------------------------------------------------------------------------------------------
+def colstats(X: Tensor, run_mean: Optional[Tensor] = None, run_var: Optional[Tensor] = None):
+    _chk_f32(X, run_mean, run_var)
+    lib = _lib.load()
+    M, H = X.shape
+    mean = torch.empty(H, dtype=torch.float32, device=X.device)
+    var = torch.empty_like(mean)
+    wsb = lib.ds2_colreduce_workspace_bytes(M, H)
+    ws = _ws(wsb, X.device)
+    _lib.check(lib.ds2_colstats_f32(X.data_ptr(), _row_pitch(X), M, H, mean.data_ptr(), var.data_ptr(), _ptr(run_mean),
+                                    _ptr(run_var), BN_MOMENTUM, ws.data_ptr(), wsb, _stream()), "ds2_colstats_f32")
+    return mean, var
+
+
+def add_colstats(Xa: Tensor, Xb: Tensor, run_mean: Optional[Tensor] = None, run_var: Optional[Tensor] = None):
+    """Y = Xa + Xb with column mean / biased var of Y (and optional running-stat update)."""
+    _chk_f32(Xa, Xb, run_mean, run_var)
+    lib = _lib.load()
+    M, H = Xa.shape
+    Y = torch.empty(M, H, dtype=torch.float32, device=Xa.device)
+    mean = torch.empty(H, dtype=torch.float32, device=Xa.device)
+    var = torch.empty_like(mean)
+    wsb = lib.ds2_colreduce_workspace_bytes(M, H)
+    ws = _ws(wsb, Xa.device)
+    _lib.check(lib.ds2_add_colstats_f32(Xa.data_ptr(), _row_pitch(Xa), Xb.data_ptr(), _row_pitch(Xb), Y.data_ptr(), H, M, H,
+                                        mean.data_ptr(), var.data_ptr(), _ptr(run_mean), _ptr(run_var), BN_MOMENTUM,
+                                        ws.data_ptr(), wsb, _stream()), "ds2_add_colstats_f32")
+    return Y, mean, var
+
+
+def colsum(X: Tensor) -> Tensor:
+    _chk_f32(X)
+    lib = _lib.load()
+    M, H = X.shape
+    s = torch.empty(H, dtype=torch.float32, device=X.device)
+    s2 = torch.empty_like(s)
+    wsb = lib.ds2_colreduce_workspace_bytes(M, H)
+    ws = _ws(wsb, X.device)
+    _lib.check(lib.ds2_colsum_f32(X.data_ptr(), _row_pitch(X), M, H, s.data_ptr(), s2.data_ptr(), ws.data_ptr(), wsb, _stream()),
+               "ds2_colsum_f32")
+    return s
+
+
+def bn1d_apply(X: Tensor, mean: Tensor, var: Tensor, gamma: Tensor, beta: Tensor) -> Tensor:
+    _chk_f32(X, mean, var, gamma, beta)
+    M, H = X.shape
+    Y = torch.empty(M, H, dtype=torch.float32, device=X.device)
+    _lib.check(_lib.load().ds2_bn1d_apply_f32(X.data_ptr(), _row_pitch(X), Y.data_ptr(), H, M, H, mean.data_ptr(), var.data_ptr(),
+                                              gamma.data_ptr(), beta.data_ptr(), BN_EPS, _stream()), "ds2_bn1d_apply_f32")
+    return Y
+
+
+def bn1d_bwd(dY: Tensor, X: Tensor, mean: Tensor, var: Tensor, gamma: Tensor, dgamma: Tensor, dbeta: Tensor,
+             dX: Optional[Tensor] = None) -> Tensor:
+    _chk_f32(dY, X, mean, var, gamma, dgamma, dbeta, dX)
+    lib = _lib.load()
+    M, H = X.shape
+    if dX is None:
+        dX = torch.empty(M, H, dtype=torch.float32, device=X.device)
+    wsb = lib.ds2_colreduce_workspace_bytes(M, H)
+    ws = _ws(wsb, X.device)
+    _lib.check(lib.ds2_bn1d_bwd_f32(dY.data_ptr(), _row_pitch(dY), X.data_ptr(), _row_pitch(X), dX.data_ptr(), _row_pitch(dX), M, H,
+                                    mean.data_ptr(), var.data_ptr(), gamma.data_ptr(), BN_EPS, dgamma.data_ptr(), dbeta.data_ptr(),
+                                    ws.data_ptr(), wsb, _stream()), "ds2_bn1d_bwd_f32")
+    return dX
+
+
+# ------------------------------------------------------------------------------------------------
+# BatchNorm2d + Hardtanh + mask on (B, C, D, T)
+# ------------------------------------------------------------------------------------------------
+def bn2d_stats(Y: Tensor, run_mean: Optional[Tensor] = None, run_var: Optional[Tensor] = None):
+    _chk_f32(Y, run_mean, run_var)
+    lib = _lib.load()
+    B, Cc, D, T = Y.shape
+    mean = torch.empty(Cc, dtype=torch.float32, device=Y.device)
+    var = torch.empty_like(mean)
+    wsb = lib.ds2_chanreduce_workspace_bytes(Cc)
+    ws = _ws(wsb, Y.device)
+    _lib.check(lib.ds2_bn2d_stats_f32(Y.data_ptr(), B, Cc, D, T, mean.data_ptr(), var.data_ptr(), _ptr(run_mean), _ptr(run_var),
+                                      BN_MOMENTUM, ws.data_ptr(), wsb, _stream()), "ds2_bn2d_stats_f32")
+    return mean, var
+
+
+def bn2d_act_fwd(Y: Tensor, lens_dev: Tensor, mean, var, gamma, beta) -> Tensor:
+    _chk_f32(Y, mean, var, gamma, beta)
+    B, Cc, D, T = Y.shape
+    A = torch.empty_like(Y)
+    _lib.check(_lib.load().ds2_bn2d_act_fwd_f32(Y.data_ptr(), A.data_ptr(), B, Cc, D, T, lens_dev.data_ptr(), mean.data_ptr(),
+                                                var.data_ptr(), gamma.data_ptr(), beta.data_ptr(), BN_EPS, _stream()),
+               "ds2_bn2d_act_fwd_f32")
+    return A
+
+
+def bn2d_act_bwd(Y: Tensor, dA: Tensor, lens_dev: Tensor, mean, var, gamma, beta, dgamma: Tensor, dbeta: Tensor) -> Tensor:
+    _chk_f32(Y, dA, mean, var, gamma, beta, dgamma, dbeta)
+    lib = _lib.load()
+    B, Cc, D, T = Y.shape
+    dY = torch.empty_like(Y)
+    wsb = lib.ds2_chanreduce_workspace_bytes(Cc)
+    ws = _ws(wsb, Y.device)
+    _lib.check(lib.ds2_bn2d_act_bwd_f32(Y.data_ptr(), dA.data_ptr(), dY.data_ptr(), B, Cc, D, T, lens_dev.data_ptr(), mean.data_ptr(),
+                                        var.data_ptr(), gamma.data_ptr(), beta.data_ptr(), BN_EPS, dgamma.data_ptr(), dbeta.data_ptr(),
+                                        ws.data_ptr(), wsb, _stream()), "ds2_bn2d_act_bwd_f32")
+    return dY
+
+
+def chan_sum(Y: Tensor) -> Tensor:
+    """per-channel sum over (B, D, T) of a (B,C,D,T) tensor (bias gradients)."""
+    mean, _ = bn2d_stats(Y)
+    B, Cc, D, T = Y.shape
+    return mean * float(B * D * T)
+
+
+def transpose_bft(src: Tensor, B: int, F: int, T: int, to_tbf: bool) -> Tensor:
+    _chk_f32(src)
+    dst = torch.empty((T, B, F) if to_tbf else (B, F, T), dtype=torch.float32, device=src.device)
+    _lib.check(_lib.load().ds2_transpose_bft_f32(src.data_ptr(), dst.data_ptr(), B, F, T, 0 if to_tbf else 1, _stream()),
+               "ds2_transpose_bft_f32")
+    return dst
+
+
+def transpose_batched(src: Tensor) -> Tensor:
+    """(batch, R, C) contiguous -> (batch, C, R) contiguous."""
+    _chk_f32(src)
+    nb, R, Cc = src.shape
+    dst = torch.empty(nb, Cc, R, dtype=torch.float32, device=src.device)
+    _lib.check(_lib.load().ds2_transpose2d_f32(src.data_ptr(), Cc, R * Cc, dst.data_ptr(), R, R * Cc, R, Cc, nb, _stream()),
+               "ds2_transpose2d_f32")
+    return dst
+
+
+# ------------------------------------------------------------------------------------------------
+# conv front-end
+# ------------------------------------------------------------------------------------------------
+def conv_pack(w1: Tensor, w2: Tensor):
+    _chk_f32(w1, w2)
+    lib = _lib.load()
+    dev = w1.device
+    wpk1 = torch.empty(lib.ds2_conv_packed_floats(0), dtype=torch.float32, device=dev)
+    wpk2 = torch.empty(lib.ds2_conv_packed_floats(1), dtype=torch.float32, device=dev)
+    wpk2d = torch.empty(lib.ds2_conv_packed_floats(2), dtype=torch.float32, device=dev)
+    _lib.check(lib.ds2_conv_pack_f32(w1.data_ptr(), w2.data_ptr(), wpk1.data_ptr(), wpk2.data_ptr(), wpk2d.data_ptr(), _stream()),
+               "ds2_conv_pack_f32")
+    return wpk1, wpk2, wpk2d
+
+
+def conv1_fwd(x: Tensor, wpk1: Tensor, bias: Tensor, lens_dev: Tensor) -> Tensor:
+    _chk_f32(x, wpk1, bias)
+    B, _, F, Tin = x.shape
+    D1, D2, T = _lib.conv_dims(F, Tin)
+    y1 = torch.empty(B, 32, D1, T, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().ds2_conv1_fwd_f32(x.data_ptr(), wpk1.data_ptr(), bias.data_ptr(), lens_dev.data_ptr(), y1.data_ptr(), B, F,
+                                             Tin, _stream()), "ds2_conv1_fwd_f32")
+    return y1
+
+
+def conv2_fwd(a1: Tensor, wpk2: Tensor, bias: Tensor, lens_dev: Tensor) -> Tensor:
+    _chk_f32(a1, wpk2, bias)
+    B, _, D1, T = a1.shape
+    D2 = (D1 + 20 - 21) // 2 + 1
+    y2 = torch.empty(B, 32, D2, T, dtype=torch.float32, device=a1.device)
+    _lib.check(_lib.load().ds2_conv2_fwd_f32(a1.data_ptr(), wpk2.data_ptr(), bias.data_ptr(), lens_dev.data_ptr(), y2.data_ptr(), B, D1,
+                                             T, _stream()), "ds2_conv2_fwd_f32")
+    return y2
+
+
+def conv2_dgrad(dy2: Tensor, wpk2d: Tensor, D1: int) -> Tensor:
+    _chk_f32(dy2, wpk2d)
+    B, _, D2, T = dy2.shape
+    da1 = torch.empty(B, 32, D1, T, dtype=torch.float32, device=dy2.device)
+    _lib.check(_lib.load().ds2_conv2_dgrad_f32(dy2.data_ptr(), wpk2d.data_ptr(), da1.data_ptr(), B, D1, T, _stream()),
+               "ds2_conv2_dgrad_f32")
+    return da1
+
+
+def conv1_wgrad(x: Tensor, dy1: Tensor, lens_dev: Tensor, dW1: Tensor):
+    _chk_f32(x, dy1, dW1)
+    lib = _lib.load()
+    B, _, F, Tin = x.shape
+    wsb = lib.ds2_conv_wgrad_workspace_bytes(0, B, F)
+    ws = _ws(wsb, x.device)
+    _lib.check(lib.ds2_conv1_wgrad_f32(x.data_ptr(), dy1.data_ptr(), lens_dev.data_ptr(), dW1.data_ptr(), B, F, Tin, 0, ws.data_ptr(),
+                                       wsb, _stream()), "ds2_conv1_wgrad_f32")
+
+
+def conv2_wgrad(a1: Tensor, dy2: Tensor, lens_dev: Tensor, dW2: Tensor):
+    _chk_f32(a1, dy2, dW2)
+    lib = _lib.load()
+    B, _, D1, T = a1.shape
+    wsb = lib.ds2_conv_wgrad_workspace_bytes(1, B, 161)
+    ws = _ws(wsb, a1.device)
+    _lib.check(lib.ds2_conv2_wgrad_f32(a1.data_ptr(), dy2.data_ptr(), lens_dev.data_ptr(), dW2.data_ptr(), B, D1, T, 0, ws.data_ptr(),
+                                       wsb, _stream()), "ds2_conv2_wgrad_f32")
+
+
+# ------------------------------------------------------------------------------------------------
+# recurrence
+# ------------------------------------------------------------------------------------------------
+def rnn_fwd(gates: int, gx: Tensor, whh: Tensor, bhh: Tensor, lens_dev: Tensor, T: int, B: int, H: int):
+    """gx (T*B, 2*G*H) in/out; returns (hbuf (T*B, 2H), aux (T*B, 2H))."""
+    _chk_f32(gx, whh, bhh)
+    assert gx.is_contiguous() and whh.is_contiguous() and bhh.is_contiguous()
+    hbuf = torch.empty(T * B, 2 * H, dtype=torch.float32, device=gx.device)
+    aux = torch.empty_like(hbuf)
+    _lib.check(_lib.load().ds2_rnn_fwd_f32(gates, gx.data_ptr(), whh.data_ptr(), bhh.data_ptr(), hbuf.data_ptr(), aux.data_ptr(),
+                                           lens_dev.data_ptr(), T, B, H, _stream()), "ds2_rnn_fwd_f32")
+    return hbuf, aux
+
+
+def rnn_bwd(gates: int, dy: Tensor, gx: Tensor, aux: Tensor, hbuf: Tensor, whhT: Tensor, lens_dev: Tensor, T: int, B: int, H: int):
+    _chk_f32(dy, gx, aux, hbuf, whhT)
+    lib = _lib.load()
+    wsb = lib.ds2_rnn_bwd_workspace_bytes(B, H)
+    ws = _ws(wsb, gx.device)
+    _lib.check(lib.ds2_rnn_bwd_f32(gates, dy.data_ptr(), _row_pitch(dy), gx.data_ptr(), aux.data_ptr(), hbuf.data_ptr(), whhT.data_ptr(),
+                                   lens_dev.data_ptr(), T, B, H, ws.data_ptr(), wsb, _stream()), "ds2_rnn_bwd_f32")
+
+
+# ------------------------------------------------------------------------------------------------
+# CTC
+# ------------------------------------------------------------------------------------------------
+def ctc_loss(logits: Tensor, targets_dev: Tensor, tgt_off_dev: Tensor, in_lens_dev: Tensor, tgt_lens_dev: Tensor, max_tgt: int,
+             grad_scale: float, want_grad: bool = True):
+    """logits (T,B,C) (last dim contiguous, uniform row pitch).  Returns (nll (B,), grad (T,B,C) or None)."""
+    _chk_f32(logits)
+    lib = _lib.load()
+    T, B, Cc = logits.shape
+    assert logits.stride(2) == 1 and logits.stride(0) == B * logits.stride(1)
+    ld = logits.stride(1)
+    nll = torch.empty(B, dtype=torch.float32, device=logits.device)
+    grad = torch.empty(T, B, Cc, dtype=torch.float32, device=logits.device) if want_grad else None
+    wsb = lib.ds2_ctc_workspace_bytes(T, B, max_tgt)
+    ws = _ws(wsb, logits.device)
+    _lib.check(lib.ds2_ctc_loss_f32(logits.data_ptr(), ld, T, B, Cc, targets_dev.data_ptr(), tgt_off_dev.data_ptr(),
+                                    in_lens_dev.data_ptr(), tgt_lens_dev.data_ptr(), int(max_tgt), nll.data_ptr(), _ptr(grad), Cc,
+                                    float(grad_scale), ws.data_ptr(), wsb, _stream()), "ds2_ctc_loss_f32")
+    return nll, grad
+
+
+def softmax_rows(x: Tensor) -> Tensor:
+    """softmax over the last dim of a (rows, C) row-major view."""
+    _chk_f32(x)
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().ds2_softmax_rows_f32(x.data_ptr(), _row_pitch(x), y.data_ptr(), x.size(1), x.size(0), x.size(1), _stream()),
+               "ds2_softmax_rows_f32")
+    return y
+
+
+# ------------------------------------------------------------------------------------------------
+# optimizer
+# ------------------------------------------------------------------------------------------------
+def adamw(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float, betas=(0.9, 0.999), eps: float = 1e-8,
+          weight_decay: float = 1e-5, grad_scale: float = 1.0):
+    _chk_f32(p, g, m, v)
+    assert p.is_contiguous() and g.is_contiguous() and m.is_contiguous() and v.is_contiguous()
+    _lib.check(_lib.load().ds2_adamw_f32(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, betas[0], betas[1],
+                                         eps, weight_decay, int(step), grad_scale, _stream()), "ds2_adamw_f32")

@@ -1,0 +1,217 @@
+"""`DeepSpeechTrainer` — same constructor arguments, `fit`/`train`/`test`/`update`/`load`/`save`
+behaviour as asr_deepspeech/trainers/deepspeech_trainer.py:14-188, standalone (the reference derives
+from `sakura.ml.SakuraTrainer`, a third-party class whose source is not in the tree), plus:
+
+  * `step(data)`   — the fused MI355X train step: forward, CTC, hand-written backward, bucketed RCCL
+                     gradient all-reduce overlapped with backward, fused AdamW; ONE host sync per step
+                     (the reference's `loss.item()`), validity of the loss agreed across ranks.
+  * data-parallel operation when torch.distributed is initialised (one process per GPU).
+"""
+from __future__ import annotations
+
+import os
+from types import SimpleNamespace
+
+import torch
+import torch.distributed as dist
+
+from .. import engine, ops
+from ..ctc import CTCLoss, _prep_targets
+from ..device import autocast, make_grad_scaler, resolve_device
+from ..functional import check_loss
+from ..optim import FusedAdamW
+from ..parallel import BucketedAllReducer
+
+
+class Epochs:
+    """Iterable epoch counter with the attributes the reference trainer touches
+    (`_epochs.current/.total/.best/.start`, deepspeech_trainer.py:50,66,137,166-170)."""
+
+    def __init__(self, total, start=0):
+        self.total, self.start, self.current, self.best = int(total), int(start), int(start), int(start)
+
+    def __iter__(self):
+        for e in range(self.start, self.total):
+            self.current = e
+            yield e
+
+
+def asr_metrics():
+    """Minimal stand-in for `sakura.functional.asr_metrics`: metrics.{train,test}.{current,best}."""
+    def blank():
+        return SimpleNamespace(loss=0.0, wer=None, cer=None)
+    return SimpleNamespace(train=SimpleNamespace(current=blank(), best=blank()), test=SimpleNamespace(current=blank(), best=blank()))
+
+
+class DeepSpeechTrainer:
+    def __init__(self, model, criterion, epochs, metrics, optimizer, model_path, checkpoint_path, device, device_test,
+                 mixed_precision, output_file, scheduler=None, overwrite_lr=None):
+        self._device = resolve_device(device)
+        self._device_test = resolve_device(device_test)
+        self._model, self._optimizer, self._scheduler = model, optimizer, scheduler
+        self._metrics = metrics() if callable(metrics) else (metrics if metrics is not None else asr_metrics())
+        self._epochs = epochs if hasattr(epochs, "__iter__") else Epochs(epochs)
+        self._epoch = getattr(self._epochs, "current", 0)
+        self._model_path, self._checkpoint_path = model_path, checkpoint_path
+        self.criterion = criterion
+        self.mixed_precision = mixed_precision
+        self.output_file = output_file
+        self.overwrite_lr = overwrite_lr
+        self._reducer = None
+        self.load()
+
+    # -- epoch loop (deepspeech_trainer.py:50-66) -------------------------------------------------
+    def run(self, train_loader, test_loader):
+        for self._epoch in self._epochs:
+            self.train(train_loader)
+            self.test(test_loader)
+
+    def checkpoint(self):
+        if self._metrics.test.current == self._metrics.test.best:
+            self.save()
+
+    def description(self):
+        lr = self._optimizer.param_groups[0]["lr"] * pow(10, 5)
+        current, best = self._metrics.test.current, self._metrics.test.best
+        tcurrent, tbest = self._metrics.train.current, self._metrics.train.best
+        cer, bcer = (current.cer or 0.0), (best.cer or 0.0)
+        return (f"({self._epochs.best}) {self._model.id} | CER: {cer:.4f} / ({bcer:.4f}) | Loss:{tcurrent.loss:.4f} / "
+                f"({tbest.loss:.4f}) | Lr: {lr:.4f}e-5 | Epoch: {self._epochs.current}/{self._epochs.total}")
+
+    # -- train (deepspeech_trainer.py:68-100) -----------------------------------------------------
+    def train(self, train_loader):
+        self._model.train()
+        self._model.to(self._device)
+        current, best = self._metrics.train.current, self._metrics.train.best
+        fused = isinstance(self._optimizer, FusedAdamW)
+        for data in train_loader:
+            if fused:
+                valid_loss, loss_value = self.step(data)
+            else:
+                valid_loss, loss, loss_value = self.fit(data)
+                if valid_loss:
+                    self._optimizer.zero_grad()
+                    loss.backward()
+                    self._optimizer.step()
+            if valid_loss:
+                current.loss += loss_value
+            else:
+                print("Loss non valid, skipped")
+        self.update(current, best, train_loader, update_best=False)
+        if self._scheduler is not None:
+            self._scheduler.step()
+
+    # -- fit (deepspeech_trainer.py:102-117) ------------------------------------------------------
+    def fit(self, data):
+        """Reference semantics: returns (valid_loss, loss tensor with graph, loss_value)."""
+        inputs, targets, input_percentages, target_sizes = data
+        input_sizes = input_percentages.mul_(int(inputs.size(3))).int()      # in place + fp32 truncation (A.5)
+        inputs = inputs.to(self._device)
+        out, output_sizes = self._model.forward(inputs, input_sizes)
+        out = out.transpose(0, 1)                                            # TxNxC
+        float_out = out.float()
+        if not isinstance(self.criterion, CTCLoss):
+            float_out = float_out.log_softmax(2)        # torch criterion: keep the reference's op sequence
+        # (asr_amd.CTCLoss fuses the row log-softmax into the CTC kernels)
+        loss = self.criterion(float_out, targets, output_sizes, target_sizes).to(self._device)
+        loss = loss / inputs.size(0)
+        loss_value = loss.item()
+        valid_loss, _ = check_loss(loss, loss_value)
+        return valid_loss, loss, loss_value
+
+    # -- fused step ---------------------------------------------------------------------------------
+    def _get_reducer(self):
+        flat, grad = self._model.flat_parameters()
+        if self._reducer is None or self._reducer.flat_grad.data_ptr() != grad.data_ptr():
+            self._reducer = BucketedAllReducer(grad, self._model._flat.layer_buckets())
+        return self._reducer
+
+    def step(self, data):
+        """One full train step on the HIP kernels; returns (valid_loss, loss_value)."""
+        model = self._model
+        inputs, targets, input_percentages, target_sizes = data
+        input_sizes = input_percentages.mul_(int(inputs.size(3))).int()
+        inputs = inputs.to(self._device, non_blocking=True)
+        B = inputs.size(0)
+        output_sizes = model.get_seq_lens(input_sizes.cpu().int())
+        model._ensure_flat(inputs.device)
+        lens_dev = output_sizes.to(inputs.device, non_blocking=True)
+        tg, off, tl, max_u = _prep_targets(targets, target_sizes, inputs.device)
+        with torch.no_grad():
+            W = model._flat.tensors(model)
+            Gr = model._flat.tensors(model, grads=True)
+            logits, ctx = engine.forward(W, model._cfg, inputs, lens_dev, training=True, save=True)
+            nll, dlogits = ops.ctc_loss(logits, tg, off, lens_dev, tl, max_u, 1.0 / B, want_grad=True)
+            loss = nll.sum() / B
+            red = self._get_reducer()
+            engine.backward(W, Gr, model._cfg, ctx, dlogits, on_bucket=red.on_bucket)
+            red.finish()
+            loss_value = loss.item()                                         # the step's single host sync
+            valid_loss, _ = check_loss(loss, loss_value)
+            valid_loss = red.all_valid(valid_loss, inputs.device)
+            if valid_loss:
+                if isinstance(self._optimizer, FusedAdamW):
+                    self._optimizer.grad_scale = 1.0 / red.world
+                    self._optimizer.step()
+                else:
+                    for n, p in model.named_parameters():
+                        p.grad = Gr[n] if red.world == 1 else Gr[n] / red.world
+                    self._optimizer.step()
+        return valid_loss, loss_value
+
+    # -- eval / bookkeeping (deepspeech_trainer.py:119-137) ----------------------------------------
+    def test(self, test_loader):
+        current, best = self._metrics.test.current, self._metrics.test.best
+        wer, cer, _ = self._model(loader=test_loader, device=self._device_test, output_file=self.output_file)
+        current.wer, current.cer = wer, cer
+        self.update(current, best, test_loader, update_best=True)
+        self.checkpoint()
+
+    def update(self, current, best, loader, update_best=False):
+        n = len(loader.dataset) if hasattr(loader, "dataset") else max(len(loader), 1)
+        current.loss /= n
+        try:
+            assert best.cer is not None
+            assert best.cer < current.cer
+        except (AssertionError, TypeError):
+            vars(best).update(vars(current))
+            if update_best:
+                self._epochs.best = self._epochs.current
+
+    @staticmethod
+    def optimizer_to(optim, device):
+        for param in getattr(optim, "state", {}).values():
+            if isinstance(param, torch.Tensor):
+                param.data = param.data.to(device)
+            elif isinstance(param, dict):
+                for k, sub in param.items():
+                    if isinstance(sub, torch.Tensor):
+                        sub.data = sub.data.to(device)
+
+    # -- checkpoints (deepspeech_trainer.py:154-188): same dict keys ------------------------------------
+    def load(self, all=True):
+        model_path = self._model_path
+        if model_path and os.path.exists(model_path):
+            ckpt = torch.load(model_path, map_location="cpu", weights_only=False)
+            self._model.load_state_dict(ckpt["state_dict"])
+            if all:
+                try:
+                    self._optimizer.load_state_dict(ckpt["optimizer"])
+                except Exception as e:  # optimizer kind changed (torch AdamW <-> FusedAdamW)
+                    print(f"optimizer state not restored: {e}")
+                if self.overwrite_lr is not None:
+                    self._optimizer.param_groups[0]["lr"] = self.overwrite_lr
+                if ckpt.get("scheduler") is not None:
+                    self._scheduler = ckpt["scheduler"]
+                    self._scheduler.optimizer = self._optimizer
+            self._metrics = ckpt["metrics"]
+            self._epochs.start = self._epochs.current = self._epochs.best = ckpt["epoch"]
+            print(f"restart from {model_path}")
+
+    def save(self):
+        os.makedirs(os.path.dirname(os.path.abspath(self._model_path)), exist_ok=True)
+        if dist.is_initialized() and dist.get_rank() != 0:
+            return  # DDP convention: rank 0 owns the checkpoint (BN running stats are per-rank)
+        torch.save({"epoch": self._epochs.best, "metrics": self._metrics, "optimizer": self._optimizer.state_dict(),
+                    "scheduler": self._scheduler, "state_dict": self._model.state_dict()}, self._model_path)
+        print(f"{self._model_path} saved...")

@@ -1,0 +1,273 @@
+#!/usr/bin/env python
+"""bench.py — DeepSpeech2 CTC train-step throughput (utterances/sec) on MI355X, BASELINE.json metric.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+A "step" = one full train step of the hot path on one synthetic batch already resident in HBM:
+forward, CTC, backward, (RCCL gradient all-reduce,) fused AdamW, loss.item() sync.
+Workloads (--workload): c3 = BASELINE metric config (5x1024 BiGRU, 10 s / 161-bin, B=64 per GPU, C=29),
+c2 = configs[1] (5x768 BiGRU, B=32).  Weak scaling: per-GPU batch fixed.
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, measured live with HIP events on the
+launch stream) and `cpu_baseline` (the CPU oracle timed on the host cores on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+from types import SimpleNamespace
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (rnn, hidden, layers, classes, per-GPU batch, input frames)
+    "c3": ("gru", 1024, 5, 29, 64, 1001),
+    "c2": ("gru", 768, 5, 29, 32, 1001),
+    "c1": ("gru", 256, 2, 29, 4, 201),
+    "c4": ("lstm", 1280, 7, 29, 32, 1501),
+}
+FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, dense f32-input matrix rate
+HBM_PEAK_GBS = 8000.0
+
+
+def train_flops_per_utt(rnn, H, L, C, T):
+    """FLOPs(train) = 2*conv1 + 3*(conv2 + rnn + fc)."""
+    G = 3 if rnn == "gru" else 4
+    conv1 = 2 * 32 * 81 * T * 451
+    conv2 = 2 * 32 * 41 * T * 7392
+    rnn_f = sum(2 * 2 * T * G * H * ((1312 if l == 0 else H) + H) for l in range(L))
+    fc = 2 * T * H * C
+    return 2 * conv1 + 3 * (conv2 + rnn_f + fc)
+
+
+def audio_conf():
+    return SimpleNamespace(sample_rate=16000, window_size=0.02, window_stride=0.01, window="hamming", speed_volume_perturb=False,
+                           spec_augment=False, noise_dir=None, noise_prob=0.4, noise_levels=(0.0, 0.5))
+
+
+def label_file(tmp, n):
+    import pandas as pd
+    chars = ["_", "'"] + list("abcdefghijklmnopqrstuvwxyz") + ["|"] + [chr(0x3041 + i) for i in range(200)]
+    path = os.path.join(tmp, "labels.csv")
+    pd.DataFrame({"label": chars[:n]}).to_csv(path, index=False)
+    return path
+
+
+def synthetic_batch(B, tin, C, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, 1, 161, tin, generator=g)
+    pct = torch.ones(B, dtype=torch.float32)
+    U = tin // 20
+    targets = torch.randint(1, C, (B * U,), generator=torch.Generator().manual_seed(seed + 1), dtype=torch.int32)
+    tsz = torch.full((B,), U, dtype=torch.int32)
+    return x, targets, pct, tsz
+
+
+def cpu_baseline(rnn, H, L, C, tin, budget_s=25.0):
+    """CPU oracle (padded+masked restatement, oracle/ds2_oracle.py) on the host cores: same model
+    config and utterance length, bounded batch (B=1..2) so it costs ~10-30 s."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import det
+    from oracle import ds2_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    Bs = 1
+    shapes = det.state_shapes(rnn, H, L, C)
+    g = torch.Generator().manual_seed(0)
+    sd = {}
+    for k, shp in shapes.items():
+        if k.endswith("num_batches_tracked"):
+            sd[k] = torch.zeros((), dtype=torch.int64)
+        elif k.endswith("running_var") or (k.endswith("weight") and len(shp) == 1):
+            sd[k] = torch.ones(shp)
+        elif k.endswith("running_mean") or (k.endswith("bias") and ("batch_norm" in k or k.startswith("fc.") or ".1." in k or ".4." in k)):
+            sd[k] = torch.zeros(shp)
+        else:
+            sd[k] = (torch.rand(shp, generator=g) * 2 - 1) * (1.0 / (H ** 0.5))
+    x, targets, pct, tsz = synthetic_batch(Bs, tin, C, 1)
+    t0 = time.time()
+    O.fit_and_grads(sd, x, targets, pct, tsz)
+    dt = time.time() - t0
+    n = 1
+    while dt < budget_s * 0.4 and n < 3:      # a second/third repetition only if cheap
+        t1 = time.time()
+        O.fit_and_grads(sd, x, targets, pct, tsz)
+        dt = min(dt, time.time() - t1)
+        n += 1
+    return {"value": Bs / dt, "unit": "utterances/sec", "cores": cores, "kind": "port",
+            "sample": f"oracle fit+backward (no optimizer), B={Bs} of the same {L}x{H} {rnn} model at T_in={tin}, best of {n}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3", choices=list(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="override per-GPU batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="print a per-section time breakdown to stderr")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from asr_amd import CTCLoss, DeepSpeech, FusedAdamW, ops
+    from asr_amd.trainers import DeepSpeechTrainer
+
+    rnn, H, L, C, B, tin = WORKLOADS[args.workload]
+    if args.batch:
+        B = args.batch
+    torch.manual_seed(0)
+    with tempfile.TemporaryDirectory() as tmp:
+        model = DeepSpeech(audio_conf=audio_conf(), decoder=None, label_path=label_file(tmp, C), rnn_type=rnn, rnn_hidden_size=H,
+                           rnn_hidden_layers=L, bidirectional=True)
+    model.to(dev).train()
+    opt = FusedAdamW(model, lr=1.5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5)
+    tr = DeepSpeechTrainer(model, CTCLoss(reduction="sum"), 1, None, opt, None, None, dev, dev, False, None)
+    x, targets, pct, tsz = synthetic_batch(B, tin, C, 1 + rank)
+    x = x.to(dev)                                     # inputs resident in HBM before the timed region
+
+    def one_step():
+        return tr.step((x, targets, pct.clone(), tsz))
+
+    for _ in range(args.warmup):
+        valid, lv = one_step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        valid, lv = one_step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms = dt / args.steps * 1e3
+    utts = world * B * args.steps / dt
+
+    # ---- roofline of the dominant kernel: the recurrent step kernel (fwd), timed live with HIP events on
+    # torch's current stream, which is the stream libds2hip launches on.
+    G = 3 if rnn == "gru" else 4
+    T = (tin + 1) // 2
+    M = T * B
+    gx = torch.randn(M, 2 * G * H, device=dev) * 0.5
+    whh = (torch.rand(2, G * H, H, device=dev) * 2 - 1) / H ** 0.5
+    bhh = torch.zeros(2, G * H, device=dev)
+    lens = torch.full((B,), T, dtype=torch.int32, device=dev)
+    ops.rnn_fwd(G, gx.clone(), whh, bhh, lens, T, B, H)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    gx2 = gx.clone()
+    torch.cuda.synchronize()
+    e0.record()
+    ops.rnn_fwd(G, gx2, whh, bhh, lens, T, B, H)
+    e1.record()
+    torch.cuda.synchronize()
+    us_per_launch = e0.elapsed_time(e1) * 1e3 / T
+    flops_per_launch = 2.0 * 2 * B * H * G * H           # both directions, one time step
+    achieved = flops_per_launch / (us_per_launch * 1e-6) / 1e12
+    roofline = {"kernel": "rnn_fwd_step_kernel", "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                "us_per_launch": us_per_launch, "launches_per_step": 2 * T * L}
+
+    if args.breakdown and rank == 0:
+        breakdown(model, tr, x, targets, pct, tsz)
+
+    if rank == 0:
+        step_flops = train_flops_per_utt(rnn, H, L, C, T) * B
+        out = {
+            "metric": "utterances/sec (10 s, 161-bin) DS2 5x1024 BiGRU CTC train step" if args.workload == "c3"
+                      else f"utterances/sec DS2 {L}x{H} bi-{rnn} CTC train step",
+            "value": utts, "unit": "utterances/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic N(0,1) 161-bin spectrograms, random-init weights, random labels U=T_in/20",
+            "config": {"workload": f"{args.workload}: DS2 {L}x{H} bi-{rnn.upper()} fp32, {tin} input frames ({tin // 100} s), "
+                                   f"batch {B}/GPU, {C} classes", "global_batch": B * world, "parallelism": f"dp{world}"},
+            "loss": lv, "step_tflops": step_flops * world / (ms * 1e-3) / 1e12,
+            "step_frac_of_fp32_mfma_peak": step_flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(rnn, H, L, C, tin)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def breakdown(model, tr, x, targets, pct, tsz):
+    """Section timing with events (one extra step, outside the timed region)."""
+    from asr_amd import engine, ops
+    from asr_amd.ctc import _prep_targets
+    dev = x.device
+    B = x.size(0)
+    ev = []
+
+    def mark(name):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        ev.append((name, e))
+
+    input_sizes = pct.clone().mul_(int(x.size(3))).int()
+    out_lens = model.get_seq_lens(input_sizes)
+    lens_dev = out_lens.to(dev)
+    tg, off, tl, max_u = _prep_targets(targets, tsz, dev)
+    W = model._flat.tensors(model)
+    Gr = model._flat.tensors(model, grads=True)
+    orig_rnn_fwd, orig_rnn_bwd, orig_gemm = ops.rnn_fwd, ops.rnn_bwd, ops.gemm_raw
+    acc = {"rnn_fwd": 0.0, "rnn_bwd": 0.0, "gemm": 0.0}
+
+    def timed(fn, key):
+        def w(*a, **k):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = fn(*a, **k)
+            e.record()
+            pend.append((key, s, e))
+            return r
+        return w
+    pend = []
+    ops.rnn_fwd, ops.rnn_bwd, ops.gemm_raw = timed(orig_rnn_fwd, "rnn_fwd"), timed(orig_rnn_bwd, "rnn_bwd"), timed(orig_gemm, "gemm")
+    try:
+        with torch.no_grad():
+            torch.cuda.synchronize()
+            mark("start")
+            logits, ctx = engine.forward(W, model._cfg, x, lens_dev, training=True, save=True)
+            mark("forward")
+            nll, dlogits = ops.ctc_loss(logits, tg, off, lens_dev, tl, max_u, 1.0 / B)
+            mark("ctc")
+            engine.backward(W, Gr, model._cfg, ctx, dlogits)
+            mark("backward")
+            tr._optimizer.step()
+            mark("adamw")
+            torch.cuda.synchronize()
+    finally:
+        ops.rnn_fwd, ops.rnn_bwd, ops.gemm_raw = orig_rnn_fwd, orig_rnn_bwd, orig_gemm
+    for key, s, e in pend:
+        acc[key] += s.elapsed_time(e)
+    msg = ["breakdown (ms):"]
+    for (n0, e0), (n1, e1) in zip(ev[:-1], ev[1:]):
+        msg.append(f"  {n1}: {e0.elapsed_time(e1):.2f}")
+    msg.append("  of which " + ", ".join(f"{k}={v:.2f}" for k, v in acc.items()))
+    print("\n".join(msg), file=sys.stderr, flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,120 @@
+/* libds2hip — C ABI of the MI355X-native (gfx950) DeepSpeech2 train-step kernels.
+ *
+ * Drop-in boundary for the hot path of zakuro-ai/asr (`asr_deepspeech`).  The reference has no FFI
+ * of its own (it is pure Python over torch ops); each entry point below replaces the torch/ATen op
+ * sequence at the cited reference call site (paths relative to the reference tree).  The Python
+ * host layer `asr_amd/` binds these with ctypes (see INTEGRATION.md for the stub a maintainer of
+ * the reference would add).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in `_host`; the library never
+ *     allocates, frees or retains memory: caller owns inputs, outputs, saved tensors, workspaces.
+ *   - `stream` is a hipStream_t (as void*); all work is enqueued asynchronously on it.
+ *   - return 0 on success, negative on error; `ds2_last_error()` returns a thread-local message.
+ *   - all tensors fp32, row-major, contiguous unless a pitch (`ld*`) is given.
+ *   - lengths (`lens_dev`) are int32 per-sample valid OUTPUT frame counts (after the conv stack,
+ *     modules/deepspeech.py:275-288), sorted descending as the reference requires (blocks.py:87).
+ */
+#ifndef DS2HIP_H
+#define DS2HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* ds2_version(void);
+const char* ds2_last_error(void);
+int ds2_device_info(int* cu_count, int* wave_size, char* arch, int arch_len);
+
+/* ---- dense GEMM on the f32 matrix cores -------------------------------------------------------
+ * C[M,N] (+)= op(A) op(B) (+ bias[N]);  transA: A stored (K,M);  transB: B stored (N,K).
+ * Replaces aten::addmm/mm inside aten::gru / aten::lstm (input projections, modules/blocks.py:76-78,88),
+ * nn.Linear (modules/deepspeech.py:105) and their autograd backward (dX, dW).
+ * batch > 1: strided batches; splitk > 1: deterministic split-K through `workspace`. */
+size_t ds2_gemm_f32_workspace_bytes(int M, int N, int batch, int splitk);
+int ds2_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, long long strideA, const float* B, int ldb,
+                 long long strideB, float* C, int ldc, long long strideC, const float* bias, int accumulate, int batch, int splitk,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- BatchNorm1d over (T*B, H) rows, padding rows included -----------------------------------
+ * modules/blocks.py:75,85-86 (SequenceWise(BatchNorm1d)) and modules/deepspeech.py:104 (fc block).
+ * stats: biased variance for normalisation; running stats updated with momentum and the unbiased
+ * variance when run_mean/run_var are non-null (torch.nn.BatchNorm1d training semantics). */
+size_t ds2_colreduce_workspace_bytes(int M, int H);
+int ds2_colstats_f32(const float* X, int ldx, int M, int H, float* mean, float* var, float* run_mean, float* run_var, float momentum,
+                     void* ws, size_t ws_bytes, void* stream);
+/* Y = Xa + Xb (sum of the two RNN directions, modules/blocks.py:92) fused with the statistics of Y */
+int ds2_add_colstats_f32(const float* Xa, int lda, const float* Xb, int ldb, float* Y, int ldy, int M, int H, float* mean, float* var,
+                         float* run_mean, float* run_var, float momentum, void* ws, size_t ws_bytes, void* stream);
+int ds2_colsum_f32(const float* X, int ldx, int M, int H, float* sum, float* sumsq, void* ws, size_t ws_bytes, void* stream);
+int ds2_bn1d_apply_f32(const float* X, int ldx, float* Y, int ldy, int M, int H, const float* mean, const float* var,
+                       const float* gamma, const float* beta, float eps, void* stream);
+int ds2_bn1d_bwd_f32(const float* dY, int lddy, const float* X, int ldx, float* dX, int lddx, int M, int H, const float* mean,
+                     const float* var, const float* gamma, float eps, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                     void* stream);
+
+/* ---- BatchNorm2d + Hardtanh(0,20) + MaskConv time mask on (B,C,D,T) ----------------------------
+ * modules/deepspeech.py:62-63,65-66 under modules/blocks.py:48-55 (mask after EVERY sub-module). */
+size_t ds2_chanreduce_workspace_bytes(int C);
+int ds2_bn2d_stats_f32(const float* Y, int B, int C, int D, int T, float* mean, float* var, float* run_mean, float* run_var,
+                       float momentum, void* ws, size_t ws_bytes, void* stream);
+int ds2_bn2d_act_fwd_f32(const float* Y, float* A, int B, int C, int D, int T, const int* lens_dev, const float* mean,
+                         const float* var, const float* gamma, const float* beta, float eps, void* stream);
+int ds2_bn2d_act_bwd_f32(const float* Y, const float* dA, float* dY, int B, int C, int D, int T, const int* lens_dev, const float* mean,
+                         const float* var, const float* gamma, const float* beta, float eps, float* dgamma, float* dbeta, void* ws,
+                         size_t ws_bytes, void* stream);
+/* dir 0: (B,F,T) -> (T,B,F) = view+transpose+contiguous of modules/deepspeech.py:135-137; dir 1: inverse */
+int ds2_transpose_bft_f32(const float* src, float* dst, int B, int F, int T, int dir, void* stream);
+int ds2_transpose2d_f32(const float* src, int ld_src, long long stride_src, float* dst, int ld_dst, long long stride_dst, int R, int Cc,
+                        int batch, void* stream);
+
+/* ---- conv front-end (MFMA implicit GEMM) -------------------------------------------------------
+ * conv1 = nn.Conv2d(1,32,(41,11),(2,2),(20,5)) modules/deepspeech.py:61; conv2 = nn.Conv2d(32,32,(21,11),(2,1),(10,5)) :64;
+ * forward epilogues add the bias and apply the MaskConv mask (modules/blocks.py:50-55). */
+void ds2_conv_dims(int F, int Tin, int* D1, int* D2, int* T);
+size_t ds2_conv_packed_floats(int which /*0: conv1 fwd, 1: conv2 fwd, 2: conv2 dgrad*/);
+int ds2_conv_pack_f32(const float* w1, const float* w2, float* wpk1, float* wpk2, float* wpk2d, void* stream);
+int ds2_conv1_fwd_f32(const float* x, const float* wpk1, const float* bias, const int* lens_dev, float* y1, int B, int F, int Tin,
+                      void* stream);
+int ds2_conv2_fwd_f32(const float* a1, const float* wpk2, const float* bias, const int* lens_dev, float* y2, int B, int D1, int T,
+                      void* stream);
+int ds2_conv2_dgrad_f32(const float* dy2, const float* wpk2d, float* da1, int B, int D1, int T, void* stream);
+size_t ds2_conv_wgrad_workspace_bytes(int which /*0: conv1, 1: conv2*/, int B, int F);
+int ds2_conv1_wgrad_f32(const float* x, const float* dy1, const int* lens_dev, float* dW1, int B, int F, int Tin, int accumulate, void* ws,
+                        size_t ws_bytes, void* stream);
+int ds2_conv2_wgrad_f32(const float* a1, const float* dy2, const int* lens_dev, float* dW2, int B, int D1, int T, int accumulate, void* ws,
+                        size_t ws_bytes, void* stream);
+
+/* ---- bidirectional GRU / LSTM recurrence -------------------------------------------------------
+ * pack_padded_sequence -> aten::gru / aten::lstm -> pad_packed_sequence, modules/blocks.py:87-89, h0 = 0,
+ * gate order r,z,n (GRU) / i,f,g,o (LSTM); gates = 3 | 4.  See asr_amd/csrc/rnn.hip for buffer roles. */
+int ds2_rnn_fwd_f32(int gates, float* gx, const float* whh, const float* bhh, float* hbuf, float* aux, const int* lens_dev, int T, int B,
+                    int H, void* stream);
+size_t ds2_rnn_bwd_workspace_bytes(int B, int H);
+int ds2_rnn_bwd_f32(int gates, const float* dy, int lddy, float* gx, float* aux, const float* hbuf, const float* whhT,
+                    const int* lens_dev, int T, int B, int H, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- log-softmax + CTC loss + gradient ---------------------------------------------------------
+ * out.float().log_softmax(2) + torch.nn.CTCLoss(reduction="sum") and their backward,
+ * trainers/deepspeech_trainer.py:108-112, trainers/__main__.py:53.  blank = 0, zero_infinity = False. */
+size_t ds2_ctc_workspace_bytes(int T, int B, int max_target_len);
+int ds2_ctc_loss_f32(const float* logits, int ld, int T, int B, int C, const int* targets_dev, const int* tgt_off_dev,
+                     const int* in_lens_dev, const int* tgt_lens_dev, int max_target_len, float* nll_dev, float* grad, int ldg,
+                     float grad_scale, void* ws, size_t ws_bytes, void* stream);
+
+/* softmax over the last dim (eval-mode InferenceBatchSoftmax, modules/blocks.py:59-64) */
+int ds2_softmax_rows_f32(const float* x, int ldx, float* y, int ldy, int rows, int C, void* stream);
+
+/* ---- optimizer ----------------------------------------------------------------------------------
+ * torch.optim.AdamW.step over one flat parameter buffer, trainers/__main__.py:41-47. */
+int ds2_adamw_f32(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int step, float grad_scale, void* stream);
+int ds2_scale_f32(float* x, long long n, float s, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DS2HIP_H */

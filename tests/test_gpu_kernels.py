@@ -1,0 +1,298 @@
+"""-m gpu: each HIP kernel family (through the C-ABI, asr_amd.ops) against a CPU restatement of the
+reference op on the same seeded inputs.  Tolerance: fp32, 1e-3 relative is the north-star bar; the
+kernels are expected to sit at 1e-5..1e-6 (fp32 round-off) and the asserts are set accordingly."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, rel_l2
+import det
+from oracle import ds2_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need the MI355X"
+    from asr_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def g(a, dev):
+    return torch.as_tensor(np.asarray(a)).to(dev)
+
+
+def T_(seed, *shape):
+    return torch.from_numpy(det.unitvar(shape, seed))
+
+
+# ---------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(70, 45, 33), (300, 260, 520), (128, 128, 16), (29, 96, 1000), (513, 31, 7)])
+def test_gemm(dev, ta, tb, M, N, K):
+    from asr_amd import ops
+    A = T_(1, *((K, M) if ta else (M, K)))
+    B = T_(2, *((N, K) if tb else (K, N)))
+    bias = T_(3, N)
+    ref = (A.t() if ta else A).double() @ (B.t() if tb else B).double() + bias.double()
+    out = ops.gemm(g(A, dev), g(B, dev), transA=bool(ta), transB=bool(tb), bias=g(bias, dev))
+    assert rel_l2(out.cpu(), ref) < 2e-6
+    # accumulate into existing C, asymmetric check (transposes cannot hide)
+    C0 = T_(4, M, N)
+    out2 = g(C0, dev).clone()
+    ops.gemm(g(A, dev), g(B, dev), transA=bool(ta), transB=bool(tb), out=out2, accumulate=True)
+    assert rel_l2(out2.cpu(), ref - bias.double() + C0.double()) < 2e-6
+
+
+def test_gemm_splitk_batched_strided(dev):
+    from asr_amd import ops
+    # column-sliced operands with pitches, batch of 2 with (negative) strides, forced split-K
+    Tn, Bn, GH, H = 7, 3, 24, 8
+    dg = T_(5, Tn * Bn, 2 * GH)
+    hb = T_(6, Tn * Bn, 2 * H)
+    out = torch.zeros(2, GH, H, device=dev)
+    dgd, hbd = g(dg, dev), g(hb, dev)
+    K = (Tn - 1) * Bn
+    a0 = dgd.data_ptr() + 4 * (Bn * 2 * GH)
+    b0 = hbd.data_ptr()
+    a1 = dgd.data_ptr() + 4 * GH
+    b1 = hbd.data_ptr() + 4 * (H + Bn * 2 * H)
+    ops.gemm_raw(True, False, GH, H, K, a0, 2 * GH, (a1 - a0) // 4, b0, 2 * H, (b1 - b0) // 4, out.data_ptr(), H, GH * H, dev,
+                 batch=2, splitk=2)
+    ref0 = dg[Bn:, :GH].double().t() @ hb[:-Bn, :H].double()
+    ref1 = dg[:-Bn, GH:].double().t() @ hb[Bn:, H:].double()
+    assert rel_l2(out[0].cpu(), ref0) < 2e-6 and rel_l2(out[1].cpu(), ref1) < 2e-6
+
+
+# ---------------------------------------------------------------------------------------------- BN1d
+@pytest.mark.parametrize("M,H", [(50, 24), (1000, 96), (333, 1312), (64, 5)])
+def test_bn1d(dev, M, H):
+    from asr_amd import ops
+    X = T_(7, M, H) * 1.7 + 0.3
+    Xb = T_(8, M, H)
+    gam, bet = T_(9, H) * 0.2 + 1.0, T_(10, H) * 0.1
+    rm, rv = torch.zeros(H), torch.ones(H)
+    rmd, rvd = g(rm, dev), g(rv, dev)
+    mean, var = ops.colstats(g(X, dev), rmd, rvd)
+    Xd = X.double()
+    assert rel_l2(mean.cpu(), Xd.mean(0)) < 1e-5 and rel_l2(var.cpu(), Xd.var(0, unbiased=False)) < 1e-5
+    assert rel_l2(rmd.cpu(), 0.1 * Xd.mean(0)) < 1e-5
+    assert rel_l2(rvd.cpu(), 0.9 + 0.1 * Xd.var(0, unbiased=True)) < 1e-5
+    Y, m2, v2 = ops.add_colstats(g(X, dev), g(Xb, dev))
+    S = (X + Xb).double()
+    assert torch.equal(Y.cpu(), X + Xb)
+    assert rel_l2(m2.cpu(), S.mean(0)) < 1e-5 and rel_l2(v2.cpu(), S.var(0, unbiased=False)) < 1e-5
+    assert rel_l2(ops.colsum(g(X, dev)).cpu(), Xd.sum(0)) < 1e-5
+    # apply + backward vs autograd of the oracle's batch norm
+    Xr = X.clone().double().requires_grad_(True)
+    gr = gam.clone().double().requires_grad_(True)
+    br = bet.clone().double().requires_grad_(True)
+    y, mu, vv = O.batch_norm_train(Xr, gr, br, (0,), (1, -1))
+    dY = T_(11, M, H).double()
+    (y * dY).sum().backward()
+    yd = ops.bn1d_apply(g(X, dev), mean, var, g(gam, dev), g(bet, dev))
+    assert rel_l2(yd.cpu(), y.detach()) < 1e-5
+    dgam, dbet = torch.empty(H, device=dev), torch.empty(H, device=dev)
+    dX = ops.bn1d_bwd(g(dY.float(), dev), g(X, dev), mean, var, g(gam, dev), dgam, dbet)
+    assert rel_l2(dX.cpu(), Xr.grad) < 2e-5
+    assert rel_l2(dgam.cpu(), gr.grad) < 1e-5 and rel_l2(dbet.cpu(), br.grad) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------- BN2d
+@pytest.mark.parametrize("B,D,T,lens", [(3, 5, 20, [20, 13, 7]), (2, 41, 37, [37, 30]), (4, 3, 130, [130, 129, 64, 1])])
+def test_bn2d_act(dev, B, D, T, lens):
+    from asr_amd import ops
+    C = 32
+    lens_t = torch.tensor(lens, dtype=torch.int32)
+    mask = (torch.arange(T).view(1, 1, 1, T) < lens_t.view(B, 1, 1, 1)).double()
+    Y = (T_(12, B, C, D, T).double() * 2.0 + 0.5) * mask              # conv output already masked
+    gam, bet = T_(13, C).double() * 0.3 + 1.0, T_(14, C).double() * 0.5 + 3.0
+    Yr = Y.clone().requires_grad_(True)
+    gr, br = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    z, mu, vv = O.batch_norm_train(Yr * mask, gr, br, (0, 2, 3), (1, -1, 1, 1))
+    a = torch.clamp(z * mask, 0.0, 20.0) * mask
+    dA = T_(15, B, C, D, T).double()
+    (a * dA).sum().backward()
+    ld = g(lens_t, dev)
+    mean, var = ops.bn2d_stats(g(Y.float(), dev))
+    assert rel_l2(mean.cpu(), mu.detach()) < 1e-5 and rel_l2(var.cpu(), vv.detach()) < 1e-5
+    A = ops.bn2d_act_fwd(g(Y.float(), dev), ld, mean, var, g(gam.float(), dev), g(bet.float(), dev))
+    assert rel_l2(A.cpu(), a.detach()) < 1e-5
+    dg_, db_ = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    dY = ops.bn2d_act_bwd(g(Y.float(), dev), g(dA.float(), dev), ld, mean, var, g(gam.float(), dev), g(bet.float(), dev), dg_, db_)
+    assert rel_l2(dY.cpu(), Yr.grad) < 3e-5
+    assert rel_l2(dg_.cpu(), gr.grad) < 2e-5 and rel_l2(db_.cpu(), br.grad) < 2e-5
+    assert rel_l2(ops.chan_sum(g(Y.float(), dev)).cpu(), Y.sum((0, 2, 3))) < 1e-5
+
+
+def test_transposes(dev):
+    from asr_amd import ops
+    B, F, T = 3, 70, 45
+    a = T_(16, B, F, T)
+    tbf = ops.transpose_bft(g(a, dev), B, F, T, True)
+    assert torch.equal(tbf.cpu(), a.permute(2, 0, 1).contiguous())
+    back = ops.transpose_bft(tbf, B, F, T, False)
+    assert torch.equal(back.cpu(), a)
+    w = T_(17, 2, 72, 24)
+    assert torch.equal(ops.transpose_batched(g(w, dev)).cpu(), w.transpose(1, 2).contiguous())
+
+
+# ---------------------------------------------------------------------------------------------- conv
+def _conv_case(B, Tin, lens_in):
+    x = T_(20, B, 1, 161, Tin)
+    for i, l in enumerate(lens_in):
+        x[i, :, :, l:] = 0
+    out_lens = O.seq_lens_after_conv(torch.tensor(lens_in, dtype=torch.int32))
+    w1 = torch.from_numpy(det.uniform((32, 1, 41, 11), 21, -0.05, 0.05))
+    b1 = torch.from_numpy(det.uniform((32,), 22, -0.1, 0.1))
+    w2 = torch.from_numpy(det.uniform((32, 32, 21, 11), 23, -0.02, 0.02))
+    b2 = torch.from_numpy(det.uniform((32,), 24, -0.1, 0.1))
+    return x, out_lens, w1, b1, w2, b2
+
+
+@pytest.mark.parametrize("B,Tin,lens_in", [(2, 40, [40, 21]), (3, 300, [300, 257, 90]), (1, 257, [257])])
+def test_conv_fwd_bwd(dev, B, Tin, lens_in):
+    from asr_amd import ops
+    x, out_lens, w1, b1, w2, b2 = _conv_case(B, Tin, lens_in)
+    T = int((Tin + 1) // 2)
+    mask = (torch.arange(T).view(1, 1, 1, T) < out_lens.view(B, 1, 1, 1)).double()
+    w1r, b1r = w1.double().requires_grad_(True), b1.double().requires_grad_(True)
+    w2r, b2r = w2.double().requires_grad_(True), b2.double().requires_grad_(True)
+    y1 = torch.nn.functional.conv2d(x.double(), w1r, b1r, stride=(2, 2), padding=(20, 5)) * mask
+    a1 = (torch.clamp(y1, 0.0, 20.0) * mask).detach().requires_grad_(True)   # stand-in activation
+    y2 = torch.nn.functional.conv2d(a1, w2r, b2r, stride=(2, 1), padding=(10, 5)) * mask
+    dy2 = T_(25, *y2.shape).double() * mask
+    dy1 = T_(26, *y1.shape).double() * mask
+    (y2 * dy2).sum().backward()
+    gw1 = torch.autograd.grad((y1 * dy1).sum(), w1r)[0]
+    ld = g(out_lens, dev)
+    wpk1, wpk2, wpk2d = ops.conv_pack(g(w1, dev), g(w2, dev))
+    y1d = ops.conv1_fwd(g(x, dev), wpk1, g(b1, dev), ld)
+    assert y1d.shape == y1.shape
+    assert rel_l2(y1d.cpu(), y1.detach()) < 1e-5
+    a1d = g(a1.detach().float(), dev)
+    y2d = ops.conv2_fwd(a1d, wpk2, g(b2, dev), ld)
+    assert rel_l2(y2d.cpu(), y2.detach()) < 1e-5
+    da1 = ops.conv2_dgrad(g(dy2.float(), dev), wpk2d, 81)
+    assert rel_l2(da1.cpu(), a1.grad) < 1e-5
+    dW2 = torch.empty(32, 32, 21, 11, device=dev)
+    ops.conv2_wgrad(a1d, g(dy2.float(), dev), ld, dW2)
+    assert rel_l2(dW2.cpu(), w2r.grad) < 2e-5
+    dW1 = torch.empty(32, 1, 41, 11, device=dev)
+    ops.conv1_wgrad(g(x, dev), g(dy1.float(), dev), ld, dW1)
+    assert rel_l2(dW1.cpu(), gw1) < 2e-5
+    assert rel_l2(ops.chan_sum(g(dy2.float(), dev)).cpu(), b2r.grad) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------- RNN
+@pytest.mark.parametrize("kind,H,B,T,lens", [("gru", 32, 3, 9, [9, 6, 2]), ("lstm", 24, 3, 9, [9, 6, 2]), ("gru", 72, 20, 17, None),
+                                             ("lstm", 40, 37, 11, None), ("gru", 16, 1, 5, [5])])
+def test_rnn_fwd_bwd(dev, kind, H, B, T, lens):
+    from asr_amd import ops
+    G = 3 if kind == "gru" else 4
+    if lens is None:
+        lens = sorted([int(v) for v in det.randint((B,), 30, 1, T + 1)], reverse=True)
+        lens[0] = T
+    lens_t = torch.tensor(lens, dtype=torch.int32)
+    k = 1.0 / H ** 0.5
+    gx = (T_(31, T, B, 2, G * H) * 0.8).double().requires_grad_(True)
+    whh = torch.from_numpy(det.uniform((2, G * H, H), 32, -k, k)).double().requires_grad_(True)
+    bhh = torch.from_numpy(det.uniform((2, G * H), 33, -k, k)).double().requires_grad_(True)
+    step = O.gru_direction if kind == "gru" else O.lstm_direction
+    yf = step(gx[:, :, 0], whh[0], bhh[0], lens_t, False)
+    yb = step(gx[:, :, 1], whh[1], bhh[1], lens_t, True)
+    y = yf + yb
+    dy = T_(34, T, B, H).double()
+    (y * dy).sum().backward()
+
+    ld = g(lens_t, dev)
+    gxd = g(gx.detach().float().reshape(T * B, 2 * G * H), dev).clone()
+    whd, bhd = g(whh.detach().float(), dev), g(bhh.detach().float(), dev)
+    hbuf, aux = ops.rnn_fwd(G, gxd, whd, bhd, ld, T, B, H)
+    hb = hbuf.view(T, B, 2, H).cpu()
+    assert rel_l2(hb[:, :, 0], yf.detach()) < 2e-5 and rel_l2(hb[:, :, 1], yb.detach()) < 2e-5
+    ysum, _, _ = ops.add_colstats(hbuf[:, :H], hbuf[:, H:])
+    assert rel_l2(ysum.view(T, B, H).cpu(), y.detach()) < 2e-5
+    whhT = ops.transpose_batched(whd)
+    ops.rnn_bwd(G, g(dy.float().reshape(T * B, H), dev), gxd, aux, hbuf, whhT, ld, T, B, H)
+    assert rel_l2(gxd.view(T, B, 2, G * H).cpu(), gx.grad) < 5e-5          # dGx
+    # dW_hh / db_hh from the saved buffers exactly as engine.backward assembles them
+    dgx = gxd
+    dwhh = torch.zeros(2, G * H, H, device=dev)
+    if T > 1:
+        K = (T - 1) * B
+        ldg, ldh = 2 * G * H, 2 * H
+        a0 = dgx.data_ptr() + 4 * (B * ldg)
+        b0 = hbuf.data_ptr()
+        a1 = dgx.data_ptr() + 4 * (G * H)
+        b1 = hbuf.data_ptr() + 4 * (H + B * ldh)
+        rows = 2 * H if G == 3 else 4 * H
+        ops.gemm_raw(True, False, rows, H, K, a0, ldg, (a1 - a0) // 4, b0, ldh, (b1 - b0) // 4, dwhh.data_ptr(), H, G * H * H, dev, batch=2)
+        if G == 3:
+            x0 = aux.data_ptr() + 4 * (B * ldh)
+            x1 = aux.data_ptr() + 4 * H
+            ops.gemm_raw(True, False, H, H, K, x0, ldh, (x1 - x0) // 4, b0, ldh, (b1 - b0) // 4, dwhh.data_ptr() + 4 * (2 * H * H), H,
+                         G * H * H, dev, batch=2)
+    assert rel_l2(dwhh.cpu(), whh.grad) < 5e-5
+    dbih = ops.colsum(dgx).view(2, G * H)
+    dbhh = dbih.clone()
+    if G == 3:
+        dbhh[:, 2 * H:] = ops.colsum(aux).view(2, H)
+    assert rel_l2(dbhh.cpu(), bhh.grad) < 5e-5
+
+
+# ---------------------------------------------------------------------------------------------- CTC
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_ctc_golden(dev, case):
+    from asr_amd import ops
+    from asr_amd.ctc import _prep_targets
+    z = np.load(f"{GOLDEN}/ctc.npz")
+    T, B, C = int(z[f"{case}_T"]), int(z[f"{case}_B"]), int(z[f"{case}_C"])
+    scale = float(z[f"{case}_scale"]) if f"{case}_scale" in z else 1.0
+    logits = det.unitvar((T, B, C), int(z[f"{case}_seed"])) * np.float32(scale)
+    tg, off, tl, max_u = _prep_targets(torch.from_numpy(z[f"{case}_targets"]), torch.from_numpy(z[f"{case}_tl"]), dev)
+    il = g(z[f"{case}_il"].astype(np.int32), dev)
+    for inp in (logits, torch.from_numpy(logits).log_softmax(2).numpy()):      # raw logits and log-probs give the same answer
+        nll, grad = ops.ctc_loss(g(inp, dev), tg, off, il, tl, max_u, 1.0)
+        ref = z[f"{case}_nll"]
+        fin = np.isfinite(ref)
+        got = nll.cpu().numpy()
+        assert np.array_equal(np.isinf(got), ~fin)
+        assert np.allclose(got[fin], ref[fin], rtol=1e-5, atol=1e-4)
+        if f"{case}_grad" in z:
+            assert rel_l2(grad.cpu(), z[f"{case}_grad"]) < 2e-4
+
+
+def test_ctc_vs_numpy_oracle_large(dev):
+    from asr_amd import ops
+    from asr_amd.ctc import _prep_targets
+    T, B, C = 120, 6, 40
+    logits = det.unitvar((T, B, C), 40) * np.float32(1.5)
+    tl = np.array([25, 17, 9, 3, 1, 0], dtype=np.int32)
+    il = np.array([120, 100, 77, 40, 13, 5], dtype=np.int32)
+    targets = det.randint((int(tl.sum()),), 41, 1, C).astype(np.int32)
+    targets[3:6] = targets[3]                                                   # repeated labels
+    lp = torch.from_numpy(logits).double().log_softmax(2).numpy()
+    nll_ref, grad_ref = O.ctc_nll_and_grad_np(lp, targets, il, tl)
+    tg, off, tld, max_u = _prep_targets(torch.from_numpy(targets), torch.from_numpy(tl), dev)
+    nll, grad = ops.ctc_loss(g(logits, dev), tg, off, g(il, dev), tld, max_u, 0.25)
+    assert np.allclose(nll.cpu().numpy(), nll_ref, rtol=1e-5, atol=1e-4)
+    assert rel_l2(grad.cpu(), 0.25 * grad_ref) < 1e-4
+    assert float(grad[il[1]:, 1].abs().max()) == 0.0                             # frames beyond the length get zero grad
+
+
+def test_softmax_and_adamw(dev):
+    from asr_amd import ops
+    x = T_(50, 77, 29) * 3
+    assert rel_l2(ops.softmax_rows(g(x, dev)).cpu(), x.double().softmax(1)) < 1e-6
+    n = 1003
+    p, gr = T_(51, n), T_(52, n) * 0.1
+    pd, gd = g(p, dev).clone(), g(gr, dev)
+    m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    pn, mn, vn = p.double().numpy(), np.zeros(n), np.zeros(n)
+    for step in range(1, 4):
+        ops.adamw(pd, gd, m, v, step, 1.5e-4, (0.9, 0.999), 1e-8, 1e-5, 1.0)
+        pn, mn, vn = O.adamw_step_np(pn, gr.double().numpy(), mn, vn, step)
+    assert rel_l2(pd.cpu(), pn) < 1e-6

@@ -1,0 +1,196 @@
+"""-m gpu: whole DeepSpeech train step on the HIP path vs (a) golden vectors from the unmodified
+reference, (b) the CPU oracle at larger shapes, (c) size-independent properties at full BASELINE sizes.
+Tolerance (north_star): logits, CTC loss, grads within 1e-3 relative, fp32."""
+import os
+import tempfile
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import MODEL_FIXTURES, load_model_fixture, model_inputs, rel_l2, subsample
+import det
+from oracle import ds2_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def audio_conf():
+    return SimpleNamespace(sample_rate=16000, window_size=0.02, window_stride=0.01, window="hamming", speed_volume_perturb=False,
+                           spec_augment=False, noise_dir=None, noise_prob=0.4, noise_levels=(0.0, 0.5))
+
+
+def make_model(cfg, sd=None, device="cuda:0"):
+    import pandas as pd
+    from asr_amd import DeepSpeech
+    chars = ["_", "'"] + list("abcdefghijklmnopqrstuvwxyz") + ["|"] + [chr(0x3041 + i) for i in range(100)]
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "labels.csv")
+        pd.DataFrame({"label": chars[: cfg["classes"]]}).to_csv(path, index=False)
+        model = DeepSpeech(audio_conf=audio_conf(), decoder=None, label_path=path, rnn_type=cfg["rnn"], rnn_hidden_size=cfg["hidden"],
+                           rnn_hidden_layers=cfg["layers"], bidirectional=True)
+    if sd is not None:
+        model.load_state_dict({k: v.cpu() for k, v in sd.items()})
+    model.to(device)
+    model.train()
+    return model
+
+
+def grad_check(name, got, ref_sub, ref_norm, tol=TOL):
+    got = subsample(np.asarray(got))
+    err = np.linalg.norm(got.astype(np.float64) - ref_sub.astype(np.float64))
+    scale = max(np.linalg.norm(ref_sub.astype(np.float64)), 1e-3 * float(ref_norm), 1e-12)
+    assert err <= tol * scale, (name, err, scale)
+
+
+@pytest.mark.parametrize("name", MODEL_FIXTURES)
+def test_fit_matches_reference_golden(name):
+    """fit() + loss.backward() (autograd path, torch-compatible criterion) vs the reference's golden step 0."""
+    from asr_amd import CTCLoss
+    from asr_amd.trainers import DeepSpeechTrainer
+    z, cfg = load_model_fixture(name)
+    sd, x, targets, pct, tsz = model_inputs(cfg)
+    model = make_model(cfg, sd)
+    opt = torch.optim.AdamW(model.parameters(), lr=1.5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5)
+    tr = DeepSpeechTrainer(model, CTCLoss(reduction="sum"), 1, None, opt, None, None, "cuda", "cuda", False, None)
+    losses = []
+    for step in range(3):
+        valid, loss, lv = tr.fit((x, targets, pct.clone(), tsz))
+        assert valid
+        opt.zero_grad()
+        loss.backward()
+        if step == 0:
+            out, out_lens = None, None
+            for k, p in model.named_parameters():
+                grad_check(k, p.grad.cpu().numpy(), z["grad_" + k], z["gradnorm_" + k])
+            for k, v in model.state_dict().items():
+                if "running_" in k:
+                    assert np.allclose(v.cpu().numpy(), z["buf_" + k], rtol=1e-3, atol=1e-5), k
+        opt.step()
+        losses.append(lv)
+    assert np.allclose(losses, z["losses"], rtol=TOL), (losses, z["losses"])
+    for k, p in model.named_parameters():
+        assert rel_l2(subsample(p.detach().cpu().numpy()), z["final_" + k]) < TOL, k
+    # eval-mode forward (softmax probabilities) after the 3 steps
+    model.eval()
+    with torch.no_grad():
+        probs, _ = model.forward(x.cuda(), O.lengths_from_percentages(pct, x.size(3)))
+    assert rel_l2(probs.cpu().numpy(), z["eval_probs"]) < TOL
+
+
+@pytest.mark.parametrize("name", MODEL_FIXTURES)
+def test_fused_step_matches_reference_golden(name):
+    """trainer.step() (no autograd, FusedAdamW on the flat buffer) reproduces the reference's 3-step loss curve
+    and final weights; logits of step 0 checked through forward()."""
+    from asr_amd import CTCLoss, FusedAdamW
+    from asr_amd.trainers import DeepSpeechTrainer
+    z, cfg = load_model_fixture(name)
+    sd, x, targets, pct, tsz = model_inputs(cfg)
+    model = make_model(cfg, sd)
+    with torch.no_grad():
+        logits, out_lens = model.forward(x.cuda(), O.lengths_from_percentages(pct, x.size(3)))   # train mode => raw logits
+    assert np.array_equal(out_lens.numpy(), z["output_sizes"])
+    assert rel_l2(logits.cpu().numpy(), z["logits"]) < TOL
+    model = make_model(cfg, sd)   # fresh (the no-grad forward above advanced BN running stats)
+    opt = FusedAdamW(model, lr=1.5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5)
+    tr = DeepSpeechTrainer(model, CTCLoss(reduction="sum"), 1, None, opt, None, None, "cuda", "cuda", False, None)
+    losses = []
+    for step in range(3):
+        valid, lv = tr.step((x, targets, pct.clone(), tsz))
+        assert valid
+        losses.append(lv)
+    assert np.allclose(losses, z["losses"], rtol=TOL), (losses, z["losses"])
+    for k, p in model.named_parameters():
+        assert rel_l2(subsample(p.detach().cpu().numpy()), z["final_" + k]) < TOL, k
+
+
+@pytest.mark.parametrize("rnn,hidden,layers,B,tmax", [("gru", 72, 3, 6, 151), ("lstm", 56, 2, 5, 120), ("gru", 128, 2, 33, 90)])
+def test_step_vs_oracle_larger(rnn, hidden, layers, B, tmax):
+    """Shapes the golden files do not cover (ragged, H not a multiple of 16/32, B > 32): HIP vs CPU oracle."""
+    cfg = dict(rnn=rnn, hidden=hidden, layers=layers, classes=29)
+    t_ins = sorted([int(v) for v in det.randint((B,), 60, tmax // 3, tmax + 1)], reverse=True)
+    t_ins[0] = tmax
+    cfg["t_ins"] = t_ins
+    sd, x, targets, pct, tsz = model_inputs(cfg)
+    ref = O.fit_and_grads(sd, x, targets, pct, tsz, dtype=torch.float64)
+    model = make_model(cfg, sd)
+    lens = O.lengths_from_percentages(pct, x.size(3))
+    out, out_lens = model.forward(x.cuda(), lens)
+    from asr_amd import CTCLoss
+    loss = CTCLoss(reduction="sum")(out.transpose(0, 1), targets, out_lens, tsz) / B
+    loss.backward()
+    assert rel_l2(out.detach().cpu().numpy(), ref["logits"].numpy()) < TOL
+    assert abs(float(loss) - ref["loss"]) / ref["loss"] < TOL
+    for k, p in model.named_parameters():
+        gref = ref["grads"][k].numpy()
+        err = np.linalg.norm(p.grad.cpu().numpy().astype(np.float64) - gref)
+        assert err <= TOL * max(np.linalg.norm(gref), 1e-12), (k, err, np.linalg.norm(gref))
+
+
+def test_infeasible_batch_is_skipped():
+    """An utterance with no valid alignment gives loss = inf -> check_loss invalid -> weights untouched
+    (deepspeech_trainer.py:86-97)."""
+    from asr_amd import CTCLoss, FusedAdamW
+    from asr_amd.trainers import DeepSpeechTrainer
+    cfg = dict(rnn="gru", hidden=32, layers=1, classes=7, t_ins=[40, 21])
+    sd, x, targets, pct, tsz = model_inputs(cfg)
+    targets = torch.ones(30, dtype=torch.int32)                      # 15 repeated labels need 29 frames; only 20 / 11 exist
+    tsz = torch.tensor([15, 15], dtype=torch.int32)
+    model = make_model(cfg, sd)
+    opt = FusedAdamW(model)
+    tr = DeepSpeechTrainer(model, CTCLoss(reduction="sum"), 1, None, opt, None, None, "cuda", "cuda", False, None)
+    model._ensure_flat(torch.device("cuda:0"))
+    before = model.flat_parameters()[0].clone()
+    valid, lv = tr.step((x, targets, pct.clone(), tsz))
+    assert not valid and lv == float("inf")
+    assert torch.equal(before, model.flat_parameters()[0])
+
+
+def test_full_size_properties():
+    """BASELINE configs[1] shape (5x768 GRU, B=32, 10 s): too big for the oracle in seconds, so check
+    size-independent properties: determinism (bit-identical reruns), exact zeros beyond each sample's
+    length, zero input-side gradient contribution of padded frames, loss decreases over fused steps."""
+    from asr_amd import CTCLoss, FusedAdamW
+    from asr_amd.trainers import DeepSpeechTrainer
+    cfg = dict(rnn="gru", hidden=768, layers=5, classes=29)
+    B, tmax = 32, 1001
+    t_ins = sorted([int(v) for v in det.randint((B,), 61, 400, tmax + 1)], reverse=True)
+    t_ins[0] = tmax
+    cfg["t_ins"] = t_ins
+    torch.manual_seed(0)
+    model = make_model(cfg)
+    x, targets, pct, tsz = det.batch(B, t_ins, 29, seed=1)
+    x, targets, pct, tsz = map(torch.from_numpy, (x, targets, pct, tsz))
+    lens = O.lengths_from_percentages(pct, tmax)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    outs = []
+    for _ in range(2):
+        model.load_state_dict(sd0)
+        out, out_lens = model.forward(x.cuda(), lens)
+        loss = CTCLoss(reduction="sum")(out.transpose(0, 1), targets, out_lens, tsz) / B
+        model._flat.flat_grad.zero_()
+        loss.backward()
+        outs.append((out.detach().clone(), float(loss), model._flat.flat_grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1] and torch.equal(outs[0][2], outs[1][2])
+    assert np.isfinite(outs[0][1]) and outs[0][1] > 0
+    # the same utterances with EXTRA zero padding appended change nothing for frames < len except through
+    # BatchNorm statistics (A.3) — so instead check the masking invariants directly on saved activations:
+    from asr_amd import engine
+    model.load_state_dict(sd0)
+    W = model._flat.tensors(model)
+    with torch.no_grad():
+        logits, ctx = engine.forward(W, model._cfg, x.cuda(), out_lens.cuda(), training=True, save=True)
+    T = logits.shape[0]
+    tmask = (torch.arange(T).view(T, 1) >= out_lens.view(1, B)).cuda()                 # (T,B) True on padding
+    for lc in ctx.layers:
+        hb = lc.hbuf.view(T, B, -1)
+        assert float(hb[tmask].abs().max()) == 0.0
+    assert float(ctx.y2.permute(3, 0, 1, 2)[tmask].abs().max()) == 0.0
+    # loss goes down under the fused optimizer
+    model.load_state_dict(sd0)
+    opt = FusedAdamW(model, lr=3e-4)
+    tr = DeepSpeechTrainer(model, CTCLoss(reduction="sum"), 1, None, opt, None, None, "cuda", "cuda", False, None)
+    ls = [tr.step((x, targets, pct.clone(), tsz))[1] for _ in range(4)]
+    assert ls[-1] < ls[0], ls
