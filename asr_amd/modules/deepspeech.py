@@ -39,8 +39,21 @@ class _DS2Function(torch.autograd.Function):
     def backward(ctx, dlogits):
         model = ctx.model
         W = model._flat.tensors(model)
-        Gr = model._flat.tensors(model, grads=True)
-        engine.backward(W, Gr, model._cfg, ctx.saved, dlogits.contiguous(), on_bucket=model._on_bucket)
+        flat = model._flat
+        # autograd installs the returned tensors as `p.grad` without a copy, i.e. p.grad then ALIASES the flat
+        # gradient buffer (the zero-copy normal case: zero_grad(set_to_none=True) -> backward -> step).  If some
+        # p.grad is still alive (gradient accumulation, zero_grad(set_to_none=False)) the kernels must not
+        # overwrite it: compute into a scratch buffer and let autograd add.
+        accumulating = any(p.grad is not None for p in model.parameters())
+        if accumulating:
+            keep, flat.flat_grad = flat.flat_grad, torch.empty_like(flat.flat_grad)
+        try:
+            Gr = flat.tensors(model, grads=True)
+            engine.backward(W, Gr, model._cfg, ctx.saved, dlogits.contiguous(),
+                            on_bucket=None if accumulating else model._on_bucket)
+        finally:
+            if accumulating:
+                flat.flat_grad = keep
         ctx.saved = None
         grads = tuple(Gr[n] for n in model._param_names)
         return (None, None, None) + grads

@@ -107,6 +107,8 @@ def conv_stack(x: Tensor, out_lens: Tensor, sd: Dict[str, Tensor], training: boo
     else:
         z = batch_norm_eval(y, sd[p + "1.weight"], sd[p + "1.bias"], sd[p + "1.running_mean"],
                             sd[p + "1.running_var"], (1, -1, 1, 1))
+    if taps is not None:
+        taps["bn1"] = z
     z = mask(z)
     a = mask(torch.clamp(z, 0.0, 20.0))
     if taps is not None:
@@ -121,11 +123,34 @@ def conv_stack(x: Tensor, out_lens: Tensor, sd: Dict[str, Tensor], training: boo
     else:
         z = batch_norm_eval(y, sd[p + "4.weight"], sd[p + "4.bias"], sd[p + "4.running_mean"],
                             sd[p + "4.running_var"], (1, -1, 1, 1))
+    if taps is not None:
+        taps["bn2"] = z
     z = mask(z)
     a = mask(torch.clamp(z, 0.0, 20.0))
     if taps is not None:
         taps["act2"] = a
     return a
+
+
+def hardtanh_kink_margin(sd: Dict[str, Tensor], x: Tensor, lengths: Tensor) -> float:
+    """Smallest distance of any un-masked BatchNorm2d output to a Hardtanh kink (0 or 20).
+    d/dz Hardtanh is discontinuous there: an element within fp32 round-off (~1e-6) of a kink takes
+    either branch depending on summation order — in the reference's own CPU kernels too — and moves
+    the gradients by O(1/sqrt(#elements)).  Parity fixtures are chosen with margin >= 4e-6 (10x round-off) so that
+    they test the kernels, not this ill-conditioning ('Numerics')."""
+    out_lens = seq_lens_after_conv(lengths.cpu().int())
+    taps: dict = {}
+    with torch.no_grad():
+        conv_stack(x.double(), out_lens, {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()
+                                           if k.startswith("conv.")}, True, None, taps)
+    B = x.shape[0]
+    m = 1e30
+    for key in ("bn1", "bn2"):
+        z = taps[key]
+        msk = _time_mask(out_lens, z.shape[3], torch.bool, z.device).view(B, 1, 1, -1).expand_as(z)
+        zz = z[msk]
+        m = min(m, float(torch.minimum(zz.abs(), (zz - 20.0).abs()).min()))
+    return m
 
 
 def collapse_to_tbf(a: Tensor) -> Tensor:

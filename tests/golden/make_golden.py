@@ -141,8 +141,30 @@ def gen_model(out, name, DeepSpeech, tmp):
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in weights.items()})
     model.train()
 
-    x, targets, pct, tsz = det.batch(len(t_ins), t_ins, classes, seed=1)
-    inputs = torch.from_numpy(x)
+    # data seed: first one whose BatchNorm2d outputs (reference modules, fp32) keep >= 4e-6 distance (10x fp32 round-off of z) to the
+    # Hardtanh kinks at every un-masked position (ill-conditioned otherwise: oracle.hardtanh_kink_margin)
+    seed = 1
+    while True:
+        x, targets, pct, tsz = det.batch(len(t_ins), t_ins, classes, seed=seed)
+        inputs = torch.from_numpy(x)
+        zs = []
+        hk = [model.conv.seq_module[i].register_forward_hook(lambda m, i, o: zs.append(o.detach().clone())) for i in (1, 4)]
+        with torch.no_grad():
+            sizes = torch.from_numpy(pct.copy()).mul_(int(inputs.size(3))).int()
+            ol = model.get_seq_lens(sizes)
+            model.conv(inputs, ol)
+        for h in hk:
+            h.remove()
+        margin = 1e30
+        for zt in zs:
+            msk = (torch.arange(zt.size(3)).view(1, 1, 1, -1) < ol.view(-1, 1, 1, 1)).expand_as(zt)
+            v = zt[msk].double()
+            margin = min(margin, float(torch.minimum(v.abs(), (v - 20).abs()).min()))
+        if margin >= 4e-6 or seed > 400:
+            break
+        seed += 2
+    print(name, "data seed", seed, "kink margin", margin)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in weights.items()})  # undo BN running-stat updates
     targets = torch.from_numpy(targets)
     tsz = torch.from_numpy(tsz)
     criterion = torch.nn.CTCLoss(reduction="sum")
@@ -198,7 +220,7 @@ def gen_model(out, name, DeepSpeech, tmp):
         input_sizes = input_percentages.mul_(int(inputs.size(3))).int()
         o, _ = model.forward(inputs, input_sizes)
     rec["eval_probs"] = o.numpy()
-    rec["cfg"] = np.array(json.dumps(dict(rnn=rnn, hidden=hidden, layers=layers, classes=classes, t_ins=t_ins)))
+    rec["cfg"] = np.array(json.dumps(dict(rnn=rnn, hidden=hidden, layers=layers, classes=classes, t_ins=t_ins, seed=seed)))
     np.savez_compressed(os.path.join(out, f"model_{name}.npz"), **rec)
     print(name, "losses", losses)
 

@@ -33,13 +33,26 @@ def load_model_fixture(name):
     return z, cfg
 
 
-def model_inputs(cfg, device="cpu"):
-    """(state_dict of torch tensors, inputs, targets, pct, target_sizes) regenerated from hashes."""
+def model_inputs(cfg, device="cpu", well_conditioned=True):
+    """(state_dict of torch tensors, inputs, targets, pct, target_sizes) regenerated from hashes.
+    cfg["seed"] (golden fixtures) pins the data seed; otherwise, when `well_conditioned`, the first
+    seed >= 1 whose BatchNorm2d outputs all stay >= 4e-6 away from the Hardtanh kinks is used
+    (oracle.hardtanh_kink_margin explains why)."""
+    from oracle import ds2_oracle as O
     shapes = det.state_shapes(cfg["rnn"], cfg["hidden"], cfg["layers"], cfg["classes"])
     w = det.model_state(shapes, base_seed=0)
     sd = {k: torch.from_numpy(np.asarray(v)).to(device) for k, v in w.items()}
-    x, targets, pct, tsz = det.batch(len(cfg["t_ins"]), cfg["t_ins"], cfg["classes"], seed=1)
-    return sd, torch.from_numpy(x), torch.from_numpy(targets), torch.from_numpy(pct), torch.from_numpy(tsz)
+    seed = int(cfg.get("seed", 1))
+    while True:
+        x, targets, pct, tsz = det.batch(len(cfg["t_ins"]), cfg["t_ins"], cfg["classes"], seed=seed)
+        x, targets, pct, tsz = torch.from_numpy(x), torch.from_numpy(targets), torch.from_numpy(pct), torch.from_numpy(tsz)
+        if "seed" in cfg or not well_conditioned or x.numel() > 150_000:  # big cases: a flip moves grads by ~1/sqrt(N) << tol
+            break
+        if O.hardtanh_kink_margin(sd, x, O.lengths_from_percentages(pct, x.size(3))) >= 4e-6 or seed > 200:
+            break
+        seed += 2
+    cfg["seed_used"] = seed
+    return sd, x, targets, pct, tsz
 
 
 MODEL_FIXTURES = ["gru_h32_l2", "lstm_h24_l2", "gru_h48_l3", "lstm_h40_l3"]

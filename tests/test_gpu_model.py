@@ -122,7 +122,7 @@ def test_step_vs_oracle_larger(rnn, hidden, layers, B, tmax):
     loss = CTCLoss(reduction="sum")(out.transpose(0, 1), targets, out_lens, tsz) / B
     loss.backward()
     assert rel_l2(out.detach().cpu().numpy(), ref["logits"].numpy()) < TOL
-    assert abs(float(loss) - ref["loss"]) / ref["loss"] < TOL
+    assert abs(float(loss.detach()) - ref["loss"]) / ref["loss"] < TOL
     for k, p in model.named_parameters():
         gref = ref["grads"][k].numpy()
         err = np.linalg.norm(p.grad.cpu().numpy().astype(np.float64) - gref)
@@ -168,12 +168,17 @@ def test_full_size_properties():
     outs = []
     for _ in range(2):
         model.load_state_dict(sd0)
+        model.zero_grad(set_to_none=True)
         out, out_lens = model.forward(x.cuda(), lens)
         loss = CTCLoss(reduction="sum")(out.transpose(0, 1), targets, out_lens, tsz) / B
-        model._flat.flat_grad.zero_()
         loss.backward()
-        outs.append((out.detach().clone(), float(loss), model._flat.flat_grad.clone()))
+        outs.append((out.detach().clone(), float(loss.detach()), torch.cat([p.grad.reshape(-1) for p in model.parameters()])))
     assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1] and torch.equal(outs[0][2], outs[1][2])
+    # gradient accumulation (p.grad alive) must ADD, not alias-and-double
+    out, out_lens = model.forward(x.cuda(), lens)
+    (CTCLoss(reduction="sum")(out.transpose(0, 1), targets, out_lens, tsz) / B).backward()
+    acc = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    assert torch.allclose(acc, 2 * outs[0][2], rtol=1e-5, atol=1e-7)
     assert np.isfinite(outs[0][1]) and outs[0][1] > 0
     # the same utterances with EXTRA zero padding appended change nothing for frames < len except through
     # BatchNorm statistics (A.3) — so instead check the masking invariants directly on saved activations:
