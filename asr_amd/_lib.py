@@ -22,6 +22,7 @@ SIGNATURES = {
     "ds2_version": (C.c_char_p, []),
     "ds2_last_error": (C.c_char_p, []),
     "ds2_device_info": (i32, [C.POINTER(i32), C.POINTER(i32), C.c_char_p, i32]),
+    "ds2_debug_flags": (i32, [i32]),
     "ds2_gemm_f32_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "ds2_gemm_f32": (i32, [i32, i32, i32, i32, i32, vp, i32, i64, vp, i32, i64, vp, i32, i64, vp, i32, i32, i32, vp, sz, vp]),
     "ds2_colreduce_workspace_bytes": (sz, [i32, i32]),
@@ -45,8 +46,11 @@ SIGNATURES = {
     "ds2_conv_wgrad_workspace_bytes": (sz, [i32, i32, i32]),
     "ds2_conv1_wgrad_f32": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp]),
     "ds2_conv2_wgrad_f32": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp]),
-    "ds2_rnn_fwd_f32": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
-    "ds2_rnn_bwd_workspace_bytes": (sz, [i32, i32]),
+    "ds2_rnn_packed_floats": (sz, [i32, i32, i32]),
+    "ds2_rnn_pack_whh_f32": (i32, [i32, vp, vp, vp, i32, vp]),
+    "ds2_rnn_fwd_workspace_bytes": (sz, [i32, i32]),
+    "ds2_rnn_fwd_f32": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, sz, vp]),
+    "ds2_rnn_bwd_workspace_bytes": (sz, [i32, i32, i32]),
     "ds2_rnn_bwd_f32": (i32, [i32, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp, sz, vp]),
     "ds2_ctc_workspace_bytes": (sz, [i32, i32, i32]),
     "ds2_ctc_loss_f32": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, i32, f32, vp, sz, vp]),

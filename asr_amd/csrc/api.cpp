@@ -26,3 +26,8 @@ extern "C" int ds2_device_info(int* cu_count, int* wave_size, char* arch, int ar
   if (arch && arch_len > 0) snprintf(arch, arch_len, "%s", p.gcnArchName);
   return 0;
 }
+
+// Profiling/ablation switch (scripts/ablate_rnn.py only; 0 in production): bit0 = skip the h.W_hh GEMM,
+// bit1 = skip the gate epilogue, in the recurrent step kernels.
+int g_ds2_debug_flags = 0;
+extern "C" int ds2_debug_flags(int flags) { int old = g_ds2_debug_flags; g_ds2_debug_flags = flags; return old; }

@@ -4,106 +4,148 @@
 // The input projections X W_ih^T + b_ih for all t and both directions are one big MFMA GEMM
 // (gemm.hip); this file is the strictly sequential part.  One launch per time step and BOTH
 // directions per launch (dir 0 walks t = s, dir 1 walks t = T-1-s): a kernel boundary is the
-// cheapest all-to-all seam on MI355X (≈1.5 us, vs 4-7 us for an in-kernel grid barrier), and the
-// W_hh slices a block re-reads every step stay resident in its XCD's L2.
+// cheapest all-to-all seam on MI355X (measured launch floor 2.7 us/step; an in-kernel grid barrier
+// costs 4-7 us), and the W_hh slices a block re-reads every step stay in its XCD's L2.
 //
-// Step kernel = [h_{t-1} (BT x H) @ W_hh^T slice] on the f32 matrix cores (v_mfma_f32_16x16x4_f32,
-// operands loaded straight global/L2 -> VGPR as K-contiguous 16-byte fragments, K split over the
-// block's 4 waves, partial tiles reduced through LDS) fused with the gate non-linearities, the
-// per-sample length mask and the state write-back.  A block owns 16 hidden units x all gates x
-// BT batch rows of one direction.
+// Step kernel = [h_{t-1} (BT x H) @ W_hh^T slice] on the f32 matrix cores (v_mfma_f32_16x16x4_f32)
+// fused with the gate non-linearities, the per-sample length mask and the state write-back.
+// A block owns 16 hidden units x all gates x BT (16|32) batch rows of one direction; K is split over
+// the block's 8 waves and the partial tiles are reduced through LDS.
+//
+// FRAGMENT-MAJOR OPERANDS.  An MFMA 16x16x4 operand wants lane l to hold row (l & 15), k-quad (l >> 4):
+// loading that straight from a row-major matrix makes the 64 lanes of one instruction touch 64 different
+// 16-byte pieces of 16 rows — measured 12 B/clk/CU, the whole kernel's bound.  So both operands live in
+// memory *in fragment order*: one (16 rows x 16 k) chunk = 64 lanes x 16 B = ONE contiguous 1 KiB block,
+// and every wave-load is a perfectly coalesced `global_load_dwordx4` with no predication (zero padded):
+//   * W_hh (fwd) / W_hh^T (bwd) are re-packed once per optimizer step (ds2_rnn_pack_whh_f32);
+//   * h_t (fwd) and dGh_t (bwd) are written in packed form by the epilogue of the step that produces
+//     them (ping-pong buffer), next to the plain-layout copies the big GEMMs consume.
 //
 // Saved for backward (in place of the x-projections): activated gates; aux = W_hn h + b_hn (GRU)
 // or the cell state c (LSTM); h per direction.  Rows t >= len[b] hold zeros everywhere, which is
 // what makes the reverse direction start at each sample's own last frame.
 #include "common.h"
 
+extern int g_ds2_debug_flags;
+
 namespace {
+
+constexpr int NW = 8;          // waves per block
 
 struct RnnArgs {
   float* gx;          // (T,B,2,G*H)  fwd: in x-proj / out gates ; bwd: in gates / out d(pre-activations wrt x-proj)
   float* aux;         // (T,B,2,H)    GRU fwd: out hn ; GRU bwd: in hn / out d(hn) ; LSTM: cell state (read-only in bwd)
   float* hbuf;        // (T,B,2,H)    h per direction (fwd: out, bwd: in)
-  const float* w;     // fwd: W_hh (2, G*H, H) ; bwd: W_hh^T (2, H, G*H)
+  const float* wp;    // packed weights: fwd [2][nsl][G][nch][256] ; bwd [2][nsl][nchb][256]
   const float* bhh;   // (2, G*H) (fwd only)
   const float* dy;    // (T,B,H) grad wrt y = h_fwd + h_bwd (bwd only), row pitch lddy
+  float* pk;          // packed moving operand, ping-pong: [2 parity][2 dir][nbt16][nchK][256]  (h fwd / dGh bwd)
   float* dcar;        // (2 parity, 2 dir, B, H) bwd carry: GRU dh*z ; LSTM dc*f
   const int* lens;    // (B) valid output frames per sample
   int T, B, H, lddy;
+  int nsl, nbt16;     // hidden slices of 16 ; allocated 16-row batch tiles (multiple of MB)
+  int dbg;            // ablation flags (0 in production)
 };
 
-__device__ __forceinline__ f32x4 ldfrag(const float* __restrict__ p, int valid) {
-  f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  if (valid >= 4) {
-    v = *reinterpret_cast<const f32x4*>(p);
-  } else {
-    if (valid > 0) v.x = p[0];
-    if (valid > 1) v.y = p[1];
-    if (valid > 2) v.z = p[2];
-  }
-  return v;
+// element (row r, column k) of a packed [tiles][chunks][256] operand: tile = r/16, chunk = k/16,
+// lane = ((k%16)/4)*16 + r%16, component = k%4
+__device__ __forceinline__ long long packed_index(int r, int k, int nchunks) {
+  return (((long long)(r >> 4) * nchunks + (k >> 4)) * 64 + (((k & 15) >> 2) << 4) + (r & 15)) * 4 + (k & 3);
 }
 
-// D[mb][nb] (16x16 tiles) += A(16*MB rows x K) * B(16*NB rows x K)^T, both K-contiguous.
-// aptr(mb, k) / bptr(nb, k) return this lane's row pointer at column k, or nullptr for a zero row.
-// K is consumed in chunks of 16 (4 k-quads x float4), chunk c handled by wave (c & 3).
-template <int MB, int NB, class AP, class BP>
-__device__ __forceinline__ void mfma_rows_kcont(f32x4 (&acc)[MB][NB], int K, int wave, int kq, AP aptr, BP bptr) {
-  const int nch = (K + 15) / 16;
-  f32x4 a0[MB], b0[NB], a1[MB], b1[NB];
+// acc[i][j] += A-tile i (16 rows) x B-tile j (16 rows)^T over `nch` packed chunks.
+// pa + i*sa / pb + j*sb point at this lane's float4 of chunk 0; consecutive chunks are 256 floats apart.
+// Chunk c belongs to wave (c % NW); each wave keeps PF chunks of loads in flight.
+template <int MB, int NB, int PF>
+__device__ __forceinline__ void mfma_packed(f32x4 (&acc)[MB][NB], int nch, int wave, const float* __restrict__ pa, long long sa,
+                                            const float* __restrict__ pb, long long sb) {
+  f32x4 fa[PF][MB], fb[PF][NB];
   auto load = [&](f32x4(&a)[MB], f32x4(&b)[NB], int c) {
-    const int k = c * 16 + 4 * kq;
-    const int valid = (c < nch) ? (K - k) : 0;
+    if (c < nch) {   // wave-uniform
 #pragma unroll
-    for (int i = 0; i < MB; ++i) {
-      const float* p = aptr(i, k);
-      a[i] = ldfrag(p, p ? valid : 0);
+      for (int i = 0; i < MB; ++i) a[i] = *reinterpret_cast<const f32x4*>(pa + i * sa + (long long)c * 256);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) b[j] = *reinterpret_cast<const f32x4*>(pb + j * sb + (long long)c * 256);
     }
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      const float* p = bptr(j, k);
-      b[j] = ldfrag(p, p ? valid : 0);
-    }
-  };
-  auto mul = [&](const f32x4(&a)[MB], const f32x4(&b)[NB]) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-      for (int i = 0; i < MB; ++i)
-#pragma unroll
-        for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
   };
   int c = wave;
-  load(a0, b0, c);
-  load(a1, b1, c + 4);
-  for (; c < nch; c += 8) {
-    f32x4 ta[MB], tb[NB], ua[MB], ub[NB];
 #pragma unroll
-    for (int i = 0; i < MB; ++i) { ta[i] = a0[i]; ua[i] = a1[i]; }
+  for (int p = 0; p < PF; ++p) load(fa[p], fb[p], c + p * NW);
+  for (; c < nch; c += NW * PF) {
 #pragma unroll
-    for (int j = 0; j < NB; ++j) { tb[j] = b0[j]; ub[j] = b1[j]; }
-    load(a0, b0, c + 8);
-    load(a1, b1, c + 12);
-    mul(ta, tb);
-    mul(ua, ub);   // chunk c+4 (zeros if beyond K)
+    for (int p = 0; p < PF; ++p) {
+      f32x4 ta[MB], tb[NB];
+#pragma unroll
+      for (int i = 0; i < MB; ++i) ta[i] = fa[p][i];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) tb[j] = fb[p][j];
+      load(fa[p], fb[p], c + (p + PF) * NW);
+      if (c + p * NW < nch) {   // wave-uniform
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[i][e], tb[j][e], acc[i][j], 0, 0, 0);
+      }
+    }
   }
 }
 
 // ------------------------------------------------------------------------------------------
-// forward step
+// forward step.  grid = (nsl * nbt, 2 dirs), block = NW waves.
+// blockIdx.x = bt * nsl + slice: the batch tiles of one W_hh slice sit nsl blocks apart, i.e. on the
+// same XCD when nsl % 8 == 0, so each XCD's L2 holds every slice once.
 // ------------------------------------------------------------------------------------------
 template <int G, int MB>
-__global__ __launch_bounds__(256) void rnn_fwd_step_kernel(RnnArgs a, int s, int nbt) {
-  __shared__ __attribute__((aligned(16))) f32x4 red[4][MB * G][64];
+__global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(RnnArgs a, int s) {
+  __shared__ __attribute__((aligned(16))) f32x4 red[NW][MB * G][64];
+  constexpr int NTHR = NW * 64;
+  constexpr int PAIRS = (MB * 256 + NTHR - 1) / NTHR;   // (b, j) pairs per thread
   const int dir = blockIdx.y;
-  const int slice = blockIdx.x / nbt, bt = blockIdx.x % nbt;
+  const int nsl = a.nsl;
+  const int slice = blockIdx.x % nsl, bt = blockIdx.x / nsl;
   const int j0 = slice * 16, b0 = bt * (16 * MB);
   const int T = a.T, B = a.B, H = a.H;
+  const int nch = (H + 15) >> 4;
   const int t = dir == 0 ? s : T - 1 - s;
   const int tp = dir == 0 ? t - 1 : t + 1;
   const bool has_prev = s > 0;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r16 = lane & 15, kq = lane >> 4;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform
+  float* pk_out = a.pk + ((long long)((s & 1) * 2 + dir) * a.nbt16) * nch * 256;
+  const float* pk_in = a.pk + ((long long)(((s + 1) & 1) * 2 + dir) * a.nbt16) * nch * 256;
+
+  // ---- epilogue operands: issue their (HBM-latency) loads first, consume after the GEMM --------
+  float pgx[PAIRS][G], pb[PAIRS][G], pprev[PAIRS];
+  bool pact[PAIRS], pvalid[PAIRS];
+#pragma unroll
+  for (int i = 0; i < PAIRS; ++i) {
+    const int q = threadIdx.x + i * NTHR;
+    const int jl = q & 15, brow = (q >> 4) & 15, mb = q >> 8;
+    const int b = b0 + mb * 16 + brow, j = j0 + jl;
+    pact[i] = (mb < MB) && b < B && j < H;
+    pvalid[i] = false;
+    pprev[i] = 0.f;
+#pragma unroll
+    for (int g = 0; g < G; ++g) { pgx[i][g] = 0.f; pb[i][g] = 0.f; }
+    if (pact[i]) {
+      pvalid[i] = t < a.lens[b];
+      const long long row = ((long long)t * B + b) * 2 + dir;
+      if (pvalid[i]) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          pgx[i][g] = a.gx[row * G * H + g * H + j];
+          pb[i][g] = a.bhh[(dir * G + g) * H + j];
+        }
+        if (has_prev) {
+          const long long prow = ((long long)tp * B + b) * 2 + dir;
+          pprev[i] = (G == 3) ? a.hbuf[prow * H + j] : a.aux[prow * H + j];
+        }
+      }
+    }
+  }
 
   f32x4 acc[MB][G];
 #pragma unroll
@@ -111,185 +153,239 @@ __global__ __launch_bounds__(256) void rnn_fwd_step_kernel(RnnArgs a, int s, int
 #pragma unroll
     for (int g = 0; g < G; ++g) acc[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (has_prev) {
-    const float* hprev = a.hbuf + ((long long)tp * B * 2 + dir) * H;   // + b*2H
-    const float* w = a.w + (long long)dir * G * H * H;
-    auto aptr = [&](int mb, int k) -> const float* {
-      const int b = b0 + mb * 16 + r16;
-      return (b < B) ? hprev + (long long)b * 2 * H + k : nullptr;
-    };
-    auto bptr = [&](int g, int k) -> const float* {
-      const int j = j0 + r16;
-      return (j < H) ? w + ((long long)g * H + j) * H + k : nullptr;
-    };
-    mfma_rows_kcont<MB, G>(acc, H, wave, kq, aptr, bptr);
+  if (has_prev && !(a.dbg & 1)) {
+    const float* pa = pk_in + ((long long)(bt * MB) * nch) * 256 + lane * 4;                      // + mb*nch*256 + c*256
+    const float* pw = a.wp + ((((long long)dir * nsl + slice) * G) * nch) * 256 + lane * 4;         // + g*nch*256 + c*256
+    mfma_packed<MB, G, 4>(acc, nch, wave, pa, (long long)nch * 256, pw, (long long)nch * 256);
   }
 #pragma unroll
   for (int i = 0; i < MB; ++i)
 #pragma unroll
     for (int g = 0; g < G; ++g) red[wave][i * G + g][lane] = acc[i][g];
   __syncthreads();
+  if (a.dbg & 2) return;
 
-  // epilogue: MB*256 (b, j) pairs, consecutive threads -> consecutive j
 #pragma unroll
-  for (int i = 0; i < MB; ++i) {
-    const int q = threadIdx.x;
-    const int jl = q & 15, brow = q >> 4;
+  for (int i = 0; i < PAIRS; ++i) {
+    if (!pact[i]) continue;
+    const int q = threadIdx.x + i * NTHR;
+    const int jl = q & 15, brow = (q >> 4) & 15, mb = q >> 8;
     const int src_lane = (brow >> 2) * 16 + jl, reg = brow & 3;
-    const int b = b0 + i * 16 + brow, j = j0 + jl;
-    if (b >= B || j >= H) continue;
-    float gh[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      const int tile = i * G + g;
-      gh[g] = red[0][tile][src_lane][reg] + red[1][tile][src_lane][reg] + red[2][tile][src_lane][reg] +
-              red[3][tile][src_lane][reg] + a.bhh[(dir * G + g) * H + j];
-    }
-    const bool valid = t < a.lens[b];
+    const int b = b0 + mb * 16 + brow, j = j0 + jl;
     const long long row = ((long long)t * B + b) * 2 + dir;
     float* gx = a.gx + row * G * H + j;
     float* ho = a.hbuf + row * H + j;
     float* ax = a.aux + row * H + j;
-    if (!valid) {
+    float* hp = pk_out + packed_index(b, j, nch);
+    if (!pvalid[i]) {
 #pragma unroll
       for (int g = 0; g < G; ++g) gx[g * H] = 0.f;
       *ho = 0.f;
       *ax = 0.f;
+      *hp = 0.f;
       continue;
     }
-    const long long prow = ((long long)tp * B + b) * 2 + dir;
+    float gh[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      float sum = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) sum += red[w][mb * G + g][src_lane][reg];
+      gh[g] = sum + pb[i][g];
+    }
+    float hnew;
     if constexpr (G == 3) {
-      const float hp = has_prev ? a.hbuf[prow * H + j] : 0.f;
-      const float r = sigmoidf_(gx[0] + gh[0]);
-      const float z = sigmoidf_(gx[H] + gh[1]);
-      const float n = tanhf(gx[2 * H] + r * gh[2]);
+      const float r = sigmoidf_(pgx[i][0] + gh[0]);
+      const float z = sigmoidf_(pgx[i][1] + gh[1]);
+      const float n = tanhf(pgx[i][2] + r * gh[2]);
       gx[0] = r; gx[H] = z; gx[2 * H] = n;
       *ax = gh[2];
-      *ho = (1.f - z) * n + z * hp;
+      hnew = (1.f - z) * n + z * pprev[i];
     } else {
-      const float cp = has_prev ? a.aux[prow * H + j] : 0.f;
-      const float ig = sigmoidf_(gx[0] + gh[0]);
-      const float fg = sigmoidf_(gx[H] + gh[1]);
-      const float gg = tanhf(gx[2 * H] + gh[2]);
-      const float og = sigmoidf_(gx[3 * H] + gh[G - 1]);
-      const float c = fg * cp + ig * gg;
-      gx[0] = ig; gx[H] = fg; gx[2 * H] = gg; gx[3 * H] = og;
+      const float ig = sigmoidf_(pgx[i][0] + gh[0]);
+      const float fg = sigmoidf_(pgx[i][1] + gh[1]);
+      const float gg = tanhf(pgx[i][2] + gh[2]);
+      const float og = sigmoidf_(pgx[i][G - 1] + gh[G - 1]);
+      const float c = fg * pprev[i] + ig * gg;
+      gx[0] = ig; gx[H] = fg; gx[2 * H] = gg; gx[(G - 1) * H] = og;
       *ax = c;
-      *ho = og * tanhf(c);
+      hnew = og * tanhf(c);
     }
+    *ho = hnew;
+    *hp = hnew;
   }
 }
 
 // ------------------------------------------------------------------------------------------
-// backward step
+// backward step (same grid mapping).  carry[b][j] = sum_k dGh[tq][b][k] * W_hh[k][j]
 // ------------------------------------------------------------------------------------------
 template <int G, int MB>
-__global__ __launch_bounds__(256) void rnn_bwd_step_kernel(RnnArgs a, int s, int nbt) {
-  __shared__ __attribute__((aligned(16))) f32x4 red[4][MB][64];
+__global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(RnnArgs a, int s) {
+  __shared__ __attribute__((aligned(16))) f32x4 red[NW][MB][64];
+  constexpr int NTHR = NW * 64;
+  constexpr int PAIRS = (MB * 256 + NTHR - 1) / NTHR;
   const int dir = blockIdx.y;
-  const int slice = blockIdx.x / nbt, bt = blockIdx.x % nbt;
+  const int nsl = a.nsl;
+  const int slice = blockIdx.x % nsl, bt = blockIdx.x / nsl;
   const int j0 = slice * 16, b0 = bt * (16 * MB);
   const int T = a.T, B = a.B, H = a.H;
+  const int nchb = (G * H + 15) >> 4;
   const int t = dir == 0 ? T - 1 - s : s;          // reverse of the forward order
-  const int tq = dir == 0 ? t + 1 : t - 1;         // step processed just before (its d-gates feed our carry)
   const int tpf = dir == 0 ? t - 1 : t + 1;        // previous step in FORWARD order (h_{prev}, c_{prev})
-  const bool has_q = s > 0;
+  const bool has_q = s > 0;                        // a step was processed before us: its d-gates feed our carry
   const bool has_pf = dir == 0 ? (t > 0) : (t < T - 1);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r16 = lane & 15, kq = lane >> 4;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const float* dcar_in = a.dcar + ((long long)(((s + 1) & 1) * 2 + dir)) * B * H;
+  float* dcar_out = a.dcar + ((long long)((s & 1) * 2 + dir)) * B * H;
+  float* pk_out = a.pk + ((long long)((s & 1) * 2 + dir) * a.nbt16) * nchb * 256;
+  const float* pk_in = a.pk + ((long long)(((s + 1) & 1) * 2 + dir) * a.nbt16) * nchb * 256;
+
+  // ---- epilogue operands first ----------------------------------------------------------------
+  float pg[PAIRS][G], pax[PAIRS], pprev[PAIRS], pdy[PAIRS], pdc[PAIRS];
+  bool pact[PAIRS], pvalid[PAIRS];
+#pragma unroll
+  for (int i = 0; i < PAIRS; ++i) {
+    const int q = threadIdx.x + i * NTHR;
+    const int jl = q & 15, brow = (q >> 4) & 15, mb = q >> 8;
+    const int b = b0 + mb * 16 + brow, j = j0 + jl;
+    pact[i] = (mb < MB) && b < B && j < H;
+    pvalid[i] = false;
+    pax[i] = pprev[i] = pdy[i] = pdc[i] = 0.f;
+#pragma unroll
+    for (int g = 0; g < G; ++g) pg[i][g] = 0.f;
+    if (pact[i]) {
+      pvalid[i] = t < a.lens[b];
+      if (pvalid[i]) {
+        const long long row = ((long long)t * B + b) * 2 + dir;
+#pragma unroll
+        for (int g = 0; g < G; ++g) pg[i][g] = a.gx[row * G * H + g * H + j];
+        pax[i] = a.aux[row * H + j];
+        pdy[i] = a.dy[((long long)t * B + b) * a.lddy + j];
+        if (has_q) pdc[i] = dcar_in[(long long)b * H + j];
+        if (has_pf) {
+          const long long prow = ((long long)tpf * B + b) * 2 + dir;
+          pprev[i] = (G == 3) ? a.hbuf[prow * H + j] : a.aux[prow * H + j];
+        }
+      }
+    }
+  }
 
   f32x4 acc[MB][1];
 #pragma unroll
   for (int i = 0; i < MB; ++i) acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (has_q) {
-    const float* dg = a.gx + ((long long)tq * B * 2 + dir) * G * H;     // + b*2*G*H
-    const float* dn = a.aux + ((long long)tq * B * 2 + dir) * H;        // + b*2*H   (GRU d(hn))
-    const float* wt = a.w + (long long)dir * H * G * H;
-    auto aptr = [&](int mb, int k) -> const float* {
-      const int b = b0 + mb * 16 + r16;
-      if (b >= B) return nullptr;
-      if (G == 3 && k >= 2 * H) return dn + (long long)b * 2 * H + (k - 2 * H);
-      return dg + (long long)b * 2 * G * H + k;
-    };
-    auto bptr = [&](int, int k) -> const float* {
-      const int j = j0 + r16;
-      return (j < H) ? wt + (long long)j * G * H + k : nullptr;
-    };
-    mfma_rows_kcont<MB, 1>(acc, G * H, wave, kq, aptr, bptr);
+  if (has_q && !(a.dbg & 1)) {
+    const float* pa = pk_in + ((long long)(bt * MB) * nchb) * 256 + lane * 4;
+    const float* pw = a.wp + (((long long)dir * nsl + slice) * nchb) * 256 + lane * 4;
+    mfma_packed<MB, 1, 6>(acc, nchb, wave, pa, (long long)nchb * 256, pw, 0);
   }
 #pragma unroll
   for (int i = 0; i < MB; ++i) red[wave][i][lane] = acc[i][0];
   __syncthreads();
+  if (a.dbg & 2) return;
 
-  const float* dcar_in = a.dcar + ((long long)(((s + 1) & 1) * 2 + dir)) * B * H;
-  float* dcar_out = a.dcar + ((long long)((s & 1) * 2 + dir)) * B * H;
 #pragma unroll
-  for (int i = 0; i < MB; ++i) {
-    const int q = threadIdx.x;
-    const int jl = q & 15, brow = q >> 4;
+  for (int i = 0; i < PAIRS; ++i) {
+    if (!pact[i]) continue;
+    const int q = threadIdx.x + i * NTHR;
+    const int jl = q & 15, brow = (q >> 4) & 15, mb = q >> 8;
     const int src_lane = (brow >> 2) * 16 + jl, reg = brow & 3;
-    const int b = b0 + i * 16 + brow, j = j0 + jl;
-    if (b >= B || j >= H) continue;
-    const float carry = red[0][i][src_lane][reg] + red[1][i][src_lane][reg] + red[2][i][src_lane][reg] + red[3][i][src_lane][reg];
-    const bool valid = t < a.lens[b];
+    const int b = b0 + mb * 16 + brow, j = j0 + jl;
     const long long row = ((long long)t * B + b) * 2 + dir;
     float* gx = a.gx + row * G * H + j;
     float* ax = a.aux + row * H + j;
     float* dco = dcar_out + (long long)b * H + j;
-    if (!valid) {
+    float dgh[G];
+    if (!pvalid[i]) {
 #pragma unroll
-      for (int g = 0; g < G; ++g) gx[g * H] = 0.f;
+      for (int g = 0; g < G; ++g) { gx[g * H] = 0.f; dgh[g] = 0.f; }
       if (G == 3) *ax = 0.f;
       *dco = 0.f;
-      continue;
-    }
-    const float dci = has_q ? dcar_in[(long long)b * H + j] : 0.f;
-    const float dyv = a.dy[((long long)t * B + b) * a.lddy + j];
-    const long long prow = ((long long)tpf * B + b) * 2 + dir;
-    if constexpr (G == 3) {
-      const float dh = dyv + carry + dci;
-      const float hp = has_pf ? a.hbuf[prow * H + j] : 0.f;
-      const float r = gx[0], z = gx[H], n = gx[2 * H], hn = *ax;
-      const float dn = dh * (1.f - z);
-      const float dz = dh * (hp - n);
-      const float dpn = dn * (1.f - n * n);
-      const float dr = dpn * hn;
-      gx[0] = dr * r * (1.f - r);
-      gx[H] = dz * z * (1.f - z);
-      gx[2 * H] = dpn;
-      *ax = dpn * r;
-      *dco = dh * z;
     } else {
-      const float dh = dyv + carry;
-      const float ig = gx[0], fg = gx[H], gg = gx[2 * H], og = gx[3 * H];
-      const float c = *ax;
-      const float cp = has_pf ? a.aux[prow * H + j] : 0.f;
-      const float tc = tanhf(c);
-      const float dc = dci + dh * og * (1.f - tc * tc);
-      gx[0] = dc * gg * ig * (1.f - ig);
-      gx[H] = dc * cp * fg * (1.f - fg);
-      gx[2 * H] = dc * ig * (1.f - gg * gg);
-      gx[3 * H] = dh * tc * og * (1.f - og);
-      *dco = dc * fg;
+      float carry = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) carry += red[w][mb][src_lane][reg];
+      if constexpr (G == 3) {
+        const float dh = pdy[i] + carry + pdc[i];
+        const float r = pg[i][0], z = pg[i][1], n = pg[i][2], hn = pax[i];
+        const float dn_ = dh * (1.f - z);
+        const float dz = dh * (pprev[i] - n);
+        const float dpn = dn_ * (1.f - n * n);
+        const float dr = dpn * hn;
+        dgh[0] = dr * r * (1.f - r);
+        dgh[1] = dz * z * (1.f - z);
+        dgh[2] = dpn * r;                  // d(hn): the n-gate row of dGh
+        gx[0] = dgh[0]; gx[H] = dgh[1]; gx[2 * H] = dpn;
+        *ax = dgh[2];
+        *dco = dh * z;
+      } else {
+        const float dh = pdy[i] + carry;
+        const float ig = pg[i][0], fg = pg[i][1], gg = pg[i][2], og = pg[i][G - 1];
+        const float c = pax[i];
+        const float tc = tanhf(c);
+        const float dc = pdc[i] + dh * og * (1.f - tc * tc);
+        dgh[0] = dc * gg * ig * (1.f - ig);
+        dgh[1] = dc * pprev[i] * fg * (1.f - fg);
+        dgh[2] = dc * ig * (1.f - gg * gg);
+        dgh[G - 1] = dh * tc * og * (1.f - og);
+#pragma unroll
+        for (int g = 0; g < G; ++g) gx[g * H] = dgh[g];
+        *dco = dc * fg;
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) pk_out[packed_index(b, g * H + j, nchb)] = dgh[g];
+  }
+}
+
+// W_hh (2, G*H, H) -> fwd-packed [2][nsl][G][nch][64][4] and bwd-packed [2][nsl][nchb][64][4]
+__global__ void rnn_pack_kernel(const float* __restrict__ whh, float* __restrict__ wpf, float* __restrict__ wpb, int G, int H) {
+  const int nsl = (H + 15) >> 4, nch = (H + 15) >> 4, nchb = (G * H + 15) >> 4;
+  const long long nf = (long long)2 * nsl * G * nch * 256, nb = (long long)2 * nsl * nchb * 256;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nf + nb; i += stride) {
+    if (i < nf) {
+      const int e = i & 3, lane = (i >> 2) & 63;
+      long long r = i >> 8;
+      const int c = r % nch; r /= nch;
+      const int g = r % G; r /= G;
+      const int slice = r % nsl, dir = r / nsl;
+      const int j = slice * 16 + (lane & 15), k = c * 16 + (lane >> 4) * 4 + e;
+      wpf[i] = (j < H && k < H) ? whh[((long long)dir * G * H + g * H + j) * H + k] : 0.f;
+    } else {
+      const long long ii = i - nf;
+      const int e = ii & 3, lane = (ii >> 2) & 63;
+      long long r = ii >> 8;
+      const int c = r % nchb; r /= nchb;
+      const int slice = r % nsl, dir = r / nsl;
+      const int j = slice * 16 + (lane & 15), k = c * 16 + (lane >> 4) * 4 + e;   // k = gate-unit row of W_hh
+      wpb[ii] = (j < H && k < G * H) ? whh[((long long)dir * G * H + k) * H + j] : 0.f;
     }
   }
 }
 
+inline int pick_mb(int B, int H) {
+  const int nsl = ceil_div(H, 16);
+  // 32-row batch tiles halve the W_hh re-reads; use them when that still fills the chip
+  return (B > 16 && (long long)nsl * ceil_div(B, 32) * 2 >= 200) ? 2 : 1;
+}
+
 template <int G>
 int launch_steps(bool bwd, RnnArgs a, hipStream_t st) {
-  const int nsl = ceil_div(a.H, 16);
-  // 32-row batch tiles halve the W_hh re-reads; use them when that still fills the chip
-  int mb = (a.B > 16 && (long long)nsl * ceil_div(a.B, 32) * 2 >= 200) ? 2 : 1;
+  a.dbg = g_ds2_debug_flags;
+  const int mb = pick_mb(a.B, a.H);
   const int nbt = ceil_div(a.B, 16 * mb);
-  dim3 grid(nsl * nbt, 2), block(256);
+  a.nsl = ceil_div(a.H, 16);
+  a.nbt16 = nbt * mb;
+  dim3 grid(a.nsl * nbt, 2), block(NW * 64);
   for (int s = 0; s < a.T; ++s) {
     if (!bwd) {
-      if (mb == 2) hipLaunchKernelGGL((rnn_fwd_step_kernel<G, 2>), grid, block, 0, st, a, s, nbt);
-      else hipLaunchKernelGGL((rnn_fwd_step_kernel<G, 1>), grid, block, 0, st, a, s, nbt);
+      if (mb == 2) hipLaunchKernelGGL((rnn_fwd_step_kernel<G, 2>), grid, block, 0, st, a, s);
+      else hipLaunchKernelGGL((rnn_fwd_step_kernel<G, 1>), grid, block, 0, st, a, s);
     } else {
-      if (mb == 2) hipLaunchKernelGGL((rnn_bwd_step_kernel<G, 2>), grid, block, 0, st, a, s, nbt);
-      else hipLaunchKernelGGL((rnn_bwd_step_kernel<G, 1>), grid, block, 0, st, a, s, nbt);
+      if (mb == 2) hipLaunchKernelGGL((rnn_bwd_step_kernel<G, 2>), grid, block, 0, st, a, s);
+      else hipLaunchKernelGGL((rnn_bwd_step_kernel<G, 1>), grid, block, 0, st, a, s);
     }
   }
   hipError_t e = hipGetLastError();
@@ -297,37 +393,67 @@ int launch_steps(bool bwd, RnnArgs a, hipStream_t st) {
   return 0;
 }
 
+size_t pk_floats(int B, int H, int kdim) {
+  const int mb = pick_mb(B, H);
+  const int nbt16 = ceil_div(B, 16 * mb) * mb;
+  return (size_t)2 * 2 * nbt16 * ceil_div(kdim, 16) * 256;
+}
+
 }  // namespace
 
+// packed-weight sizes in floats: which = 0 forward operand, 1 backward operand
+extern "C" size_t ds2_rnn_packed_floats(int gates, int H, int which) {
+  const size_t nsl = (size_t)ceil_div(H, 16);
+  return which == 0 ? 2 * nsl * gates * ceil_div(H, 16) * 256 : 2 * nsl * ceil_div(gates * H, 16) * 256;
+}
+
+// Re-pack W_hh = [weight_hh_l0 ; weight_hh_l0_reverse] (2, G*H, H) into MFMA-fragment order (call after every
+// optimizer step / load_state_dict).  wp_fwd feeds ds2_rnn_fwd_f32, wp_bwd feeds ds2_rnn_bwd_f32.
+extern "C" int ds2_rnn_pack_whh_f32(int gates, const float* whh, float* wp_fwd, float* wp_bwd, int H, void* stream) {
+  DS2_REQUIRE(gates == 3 || gates == 4, "ds2_rnn_pack_whh_f32: gates must be 3 or 4");
+  DS2_REQUIRE(whh && wp_fwd && wp_bwd && H > 0 && (H % 4) == 0, "ds2_rnn_pack_whh_f32: bad args");
+  hipLaunchKernelGGL(rnn_pack_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, whh, wp_fwd, wp_bwd, gates, H);
+  DS2_LAUNCH_CHECK("rnn_pack_kernel");
+  return 0;
+}
+
+extern "C" size_t ds2_rnn_fwd_workspace_bytes(int B, int H) { return pk_floats(B, H, H) * sizeof(float); }
+
 // gates: 3 = GRU (r,z,n), 4 = LSTM (i,f,g,o).
-//   gx   (T,B,2,G*H)  in: X W_ih^T + b_ih for [fwd | reverse] ; out: activated gates (saved for backward)
-//   whh  (2,G*H,H), bhh (2,G*H)     [weight_hh_l0, weight_hh_l0_reverse], [bias_hh_l0, bias_hh_l0_reverse]
-//   hbuf (T,B,2,H) out: h per direction (0 beyond each sample's length)
-//   aux  (T,B,2,H) out: GRU W_hn h + b_hn ; LSTM cell state
-extern "C" int ds2_rnn_fwd_f32(int gates, float* gx, const float* whh, const float* bhh, float* hbuf, float* aux,
-                               const int* lens_dev, int T, int B, int H, void* stream) {
+//   gx     (T,B,2,G*H)  in: X W_ih^T + b_ih for [fwd | reverse] ; out: activated gates (saved for backward)
+//   wp_fwd packed W_hh (ds2_rnn_pack_whh_f32), bhh (2,G*H) = [bias_hh_l0, bias_hh_l0_reverse]
+//   hbuf   (T,B,2,H) out: h per direction (0 beyond each sample's length)
+//   aux    (T,B,2,H) out: GRU W_hn h + b_hn ; LSTM cell state
+extern "C" int ds2_rnn_fwd_f32(int gates, float* gx, const float* wp_fwd, const float* bhh, float* hbuf, float* aux,
+                               const int* lens_dev, int T, int B, int H, void* ws, size_t ws_bytes, void* stream) {
   DS2_REQUIRE(gates == 3 || gates == 4, "ds2_rnn_fwd_f32: gates must be 3 (GRU) or 4 (LSTM)");
-  DS2_REQUIRE(gx && whh && bhh && hbuf && aux && lens_dev, "ds2_rnn_fwd_f32: null pointer");
+  DS2_REQUIRE(gx && wp_fwd && bhh && hbuf && aux && lens_dev, "ds2_rnn_fwd_f32: null pointer");
   DS2_REQUIRE(T > 0 && B > 0 && H > 0 && (H % 4) == 0, "ds2_rnn_fwd_f32: need H %% 4 == 0 (H=%d)", H);
+  DS2_REQUIRE(ws && ws_bytes >= ds2_rnn_fwd_workspace_bytes(B, H), "ds2_rnn_fwd_f32: workspace too small");
+  DS2_HIP(hipMemsetAsync(ws, 0, ds2_rnn_fwd_workspace_bytes(B, H), (hipStream_t)stream));   // zero padding rows / columns
   RnnArgs a{};
-  a.gx = gx; a.aux = aux; a.hbuf = hbuf; a.w = whh; a.bhh = bhh; a.lens = lens_dev; a.T = T; a.B = B; a.H = H;
+  a.gx = gx; a.aux = aux; a.hbuf = hbuf; a.wp = wp_fwd; a.bhh = bhh; a.pk = (float*)ws; a.lens = lens_dev; a.T = T; a.B = B; a.H = H;
   return gates == 3 ? launch_steps<3>(false, a, (hipStream_t)stream) : launch_steps<4>(false, a, (hipStream_t)stream);
 }
 
-extern "C" size_t ds2_rnn_bwd_workspace_bytes(int B, int H) { return (size_t)4 * B * H * sizeof(float); }
+extern "C" size_t ds2_rnn_bwd_workspace_bytes(int gates, int B, int H) {
+  return ((size_t)4 * B * H + pk_floats(B, H, gates * H)) * sizeof(float);
+}
 
-//   dy    (T,B,H) pitch lddy: grad wrt y = h_fwd + h_bwd
-//   gx    in: gates from fwd ; out: grad wrt the x-projections (T,B,2,G*H)  (= dGx, feeds dW_ih, db_ih, dX)
-//   aux   GRU: in hn, out d(hn) [so that dGh = (dGx_r, dGx_z, aux)] ; LSTM: cell state (unchanged; dGh = dGx)
-//   whhT  (2,H,G*H): per-direction transpose of W_hh
-extern "C" int ds2_rnn_bwd_f32(int gates, const float* dy, int lddy, float* gx, float* aux, const float* hbuf, const float* whhT,
+//   dy     (T,B,H) pitch lddy: grad wrt y = h_fwd + h_bwd
+//   gx     in: gates from fwd ; out: grad wrt the x-projections (T,B,2,G*H)  (= dGx, feeds dW_ih, db_ih, dX)
+//   aux    GRU: in hn, out d(hn) [so that dGh = (dGx_r, dGx_z, aux)] ; LSTM: cell state (unchanged; dGh = dGx)
+//   wp_bwd packed W_hh^T (ds2_rnn_pack_whh_f32)
+extern "C" int ds2_rnn_bwd_f32(int gates, const float* dy, int lddy, float* gx, float* aux, const float* hbuf, const float* wp_bwd,
                                const int* lens_dev, int T, int B, int H, void* ws, size_t ws_bytes, void* stream) {
   DS2_REQUIRE(gates == 3 || gates == 4, "ds2_rnn_bwd_f32: gates must be 3 (GRU) or 4 (LSTM)");
-  DS2_REQUIRE(dy && gx && aux && hbuf && whhT && lens_dev, "ds2_rnn_bwd_f32: null pointer");
+  DS2_REQUIRE(dy && gx && aux && hbuf && wp_bwd && lens_dev, "ds2_rnn_bwd_f32: null pointer");
   DS2_REQUIRE(T > 0 && B > 0 && H > 0 && (H % 4) == 0, "ds2_rnn_bwd_f32: need H %% 4 == 0 (H=%d)", H);
-  DS2_REQUIRE(ws && ws_bytes >= ds2_rnn_bwd_workspace_bytes(B, H), "ds2_rnn_bwd_f32: workspace too small");
+  DS2_REQUIRE(ws && ws_bytes >= ds2_rnn_bwd_workspace_bytes(gates, B, H), "ds2_rnn_bwd_f32: workspace too small");
+  DS2_HIP(hipMemsetAsync(ws, 0, ds2_rnn_bwd_workspace_bytes(gates, B, H), (hipStream_t)stream));
   RnnArgs a{};
-  a.gx = gx; a.aux = aux; a.hbuf = const_cast<float*>(hbuf); a.w = whhT; a.dy = dy; a.lddy = lddy; a.dcar = (float*)ws;
+  a.gx = gx; a.aux = aux; a.hbuf = const_cast<float*>(hbuf); a.wp = wp_bwd; a.dy = dy; a.lddy = lddy;
+  a.dcar = (float*)ws; a.pk = (float*)ws + (size_t)4 * B * H;
   a.lens = lens_dev; a.T = T; a.B = B; a.H = H;
   return gates == 3 ? launch_steps<3>(true, a, (hipStream_t)stream) : launch_steps<4>(true, a, (hipStream_t)stream);
 }

@@ -44,6 +44,7 @@ class LayerCtx:
     aux: Optional[Tensor] = None     # (M, 2H)
     mean: Optional[Tensor] = None    # BN batch stats of this layer's INPUT (layers >= 1)
     var: Optional[Tensor] = None
+    wpb: Optional[Tensor] = None     # W_hh^T in fragment order for the backward recurrence
 
 
 @dataclass
@@ -115,7 +116,9 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
         else:
             xn = xin
         gx = ops.gemm(xn, W[f"rnns.{l}.wih_cat"], transB=True, bias=W[f"rnns.{l}.bih_cat"])      # (M, 2GH)
-        hbuf, aux = ops.rnn_fwd(G, gx, W[f"rnns.{l}.whh_cat"], W[f"rnns.{l}.bhh_cat"], lens_dev, T, B, H)
+        wpf, wpb = ops.rnn_pack(G, W[f"rnns.{l}.whh_cat"])
+        hbuf, aux = ops.rnn_fwd(G, gx, wpf, W[f"rnns.{l}.bhh_cat"], lens_dev, T, B, H)
+        lc.wpb = wpb
         nxt = f"rnns.{l + 1}.batch_norm.module" if l + 1 < L else "fc.0.module.0"
         y, mean, var = ops.add_colstats(hbuf[:, :H], hbuf[:, H:], *run(nxt))
         if save:
@@ -161,8 +164,7 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
     for l in range(L - 1, -1, -1):
         lc = ctx.layers[l]
         I = lc.xn.shape[1]
-        whhT = ops.transpose_batched(W[f"rnns.{l}.whh_cat"])                                      # (2, H, GH)
-        ops.rnn_bwd(G, dy, lc.gx, lc.aux, lc.hbuf, whhT, lens_dev, T, B, H)
+        ops.rnn_bwd(G, dy, lc.gx, lc.aux, lc.hbuf, lc.wpb, lens_dev, T, B, H)
         dgx = lc.gx                                                                               # now dGx (M, 2GH)
         # bias grads
         dbih = Gr[f"rnns.{l}.bih_cat"]
@@ -193,7 +195,7 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
         # dW_ih (2GH, I) = dGx^T Xn ;  dXn = dGx W_ih
         ops.gemm(dgx, lc.xn, transA=True, out=Gr[f"rnns.{l}.wih_cat"])
         dxn = ops.gemm(dgx, W[f"rnns.{l}.wih_cat"])                                               # (M, I)
-        lc.gx = lc.aux = lc.hbuf = lc.xn = None
+        lc.gx = lc.aux = lc.hbuf = lc.xn = lc.wpb = None
         if l > 0:
             bp = f"rnns.{l}.batch_norm.module."
             dy = ops.bn1d_bwd(dxn, lc.xin, lc.mean, lc.var, W[bp + "weight"], Gr[bp + "weight"], Gr[bp + "bias"])

@@ -100,7 +100,8 @@ class BatchRNN(nn.Module):
         whh = torch.stack([r.weight_hh_l0.detach(), r.weight_hh_l0_reverse.detach()], 0).contiguous()
         bhh = torch.stack([r.bias_hh_l0.detach(), r.bias_hh_l0_reverse.detach()], 0).contiguous()
         gx = ops.gemm(flat, wih, transB=True, bias=bih)
-        hbuf, _ = ops.rnn_fwd(gates, gx, whh, bhh, lens_dev, T, N, H)
+        wpf, _ = ops.rnn_pack(gates, whh)
+        hbuf, _ = ops.rnn_fwd(gates, gx, wpf, bhh, lens_dev, T, N, H)
         y, _, _ = ops.add_colstats(hbuf[:, :H], hbuf[:, H:])
         return y.view(T, N, H)
 

@@ -56,7 +56,9 @@ def gemm_raw(transA: bool, transB: bool, M: int, N: int, K: int, A_ptr: int, lda
     if splitk <= 0:
         tiles = ((M + 127) // 128) * ((N + 127) // 128) * batch
         splitk = 1
-        if tiles < 128 and K >= 1024:
+        if tiles < 400 and K >= 2048:      # under-filled grid with a long reduction: aim at >= 2 blocks per CU
+            splitk = max(1, min((512 + tiles - 1) // tiles, K // 1024))
+        elif tiles < 128 and K >= 1024:
             splitk = max(1, min((384 + tiles - 1) // tiles, K // 256))
     ws = None
     wsb = 0
@@ -282,23 +284,38 @@ def conv2_wgrad(a1: Tensor, dy2: Tensor, lens_dev: Tensor, dW2: Tensor):
 # ------------------------------------------------------------------------------------------------
 # recurrence
 # ------------------------------------------------------------------------------------------------
-def rnn_fwd(gates: int, gx: Tensor, whh: Tensor, bhh: Tensor, lens_dev: Tensor, T: int, B: int, H: int):
+def rnn_pack(gates: int, whh: Tensor):
+    """W_hh (2, G*H, H) -> (wp_fwd, wp_bwd) in MFMA-fragment order (see csrc/rnn.hip)."""
+    _chk_f32(whh)
+    assert whh.is_contiguous() and whh.dim() == 3
+    lib = _lib.load()
+    H = whh.size(2)
+    wpf = torch.empty(lib.ds2_rnn_packed_floats(gates, H, 0), dtype=torch.float32, device=whh.device)
+    wpb = torch.empty(lib.ds2_rnn_packed_floats(gates, H, 1), dtype=torch.float32, device=whh.device)
+    _lib.check(lib.ds2_rnn_pack_whh_f32(gates, whh.data_ptr(), wpf.data_ptr(), wpb.data_ptr(), H, _stream()), "ds2_rnn_pack_whh_f32")
+    return wpf, wpb
+
+
+def rnn_fwd(gates: int, gx: Tensor, wp_fwd: Tensor, bhh: Tensor, lens_dev: Tensor, T: int, B: int, H: int):
     """gx (T*B, 2*G*H) in/out; returns (hbuf (T*B, 2H), aux (T*B, 2H))."""
-    _chk_f32(gx, whh, bhh)
-    assert gx.is_contiguous() and whh.is_contiguous() and bhh.is_contiguous()
+    _chk_f32(gx, wp_fwd, bhh)
+    assert gx.is_contiguous() and bhh.is_contiguous()
+    lib = _lib.load()
     hbuf = torch.empty(T * B, 2 * H, dtype=torch.float32, device=gx.device)
     aux = torch.empty_like(hbuf)
-    _lib.check(_lib.load().ds2_rnn_fwd_f32(gates, gx.data_ptr(), whh.data_ptr(), bhh.data_ptr(), hbuf.data_ptr(), aux.data_ptr(),
-                                           lens_dev.data_ptr(), T, B, H, _stream()), "ds2_rnn_fwd_f32")
+    wsb = lib.ds2_rnn_fwd_workspace_bytes(B, H)
+    ws = _ws(wsb, gx.device)
+    _lib.check(lib.ds2_rnn_fwd_f32(gates, gx.data_ptr(), wp_fwd.data_ptr(), bhh.data_ptr(), hbuf.data_ptr(), aux.data_ptr(),
+                                   lens_dev.data_ptr(), T, B, H, ws.data_ptr(), wsb, _stream()), "ds2_rnn_fwd_f32")
     return hbuf, aux
 
 
-def rnn_bwd(gates: int, dy: Tensor, gx: Tensor, aux: Tensor, hbuf: Tensor, whhT: Tensor, lens_dev: Tensor, T: int, B: int, H: int):
-    _chk_f32(dy, gx, aux, hbuf, whhT)
+def rnn_bwd(gates: int, dy: Tensor, gx: Tensor, aux: Tensor, hbuf: Tensor, wp_bwd: Tensor, lens_dev: Tensor, T: int, B: int, H: int):
+    _chk_f32(dy, gx, aux, hbuf, wp_bwd)
     lib = _lib.load()
-    wsb = lib.ds2_rnn_bwd_workspace_bytes(B, H)
+    wsb = lib.ds2_rnn_bwd_workspace_bytes(gates, B, H)
     ws = _ws(wsb, gx.device)
-    _lib.check(lib.ds2_rnn_bwd_f32(gates, dy.data_ptr(), _row_pitch(dy), gx.data_ptr(), aux.data_ptr(), hbuf.data_ptr(), whhT.data_ptr(),
+    _lib.check(lib.ds2_rnn_bwd_f32(gates, dy.data_ptr(), _row_pitch(dy), gx.data_ptr(), aux.data_ptr(), hbuf.data_ptr(), wp_bwd.data_ptr(),
                                    lens_dev.data_ptr(), T, B, H, ws.data_ptr(), wsb, _stream()), "ds2_rnn_bwd_f32")
 
 

@@ -173,12 +173,13 @@ def main():
     whh = (torch.rand(2, G * H, H, device=dev) * 2 - 1) / H ** 0.5
     bhh = torch.zeros(2, G * H, device=dev)
     lens = torch.full((B,), T, dtype=torch.int32, device=dev)
-    ops.rnn_fwd(G, gx.clone(), whh, bhh, lens, T, B, H)
+    wpf, _ = ops.rnn_pack(G, whh)
+    ops.rnn_fwd(G, gx.clone(), wpf, bhh, lens, T, B, H)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     gx2 = gx.clone()
     torch.cuda.synchronize()
     e0.record()
-    ops.rnn_fwd(G, gx2, whh, bhh, lens, T, B, H)
+    ops.rnn_fwd(G, gx2, wpf, bhh, lens, T, B, H)
     e1.record()
     torch.cuda.synchronize()
     us_per_launch = e0.elapsed_time(e1) * 1e3 / T

@@ -28,6 +28,8 @@ extern "C" {
 const char* ds2_version(void);
 const char* ds2_last_error(void);
 int ds2_device_info(int* cu_count, int* wave_size, char* arch, int arch_len);
+/* profiling/ablation switch used by scripts/ablate_rnn.py; returns the previous value; 0 = production */
+int ds2_debug_flags(int flags);
 
 /* ---- dense GEMM on the f32 matrix cores -------------------------------------------------------
  * C[M,N] (+)= op(A) op(B) (+ bias[N]);  transA: A stored (K,M);  transB: B stored (N,K).
@@ -91,10 +93,14 @@ int ds2_conv2_wgrad_f32(const float* a1, const float* dy2, const int* lens_dev, 
 /* ---- bidirectional GRU / LSTM recurrence -------------------------------------------------------
  * pack_padded_sequence -> aten::gru / aten::lstm -> pad_packed_sequence, modules/blocks.py:87-89, h0 = 0,
  * gate order r,z,n (GRU) / i,f,g,o (LSTM); gates = 3 | 4.  See asr_amd/csrc/rnn.hip for buffer roles. */
-int ds2_rnn_fwd_f32(int gates, float* gx, const float* whh, const float* bhh, float* hbuf, float* aux, const int* lens_dev, int T, int B,
-                    int H, void* stream);
-size_t ds2_rnn_bwd_workspace_bytes(int B, int H);
-int ds2_rnn_bwd_f32(int gates, const float* dy, int lddy, float* gx, float* aux, const float* hbuf, const float* whhT,
+size_t ds2_rnn_packed_floats(int gates, int H, int which /*0: forward operand, 1: backward operand*/);
+/* re-pack W_hh = [weight_hh_l0 ; weight_hh_l0_reverse] (2,G*H,H) into MFMA-fragment order (once per optimizer step) */
+int ds2_rnn_pack_whh_f32(int gates, const float* whh, float* wp_fwd, float* wp_bwd, int H, void* stream);
+size_t ds2_rnn_fwd_workspace_bytes(int B, int H);
+int ds2_rnn_fwd_f32(int gates, float* gx, const float* wp_fwd, const float* bhh, float* hbuf, float* aux, const int* lens_dev, int T,
+                    int B, int H, void* ws, size_t ws_bytes, void* stream);
+size_t ds2_rnn_bwd_workspace_bytes(int gates, int B, int H);
+int ds2_rnn_bwd_f32(int gates, const float* dy, int lddy, float* gx, float* aux, const float* hbuf, const float* wp_bwd,
                     const int* lens_dev, int T, int B, int H, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- log-softmax + CTC loss + gradient ---------------------------------------------------------

@@ -210,13 +210,13 @@ def test_rnn_fwd_bwd(dev, kind, H, B, T, lens):
     ld = g(lens_t, dev)
     gxd = g(gx.detach().float().reshape(T * B, 2 * G * H), dev).clone()
     whd, bhd = g(whh.detach().float(), dev), g(bhh.detach().float(), dev)
-    hbuf, aux = ops.rnn_fwd(G, gxd, whd, bhd, ld, T, B, H)
+    wpf, wpb = ops.rnn_pack(G, whd)
+    hbuf, aux = ops.rnn_fwd(G, gxd, wpf, bhd, ld, T, B, H)
     hb = hbuf.view(T, B, 2, H).cpu()
     assert rel_l2(hb[:, :, 0], yf.detach()) < 2e-5 and rel_l2(hb[:, :, 1], yb.detach()) < 2e-5
     ysum, _, _ = ops.add_colstats(hbuf[:, :H], hbuf[:, H:])
     assert rel_l2(ysum.view(T, B, H).cpu(), y.detach()) < 2e-5
-    whhT = ops.transpose_batched(whd)
-    ops.rnn_bwd(G, g(dy.float().reshape(T * B, H), dev), gxd, aux, hbuf, whhT, ld, T, B, H)
+    ops.rnn_bwd(G, g(dy.float().reshape(T * B, H), dev), gxd, aux, hbuf, wpb, ld, T, B, H)
     assert rel_l2(gxd.view(T, B, 2, G * H).cpu(), gx.grad) < 5e-5          # dGx
     # dW_hh / db_hh from the saved buffers exactly as engine.backward assembles them
     dgx = gxd
