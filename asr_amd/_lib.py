@@ -25,6 +25,10 @@ SIGNATURES = {
     "ds2_debug_flags": (i32, [i32]),
     "ds2_gemm_f32_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "ds2_gemm_f32": (i32, [i32, i32, i32, i32, i32, vp, i32, i64, vp, i32, i64, vp, i32, i64, vp, i32, i32, i32, vp, sz, vp]),
+    "ds2_gemm_bf16_workspace_bytes": (sz, [i32, i32, i32, i32]),
+    "ds2_gemm_bf16_nt": (i32, [i32, i32, i32, vp, i32, i64, vp, i32, i64, vp, i32, i64, vp, i32, i32, i32, vp, sz, vp]),
+    "ds2_cast_bf16": (i32, [vp, i32, vp, i32, i32, i32, vp]),
+    "ds2_cast_transpose_bf16": (i32, [vp, i32, vp, i32, i32, i32, vp]),
     "ds2_colreduce_workspace_bytes": (sz, [i32, i32]),
     "ds2_colstats_f32": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, f32, vp, sz, vp]),
     "ds2_add_colstats_f32": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, vp, vp, vp, vp, f32, vp, sz, vp]),

@@ -48,7 +48,9 @@ __device__ __forceinline__ f32x4 load4(const float* __restrict__ p, int valid, b
 // KCONT == false: operand stored (rows = k, cols = m-or-n index) -> tile 16 k x 128
 template <bool KCONT>
 struct TileLoader {
-  // two float4 per thread
+  // two float4 per thread.  FULL: the whole 128 x 16 tile is in range and 16-byte aligned -> unconditional
+  // vector loads, no control flow (keeps the loads of tile k+1 in flight across the MFMAs of tile k).
+  template <bool FULL>
   __device__ static void load(const float* __restrict__ base, int ld, int r0, int rmax, int k0, int kmax,
                               bool vec, f32x4 (&reg)[2]) {
     const int tid = threadIdx.x;
@@ -58,8 +60,9 @@ struct TileLoader {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int r = r0 + (tid >> 2) + 64 * i;
-        const int valid = (r < rmax) ? (kmax - k) : 0;
-        reg[i] = load4(base + (long long)r * ld + k, valid, vec);
+        const float* p = base + (long long)r * ld + k;
+        if (FULL) reg[i] = *reinterpret_cast<const f32x4*>(p);
+        else reg[i] = load4(p, (r < rmax) ? (kmax - k) : 0, vec);
       }
     } else {
       const int mq = tid & 31;
@@ -67,8 +70,9 @@ struct TileLoader {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int k = k0 + (tid >> 5) + 8 * i;
-        const int valid = (k < kmax) ? (rmax - m) : 0;
-        reg[i] = load4(base + (long long)k * ld + m, valid, vec);
+        const float* p = base + (long long)k * ld + m;
+        if (FULL) reg[i] = *reinterpret_cast<const f32x4*>(p);
+        else reg[i] = load4(p, (k < kmax) ? (rmax - m) : 0, vec);
       }
     }
   }
@@ -95,6 +99,51 @@ struct TileLoader {
   }
 };
 
+template <bool TA, bool TB, bool FULL>
+__device__ __forceinline__ void gemm_mainloop(const GemmArgs& g, const float* __restrict__ A, const float* __restrict__ B, int m0,
+                                              int n0, int kbeg, int kend, int nkt, int vecA, int vecB, float* __restrict__ lds0,
+                                              f32x16 (&acc)[2][2]) {
+  // lds0: [2 buffers][A,B][BK*LDT]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x4 ra[2], rb[2];
+  TileLoader<!TA>::template load<FULL>(A, g.lda, m0, g.M, kbeg, kend, vecA, ra);
+  TileLoader<TB>::template load<FULL>(B, g.ldb, n0, g.N, kbeg, kend, vecB, rb);
+  TileLoader<!TA>::store(lds0, ra);
+  TileLoader<TB>::store(lds0 + BK * LDT, rb);
+  __syncthreads();
+  const int arow = wm * 64 + (lane & 31);
+  const int brow = wn * 64 + (lane & 31);
+  const int khalf = lane >> 5;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nkt) {
+      const int k0 = kbeg + (kt + 1) * BK;
+      TileLoader<!TA>::template load<FULL>(A, g.lda, m0, g.M, k0, kend, vecA, ra);
+      TileLoader<TB>::template load<FULL>(B, g.ldb, n0, g.N, k0, kend, vecB, rb);
+    }
+    const float* As = lds0 + (cur * 2 + 0) * (BK * LDT);
+    const float* Bs = lds0 + (cur * 2 + 1) * (BK * LDT);
+#pragma unroll
+    for (int ks = 0; ks < BK / 2; ++ks) {
+      const int k = 2 * ks + khalf;
+      const float a0 = As[k * LDT + arow];
+      const float a1 = As[k * LDT + arow + 32];
+      const float b0 = Bs[k * LDT + brow];
+      const float b1 = Bs[k * LDT + brow + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (kt + 1 < nkt) {
+      TileLoader<!TA>::store(lds0 + ((cur ^ 1) * 2 + 0) * (BK * LDT), ra);
+      TileLoader<TB>::store(lds0 + ((cur ^ 1) * 2 + 1) * (BK * LDT), rb);
+    }
+    __syncthreads();
+  }
+}
+
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g, int vecA, int vecB) {
   __shared__ __attribute__((aligned(16))) float lds[2][2][BK * LDT];  // [buf][A/B]
@@ -118,46 +167,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g, int vecA, int
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  f32x4 ra[2], rb[2];
   // A operand: transA==0 -> stored (M,K): K-contiguous. transA==1 -> stored (K,M): M-contiguous.
   // B operand: transB==1 -> stored (N,K): K-contiguous. transB==0 -> stored (K,N): N-contiguous.
-  TileLoader<!TA>::load(A, g.lda, m0, g.M, kbeg, kend, vecA, ra);
-  TileLoader<TB>::load(B, g.ldb, n0, g.N, kbeg, kend, vecB, rb);
-  TileLoader<!TA>::store(lds[0][0], ra);
-  TileLoader<TB>::store(lds[0][1], rb);
-  __syncthreads();
-
-  const int arow = wm * 64 + (lane & 31);
-  const int brow = wn * 64 + (lane & 31);
+  const bool full = vecA && vecB && (m0 + BM <= g.M) && (n0 + BN <= g.N) && ((kend - kbeg) % BK == 0);   // block-uniform
+  float* lds0 = &lds[0][0][0];
+  if (full) gemm_mainloop<TA, TB, true>(g, A, B, m0, n0, kbeg, kend, nkt, vecA, vecB, lds0, acc);
+  else gemm_mainloop<TA, TB, false>(g, A, B, m0, n0, kbeg, kend, nkt, vecA, vecB, lds0, acc);
   const int khalf = lane >> 5;
-
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nkt) {
-      const int k0 = kbeg + (kt + 1) * BK;
-      TileLoader<!TA>::load(A, g.lda, m0, g.M, k0, kend, vecA, ra);
-      TileLoader<TB>::load(B, g.ldb, n0, g.N, k0, kend, vecB, rb);
-    }
-    const float* As = lds[cur][0];
-    const float* Bs = lds[cur][1];
-#pragma unroll
-    for (int ks = 0; ks < BK / 2; ++ks) {
-      const int k = 2 * ks + khalf;
-      const float a0 = As[k * LDT + arow];
-      const float a1 = As[k * LDT + arow + 32];
-      const float b0 = Bs[k * LDT + brow];
-      const float b1 = Bs[k * LDT + brow + 32];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-    }
-    if (kt + 1 < nkt) {
-      TileLoader<!TA>::store(lds[cur ^ 1][0], ra);
-      TileLoader<TB>::store(lds[cur ^ 1][1], rb);
-    }
-    __syncthreads();
-  }
 
   // epilogue. C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   float* C;

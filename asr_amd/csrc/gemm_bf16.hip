@@ -1,0 +1,258 @@
+// bf16-operand / fp32-accumulate GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x16_bf16, ~2.5 PF/s dense)
+// for the dense input-to-hidden GEMMs of the RNN gates — the one place the north-star asks for MFMA —
+// plus the fp32 -> bf16 cast / transposing-cast passes that feed it.
+//
+// ONE kernel form: "NT",  C[M,N] (fp32) (+)= A[M,K] (bf16) * B[N,K]^T (bf16) (+ bias[N]); both operands K-contiguous,
+// so every staging load is a 16-byte run and every MFMA fragment a single ds_read_b128.  The other two GEMM
+// forms of the backward pass are brought to NT by a transposing cast of one operand (an HBM-bound pass that
+// costs ~1% of the GEMM it enables):
+//     forward   Gx  = Xn W_ih^T        A = bf16(Xn)        B = bf16(W_ih)
+//     dXn       = dGx W_ih             A = bf16(dGx)       B = bf16(W_ih)^T   (transposing cast of the weights)
+//     dW_ih     = dGx^T Xn             A = bf16(dGx)^T     B = bf16(Xn)^T     (transposing casts, K = T*B)
+//
+// Tiling: 128x128x64 block tile, 4 waves (2x2), each wave 64x64 = 2x2 MFMA 32x32x16 tiles x 4 k-steps.
+// LDS tile rows are 64 bf16 = 128 B + 16 B pad (pitch 144 B): ds_write_b128 by 8-lane groups and
+// ds_read_b128 by the MFMA's 16-lane groups are both bank-conflict-free.  Global loads of tile k+1 are issued
+// before the MFMAs of tile k and parked in registers; out-of-range rows / k-segments read a zero page
+// (pointer select before the load, no control flow in the loop).
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int PITCH = 144;                       // bytes per LDS tile row (128 + 16 pad)
+constexpr int TILE_BYTES = BM * PITCH;           // 18432
+
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};   // global address space zero page
+
+struct BArgs {
+  const __bf16* A; const __bf16* B; float* C; const float* bias;
+  int M, N, K, lda, ldb, ldc;
+  long long sA, sB, sC;
+  int splitk, kchunk, accumulate;
+  float* partial;
+};
+
+// 4 x 16-byte loads per thread per operand tile: row = (tid >> 3) + 32*i, k-segment = tid & 7 (8 bf16 each)
+__device__ __forceinline__ void load_tile(const __bf16* __restrict__ base, int ld, int r0, int rmax, int k0, int kmax, f32x4 (&reg)[4]) {
+  const int seg = threadIdx.x & 7;
+  const int k = k0 + seg * 8;
+  const bool kok = k + 8 <= kmax;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + (threadIdx.x >> 3) + 32 * i;
+    const bool ok = kok && r < rmax;
+    const void* p = ok ? (const void*)(base + (long long)r * ld + k) : (const void*)g_zero16;
+    reg[i] = *reinterpret_cast<const f32x4*>(p);
+  }
+}
+__device__ __forceinline__ void store_tile(char* __restrict__ lds, const f32x4 (&reg)[4]) {
+  const int seg = threadIdx.x & 7;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (threadIdx.x >> 3) + 32 * i;
+    *reinterpret_cast<f32x4*>(lds + r * PITCH + seg * 16) = reg[i];
+  }
+}
+
+__global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(BArgs g) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * TILE_BYTES];   // [A | B]
+  const int z = blockIdx.z;
+  const int zb = z / g.splitk, zs = z % g.splitk;
+  const __bf16* A = g.A + (long long)zb * g.sA;
+  const __bf16* B = g.B + (long long)zb * g.sB;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int kbeg = zs * g.kchunk;
+  const int kend = min(g.K, kbeg + g.kchunk);
+  const int nkt = (kend - kbeg + BK - 1) / BK;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, half = lane >> 5;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 ra[4], rb[4];
+  load_tile(A, g.lda, m0, g.M, kbeg, kend, ra);
+  load_tile(B, g.ldb, n0, g.N, kbeg, kend, rb);
+  char* As = lds;
+  char* Bs = lds + TILE_BYTES;
+  const char* afrag = As + (wm * 64 + l31) * PITCH + half * 16;   // + mi*32*PITCH + kk*32
+  const char* bfrag = Bs + (wn * 64 + l31) * PITCH + half * 16;
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();                    // previous tile's fragment reads are done
+    store_tile(As, ra);
+    store_tile(Bs, rb);
+    __syncthreads();
+    if (kt + 1 < nkt) {
+      const int k0 = kbeg + (kt + 1) * BK;
+      load_tile(A, g.lda, m0, g.M, k0, kend, ra);
+      load_tile(B, g.ldb, n0, g.N, k0, kend, rb);
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(afrag + kk * 32);
+      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(afrag + 32 * PITCH + kk * 32);
+      const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(bfrag + kk * 32);
+      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(bfrag + 32 * PITCH + kk * 32);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+    }
+  }
+
+  float* C;
+  long long ldc;
+  const bool partial = g.splitk > 1;
+  if (partial) {
+    C = g.partial + ((long long)zb * g.splitk + zs) * (long long)g.M * g.N;
+    ldc = g.N;
+  } else {
+    C = g.C + (long long)zb * g.sC;
+    ldc = g.ldc;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + l31;
+      if (col >= g.N) continue;
+      const float bv = (!partial && g.bias) ? g.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (row < g.M) {
+          float v = acc[i][j][r] + bv;
+          float* p = C + (long long)row * ldc + col;
+          if (!partial && g.accumulate) v += *p;
+          *p = v;
+        }
+      }
+    }
+  }
+}
+
+__global__ void splitk_reduce_bf_kernel(const float* __restrict__ part, float* __restrict__ C, const float* __restrict__ bias, int M, int N,
+                                        int ldc, long long sC, int splitk, int accumulate) {
+  const long long zb = blockIdx.y;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)M * N) return;
+  const int row = idx / N, col = idx % N;
+  const float* p = part + zb * splitk * (long long)M * N + idx;
+  float s = 0.f;
+  for (int k = 0; k < splitk; ++k) s += p[(long long)k * M * N];
+  if (bias) s += bias[col];
+  float* c = C + zb * sC + (long long)row * ldc + col;
+  if (accumulate) s += *c;
+  *c = s;
+}
+
+// dst[r][c] = bf16(src[r][c]), c < C ; dst[r][c] = 0 for C <= c < ldd      (ldd % 8 == 0)
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, int lds_, __bf16* __restrict__ dst, int ldd, int R,
+                                                        int Cc, int vec) {
+  const int cq = ldd / 4;
+  const long long total = (long long)R * cq;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int r = i / cq, c0 = (i % cq) * 4;
+    const float* s = src + (long long)r * lds_ + c0;
+    float v[4];
+    if (c0 + 4 <= Cc && vec) {
+      const f32x4 q = *reinterpret_cast<const f32x4*>(s);
+      v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = (c0 + j < Cc) ? s[j] : 0.f;
+    }
+    bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    *reinterpret_cast<bf16x4*>(dst + (long long)r * ldd + c0) = o;
+  }
+}
+
+// dst[c][r] = bf16(src[r][c]) ; dst row pitch ldd >= R (ldd % 8 == 0), pad columns R..ldd zero-filled.
+// 64x64 tiles through LDS: fp32 reads are 256-B runs along c, bf16 writes are 128-B runs along r.
+__global__ __launch_bounds__(256) void cast_transpose_bf16_kernel(const float* __restrict__ src, int lds_, __bf16* __restrict__ dst, int ldd,
+                                                                  int R, int Cc) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // ty 0..3
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = r0 + ty + 4 * i, c = c0 + tx;
+    tile[ty + 4 * i][tx] = (r < R && c < Cc) ? src[(long long)r * lds_ + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = c0 + ty + 4 * i, r = r0 + tx;
+    if (c < Cc && r < ldd) dst[(long long)c * ldd + r] = (__bf16)tile[tx][ty + 4 * i];   // r >= R rows were loaded as 0
+  }
+}
+
+}  // namespace
+
+extern "C" size_t ds2_gemm_bf16_workspace_bytes(int M, int N, int batch, int splitk) {
+  if (splitk <= 1) return 0;
+  return (size_t)batch * splitk * (size_t)M * N * sizeof(float);
+}
+
+// C[M,N] fp32 (+)= A[M,K] bf16 (pitch lda) * B[N,K]^T bf16 (pitch ldb) (+ bias).  K, lda, ldb multiples of 8; 16-byte aligned bases.
+extern "C" int ds2_gemm_bf16_nt(int M, int N, int K, const void* A, int lda, long long strideA, const void* B, int ldb, long long strideB,
+                                float* C, int ldc, long long strideC, const float* bias, int accumulate, int batch, int splitk,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  DS2_REQUIRE(M > 0 && N > 0 && K > 0 && batch >= 1, "ds2_gemm_bf16_nt: bad dims M=%d N=%d K=%d", M, N, K);
+  DS2_REQUIRE(A && B && C, "ds2_gemm_bf16_nt: null pointer");
+  DS2_REQUIRE((K % 8) == 0 && (lda % 8) == 0 && (ldb % 8) == 0 && (strideA % 8) == 0 && (strideB % 8) == 0,
+              "ds2_gemm_bf16_nt: K, lda, ldb, strides must be multiples of 8 (K=%d lda=%d ldb=%d)", K, lda, ldb);
+  DS2_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "ds2_gemm_bf16_nt: operands must be 16-byte aligned");
+  if (splitk < 1) splitk = 1;
+  int kchunk = ceil_div(ceil_div(K, splitk), BK) * BK;
+  splitk = ceil_div(K, kchunk);
+  if (splitk > 1)
+    DS2_REQUIRE(workspace && workspace_bytes >= ds2_gemm_bf16_workspace_bytes(M, N, batch, splitk), "ds2_gemm_bf16_nt: workspace too small");
+  BArgs g;
+  g.A = (const __bf16*)A; g.B = (const __bf16*)B; g.C = C; g.bias = bias;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.sA = strideA; g.sB = strideB; g.sC = strideC;
+  g.splitk = splitk; g.kchunk = kchunk; g.accumulate = accumulate; g.partial = (float*)workspace;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(ceil_div(N, BN), ceil_div(M, BM), batch * splitk);
+  hipLaunchKernelGGL(gemm_bf16_nt_kernel, grid, dim3(256), 0, s, g);
+  DS2_LAUNCH_CHECK("gemm_bf16_nt_kernel");
+  if (splitk > 1) {
+    hipLaunchKernelGGL(splitk_reduce_bf_kernel, dim3(ceil_div(M * N, 256), batch), dim3(256), 0, s, (const float*)workspace, C, bias, M, N,
+                       ldc, strideC, splitk, accumulate);
+    DS2_LAUNCH_CHECK("splitk_reduce_bf_kernel");
+  }
+  return 0;
+}
+
+// dst (R, ldd) bf16 = cast(src (R, C) fp32, pitch lds); ldd % 8 == 0, ldd >= C, pad columns zero.
+extern "C" int ds2_cast_bf16(const float* src, int ld_src, void* dst, int ld_dst, int R, int Cc, void* stream) {
+  DS2_REQUIRE(src && dst && R > 0 && Cc > 0 && ld_dst >= Cc && (ld_dst % 8) == 0, "ds2_cast_bf16: bad args");
+  const long long total = (long long)R * (ld_dst / 4);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  const int vec = ((ld_src % 4) == 0) && (((uintptr_t)src % 16) == 0);
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, ld_src, (__bf16*)dst, ld_dst, R, Cc, vec);
+  DS2_LAUNCH_CHECK("cast_bf16_kernel");
+  return 0;
+}
+
+// dst (C, ldd) bf16 = cast(src (R, C) fp32)^T ; ldd % 8 == 0, ldd >= R, pad columns zero.
+extern "C" int ds2_cast_transpose_bf16(const float* src, int ld_src, void* dst, int ld_dst, int R, int Cc, void* stream) {
+  DS2_REQUIRE(src && dst && R > 0 && Cc > 0 && ld_dst >= R && (ld_dst % 8) == 0, "ds2_cast_transpose_bf16: bad args");
+  dim3 grid(ceil_div(Cc, 64), ceil_div(ld_dst, 64));
+  hipLaunchKernelGGL(cast_transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, (__bf16*)dst, ld_dst, R, Cc);
+  DS2_LAUNCH_CHECK("cast_transpose_bf16_kernel");
+  return 0;
+}

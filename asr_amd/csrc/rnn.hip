@@ -32,6 +32,11 @@ namespace {
 
 constexpr int NW = 8;          // waves per block
 
+// Streamed-once traffic (gate pre-activations in, gates / h / aux out, dy in) is marked non-temporal so that it does
+// not evict the per-XCD working set that IS re-read every step (W_hh slices 3.1 MB + packed h at H=1024) from the 4 MB L2.
+__device__ __forceinline__ float ldnt(const float* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void stnt(float* p, float v) { __builtin_nontemporal_store(v, p); }
+
 struct RnnArgs {
   float* gx;          // (T,B,2,G*H)  fwd: in x-proj / out gates ; bwd: in gates / out d(pre-activations wrt x-proj)
   float* aux;         // (T,B,2,H)    GRU fwd: out hn ; GRU bwd: in hn / out d(hn) ; LSTM: cell state (read-only in bwd)
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(RnnArgs a, int s)
       if (pvalid[i]) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-          pgx[i][g] = a.gx[row * G * H + g * H + j];
+          pgx[i][g] = ldnt(&a.gx[row * G * H + g * H + j]);
           pb[i][g] = a.bhh[(dir * G + g) * H + j];
         }
         if (has_prev) {
@@ -179,9 +184,9 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(RnnArgs a, int s)
     float* hp = pk_out + packed_index(b, j, nch);
     if (!pvalid[i]) {
 #pragma unroll
-      for (int g = 0; g < G; ++g) gx[g * H] = 0.f;
-      *ho = 0.f;
-      *ax = 0.f;
+      for (int g = 0; g < G; ++g) stnt(&gx[g * H], 0.f);
+      stnt(ho, 0.f);
+      stnt(ax, 0.f);
       *hp = 0.f;
       continue;
     }
@@ -198,8 +203,8 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(RnnArgs a, int s)
       const float r = sigmoidf_(pgx[i][0] + gh[0]);
       const float z = sigmoidf_(pgx[i][1] + gh[1]);
       const float n = tanhf(pgx[i][2] + r * gh[2]);
-      gx[0] = r; gx[H] = z; gx[2 * H] = n;
-      *ax = gh[2];
+      stnt(&gx[0], r); stnt(&gx[H], z); stnt(&gx[2 * H], n);
+      stnt(ax, gh[2]);
       hnew = (1.f - z) * n + z * pprev[i];
     } else {
       const float ig = sigmoidf_(pgx[i][0] + gh[0]);
@@ -207,8 +212,8 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(RnnArgs a, int s)
       const float gg = tanhf(pgx[i][2] + gh[2]);
       const float og = sigmoidf_(pgx[i][G - 1] + gh[G - 1]);
       const float c = fg * pprev[i] + ig * gg;
-      gx[0] = ig; gx[H] = fg; gx[2 * H] = gg; gx[(G - 1) * H] = og;
-      *ax = c;
+      stnt(&gx[0], ig); stnt(&gx[H], fg); stnt(&gx[2 * H], gg); stnt(&gx[(G - 1) * H], og);
+      *ax = c;                       // c_{t} is re-read by the next step (same block): keep it cacheable
       hnew = og * tanhf(c);
     }
     *ho = hnew;
@@ -259,9 +264,9 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(RnnArgs a, int s)
       if (pvalid[i]) {
         const long long row = ((long long)t * B + b) * 2 + dir;
 #pragma unroll
-        for (int g = 0; g < G; ++g) pg[i][g] = a.gx[row * G * H + g * H + j];
-        pax[i] = a.aux[row * H + j];
-        pdy[i] = a.dy[((long long)t * B + b) * a.lddy + j];
+        for (int g = 0; g < G; ++g) pg[i][g] = ldnt(&a.gx[row * G * H + g * H + j]);
+        pax[i] = ldnt(&a.aux[row * H + j]);
+        pdy[i] = ldnt(&a.dy[((long long)t * B + b) * a.lddy + j]);
         if (has_q) pdc[i] = dcar_in[(long long)b * H + j];
         if (has_pf) {
           const long long prow = ((long long)tpf * B + b) * 2 + dir;
@@ -299,8 +304,8 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(RnnArgs a, int s)
     float dgh[G];
     if (!pvalid[i]) {
 #pragma unroll
-      for (int g = 0; g < G; ++g) { gx[g * H] = 0.f; dgh[g] = 0.f; }
-      if (G == 3) *ax = 0.f;
+      for (int g = 0; g < G; ++g) { stnt(&gx[g * H], 0.f); dgh[g] = 0.f; }
+      if (G == 3) stnt(ax, 0.f);
       *dco = 0.f;
     } else {
       float carry = 0.f;
@@ -316,8 +321,8 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(RnnArgs a, int s)
         dgh[0] = dr * r * (1.f - r);
         dgh[1] = dz * z * (1.f - z);
         dgh[2] = dpn * r;                  // d(hn): the n-gate row of dGh
-        gx[0] = dgh[0]; gx[H] = dgh[1]; gx[2 * H] = dpn;
-        *ax = dgh[2];
+        stnt(&gx[0], dgh[0]); stnt(&gx[H], dgh[1]); stnt(&gx[2 * H], dpn);
+        stnt(ax, dgh[2]);
         *dco = dh * z;
       } else {
         const float dh = pdy[i] + carry;
@@ -330,7 +335,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(RnnArgs a, int s)
         dgh[2] = dc * ig * (1.f - gg * gg);
         dgh[G - 1] = dh * tc * og * (1.f - og);
 #pragma unroll
-        for (int g = 0; g < G; ++g) gx[g * H] = dgh[g];
+        for (int g = 0; g < G; ++g) stnt(&gx[g * H], dgh[g]);
         *dco = dc * fg;
       }
     }

@@ -29,6 +29,7 @@ class ModelCfg:
     layers: int
     classes: int
     freq: int = 161
+    precision: str = "fp32"   # "fp32": everything fp32 (parity path) | "bf16": bf16 MFMA operands, fp32 accumulate/state
 
     @property
     def gates(self) -> int:
@@ -115,7 +116,10 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
             lc.mean, lc.var = mean, var
         else:
             xn = xin
-        gx = ops.gemm(xn, W[f"rnns.{l}.wih_cat"], transB=True, bias=W[f"rnns.{l}.bih_cat"])      # (M, 2GH)
+        if cfg.precision == "bf16":
+            gx = ops.gemm_bf16_nt(ops.cast_bf16(xn), ops.cast_bf16(W[f"rnns.{l}.wih_cat"]), bias=W[f"rnns.{l}.bih_cat"])
+        else:
+            gx = ops.gemm(xn, W[f"rnns.{l}.wih_cat"], transB=True, bias=W[f"rnns.{l}.bih_cat"])  # (M, 2GH)
         wpf, wpb = ops.rnn_pack(G, W[f"rnns.{l}.whh_cat"])
         hbuf, aux = ops.rnn_fwd(G, gx, wpf, W[f"rnns.{l}.bhh_cat"], lens_dev, T, B, H)
         lc.wpb = wpb
@@ -193,8 +197,12 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
         else:
             dwhh.zero_()
         # dW_ih (2GH, I) = dGx^T Xn ;  dXn = dGx W_ih
-        ops.gemm(dgx, lc.xn, transA=True, out=Gr[f"rnns.{l}.wih_cat"])
-        dxn = ops.gemm(dgx, W[f"rnns.{l}.wih_cat"])                                               # (M, I)
+        if cfg.precision == "bf16":
+            ops.gemm_bf16_nt(ops.cast_transpose_bf16(dgx), ops.cast_transpose_bf16(lc.xn), out=Gr[f"rnns.{l}.wih_cat"])
+            dxn = ops.gemm_bf16_nt(ops.cast_bf16(dgx), ops.cast_transpose_bf16(W[f"rnns.{l}.wih_cat"]))
+        else:
+            ops.gemm(dgx, lc.xn, transA=True, out=Gr[f"rnns.{l}.wih_cat"])
+            dxn = ops.gemm(dgx, W[f"rnns.{l}.wih_cat"])                                           # (M, I)
         lc.gx = lc.aux = lc.hbuf = lc.xn = lc.wpb = None
         if l > 0:
             bp = f"rnns.{l}.batch_norm.module."

@@ -114,6 +114,18 @@ class DeepSpeech(nn.Module):
         self.inference_softmax = InferenceBatchSoftmax()
 
     # -- flat parameter storage -------------------------------------------------------------------
+    @property
+    def precision(self) -> str:
+        """"fp32" (default; the parity path) or "bf16" (bf16 MFMA operands for the input-to-hidden GEMMs, fp32
+        accumulation / state / BN / CTC — the BASELINE configs[2],[4] setting)."""
+        return self._cfg.precision
+
+    @precision.setter
+    def precision(self, value: str):
+        if value not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        self._cfg.precision = value
+
     def _ensure_flat(self, device):
         device = torch.device(device)
         if self._flat is None or self._flat.device != device or not self._flat.owns(self):

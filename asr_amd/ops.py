@@ -84,6 +84,53 @@ def gemm(A: Tensor, B: Tensor, transA: bool = False, transB: bool = False, bias:
     return out
 
 
+def _pad8(n: int) -> int:
+    return (n + 7) // 8 * 8
+
+
+def cast_bf16(src: Tensor) -> Tensor:
+    """(R, C) fp32 row-major view -> (R, pad8(C)) bf16, pad columns zero."""
+    _chk_f32(src)
+    R, Cc = src.shape
+    dst = torch.empty(R, _pad8(Cc), dtype=torch.bfloat16, device=src.device)
+    _lib.check(_lib.load().ds2_cast_bf16(src.data_ptr(), _row_pitch(src), dst.data_ptr(), dst.size(1), R, Cc, _stream()), "ds2_cast_bf16")
+    return dst
+
+
+def cast_transpose_bf16(src: Tensor) -> Tensor:
+    """(R, C) fp32 row-major view -> (C, pad8(R)) bf16 = src^T, pad columns zero."""
+    _chk_f32(src)
+    R, Cc = src.shape
+    dst = torch.empty(Cc, _pad8(R), dtype=torch.bfloat16, device=src.device)
+    _lib.check(_lib.load().ds2_cast_transpose_bf16(src.data_ptr(), _row_pitch(src), dst.data_ptr(), dst.size(1), R, Cc, _stream()),
+               "ds2_cast_transpose_bf16")
+    return dst
+
+
+def gemm_bf16_nt(A: Tensor, B: Tensor, bias: Optional[Tensor] = None, out: Optional[Tensor] = None, accumulate: bool = False,
+                 splitk: int = 0) -> Tensor:
+    """out[M,N] fp32 (+)= A[M,K] @ B[N,K]^T, A/B bf16 with K (incl. zero padding) a multiple of 8."""
+    assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and A.is_cuda and B.is_cuda
+    lib = _lib.load()
+    M, K = A.shape
+    N, Kb = B.shape
+    assert K == Kb and K % 8 == 0, (A.shape, B.shape)
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    if splitk <= 0:
+        tiles = ((M + 127) // 128) * ((N + 127) // 128)
+        splitk = 1
+        if tiles < 400 and K >= 4096:
+            splitk = max(1, min((768 + tiles - 1) // tiles, K // 2048))
+    ws, wsb = None, 0
+    if splitk > 1:
+        wsb = lib.ds2_gemm_bf16_workspace_bytes(M, N, 1, splitk)
+        ws = _ws(wsb, A.device)
+    _lib.check(lib.ds2_gemm_bf16_nt(M, N, K, A.data_ptr(), A.stride(0), 0, B.data_ptr(), B.stride(0), 0, out.data_ptr(), _row_pitch(out), 0,
+                                    _ptr(bias), int(accumulate), 1, splitk, _ptr(ws), wsb, _stream()), "ds2_gemm_bf16_nt")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # BatchNorm1d family on (M, H)
 # ------------------------------------------------------------------------------------------------

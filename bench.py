@@ -70,15 +70,9 @@ def synthetic_batch(B, tin, C, seed):
     return x, targets, pct, tsz
 
 
-def cpu_baseline(rnn, H, L, C, tin, budget_s=25.0):
-    """CPU oracle (padded+masked restatement, oracle/ds2_oracle.py) on the host cores: same model
-    config and utterance length, bounded batch (B=1..2) so it costs ~10-30 s."""
+def _oracle_state(rnn, H, L, C):
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import det
-    from oracle import ds2_oracle as O
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    Bs = 1
     shapes = det.state_shapes(rnn, H, L, C)
     g = torch.Generator().manual_seed(0)
     sd = {}
@@ -91,27 +85,74 @@ def cpu_baseline(rnn, H, L, C, tin, budget_s=25.0):
             sd[k] = torch.zeros(shp)
         else:
             sd[k] = (torch.rand(shp, generator=g) * 2 - 1) * (1.0 / (H ** 0.5))
-    x, targets, pct, tsz = synthetic_batch(Bs, tin, C, 1)
-    t0 = time.time()
-    O.fit_and_grads(sd, x, targets, pct, tsz)
-    dt = time.time() - t0
-    n = 1
-    while dt < budget_s * 0.4 and n < 3:      # a second/third repetition only if cheap
-        t1 = time.time()
-        O.fit_and_grads(sd, x, targets, pct, tsz)
-        dt = min(dt, time.time() - t1)
-        n += 1
-    return {"value": Bs / dt, "unit": "utterances/sec", "cores": cores, "kind": "port",
-            "sample": f"oracle fit+backward (no optimizer), B={Bs} of the same {L}x{H} {rnn} model at T_in={tin}, best of {n}"}
+    return sd
+
+
+def cpu_baseline_worker(rnn, H, L, C, tin):
+    """Runs in a child process (hard wall-clock limit enforced by the parent).  Times the CPU oracle
+    (oracle/ds2_oracle.py: padded+masked restatement of fit + backward) on B=1 of the same model and
+    utterance length.  The thread count is probed first: on many-core hosts the op mix of this model
+    (thousands of tiny per-frame ops) is SLOWER with all cores than with 8-32 threads."""
+    from oracle import ds2_oracle as O
+    cores = os.cpu_count() or 1
+    sd = _oracle_state(rnn, H, L, C)
+
+    def run(t_in, reps=1):
+        x, targets, pct, tsz = synthetic_batch(1, t_in, C, 1)
+        best = 1e30
+        for _ in range(reps):
+            t0 = time.time()
+            O.fit_and_grads(sd, x, targets, pct, tsz)
+            best = min(best, time.time() - t0)
+        return best
+
+    cands = sorted({min(cores, 8), min(cores, 32), cores})
+    probe = {}
+    for n in cands:
+        torch.set_num_threads(n)
+        run(41)                       # warm-up (thread pool, allocator)
+        probe[n] = run(41)
+        if probe[n] > 8.0:            # hopeless setting, do not try even larger teams
+            break
+    nthr = min(probe, key=probe.get)
+    torch.set_num_threads(nthr)
+    t_small = run(201)
+    est_full = t_small * tin / 201.0
+    if est_full <= 45.0:
+        dt, sample_t = run(tin), tin
+    else:
+        dt, sample_t = est_full, 201
+    out = {"value": 1.0 / dt, "unit": "utterances/sec", "cores": nthr, "kind": "port", "host_cores": cores,
+           "sample": (f"CPU oracle fit+backward, B=1 of the same {L}x{H} {rnn} model, T_in={sample_t}"
+                      + ("" if sample_t == tin else f" scaled linearly to T_in={tin}")
+                      + f"; threads probed {probe} -> {nthr}")}
+    print("CPU_BASELINE_JSON " + json.dumps(out), flush=True)
+
+
+def cpu_baseline(rnn, H, L, C, tin, limit_s=150):
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", rnn, str(H), str(L), str(C), str(tin)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=limit_s, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
+        for line in r.stdout.splitlines():
+            if line.startswith("CPU_BASELINE_JSON "):
+                return json.loads(line[len("CPU_BASELINE_JSON "):])
+        return {"value": None, "unit": "utterances/sec", "cores": 0, "kind": "port", "sample": "worker failed: " + r.stderr[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "utterances/sec", "cores": 0, "kind": "port", "sample": f"worker exceeded {limit_s}s"}
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-baseline-worker":
+        rnn, H, L, C, tin = sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
+        return cpu_baseline_worker(rnn, H, L, C, tin)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override per-GPU batch")
+    ap.add_argument("--dtype", default="", choices=["", "f32", "bf16"], help="default: bf16 for c3 (the config's dtype), f32 otherwise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print a per-section time breakdown to stderr")
     args = ap.parse_args()
@@ -137,6 +178,8 @@ def main():
         model = DeepSpeech(audio_conf=audio_conf(), decoder=None, label_path=label_file(tmp, C), rnn_type=rnn, rnn_hidden_size=H,
                            rnn_hidden_layers=L, bidirectional=True)
     model.to(dev).train()
+    dtype = args.dtype or ("bf16" if args.workload == "c3" else "f32")
+    model.precision = "bf16" if dtype == "bf16" else "fp32"
     opt = FusedAdamW(model, lr=1.5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5)
     tr = DeepSpeechTrainer(model, CTCLoss(reduction="sum"), 1, None, opt, None, None, dev, dev, False, None)
     x, targets, pct, tsz = synthetic_batch(B, tin, C, 1 + rank)
@@ -198,9 +241,9 @@ def main():
             "metric": "utterances/sec (10 s, 161-bin) DS2 5x1024 BiGRU CTC train step" if args.workload == "c3"
                       else f"utterances/sec DS2 {L}x{H} bi-{rnn} CTC train step",
             "value": utts, "unit": "utterances/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
             "data": "synthetic N(0,1) 161-bin spectrograms, random-init weights, random labels U=T_in/20",
-            "config": {"workload": f"{args.workload}: DS2 {L}x{H} bi-{rnn.upper()} fp32, {tin} input frames ({tin // 100} s), "
+            "config": {"workload": f"{args.workload}: DS2 {L}x{H} bi-{rnn.upper()} {dtype}, {tin} input frames ({tin // 100} s), "
                                    f"batch {B}/GPU, {C} classes", "global_batch": B * world, "parallelism": f"dp{world}"},
             "loss": lv, "step_tflops": step_flops * world / (ms * 1e-3) / 1e12,
             "step_frac_of_fp32_mfma_peak": step_flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,

@@ -41,6 +41,16 @@ int ds2_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, in
                  long long strideB, float* C, int ldc, long long strideC, const float* bias, int accumulate, int batch, int splitk,
                  void* workspace, size_t workspace_bytes, void* stream);
 
+/* bf16-operand / fp32-accumulate GEMM (v_mfma_f32_32x32x16_bf16), "NT" form only: C[M,N] (+)= A[M,K] B[N,K]^T (+bias).
+ * Used for the RNN input projections and their dX / dW when the model runs with precision="bf16" (BASELINE configs[2],[4]);
+ * the cast passes produce the K-contiguous bf16 operands (dst pitch % 8 == 0, pad columns zero-filled). */
+size_t ds2_gemm_bf16_workspace_bytes(int M, int N, int batch, int splitk);
+int ds2_gemm_bf16_nt(int M, int N, int K, const void* A, int lda, long long strideA, const void* B, int ldb, long long strideB, float* C,
+                     int ldc, long long strideC, const float* bias, int accumulate, int batch, int splitk, void* workspace,
+                     size_t workspace_bytes, void* stream);
+int ds2_cast_bf16(const float* src, int ld_src, void* dst, int ld_dst, int R, int Cc, void* stream);
+int ds2_cast_transpose_bf16(const float* src, int ld_src, void* dst, int ld_dst, int R, int Cc, void* stream);
+
 /* ---- BatchNorm1d over (T*B, H) rows, padding rows included -----------------------------------
  * modules/blocks.py:75,85-86 (SequenceWise(BatchNorm1d)) and modules/deepspeech.py:104 (fc block).
  * stats: biased variance for normalisation; running stats updated with momentum and the unbiased

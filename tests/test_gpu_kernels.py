@@ -66,6 +66,26 @@ def test_gemm_splitk_batched_strided(dev):
     assert rel_l2(out[0].cpu(), ref0) < 2e-6 and rel_l2(out[1].cpu(), ref1) < 2e-6
 
 
+@pytest.mark.parametrize("M,N,K", [(70, 45, 33), (300, 260, 520), (129, 257, 64), (29, 96, 1000)])
+def test_gemm_bf16_and_casts(dev, M, N, K):
+    from asr_amd import ops
+    A, B, bias = T_(1, M, K), T_(2, N, K), T_(3, N)
+    Ab, Bb = ops.cast_bf16(g(A, dev)), ops.cast_bf16(g(B, dev))
+    assert Ab.shape == (M, (K + 7) // 8 * 8) and torch.equal(Ab[:, :K].cpu(), A.bfloat16()) and float(Ab[:, K:].abs().sum()) == 0
+    ref = Ab.cpu().double() @ Bb.cpu().double().t() + bias.double()
+    out = ops.gemm_bf16_nt(Ab, Bb, bias=g(bias, dev))
+    assert rel_l2(out.cpu(), ref) < 3e-6
+    out2 = ops.gemm_bf16_nt(Ab, Bb, splitk=3)                        # deterministic split-K
+    assert rel_l2(out2.cpu(), ref - bias.double()) < 3e-6
+    # transposing cast: (K, M) fp32 -> (M, pad8(K)) bf16
+    At = ops.cast_transpose_bf16(g(A.t().contiguous(), dev))
+    assert torch.equal(At.cpu(), Ab.cpu())
+    # TN through transposing casts: C = X^T Y with X (K, M), Y (K, N)
+    X, Y = A.t().contiguous(), B.t().contiguous()
+    outT = ops.gemm_bf16_nt(ops.cast_transpose_bf16(g(X, dev)), ops.cast_transpose_bf16(g(Y, dev)))
+    assert rel_l2(outT.cpu(), ref - bias.double()) < 3e-6
+
+
 # ---------------------------------------------------------------------------------------------- BN1d
 @pytest.mark.parametrize("M,H", [(50, 24), (1000, 96), (333, 1312), (64, 5)])
 def test_bn1d(dev, M, H):

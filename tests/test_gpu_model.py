@@ -129,6 +129,32 @@ def test_step_vs_oracle_larger(rnn, hidden, layers, B, tmax):
         assert err <= TOL * max(np.linalg.norm(gref), 1e-12), (k, err, np.linalg.norm(gref))
 
 
+@pytest.mark.parametrize("rnn,hidden,layers,B,tmax", [("gru", 128, 3, 16, 120), ("lstm", 96, 2, 9, 90)])
+def test_bf16_precision_vs_oracle(rnn, hidden, layers, B, tmax):
+    """precision="bf16": bf16 MFMA operands for the input-to-hidden GEMMs (fp32 accumulate, fp32 everything else).
+    Separately stated tolerance: logits/loss 2e-2, gradients 6e-2 relative to the fp64 oracle."""
+    cfg = dict(rnn=rnn, hidden=hidden, layers=layers, classes=29)
+    t_ins = sorted([int(v) for v in det.randint((B,), 62, tmax // 2, tmax + 1)], reverse=True)
+    t_ins[0] = tmax
+    cfg["t_ins"] = t_ins
+    sd, x, targets, pct, tsz = model_inputs(cfg)
+    ref = O.fit_and_grads(sd, x, targets, pct, tsz, dtype=torch.float64)
+    model = make_model(cfg, sd)
+    model.precision = "bf16"
+    lens = O.lengths_from_percentages(pct, x.size(3))
+    out, out_lens = model.forward(x.cuda(), lens)
+    from asr_amd import CTCLoss
+    loss = CTCLoss(reduction="sum")(out.transpose(0, 1), targets, out_lens, tsz) / B
+    loss.backward()
+    e_logits = rel_l2(out.detach().cpu().numpy(), ref["logits"].numpy())
+    assert 1e-5 < e_logits < 2e-2, e_logits                 # > 1e-5: make sure the bf16 path really ran
+    assert abs(float(loss.detach()) - ref["loss"]) / ref["loss"] < 2e-2
+    for k, p in model.named_parameters():
+        gref = ref["grads"][k].numpy()
+        err = np.linalg.norm(p.grad.cpu().numpy().astype(np.float64) - gref)
+        assert err <= 6e-2 * max(np.linalg.norm(gref), 1e-12), (k, err / np.linalg.norm(gref))
+
+
 def test_infeasible_batch_is_skipped():
     """An utterance with no valid alignment gives loss = inf -> check_loss invalid -> weights untouched
     (deepspeech_trainer.py:86-97)."""
