@@ -52,16 +52,28 @@ struct RnnArgs {
   int dbg;            // ablation flags (0 in production)
 };
 
-// element (row r, column k) of a packed [tiles][chunks][256] operand: tile = r/16, chunk = k/16,
-// lane = ((k%16)/4)*16 + r%16, component = k%4
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// element (row r, column k) of a packed [tiles][chunks][64 lanes][16 bytes] operand.
+//   fp32 (16x16x4 MFMA):  chunk = k/16, lane = ((k%16)/4)*16 + r%16, component = k%4   (4 floats per lane)
+//   bf16 (16x16x32 MFMA): chunk = k/32, lane = ((k%32)/8)*16 + r%16, component = k%8   (8 bf16 per lane)
+// Either way one chunk = 1 KiB and a wave loads it with one coalesced global_load_dwordx4.
+template <bool BF>
 __device__ __forceinline__ long long packed_index(int r, int k, int nchunks) {
+  if (BF) return (((long long)(r >> 4) * nchunks + (k >> 5)) * 64 + (((k & 31) >> 3) << 4) + (r & 15)) * 8 + (k & 7);
   return (((long long)(r >> 4) * nchunks + (k >> 4)) * 64 + (((k & 15) >> 2) << 4) + (r & 15)) * 4 + (k & 3);
 }
+template <bool BF>
+__device__ __forceinline__ void packed_store(void* base, long long idx, float v) {
+  if (BF) reinterpret_cast<__bf16*>(base)[idx] = (__bf16)v;
+  else reinterpret_cast<float*>(base)[idx] = v;
+}
+template <bool BF> __host__ __device__ constexpr int kchunk() { return BF ? 32 : 16; }
 
 // acc[i][j] += A-tile i (16 rows) x B-tile j (16 rows)^T over `nch` packed chunks.
 // pa + i*sa / pb + j*sb point at this lane's float4 of chunk 0; consecutive chunks are 256 floats apart.
 // Chunk c belongs to wave (c % NW); each wave keeps PF chunks of loads in flight.
-template <int MB, int NB, int PF>
+template <bool BF, int MB, int NB, int PF>
 __device__ __forceinline__ void mfma_packed(f32x4 (&acc)[MB][NB], int nch, int wave, const float* __restrict__ pa, long long sa,
                                             const float* __restrict__ pb, long long sb) {
   f32x4 fa[PF][MB], fb[PF][NB];
@@ -86,13 +98,22 @@ __device__ __forceinline__ void mfma_packed(f32x4 (&acc)[MB][NB], int nch, int w
       for (int j = 0; j < NB; ++j) tb[j] = fb[p][j];
       load(fa[p], fb[p], c + (p + PF) * NW);
       if (c + p * NW < nch) {   // wave-uniform
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
+        if constexpr (BF) {
 #pragma unroll
           for (int i = 0; i < MB; ++i)
 #pragma unroll
             for (int j = 0; j < NB; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[i][e], tb[j][e], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ta[i]), __builtin_bit_cast(bf16x8, tb[j]),
+                                                                  acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+              for (int j = 0; j < NB; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[i][e], tb[j][e], acc[i][j], 0, 0, 0);
+        }
       }
     }
   }
@@ -103,7 +124,7 @@ __device__ __forceinline__ void mfma_packed(f32x4 (&acc)[MB][NB], int nch, int w
 // blockIdx.x = bt * nsl + slice: the batch tiles of one W_hh slice sit nsl blocks apart, i.e. on the
 // same XCD when nsl % 8 == 0, so each XCD's L2 holds every slice once.
 // ------------------------------------------------------------------------------------------
-template <int G, int MB>
+template <int G, int MB, bool BF>
 __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(RnnArgs a, int s) {
   __shared__ __attribute__((aligned(16))) f32x4 red[NW][MB * G][64];
   constexpr int NTHR = NW * 64;
@@ -113,7 +134,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(RnnArgs a, int s)
   const int slice = blockIdx.x % nsl, bt = blockIdx.x / nsl;
   const int j0 = slice * 16, b0 = bt * (16 * MB);
   const int T = a.T, B = a.B, H = a.H;
-  const int nch = (H + 15) >> 4;
+  const int nch = (H + kchunk<BF>() - 1) / kchunk<BF>();
   const int t = dir == 0 ? s : T - 1 - s;
   const int tp = dir == 0 ? t - 1 : t + 1;
   const bool has_prev = s > 0;
@@ -161,7 +182,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(RnnArgs a, int s)
   if (has_prev && !(a.dbg & 1)) {
     const float* pa = pk_in + ((long long)(bt * MB) * nch) * 256 + lane * 4;                      // + mb*nch*256 + c*256
     const float* pw = a.wp + ((((long long)dir * nsl + slice) * G) * nch) * 256 + lane * 4;         // + g*nch*256 + c*256
-    mfma_packed<MB, G, 4>(acc, nch, wave, pa, (long long)nch * 256, pw, (long long)nch * 256);
+    mfma_packed<BF, MB, G, 4>(acc, nch, wave, pa, (long long)nch * 256, pw, (long long)nch * 256);
   }
 #pragma unroll
   for (int i = 0; i < MB; ++i)
@@ -181,13 +202,13 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(RnnArgs a, int s)
     float* gx = a.gx + row * G * H + j;
     float* ho = a.hbuf + row * H + j;
     float* ax = a.aux + row * H + j;
-    float* hp = pk_out + packed_index(b, j, nch);
+    const long long hpi = packed_index<BF>(b, j, nch);
     if (!pvalid[i]) {
 #pragma unroll
       for (int g = 0; g < G; ++g) stnt(&gx[g * H], 0.f);
       stnt(ho, 0.f);
       stnt(ax, 0.f);
-      *hp = 0.f;
+      packed_store<BF>(pk_out, hpi, 0.f);
       continue;
     }
     float gh[G];
@@ -217,14 +238,14 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(RnnArgs a, int s)
       hnew = og * tanhf(c);
     }
     *ho = hnew;
-    *hp = hnew;
+    packed_store<BF>(pk_out, hpi, hnew);
   }
 }
 
 // ------------------------------------------------------------------------------------------
 // backward step (same grid mapping).  carry[b][j] = sum_k dGh[tq][b][k] * W_hh[k][j]
 // ------------------------------------------------------------------------------------------
-template <int G, int MB>
+template <int G, int MB, bool BF>
 __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(RnnArgs a, int s) {
   __shared__ __attribute__((aligned(16))) f32x4 red[NW][MB][64];
   constexpr int NTHR = NW * 64;
@@ -234,7 +255,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(RnnArgs a, int s)
   const int slice = blockIdx.x % nsl, bt = blockIdx.x / nsl;
   const int j0 = slice * 16, b0 = bt * (16 * MB);
   const int T = a.T, B = a.B, H = a.H;
-  const int nchb = (G * H + 15) >> 4;
+  const int nchb = (G * H + kchunk<BF>() - 1) / kchunk<BF>();
   const int t = dir == 0 ? T - 1 - s : s;          // reverse of the forward order
   const int tpf = dir == 0 ? t - 1 : t + 1;        // previous step in FORWARD order (h_{prev}, c_{prev})
   const bool has_q = s > 0;                        // a step was processed before us: its d-gates feed our carry
@@ -283,7 +304,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(RnnArgs a, int s)
   if (has_q && !(a.dbg & 1)) {
     const float* pa = pk_in + ((long long)(bt * MB) * nchb) * 256 + lane * 4;
     const float* pw = a.wp + (((long long)dir * nsl + slice) * nchb) * 256 + lane * 4;
-    mfma_packed<MB, 1, 6>(acc, nchb, wave, pa, (long long)nchb * 256, pw, 0);
+    mfma_packed<BF, MB, 1, 6>(acc, nchb, wave, pa, (long long)nchb * 256, pw, 0);
   }
 #pragma unroll
   for (int i = 0; i < MB; ++i) red[wave][i][lane] = acc[i][0];
@@ -340,33 +361,37 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(RnnArgs a, int s)
       }
     }
 #pragma unroll
-    for (int g = 0; g < G; ++g) pk_out[packed_index(b, g * H + j, nchb)] = dgh[g];
+    for (int g = 0; g < G; ++g) packed_store<BF>(pk_out, packed_index<BF>(b, g * H + j, nchb), dgh[g]);
   }
 }
 
-// W_hh (2, G*H, H) -> fwd-packed [2][nsl][G][nch][64][4] and bwd-packed [2][nsl][nchb][64][4]
-__global__ void rnn_pack_kernel(const float* __restrict__ whh, float* __restrict__ wpf, float* __restrict__ wpb, int G, int H) {
-  const int nsl = (H + 15) >> 4, nch = (H + 15) >> 4, nchb = (G * H + 15) >> 4;
-  const long long nf = (long long)2 * nsl * G * nch * 256, nb = (long long)2 * nsl * nchb * 256;
+// W_hh (2, G*H, H) -> fwd-packed [2][nsl][G][nch][64 lanes][16 B] and bwd-packed [2][nsl][nchb][64 lanes][16 B]
+template <bool BF>
+__global__ void rnn_pack_kernel(const float* __restrict__ whh, void* __restrict__ wpf, void* __restrict__ wpb, int G, int H) {
+  constexpr int KC = kchunk<BF>();
+  constexpr int EPL = BF ? 8 : 4;                 // elements per lane
+  const int nsl = (H + 15) >> 4, nch = (H + KC - 1) / KC, nchb = (G * H + KC - 1) / KC;
+  const long long nf = (long long)2 * nsl * G * nch * 64 * EPL, nb = (long long)2 * nsl * nchb * 64 * EPL;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nf + nb; i += stride) {
-    if (i < nf) {
-      const int e = i & 3, lane = (i >> 2) & 63;
-      long long r = i >> 8;
+    const bool fwd = i < nf;
+    const long long ii = fwd ? i : i - nf;
+    const int e = ii % EPL, lane = (ii / EPL) & 63;
+    long long r = ii / (64 * EPL);
+    float v;
+    if (fwd) {
       const int c = r % nch; r /= nch;
       const int g = r % G; r /= G;
       const int slice = r % nsl, dir = r / nsl;
-      const int j = slice * 16 + (lane & 15), k = c * 16 + (lane >> 4) * 4 + e;
-      wpf[i] = (j < H && k < H) ? whh[((long long)dir * G * H + g * H + j) * H + k] : 0.f;
+      const int j = slice * 16 + (lane & 15), k = c * KC + (lane >> 4) * EPL + e;
+      v = (j < H && k < H) ? whh[((long long)dir * G * H + g * H + j) * H + k] : 0.f;
     } else {
-      const long long ii = i - nf;
-      const int e = ii & 3, lane = (ii >> 2) & 63;
-      long long r = ii >> 8;
       const int c = r % nchb; r /= nchb;
       const int slice = r % nsl, dir = r / nsl;
-      const int j = slice * 16 + (lane & 15), k = c * 16 + (lane >> 4) * 4 + e;   // k = gate-unit row of W_hh
-      wpb[ii] = (j < H && k < G * H) ? whh[((long long)dir * G * H + k) * H + j] : 0.f;
+      const int j = slice * 16 + (lane & 15), k = c * KC + (lane >> 4) * EPL + e;   // k = gate-unit row of W_hh
+      v = (j < H && k < G * H) ? whh[((long long)dir * G * H + k) * H + j] : 0.f;
     }
+    packed_store<BF>(fwd ? wpf : wpb, ii, v);
   }
 }
 
@@ -376,7 +401,7 @@ inline int pick_mb(int B, int H) {
   return (B > 16 && (long long)nsl * ceil_div(B, 32) * 2 >= 200) ? 2 : 1;
 }
 
-template <int G>
+template <int G, bool BF>
 int launch_steps(bool bwd, RnnArgs a, hipStream_t st) {
   a.dbg = g_ds2_debug_flags;
   const int mb = pick_mb(a.B, a.H);
@@ -386,11 +411,11 @@ int launch_steps(bool bwd, RnnArgs a, hipStream_t st) {
   dim3 grid(a.nsl * nbt, 2), block(NW * 64);
   for (int s = 0; s < a.T; ++s) {
     if (!bwd) {
-      if (mb == 2) hipLaunchKernelGGL((rnn_fwd_step_kernel<G, 2>), grid, block, 0, st, a, s);
-      else hipLaunchKernelGGL((rnn_fwd_step_kernel<G, 1>), grid, block, 0, st, a, s);
+      if (mb == 2) hipLaunchKernelGGL((rnn_fwd_step_kernel<G, 2, BF>), grid, block, 0, st, a, s);
+      else hipLaunchKernelGGL((rnn_fwd_step_kernel<G, 1, BF>), grid, block, 0, st, a, s);
     } else {
-      if (mb == 2) hipLaunchKernelGGL((rnn_bwd_step_kernel<G, 2>), grid, block, 0, st, a, s);
-      else hipLaunchKernelGGL((rnn_bwd_step_kernel<G, 1>), grid, block, 0, st, a, s);
+      if (mb == 2) hipLaunchKernelGGL((rnn_bwd_step_kernel<G, 2, BF>), grid, block, 0, st, a, s);
+      else hipLaunchKernelGGL((rnn_bwd_step_kernel<G, 1, BF>), grid, block, 0, st, a, s);
     }
   }
   hipError_t e = hipGetLastError();
@@ -398,67 +423,76 @@ int launch_steps(bool bwd, RnnArgs a, hipStream_t st) {
   return 0;
 }
 
-size_t pk_floats(int B, int H, int kdim) {
+size_t pk_floats(int B, int H, int kdim, int bf16) {   // size in 4-byte units (1 chunk = 1 KiB = 256 units in both precisions)
   const int mb = pick_mb(B, H);
   const int nbt16 = ceil_div(B, 16 * mb) * mb;
-  return (size_t)2 * 2 * nbt16 * ceil_div(kdim, 16) * 256;
+  return (size_t)2 * 2 * nbt16 * ceil_div(kdim, bf16 ? 32 : 16) * 256;
+}
+
+template <bool BF>
+int dispatch(int gates, bool bwd, const RnnArgs& a, hipStream_t st) {
+  return gates == 3 ? launch_steps<3, BF>(bwd, a, st) : launch_steps<4, BF>(bwd, a, st);
 }
 
 }  // namespace
 
-// packed-weight sizes in floats: which = 0 forward operand, 1 backward operand
-extern "C" size_t ds2_rnn_packed_floats(int gates, int H, int which) {
+// packed-weight sizes in BYTES: which = 0 forward operand, 1 backward operand; bf16 = 0 | 1
+extern "C" size_t ds2_rnn_packed_bytes(int gates, int H, int which, int bf16) {
   const size_t nsl = (size_t)ceil_div(H, 16);
-  return which == 0 ? 2 * nsl * gates * ceil_div(H, 16) * 256 : 2 * nsl * ceil_div(gates * H, 16) * 256;
+  const int kc = bf16 ? 32 : 16;
+  return (which == 0 ? 2 * nsl * gates * ceil_div(H, kc) : 2 * nsl * ceil_div(gates * H, kc)) * 1024;
 }
 
-// Re-pack W_hh = [weight_hh_l0 ; weight_hh_l0_reverse] (2, G*H, H) into MFMA-fragment order (call after every
-// optimizer step / load_state_dict).  wp_fwd feeds ds2_rnn_fwd_f32, wp_bwd feeds ds2_rnn_bwd_f32.
-extern "C" int ds2_rnn_pack_whh_f32(int gates, const float* whh, float* wp_fwd, float* wp_bwd, int H, void* stream) {
-  DS2_REQUIRE(gates == 3 || gates == 4, "ds2_rnn_pack_whh_f32: gates must be 3 or 4");
-  DS2_REQUIRE(whh && wp_fwd && wp_bwd && H > 0 && (H % 4) == 0, "ds2_rnn_pack_whh_f32: bad args");
-  hipLaunchKernelGGL(rnn_pack_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, whh, wp_fwd, wp_bwd, gates, H);
+// Re-pack W_hh = [weight_hh_l0 ; weight_hh_l0_reverse] (2, G*H, H) fp32 into MFMA-fragment order, as fp32 (bf16 = 0) or
+// bf16 (bf16 = 1) fragments (call after every optimizer step / load_state_dict).
+extern "C" int ds2_rnn_pack_whh(int gates, const float* whh, void* wp_fwd, void* wp_bwd, int H, int bf16, void* stream) {
+  DS2_REQUIRE(gates == 3 || gates == 4, "ds2_rnn_pack_whh: gates must be 3 or 4");
+  DS2_REQUIRE(whh && wp_fwd && wp_bwd && H > 0 && (H % 4) == 0, "ds2_rnn_pack_whh: bad args");
+  if (bf16) hipLaunchKernelGGL(rnn_pack_kernel<true>, dim3(2048), dim3(256), 0, (hipStream_t)stream, whh, wp_fwd, wp_bwd, gates, H);
+  else hipLaunchKernelGGL(rnn_pack_kernel<false>, dim3(2048), dim3(256), 0, (hipStream_t)stream, whh, wp_fwd, wp_bwd, gates, H);
   DS2_LAUNCH_CHECK("rnn_pack_kernel");
   return 0;
 }
 
-extern "C" size_t ds2_rnn_fwd_workspace_bytes(int B, int H) { return pk_floats(B, H, H) * sizeof(float); }
+extern "C" size_t ds2_rnn_fwd_workspace_bytes(int B, int H, int bf16) { return pk_floats(B, H, H, bf16) * sizeof(float); }
 
-// gates: 3 = GRU (r,z,n), 4 = LSTM (i,f,g,o).
+// gates: 3 = GRU (r,z,n), 4 = LSTM (i,f,g,o).  bf16 = 1: the h W_hh^T product uses bf16 MFMA operands (fp32 accumulate;
+// h, c, gates stay fp32) and wp_fwd must have been packed with bf16 = 1.
 //   gx     (T,B,2,G*H)  in: X W_ih^T + b_ih for [fwd | reverse] ; out: activated gates (saved for backward)
-//   wp_fwd packed W_hh (ds2_rnn_pack_whh_f32), bhh (2,G*H) = [bias_hh_l0, bias_hh_l0_reverse]
+//   wp_fwd packed W_hh (ds2_rnn_pack_whh), bhh (2,G*H) = [bias_hh_l0, bias_hh_l0_reverse]
 //   hbuf   (T,B,2,H) out: h per direction (0 beyond each sample's length)
 //   aux    (T,B,2,H) out: GRU W_hn h + b_hn ; LSTM cell state
-extern "C" int ds2_rnn_fwd_f32(int gates, float* gx, const float* wp_fwd, const float* bhh, float* hbuf, float* aux,
-                               const int* lens_dev, int T, int B, int H, void* ws, size_t ws_bytes, void* stream) {
-  DS2_REQUIRE(gates == 3 || gates == 4, "ds2_rnn_fwd_f32: gates must be 3 (GRU) or 4 (LSTM)");
-  DS2_REQUIRE(gx && wp_fwd && bhh && hbuf && aux && lens_dev, "ds2_rnn_fwd_f32: null pointer");
-  DS2_REQUIRE(T > 0 && B > 0 && H > 0 && (H % 4) == 0, "ds2_rnn_fwd_f32: need H %% 4 == 0 (H=%d)", H);
-  DS2_REQUIRE(ws && ws_bytes >= ds2_rnn_fwd_workspace_bytes(B, H), "ds2_rnn_fwd_f32: workspace too small");
-  DS2_HIP(hipMemsetAsync(ws, 0, ds2_rnn_fwd_workspace_bytes(B, H), (hipStream_t)stream));   // zero padding rows / columns
+extern "C" int ds2_rnn_fwd(int gates, float* gx, const void* wp_fwd, const float* bhh, float* hbuf, float* aux, const int* lens_dev, int T,
+                           int B, int H, int bf16, void* ws, size_t ws_bytes, void* stream) {
+  DS2_REQUIRE(gates == 3 || gates == 4, "ds2_rnn_fwd: gates must be 3 (GRU) or 4 (LSTM)");
+  DS2_REQUIRE(gx && wp_fwd && bhh && hbuf && aux && lens_dev, "ds2_rnn_fwd: null pointer");
+  DS2_REQUIRE(T > 0 && B > 0 && H > 0 && (H % 4) == 0, "ds2_rnn_fwd: need H %% 4 == 0 (H=%d)", H);
+  DS2_REQUIRE(ws && ws_bytes >= ds2_rnn_fwd_workspace_bytes(B, H, bf16), "ds2_rnn_fwd: workspace too small");
+  DS2_HIP(hipMemsetAsync(ws, 0, ds2_rnn_fwd_workspace_bytes(B, H, bf16), (hipStream_t)stream));   // zero padding rows / columns
   RnnArgs a{};
-  a.gx = gx; a.aux = aux; a.hbuf = hbuf; a.wp = wp_fwd; a.bhh = bhh; a.pk = (float*)ws; a.lens = lens_dev; a.T = T; a.B = B; a.H = H;
-  return gates == 3 ? launch_steps<3>(false, a, (hipStream_t)stream) : launch_steps<4>(false, a, (hipStream_t)stream);
+  a.gx = gx; a.aux = aux; a.hbuf = hbuf; a.wp = (const float*)wp_fwd; a.bhh = bhh; a.pk = (float*)ws; a.lens = lens_dev;
+  a.T = T; a.B = B; a.H = H;
+  return bf16 ? dispatch<true>(gates, false, a, (hipStream_t)stream) : dispatch<false>(gates, false, a, (hipStream_t)stream);
 }
 
-extern "C" size_t ds2_rnn_bwd_workspace_bytes(int gates, int B, int H) {
-  return ((size_t)4 * B * H + pk_floats(B, H, gates * H)) * sizeof(float);
+extern "C" size_t ds2_rnn_bwd_workspace_bytes(int gates, int B, int H, int bf16) {
+  return ((size_t)4 * B * H + pk_floats(B, H, gates * H, bf16)) * sizeof(float);
 }
 
 //   dy     (T,B,H) pitch lddy: grad wrt y = h_fwd + h_bwd
 //   gx     in: gates from fwd ; out: grad wrt the x-projections (T,B,2,G*H)  (= dGx, feeds dW_ih, db_ih, dX)
 //   aux    GRU: in hn, out d(hn) [so that dGh = (dGx_r, dGx_z, aux)] ; LSTM: cell state (unchanged; dGh = dGx)
-//   wp_bwd packed W_hh^T (ds2_rnn_pack_whh_f32)
-extern "C" int ds2_rnn_bwd_f32(int gates, const float* dy, int lddy, float* gx, float* aux, const float* hbuf, const float* wp_bwd,
-                               const int* lens_dev, int T, int B, int H, void* ws, size_t ws_bytes, void* stream) {
-  DS2_REQUIRE(gates == 3 || gates == 4, "ds2_rnn_bwd_f32: gates must be 3 (GRU) or 4 (LSTM)");
-  DS2_REQUIRE(dy && gx && aux && hbuf && wp_bwd && lens_dev, "ds2_rnn_bwd_f32: null pointer");
-  DS2_REQUIRE(T > 0 && B > 0 && H > 0 && (H % 4) == 0, "ds2_rnn_bwd_f32: need H %% 4 == 0 (H=%d)", H);
-  DS2_REQUIRE(ws && ws_bytes >= ds2_rnn_bwd_workspace_bytes(gates, B, H), "ds2_rnn_bwd_f32: workspace too small");
-  DS2_HIP(hipMemsetAsync(ws, 0, ds2_rnn_bwd_workspace_bytes(gates, B, H), (hipStream_t)stream));
+//   wp_bwd packed W_hh^T (ds2_rnn_pack_whh)
+extern "C" int ds2_rnn_bwd(int gates, const float* dy, int lddy, float* gx, float* aux, const float* hbuf, const void* wp_bwd,
+                           const int* lens_dev, int T, int B, int H, int bf16, void* ws, size_t ws_bytes, void* stream) {
+  DS2_REQUIRE(gates == 3 || gates == 4, "ds2_rnn_bwd: gates must be 3 (GRU) or 4 (LSTM)");
+  DS2_REQUIRE(dy && gx && aux && hbuf && wp_bwd && lens_dev, "ds2_rnn_bwd: null pointer");
+  DS2_REQUIRE(T > 0 && B > 0 && H > 0 && (H % 4) == 0, "ds2_rnn_bwd: need H %% 4 == 0 (H=%d)", H);
+  DS2_REQUIRE(ws && ws_bytes >= ds2_rnn_bwd_workspace_bytes(gates, B, H, bf16), "ds2_rnn_bwd: workspace too small");
+  DS2_HIP(hipMemsetAsync(ws, 0, ds2_rnn_bwd_workspace_bytes(gates, B, H, bf16), (hipStream_t)stream));
   RnnArgs a{};
-  a.gx = gx; a.aux = aux; a.hbuf = const_cast<float*>(hbuf); a.wp = wp_bwd; a.dy = dy; a.lddy = lddy;
+  a.gx = gx; a.aux = aux; a.hbuf = const_cast<float*>(hbuf); a.wp = (const float*)wp_bwd; a.dy = dy; a.lddy = lddy;
   a.dcar = (float*)ws; a.pk = (float*)ws + (size_t)4 * B * H;
   a.lens = lens_dev; a.T = T; a.B = B; a.H = H;
-  return gates == 3 ? launch_steps<3>(true, a, (hipStream_t)stream) : launch_steps<4>(true, a, (hipStream_t)stream);
+  return bf16 ? dispatch<true>(gates, true, a, (hipStream_t)stream) : dispatch<false>(gates, true, a, (hipStream_t)stream);
 }

@@ -120,8 +120,9 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
             gx = ops.gemm_bf16_nt(ops.cast_bf16(xn), ops.cast_bf16(W[f"rnns.{l}.wih_cat"]), bias=W[f"rnns.{l}.bih_cat"])
         else:
             gx = ops.gemm(xn, W[f"rnns.{l}.wih_cat"], transB=True, bias=W[f"rnns.{l}.bih_cat"])  # (M, 2GH)
-        wpf, wpb = ops.rnn_pack(G, W[f"rnns.{l}.whh_cat"])
-        hbuf, aux = ops.rnn_fwd(G, gx, wpf, W[f"rnns.{l}.bhh_cat"], lens_dev, T, B, H)
+        bf = cfg.precision == "bf16"
+        wpf, wpb = ops.rnn_pack(G, W[f"rnns.{l}.whh_cat"], bf16=bf)
+        hbuf, aux = ops.rnn_fwd(G, gx, wpf, W[f"rnns.{l}.bhh_cat"], lens_dev, T, B, H, bf16=bf)
         lc.wpb = wpb
         nxt = f"rnns.{l + 1}.batch_norm.module" if l + 1 < L else "fc.0.module.0"
         y, mean, var = ops.add_colstats(hbuf[:, :H], hbuf[:, H:], *run(nxt))
@@ -168,7 +169,8 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
     for l in range(L - 1, -1, -1):
         lc = ctx.layers[l]
         I = lc.xn.shape[1]
-        ops.rnn_bwd(G, dy, lc.gx, lc.aux, lc.hbuf, lc.wpb, lens_dev, T, B, H)
+        bf = cfg.precision == "bf16"
+        ops.rnn_bwd(G, dy, lc.gx, lc.aux, lc.hbuf, lc.wpb, lens_dev, T, B, H, bf16=bf)
         dgx = lc.gx                                                                               # now dGx (M, 2GH)
         # bias grads
         dbih = Gr[f"rnns.{l}.bih_cat"]
@@ -179,7 +181,20 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
             dbhh[:, 2 * H:] = ops.colsum(lc.aux).view(2, H)
         # dW_hh[dir] = sum_t dGh[t]^T h_prev[t]  (h_prev = h[t-1] fwd / h[t+1] reverse)
         dwhh = Gr[f"rnns.{l}.whh_cat"]                                                            # (2, GH, H)
-        if T > 1:
+        dgxT = None
+        if T > 1 and bf and B % 8 == 0:
+            # bf16 MFMA path: transposed bf16 copies, the time shift is a column offset of B elements
+            dgxT = ops.cast_transpose_bf16(dgx)                                                   # (2GH, M)
+            hT = ops.cast_transpose_bf16(lc.hbuf)                                                 # (2H, M)
+            auxT = ops.cast_transpose_bf16(lc.aux) if G == 3 else None
+            rows = 2 * H if G == 3 else 4 * H
+            for d in range(2):
+                ka = slice(B, M) if d == 0 else slice(0, M - B)      # rows t of dGh
+                kb = slice(0, M - B) if d == 0 else slice(B, M)      # rows t-1 (fwd) / t+1 (reverse) of h
+                ops.gemm_bf16_nt(dgxT[d * G * H:d * G * H + rows, ka], hT[d * H:(d + 1) * H, kb], out=dwhh[d, :rows])
+                if G == 3:
+                    ops.gemm_bf16_nt(auxT[d * H:(d + 1) * H, ka], hT[d * H:(d + 1) * H, kb], out=dwhh[d, 2 * H:])
+        elif T > 1:
             K = (T - 1) * B
             ldg, ldh = 2 * G * H, 2 * H
             a0 = dgx.data_ptr() + 4 * (B * ldg)                 # dir 0: rows t >= 1
@@ -197,8 +212,10 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
         else:
             dwhh.zero_()
         # dW_ih (2GH, I) = dGx^T Xn ;  dXn = dGx W_ih
-        if cfg.precision == "bf16":
-            ops.gemm_bf16_nt(ops.cast_transpose_bf16(dgx), ops.cast_transpose_bf16(lc.xn), out=Gr[f"rnns.{l}.wih_cat"])
+        if bf:
+            if dgxT is None:
+                dgxT = ops.cast_transpose_bf16(dgx)
+            ops.gemm_bf16_nt(dgxT, ops.cast_transpose_bf16(lc.xn), out=Gr[f"rnns.{l}.wih_cat"])
             dxn = ops.gemm_bf16_nt(ops.cast_bf16(dgx), ops.cast_transpose_bf16(W[f"rnns.{l}.wih_cat"]))
         else:
             ops.gemm(dgx, lc.xn, transA=True, out=Gr[f"rnns.{l}.wih_cat"])

@@ -110,7 +110,7 @@ def cast_transpose_bf16(src: Tensor) -> Tensor:
 def gemm_bf16_nt(A: Tensor, B: Tensor, bias: Optional[Tensor] = None, out: Optional[Tensor] = None, accumulate: bool = False,
                  splitk: int = 0) -> Tensor:
     """out[M,N] fp32 (+)= A[M,K] @ B[N,K]^T, A/B bf16 with K (incl. zero padding) a multiple of 8."""
-    assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and A.is_cuda and B.is_cuda
+    assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and A.is_cuda and B.is_cuda and A.stride(1) == 1 and B.stride(1) == 1
     lib = _lib.load()
     M, K = A.shape
     N, Kb = B.shape
@@ -331,39 +331,40 @@ def conv2_wgrad(a1: Tensor, dy2: Tensor, lens_dev: Tensor, dW2: Tensor):
 # ------------------------------------------------------------------------------------------------
 # recurrence
 # ------------------------------------------------------------------------------------------------
-def rnn_pack(gates: int, whh: Tensor):
-    """W_hh (2, G*H, H) -> (wp_fwd, wp_bwd) in MFMA-fragment order (see csrc/rnn.hip)."""
+def rnn_pack(gates: int, whh: Tensor, bf16: bool = False):
+    """W_hh (2, G*H, H) fp32 -> (wp_fwd, wp_bwd) in MFMA-fragment order (fp32 or bf16 fragments; see csrc/rnn.hip)."""
     _chk_f32(whh)
     assert whh.is_contiguous() and whh.dim() == 3
     lib = _lib.load()
     H = whh.size(2)
-    wpf = torch.empty(lib.ds2_rnn_packed_floats(gates, H, 0), dtype=torch.float32, device=whh.device)
-    wpb = torch.empty(lib.ds2_rnn_packed_floats(gates, H, 1), dtype=torch.float32, device=whh.device)
-    _lib.check(lib.ds2_rnn_pack_whh_f32(gates, whh.data_ptr(), wpf.data_ptr(), wpb.data_ptr(), H, _stream()), "ds2_rnn_pack_whh_f32")
+    wpf = torch.empty(lib.ds2_rnn_packed_bytes(gates, H, 0, int(bf16)), dtype=torch.uint8, device=whh.device)
+    wpb = torch.empty(lib.ds2_rnn_packed_bytes(gates, H, 1, int(bf16)), dtype=torch.uint8, device=whh.device)
+    _lib.check(lib.ds2_rnn_pack_whh(gates, whh.data_ptr(), wpf.data_ptr(), wpb.data_ptr(), H, int(bf16), _stream()), "ds2_rnn_pack_whh")
     return wpf, wpb
 
 
-def rnn_fwd(gates: int, gx: Tensor, wp_fwd: Tensor, bhh: Tensor, lens_dev: Tensor, T: int, B: int, H: int):
+def rnn_fwd(gates: int, gx: Tensor, wp_fwd: Tensor, bhh: Tensor, lens_dev: Tensor, T: int, B: int, H: int, bf16: bool = False):
     """gx (T*B, 2*G*H) in/out; returns (hbuf (T*B, 2H), aux (T*B, 2H))."""
-    _chk_f32(gx, wp_fwd, bhh)
+    _chk_f32(gx, bhh)
     assert gx.is_contiguous() and bhh.is_contiguous()
     lib = _lib.load()
     hbuf = torch.empty(T * B, 2 * H, dtype=torch.float32, device=gx.device)
     aux = torch.empty_like(hbuf)
-    wsb = lib.ds2_rnn_fwd_workspace_bytes(B, H)
+    wsb = lib.ds2_rnn_fwd_workspace_bytes(B, H, int(bf16))
     ws = _ws(wsb, gx.device)
-    _lib.check(lib.ds2_rnn_fwd_f32(gates, gx.data_ptr(), wp_fwd.data_ptr(), bhh.data_ptr(), hbuf.data_ptr(), aux.data_ptr(),
-                                   lens_dev.data_ptr(), T, B, H, ws.data_ptr(), wsb, _stream()), "ds2_rnn_fwd_f32")
+    _lib.check(lib.ds2_rnn_fwd(gates, gx.data_ptr(), wp_fwd.data_ptr(), bhh.data_ptr(), hbuf.data_ptr(), aux.data_ptr(),
+                               lens_dev.data_ptr(), T, B, H, int(bf16), ws.data_ptr(), wsb, _stream()), "ds2_rnn_fwd")
     return hbuf, aux
 
 
-def rnn_bwd(gates: int, dy: Tensor, gx: Tensor, aux: Tensor, hbuf: Tensor, wp_bwd: Tensor, lens_dev: Tensor, T: int, B: int, H: int):
-    _chk_f32(dy, gx, aux, hbuf, wp_bwd)
+def rnn_bwd(gates: int, dy: Tensor, gx: Tensor, aux: Tensor, hbuf: Tensor, wp_bwd: Tensor, lens_dev: Tensor, T: int, B: int, H: int,
+            bf16: bool = False):
+    _chk_f32(dy, gx, aux, hbuf)
     lib = _lib.load()
-    wsb = lib.ds2_rnn_bwd_workspace_bytes(gates, B, H)
+    wsb = lib.ds2_rnn_bwd_workspace_bytes(gates, B, H, int(bf16))
     ws = _ws(wsb, gx.device)
-    _lib.check(lib.ds2_rnn_bwd_f32(gates, dy.data_ptr(), _row_pitch(dy), gx.data_ptr(), aux.data_ptr(), hbuf.data_ptr(), wp_bwd.data_ptr(),
-                                   lens_dev.data_ptr(), T, B, H, ws.data_ptr(), wsb, _stream()), "ds2_rnn_bwd_f32")
+    _lib.check(lib.ds2_rnn_bwd(gates, dy.data_ptr(), _row_pitch(dy), gx.data_ptr(), aux.data_ptr(), hbuf.data_ptr(), wp_bwd.data_ptr(),
+                               lens_dev.data_ptr(), T, B, H, int(bf16), ws.data_ptr(), wsb, _stream()), "ds2_rnn_bwd")
 
 
 # ------------------------------------------------------------------------------------------------

@@ -103,15 +103,16 @@ int ds2_conv2_wgrad_f32(const float* a1, const float* dy2, const int* lens_dev, 
 /* ---- bidirectional GRU / LSTM recurrence -------------------------------------------------------
  * pack_padded_sequence -> aten::gru / aten::lstm -> pad_packed_sequence, modules/blocks.py:87-89, h0 = 0,
  * gate order r,z,n (GRU) / i,f,g,o (LSTM); gates = 3 | 4.  See asr_amd/csrc/rnn.hip for buffer roles. */
-size_t ds2_rnn_packed_floats(int gates, int H, int which /*0: forward operand, 1: backward operand*/);
-/* re-pack W_hh = [weight_hh_l0 ; weight_hh_l0_reverse] (2,G*H,H) into MFMA-fragment order (once per optimizer step) */
-int ds2_rnn_pack_whh_f32(int gates, const float* whh, float* wp_fwd, float* wp_bwd, int H, void* stream);
-size_t ds2_rnn_fwd_workspace_bytes(int B, int H);
-int ds2_rnn_fwd_f32(int gates, float* gx, const float* wp_fwd, const float* bhh, float* hbuf, float* aux, const int* lens_dev, int T,
-                    int B, int H, void* ws, size_t ws_bytes, void* stream);
-size_t ds2_rnn_bwd_workspace_bytes(int gates, int B, int H);
-int ds2_rnn_bwd_f32(int gates, const float* dy, int lddy, float* gx, float* aux, const float* hbuf, const float* wp_bwd,
-                    const int* lens_dev, int T, int B, int H, void* ws, size_t ws_bytes, void* stream);
+size_t ds2_rnn_packed_bytes(int gates, int H, int which /*0: forward operand, 1: backward operand*/, int bf16);
+/* re-pack W_hh = [weight_hh_l0 ; weight_hh_l0_reverse] (2,G*H,H) fp32 into MFMA-fragment order, fp32 or bf16 fragments
+ * (once per optimizer step) */
+int ds2_rnn_pack_whh(int gates, const float* whh, void* wp_fwd, void* wp_bwd, int H, int bf16, void* stream);
+size_t ds2_rnn_fwd_workspace_bytes(int B, int H, int bf16);
+int ds2_rnn_fwd(int gates, float* gx, const void* wp_fwd, const float* bhh, float* hbuf, float* aux, const int* lens_dev, int T, int B,
+                int H, int bf16, void* ws, size_t ws_bytes, void* stream);
+size_t ds2_rnn_bwd_workspace_bytes(int gates, int B, int H, int bf16);
+int ds2_rnn_bwd(int gates, const float* dy, int lddy, float* gx, float* aux, const float* hbuf, const void* wp_bwd, const int* lens_dev,
+                int T, int B, int H, int bf16, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- log-softmax + CTC loss + gradient ---------------------------------------------------------
  * out.float().log_softmax(2) + torch.nn.CTCLoss(reduction="sum") and their backward,

@@ -207,9 +207,11 @@ def test_conv_fwd_bwd(dev, B, Tin, lens_in):
 
 
 # ---------------------------------------------------------------------------------------------- RNN
+@pytest.mark.parametrize("bf", [False, True])
 @pytest.mark.parametrize("kind,H,B,T,lens", [("gru", 32, 3, 9, [9, 6, 2]), ("lstm", 24, 3, 9, [9, 6, 2]), ("gru", 72, 20, 17, None),
                                              ("lstm", 40, 37, 11, None), ("gru", 16, 1, 5, [5])])
-def test_rnn_fwd_bwd(dev, kind, H, B, T, lens):
+def test_rnn_fwd_bwd(dev, kind, H, B, T, lens, bf):
+    tol = 3e-2 if bf else 1.0      # bf16 operands in the h W_hh product: separately stated tolerance (x the fp32 asserts' 2e-5..5e-5 -> 2e-2)
     from asr_amd import ops
     G = 3 if kind == "gru" else 4
     if lens is None:
@@ -230,14 +232,16 @@ def test_rnn_fwd_bwd(dev, kind, H, B, T, lens):
     ld = g(lens_t, dev)
     gxd = g(gx.detach().float().reshape(T * B, 2 * G * H), dev).clone()
     whd, bhd = g(whh.detach().float(), dev), g(bhh.detach().float(), dev)
-    wpf, wpb = ops.rnn_pack(G, whd)
-    hbuf, aux = ops.rnn_fwd(G, gxd, wpf, bhd, ld, T, B, H)
+    wpf, wpb = ops.rnn_pack(G, whd, bf16=bf)
+    hbuf, aux = ops.rnn_fwd(G, gxd, wpf, bhd, ld, T, B, H, bf16=bf)
     hb = hbuf.view(T, B, 2, H).cpu()
-    assert rel_l2(hb[:, :, 0], yf.detach()) < 2e-5 and rel_l2(hb[:, :, 1], yb.detach()) < 2e-5
+    e1 = 2e-2 if bf else 2e-5
+    e2 = 5e-2 if bf else 5e-5
+    assert rel_l2(hb[:, :, 0], yf.detach()) < e1 and rel_l2(hb[:, :, 1], yb.detach()) < e1
     ysum, _, _ = ops.add_colstats(hbuf[:, :H], hbuf[:, H:])
-    assert rel_l2(ysum.view(T, B, H).cpu(), y.detach()) < 2e-5
-    ops.rnn_bwd(G, g(dy.float().reshape(T * B, H), dev), gxd, aux, hbuf, wpb, ld, T, B, H)
-    assert rel_l2(gxd.view(T, B, 2, G * H).cpu(), gx.grad) < 5e-5          # dGx
+    assert rel_l2(ysum.view(T, B, H).cpu(), y.detach()) < e1
+    ops.rnn_bwd(G, g(dy.float().reshape(T * B, H), dev), gxd, aux, hbuf, wpb, ld, T, B, H, bf16=bf)
+    assert rel_l2(gxd.view(T, B, 2, G * H).cpu(), gx.grad) < e2          # dGx
     # dW_hh / db_hh from the saved buffers exactly as engine.backward assembles them
     dgx = gxd
     dwhh = torch.zeros(2, G * H, H, device=dev)
@@ -255,12 +259,12 @@ def test_rnn_fwd_bwd(dev, kind, H, B, T, lens):
             x1 = aux.data_ptr() + 4 * H
             ops.gemm_raw(True, False, H, H, K, x0, ldh, (x1 - x0) // 4, b0, ldh, (b1 - b0) // 4, dwhh.data_ptr() + 4 * (2 * H * H), H,
                          G * H * H, dev, batch=2)
-    assert rel_l2(dwhh.cpu(), whh.grad) < 5e-5
+    assert rel_l2(dwhh.cpu(), whh.grad) < e2
     dbih = ops.colsum(dgx).view(2, G * H)
     dbhh = dbih.clone()
     if G == 3:
         dbhh[:, 2 * H:] = ops.colsum(aux).view(2, H)
-    assert rel_l2(dbhh.cpu(), bhh.grad) < 5e-5
+    assert rel_l2(dbhh.cpu(), bhh.grad) < e2
 
 
 # ---------------------------------------------------------------------------------------------- CTC
