@@ -37,6 +37,38 @@ struct ConvArgs {
   int OS, OO;         // out_row = OS*o + OO
 };
 
+__device__ __attribute__((aligned(16))) float g_zero_conv[4] = {0.f, 0.f, 0.f, 0.f};   // global-address-space zero page
+
+// Stage `NROWS` input rows of ROWLEN floats (rows kd0.. of channel ci, window starting at ST*t0 - PT) into LDS.
+// Loads are issued in unrolled batches with out-of-range elements redirected to a zero page (pointer select, no
+// branch), so each batch costs ONE memory round trip instead of one per element.
+template <int NROWS, int ROWLEN, int ROWP, int ST>
+__device__ __forceinline__ void stage_rows(float* __restrict__ lds, const float* __restrict__ in_bc /* in + (b*Cin+ci)*Din*Tin */,
+                                           int Din, int Tin, int frow0 /* input row of local row 0 */, int nvalid_rows, int tstart) {
+  constexpr int TOTAL = NROWS * ROWLEN;
+  constexpr int NIT = (TOTAL + 255) / 256;
+  constexpr int BATCH = 12;
+#pragma unroll
+  for (int n0 = 0; n0 < NIT; n0 += BATCH) {
+    float v[BATCH];
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      const int idx = threadIdx.x + 256 * (n0 + u);
+      const int kdl = idx / ROWLEN, i = idx - kdl * ROWLEN;
+      const int f = frow0 + kdl, ti = tstart + i;
+      const bool ok = (n0 + u < NIT) && idx < TOTAL && kdl < nvalid_rows && f >= 0 && f < Din && ti >= 0 && ti < Tin;
+      const float* p = ok ? in_bc + (long long)f * Tin + ti : g_zero_conv;
+      v[u] = *p;
+    }
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      const int idx = threadIdx.x + 256 * (n0 + u);
+      const int kdl = idx / ROWLEN, i = idx - kdl * ROWLEN;
+      if ((n0 + u < NIT) && idx < TOTAL) lds[kdl * ROWP + i] = v[u];
+    }
+  }
+}
+
 template <int KDC, int KT, int ST>
 struct ConvGeom {
   static constexpr int ROWLEN = ST * TT + KT - 1;
@@ -77,17 +109,23 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
   for (int st = 0; st < NS; ++st) {
     const int ci = st / a.SPC, kd0 = (st % a.SPC) * KDC;
     __syncthreads();
-    for (int idx = tid; idx < KDC * G::ROWLEN; idx += 256) {
-      const int kdl = idx / G::ROWLEN, i = idx % G::ROWLEN;
-      const int f = a.SD * o + (kd0 + kdl) - a.PD;
-      const int ti = ST * t0 + i - a.PT;
-      float v = 0.f;
-      if (kd0 + kdl < a.KD && f >= 0 && f < a.Din && ti >= 0 && ti < a.Tin)
-        v = a.in[(((long long)b * a.Cin + ci) * a.Din + f) * a.Tin + ti];
-      in_lds[kdl * G::ROWP + i] = v;
+    stage_rows<KDC, G::ROWLEN, G::ROWP, ST>(in_lds, a.in + ((long long)b * a.Cin + ci) * a.Din * a.Tin, a.Din, a.Tin,
+                                            a.SD * o + kd0 - a.PD, a.KD - kd0, ST * t0 - a.PT);
+    {
+      const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.wpk + (long long)st * G::KK2 * CO);
+      constexpr int NW4 = G::KK2 * CO / 4, WIT = (NW4 + 255) / 256;
+      f32x4 wv[WIT];
+#pragma unroll
+      for (int u = 0; u < WIT; ++u) {
+        const int idx = tid + 256 * u;
+        wv[u] = wsrc[idx < NW4 ? idx : 0];
+      }
+#pragma unroll
+      for (int u = 0; u < WIT; ++u) {
+        const int idx = tid + 256 * u;
+        if (idx < NW4) reinterpret_cast<f32x4*>(w_lds)[idx] = wv[u];
+      }
     }
-    const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.wpk + (long long)st * G::KK2 * CO);
-    for (int idx = tid; idx < G::KK2 * CO / 4; idx += 256) reinterpret_cast<f32x4*>(w_lds)[idx] = wsrc[idx];
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < G::KK2 / 2; ++s) {
@@ -156,24 +194,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const int len = a.lens ? min(a.lens[b], a.Tout) : a.Tout;
     for (int t0 = 0; t0 < len; t0 += TT) {
       __syncthreads();
-      for (int idx = tid; idx < CO * TT; idx += 256) {
-        const int co = idx / TT, i = idx % TT;
-        const int t = t0 + i;
-        dy_lds[co * LDY + i] = (t < a.Tout) ? a.dy[(((long long)b * CO + co) * a.Dy + o) * a.Tout + t] : 0.f;
-      }
-      for (int idx = tid; idx < SPB * KDC * G::ROWLEN; idx += 256) {
-        const int sl = idx / (KDC * G::ROWLEN), rem = idx % (KDC * G::ROWLEN);
-        const int kdl = rem / G::ROWLEN, i = rem % G::ROWLEN;
-        const int st = grp * SPB + sl;
-        float v = 0.f;
-        if (st < NS) {
-          const int ci = st / a.SPC, kd = (st % a.SPC) * KDC + kdl;
-          const int f = a.SD * o + kd - a.PD;
-          const int ti = ST * t0 + i - a.PT;
-          if (kd < a.KD && f >= 0 && f < a.Din && ti >= 0 && ti < a.Tin)
-            v = a.in[(((long long)b * a.Cin + ci) * a.Din + f) * a.Tin + ti];
+      {   // dy tile: 32 rows (co) x TT, rows are D*T apart
+        constexpr int NIT = CO * TT / 256;   // 16
+        float v[NIT];
+        const float* dyb = a.dy + (((long long)b * CO) * a.Dy + o) * a.Tout;
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+          const int idx = tid + 256 * u;
+          const int co = idx / TT, i = idx % TT;
+          const int t = t0 + i;
+          const float* p = (t < a.Tout) ? dyb + (long long)co * a.Dy * a.Tout + t : g_zero_conv;
+          v[u] = *p;
         }
-        in_lds[(sl * KDC + kdl) * G::ROWP + i] = v;
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+          const int idx = tid + 256 * u;
+          dy_lds[(idx / TT) * LDY + (idx % TT)] = v[u];
+        }
+      }
+#pragma unroll
+      for (int sl = 0; sl < SPB; ++sl) {
+        const int st = grp * SPB + sl;
+        const int ci = (st < NS) ? st / a.SPC : 0, kd0 = (st < NS) ? (st % a.SPC) * KDC : 0;
+        stage_rows<KDC, G::ROWLEN, G::ROWP, ST>(in_lds + sl * KDC * G::ROWP, a.in + ((long long)b * a.Cin + ci) * a.Din * a.Tin, a.Din, a.Tin,
+                                                a.SD * o + kd0 - a.PD, (st < NS) ? a.KD - kd0 : 0, ST * t0 - a.PT);
       }
       __syncthreads();
 #pragma unroll 4

@@ -8,6 +8,7 @@ Works on any backend: `nccl` (= RCCL over xGMI on ROCm) on GPUs, `gloo` on CPU t
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -20,6 +21,9 @@ class BucketedAllReducer:
         self.buckets: Dict[str, Tuple[int, int]] = {n: (a, b) for n, a, b in buckets}
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # DS2_FORCE_ALLREDUCE=1: run the bucketed all-reduce even with a single rank (exercises the RCCL / side-stream
+        # path on a 1-GPU box; a 1-rank SUM is the identity)
+        self.force = dist.is_initialized() and os.environ.get("DS2_FORCE_ALLREDUCE") == "1"
         self.use_stream = flat_grad.is_cuda
         self.comm_stream = torch.cuda.Stream(device=flat_grad.device) if self.use_stream else None
         self._pending = []
@@ -27,7 +31,7 @@ class BucketedAllReducer:
 
     def on_bucket(self, name: str):
         """Called by engine.backward when bucket `name`'s gradient kernels are enqueued."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         a, b = self.buckets[name]
         view = self.flat_grad[a:b]
