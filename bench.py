@@ -32,6 +32,7 @@ WORKLOADS = {
     "c2": ("gru", 768, 5, 29, 32, 1001),
     "c1": ("gru", 256, 2, 29, 4, 201),
     "c4": ("lstm", 1280, 7, 29, 32, 1501),
+    "c5": ("gru", 1024, 5, 80, 64, 2001),       # ragged 3-20 s (T_b ~ U{301..2001}), length-sorted, ~80 kana classes
 }
 FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, dense f32-input matrix rate
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # same guide: dense bf16 MFMA (the 5 PF marketing figure is 2:1 sparse)
@@ -61,13 +62,20 @@ def label_file(tmp, n):
     return path
 
 
-def synthetic_batch(B, tin, C, seed):
+def synthetic_batch(B, tin, C, seed, ragged=False):
+    """Collated batch in the reference's contract (functional.py:9-32).  ragged: T_b ~ U{301..tin}, sorted descending."""
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(B, 1, 161, tin, generator=g)
-    pct = torch.ones(B, dtype=torch.float32)
-    U = tin // 20
-    targets = torch.randint(1, C, (B * U,), generator=torch.Generator().manual_seed(seed + 1), dtype=torch.int32)
-    tsz = torch.full((B,), U, dtype=torch.int32)
+    if ragged:
+        tb = torch.randint(301, tin + 1, (B,), generator=g).sort(descending=True).values
+        tb[0] = tin
+    else:
+        tb = torch.full((B,), tin)
+    for i in range(B):
+        x[i, :, :, int(tb[i]):] = 0.0
+    pct = torch.tensor([int(t) / float(tin) for t in tb], dtype=torch.float32)
+    tsz = (tb // 20).to(torch.int32)
+    targets = torch.randint(1, C, (int(tsz.sum()),), generator=torch.Generator().manual_seed(seed + 1), dtype=torch.int32)
     return x, targets, pct, tsz
 
 
@@ -182,7 +190,7 @@ def main():
     model.precision = "bf16" if dtype == "bf16" else "fp32"
     opt = FusedAdamW(model, lr=1.5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5)
     tr = DeepSpeechTrainer(model, CTCLoss(reduction="sum"), 1, None, opt, None, None, dev, dev, False, None)
-    x, targets, pct, tsz = synthetic_batch(B, tin, C, 1 + rank)
+    x, targets, pct, tsz = synthetic_batch(B, tin, C, 1 + rank, ragged=(args.workload == "c5"))
     x = x.to(dev)                                     # inputs resident in HBM before the timed region
 
     def one_step():
@@ -238,7 +246,7 @@ def main():
         breakdown(model, tr, x, targets, pct, tsz)
 
     if rank == 0:
-        step_flops = train_flops_per_utt(rnn, H, L, C, T) * B
+        step_flops = sum(train_flops_per_utt(rnn, H, L, C, (int(round(float(p) * tin)) + 1) // 2) for p in pct)
         out = {
             "metric": "utterances/sec (10 s, 161-bin) DS2 5x1024 BiGRU CTC train step" if args.workload == "c3"
                       else f"utterances/sec DS2 {L}x{H} bi-{rnn} CTC train step",
