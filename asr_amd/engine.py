@@ -20,6 +20,16 @@ import torch
 from . import _lib, ops
 
 Tensor = torch.Tensor
+import os as _os
+OVERLAP_WGRAD = _os.environ.get("DS2_OVERLAP", "0") == "1"   # measured: a slight net loss on MI355X, keep opt-in
+_SIDE = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
 
 
 @dataclass
@@ -93,7 +103,12 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
     else:
         m1, v1 = W[cp + "1.running_mean"], W[cp + "1.running_var"]
     a1 = ops.bn2d_act_fwd(y1, lens_dev, m1, v1, W[cp + "1.weight"], W[cp + "1.bias"])
-    y2 = ops.conv2_fwd(a1, wpk2, W[cp + "3.bias"], lens_dev)
+    if cfg.precision == "bf16":
+        cwf, cwd0, cwd1 = ops.conv2_pack_bf16(W[cp + "3.weight"])
+        ctx.packs = (wpk2d, cwd0, cwd1)
+        y2 = ops.conv2_fwd_bf16(ops.nhwc_bf16(a1), cwf, W[cp + "3.bias"], lens_dev)
+    else:
+        y2 = ops.conv2_fwd(a1, wpk2, W[cp + "3.bias"], lens_dev)
     if training:
         m2, v2 = ops.bn2d_stats(y2, *run(cp + "4"))
     else:
@@ -153,6 +168,11 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
     communication overlaps the rest of the backward pass."""
     done = on_bucket if on_bucket is not None else (lambda name: None)
     G, H, L, Cn = cfg.gates, cfg.hidden, cfg.layers, cfg.classes
+    # Weight gradients (dW_ih, dW_hh and their casts) are not on the critical path of backward: they run on a side
+    # stream and fill the CUs the latency-bound recurrent step kernels of the NEXT layer leave idle.
+    main = torch.cuda.current_stream()
+    side = _side_stream(dlogits.device) if OVERLAP_WGRAD else main
+    keep = []      # tensors used on the side stream must outlive it (caching-allocator reuse is per stream)
     B, T, D1, D2 = ctx.B, ctx.T, ctx.D1, ctx.D2
     M = T * B
     lens_dev = ctx.lens_dev
@@ -172,54 +192,63 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
         bf = cfg.precision == "bf16"
         ops.rnn_bwd(G, dy, lc.gx, lc.aux, lc.hbuf, lc.wpb, lens_dev, T, B, H, bf16=bf)
         dgx = lc.gx                                                                               # now dGx (M, 2GH)
-        # bias grads
-        dbih = Gr[f"rnns.{l}.bih_cat"]
-        dbih.copy_(ops.colsum(dgx))
-        dbhh = Gr[f"rnns.{l}.bhh_cat"]                                                            # (2, GH)
-        dbhh.copy_(dbih.view(2, G * H))
-        if G == 3:
-            dbhh[:, 2 * H:] = ops.colsum(lc.aux).view(2, H)
-        # dW_hh[dir] = sum_t dGh[t]^T h_prev[t]  (h_prev = h[t-1] fwd / h[t+1] reverse)
-        dwhh = Gr[f"rnns.{l}.whh_cat"]                                                            # (2, GH, H)
-        dgxT = None
-        if T > 1 and bf and B % 8 == 0:
-            # bf16 MFMA path: transposed bf16 copies, the time shift is a column offset of B elements
-            dgxT = ops.cast_transpose_bf16(dgx)                                                   # (2GH, M)
-            hT = ops.cast_transpose_bf16(lc.hbuf)                                                 # (2H, M)
-            auxT = ops.cast_transpose_bf16(lc.aux) if G == 3 else None
-            rows = 2 * H if G == 3 else 4 * H
-            for d in range(2):
-                ka = slice(B, M) if d == 0 else slice(0, M - B)      # rows t of dGh
-                kb = slice(0, M - B) if d == 0 else slice(B, M)      # rows t-1 (fwd) / t+1 (reverse) of h
-                ops.gemm_bf16_nt(dgxT[d * G * H:d * G * H + rows, ka], hT[d * H:(d + 1) * H, kb], out=dwhh[d, :rows])
-                if G == 3:
-                    ops.gemm_bf16_nt(auxT[d * H:(d + 1) * H, ka], hT[d * H:(d + 1) * H, kb], out=dwhh[d, 2 * H:])
-        elif T > 1:
-            K = (T - 1) * B
-            ldg, ldh = 2 * G * H, 2 * H
-            a0 = dgx.data_ptr() + 4 * (B * ldg)                 # dir 0: rows t >= 1
-            b0 = lc.hbuf.data_ptr()                             #        h[t-1]
-            a1 = dgx.data_ptr() + 4 * (G * H)                   # dir 1: rows t <= T-2, column block of dir 1
-            b1 = lc.hbuf.data_ptr() + 4 * (H + B * ldh)         #        h[t+1]
-            sA, sB = (a1 - a0) // 4, (b1 - b0) // 4
-            rows = 2 * H if G == 3 else 4 * H
-            ops.gemm_raw(True, False, rows, H, K, a0, ldg, sA, b0, ldh, sB, dwhh.data_ptr(), H, G * H * H, dgx.device, batch=2)
-            if G == 3:  # n-gate rows use d(hn) (aux) instead of dGx_n
-                x0 = lc.aux.data_ptr() + 4 * (B * ldh)
-                x1 = lc.aux.data_ptr() + 4 * H
-                ops.gemm_raw(True, False, H, H, K, x0, ldh, (x1 - x0) // 4, b0, ldh, sB, dwhh.data_ptr() + 4 * (2 * H * H), H,
-                             G * H * H, dgx.device, batch=2)
-        else:
-            dwhh.zero_()
-        # dW_ih (2GH, I) = dGx^T Xn ;  dXn = dGx W_ih
+        # ---- critical path: dXn = dGx W_ih (feeds the next layer's backward) ---------------------------------------
         if bf:
-            if dgxT is None:
-                dgxT = ops.cast_transpose_bf16(dgx)
-            ops.gemm_bf16_nt(dgxT, ops.cast_transpose_bf16(lc.xn), out=Gr[f"rnns.{l}.wih_cat"])
             dxn = ops.gemm_bf16_nt(ops.cast_bf16(dgx), ops.cast_transpose_bf16(W[f"rnns.{l}.wih_cat"]))
         else:
-            ops.gemm(dgx, lc.xn, transA=True, out=Gr[f"rnns.{l}.wih_cat"])
             dxn = ops.gemm(dgx, W[f"rnns.{l}.wih_cat"])                                           # (M, I)
+        # ---- off the critical path: bias and weight gradients ------------------------------------------------------
+        side.wait_stream(main)
+        keep.append((dgx, lc.aux, lc.hbuf, lc.xn))
+        with torch.cuda.stream(side):
+            dbih = Gr[f"rnns.{l}.bih_cat"]
+            dbih.copy_(ops.colsum(dgx))
+            dbhh = Gr[f"rnns.{l}.bhh_cat"]                                                        # (2, GH)
+            dbhh.copy_(dbih.view(2, G * H))
+            if G == 3:
+                dbhh[:, 2 * H:] = ops.colsum(lc.aux).view(2, H)
+            # dW_hh[dir] = sum_t dGh[t]^T h_prev[t]  (h_prev = h[t-1] fwd / h[t+1] reverse)
+            dwhh = Gr[f"rnns.{l}.whh_cat"]                                                        # (2, GH, H)
+            dgxT = None
+            if T > 1 and bf and B % 8 == 0:
+                # bf16 MFMA path: transposed bf16 copies, the time shift is a column offset of B elements
+                dgxT = ops.cast_transpose_bf16(dgx)                                               # (2GH, M)
+                hT = ops.cast_transpose_bf16(lc.hbuf)                                             # (2H, M)
+                auxT = ops.cast_transpose_bf16(lc.aux) if G == 3 else None
+                rows = 2 * H if G == 3 else 4 * H
+                for d in range(2):
+                    ka = slice(B, M) if d == 0 else slice(0, M - B)      # rows t of dGh
+                    kb = slice(0, M - B) if d == 0 else slice(B, M)      # rows t-1 (fwd) / t+1 (reverse) of h
+                    ops.gemm_bf16_nt(dgxT[d * G * H:d * G * H + rows, ka], hT[d * H:(d + 1) * H, kb], out=dwhh[d, :rows])
+                    if G == 3:
+                        ops.gemm_bf16_nt(auxT[d * H:(d + 1) * H, ka], hT[d * H:(d + 1) * H, kb], out=dwhh[d, 2 * H:])
+                keep.append((dgxT, hT, auxT))
+            elif T > 1:
+                K = (T - 1) * B
+                ldg, ldh = 2 * G * H, 2 * H
+                a0 = dgx.data_ptr() + 4 * (B * ldg)                 # dir 0: rows t >= 1
+                b0 = lc.hbuf.data_ptr()                             #        h[t-1]
+                a1 = dgx.data_ptr() + 4 * (G * H)                   # dir 1: rows t <= T-2, column block of dir 1
+                b1 = lc.hbuf.data_ptr() + 4 * (H + B * ldh)         #        h[t+1]
+                sA, sB = (a1 - a0) // 4, (b1 - b0) // 4
+                rows = 2 * H if G == 3 else 4 * H
+                ops.gemm_raw(True, False, rows, H, K, a0, ldg, sA, b0, ldh, sB, dwhh.data_ptr(), H, G * H * H, dgx.device, batch=2)
+                if G == 3:  # n-gate rows use d(hn) (aux) instead of dGx_n
+                    x0 = lc.aux.data_ptr() + 4 * (B * ldh)
+                    x1 = lc.aux.data_ptr() + 4 * H
+                    ops.gemm_raw(True, False, H, H, K, x0, ldh, (x1 - x0) // 4, b0, ldh, sB, dwhh.data_ptr() + 4 * (2 * H * H), H,
+                                 G * H * H, dgx.device, batch=2)
+            else:
+                dwhh.zero_()
+            # dW_ih (2GH, I) = dGx^T Xn
+            if bf:
+                if dgxT is None:
+                    dgxT = ops.cast_transpose_bf16(dgx)
+                xnT = ops.cast_transpose_bf16(lc.xn)
+                ops.gemm_bf16_nt(dgxT, xnT, out=Gr[f"rnns.{l}.wih_cat"])
+                keep.append((dgxT, xnT))
+            else:
+                ops.gemm(dgx, lc.xn, transA=True, out=Gr[f"rnns.{l}.wih_cat"])
         lc.gx = lc.aux = lc.hbuf = lc.xn = lc.wpb = None
         if l > 0:
             bp = f"rnns.{l}.batch_norm.module."
@@ -227,7 +256,10 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
         else:
             dy = dxn
         del dxn
-        done(f"rnns.{l}")
+        if side is not main:
+            side.wait_stream(main)          # the bucket also holds this layer's BN grads (main stream)
+        with torch.cuda.stream(side):
+            done(f"rnns.{l}")
     # ---- conv stack -----------------------------------------------------------------------------
     cp = "conv.seq_module."
     da2 = ops.transpose_bft(dy, B, 32 * D2, T, to_tbf=False).view(B, 32, D2, T)
@@ -236,7 +268,10 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
     del da2
     Gr[cp + "3.bias"].copy_(ops.chan_sum(dy2))
     ops.conv2_wgrad(ctx.a1, dy2, lens_dev, Gr[cp + "3.weight"])
-    da1 = ops.conv2_dgrad(dy2, ctx.packs[0], D1)
+    if cfg.precision == "bf16":
+        da1 = ops.conv2_dgrad_bf16(ops.nhwc_bf16(dy2), ctx.packs[1], ctx.packs[2], D1)
+    else:
+        da1 = ops.conv2_dgrad(dy2, ctx.packs[0], D1)
     del dy2
     m1, v1 = ctx.st1
     dy1 = ops.bn2d_act_bwd(ctx.y1, da1, lens_dev, m1, v1, W[cp + "1.weight"], W[cp + "1.bias"], Gr[cp + "1.weight"], Gr[cp + "1.bias"])
@@ -244,3 +279,6 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
     Gr[cp + "0.bias"].copy_(ops.chan_sum(dy1))
     ops.conv1_wgrad(ctx.x, dy1, lens_dev, Gr[cp + "0.weight"])
     done("conv")
+    if side is not main:
+        main.wait_stream(side)              # all weight gradients are final for whoever runs next on the main stream
+    keep.clear()

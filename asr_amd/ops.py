@@ -328,6 +328,42 @@ def conv2_wgrad(a1: Tensor, dy2: Tensor, lens_dev: Tensor, dW2: Tensor):
                                        wsb, _stream()), "ds2_conv2_wgrad_f32")
 
 
+def conv2_pack_bf16(w2: Tensor):
+    _chk_f32(w2)
+    lib = _lib.load()
+    bufs = [torch.empty(lib.ds2_conv2_bf16_packed_bytes(i), dtype=torch.uint8, device=w2.device) for i in range(3)]
+    _lib.check(lib.ds2_conv2_pack_bf16(w2.data_ptr(), bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr(), _stream()),
+               "ds2_conv2_pack_bf16")
+    return tuple(bufs)
+
+
+def nhwc_bf16(x: Tensor) -> Tensor:
+    """(B,32,D,T) fp32 -> (B,D,T,32) bf16 channels-last."""
+    _chk_f32(x)
+    B, Cc, D, T = x.shape
+    assert Cc == 32 and x.is_contiguous()
+    out = torch.empty(B, D, T, 32, dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.load().ds2_nhwc_bf16_f32(x.data_ptr(), out.data_ptr(), B, D, T, _stream()), "ds2_nhwc_bf16_f32")
+    return out
+
+
+def conv2_fwd_bf16(a1_nhwc: Tensor, wf: Tensor, bias: Tensor, lens_dev: Tensor) -> Tensor:
+    B, D1, T, _ = a1_nhwc.shape
+    D2 = (D1 + 20 - 21) // 2 + 1
+    y2 = torch.empty(B, 32, D2, T, dtype=torch.float32, device=a1_nhwc.device)
+    _lib.check(_lib.load().ds2_conv2_fwd_bf16(a1_nhwc.data_ptr(), wf.data_ptr(), bias.data_ptr(), lens_dev.data_ptr(), y2.data_ptr(), B, D1, T,
+                                              _stream()), "ds2_conv2_fwd_bf16")
+    return y2
+
+
+def conv2_dgrad_bf16(dy2_nhwc: Tensor, wd0: Tensor, wd1: Tensor, D1: int) -> Tensor:
+    B, D2, T, _ = dy2_nhwc.shape
+    da1 = torch.empty(B, 32, D1, T, dtype=torch.float32, device=dy2_nhwc.device)
+    _lib.check(_lib.load().ds2_conv2_dgrad_bf16(dy2_nhwc.data_ptr(), wd0.data_ptr(), wd1.data_ptr(), da1.data_ptr(), B, D1, T, _stream()),
+               "ds2_conv2_dgrad_bf16")
+    return da1
+
+
 # ------------------------------------------------------------------------------------------------
 # recurrence
 # ------------------------------------------------------------------------------------------------

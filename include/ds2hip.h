@@ -100,6 +100,15 @@ int ds2_conv1_wgrad_f32(const float* x, const float* dy1, const int* lens_dev, f
 int ds2_conv2_wgrad_f32(const float* a1, const float* dy2, const int* lens_dev, float* dW2, int B, int D1, int T, int accumulate, void* ws,
                         size_t ws_bytes, void* stream);
 
+/* conv2 forward / data-gradient with bf16 MFMA operands (precision="bf16"): activations channels-last (B,D,T,32) bf16
+ * (ds2_nhwc_bf16_f32 converts from the (B,32,D,T) fp32 layout), weights re-packed by ds2_conv2_pack_bf16; fp32 output. */
+size_t ds2_conv2_bf16_packed_bytes(int which /*0: forward, 1: dgrad even rows, 2: dgrad odd rows*/);
+int ds2_conv2_pack_bf16(const float* w2, void* wf, void* wd0, void* wd1, void* stream);
+int ds2_nhwc_bf16_f32(const float* src, void* dst, int B, int D, int T, void* stream);
+int ds2_conv2_fwd_bf16(const void* a1_nhwc, const void* wf, const float* bias, const int* lens_dev, float* y2, int B, int D1, int T,
+                       void* stream);
+int ds2_conv2_dgrad_bf16(const void* dy2_nhwc, const void* wd0, const void* wd1, float* da1, int B, int D1, int T, void* stream);
+
 /* ---- bidirectional GRU / LSTM recurrence -------------------------------------------------------
  * pack_padded_sequence -> aten::gru / aten::lstm -> pad_packed_sequence, modules/blocks.py:87-89, h0 = 0,
  * gate order r,z,n (GRU) / i,f,g,o (LSTM); gates = 3 | 4.  See asr_amd/csrc/rnn.hip for buffer roles. */

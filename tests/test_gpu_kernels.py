@@ -206,6 +206,29 @@ def test_conv_fwd_bwd(dev, B, Tin, lens_in):
     assert rel_l2(ops.chan_sum(g(dy2.float(), dev)).cpu(), b2r.grad) < 1e-5
 
 
+@pytest.mark.parametrize("B,Tin,lens_in", [(2, 40, [40, 21]), (3, 300, [300, 257, 90])])
+def test_conv2_bf16(dev, B, Tin, lens_in):
+    """bf16-operand conv2 forward / dgrad (channels-last) vs fp64 conv on the bf16-rounded operands (exact up to fp32 accumulation)."""
+    from asr_amd import ops
+    x, out_lens, w1, b1, w2, b2 = _conv_case(B, Tin, lens_in)
+    T = int((Tin + 1) // 2)
+    mask = (torch.arange(T).view(1, 1, 1, T) < out_lens.view(B, 1, 1, 1)).double()
+    a1 = (T_(27, B, 32, 81, T) * mask.float()).contiguous()
+    w2b = w2.bfloat16().double()
+    a1r = a1.bfloat16().double().requires_grad_(True)
+    y2 = torch.nn.functional.conv2d(a1r, w2b, b2.double(), stride=(2, 1), padding=(10, 5)) * mask
+    dy2 = (T_(25, *y2.shape) * mask.float()).contiguous()
+    (y2 * dy2.bfloat16().double()).sum().backward()
+    ld = g(out_lens, dev)
+    wf, wd0, wd1 = ops.conv2_pack_bf16(g(w2, dev))
+    a1n = ops.nhwc_bf16(g(a1, dev))
+    assert torch.equal(a1n.cpu(), a1.bfloat16().permute(0, 2, 3, 1).contiguous())
+    y2d = ops.conv2_fwd_bf16(a1n, wf, g(b2, dev), ld)
+    assert rel_l2(y2d.cpu(), y2.detach()) < 5e-6
+    da1 = ops.conv2_dgrad_bf16(ops.nhwc_bf16(g(dy2, dev)), wd0, wd1, 81)
+    assert rel_l2(da1.cpu(), a1r.grad) < 5e-6
+
+
 # ---------------------------------------------------------------------------------------------- RNN
 @pytest.mark.parametrize("bf", [False, True])
 @pytest.mark.parametrize("kind,H,B,T,lens", [("gru", 32, 3, 9, [9, 6, 2]), ("lstm", 24, 3, 9, [9, 6, 2]), ("gru", 72, 20, 17, None),
