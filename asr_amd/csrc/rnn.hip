@@ -30,7 +30,10 @@ extern int g_ds2_debug_flags;
 
 namespace {
 
-constexpr int NW = 8;          // waves per block
+#ifndef DS2_RNN_NW
+#define DS2_RNN_NW 8
+#endif
+constexpr int NW = DS2_RNN_NW;          // waves per block
 
 // Streamed-once traffic (gate pre-activations in, gates / h / aux out, dy in) is marked non-temporal so that it does
 // not evict the per-XCD working set that IS re-read every step (W_hh slices 3.1 MB + packed h at H=1024) from the 4 MB L2.

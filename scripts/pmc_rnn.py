@@ -1,0 +1,15 @@
+"""Run ONLY the recurrent forward kernels at the bench shape (for rocprofv3 --pmc passes)."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from asr_amd import ops
+G, H, B, T = 3, 1024, 64, 101
+bf = (sys.argv[1] if len(sys.argv) > 1 else "bf16") == "bf16"
+dev = torch.device("cuda:0")
+gx = torch.randn(T * B, 2 * G * H, device=dev) * 0.5
+whh = (torch.rand(2, G * H, H, device=dev) * 2 - 1) / H ** 0.5
+bhh = torch.zeros(2, G * H, device=dev)
+lens = torch.full((B,), T, dtype=torch.int32, device=dev)
+wpf, wpb = ops.rnn_pack(G, whh, bf16=bf)
+hbuf, aux = ops.rnn_fwd(G, gx, wpf, bhh, lens, T, B, H, bf16=bf)
+torch.cuda.synchronize()
+print("done", T, "launches")
