@@ -55,6 +55,10 @@ SIGNATURES = {
     "ds2_nhwc_bf16_f32": (i32, [vp, vp, i32, i32, i32, vp]),
     "ds2_conv2_fwd_bf16": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "ds2_conv2_dgrad_bf16": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    "ds2_conv_padded_pitch": (i32, [i32]),
+    "ds2_padcast_bf16": (i32, [vp, vp, i64, i32, vp]),
+    "ds2_conv2_wgrad_bf16_workspace_bytes": (sz, [i32, i32]),
+    "ds2_conv2_wgrad_bf16": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, sz, vp]),
     "ds2_rnn_packed_bytes": (sz, [i32, i32, i32, i32]),
     "ds2_rnn_pack_whh": (i32, [i32, vp, vp, vp, i32, i32, vp]),
     "ds2_rnn_fwd_workspace_bytes": (sz, [i32, i32, i32]),

@@ -220,3 +220,189 @@ extern "C" int ds2_conv2_dgrad_bf16(const void* dy2_nhwc, const void* wd0, const
   DS2_LAUNCH_CHECK("conv2_bf16_kernel dgrad");
   return 0;
 }
+
+// =============================================================================================================
+// conv2 weight gradient with bf16 MFMA operands.
+//   dW[co][ci][kd][kt] = sum_{b,o,t} dY[b,co,o,t] * A1[b,ci,2o+kd-10,t+kt-5]
+// GEMM view per tap: M = co (32), N = ci (32), K = time.  Both tensors are read in their natural (B,C,D,T) layout as
+// zero-padded bf16 copies (row pitch Tp = 8-aligned, 8 leading zeros: x = t + 8), so time is contiguous and an MFMA
+// fragment is 8 consecutive time steps.  The tap shift s = kt-5 would make the dY fragment start at an arbitrary
+// 2-byte offset; instead the dY tile is staged in LDS as 8 copies pre-shifted by r = 0..7 elements, and tap s reads
+// copy (s mod 8) — every ds_read_b128 stays 16-byte aligned, no funnel shifts in the MFMA loop.
+//   K runs over the INPUT time t' in [t0-8, t0+72):  D[co][ci] += dYcopy_r[co][t' - s] * A1[ci][t']
+// block = (group of 3 kernel rows, chunk of (b,o) pairs); 4 waves split the 33 taps; accumulators live in registers
+// across the whole (b,o,t) loop; ordered reduction over chunks afterwards (deterministic).
+// =============================================================================================================
+namespace {
+
+constexpr int WT = 64;                  // output time steps per tile
+constexpr int WK = WT + 16;             // K extent per tile (t' in [t0-8, t0+72)) = 5 MFMA k-steps of 16
+constexpr int WPITCH = 176;             // bytes per LDS row (88 bf16): conflict-free ds_read_b128 at row stride
+constexpr int KDG = 3;                  // kernel rows per block
+constexpr int TAPS = KDG * KT;          // 33
+constexpr int TPW = (TAPS + 3) / 4;     // taps per wave (9)
+
+struct WArgs {
+  const __bf16* a1p;   // (B, 32, D1, Tp) padded bf16
+  const __bf16* dyp;   // (B, 32, D2, Tp)
+  float* part;         // [chunks][7 groups][33 taps][32 co][32 ci]
+  const int* lens;
+  int B, D1, D2, T, Tp, pairs_per_chunk;
+};
+
+__global__ __launch_bounds__(256) void conv2_wgrad_bf16_kernel(WArgs a) {
+  __shared__ __attribute__((aligned(16))) char dy_lds[8 * 32 * WPITCH];      // 45056: [r][co][88]
+  __shared__ __attribute__((aligned(16))) char a1_lds[KDG * 32 * WPITCH];    // 16896: [kdl][ci][88] (80 used)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int grp = blockIdx.x, chunk = blockIdx.y;
+  const int kd0 = grp * KDG;
+
+  f32x16 acc[TPW];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  const int npairs = a.B * a.D2;
+  const int pbeg = chunk * a.pairs_per_chunk, pend = min(npairs, pbeg + a.pairs_per_chunk);
+  for (int p = pbeg; p < pend; ++p) {
+    const int b = p / a.D2, o = p % a.D2;
+    const int len = a.lens ? min(a.lens[b], a.T) : a.T;
+    for (int t0 = 0; t0 < len; t0 += WT) {
+      __syncthreads();
+      // ---- stage dY: source x in [t0-8, t0+88) (12 chunks of 8) per co, scattered into the 8 shifted copies:
+      //      copy_r[co][j] = dY[t0 - 8 + j - r]  (x = t + 8  =>  source element x = t0 + j - r)
+      for (int c = tid; c < 32 * 12; c += 256) {
+        const int co = c / 12, ch = c % 12;
+        const int x0 = t0 - 8 + ch * 8;
+        // only THIS tile's output steps t in [t0, t0+WT) (x = t + 8 -> chunks 2..9); everything else is written as zero so
+        // that neighbouring tiles' contributions are not counted twice
+        const bool ok = ch >= 2 && ch < 2 + WT / 8 && x0 + 8 <= a.Tp;
+        const void* src = ok ? (const void*)(a.dyp + (((long long)b * 32 + co) * a.D2 + o) * a.Tp + x0) : (const void*)g_zero_cb;
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(src);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          __bf16* row = reinterpret_cast<__bf16*>(dy_lds + (r * 32 + co) * WPITCH);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int j = ch * 8 + e - 8 + r;       // j = x - t0 + r  with x = x0 + e = t0 - 8 + ch*8 + e
+            if (j >= 0 && j < 88) row[j] = v[e];
+          }
+        }
+      }
+      // ---- stage A1 rows: x in [t0, t0+80) (10 chunks) per (kdl, ci); rows outside the image are zero
+      for (int c = tid; c < KDG * 32 * 10; c += 256) {
+        const int ch = c % 10, ci = (c / 10) % 32, kdl = c / 320;
+        const int f = 2 * o + (kd0 + kdl) - 10;
+        const int x0 = t0 + ch * 8;
+        const bool ok = (kd0 + kdl) < 21 && f >= 0 && f < a.D1 && x0 + 8 <= a.Tp;
+        const void* src = ok ? (const void*)(a.a1p + (((long long)b * 32 + ci) * a.D1 + f) * a.Tp + x0) : (const void*)g_zero_cb;
+        *reinterpret_cast<f32x4*>(a1_lds + (kdl * 32 + ci) * WPITCH + ch * 16) = *reinterpret_cast<const f32x4*>(src);
+      }
+      __syncthreads();
+      // ---- MFMA: wave w owns taps w, w+4, ...
+#pragma unroll
+      for (int i = 0; i < TPW; ++i) {
+        const int tap = wave + 4 * i;
+        if (tap < TAPS) {                                  // wave-uniform
+          const int kdl = tap / KT, kt = tap % KT;
+          const int s = kt - PT;                            // dY index = t' - s
+          const int r = s & 7;                              // copy
+          const int joff = (s < 0) ? 8 : 0;                 // j = 16*ks + 8*half + joff
+          const char* ap = dy_lds + (r * 32 + l31) * WPITCH + (8 * half + joff) * 2;
+          const char* bp = a1_lds + (kdl * 32 + l31) * WPITCH + (8 * half) * 2;
+#pragma unroll
+          for (int ks = 0; ks < WK / 16; ++ks) {
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(ap + ks * 32);
+            const bf16x8 bf = *reinterpret_cast<const bf16x8*>(bp + ks * 32);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[i], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int tap = wave + 4 * i;
+    if (tap < TAPS) {
+      float* out = a.part + ((((long long)chunk * gridDim.x + grp) * TAPS + tap) * 32) * 32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
+        out[co * 32 + l31] = acc[i][r];
+      }
+    }
+  }
+}
+
+__global__ void conv2_wgrad_bf16_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW, int chunks, int ngroups) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;       // (co, ci, kd, kt)
+  if (idx >= 32 * 32 * 21 * 11) return;
+  const int kt = idx % 11, kd = (idx / 11) % 21, ci = (idx / 231) % 32, co = idx / (231 * 32);
+  const int grp = kd / KDG, tap = (kd % KDG) * KT + kt;
+  float s = 0.f;
+  for (int c = 0; c < chunks; ++c) s += part[((((long long)c * ngroups + grp) * TAPS + tap) * 32 + co) * 32 + ci];
+  dW[idx] = s;
+}
+
+// dst[r][x] = bf16(src[r][x - 8]) for 8 <= x < T + 8, else 0 ; dst pitch Tp (multiple of 8, >= T + 16)
+__global__ __launch_bounds__(256) void padcast_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long long R, int T, int Tp) {
+  const int cq = Tp / 8;
+  const long long total = R * cq;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / cq;
+    const int x0 = (int)(i % cq) * 8;
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int t = x0 + e - 8;
+      o[e] = (__bf16)((t >= 0 && t < T) ? src[r * T + t] : 0.f);
+    }
+    *reinterpret_cast<bf16x8*>(dst + r * Tp + x0) = o;
+  }
+}
+
+}  // namespace
+
+extern "C" int ds2_conv_padded_pitch(int T) { return (T + 16 + 7) / 8 * 8; }
+
+// (R, T) fp32 -> (R, Tp) bf16 with 8 leading zeros and zero tail, Tp = ds2_conv_padded_pitch(T)
+extern "C" int ds2_padcast_bf16(const float* src, void* dst, long long R, int T, void* stream) {
+  DS2_REQUIRE(src && dst && R > 0 && T > 0, "ds2_padcast_bf16: bad args");
+  const int Tp = ds2_conv_padded_pitch(T);
+  long long blocks = (R * (Tp / 8) + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(padcast_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, (__bf16*)dst, R, T, Tp);
+  DS2_LAUNCH_CHECK("padcast_kernel");
+  return 0;
+}
+
+extern "C" size_t ds2_conv2_wgrad_bf16_workspace_bytes(int B, int D1) {
+  const int D2 = (D1 + 2 * 10 - 21) / 2 + 1;
+  const int pairs = B * D2;
+  const int chunks = pairs < 73 ? pairs : 73;
+  return (size_t)chunks * 7 * TAPS * 32 * 32 * sizeof(float);
+}
+
+// dW2 (32,32,21,11) fp32 from zero-padded bf16 copies a1p (B,32,D1,Tp), dy2p (B,32,D2,Tp)  [ds2_padcast_bf16]
+extern "C" int ds2_conv2_wgrad_bf16(const void* a1p, const void* dy2p, const int* lens_dev, float* dW2, int B, int D1, int T, void* ws,
+                                    size_t ws_bytes, void* stream) {
+  DS2_REQUIRE(a1p && dy2p && dW2 && ws, "ds2_conv2_wgrad_bf16: null pointer");
+  DS2_REQUIRE(ws_bytes >= ds2_conv2_wgrad_bf16_workspace_bytes(B, D1), "ds2_conv2_wgrad_bf16: workspace too small");
+  const int D2 = (D1 + 2 * 10 - 21) / 2 + 1;
+  const int pairs = B * D2;
+  int chunks = pairs < 73 ? pairs : 73;
+  const int ppc = ceil_div(pairs, chunks);
+  chunks = ceil_div(pairs, ppc);
+  WArgs a{};
+  a.a1p = (const __bf16*)a1p; a.dyp = (const __bf16*)dy2p; a.part = (float*)ws; a.lens = lens_dev;
+  a.B = B; a.D1 = D1; a.D2 = D2; a.T = T; a.Tp = ds2_conv_padded_pitch(T); a.pairs_per_chunk = ppc;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(conv2_wgrad_bf16_kernel, dim3(7, chunks), dim3(256), 0, s, a);
+  DS2_LAUNCH_CHECK("conv2_wgrad_bf16_kernel");
+  hipLaunchKernelGGL(conv2_wgrad_bf16_reduce_kernel, dim3(ceil_div(32 * 32 * 21 * 11, 256)), dim3(256), 0, s, (const float*)ws, dW2, chunks, 7);
+  DS2_LAUNCH_CHECK("conv2_wgrad_bf16_reduce_kernel");
+  return 0;
+}

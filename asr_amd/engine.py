@@ -267,7 +267,10 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
     dy2 = ops.bn2d_act_bwd(ctx.y2, da2, lens_dev, m2, v2, W[cp + "4.weight"], W[cp + "4.bias"], Gr[cp + "4.weight"], Gr[cp + "4.bias"])
     del da2
     Gr[cp + "3.bias"].copy_(ops.chan_sum(dy2))
-    ops.conv2_wgrad(ctx.a1, dy2, lens_dev, Gr[cp + "3.weight"])
+    if cfg.precision == "bf16":
+        ops.conv2_wgrad_bf16(ops.padcast_bf16(ctx.a1), ops.padcast_bf16(dy2), lens_dev, Gr[cp + "3.weight"], T)
+    else:
+        ops.conv2_wgrad(ctx.a1, dy2, lens_dev, Gr[cp + "3.weight"])
     if cfg.precision == "bf16":
         da1 = ops.conv2_dgrad_bf16(ops.nhwc_bf16(dy2), ctx.packs[1], ctx.packs[2], D1)
     else:

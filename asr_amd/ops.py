@@ -364,6 +364,27 @@ def conv2_dgrad_bf16(dy2_nhwc: Tensor, wd0: Tensor, wd1: Tensor, D1: int) -> Ten
     return da1
 
 
+def padcast_bf16(x: Tensor) -> Tensor:
+    """(B,C,D,T) fp32 -> (B,C,D,Tp) bf16 with 8 leading zeros per row and a zero tail (operands of conv2_wgrad_bf16)."""
+    _chk_f32(x)
+    assert x.is_contiguous()
+    lib = _lib.load()
+    B, Cc, D, T = x.shape
+    Tp = lib.ds2_conv_padded_pitch(T)
+    out = torch.empty(B, Cc, D, Tp, dtype=torch.bfloat16, device=x.device)
+    _lib.check(lib.ds2_padcast_bf16(x.data_ptr(), out.data_ptr(), B * Cc * D, T, _stream()), "ds2_padcast_bf16")
+    return out
+
+
+def conv2_wgrad_bf16(a1p: Tensor, dy2p: Tensor, lens_dev: Tensor, dW2: Tensor, T: int):
+    lib = _lib.load()
+    B, _, D1, _ = a1p.shape
+    wsb = lib.ds2_conv2_wgrad_bf16_workspace_bytes(B, D1)
+    ws = _ws(wsb, a1p.device)
+    _lib.check(lib.ds2_conv2_wgrad_bf16(a1p.data_ptr(), dy2p.data_ptr(), lens_dev.data_ptr(), dW2.data_ptr(), B, D1, T, ws.data_ptr(), wsb,
+                                        _stream()), "ds2_conv2_wgrad_bf16")
+
+
 # ------------------------------------------------------------------------------------------------
 # recurrence
 # ------------------------------------------------------------------------------------------------

@@ -109,6 +109,13 @@ int ds2_conv2_fwd_bf16(const void* a1_nhwc, const void* wf, const float* bias, c
                        void* stream);
 int ds2_conv2_dgrad_bf16(const void* dy2_nhwc, const void* wd0, const void* wd1, float* da1, int B, int D1, int T, void* stream);
 
+/* conv2 weight gradient with bf16 MFMA operands: zero-padded bf16 copies (R, Tp) of the (B,32,D,T) tensors, Tp = ds2_conv_padded_pitch(T) */
+int ds2_conv_padded_pitch(int T);
+int ds2_padcast_bf16(const float* src, void* dst, long long R, int T, void* stream);
+size_t ds2_conv2_wgrad_bf16_workspace_bytes(int B, int D1);
+int ds2_conv2_wgrad_bf16(const void* a1p, const void* dy2p, const int* lens_dev, float* dW2, int B, int D1, int T, void* ws, size_t ws_bytes,
+                         void* stream);
+
 /* ---- bidirectional GRU / LSTM recurrence -------------------------------------------------------
  * pack_padded_sequence -> aten::gru / aten::lstm -> pad_packed_sequence, modules/blocks.py:87-89, h0 = 0,
  * gate order r,z,n (GRU) / i,f,g,o (LSTM); gates = 3 | 4.  See asr_amd/csrc/rnn.hip for buffer roles. */

@@ -227,6 +227,15 @@ def test_conv2_bf16(dev, B, Tin, lens_in):
     assert rel_l2(y2d.cpu(), y2.detach()) < 5e-6
     da1 = ops.conv2_dgrad_bf16(ops.nhwc_bf16(g(dy2, dev)), wd0, wd1, 81)
     assert rel_l2(da1.cpu(), a1r.grad) < 5e-6
+    # weight gradient on the bf16-rounded operands
+    w2r = w2.double().requires_grad_(True)
+    y2w = torch.nn.functional.conv2d(a1.bfloat16().double(), w2r, None, stride=(2, 1), padding=(10, 5))
+    (y2w * dy2.bfloat16().double()).sum().backward()
+    dW2 = torch.empty(32, 32, 21, 11, device=dev)
+    a1p, dyp = ops.padcast_bf16(g(a1, dev)), ops.padcast_bf16(g(dy2, dev))
+    assert float(a1p[..., :8].abs().sum()) == 0 and torch.equal(a1p[..., 8:8 + T].cpu(), a1.bfloat16())
+    ops.conv2_wgrad_bf16(a1p, dyp, ld, dW2, T)
+    assert rel_l2(dW2.cpu(), w2r.grad) < 1e-5
 
 
 # ---------------------------------------------------------------------------------------------- RNN
