@@ -226,19 +226,19 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(RnnArgs a, int s)
     if constexpr (G == 3) {
       const float r = sigmoidf_(pgx[i][0] + gh[0]);
       const float z = sigmoidf_(pgx[i][1] + gh[1]);
-      const float n = tanhf(pgx[i][2] + r * gh[2]);
+      const float n = tanhf_(pgx[i][2] + r * gh[2]);
       stnt(&gx[0], r); stnt(&gx[H], z); stnt(&gx[2 * H], n);
       stnt(ax, gh[2]);
       hnew = (1.f - z) * n + z * pprev[i];
     } else {
       const float ig = sigmoidf_(pgx[i][0] + gh[0]);
       const float fg = sigmoidf_(pgx[i][1] + gh[1]);
-      const float gg = tanhf(pgx[i][2] + gh[2]);
+      const float gg = tanhf_(pgx[i][2] + gh[2]);
       const float og = sigmoidf_(pgx[i][G - 1] + gh[G - 1]);
       const float c = fg * pprev[i] + ig * gg;
       stnt(&gx[0], ig); stnt(&gx[H], fg); stnt(&gx[2 * H], gg); stnt(&gx[(G - 1) * H], og);
       *ax = c;                       // c_{t} is re-read by the next step (same block): keep it cacheable
-      hnew = og * tanhf(c);
+      hnew = og * tanhf_(c);
     }
     *ho = hnew;
     packed_store<BF>(pk_out, hpi, hnew);
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(RnnArgs a, int s)
         const float dh = pdy[i] + carry;
         const float ig = pg[i][0], fg = pg[i][1], gg = pg[i][2], og = pg[i][G - 1];
         const float c = pax[i];
-        const float tc = tanhf(c);
+        const float tc = tanhf_(c);
         const float dc = pdc[i] + dh * og * (1.f - tc * tc);
         dgh[0] = dc * gg * ig * (1.f - ig);
         dgh[1] = dc * pprev[i] * fg * (1.f - fg);

@@ -66,7 +66,7 @@ def test_gemm_splitk_batched_strided(dev):
     assert rel_l2(out[0].cpu(), ref0) < 2e-6 and rel_l2(out[1].cpu(), ref1) < 2e-6
 
 
-@pytest.mark.parametrize("M,N,K", [(70, 45, 33), (300, 260, 520), (129, 257, 64), (29, 96, 1000)])
+@pytest.mark.parametrize("M,N,K", [(70, 45, 33), (300, 260, 520), (129, 257, 64), (29, 96, 1000), (6000, 5990, 200)])
 def test_gemm_bf16_and_casts(dev, M, N, K):
     from asr_amd import ops
     A, B, bias = T_(1, M, K), T_(2, N, K), T_(3, N)
