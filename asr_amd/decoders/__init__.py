@@ -1,5 +1,6 @@
 """Greedy CTC decoder + WER/CER (host-side mirror of asr_deepspeech/decoders/{decoder,greedy_decoder}.py).
-Needed because `DeepSpeech.__init__` instantiates one (deepspeech.py:55); eval-only, not on the train step.
+`decode()` runs on the GPU (csrc/decode.hip); process_string / convert_to_strings are the host utilities the
+reference uses for TARGET strings.  Eval-only, not on the train step.
 The edit distance is a small pure-Python DP (the reference imports the `Levenshtein` C package)."""
 from __future__ import annotations
 
@@ -71,8 +72,34 @@ class GreedyDecoder(Decoder):
         return string, torch.tensor(offsets, dtype=torch.int)
 
     def decode(self, probs, sizes=None):
-        """probs (B,T,C) -> ([[str]], [[offsets]]) ; argmax is one device op, strings are built on host."""
-        max_probs = torch.argmax(probs, 2).cpu()
-        strings, offsets = self.convert_to_strings(max_probs.view(max_probs.size(0), max_probs.size(1)), sizes,
-                                                   remove_repetitions=True, return_offsets=True)
+        """probs (B,T,C) -> ([[str]], [[offsets]]) (greedy_decoder.py:48-68).
+
+        Arg-max, repeat collapse and blank removal run as two HIP kernels (`ds2_greedy_decode_f32`); the host does
+        ONE device->host copy of the compacted ids and maps them to characters.  Host tensors are uploaded first —
+        there is no CPU implementation of decode()."""
+        from .. import ops
+        probs = torch.as_tensor(probs)
+        if not probs.is_cuda:
+            probs = probs.to(_device())
+        probs = probs.float()
+        if probs.stride(2) != 1:
+            probs = probs.contiguous()
+        if sizes is not None:
+            sizes = torch.as_tensor(sizes)
+        ids, offs, lens = ops.greedy_decode(probs, sizes, self.blank_index)
+        B, T = ids.shape
+        host = torch.cat((ids.reshape(-1), offs.reshape(-1), lens)).cpu()
+        ids_h, offs_h, lens_h = host[:B * T].view(B, T), host[B * T:2 * B * T].view(B, T), host[2 * B * T:].tolist()
+        strings, offsets = [], []
+        for b in range(B):
+            n = lens_h[b]
+            strings.append(["".join(" " if i == self.space_index else self.int_to_char.get(i, "") for i in ids_h[b, :n].tolist())])
+            offsets.append([offs_h[b, :n].clone()])
         return strings, offsets
+
+
+def _device():
+    from .._lib import DS2LibraryError
+    if not torch.cuda.is_available():
+        raise DS2LibraryError("GreedyDecoder.decode needs a GPU (no CPU fallback exists)")
+    return torch.device("cuda", torch.cuda.current_device())

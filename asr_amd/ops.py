@@ -454,6 +454,27 @@ def softmax_rows(x: Tensor) -> Tensor:
     return y
 
 
+def greedy_decode(probs: Tensor, sizes: Tensor | None = None, blank: int = 0):
+    """probs (B,T,C) fp32 on the GPU -> (ids (B,T) i32, offsets (B,T) i32, lengths (B) i32), all on the GPU."""
+    _chk_f32(probs)
+    if probs.dim() != 3 or probs.stride(2) != 1:
+        raise ValueError("greedy_decode: probs must be (B,T,C) with a contiguous class dim")
+    B, T, C = probs.shape
+    dev = probs.device
+    if sizes is not None:
+        sizes = sizes.to(device=dev, dtype=torch.int32).contiguous()
+    ids = torch.empty((B, T), dtype=torch.int32, device=dev)
+    offs = torch.empty((B, T), dtype=torch.int32, device=dev)
+    lens = torch.empty((B,), dtype=torch.int32, device=dev)
+    lib = _lib.load()
+    n = lib.ds2_greedy_decode_workspace_bytes(B, T)
+    ws = torch.empty(n, dtype=torch.uint8, device=dev)
+    _lib.check(lib.ds2_greedy_decode_f32(probs.data_ptr(), probs.stride(0), probs.stride(1), B, T, C,
+                                         sizes.data_ptr() if sizes is not None else None, blank, ids.data_ptr(), offs.data_ptr(),
+                                         lens.data_ptr(), ws.data_ptr(), n, _stream()), "ds2_greedy_decode_f32")
+    return ids, offs, lens
+
+
 # ------------------------------------------------------------------------------------------------
 # optimizer
 # ------------------------------------------------------------------------------------------------

@@ -141,6 +141,15 @@ int ds2_ctc_loss_f32(const float* logits, int ld, int T, int B, int C, const int
 /* softmax over the last dim (eval-mode InferenceBatchSoftmax, modules/blocks.py:59-64) */
 int ds2_softmax_rows_f32(const float* x, int ldx, float* y, int ldy, int rows, int C, void* stream);
 
+/* greedy CTC decode: per-frame arg-max (ties -> lowest class, torch.max's first-maximum rule), collapse repeats,
+ * drop blanks; replaces GreedyDecoder.decode / convert_to_strings / process_string,
+ * decoders/greedy_decoder.py:10-68 (a per-frame host loop with one .item() sync per frame).
+ * probs (B,T,C) fp32 with element strides ld_b, ld_t (C contiguous); sizes_dev (B) int32 or NULL (= T frames).
+ * Outputs: ids/offs (B,T) int32 — the first out_len[b] entries of row b are the kept labels and their frames. */
+size_t ds2_greedy_decode_workspace_bytes(int B, int T);
+int ds2_greedy_decode_f32(const float* probs, long long ld_b, long long ld_t, int B, int T, int C, const int* sizes_dev, int blank,
+                          int* ids, int* offs, int* out_len, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- optimizer ----------------------------------------------------------------------------------
  * torch.optim.AdamW.step over one flat parameter buffer, trainers/__main__.py:41-47. */
 int ds2_adamw_f32(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,

@@ -134,3 +134,19 @@ def batch(b: int, t_ins, classes: int, seed: int = 1):
     targets = randint((int(tgt_sizes.sum()),), seed + 1, 1, classes).astype(np.int32)
     pct = np.array([t / float(tmax) for t in t_ins], dtype=np.float64).astype(np.float32)
     return x, targets, pct, tgt_sizes
+
+
+DECODE_CASES = (  # name, labels, B, T, quantisation levels (ties exercise the first-maximum rule), sizes
+    ("small_ties", "_ABCDE ", 4, 50, 4, None),
+    ("ragged", "_'ABCDEFGHIJKLMNOPQRSTUVWXYZ ", 3, 201, 0, [201, 120, 1]),
+    ("blank_heavy", "_'ABCDEFGHIJKLMNOPQRSTUVWXYZ ", 5, 333, 3, [333, 332, 100, 64, 65]),
+)
+
+
+def decode_probs(name, b, t, c, levels):
+    p = uniform01((b, t, c), seed_of("decode." + name))
+    if levels:
+        p = np.floor(p * levels) / levels
+    if name == "blank_heavy":
+        p[..., 0] = np.where(uniform01((b, t), seed_of("decode.blank." + name)) < 0.6, 2.0, p[..., 0])
+    return p.astype(np.float32)

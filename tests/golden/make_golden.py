@@ -9,6 +9,7 @@ Outputs (committed, data only — expected outputs, never reference source):
     tests/golden/lengths.npz        get_seq_lens table, _collate_fn + fit() length recovery (A.5)
     tests/golden/collate.npz        _collate_fn on a 3-sample batch
     tests/golden/state_manifest.json  state_dict keys/shapes of the reference model (A.1)
+    tests/golden/decode.json        GreedyDecoder.decode (argmax, collapse repeats, drop blanks) known answers
     tests/golden/model_<name>.npz   whole model: logits, loss, grads (sub-sampled), BN running
                                     stats, 3 AdamW steps — reference statement sequence of
                                     DeepSpeechTrainer.fit + backward + AdamW.step
@@ -241,10 +242,27 @@ def gen_manifest(out, DeepSpeech, tmp):
         json.dump(man, f, indent=1)
 
 
+def gen_decode(out):
+    from asr_deepspeech.decoders import GreedyDecoder
+    rec = {}
+    for name, labels, b, t, levels, sizes in det.DECODE_CASES:
+        probs = torch.from_numpy(det.decode_probs(name, b, t, len(labels), levels))
+        dec = GreedyDecoder(labels, blank_index=0)
+        strings, offsets = dec.decode(probs, None if sizes is None else torch.tensor(sizes))
+        rec[name] = {"labels": labels, "B": b, "T": t, "levels": levels, "sizes": sizes,
+                     "strings": [s[0] for s in strings], "offsets": [o[0].tolist() for o in offsets]}
+    with open(os.path.join(out, "decode.json"), "w") as f:
+        json.dump(rec, f, indent=0)
+
+
 def main():
     DeepSpeech, blocks, functional = import_reference()
     torch.set_num_threads(4)
     out = HERE
+    if "--only-decode" in sys.argv:
+        gen_decode(out)
+        return
+    gen_decode(out)
     with tempfile.TemporaryDirectory() as tmp:
         gen_ctc(out)
         gen_lengths(out, DeepSpeech, functional, tmp)

@@ -139,16 +139,28 @@ def test_samplers_partition_rule():
     assert [tuple(b) for b in parts[0].bins] == [tuple(b) for b in parts[1].bins]   # same permutation on every rank
 
 
-def test_greedy_decoder_known_answers():
+def test_greedy_decoder_host_utilities_golden():
+    """process_string / convert_to_strings (host utilities, used for TARGET strings) against the reference's decode
+    goldens: feed them the first-maximum arg-max path and expect the reference's strings + offsets."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import det as mgi
     from asr_amd.decoders import GreedyDecoder
-    labels = {c: i for i, c in enumerate("_abc ")}
-    d = GreedyDecoder(labels)
-    probs = torch.zeros(1, 6, 5)
-    for t, k in enumerate([1, 1, 0, 2, 4, 3]):
-        probs[0, t, k] = 1.0
-    out, _ = d.decode(probs, torch.tensor([6]))
-    assert out[0][0] == "ab c"
+    from asr_amd._lib import DS2LibraryError
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "decode.json")))
+    for name, g in gold.items():
+        probs = mgi.decode_probs(name, g["B"], g["T"], len(g["labels"]), g["levels"])
+        path = torch.from_numpy(np.argmax(probs, axis=2))
+        d = GreedyDecoder(g["labels"])
+        sizes = g["sizes"]
+        strings, offsets = d.convert_to_strings(path, sizes, remove_repetitions=True, return_offsets=True)
+        assert [s[0] for s in strings] == g["strings"], name
+        assert [o[0].tolist() for o in offsets] == g["offsets"], name
+    d = GreedyDecoder({c: i for i, c in enumerate("_abc ")})
+    assert d.process_string(torch.tensor([1, 1, 0, 2, 4, 3]), 6, remove_repetitions=True)[0] == "ab c"
     assert d.cer("abc", "abd") == 1 and d.wer("a b c", "a x c") == 1
+    if not torch.cuda.is_available():
+        with pytest.raises(DS2LibraryError):           # decode() itself is GPU-only: no CPU path
+            d.decode(torch.zeros(1, 3, 5))
 
 
 DP_WORKER = r'''

@@ -352,3 +352,69 @@ def test_softmax_and_adamw(dev):
         ops.adamw(pd, gd, m, v, step, 1.5e-4, (0.9, 0.999), 1e-8, 1e-5, 1.0)
         pn, mn, vn = O.adamw_step_np(pn, gr.double().numpy(), mn, vn, step)
     assert rel_l2(pd.cpu(), pn) < 1e-6
+
+
+# ---- greedy CTC decode (eval path; decoders/greedy_decoder.py) ---------------------------------------
+def _collapse_np(path, n, blank=0):
+    ids, offs = [], []
+    for t in range(n):
+        k = int(path[t])
+        if k != blank and (t == 0 or k != int(path[t - 1])):
+            ids.append(k)
+            offs.append(t)
+    return ids, offs
+
+
+def test_greedy_decode_golden(dev):
+    """GreedyDecoder.decode through ds2_greedy_decode_f32 against the reference's outputs (tests/golden/decode.json,
+    incl. quantised probabilities whose ties pin the first-maximum rule, ragged sizes, size 1)."""
+    import json
+    import os
+    from asr_amd.decoders import GreedyDecoder
+    gold = json.load(open(os.path.join(GOLDEN, "decode.json")))
+    assert set(gold) == {c[0] for c in det.DECODE_CASES}
+    for name, gd in gold.items():
+        probs = det.decode_probs(name, gd["B"], gd["T"], len(gd["labels"]), gd["levels"])
+        d = GreedyDecoder(gd["labels"])
+        sizes = None if gd["sizes"] is None else torch.tensor(gd["sizes"])
+        strings, offsets = d.decode(g(probs, dev), sizes)
+        assert [s[0] for s in strings] == gd["strings"], name
+        assert [o[0].tolist() for o in offsets] == gd["offsets"], name
+        strings_h, _ = d.decode(torch.from_numpy(probs), sizes)              # host tensors are uploaded, same kernels
+        assert strings_h == strings
+
+
+def test_greedy_decode_reference_known_answers(dev):
+    """The reference's own decoder test cases (tests/test_greedy_decoder.py:56-97), as data."""
+    from asr_amd.decoders import GreedyDecoder
+    d = GreedyDecoder("_ABCDE ")
+    for path, want in (([1, 2, 3], "ABC"), ([1, 1, 2], "AB"), ([0, 1, 2], "AB"), ([1, 6, 2], "A B"), ([1, 0, 1], "AA"), ([0, 0, 0], "")):
+        probs = torch.zeros(1, len(path), 7)
+        for t, k in enumerate(path):
+            probs[0, t, k] = 1.0
+        strings, offsets = d.decode(probs.to(dev))
+        assert strings[0][0] == want, (path, strings)
+        assert len(offsets[0][0]) == len(want)
+    probs = torch.zeros(2, 2, 7)
+    probs[0, 0, 1] = probs[0, 1, 2] = probs[1, 0, 3] = probs[1, 1, 4] = 1.0
+    strings, _ = d.decode(probs.to(dev))
+    assert [s[0] for s in strings] == ["AB", "CD"]
+
+
+@pytest.mark.parametrize("B,T,C", [(64, 1001, 29), (3, 7, 200), (1, 1, 2)])
+def test_greedy_decode_ids_vs_numpy(dev, B, T, C):
+    """Raw kernel outputs (ids, offsets, lengths) bit-exact against a numpy restatement, on a strided (T,B,C)->(B,T,C)
+    view like the one DeepSpeech.forward returns; C > 64 exercises the lane-strided arg-max."""
+    from asr_amd import ops
+    x = det.unitvar((T, B, C), 60 + C)
+    x = np.round(x * 4) / 4                                                      # ties
+    sizes = np.maximum(1, (det.uniform01((B,), 61) * T).astype(np.int32))
+    sizes[0] = T
+    xd = g(x.astype(np.float32), dev).transpose(0, 1)                           # (B,T,C) view, class dim contiguous
+    ids, offs, lens = ops.greedy_decode(xd, g(sizes, dev), 0)
+    ids, offs, lens = ids.cpu().numpy(), offs.cpu().numpy(), lens.cpu().numpy()
+    path = np.argmax(x, axis=2).T                                                # first maximum
+    for b in range(B):
+        want_ids, want_offs = _collapse_np(path[b], int(sizes[b]))
+        assert lens[b] == len(want_ids)
+        assert ids[b, :lens[b]].tolist() == want_ids and offs[b, :lens[b]].tolist() == want_offs

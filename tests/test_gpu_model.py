@@ -229,3 +229,37 @@ def test_full_size_properties():
     tr = DeepSpeechTrainer(model, CTCLoss(reduction="sum"), 1, None, opt, None, None, "cuda", "cuda", False, None)
     ls = [tr.step((x, targets, pct.clone(), tsz))[1] for _ in range(4)]
     assert ls[-1] < ls[0], ls
+
+
+def test_evaluate_loop_decodes_on_gpu():
+    """DeepSpeech.evaluate (deepspeech.py:161-273): eval forward -> softmax -> greedy decode -> WER/CER.  The
+    transcripts must equal a numpy greedy decode of the CPU oracle's eval-mode probabilities wherever the
+    oracle's per-frame top-2 margin is decisive, and the WER/CER totals follow from them."""
+    cfg = dict(rnn="gru", hidden=40, layers=2, classes=29, t_ins=[140, 120, 90, 33])
+    sd, x, targets, pct, tsz = model_inputs(cfg)
+    model = make_model(cfg, sd)
+    model.eval()
+    lens = O.lengths_from_percentages(pct, x.size(3))
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    probs_ref, out_lens_ref = O.forward(sd64, x.double(), lens, training=False)
+    probs_ref = probs_ref.numpy()
+    wer, cer, output_data = model.evaluate(loader=[(x, targets, pct.clone(), tsz)], device="cuda", output_file=os.devnull)
+    probs, out_sizes, target_strings = output_data[0]
+    assert np.array_equal(np.asarray(out_sizes), np.asarray(out_lens_ref))
+    assert rel_l2(probs, probs_ref) < TOL
+    dec = model.decoder
+    strings, offsets = dec.decode(torch.from_numpy(probs).cuda(), torch.as_tensor(out_sizes))
+    tot_w = tot_c = n_w = n_c = 0
+    for b in range(len(cfg["t_ins"])):
+        n = int(out_sizes[b])
+        path = np.argmax(probs[b, :n], axis=1)
+        top2 = np.sort(probs_ref[b, :n], axis=1)[:, -2:]
+        if (top2[:, 1] - top2[:, 0]).min() > 1e-4:                              # decisive frames: oracle path == HIP path
+            assert np.array_equal(path, np.argmax(probs_ref[b, :n], axis=1))
+        want = "".join(dec.int_to_char[int(k)] for t, k in enumerate(path) if k != 0 and (t == 0 or k != path[t - 1]))
+        assert strings[b][0] == want
+        assert offsets[b][0].tolist() == [t for t, k in enumerate(path) if k != 0 and (t == 0 or k != path[t - 1])]
+        ref = target_strings[b][0]
+        tot_w += dec.wer(want, ref); tot_c += dec.cer(want, ref)
+        n_w += len(ref.split()); n_c += len(ref.replace(" ", ""))
+    assert abs(wer - 100.0 * tot_w / max(n_w, 1)) < 1e-9 and abs(cer - 100.0 * tot_c / max(n_c, 1)) < 1e-9
