@@ -147,31 +147,32 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(RnnArgs a, int s)
   const float* pk_in = a.pk + ((long long)(((s + 1) & 1) * 2 + dir) * a.nbt16) * nch * 256;
 
   // ---- epilogue operands: issue their (HBM-latency) loads first, consume after the GEMM --------
+  // Nothing here depends on a loaded value (the length mask is applied after the GEMM), so the loads below and the
+  // GEMM's operand loads all issue back to back without an intervening s_waitcnt.
   float pgx[PAIRS][G], pb[PAIRS][G], pprev[PAIRS];
-  bool pact[PAIRS], pvalid[PAIRS];
+  int plen[PAIRS];
+  bool pact[PAIRS];
 #pragma unroll
   for (int i = 0; i < PAIRS; ++i) {
     const int q = threadIdx.x + i * NTHR;
     const int jl = q & 15, brow = (q >> 4) & 15, mb = q >> 8;
     const int b = b0 + mb * 16 + brow, j = j0 + jl;
     pact[i] = (mb < MB) && b < B && j < H;
-    pvalid[i] = false;
+    plen[i] = 0;
     pprev[i] = 0.f;
 #pragma unroll
     for (int g = 0; g < G; ++g) { pgx[i][g] = 0.f; pb[i][g] = 0.f; }
     if (pact[i]) {
-      pvalid[i] = t < a.lens[b];
+      plen[i] = a.lens[b];
       const long long row = ((long long)t * B + b) * 2 + dir;
-      if (pvalid[i]) {
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-          pgx[i][g] = ldnt(&a.gx[row * G * H + g * H + j]);
-          pb[i][g] = a.bhh[(dir * G + g) * H + j];
-        }
-        if (has_prev) {
-          const long long prow = ((long long)tp * B + b) * 2 + dir;
-          pprev[i] = (G == 3) ? a.hbuf[prow * H + j] : a.aux[prow * H + j];
-        }
+      for (int g = 0; g < G; ++g) {
+        pgx[i][g] = ldnt(&a.gx[row * G * H + g * H + j]);
+        pb[i][g] = a.bhh[(dir * G + g) * H + j];
+      }
+      if (has_prev) {
+        const long long prow = ((long long)tp * B + b) * 2 + dir;
+        pprev[i] = (G == 3) ? a.hbuf[prow * H + j] : a.aux[prow * H + j];
       }
     }
   }
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(RnnArgs a, int s)
     float* ho = a.hbuf + row * H + j;
     float* ax = a.aux + row * H + j;
     const long long hpi = packed_index<BF>(b, j, nch);
-    if (!pvalid[i]) {
+    if (!(t < plen[i])) {
 #pragma unroll
       for (int g = 0; g < G; ++g) stnt(&gx[g * H], 0.f);
       stnt(ho, 0.f);
@@ -271,31 +272,31 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(RnnArgs a, int s)
   const float* pk_in = a.pk + ((long long)(((s + 1) & 1) * 2 + dir) * a.nbt16) * nchb * 256;
 
   // ---- epilogue operands first ----------------------------------------------------------------
+  // (no load below depends on a loaded value: the length mask is applied after the GEMM)
   float pg[PAIRS][G], pax[PAIRS], pprev[PAIRS], pdy[PAIRS], pdc[PAIRS];
-  bool pact[PAIRS], pvalid[PAIRS];
+  int plen[PAIRS];
+  bool pact[PAIRS];
 #pragma unroll
   for (int i = 0; i < PAIRS; ++i) {
     const int q = threadIdx.x + i * NTHR;
     const int jl = q & 15, brow = (q >> 4) & 15, mb = q >> 8;
     const int b = b0 + mb * 16 + brow, j = j0 + jl;
     pact[i] = (mb < MB) && b < B && j < H;
-    pvalid[i] = false;
+    plen[i] = 0;
     pax[i] = pprev[i] = pdy[i] = pdc[i] = 0.f;
 #pragma unroll
     for (int g = 0; g < G; ++g) pg[i][g] = 0.f;
     if (pact[i]) {
-      pvalid[i] = t < a.lens[b];
-      if (pvalid[i]) {
-        const long long row = ((long long)t * B + b) * 2 + dir;
+      plen[i] = a.lens[b];
+      const long long row = ((long long)t * B + b) * 2 + dir;
 #pragma unroll
-        for (int g = 0; g < G; ++g) pg[i][g] = ldnt(&a.gx[row * G * H + g * H + j]);
-        pax[i] = ldnt(&a.aux[row * H + j]);
-        pdy[i] = ldnt(&a.dy[((long long)t * B + b) * a.lddy + j]);
-        if (has_q) pdc[i] = dcar_in[(long long)b * H + j];
-        if (has_pf) {
-          const long long prow = ((long long)tpf * B + b) * 2 + dir;
-          pprev[i] = (G == 3) ? a.hbuf[prow * H + j] : a.aux[prow * H + j];
-        }
+      for (int g = 0; g < G; ++g) pg[i][g] = ldnt(&a.gx[row * G * H + g * H + j]);
+      pax[i] = ldnt(&a.aux[row * H + j]);
+      pdy[i] = ldnt(&a.dy[((long long)t * B + b) * a.lddy + j]);
+      if (has_q) pdc[i] = dcar_in[(long long)b * H + j];
+      if (has_pf) {
+        const long long prow = ((long long)tpf * B + b) * 2 + dir;
+        pprev[i] = (G == 3) ? a.hbuf[prow * H + j] : a.aux[prow * H + j];
       }
     }
   }
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(RnnArgs a, int s)
     float* ax = a.aux + row * H + j;
     float* dco = dcar_out + (long long)b * H + j;
     float dgh[G];
-    if (!pvalid[i]) {
+    if (!(t < plen[i])) {
 #pragma unroll
       for (int g = 0; g < G; ++g) { stnt(&gx[g * H], 0.f); dgh[g] = 0.f; }
       if (G == 3) stnt(ax, 0.f);
