@@ -250,7 +250,27 @@ struct WArgs {
   int B, D1, D2, T, Tp, pairs_per_chunk;
 };
 
-__global__ __launch_bounds__(256) void conv2_wgrad_bf16_kernel(WArgs a) {
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// The 8 pre-shifted copies of one 8-element dY chunk, built in registers: copy_r chunk m = elements [8 - r, 16 - r) of the
+// 16-element run (S[m-1] | S[m]) — a word select for even r, one v_alignbit per word for odd r — and stored with ds_write_b128.
+__device__ __forceinline__ void store_shifted_copies(const u32x4 lo, const u32x4 hi, char* dst /* copy 0, row co, chunk m */) {
+  const unsigned W[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int w0 = (8 - r) >> 1;
+    u32x4 o;
+    if ((r & 1) == 0) {
+      o = u32x4{W[w0], W[w0 + 1], W[w0 + 2], W[w0 + 3]};
+    } else {
+      o = u32x4{__builtin_amdgcn_alignbit(W[w0 + 1], W[w0], 16), __builtin_amdgcn_alignbit(W[w0 + 2], W[w0 + 1], 16),
+                __builtin_amdgcn_alignbit(W[w0 + 3], W[w0 + 2], 16), __builtin_amdgcn_alignbit(W[w0 + 4], W[w0 + 3], 16)};
+    }
+    *reinterpret_cast<u32x4*>(dst + r * 32 * WPITCH) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv2_wgrad_bf16_kernel(WArgs a) {
   __shared__ __attribute__((aligned(16))) char dy_lds[8 * 32 * WPITCH];      // 45056: [r][co][88]
   __shared__ __attribute__((aligned(16))) char a1_lds[KDG * 32 * WPITCH];    // 16896: [kdl][ci][88] (80 used)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -265,60 +285,83 @@ __global__ __launch_bounds__(256) void conv2_wgrad_bf16_kernel(WArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
+  // per-thread staging items: dY (co, m) for idx = tid, tid + 256 (< 32 * 11); A1 (kdl, ci, ch) for idx = tid + 256 k (< KDG * 32 * 10)
+  constexpr int NDY = 2, NA1 = (KDG * 32 * 10 + 255) / 256;
+  u32x4 dlo[NDY], dhi[NDY], av[NA1];
+
   const int npairs = a.B * a.D2;
-  const int pbeg = chunk * a.pairs_per_chunk, pend = min(npairs, pbeg + a.pairs_per_chunk);
-  for (int p = pbeg; p < pend; ++p) {
+  const int pend = min(npairs, (chunk + 1) * a.pairs_per_chunk);
+  int p = chunk * a.pairs_per_chunk, t0 = 0, len = 0;
+  auto settle = [&]() {                         // move (p, t0) to the next existing tile; false when the chunk is exhausted
+    while (p < pend) {
+      len = a.lens ? min(a.lens[p / a.D2], a.T) : a.T;
+      if (t0 < len) return true;
+      ++p;
+      t0 = 0;
+    }
+    return false;
+  };
+  // dY source chunk c of row co covers x in [t0 - 8 + 8c, +8) (x = t + 8); only THIS tile's output steps (chunks 2..9) are
+  // non-zero so that neighbouring tiles' contributions are not counted twice
+  auto load_tile = [&]() {
     const int b = p / a.D2, o = p % a.D2;
-    const int len = a.lens ? min(a.lens[b], a.T) : a.T;
-    for (int t0 = 0; t0 < len; t0 += WT) {
-      __syncthreads();
-      // ---- stage dY: source x in [t0-8, t0+88) (12 chunks of 8) per co, scattered into the 8 shifted copies:
-      //      copy_r[co][j] = dY[t0 - 8 + j - r]  (x = t + 8  =>  source element x = t0 + j - r)
-      for (int c = tid; c < 32 * 12; c += 256) {
-        const int co = c / 12, ch = c % 12;
-        const int x0 = t0 - 8 + ch * 8;
-        // only THIS tile's output steps t in [t0, t0+WT) (x = t + 8 -> chunks 2..9); everything else is written as zero so
-        // that neighbouring tiles' contributions are not counted twice
-        const bool ok = ch >= 2 && ch < 2 + WT / 8 && x0 + 8 <= a.Tp;
-        const void* src = ok ? (const void*)(a.dyp + (((long long)b * 32 + co) * a.D2 + o) * a.Tp + x0) : (const void*)g_zero_cb;
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(src);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          __bf16* row = reinterpret_cast<__bf16*>(dy_lds + (r * 32 + co) * WPITCH);
+    for (int k = 0; k < NDY; ++k) {
+      const int idx = tid + 256 * k;
+      const int co = idx / 11, m = idx % 11;
+      const __bf16* row = a.dyp + (((long long)b * 32 + min(co, 31)) * a.D2 + o) * a.Tp;
+      const int xl = t0 - 8 + m * 8, xh = xl + 8;           // copy_r[8m + e] = dY(x = t0 + 8m + e - r): source chunks m and m + 1
+      const bool okl = idx < 352 && m >= 2 && m < 2 + WT / 8 && xl + 8 <= a.Tp;
+      const bool okh = idx < 352 && m + 1 >= 2 && m + 1 < 2 + WT / 8 && xh + 8 <= a.Tp;
+      dlo[k] = *reinterpret_cast<const u32x4*>(okl ? (const void*)(row + xl) : (const void*)g_zero_cb);
+      dhi[k] = *reinterpret_cast<const u32x4*>(okh ? (const void*)(row + xh) : (const void*)g_zero_cb);
+    }
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const int j = ch * 8 + e - 8 + r;       // j = x - t0 + r  with x = x0 + e = t0 - 8 + ch*8 + e
-            if (j >= 0 && j < 88) row[j] = v[e];
-          }
-        }
-      }
-      // ---- stage A1 rows: x in [t0, t0+80) (10 chunks) per (kdl, ci); rows outside the image are zero
-      for (int c = tid; c < KDG * 32 * 10; c += 256) {
-        const int ch = c % 10, ci = (c / 10) % 32, kdl = c / 320;
-        const int f = 2 * o + (kd0 + kdl) - 10;
-        const int x0 = t0 + ch * 8;
-        const bool ok = (kd0 + kdl) < 21 && f >= 0 && f < a.D1 && x0 + 8 <= a.Tp;
-        const void* src = ok ? (const void*)(a.a1p + (((long long)b * 32 + ci) * a.D1 + f) * a.Tp + x0) : (const void*)g_zero_cb;
-        *reinterpret_cast<f32x4*>(a1_lds + (kdl * 32 + ci) * WPITCH + ch * 16) = *reinterpret_cast<const f32x4*>(src);
-      }
-      __syncthreads();
-      // ---- MFMA: wave w owns taps w, w+4, ...
+    for (int k = 0; k < NA1; ++k) {
+      const int c = tid + 256 * k;
+      const int ch = c % 10, ci = (c / 10) % 32, kdl = c / 320;
+      const int f = 2 * o + (kd0 + kdl) - 10;
+      const int x0 = t0 + ch * 8;
+      const bool ok = c < KDG * 320 && (kd0 + kdl) < 21 && f >= 0 && f < a.D1 && x0 + 8 <= a.Tp;
+      av[k] = *reinterpret_cast<const u32x4*>(ok ? (const void*)(a.a1p + (((long long)b * 32 + ci) * a.D1 + f) * a.Tp + x0)
+                                                 : (const void*)g_zero_cb);
+    }
+  };
+
+  bool have = settle();
+  if (have) load_tile();
+  while (have) {
+    __syncthreads();                            // previous tile's fragment reads are done
 #pragma unroll
-      for (int i = 0; i < TPW; ++i) {
-        const int tap = wave + 4 * i;
-        if (tap < TAPS) {                                  // wave-uniform
-          const int kdl = tap / KT, kt = tap % KT;
-          const int s = kt - PT;                            // dY index = t' - s
-          const int r = s & 7;                              // copy
-          const int joff = (s < 0) ? 8 : 0;                 // j = 16*ks + 8*half + joff
-          const char* ap = dy_lds + (r * 32 + l31) * WPITCH + (8 * half + joff) * 2;
-          const char* bp = a1_lds + (kdl * 32 + l31) * WPITCH + (8 * half) * 2;
+    for (int k = 0; k < NDY; ++k) {
+      const int idx = tid + 256 * k;
+      if (idx < 352) store_shifted_copies(dlo[k], dhi[k], dy_lds + (idx / 11) * WPITCH + (idx % 11) * 16);
+    }
 #pragma unroll
-          for (int ks = 0; ks < WK / 16; ++ks) {
-            const bf16x8 af = *reinterpret_cast<const bf16x8*>(ap + ks * 32);
-            const bf16x8 bf = *reinterpret_cast<const bf16x8*>(bp + ks * 32);
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[i], 0, 0, 0);
-          }
+    for (int k = 0; k < NA1; ++k) {
+      const int c = tid + 256 * k;
+      if (c < KDG * 320) *reinterpret_cast<u32x4*>(a1_lds + ((c / 320) * 32 + (c / 10) % 32) * WPITCH + (c % 10) * 16) = av[k];
+    }
+    __syncthreads();
+    t0 += WT;
+    have = settle();
+    if (have) load_tile();                      // next tile's global loads fly behind this tile's MFMAs
+    // ---- MFMA: wave w owns taps w, w+4, ...
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+      const int tap = wave + 4 * i;
+      if (tap < TAPS) {                                  // wave-uniform
+        const int kdl = tap / KT, kt = tap % KT;
+        const int s = kt - PT;                            // dY index = t' - s
+        const int r = s & 7;                              // copy
+        const int joff = (s < 0) ? 8 : 0;                 // j = 16*ks + 8*half + joff
+        const char* ap = dy_lds + (r * 32 + l31) * WPITCH + (8 * half + joff) * 2;
+        const char* bp = a1_lds + (kdl * 32 + l31) * WPITCH + (8 * half) * 2;
+#pragma unroll
+        for (int ks = 0; ks < WK / 16; ++ks) {
+          const bf16x8 af = *reinterpret_cast<const bf16x8*>(ap + ks * 32);
+          const bf16x8 bf = *reinterpret_cast<const bf16x8*>(bp + ks * 32);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[i], 0, 0, 0);
         }
       }
     }

@@ -256,6 +256,138 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(BArgs g) {
   }
 }
 
+// ---- 256 x 256 x 64, LDS-DMA staged, double-buffered: one barrier per k-tile -------------------------------------
+// 8 waves (2 x 4), each wave 128 x 64 = 4 x 2 MFMA 32x32x16 tiles.  Operand tiles go global -> LDS with
+// global_load_lds_dwordx4 (no VGPR round trip, no ds_write pass): one wave-instruction lands 8 rows x 128 B = 1 KiB
+// lane-linearly, so the LDS image has 128-B rows with NO padding; bank conflicts of the fragment reads are removed by
+// an XOR swizzle applied on the per-lane SOURCE address and again on the read: the 16-byte slot p of row r holds
+// k-segment p ^ ((r >> 1) & 7), which puts the 16 rows of every ds_read_b128 lane group on 16 distinct bank quads.
+// The DMA of tile k+1 is issued right after the barrier that publishes tile k and flies during its 32 MFMAs per wave.
+constexpr int G_TILE = 256 * 128;                 // bytes of one operand tile (256 rows x 64 bf16)
+constexpr int G_LDS = 4 * G_TILE;                 // [2 buffers][A | B] = 128 KiB
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst_wave_base) {
+  __builtin_amdgcn_global_load_lds((gbl_void*)gsrc, (lds_void*)lds_dst_wave_base, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(512) void gemm_bf16_nt_glds_kernel(BArgs g, int ntx, int nty) {
+  extern __shared__ __attribute__((aligned(1024))) char ldsg[];
+  const int z = blockIdx.z;
+  const int zb = z / g.splitk, zs = z % g.splitk;
+  const __bf16* A = g.A + (long long)zb * g.sA;
+  const __bf16* B = g.B + (long long)zb * g.sB;
+  // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs, so give each XCD one contiguous run of the
+  // (row-tile major) tile list: the tiles sharing an A row-tile then hit the same 4 MB L2.  (bijective for any count)
+  const int nt = ntx * nty;
+  const int orig = blockIdx.x;
+  const int xcd = orig & 7, q8 = nt >> 3, r8 = nt & 7;
+  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  const int m0 = (tile / ntx) * 256, n0 = (tile % ntx) * 256;
+  const int kbeg = zs * g.kchunk;
+  const int kend = min(g.K, kbeg + g.kchunk);
+  const int nkt = (kend - kbeg + BK - 1) / BK;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int l31 = lane & 31, half = lane >> 5;
+
+  // staging: wave w moves pieces w, w+8, w+16, w+24 (8 rows each) of A and of B
+  const int prow = lane >> 3;                       // row inside the piece
+  const __bf16* srcA[4];
+  const __bf16* srcB[4];
+  bool okA[4], okB[4];
+  int segk[4];                                      // k offset (elements) of the 16-byte segment this lane fetches
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wave + 8 * i) * 8 + prow;        // row inside the 256-row tile
+    segk[i] = (((lane & 7) ^ ((r >> 1) & 7)) << 3);
+    okA[i] = m0 + r < g.M;
+    okB[i] = n0 + r < g.N;
+    srcA[i] = A + (long long)(m0 + r) * g.lda + segk[i];
+    srcB[i] = B + (long long)(n0 + r) * g.ldb + segk[i];
+  }
+  auto stage = [&](int buf, int k0) {
+    char* dA = ldsg + buf * 2 * G_TILE;
+    char* dB = dA + G_TILE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool kok = k0 + segk[i] + 8 <= kend;
+      const void* pa = (okA[i] && kok) ? (const void*)(srcA[i] + k0) : (const void*)g_zero16;
+      const void* pb = (okB[i] && kok) ? (const void*)(srcB[i] + k0) : (const void*)g_zero16;
+      glds16(pa, dA + (wave + 8 * i) * 1024);
+      glds16(pb, dB + (wave + 8 * i) * 1024);
+    }
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment read offsets: row (.. + l31), k-segment kk*2 + half, swizzled with ((row >> 1) & 7) = (l31 >> 1) & 7
+  const int sx = (l31 >> 1) & 7;
+  int koff[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) koff[kk] = (((kk * 2 + half) ^ sx) << 4);
+  const int arow = (wm * 128 + l31) * 128;
+  const int brow = G_TILE + (wn * 64 + l31) * 128;
+
+  stage(0, kbeg);
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();            // (vmcnt(0) + barrier): tile kt has landed for every wave; buffer (kt+1)&1 is no longer read
+    if (kt + 1 < nkt) stage((kt + 1) & 1, kbeg + (kt + 1) * BK);
+    const char* base = ldsg + (kt & 1) * 2 * G_TILE;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      bf16x8 a[4], b[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(base + arow + i * 32 * 128 + koff[kk]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8*>(base + brow + j * 32 * 128 + koff[kk]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  float* C;
+  long long ldc;
+  const bool partial = g.splitk > 1;
+  if (partial) {
+    C = g.partial + ((long long)zb * g.splitk + zs) * (long long)g.M * g.N;
+    ldc = g.N;
+  } else {
+    C = g.C + (long long)zb * g.sC;
+    ldc = g.ldc;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + l31;
+      if (col >= g.N) continue;
+      const float bv = (!partial && g.bias) ? g.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (row < g.M) {
+          float v = acc[i][j][r] + bv;
+          float* p = C + (long long)row * ldc + col;
+          if (!partial && g.accumulate) v += *p;
+          *p = v;
+        }
+      }
+    }
+  }
+}
+
 __global__ void splitk_reduce_bf_kernel(const float* __restrict__ part, float* __restrict__ C, const float* __restrict__ bias, int M, int N,
                                         int ldc, long long sC, int splitk, int accumulate) {
   const long long zb = blockIdx.y;
@@ -339,11 +471,21 @@ extern "C" int ds2_gemm_bf16_nt(int M, int N, int K, const void* A, int lda, lon
   g.sA = strideA; g.sB = strideB; g.sC = strideC;
   g.splitk = splitk; g.kchunk = kchunk; g.accumulate = accumulate; g.partial = (float*)workspace;
   hipStream_t s = (hipStream_t)stream;
-  // big problems: 256 x 256 tiles (half the L2 traffic per flop) when that still gives >= 2 blocks per CU
+  // big problems: 256 x 256 tiles (half the L2 traffic per flop) when that still fills the chip
   const long long tiles256 = (long long)ceil_div(N, BN2) * ceil_div(M, BM2) * batch * splitk;
-  static const char* force = getenv("DS2_GEMM_TILE");      // "128" | "256": tuning override (scripts/bench_gemm.py)
-  const bool use256 = force ? (force[0] == '2') : (M >= 512 && N >= 512 && tiles256 >= 384);
-  if (use256) {
+  static const char* force = getenv("DS2_GEMM_TILE");      // "128" | "256" | "glds": tuning override (scripts/bench_gemm.py)
+  const bool big = M >= 512 && N >= 512 && tiles256 >= 384;
+  const int kind = force ? (force[0] == 'g' ? 2 : force[0] == '2' ? 1 : 0) : (big ? 2 : 0);
+  if (kind == 2) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_nt_glds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
+      attr_set = true;
+    }
+    const int ntx = ceil_div(N, 256), nty = ceil_div(M, 256);
+    hipLaunchKernelGGL(gemm_bf16_nt_glds_kernel, dim3(ntx * nty, 1, batch * splitk), dim3(512), G_LDS, s, g, ntx, nty);
+    DS2_LAUNCH_CHECK("gemm_bf16_nt_glds_kernel");
+  } else if (kind == 1) {
     static bool attr_set = false;
     if (!attr_set) {
       DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE2_BYTES));
