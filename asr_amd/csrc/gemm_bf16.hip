@@ -10,7 +10,8 @@
 //     dXn       = dGx W_ih             A = bf16(dGx)       B = bf16(W_ih)^T   (transposing cast of the weights)
 //     dW_ih     = dGx^T Xn             A = bf16(dGx)^T     B = bf16(Xn)^T     (transposing casts, K = T*B)
 //
-// Tiling: 128x128x64 block tile, 4 waves (2x2), each wave 64x64 = 2x2 MFMA 32x32x16 tiles x 4 k-steps.
+// Two kernels.  Large problems: 256x256x64 tiles staged by LDS-DMA into a double-buffered, XOR-swizzled LDS image (below).
+// Small ones: 128x128x64 block tile, 4 waves (2x2), each wave 64x64 = 2x2 MFMA 32x32x16 tiles x 4 k-steps:
 // LDS tile rows are 64 bf16 = 128 B + 16 B pad (pitch 144 B): ds_write_b128 by 8-lane groups and
 // ds_read_b128 by the MFMA's 16-lane groups are both bank-conflict-free.  Global loads of tile k+1 are issued
 // before the MFMAs of tile k and parked in registers; out-of-range rows / k-segments read a zero page
@@ -127,119 +128,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(BArgs g) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = n0 + wn * 64 + j * 32 + l31;
-      if (col >= g.N) continue;
-      const float bv = (!partial && g.bias) ? g.bias[col] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (row < g.M) {
-          float v = acc[i][j][r] + bv;
-          float* p = C + (long long)row * ldc + col;
-          if (!partial && g.accumulate) v += *p;
-          *p = v;
-        }
-      }
-    }
-  }
-}
-
-// ---- 256 x 256 x 64 variant: 8 waves (4 x 2), each wave 64 x 128 = 2 x 4 MFMA tiles (128 accumulator registers).
-// Halves the L2 -> LDS bytes per flop of the 128^2 tile, which is what bounds that kernel (~700 TF/s).  73.7 KB of
-// dynamic LDS, one block per CU; global loads of tile k+1 are parked in registers across the 32 MFMAs of tile k.
-constexpr int BM2 = 256, BN2 = 256;
-constexpr int TILE2_BYTES = BM2 * PITCH;          // 36864
-
-// 4 x 16-byte loads per thread per operand tile (256 rows x 8 segments / 512 threads)
-__device__ __forceinline__ void load_tile2(const __bf16* __restrict__ base, int ld, int r0, int rmax, int k0, int kmax, f32x4 (&reg)[4]) {
-  const int seg = threadIdx.x & 7;
-  const int k = k0 + seg * 8;
-  const bool kok = k + 8 <= kmax;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = r0 + (threadIdx.x >> 3) + 64 * i;
-    const bool ok = kok && r < rmax;
-    const void* p = ok ? (const void*)(base + (long long)r * ld + k) : (const void*)g_zero16;
-    reg[i] = *reinterpret_cast<const f32x4*>(p);
-  }
-}
-__device__ __forceinline__ void store_tile2(char* __restrict__ lds, const f32x4 (&reg)[4]) {
-  const int seg = threadIdx.x & 7;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = (threadIdx.x >> 3) + 64 * i;
-    *reinterpret_cast<f32x4*>(lds + r * PITCH + seg * 16) = reg[i];
-  }
-}
-
-__global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(BArgs g) {
-  extern __shared__ __attribute__((aligned(16))) char lds2[];   // [A 256 rows | B 256 rows] x 144 B
-  const int z = blockIdx.z;
-  const int zb = z / g.splitk, zs = z % g.splitk;
-  const __bf16* A = g.A + (long long)zb * g.sA;
-  const __bf16* B = g.B + (long long)zb * g.sB;
-  const int m0 = blockIdx.y * BM2, n0 = blockIdx.x * BN2;
-  const int kbeg = zs * g.kchunk;
-  const int kend = min(g.K, kbeg + g.kchunk);
-  const int nkt = (kend - kbeg + BK - 1) / BK;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1;          // 4 x 2 waves: rows wm*64, cols wn*128
-  const int l31 = lane & 31, half = lane >> 5;
-
-  f32x16 acc[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  f32x4 ra[4], rb[4];
-  load_tile2(A, g.lda, m0, g.M, kbeg, kend, ra);
-  load_tile2(B, g.ldb, n0, g.N, kbeg, kend, rb);
-  char* As = lds2;
-  char* Bs = lds2 + TILE2_BYTES;
-  const char* afrag = As + (wm * 64 + l31) * PITCH + half * 16;
-  const char* bfrag = Bs + (wn * 128 + l31) * PITCH + half * 16;
-
-  for (int kt = 0; kt < nkt; ++kt) {
-    __syncthreads();
-    store_tile2(As, ra);
-    store_tile2(Bs, rb);
-    __syncthreads();
-    if (kt + 1 < nkt) {
-      const int k0 = kbeg + (kt + 1) * BK;
-      load_tile2(A, g.lda, m0, g.M, k0, kend, ra);
-      load_tile2(B, g.ldb, n0, g.N, k0, kend, rb);
-    }
-#pragma unroll
-    for (int kk = 0; kk < BK / 16; ++kk) {
-      bf16x8 a[2], b[4];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const bf16x8*>(afrag + i * 32 * PITCH + kk * 32);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8*>(bfrag + j * 32 * PITCH + kk * 32);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-  }
-
-  float* C;
-  long long ldc;
-  const bool partial = g.splitk > 1;
-  if (partial) {
-    C = g.partial + ((long long)zb * g.splitk + zs) * (long long)g.M * g.N;
-    ldc = g.N;
-  } else {
-    C = g.C + (long long)zb * g.sC;
-    ldc = g.ldc;
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int col = n0 + wn * 128 + j * 32 + l31;
       if (col >= g.N) continue;
       const float bv = (!partial && g.bias) ? g.bias[col] : 0.f;
 #pragma unroll
@@ -471,12 +359,11 @@ extern "C" int ds2_gemm_bf16_nt(int M, int N, int K, const void* A, int lda, lon
   g.sA = strideA; g.sB = strideB; g.sC = strideC;
   g.splitk = splitk; g.kchunk = kchunk; g.accumulate = accumulate; g.partial = (float*)workspace;
   hipStream_t s = (hipStream_t)stream;
-  // big problems: 256 x 256 tiles (half the L2 traffic per flop) when that still fills the chip
-  const long long tiles256 = (long long)ceil_div(N, BN2) * ceil_div(M, BM2) * batch * splitk;
-  static const char* force = getenv("DS2_GEMM_TILE");      // "128" | "256" | "glds": tuning override (scripts/bench_gemm.py)
-  const bool big = M >= 512 && N >= 512 && tiles256 >= 384;
-  const int kind = force ? (force[0] == 'g' ? 2 : force[0] == '2' ? 1 : 0) : (big ? 2 : 0);
-  if (kind == 2) {
+  // 256 x 256 LDS-DMA kernel whenever its tiles cover at least half the chip; the 128 x 128 kernel for everything smaller
+  const long long tiles256 = (long long)ceil_div(N, 256) * ceil_div(M, 256) * batch * splitk;
+  static const char* force = getenv("DS2_GEMM_TILE");      // "128" | "glds": tuning override (scripts/bench_gemm.py)
+  const bool use_glds = force ? (force[0] == 'g') : (M >= 256 && N >= 256 && tiles256 >= 128);
+  if (use_glds) {
     static bool attr_set = false;
     if (!attr_set) {
       DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_nt_glds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
@@ -485,15 +372,6 @@ extern "C" int ds2_gemm_bf16_nt(int M, int N, int K, const void* A, int lda, lon
     const int ntx = ceil_div(N, 256), nty = ceil_div(M, 256);
     hipLaunchKernelGGL(gemm_bf16_nt_glds_kernel, dim3(ntx * nty, 1, batch * splitk), dim3(512), G_LDS, s, g, ntx, nty);
     DS2_LAUNCH_CHECK("gemm_bf16_nt_glds_kernel");
-  } else if (kind == 1) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE2_BYTES));
-      attr_set = true;
-    }
-    dim3 grid(ceil_div(N, BN2), ceil_div(M, BM2), batch * splitk);
-    hipLaunchKernelGGL(gemm_bf16_nt_256_kernel, grid, dim3(512), 2 * TILE2_BYTES, s, g);
-    DS2_LAUNCH_CHECK("gemm_bf16_nt_256_kernel");
   } else {
     dim3 grid(ceil_div(N, BN), ceil_div(M, BM), batch * splitk);
     hipLaunchKernelGGL(gemm_bf16_nt_kernel, grid, dim3(256), 0, s, g);

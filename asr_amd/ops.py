@@ -107,6 +107,28 @@ def cast_transpose_bf16(src: Tensor) -> Tensor:
     return dst
 
 
+def _pick_splitk(M: int, N: int, K: int) -> int:
+    """Split-K factor for the bf16 GEMM: trade chip fill (256 CUs, one 256x256 tile each per round) against the fp32 partial
+    slabs a split writes and re-reads.  Rates are the measured ones (scripts/bench_gemm.py): ~1.1 PF/s per busy CU-round for the
+    256-tile kernel, ~3 TB/s for slab traffic."""
+    if M >= 256 and N >= 256:
+        tiles = ((M + 255) // 256) * ((N + 255) // 256)
+        best, best_cost = 1, None
+        for s in (1, 2, 3, 4, 6, 8, 12, 16):
+            if s > 1 and K // s < 1024:
+                break
+            rounds = -(-tiles * s // 256)
+            util = tiles * s / (rounds * 256.0)
+            cost = 2.0 * M * N * K / (1.1e15 * util) + (0.0 if s == 1 else (s + 1) * M * N * 4 / 3e12)
+            if best_cost is None or cost < best_cost * 0.97:
+                best, best_cost = s, cost
+        return best
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if tiles < 400 and K >= 4096:
+        return max(1, min((768 + tiles - 1) // tiles, K // 2048))
+    return 1
+
+
 def gemm_bf16_nt(A: Tensor, B: Tensor, bias: Optional[Tensor] = None, out: Optional[Tensor] = None, accumulate: bool = False,
                  splitk: int = 0) -> Tensor:
     """out[M,N] fp32 (+)= A[M,K] @ B[N,K]^T, A/B bf16 with K (incl. zero padding) a multiple of 8."""
@@ -118,10 +140,7 @@ def gemm_bf16_nt(A: Tensor, B: Tensor, bias: Optional[Tensor] = None, out: Optio
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=A.device)
     if splitk <= 0:
-        tiles = ((M + 127) // 128) * ((N + 127) // 128)
-        splitk = 1
-        if tiles < 400 and K >= 4096:
-            splitk = max(1, min((768 + tiles - 1) // tiles, K // 2048))
+        splitk = _pick_splitk(M, N, K)
     ws, wsb = None, 0
     if splitk > 1:
         wsb = lib.ds2_gemm_bf16_workspace_bytes(M, N, 1, splitk)

@@ -1,4 +1,4 @@
-"""GPU micro-benchmark of the bf16 NT GEMM on the train step's three shapes (run with DS2_GEMM_TILE=128|256)."""
+"""GPU micro-benchmark of the bf16 NT GEMM on the train step's three shapes (run with DS2_GEMM_TILE=128|glds)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from asr_amd import ops
