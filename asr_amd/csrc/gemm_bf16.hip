@@ -312,23 +312,45 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
   }
 }
 
-// dst[c][r] = bf16(src[r][c]) ; dst row pitch ldd >= R (ldd % 8 == 0), pad columns R..ldd zero-filled.
-// 64x64 tiles through LDS: fp32 reads are 256-B runs along c, bf16 writes are 128-B runs along r.
-__global__ __launch_bounds__(256) void cast_transpose_bf16_kernel(const float* __restrict__ src, int lds_, __bf16* __restrict__ dst, int ldd,
-                                                                  int R, int Cc) {
+// dstT[c][r] = bf16(src[r][c]) ; dstT row pitch ldt >= R (ldt % 8 == 0), pad columns R..ldt zero-filled.  Optionally also
+// dstR[r][c] = bf16(src[r][c]) (row pitch ldr % 8 == 0, pad columns C..ldr zero) from the SAME read of src: the backward pass
+// needs dGx both ways (dX = dGx W, dW = dGx^T X) and the fp32 source is the big operand of both passes.
+// 64x64 tiles through LDS: fp32 reads are float4 (256-B runs along c), transposed writes are 16-byte runs along r.
+__global__ __launch_bounds__(256) void cast_transpose_bf16_kernel(const float* __restrict__ src, int lds_, __bf16* __restrict__ dstT, int ldt,
+                                                                  __bf16* __restrict__ dstR, int ldr, int R, int Cc, int vec) {
   __shared__ float tile[64][65];
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // ty 0..3
+  const int tid = threadIdx.x;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int r = r0 + ty + 4 * i, c = c0 + tx;
-    tile[ty + 4 * i][tx] = (r < R && c < Cc) ? src[(long long)r * lds_ + c] : 0.f;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int rl = pass * 16 + (tid >> 4), cl = (tid & 15) * 4;
+    const int r = r0 + rl, c = c0 + cl;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (r < R) {
+      const float* sp = src + (long long)r * lds_ + c;
+      if (vec && c + 4 <= Cc) {
+        const f32x4 q = *reinterpret_cast<const f32x4*>(sp);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (c + j < Cc) ? sp[j] : 0.f;
+      }
+      if (dstR && c < ldr) *reinterpret_cast<bf16x4*>(dstR + (long long)r * ldr + c) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tile[rl][cl + j] = v[j];
   }
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int c = c0 + ty + 4 * i, r = r0 + tx;
-    if (c < Cc && r < ldd) dst[(long long)c * ldd + r] = (__bf16)tile[tx][ty + 4 * i];   // r >= R rows were loaded as 0
+  for (int pass = 0; pass < 2; ++pass) {
+    const int cl = pass * 32 + (tid >> 3), rl = (tid & 7) * 8;
+    const int c = c0 + cl, r = r0 + rl;
+    if (c < Cc && r < ldt) {                      // rows >= R were staged as zeros; ldt % 8 == 0 keeps the 8-run inside the pitch
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (__bf16)tile[rl + j][cl];
+      *reinterpret_cast<bf16x8*>(dstT + (long long)c * ldt + r) = o;
+    }
   }
 }
 
@@ -397,11 +419,26 @@ extern "C" int ds2_cast_bf16(const float* src, int ld_src, void* dst, int ld_dst
   return 0;
 }
 
+static int launch_cast_transpose(const float* src, int ld_src, void* dst_t, int ld_t, void* dst_r, int ld_r, int R, int Cc, void* stream) {
+  dim3 grid(ceil_div(dst_r ? max(Cc, ld_r) : Cc, 64), ceil_div(ld_t, 64));
+  const int vec = ((ld_src % 4) == 0) && (((uintptr_t)src % 16) == 0);
+  hipLaunchKernelGGL(cast_transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, (__bf16*)dst_t, ld_t, (__bf16*)dst_r,
+                     ld_r, R, Cc, vec);
+  DS2_LAUNCH_CHECK("cast_transpose_bf16_kernel");
+  return 0;
+}
+
 // dst (C, ldd) bf16 = cast(src (R, C) fp32)^T ; ldd % 8 == 0, ldd >= R, pad columns zero.
 extern "C" int ds2_cast_transpose_bf16(const float* src, int ld_src, void* dst, int ld_dst, int R, int Cc, void* stream) {
   DS2_REQUIRE(src && dst && R > 0 && Cc > 0 && ld_dst >= R && (ld_dst % 8) == 0, "ds2_cast_transpose_bf16: bad args");
-  dim3 grid(ceil_div(Cc, 64), ceil_div(ld_dst, 64));
-  hipLaunchKernelGGL(cast_transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, (__bf16*)dst, ld_dst, R, Cc);
-  DS2_LAUNCH_CHECK("cast_transpose_bf16_kernel");
-  return 0;
+  return launch_cast_transpose(src, ld_src, dst, ld_dst, nullptr, 0, R, Cc, stream);
+}
+
+// Both bf16 copies from one read of src (R, C) fp32: dst_r (R, ld_r) row-major and dst_t (C, ld_t) transposed; pads zero.
+// ld_r % 8 == 0, C <= ld_r < C + 8 ; ld_t % 8 == 0, ld_t >= R.
+extern "C" int ds2_cast_bf16_both(const float* src, int ld_src, void* dst_r, int ld_r, void* dst_t, int ld_t, int R, int Cc, void* stream) {
+  DS2_REQUIRE(src && dst_r && dst_t && R > 0 && Cc > 0, "ds2_cast_bf16_both: bad args");
+  DS2_REQUIRE(ld_t >= R && (ld_t % 8) == 0 && ld_r >= Cc && ld_r < Cc + 8 && (ld_r % 8) == 0, "ds2_cast_bf16_both: bad pitches (ld_r=%d ld_t=%d)",
+              ld_r, ld_t);
+  return launch_cast_transpose(src, ld_src, dst_t, ld_t, dst_r, ld_r, R, Cc, stream);
 }

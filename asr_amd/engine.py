@@ -193,8 +193,12 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
         ops.rnn_bwd(G, dy, lc.gx, lc.aux, lc.hbuf, lc.wpb, lens_dev, T, B, H, bf16=bf)
         dgx = lc.gx                                                                               # now dGx (M, 2GH)
         # ---- critical path: dXn = dGx W_ih (feeds the next layer's backward) ---------------------------------------
+        dgxT = None
         if bf:
-            dxn = ops.gemm_bf16_nt(ops.cast_bf16(dgx), ops.cast_transpose_bf16(W[f"rnns.{l}.wih_cat"]))
+            # dGx is needed both ways (dXn = dGx W_ih here, dW = dGx^T [Xn | h] below): both bf16 copies from one read
+            dgx_bf, dgxT = ops.cast_bf16_both(dgx)
+            dxn = ops.gemm_bf16_nt(dgx_bf, ops.cast_transpose_bf16(W[f"rnns.{l}.wih_cat"]))
+            del dgx_bf
         else:
             dxn = ops.gemm(dgx, W[f"rnns.{l}.wih_cat"])                                           # (M, I)
         # ---- off the critical path: bias and weight gradients ------------------------------------------------------
@@ -209,10 +213,8 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
                 dbhh[:, 2 * H:] = ops.colsum(lc.aux).view(2, H)
             # dW_hh[dir] = sum_t dGh[t]^T h_prev[t]  (h_prev = h[t-1] fwd / h[t+1] reverse)
             dwhh = Gr[f"rnns.{l}.whh_cat"]                                                        # (2, GH, H)
-            dgxT = None
             if T > 1 and bf and B % 8 == 0:
-                # bf16 MFMA path: transposed bf16 copies, the time shift is a column offset of B elements
-                dgxT = ops.cast_transpose_bf16(dgx)                                               # (2GH, M)
+                # bf16 MFMA path: transposed bf16 copies (dgxT: (2GH, M)), the time shift is a column offset of B elements
                 hT = ops.cast_transpose_bf16(lc.hbuf)                                             # (2H, M)
                 auxT = ops.cast_transpose_bf16(lc.aux) if G == 3 else None
                 rows = 2 * H if G == 3 else 4 * H
@@ -242,8 +244,6 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
                 dwhh.zero_()
             # dW_ih (2GH, I) = dGx^T Xn
             if bf:
-                if dgxT is None:
-                    dgxT = ops.cast_transpose_bf16(dgx)
                 xnT = ops.cast_transpose_bf16(lc.xn)
                 ops.gemm_bf16_nt(dgxT, xnT, out=Gr[f"rnns.{l}.wih_cat"])
                 keep.append((dgxT, xnT))

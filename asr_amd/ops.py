@@ -107,6 +107,17 @@ def cast_transpose_bf16(src: Tensor) -> Tensor:
     return dst
 
 
+def cast_bf16_both(src: Tensor):
+    """(R, C) fp32 -> (bf16 (R, pad8(C)), bf16 (C, pad8(R)) = src^T) from one read of src; pads zero."""
+    _chk_f32(src)
+    R, Cc = src.shape
+    dst_r = torch.empty(R, _pad8(Cc), dtype=torch.bfloat16, device=src.device)
+    dst_t = torch.empty(Cc, _pad8(R), dtype=torch.bfloat16, device=src.device)
+    _lib.check(_lib.load().ds2_cast_bf16_both(src.data_ptr(), _row_pitch(src), dst_r.data_ptr(), dst_r.size(1), dst_t.data_ptr(), dst_t.size(1),
+                                              R, Cc, _stream()), "ds2_cast_bf16_both")
+    return dst_r, dst_t
+
+
 def _pick_splitk(M: int, N: int, K: int) -> int:
     """Split-K factor for the bf16 GEMM: trade chip fill (256 CUs, one 256x256 tile each per round) against the fp32 partial
     slabs a split writes and re-reads.  Rates are the measured ones (scripts/bench_gemm.py): ~1.1 PF/s per busy CU-round for the

@@ -84,6 +84,13 @@ def test_gemm_bf16_and_casts(dev, M, N, K):
     X, Y = A.t().contiguous(), B.t().contiguous()
     outT = ops.gemm_bf16_nt(ops.cast_transpose_bf16(g(X, dev)), ops.cast_transpose_bf16(g(Y, dev)))
     assert rel_l2(outT.cpu(), ref - bias.double()) < 3e-6
+    # both copies from one read (bit-exact against the two single-output kernels), also on a strided column-block view
+    Ar, At2 = ops.cast_bf16_both(g(A, dev))
+    assert torch.equal(Ar.cpu(), Ab.cpu()) and torch.equal(At2.cpu(), ops.cast_transpose_bf16(g(A, dev)).cpu())
+    if K >= 16:
+        view = g(A, dev)[:, 4:K - 3]
+        vr, vt = ops.cast_bf16_both(view)
+        assert torch.equal(vr.cpu(), ops.cast_bf16(view).cpu()) and torch.equal(vt.cpu(), ops.cast_transpose_bf16(view).cpu())
 
 
 # ---------------------------------------------------------------------------------------------- BN1d
