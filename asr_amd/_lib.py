@@ -29,7 +29,8 @@ SIGNATURES = {
     "ds2_gemm_bf16_nt": (i32, [i32, i32, i32, vp, i32, i64, vp, i32, i64, vp, i32, i64, vp, i32, i32, i32, vp, sz, vp]),
     "ds2_cast_bf16": (i32, [vp, i32, vp, i32, i32, i32, vp]),
     "ds2_cast_transpose_bf16": (i32, [vp, i32, vp, i32, i32, i32, vp]),
-    "ds2_cast_bf16_both": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, vp]),
+    "ds2_cast_bf16_both_workspace_bytes": (sz, [i32, i32]),
+    "ds2_cast_bf16_both": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, vp, vp, sz, vp]),
     "ds2_colreduce_workspace_bytes": (sz, [i32, i32]),
     "ds2_colstats_f32": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, f32, vp, sz, vp]),
     "ds2_add_colstats_f32": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, vp, vp, vp, vp, f32, vp, sz, vp]),

@@ -56,3 +56,7 @@ __device__ __forceinline__ float tanhf_(float x) {
   const float t = 1.0f - 2.0f * __frcp_rn(e + 1.0f);
   return copysignf(t, x);
 }
+
+// ---- cross-file internals (not part of the C ABI) ------------------------------------------------------------
+// norm.hip: out0[c] = sum_k part[k][c][0], out1[c] = sum_k part[k][c][1] over `chunks` fp32 partial rows, combined in fp64
+int ds2i_col_finalize_sums(const float* part, int chunks, int H, float* out0, float* out1, hipStream_t s);

@@ -317,7 +317,8 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
 // needs dGx both ways (dX = dGx W, dW = dGx^T X) and the fp32 source is the big operand of both passes.
 // 64x64 tiles through LDS: fp32 reads are float4 (256-B runs along c), transposed writes are 16-byte runs along r.
 __global__ __launch_bounds__(256) void cast_transpose_bf16_kernel(const float* __restrict__ src, int lds_, __bf16* __restrict__ dstT, int ldt,
-                                                                  __bf16* __restrict__ dstR, int ldr, int R, int Cc, int vec) {
+                                                                  __bf16* __restrict__ dstR, int ldr, int R, int Cc, int vec,
+                                                                  float* __restrict__ colpart) {
   __shared__ float tile[64][65];
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   const int tid = threadIdx.x;
@@ -351,6 +352,14 @@ __global__ __launch_bounds__(256) void cast_transpose_bf16_kernel(const float* _
       for (int j = 0; j < 8; ++j) o[j] = (__bf16)tile[rl + j][cl];
       *reinterpret_cast<bf16x8*>(dstT + (long long)c * ldt + r) = o;
     }
+  }
+  if (colpart && tid < 64 && c0 + tid < Cc && r0 < R) {     // column sums of this 64-row tile: partial [row tile][C][2] (second slot unused)
+    float sum = 0.f;
+#pragma unroll 16
+    for (int r = 0; r < 64; ++r) sum += tile[r][tid];
+    float* o = colpart + ((long long)blockIdx.y * Cc + c0 + tid) * 2;
+    o[0] = sum;
+    o[1] = 0.f;
   }
 }
 
@@ -419,11 +428,12 @@ extern "C" int ds2_cast_bf16(const float* src, int ld_src, void* dst, int ld_dst
   return 0;
 }
 
-static int launch_cast_transpose(const float* src, int ld_src, void* dst_t, int ld_t, void* dst_r, int ld_r, int R, int Cc, void* stream) {
+static int launch_cast_transpose(const float* src, int ld_src, void* dst_t, int ld_t, void* dst_r, int ld_r, int R, int Cc, float* colpart,
+                                 void* stream) {
   dim3 grid(ceil_div(dst_r ? max(Cc, ld_r) : Cc, 64), ceil_div(ld_t, 64));
   const int vec = ((ld_src % 4) == 0) && (((uintptr_t)src % 16) == 0);
   hipLaunchKernelGGL(cast_transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, (__bf16*)dst_t, ld_t, (__bf16*)dst_r,
-                     ld_r, R, Cc, vec);
+                     ld_r, R, Cc, vec, colpart);
   DS2_LAUNCH_CHECK("cast_transpose_bf16_kernel");
   return 0;
 }
@@ -431,14 +441,22 @@ static int launch_cast_transpose(const float* src, int ld_src, void* dst_t, int 
 // dst (C, ldd) bf16 = cast(src (R, C) fp32)^T ; ldd % 8 == 0, ldd >= R, pad columns zero.
 extern "C" int ds2_cast_transpose_bf16(const float* src, int ld_src, void* dst, int ld_dst, int R, int Cc, void* stream) {
   DS2_REQUIRE(src && dst && R > 0 && Cc > 0 && ld_dst >= R && (ld_dst % 8) == 0, "ds2_cast_transpose_bf16: bad args");
-  return launch_cast_transpose(src, ld_src, dst, ld_dst, nullptr, 0, R, Cc, stream);
+  return launch_cast_transpose(src, ld_src, dst, ld_dst, nullptr, 0, R, Cc, nullptr, stream);
 }
 
 // Both bf16 copies from one read of src (R, C) fp32: dst_r (R, ld_r) row-major and dst_t (C, ld_t) transposed; pads zero.
-// ld_r % 8 == 0, C <= ld_r < C + 8 ; ld_t % 8 == 0, ld_t >= R.
-extern "C" int ds2_cast_bf16_both(const float* src, int ld_src, void* dst_r, int ld_r, void* dst_t, int ld_t, int R, int Cc, void* stream) {
+// ld_r % 8 == 0, C <= ld_r < C + 8 ; ld_t % 8 == 0, ld_t >= R.  colsum (C) fp32, optional: column sums of src from the same
+// read (the bias gradient), needs ws of ds2_cast_bf16_both_workspace_bytes(R, C).
+extern "C" size_t ds2_cast_bf16_both_workspace_bytes(int R, int Cc) { return (size_t)ceil_div(R, 64) * Cc * 2 * sizeof(float); }
+
+extern "C" int ds2_cast_bf16_both(const float* src, int ld_src, void* dst_r, int ld_r, void* dst_t, int ld_t, int R, int Cc, float* colsum,
+                                  void* ws, size_t ws_bytes, void* stream) {
   DS2_REQUIRE(src && dst_r && dst_t && R > 0 && Cc > 0, "ds2_cast_bf16_both: bad args");
   DS2_REQUIRE(ld_t >= R && (ld_t % 8) == 0 && ld_r >= Cc && ld_r < Cc + 8 && (ld_r % 8) == 0, "ds2_cast_bf16_both: bad pitches (ld_r=%d ld_t=%d)",
               ld_r, ld_t);
-  return launch_cast_transpose(src, ld_src, dst_t, ld_t, dst_r, ld_r, R, Cc, stream);
+  if (colsum) DS2_REQUIRE(ws && ws_bytes >= ds2_cast_bf16_both_workspace_bytes(R, Cc), "ds2_cast_bf16_both: workspace too small");
+  int rc = launch_cast_transpose(src, ld_src, dst_t, ld_t, dst_r, ld_r, R, Cc, colsum ? (float*)ws : nullptr, stream);
+  if (rc || !colsum) return rc;
+  // the partial rows of tiles past R (ld_t > R padding) are never produced: exactly ceil(R/64) row tiles hold data
+  return ds2i_col_finalize_sums((const float*)ws, ceil_div(R, 64), Cc, colsum, nullptr, (hipStream_t)stream);
 }

@@ -97,15 +97,30 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
 // finalize: sums over chunks in fp64.
 //   kind 0: out0 = mean, out1 = biased var; optional running stats update (momentum, unbiased var)
 //   kind 1: out0 = s0, out1 = s1 (raw sums)
-__global__ void col_finalize_kernel(const float* __restrict__ part, int chunks, int H, double count, int kind,
-                                    float* __restrict__ out0, float* __restrict__ out1, float* __restrict__ run_mean,
-                                    float* __restrict__ run_var, float momentum) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= H) return;
+__global__ __launch_bounds__(256) void col_finalize_kernel(const float* __restrict__ part, int chunks, int H, double count, int kind,
+                                                           float* __restrict__ out0, float* __restrict__ out1,
+                                                           float* __restrict__ run_mean, float* __restrict__ run_var, float momentum) {
+  // block = 32 columns x 8 chunk groups: the chunk loop (up to 2048 partials) is split 8 ways and combined in a fixed order
+  __shared__ double red[8][32][2];
+  const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   double a = 0.0, b = 0.0;
-  for (int k = 0; k < chunks; ++k) {
-    a += (double)part[((long long)k * H + c) * 2 + 0];
-    b += (double)part[((long long)k * H + c) * 2 + 1];
+  if (c < H) {
+    for (int k = grp; k < chunks; k += 8) {
+      a += (double)part[((long long)k * H + c) * 2 + 0];
+      b += (double)part[((long long)k * H + c) * 2 + 1];
+    }
+  }
+  red[grp][cl][0] = a;
+  red[grp][cl][1] = b;
+  __syncthreads();
+  if (grp != 0 || c >= H) return;
+  a = 0.0;
+  b = 0.0;
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    a += red[g][cl][0];
+    b += red[g][cl][1];
   }
   if (kind == 0) {
     const double m = a / count;
@@ -120,7 +135,7 @@ __global__ void col_finalize_kernel(const float* __restrict__ part, int chunks, 
     }
   } else {
     out0[c] = (float)a;
-    out1[c] = (float)b;
+    if (out1) out1[c] = (float)b;
   }
 }
 
@@ -375,8 +390,16 @@ static int col_reduce_launch(int mode, const float* X, int ldx, const float* X2,
   else if (mode == 1) hipLaunchKernelGGL((col_reduce_kernel<1>), grid, block, 0, s, X, ldx, X2, ldx2, Y, ldy, M, H, rpc, mean, var, eps, part, vec);
   else hipLaunchKernelGGL((col_reduce_kernel<2>), grid, block, 0, s, X, ldx, X2, ldx2, Y, ldy, M, H, rpc, mean, var, eps, part, vec);
   DS2_LAUNCH_CHECK("col_reduce_kernel");
-  hipLaunchKernelGGL(col_finalize_kernel, dim3(ceil_div(H, 256)), dim3(256), 0, s, (const float*)part, nch, H, (double)M, kind,
+  hipLaunchKernelGGL(col_finalize_kernel, dim3(ceil_div(H, 32)), dim3(256), 0, s, (const float*)part, nch, H, (double)M, kind,
                      out0, out1, run_mean, run_var, momentum);
+  DS2_LAUNCH_CHECK("col_finalize_kernel");
+  return 0;
+}
+
+// internal (common.h): raw column sums from [chunks][H][2] fp32 partials (fp64 combine) — used by the fused cast + colsum pass
+int ds2i_col_finalize_sums(const float* part, int chunks, int H, float* out0, float* out1, hipStream_t s) {
+  hipLaunchKernelGGL(col_finalize_kernel, dim3(ceil_div(H, 32)), dim3(256), 0, s, part, chunks, H, 1.0, 1, out0, out1, (float*)nullptr,
+                     (float*)nullptr, 0.f);
   DS2_LAUNCH_CHECK("col_finalize_kernel");
   return 0;
 }
@@ -456,7 +479,7 @@ static int chan_reduce_launch(int mode, const float* Y, const float* dA, int Bn,
   if (mode == 0) hipLaunchKernelGGL((chan_reduce_kernel<0>), grid, block, 0, s, Y, dA, Bn, C, D, T, rpc, lens, mean, var, gamma, beta, eps, part);
   else hipLaunchKernelGGL((chan_reduce_kernel<1>), grid, block, 0, s, Y, dA, Bn, C, D, T, rpc, lens, mean, var, gamma, beta, eps, part);
   DS2_LAUNCH_CHECK("chan_reduce_kernel");
-  hipLaunchKernelGGL(col_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, (const float*)part, nch, C,
+  hipLaunchKernelGGL(col_finalize_kernel, dim3(ceil_div(C, 32)), dim3(256), 0, s, (const float*)part, nch, C,
                      (double)Bn * D * T, kind, out0, out1, run_mean, run_var, momentum);
   DS2_LAUNCH_CHECK("col_finalize_kernel");
   return 0;

@@ -196,7 +196,7 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
         dgxT = None
         if bf:
             # dGx is needed both ways (dXn = dGx W_ih here, dW = dGx^T [Xn | h] below): both bf16 copies from one read
-            dgx_bf, dgxT = ops.cast_bf16_both(dgx)
+            dgx_bf, dgxT, dbih_sum = ops.cast_bf16_both(dgx, colsum=True)                          # + db_ih = column sums of dGx
             dxn = ops.gemm_bf16_nt(dgx_bf, ops.cast_transpose_bf16(W[f"rnns.{l}.wih_cat"]))
             del dgx_bf
         else:
@@ -206,7 +206,7 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
         keep.append((dgx, lc.aux, lc.hbuf, lc.xn))
         with torch.cuda.stream(side):
             dbih = Gr[f"rnns.{l}.bih_cat"]
-            dbih.copy_(ops.colsum(dgx))
+            dbih.copy_(dbih_sum if bf else ops.colsum(dgx))
             dbhh = Gr[f"rnns.{l}.bhh_cat"]                                                        # (2, GH)
             dbhh.copy_(dbih.view(2, G * H))
             if G == 3:

@@ -107,15 +107,21 @@ def cast_transpose_bf16(src: Tensor) -> Tensor:
     return dst
 
 
-def cast_bf16_both(src: Tensor):
-    """(R, C) fp32 -> (bf16 (R, pad8(C)), bf16 (C, pad8(R)) = src^T) from one read of src; pads zero."""
+def cast_bf16_both(src: Tensor, colsum: bool = False):
+    """(R, C) fp32 -> (bf16 (R, pad8(C)), bf16 (C, pad8(R)) = src^T[, fp32 column sums (C)]) from one read of src; pads zero."""
     _chk_f32(src)
     R, Cc = src.shape
+    lib = _lib.load()
     dst_r = torch.empty(R, _pad8(Cc), dtype=torch.bfloat16, device=src.device)
     dst_t = torch.empty(Cc, _pad8(R), dtype=torch.bfloat16, device=src.device)
-    _lib.check(_lib.load().ds2_cast_bf16_both(src.data_ptr(), _row_pitch(src), dst_r.data_ptr(), dst_r.size(1), dst_t.data_ptr(), dst_t.size(1),
-                                              R, Cc, _stream()), "ds2_cast_bf16_both")
-    return dst_r, dst_t
+    cs, ws, wsb = None, None, 0
+    if colsum:
+        cs = torch.empty(Cc, dtype=torch.float32, device=src.device)
+        wsb = lib.ds2_cast_bf16_both_workspace_bytes(R, Cc)
+        ws = _ws(wsb, src.device)
+    _lib.check(lib.ds2_cast_bf16_both(src.data_ptr(), _row_pitch(src), dst_r.data_ptr(), dst_r.size(1), dst_t.data_ptr(), dst_t.size(1),
+                                      R, Cc, _ptr(cs), _ptr(ws), wsb, _stream()), "ds2_cast_bf16_both")
+    return (dst_r, dst_t, cs) if colsum else (dst_r, dst_t)
 
 
 def _pick_splitk(M: int, N: int, K: int) -> int:

@@ -51,8 +51,11 @@ int ds2_gemm_bf16_nt(int M, int N, int K, const void* A, int lda, long long stri
 int ds2_cast_bf16(const float* src, int ld_src, void* dst, int ld_dst, int R, int Cc, void* stream);
 int ds2_cast_transpose_bf16(const float* src, int ld_src, void* dst, int ld_dst, int R, int Cc, void* stream);
 /* both copies from ONE read of src: dst_r (R, ld_r) = bf16(src), dst_t (C, ld_t) = bf16(src)^T, pads zero
- * (ld_r % 8 == 0, C <= ld_r < C + 8; ld_t % 8 == 0, ld_t >= R) */
-int ds2_cast_bf16_both(const float* src, int ld_src, void* dst_r, int ld_r, void* dst_t, int ld_t, int R, int Cc, void* stream);
+ * (ld_r % 8 == 0, C <= ld_r < C + 8; ld_t % 8 == 0, ld_t >= R); colsum (C) optional: column sums of src from the same read
+ * (the bias gradient db_ih = sum_rows dGx), then ws >= ds2_cast_bf16_both_workspace_bytes(R, C) */
+size_t ds2_cast_bf16_both_workspace_bytes(int R, int Cc);
+int ds2_cast_bf16_both(const float* src, int ld_src, void* dst_r, int ld_r, void* dst_t, int ld_t, int R, int Cc, float* colsum, void* ws,
+                       size_t ws_bytes, void* stream);
 
 /* ---- BatchNorm1d over (T*B, H) rows, padding rows included -----------------------------------
  * modules/blocks.py:75,85-86 (SequenceWise(BatchNorm1d)) and modules/deepspeech.py:104 (fc block).

@@ -85,8 +85,9 @@ def test_gemm_bf16_and_casts(dev, M, N, K):
     outT = ops.gemm_bf16_nt(ops.cast_transpose_bf16(g(X, dev)), ops.cast_transpose_bf16(g(Y, dev)))
     assert rel_l2(outT.cpu(), ref - bias.double()) < 3e-6
     # both copies from one read (bit-exact against the two single-output kernels), also on a strided column-block view
-    Ar, At2 = ops.cast_bf16_both(g(A, dev))
+    Ar, At2, cs = ops.cast_bf16_both(g(A, dev), colsum=True)
     assert torch.equal(Ar.cpu(), Ab.cpu()) and torch.equal(At2.cpu(), ops.cast_transpose_bf16(g(A, dev)).cpu())
+    assert rel_l2(cs.cpu(), A.double().sum(0)) < 1e-6                  # fp32 column sums of the fp32 source (the bias gradient)
     if K >= 16:
         view = g(A, dev)[:, 4:K - 3]
         vr, vt = ops.cast_bf16_both(view)
