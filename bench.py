@@ -159,7 +159,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override per-GPU batch")
-    ap.add_argument("--dtype", default="", choices=["", "f32", "bf16"], help="default: bf16 for c3 (the config's dtype), f32 otherwise")
+    ap.add_argument("--dtype", default="", choices=["", "f32", "bf16"], help="default: the config dtype (bf16 for c3 and c5, f32 otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print a per-section time breakdown to stderr")
     args = ap.parse_args()
@@ -186,7 +186,7 @@ def main():
         model = DeepSpeech(audio_conf=audio_conf(), decoder=None, label_path=label_file(tmp, C), rnn_type=rnn, rnn_hidden_size=H,
                            rnn_hidden_layers=L, bidirectional=True)
     model.to(dev).train()
-    dtype = args.dtype or ("bf16" if args.workload == "c3" else "f32")
+    dtype = args.dtype or ("bf16" if args.workload in ("c3", "c5") else "f32")
     model.precision = "bf16" if dtype == "bf16" else "fp32"
     opt = FusedAdamW(model, lr=1.5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5)
     tr = DeepSpeechTrainer(model, CTCLoss(reduction="sum"), 1, None, opt, None, None, dev, dev, False, None)
