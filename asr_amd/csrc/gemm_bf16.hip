@@ -197,17 +197,18 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_glds_kernel(BArgs g, int ntx
     srcA[i] = A + (long long)(m0 + r) * g.lda + segk[i];
     srcB[i] = B + (long long)(n0 + r) * g.ldb + segk[i];
   }
-  auto stage = [&](int buf, int k0) {
+  auto stage_part = [&](int buf, int k0, int i) {     // one A piece + one B piece (2 of the wave's 8 DMA instructions)
     char* dA = ldsg + buf * 2 * G_TILE;
     char* dB = dA + G_TILE;
+    const bool kok = k0 + segk[i] + 8 <= kend;
+    const void* pa = (okA[i] && kok) ? (const void*)(srcA[i] + k0) : (const void*)g_zero16;
+    const void* pb = (okB[i] && kok) ? (const void*)(srcB[i] + k0) : (const void*)g_zero16;
+    glds16(pa, dA + (wave + 8 * i) * 1024);
+    glds16(pb, dB + (wave + 8 * i) * 1024);
+  };
+  auto stage = [&](int buf, int k0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bool kok = k0 + segk[i] + 8 <= kend;
-      const void* pa = (okA[i] && kok) ? (const void*)(srcA[i] + k0) : (const void*)g_zero16;
-      const void* pb = (okB[i] && kok) ? (const void*)(srcB[i] + k0) : (const void*)g_zero16;
-      glds16(pa, dA + (wave + 8 * i) * 1024);
-      glds16(pb, dB + (wave + 8 * i) * 1024);
-    }
+    for (int i = 0; i < 4; ++i) stage_part(buf, k0, i);
   };
 
   f32x16 acc[4][2];
@@ -229,10 +230,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_glds_kernel(BArgs g, int ntx
   stage(0, kbeg);
   for (int kt = 0; kt < nkt; ++kt) {
     __syncthreads();            // (vmcnt(0) + barrier): tile kt has landed for every wave; buffer (kt+1)&1 is no longer read
-    if (kt + 1 < nkt) stage((kt + 1) & 1, kbeg + (kt + 1) * BK);
+    const bool more = kt + 1 < nkt;                   // block-uniform
     const char* base = ldsg + (kt & 1) * 2 * G_TILE;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
+      // next tile's DMA is issued in four slices, each in the shadow of the previous k-step's MFMAs
+      if (more) stage_part((kt + 1) & 1, kbeg + (kt + 1) * BK, kk);
       bf16x8 a[4], b[2];
 #pragma unroll
       for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(base + arow + i * 32 * 128 + koff[kk]);
