@@ -47,6 +47,22 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert lib.ds2_ctc_workspace_bytes(10, 2, 3) > 0 and lib.ds2_conv_packed_floats(1) == 32 * 232 * 32
 
 
+def test_workspace_queries_and_splitk_policy():
+    """Host-side sizing logic (no GPU): workspace queries are consistent and the split-K policy is sane on the train step's shapes."""
+    from asr_amd import _lib
+    from asr_amd.ops import _pick_splitk
+    lib = _lib.load()
+    assert lib.ds2_greedy_decode_workspace_bytes(64, 1001) == 64 * 1001 * 4
+    assert lib.ds2_cast_bf16_both_workspace_bytes(32064, 6144) == 501 * 6144 * 2 * 4
+    assert lib.ds2_gemm_bf16_workspace_bytes(100, 200, 2, 4) == 2 * 4 * 100 * 200 * 4 and lib.ds2_gemm_bf16_workspace_bytes(100, 200, 2, 1) == 0
+    assert _pick_splitk(32064, 6144, 1024) == 1 and _pick_splitk(32064, 1024, 6144) == 1      # output-heavy: never split
+    for m, n, k in [(6144, 1024, 32064), (2048, 1024, 32000), (1024, 1024, 32000), (6144, 1312, 32064)]:
+        s = _pick_splitk(m, n, k)
+        tiles = -(-m // 256) * -(-n // 256) * s
+        assert 1 < s <= 16 and k // s >= 1024 and tiles >= 192, (m, n, k, s)                    # long-K weight gradients fill the chip
+    assert _pick_splitk(70, 45, 33) == 1 and _pick_splitk(29, 96, 1000) == 1
+
+
 def test_state_dict_matches_reference_manifest():
     man = json.load(open(f"{GOLDEN}/state_manifest.json"))
     for key, (rnn, h, l, c) in {"gru_32x2_c7": ("gru", 32, 2, 7), "lstm_24x2_c7": ("lstm", 24, 2, 7)}.items():
