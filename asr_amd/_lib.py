@@ -72,6 +72,9 @@ SIGNATURES = {
     "ds2_softmax_rows_f32": (i32, [vp, i32, vp, i32, i32, i32, vp]),
     "ds2_greedy_decode_workspace_bytes": (sz, [i32, i32]),
     "ds2_greedy_decode_f32": (i32, [vp, i64, i64, i32, i32, i32, vp, i32, vp, vp, vp, vp, sz, vp]),
+    "ds2_spectrogram_frames": (i32, [i32, i32]),
+    "ds2_spectrogram_workspace_bytes": (sz, [i32, i32, i32, i32]),
+    "ds2_spectrogram_f32": (i32, [vp, i64, vp, i32, i32, i32, i32, vp, i32, i32, vp, vp, sz, vp]),
     "ds2_adamw_f32": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp]),
     "ds2_scale_f32": (i32, [vp, i64, f32, vp]),
 }

@@ -4,8 +4,10 @@ DistributedBucketingSampler, AudioDataLoader, get_loader.  Host-side / I-O bound
 `SpectrogramDataset` reads the reference's manifest CSV (`audio_filepath`, `text`).  Audio decoding:
 pre-computed spectrograms (`.npy` / `.pt`, shape (161, T)) are loaded as-is; `.wav` files go through a
 numpy STFT restatement of data/parsers/spectrogram_parser.py:36-62 (n_fft = win = sr*window_size,
-hop = sr*window_stride, centred/reflect-padded frames, log1p magnitude, per-utterance mean/std).
-That STFT's parity with librosa 0.11.0 is UNPINNED (librosa is not installable here).
+hop = sr*window_stride, centred zero-padded frames, log1p magnitude, per-utterance mean/std).
+`GpuSpectrogramFrontEnd` does the same for a whole batch on the GPU (csrc/stft.hip).
+Parity with librosa 0.11.0 itself is UNPINNED (librosa is not installable here); both are held to
+oracle/stft_oracle.py, which is cross-checked against torch.stft and scipy.signal.stft.
 """
 from __future__ import annotations
 
@@ -19,16 +21,42 @@ from torch.utils.data.sampler import Sampler
 from ..functional import _collate_fn
 
 
-def _stft_spectrogram(y: np.ndarray, sample_rate: int, window_size: float, window_stride: float, window: str = "hamming"):
-    import scipy.signal.windows as W
+def _stft_spectrogram(y: np.ndarray, sample_rate: int, window_size: float, window_stride: float, window: str = "hamming",
+                      pad_mode: str = "constant"):
+    """Host (numpy) restatement used by the per-item dataset path, like the reference's CPU librosa call.  Zero padding is
+    librosa's default since 0.10 (the reference pins 0.11.0); pass pad_mode="reflect" for the pre-0.10 behaviour."""
+    from scipy.signal import get_window
     n_fft = int(sample_rate * window_size)
     hop = int(sample_rate * window_stride)
-    win = getattr(W, window)(n_fft, sym=False).astype(np.float32)
-    y = np.pad(y.astype(np.float32), n_fft // 2, mode="reflect" if len(y) > n_fft // 2 else "constant")
+    win = get_window(window, n_fft, fftbins=True).astype(np.float32)
+    y = np.pad(y.astype(np.float32), n_fft // 2, mode=pad_mode)
     n_frames = 1 + (len(y) - n_fft) // hop
     frames = np.lib.stride_tricks.as_strided(y, shape=(n_frames, n_fft), strides=(y.strides[0] * hop, y.strides[0]))
     spect = np.abs(np.fft.rfft(frames * win, axis=1)).T.astype(np.float32)  # (n_fft/2+1, frames)
     return np.log1p(spect)
+
+
+class GpuSpectrogramFrontEnd:
+    """Batch spectrogram front-end on the GPU (csrc/stft.hip, `ds2_spectrogram_f32`): a list of 1-D waveforms in, the
+    `_collate_fn` contract out — `(inputs (B,1,161,T) on the GPU, input_percentages (B,) float32)` — i.e. what
+    SpectrogramParser.parse_audio (spectrogram_parser.py:36-62) + _collate_fn (functional.py:9-32) produce per batch, with
+    the STFT, log1p, per-utterance mean/std and zero padding done in four kernels instead of per item in DataLoader workers."""
+
+    def __init__(self, audio_conf, normalize=False, pad_mode="constant", device=None):
+        self.n_fft = int(audio_conf.sample_rate * audio_conf.window_size)
+        self.hop = int(audio_conf.sample_rate * audio_conf.window_stride)
+        self.window, self.normalize, self.pad_mode, self.device = audio_conf.window, normalize, pad_mode, device
+
+    def __call__(self, waves):
+        from .. import ops
+        from ..device import resolve_device
+        dev = torch.device(self.device) if self.device is not None else resolve_device("auto")
+        n = [int(len(w)) for w in waves]
+        batch = torch.zeros(len(waves), max(n), dtype=torch.float32)
+        for i, w in enumerate(waves):
+            batch[i, :n[i]] = torch.as_tensor(w, dtype=torch.float32)
+        spect, frames = ops.spectrogram(batch.to(dev), torch.tensor(n), self.n_fft, self.hop, self.window, self.pad_mode, self.normalize)
+        return spect, frames.float() / float(spect.size(3))
 
 
 class SpectrogramDataset(Dataset):

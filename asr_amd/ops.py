@@ -511,6 +511,47 @@ def greedy_decode(probs: Tensor, sizes: Tensor | None = None, blank: int = 0):
     return ids, offs, lens
 
 
+_BASIS_CACHE = {}
+
+
+def dft_basis(n_fft: int, window: str, device) -> Tensor:
+    """(n_fft, 2*(n_fft/2+1)) fp32: column 2j = w[k] cos(2 pi k j / n_fft), column 2j+1 = -w[k] sin(...); w = scipy's periodic window
+    (what librosa.filters.get_window returns for a name), computed in float64 once per (n_fft, window, device)."""
+    key = (n_fft, window, str(device))
+    if key not in _BASIS_CACHE:
+        import numpy as np
+        from scipy.signal import get_window
+        w = get_window(window, n_fft, fftbins=True).astype(np.float64)
+        k = np.arange(n_fft)[:, None]
+        j = np.arange(n_fft // 2 + 1)[None, :]
+        ang = 2.0 * np.pi * ((k * j) % n_fft) / n_fft
+        basis = np.empty((n_fft, 2 * (n_fft // 2 + 1)))
+        basis[:, 0::2] = w[:, None] * np.cos(ang)
+        basis[:, 1::2] = -w[:, None] * np.sin(ang)
+        _BASIS_CACHE[key] = torch.from_numpy(basis.astype(np.float32)).to(device)
+    return _BASIS_CACHE[key]
+
+
+def spectrogram(audio: Tensor, n_samples: Tensor, n_fft: int, hop: int, window: str = "hamming", pad_mode: str = "constant",
+                normalize: bool = False, frames: int = 0):
+    """audio (B, L) fp32 GPU waveforms (rows zero/garbage beyond n_samples) -> (spect (B,1,n_fft/2+1,T), frames (B,) int32 CPU)."""
+    _chk_f32(audio)
+    assert audio.dim() == 2 and audio.stride(1) == 1
+    lib = _lib.load()
+    B = audio.size(0)
+    n_host = [int(v) for v in n_samples.tolist()]
+    fr = [lib.ds2_spectrogram_frames(n, hop) for n in n_host]
+    T = frames or max(max(fr), 1)
+    n_dev = torch.as_tensor(n_host, dtype=torch.int32).to(audio.device)
+    out = torch.empty((B, 1, n_fft // 2 + 1, T), dtype=torch.float32, device=audio.device)
+    wsb = lib.ds2_spectrogram_workspace_bytes(B, T, n_fft, hop)
+    ws = _ws(wsb, audio.device)
+    _lib.check(lib.ds2_spectrogram_f32(audio.data_ptr(), audio.stride(0), n_dev.data_ptr(), B, T, n_fft, hop,
+                                       dft_basis(n_fft, window, audio.device).data_ptr(), {"constant": 0, "reflect": 1}[pad_mode],
+                                       int(bool(normalize)), out.data_ptr(), ws.data_ptr(), wsb, _stream()), "ds2_spectrogram_f32")
+    return out, torch.tensor([min(f, T) for f in fr], dtype=torch.int32)
+
+
 # ------------------------------------------------------------------------------------------------
 # optimizer
 # ------------------------------------------------------------------------------------------------

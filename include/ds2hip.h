@@ -156,6 +156,17 @@ size_t ds2_greedy_decode_workspace_bytes(int B, int T);
 int ds2_greedy_decode_f32(const float* probs, long long ld_b, long long ld_t, int B, int T, int C, const int* sizes_dev, int blank,
                           int* ids, int* offs, int* out_len, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- spectrogram front-end -------------------------------------------------------------
+ * SpectrogramParser.parse_audio's arithmetic, data/parsers/spectrogram_parser.py:45-60, for a whole batch:
+ * librosa.stft (centred frames, win_length = n_fft) -> |.| -> log1p -> optional (x - mean) / std(unbiased) per utterance,
+ * written in the zero-padded (B,1,n_bins,T) layout of _collate_fn (functional.py:18-30).
+ * audio (B, ld_audio) fp32 device waveforms, n_samples_dev (B) int32; basis (n_fft, 2*n_bins) = window-folded DFT basis
+ * [w cos | -w sin interleaved per bin]; pad_mode 0 = zeros (librosa >= 0.10 default) / 1 = reflect; hop % 4 == 0. */
+int ds2_spectrogram_frames(int n_samples, int hop);
+size_t ds2_spectrogram_workspace_bytes(int B, int T, int n_fft, int hop);
+int ds2_spectrogram_f32(const float* audio, long long ld_audio, const int* n_samples_dev, int B, int T, int n_fft, int hop,
+                        const float* basis, int pad_mode, int normalize, float* out, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- optimizer ----------------------------------------------------------------------------------
  * torch.optim.AdamW.step over one flat parameter buffer, trainers/__main__.py:41-47. */
 int ds2_adamw_f32(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,

@@ -426,3 +426,46 @@ def test_greedy_decode_ids_vs_numpy(dev, B, T, C):
         want_ids, want_offs = _collapse_np(path[b], int(sizes[b]))
         assert lens[b] == len(want_ids)
         assert ids[b, :lens[b]].tolist() == want_ids and offs[b, :lens[b]].tolist() == want_offs
+
+
+# ---- spectrogram front-end (data/parsers/spectrogram_parser.py:45-60 for a whole batch) ----------------------------------
+@pytest.mark.parametrize("pad_mode", ["constant", "reflect"])
+@pytest.mark.parametrize("normalize", [False, True])
+def test_spectrogram_vs_oracle(dev, pad_mode, normalize):
+    """ds2_spectrogram_f32 against the float64 STFT restatement on a ragged batch (incl. a length that is a multiple of the hop,
+    one shorter than a window, and garbage beyond n_samples that must not leak in).  fp32 DFT of 320 points: 2e-5 absolute."""
+    from asr_amd import ops
+    from oracle import stft_oracle as S
+    lens = [16000, 8000, 4321, 777, 250]
+    t = np.arange(16000) / 16000.0
+    waves = [(0.3 * np.sin(2 * np.pi * (200.0 + 150 * i) * t[:n]) + 0.1 * det.unitvar((n,), 70 + i)).astype(np.float32) for i, n in enumerate(lens)]
+    batch = np.full((len(lens), 16000 + 37), 7.5, dtype=np.float32)               # garbage beyond each length, odd pitch
+    for i, w in enumerate(waves):
+        batch[i, :len(w)] = w
+    ref, frames_ref = S.batch_spectrogram(waves, 320, 160, "hamming", pad_mode, normalize)
+    out, frames = ops.spectrogram(g(batch, dev), torch.tensor(lens), 320, 160, "hamming", pad_mode, normalize)
+    assert frames.tolist() == frames_ref and out.shape == ref.shape
+    got = out.cpu().numpy()
+    tol = 2e-5 * (10.0 if normalize else 1.0)                                      # normalisation divides by std ~ 0.3-1
+    assert np.abs(got - ref).max() < tol, np.abs(got - ref).max()
+    for i, f in enumerate(frames_ref):
+        assert float(np.abs(got[i, 0, :, f:]).max(initial=0.0)) == 0.0            # exact zero padding (functional.py:18-30)
+
+
+def test_spectrogram_full_size_properties(dev):
+    """B=64 x 10 s (the metric config's input shape): finite, (161, 1001), ~0 mean / unit std per utterance, deterministic."""
+    from asr_amd import ops
+    from types import SimpleNamespace
+    from asr_amd.data import GpuSpectrogramFrontEnd
+    conf = SimpleNamespace(sample_rate=16000, window_size=0.02, window_stride=0.01, window="hamming")
+    waves = [det.unitvar((160000 - 160 * (i % 5),), 90 + i) for i in range(64)]
+    fe = GpuSpectrogramFrontEnd(conf, normalize=True, device=dev)
+    x, pct = fe(waves)
+    assert x.shape == (64, 1, 161, 1001) and bool(torch.isfinite(x).all())
+    x2, _ = fe(waves)
+    assert torch.equal(x, x2)
+    for i in (0, 3, 63):
+        f = int(round(float(pct[i]) * 1001))
+        assert f == 1 + len(waves[i]) // 160
+        v = x[i, 0, :, :f]
+        assert abs(float(v.mean())) < 1e-3 and abs(float(v.std()) - 1.0) < 1e-3

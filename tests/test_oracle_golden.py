@@ -97,3 +97,41 @@ def test_running_stats_and_eval(name):
     with torch.no_grad():
         probs, _ = O.forward(sd, x, lens, training=False)
     assert rel_l2(probs.numpy(), z["eval_probs"]) < 1e-4
+
+
+# ---- spectrogram front-end oracle: librosa itself is absent, so the restatement is cross-checked against
+# ---- two independent implementations that are present in the image, and the reference's own test properties.
+def _wave(seed, n):
+    t = np.arange(n) / 16000.0
+    return (0.3 * np.sin(2 * np.pi * 440.0 * t) + 0.1 * det.unitvar((n,), seed)).astype(np.float32)
+
+
+@pytest.mark.parametrize("n,pad_mode", [(16000, "constant"), (16000, "reflect"), (4321, "constant"), (161, "constant")])
+def test_stft_oracle_vs_torch_and_scipy(n, pad_mode):
+    from scipy.signal import stft as sp_stft, get_window
+    from oracle import stft_oracle as S
+    y = _wave(3, n)
+    ref = S.stft_log_spectrogram(y, 320, 160, "hamming", pad_mode)
+    assert ref.shape == (161, 1 + n // 160)                                      # tests/test_spectrogram_dataset.py:37-46
+    win = torch.from_numpy(get_window("hamming", 320, fftbins=True))
+    D = torch.stft(torch.from_numpy(y).double(), 320, hop_length=160, win_length=320, window=win, center=True, pad_mode=pad_mode,
+                   normalized=False, onesided=True, return_complex=True)
+    assert np.allclose(np.log1p(D.abs().numpy()), ref, rtol=1e-9, atol=1e-9)
+    if pad_mode == "constant" and n % 160 == 0:
+        # scipy: boundary="zeros" is the same centring; it scales by 1/sum(window) and appends whole padded segments
+        _, _, Z = sp_stft(y.astype(np.float64), window="hamming", nperseg=320, noverlap=160, boundary="zeros", padded=False)
+        Z = np.abs(Z) * get_window("hamming", 320, fftbins=True).sum()
+        assert np.allclose(np.log1p(Z[:, :ref.shape[1]]), ref, rtol=1e-9, atol=1e-9)
+    norm = S.stft_log_spectrogram(y, 320, 160, "hamming", pad_mode, normalize=True)
+    t = torch.from_numpy(ref).float()
+    assert np.allclose(norm, ((t - t.mean()) / t.std()).numpy(), atol=2e-5)      # spectrogram_parser.py:56-60 (torch: unbiased std)
+    assert abs(norm.mean()) < 1e-3 and np.isfinite(norm).all()                    # tests/test_spectrogram_dataset.py:49-58
+
+
+def test_host_dataset_stft_matches_oracle():
+    from asr_amd.data import _stft_spectrogram
+    from oracle import stft_oracle as S
+    y = _wave(5, 12345)
+    for pad_mode in ("constant", "reflect"):
+        got = _stft_spectrogram(y, 16000, 0.02, 0.01, "hamming", pad_mode)
+        assert got.dtype == np.float32 and np.allclose(got, S.stft_log_spectrogram(y, 320, 160, "hamming", pad_mode), atol=2e-5)
