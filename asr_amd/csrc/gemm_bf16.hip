@@ -35,6 +35,7 @@ struct BArgs {
   int M, N, K, lda, ldb, ldc;
   long long sA, sB, sC;
   int splitk, kchunk, accumulate;
+  int nt_store;        // final C written with non-temporal stores (streamed out once)
   float* partial;
 };
 
@@ -272,7 +273,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_glds_kernel(BArgs g, int ntx
           float v = acc[i][j][r] + bv;
           float* p = C + (long long)row * ldc + col;
           if (!partial && g.accumulate) v += *p;
-          *p = v;
+          // final C is streamed out once (788 MB for the forward Gx) -> non-temporal; split-K slabs are re-read right away -> cached
+          if (partial || !g.nt_store) *p = v;
+          else __builtin_nontemporal_store(v, p);
         }
       }
     }
@@ -392,6 +395,8 @@ extern "C" int ds2_gemm_bf16_nt(int M, int N, int K, const void* A, int lda, lon
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.sA = strideA; g.sB = strideB; g.sC = strideC;
   g.splitk = splitk; g.kchunk = kchunk; g.accumulate = accumulate; g.partial = (float*)workspace;
+  static const char* nt_env = getenv("DS2_GEMM_NT");       // tuning override, default on
+  g.nt_store = nt_env ? (nt_env[0] != '0') : 1;
   hipStream_t s = (hipStream_t)stream;
   // 256 x 256 LDS-DMA kernel whenever its tiles cover at least half the chip; the 128 x 128 kernel for everything smaller
   const long long tiles256 = (long long)ceil_div(N, 256) * ceil_div(M, 256) * batch * splitk;
