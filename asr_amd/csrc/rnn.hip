@@ -57,6 +57,13 @@ struct RnnArgs {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// Pin every pointer argument into SGPRs at kernel entry: the compiler otherwise sinks the s_load of pointers that are first
+// used inside a branch (lens, bhh) to that branch, which costs a second dependent scalar-load round trip (~0.3 us) before
+// the first global load of every step kernel can issue.
+__device__ __forceinline__ void hoist_kernargs(const RnnArgs& a) {
+  asm volatile("" ::"s"(a.gx), "s"(a.aux), "s"(a.hbuf), "s"(a.wp), "s"(a.bhh), "s"(a.dy), "s"(a.pk), "s"(a.dcar), "s"(a.lens));
+}
+
 // element (row r, column k) of a packed [tiles][chunks][64 lanes][16 bytes] operand.
 //   fp32 (16x16x4 MFMA):  chunk = k/16, lane = ((k%16)/4)*16 + r%16, component = k%4   (4 floats per lane)
 //   bf16 (16x16x32 MFMA): chunk = k/32, lane = ((k%32)/8)*16 + r%16, component = k%8   (8 bf16 per lane)
@@ -124,7 +131,8 @@ __device__ __forceinline__ void mfma_packed(f32x4 (&acc)[MB][NB], int nch, int w
 
 // ------------------------------------------------------------------------------------------
 // forward step.  grid = (nsl * nbt, 2 dirs), block = NW waves.
-// blockIdx.x = bt * nsl + slice: the batch tiles of one W_hh slice sit nsl blocks apart, i.e. on the
+// grid = (slice, batch tile, direction): the linear workgroup id is slice + nsl * (bt + nbt * dir), so the batch tiles (and
+// directions) of one slice index sit a multiple of nsl blocks apart, i.e. on the
 // same XCD when nsl % 8 == 0, so each XCD's L2 holds every slice once.
 // ------------------------------------------------------------------------------------------
 template <int G, int MB, bool BF>
@@ -132,9 +140,10 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(RnnArgs a, int s)
   __shared__ __attribute__((aligned(16))) f32x4 red[NW][MB * G][64];
   constexpr int NTHR = NW * 64;
   constexpr int PAIRS = (MB * 256 + NTHR - 1) / NTHR;   // (b, j) pairs per thread
-  const int dir = blockIdx.y;
+  const int dir = blockIdx.z;
   const int nsl = a.nsl;
-  const int slice = blockIdx.x % nsl, bt = blockIdx.x / nsl;
+  const int slice = blockIdx.x, bt = blockIdx.y;
+  hoist_kernargs(a);
   const int j0 = slice * 16, b0 = bt * (16 * MB);
   const int T = a.T, B = a.B, H = a.H;
   const int nch = (H + kchunk<BF>() - 1) / kchunk<BF>();
@@ -254,9 +263,10 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(RnnArgs a, int s)
   __shared__ __attribute__((aligned(16))) f32x4 red[NW][MB][64];
   constexpr int NTHR = NW * 64;
   constexpr int PAIRS = (MB * 256 + NTHR - 1) / NTHR;
-  const int dir = blockIdx.y;
+  const int dir = blockIdx.z;
   const int nsl = a.nsl;
-  const int slice = blockIdx.x % nsl, bt = blockIdx.x / nsl;
+  const int slice = blockIdx.x, bt = blockIdx.y;
+  hoist_kernargs(a);
   const int j0 = slice * 16, b0 = bt * (16 * MB);
   const int T = a.T, B = a.B, H = a.H;
   const int nchb = (G * H + kchunk<BF>() - 1) / kchunk<BF>();
@@ -412,7 +422,7 @@ int launch_steps(bool bwd, RnnArgs a, hipStream_t st) {
   const int nbt = ceil_div(a.B, 16 * mb);
   a.nsl = ceil_div(a.H, 16);
   a.nbt16 = nbt * mb;
-  dim3 grid(a.nsl * nbt, 2), block(NW * 64);
+  dim3 grid(a.nsl, nbt, 2), block(NW * 64);
   for (int s = 0; s < a.T; ++s) {
     if (!bwd) {
       if (mb == 2) hipLaunchKernelGGL((rnn_fwd_step_kernel<G, 2, BF>), grid, block, 0, st, a, s);
