@@ -263,3 +263,28 @@ def test_evaluate_loop_decodes_on_gpu():
         tot_w += dec.wer(want, ref); tot_c += dec.cer(want, ref)
         n_w += len(ref.split()); n_c += len(ref.replace(" ", ""))
     assert abs(wer - 100.0 * tot_w / max(n_w, 1)) < 1e-9 and abs(cer - 100.0 * tot_c / max(n_c, 1)) < 1e-9
+
+
+def test_bf16_loss_matches_fp32_on_the_metric_config():
+    """north_star: throughput is quoted "at matched CTC loss (+-1e-3)".  On BASELINE's metric config (5x1024 BiGRU, B=64, 10 s)
+    the bf16-mode loss (the bench's dtype) must sit within 1e-3 relative of the fp32 parity path's loss for the same weights and
+    batch (measured 5e-6), logits within the bf16 tolerance."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from asr_amd import CTCLoss
+    rnn, H, L, C, B, tin = bench.WORKLOADS["c3"]
+    torch.manual_seed(0)
+    model = make_model(dict(rnn=rnn, hidden=H, layers=L, classes=C))
+    x, targets, pct, tsz = bench.synthetic_batch(B, tin, C, 1)
+    lens = (pct * x.size(3)).int()
+    res = {}
+    for prec in ("fp32", "bf16"):
+        model.precision = prec
+        with torch.no_grad():
+            out, out_lens = model.forward(x.cuda(), lens)
+            res[prec] = (float(CTCLoss(reduction="sum")(out.transpose(0, 1), targets, out_lens, tsz) / B), out.float().cpu())
+    model.precision = "fp32"
+    l32, l16 = res["fp32"][0], res["bf16"][0]
+    assert np.isfinite(l32) and abs(l16 - l32) <= 1e-3 * abs(l32), (l32, l16)
+    assert rel_l2(res["bf16"][1].numpy(), res["fp32"][1].numpy()) < 2e-2
