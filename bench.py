@@ -20,6 +20,8 @@ import tempfile
 import time
 from types import SimpleNamespace
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: RCCL across processes needs it on this driver
+
 import torch
 import torch.distributed as dist
 
