@@ -224,3 +224,81 @@ def test_trainer_api_surface():
     assert list(e) == [0, 1, 2] and e.total == 3
     m = asr_metrics()
     assert m.train.current.loss == 0.0 and m.test.best.cer is None
+
+
+def test_checkpoint_wire_format_and_finetune(tmp_path):
+    """the `.pth` layout of DeepSpeechTrainer.save/load (deepspeech_trainer.py:154-188: keys epoch / metrics /
+    optimizer / scheduler / state_dict, torch AdamW + StepLR objects as wired by trainers/__main__.py:41-52) and
+    DeepSpeech.finetune_from (deepspeech.py:112-128).  Pure host logic: no kernels run."""
+    from asr_amd.trainers import DeepSpeechTrainer
+    torch.manual_seed(3)
+    m = make("gru", 16, 2, 7)
+    opt = torch.optim.AdamW(m.parameters(), lr=1.5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5)
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=1, gamma=0.99)
+    path = str(tmp_path / "ckpt" / "model.pth")
+    tr = DeepSpeechTrainer(m, None, 5, None, opt, path, None, "cpu", "cpu", False, None, scheduler=sched)
+    tr._epochs.best = 2
+    tr._metrics.test.best.cer = 12.5
+    tr.save()
+    raw = torch.load(path, map_location="cpu", weights_only=False)
+    assert set(raw) == {"epoch", "metrics", "optimizer", "scheduler", "state_dict"} and raw["epoch"] == 2
+    man = json.load(open(f"{GOLDEN}/state_manifest.json"))["gru_32x2_c7"]["keys"]
+    assert list(raw["state_dict"].keys()) == list(man.keys())                     # the reference's key order
+    assert set(raw["optimizer"]) == {"state", "param_groups"}
+    # restore into a fresh model / optimizer
+    torch.manual_seed(4)
+    m2 = make("gru", 16, 2, 7)
+    assert not torch.equal(m2.state_dict()["fc.0.module.1.weight"], m.state_dict()["fc.0.module.1.weight"])
+    opt2 = torch.optim.AdamW(m2.parameters(), lr=1.0)
+    tr2 = DeepSpeechTrainer(m2, None, 5, None, opt2, path, None, "cpu", "cpu", False, None, overwrite_lr=7e-5)
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+    assert tr2._epochs.start == tr2._epochs.current == 2 and tr2._metrics.test.best.cer == 12.5
+    assert opt2.param_groups[0]["lr"] == 7e-5 and opt2.param_groups[0]["betas"] == (0.9, 0.999)
+    assert tr2._scheduler is not None and tr2._scheduler.optimizer is opt2
+    # finetune_from: shape-checked partial load (a 9-class head does not take the 7-class fc), all but the last tensor frozen
+    sd_path = str(tmp_path / "sd.pth")
+    torch.save(m.state_dict(), sd_path)
+    m3 = make("gru", 16, 2, 9)
+    before_fc = m3.state_dict()["fc.0.module.1.weight"].clone()
+    m3.finetune_from(sd_path, nlayers=1)
+    assert torch.equal(m3.state_dict()["conv.seq_module.0.weight"], m.state_dict()["conv.seq_module.0.weight"])
+    assert torch.equal(m3.state_dict()["fc.0.module.1.weight"], before_fc)
+    flags = [p.requires_grad for p in m3.parameters()]
+    assert flags[-1] and not any(flags[:-1])
+
+
+def test_manifest_label_formats_and_loader(tmp_path):
+    """the on-disk formats the reference's ETL writes — manifest CSV `audio_filepath,duration,fq,text,text_size`
+    (etl/jsut_dataset.py:36-42) and labels.csv with one `label` column (jsut_dataset.py:56-60) — through SpectrogramDataset /
+    get_loader / _collate_fn.  Host logic only; the wav goes through the numpy STFT restatement."""
+    import pandas as pd
+    from scipy.io import wavfile
+    from asr_amd.data import SpectrogramDataset, get_loader
+    from oracle import stft_oracle as S
+    sr = 16000
+    waves = {}
+    for i, n in enumerate((8000, 12000, 4000)):
+        y = (0.3 * np.sin(2 * np.pi * (300 + 100 * i) * np.arange(n) / sr)).astype(np.float32)
+        waves[i] = (np.round(y * 32767)).astype(np.int16)
+        wavfile.write(str(tmp_path / f"u{i}.wav"), sr, waves[i])
+    texts = ["ab c", "cab", "b?a"]                                             # '?' is not a label: dropped (spectrogram_dataset.py:70-73)
+    pd.DataFrame({"audio_filepath": [str(tmp_path / f"u{i}.wav") for i in range(3)], "duration": [0.5, 0.75, 0.25], "fq": [sr] * 3,
+                  "text": texts, "text_size": [len(t) for t in texts]}).to_csv(tmp_path / "manifest.csv", index=False)
+    pd.DataFrame({"label": ["_", "a", "b", "c", " "]}).to_csv(tmp_path / "labels.csv", index=False)
+    conf = audio_conf()
+    ds = SpectrogramDataset(audio_conf=conf, manifest_filepath=str(tmp_path / "manifest.csv"), labels=str(tmp_path / "labels.csv"), normalize=False)
+    assert len(ds) == 3
+    spect, ids = ds[0]
+    assert spect.dtype == torch.float32 and spect.shape == (161, 1 + 8000 // 160) and bool(torch.isfinite(spect).all())
+    ref = S.stft_log_spectrogram(waves[0].astype(np.float32) / 32767.0, 320, 160, "hamming", "constant")
+    assert np.allclose(spect.numpy(), ref, atol=2e-5)
+    # space-row quirk PRESERVED (SURVEY §8(f) rank 4): pandas.read_csv skips the whitespace-only row of labels.csv, so ' ' never
+    # becomes a label (and rows after it would shift down by one) — same call as spectrogram_dataset.py:36 / deepspeech.py:48
+    assert " " not in ds.labels_map and ds.labels_map == {"_": 0, "a": 1, "b": 2, "c": 3}
+    assert ids == [1, 2, 3] and ds[2][1] == [2, 1]                               # "ab c" -> a b c ; "b?a" -> b a ; index-0 '_' is never emitted
+    loader, sampler = get_loader(conf, str(tmp_path / "labels.csv"), str(tmp_path / "manifest.csv"), batch_size=2, num_workers=0)
+    batches = list(loader)
+    assert len(batches) == 2 and len(sampler) == 2
+    for inputs, targets, pct, tsz in batches:
+        assert inputs.dim() == 4 and inputs.size(1) == 1 and inputs.size(2) == 161
+        assert float(pct.max()) == 1.0 and int(tsz.sum()) == targets.numel()
