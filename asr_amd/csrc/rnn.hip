@@ -411,8 +411,11 @@ __global__ void rnn_pack_kernel(const float* __restrict__ whh, void* __restrict_
 
 inline int pick_mb(int B, int H) {
   const int nsl = ceil_div(H, 16);
-  // 32-row batch tiles halve the W_hh re-reads; use them when that still fills the chip
-  return (B > 16 && (long long)nsl * ceil_div(B, 32) * 2 >= 200) ? 2 : 1;
+  if (B <= 16) return 1;
+  // 16-row tiles that would not all be resident at once (> 256 CUs -> a second, mostly empty round doubles the step latency):
+  // take 32-row tiles instead.  Otherwise 32-row tiles (half the W_hh re-reads) only when they still fill the chip.
+  if ((long long)nsl * ceil_div(B, 16) * 2 > 256) return 2;
+  return ((long long)nsl * ceil_div(B, 32) * 2 >= 200) ? 2 : 1;
 }
 
 template <int G, bool BF>
