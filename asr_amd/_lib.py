@@ -31,6 +31,7 @@ SIGNATURES = {
     "ds2_cast_transpose_bf16": (i32, [vp, i32, vp, i32, i32, i32, vp]),
     "ds2_cast_bf16_both_workspace_bytes": (sz, [i32, i32]),
     "ds2_cast_bf16_both": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, vp, vp, sz, vp]),
+    "ds2_transpose_bf16": (i32, [vp, i32, vp, i32, i32, i32, vp, vp, sz, vp]),
     "ds2_colreduce_workspace_bytes": (sz, [i32, i32]),
     "ds2_colstats_f32": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, f32, vp, sz, vp]),
     "ds2_add_colstats_f32": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, vp, vp, vp, vp, f32, vp, sz, vp]),
@@ -66,7 +67,7 @@ SIGNATURES = {
     "ds2_rnn_fwd_workspace_bytes": (sz, [i32, i32, i32]),
     "ds2_rnn_fwd": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp]),
     "ds2_rnn_bwd_workspace_bytes": (sz, [i32, i32, i32, i32]),
-    "ds2_rnn_bwd": (i32, [i32, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp]),
+    "ds2_rnn_bwd": (i32, [i32, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, sz, vp]),
     "ds2_ctc_workspace_bytes": (sz, [i32, i32, i32]),
     "ds2_ctc_loss_f32": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, i32, f32, vp, sz, vp]),
     "ds2_softmax_rows_f32": (i32, [vp, i32, vp, i32, i32, i32, vp]),

@@ -369,6 +369,55 @@ __global__ __launch_bounds__(256) void cast_transpose_bf16_kernel(const float* _
   }
 }
 
+// bf16 (R, C) -> bf16 (C, ldt) transposed (+ optional fp32 column sums): the bf16-mode backward writes dGx in bf16 straight from
+// the recurrent epilogue, so the only preparation left for the weight-gradient GEMMs is this half-traffic transpose.
+// 64x64 tiles through LDS; 16-byte loads along c, 16-byte stores along r.
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const __bf16* __restrict__ src, int lds_, __bf16* __restrict__ dstT, int ldt, int R, int Cc,
+                                                             float* __restrict__ colpart) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int rl = pass * 32 + (tid >> 3), cl = (tid & 7) * 8;
+    const int r = r0 + rl, c = c0 + cl;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (r < R) {
+      const __bf16* sp = src + (long long)r * lds_ + c;
+      if (c + 8 <= Cc) {
+        const bf16x8 q = *reinterpret_cast<const bf16x8*>(sp);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)q[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (c + j < Cc) ? (float)sp[j] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) tile[rl][cl + j] = v[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int cl = pass * 32 + (tid >> 3), rl = (tid & 7) * 8;
+    const int c = c0 + cl, r = r0 + rl;
+    if (c < Cc && r < ldt) {
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (__bf16)tile[rl + j][cl];
+      *reinterpret_cast<bf16x8*>(dstT + (long long)c * ldt + r) = o;
+    }
+  }
+  if (colpart && tid < 64 && c0 + tid < Cc && r0 < R) {
+    float sum = 0.f;
+#pragma unroll 16
+    for (int r = 0; r < 64; ++r) sum += tile[r][tid];
+    float* o = colpart + ((long long)blockIdx.y * Cc + c0 + tid) * 2;
+    o[0] = sum;
+    o[1] = 0.f;
+  }
+}
+
 }  // namespace
 
 extern "C" size_t ds2_gemm_bf16_workspace_bytes(int M, int N, int batch, int splitk) {
@@ -466,5 +515,18 @@ extern "C" int ds2_cast_bf16_both(const float* src, int ld_src, void* dst_r, int
   int rc = launch_cast_transpose(src, ld_src, dst_t, ld_t, dst_r, ld_r, R, Cc, colsum ? (float*)ws : nullptr, stream);
   if (rc || !colsum) return rc;
   // the partial rows of tiles past R (ld_t > R padding) are never produced: exactly ceil(R/64) row tiles hold data
+  return ds2i_col_finalize_sums((const float*)ws, ceil_div(R, 64), Cc, colsum, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int ds2_transpose_bf16(const void* src, int ld_src, void* dst_t, int ld_t, int R, int Cc, float* colsum, void* ws, size_t ws_bytes,
+                                  void* stream) {
+  DS2_REQUIRE(src && dst_t && R > 0 && Cc > 0, "ds2_transpose_bf16: bad args");
+  DS2_REQUIRE(ld_t >= R && (ld_t % 8) == 0 && (ld_src % 8) == 0 && ((uintptr_t)src % 16) == 0, "ds2_transpose_bf16: bad pitches / alignment");
+  if (colsum) DS2_REQUIRE(ws && ws_bytes >= ds2_cast_bf16_both_workspace_bytes(R, Cc), "ds2_transpose_bf16: workspace too small");
+  dim3 grid(ceil_div(Cc, 64), ceil_div(ld_t, 64));
+  hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)src, ld_src, (__bf16*)dst_t, ld_t, R, Cc,
+                     colsum ? (float*)ws : nullptr);
+  DS2_LAUNCH_CHECK("transpose_bf16_kernel");
+  if (!colsum) return 0;
   return ds2i_col_finalize_sums((const float*)ws, ceil_div(R, 64), Cc, colsum, nullptr, (hipStream_t)stream);
 }

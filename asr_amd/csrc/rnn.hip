@@ -49,6 +49,7 @@ struct RnnArgs {
   const float* dy;    // (T,B,H) grad wrt y = h_fwd + h_bwd (bwd only), row pitch lddy
   float* pk;          // packed moving operand, ping-pong: [2 parity][2 dir][nbt16][nchK][256]  (h fwd / dGh bwd)
   float* dcar;        // (2 parity, 2 dir, B, H) bwd carry: GRU dh*z ; LSTM dc*f
+  __bf16* dgx_bf;     // bwd, optional: (T,B,2,G*H) bf16 — d(pre-activations) go HERE instead of overwriting gx (fp32)
   const int* lens;    // (B) valid output frames per sample
   int T, B, H, lddy;
   int nsl, nbt16;     // hidden slices of 16 ; allocated 16-row batch tiles (multiple of MB)
@@ -61,7 +62,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // used inside a branch (lens, bhh) to that branch, which costs a second dependent scalar-load round trip (~0.3 us) before
 // the first global load of every step kernel can issue.
 __device__ __forceinline__ void hoist_kernargs(const RnnArgs& a) {
-  asm volatile("" ::"s"(a.gx), "s"(a.aux), "s"(a.hbuf), "s"(a.wp), "s"(a.bhh), "s"(a.dy), "s"(a.pk), "s"(a.dcar), "s"(a.lens));
+  asm volatile("" ::"s"(a.gx), "s"(a.aux), "s"(a.hbuf), "s"(a.wp), "s"(a.bhh), "s"(a.dy), "s"(a.pk), "s"(a.dcar), "s"(a.lens), "s"(a.dgx_bf));
 }
 
 // element (row r, column k) of a packed [tiles][chunks][64 lanes][16 bytes] operand.
@@ -79,6 +80,13 @@ __device__ __forceinline__ void packed_store(void* base, long long idx, float v)
   else reinterpret_cast<float*>(base)[idx] = v;
 }
 template <bool BF> __host__ __device__ constexpr int kchunk() { return BF ? 32 : 16; }
+
+// backward: d(pre-activation) either overwrites the saved gate in the fp32 buffer or goes to the bf16 side buffer that the
+// bf16-mode GEMMs consume directly (half the store bytes per step, no separate cast pass)
+__device__ __forceinline__ void dgx_store(float* gx, __bf16* gb, int off, float v) {
+  if (gb) __builtin_nontemporal_store((__bf16)v, gb + off);
+  else stnt(gx + off, v);
+}
 
 // acc[i][j] += A-tile i (16 rows) x B-tile j (16 rows)^T over `nch` packed chunks.
 // pa + i*sa / pb + j*sb point at this lane's float4 of chunk 0; consecutive chunks are 256 floats apart.
@@ -337,9 +345,10 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(RnnArgs a, int s)
     float* ax = a.aux + row * H + j;
     float* dco = dcar_out + (long long)b * H + j;
     float dgh[G];
+    __bf16* gb = a.dgx_bf ? a.dgx_bf + row * G * H + j : nullptr;            // wave-uniform choice of the dGx destination
     if (!(t < plen[i])) {
 #pragma unroll
-      for (int g = 0; g < G; ++g) { stnt(&gx[g * H], 0.f); dgh[g] = 0.f; }
+      for (int g = 0; g < G; ++g) { dgx_store(gx, gb, g * H, 0.f); dgh[g] = 0.f; }
       if (G == 3) stnt(ax, 0.f);
       *dco = 0.f;
     } else {
@@ -356,7 +365,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(RnnArgs a, int s)
         dgh[0] = dr * r * (1.f - r);
         dgh[1] = dz * z * (1.f - z);
         dgh[2] = dpn * r;                  // d(hn): the n-gate row of dGh
-        stnt(&gx[0], dgh[0]); stnt(&gx[H], dgh[1]); stnt(&gx[2 * H], dpn);
+        dgx_store(gx, gb, 0, dgh[0]); dgx_store(gx, gb, H, dgh[1]); dgx_store(gx, gb, 2 * H, dpn);
         stnt(ax, dgh[2]);
         *dco = dh * z;
       } else {
@@ -370,7 +379,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(RnnArgs a, int s)
         dgh[2] = dc * ig * (1.f - gg * gg);
         dgh[G - 1] = dh * tc * og * (1.f - og);
 #pragma unroll
-        for (int g = 0; g < G; ++g) stnt(&gx[g * H], dgh[g]);
+        for (int g = 0; g < G; ++g) dgx_store(gx, gb, g * H, dgh[g]);
         *dco = dc * fg;
       }
     }
@@ -498,10 +507,11 @@ extern "C" size_t ds2_rnn_bwd_workspace_bytes(int gates, int B, int H, int bf16)
 
 //   dy     (T,B,H) pitch lddy: grad wrt y = h_fwd + h_bwd
 //   gx     in: gates from fwd ; out: grad wrt the x-projections (T,B,2,G*H)  (= dGx, feeds dW_ih, db_ih, dX)
+//   dgx_bf16  optional (T,B,2,G*H) bf16: when given, dGx is written THERE (rounded to bf16) and gx keeps the gates
 //   aux    GRU: in hn, out d(hn) [so that dGh = (dGx_r, dGx_z, aux)] ; LSTM: cell state (unchanged; dGh = dGx)
 //   wp_bwd packed W_hh^T (ds2_rnn_pack_whh)
 extern "C" int ds2_rnn_bwd(int gates, const float* dy, int lddy, float* gx, float* aux, const float* hbuf, const void* wp_bwd,
-                           const int* lens_dev, int T, int B, int H, int bf16, void* ws, size_t ws_bytes, void* stream) {
+                           const int* lens_dev, int T, int B, int H, int bf16, void* dgx_bf16, void* ws, size_t ws_bytes, void* stream) {
   DS2_REQUIRE(gates == 3 || gates == 4, "ds2_rnn_bwd: gates must be 3 (GRU) or 4 (LSTM)");
   DS2_REQUIRE(dy && gx && aux && hbuf && wp_bwd && lens_dev, "ds2_rnn_bwd: null pointer");
   DS2_REQUIRE(T > 0 && B > 0 && H > 0 && (H % 4) == 0, "ds2_rnn_bwd: need H %% 4 == 0 (H=%d)", H);
@@ -510,6 +520,7 @@ extern "C" int ds2_rnn_bwd(int gates, const float* dy, int lddy, float* gx, floa
   RnnArgs a{};
   a.gx = gx; a.aux = aux; a.hbuf = const_cast<float*>(hbuf); a.wp = (const float*)wp_bwd; a.dy = dy; a.lddy = lddy;
   a.dcar = (float*)ws; a.pk = (float*)ws + (size_t)4 * B * H;
+  a.dgx_bf = (__bf16*)dgx_bf16;
   a.lens = lens_dev; a.T = T; a.B = B; a.H = H;
   return bf16 ? dispatch<true>(gates, true, a, (hipStream_t)stream) : dispatch<false>(gates, true, a, (hipStream_t)stream);
 }

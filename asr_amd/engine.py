@@ -190,15 +190,22 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
         lc = ctx.layers[l]
         I = lc.xn.shape[1]
         bf = cfg.precision == "bf16"
-        ops.rnn_bwd(G, dy, lc.gx, lc.aux, lc.hbuf, lc.wpb, lens_dev, T, B, H, bf16=bf)
-        dgx = lc.gx                                                                               # now dGx (M, 2GH)
+        # bf16 mode: the step kernels write dGx in bf16 (row-major) into a side buffer that the GEMMs consume directly (needs
+        # B % 8 == 0 for the 16-byte aligned time-shifted operand views below; other batch sizes keep fp32 dGx + a cast pass)
+        bfd = bf and B % 8 == 0
+        dgx_bf = torch.empty(lc.gx.shape, dtype=torch.bfloat16, device=lc.gx.device) if bfd else None
+        ops.rnn_bwd(G, dy, lc.gx, lc.aux, lc.hbuf, lc.wpb, lens_dev, T, B, H, bf16=bf, dgx_bf16=dgx_bf)
+        dgx = dgx_bf if bfd else lc.gx                                                            # dGx (M, 2GH)
         # ---- critical path: dXn = dGx W_ih (feeds the next layer's backward) ---------------------------------------
         dgxT = None
-        if bf:
-            # dGx is needed both ways (dXn = dGx W_ih here, dW = dGx^T [Xn | h] below): both bf16 copies from one read
-            dgx_bf, dgxT, dbih_sum = ops.cast_bf16_both(dgx, colsum=True)                          # + db_ih = column sums of dGx
+        if bfd:
             dxn = ops.gemm_bf16_nt(dgx_bf, ops.cast_transpose_bf16(W[f"rnns.{l}.wih_cat"]))
-            del dgx_bf
+            # dW = dGx^T [Xn | h] needs the transposed copy; the same read gives db_ih = column sums of dGx
+            dgxT, dbih_sum = ops.transpose_bf16(dgx_bf, colsum=True)
+        elif bf:
+            dgx_r, dgxT, dbih_sum = ops.cast_bf16_both(dgx, colsum=True)
+            dxn = ops.gemm_bf16_nt(dgx_r, ops.cast_transpose_bf16(W[f"rnns.{l}.wih_cat"]))
+            del dgx_r
         else:
             dxn = ops.gemm(dgx, W[f"rnns.{l}.wih_cat"])                                           # (M, I)
         # ---- off the critical path: bias and weight gradients ------------------------------------------------------
@@ -213,7 +220,7 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
                 dbhh[:, 2 * H:] = ops.colsum(lc.aux).view(2, H)
             # dW_hh[dir] = sum_t dGh[t]^T h_prev[t]  (h_prev = h[t-1] fwd / h[t+1] reverse)
             dwhh = Gr[f"rnns.{l}.whh_cat"]                                                        # (2, GH, H)
-            if T > 1 and bf and B % 8 == 0:
+            if T > 1 and bfd:
                 # bf16 MFMA path: transposed bf16 copies (dgxT: (2GH, M)), the time shift is a column offset of B elements
                 hT = ops.cast_transpose_bf16(lc.hbuf)                                             # (2H, M)
                 auxT = ops.cast_transpose_bf16(lc.aux) if G == 3 else None

@@ -124,6 +124,22 @@ def cast_bf16_both(src: Tensor, colsum: bool = False):
     return (dst_r, dst_t, cs) if colsum else (dst_r, dst_t)
 
 
+def transpose_bf16(src: Tensor, colsum: bool = False):
+    """(R, C) bf16 row-major -> bf16 (C, pad8(R)) = src^T [, fp32 column sums (C)] from one read; pads zero."""
+    assert src.dtype == torch.bfloat16 and src.is_cuda and src.dim() == 2 and src.stride(1) == 1 and src.stride(0) % 8 == 0
+    R, Cc = src.shape
+    lib = _lib.load()
+    dst_t = torch.empty(Cc, _pad8(R), dtype=torch.bfloat16, device=src.device)
+    cs, ws, wsb = None, None, 0
+    if colsum:
+        cs = torch.empty(Cc, dtype=torch.float32, device=src.device)
+        wsb = lib.ds2_cast_bf16_both_workspace_bytes(R, Cc)
+        ws = _ws(wsb, src.device)
+    _lib.check(lib.ds2_transpose_bf16(src.data_ptr(), src.stride(0), dst_t.data_ptr(), dst_t.size(1), R, Cc, _ptr(cs), _ptr(ws), wsb,
+                                      _stream()), "ds2_transpose_bf16")
+    return (dst_t, cs) if colsum else dst_t
+
+
 def _pick_splitk(M: int, N: int, K: int) -> int:
     """Split-K factor for the bf16 GEMM: trade chip fill (256 CUs, one 256x256 tile each per round) against the fp32 partial
     slabs a split writes and re-reads.  Rates are the measured ones (scripts/bench_gemm.py): ~1.1 PF/s per busy CU-round for the
@@ -451,13 +467,16 @@ def rnn_fwd(gates: int, gx: Tensor, wp_fwd: Tensor, bhh: Tensor, lens_dev: Tenso
 
 
 def rnn_bwd(gates: int, dy: Tensor, gx: Tensor, aux: Tensor, hbuf: Tensor, wp_bwd: Tensor, lens_dev: Tensor, T: int, B: int, H: int,
-            bf16: bool = False):
+            bf16: bool = False, dgx_bf16: Optional[Tensor] = None):
+    """dgx_bf16: optional (T*B, 2*G*H) bf16 buffer that receives dGx (then `gx` keeps the gates)."""
     _chk_f32(dy, gx, aux, hbuf)
+    if dgx_bf16 is not None:
+        assert dgx_bf16.dtype == torch.bfloat16 and dgx_bf16.is_contiguous() and dgx_bf16.numel() == gx.numel()
     lib = _lib.load()
     wsb = lib.ds2_rnn_bwd_workspace_bytes(gates, B, H, int(bf16))
     ws = _ws(wsb, gx.device)
     _lib.check(lib.ds2_rnn_bwd(gates, dy.data_ptr(), _row_pitch(dy), gx.data_ptr(), aux.data_ptr(), hbuf.data_ptr(), wp_bwd.data_ptr(),
-                               lens_dev.data_ptr(), T, B, H, int(bf16), ws.data_ptr(), wsb, _stream()), "ds2_rnn_bwd")
+                               lens_dev.data_ptr(), T, B, H, int(bf16), _ptr(dgx_bf16), ws.data_ptr(), wsb, _stream()), "ds2_rnn_bwd")
 
 
 # ------------------------------------------------------------------------------------------------

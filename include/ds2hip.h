@@ -56,6 +56,10 @@ int ds2_cast_transpose_bf16(const float* src, int ld_src, void* dst, int ld_dst,
 size_t ds2_cast_bf16_both_workspace_bytes(int R, int Cc);
 int ds2_cast_bf16_both(const float* src, int ld_src, void* dst_r, int ld_r, void* dst_t, int ld_t, int R, int Cc, float* colsum, void* ws,
                        size_t ws_bytes, void* stream);
+/* bf16 (R, C) row-major (pitch ld_src % 8 == 0) -> bf16 (C, ld_t) transposed, pads zero; colsum (C) fp32 optional: column sums from
+ * the same read (ws >= ds2_cast_bf16_both_workspace_bytes(R, C)). */
+int ds2_transpose_bf16(const void* src, int ld_src, void* dst_t, int ld_t, int R, int Cc, float* colsum, void* ws, size_t ws_bytes,
+                       void* stream);
 
 /* ---- BatchNorm1d over (T*B, H) rows, padding rows included -----------------------------------
  * modules/blocks.py:75,85-86 (SequenceWise(BatchNorm1d)) and modules/deepspeech.py:104 (fc block).
@@ -133,8 +137,10 @@ size_t ds2_rnn_fwd_workspace_bytes(int B, int H, int bf16);
 int ds2_rnn_fwd(int gates, float* gx, const void* wp_fwd, const float* bhh, float* hbuf, float* aux, const int* lens_dev, int T, int B,
                 int H, int bf16, void* ws, size_t ws_bytes, void* stream);
 size_t ds2_rnn_bwd_workspace_bytes(int gates, int B, int H, int bf16);
+/* dgx_bf16: NULL, or a (T,B,2,G*H) bf16 buffer that receives the gradient wrt the x-projections instead of gx (which then keeps
+ * the gates): the bf16-mode GEMMs consume it directly. */
 int ds2_rnn_bwd(int gates, const float* dy, int lddy, float* gx, float* aux, const float* hbuf, const void* wp_bwd, const int* lens_dev,
-                int T, int B, int H, int bf16, void* ws, size_t ws_bytes, void* stream);
+                int T, int B, int H, int bf16, void* dgx_bf16, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- log-softmax + CTC loss + gradient ---------------------------------------------------------
  * out.float().log_softmax(2) + torch.nn.CTCLoss(reduction="sum") and their backward,

@@ -280,8 +280,18 @@ def test_rnn_fwd_bwd(dev, kind, H, B, T, lens, bf):
     assert rel_l2(hb[:, :, 0], yf.detach()) < e1 and rel_l2(hb[:, :, 1], yb.detach()) < e1
     ysum, _, _ = ops.add_colstats(hbuf[:, :H], hbuf[:, H:])
     assert rel_l2(ysum.view(T, B, H).cpu(), y.detach()) < e1
+    if bf:
+        # bf16 mode's side buffer: dGx lands in bf16 and the fp32 buffer keeps the gates; must equal the fp32 result rounded to bf16
+        gates_saved, aux2, side_buf = gxd.clone(), aux.clone(), torch.empty(T * B, 2 * G * H, dtype=torch.bfloat16, device=dev)
+        ops.rnn_bwd(G, g(dy.float().reshape(T * B, H), dev), gates_saved, aux2, hbuf, wpb, ld, T, B, H, bf16=True, dgx_bf16=side_buf)
+        assert torch.equal(gates_saved, gxd)
     ops.rnn_bwd(G, g(dy.float().reshape(T * B, H), dev), gxd, aux, hbuf, wpb, ld, T, B, H, bf16=bf)
     assert rel_l2(gxd.view(T, B, 2, G * H).cpu(), gx.grad) < e2          # dGx
+    if bf:
+        assert torch.equal(side_buf, gxd.bfloat16()) and torch.equal(aux2, aux)
+        tT, cs = ops.transpose_bf16(side_buf, colsum=True)
+        assert torch.equal(tT[:, :T * B].cpu(), side_buf.t().contiguous().cpu()) and float(tT[:, T * B:].float().abs().sum()) == 0
+        assert rel_l2(cs.cpu(), side_buf.double().sum(0).cpu()) < 1e-5
     # dW_hh / db_hh from the saved buffers exactly as engine.backward assembles them
     dgx = gxd
     dwhh = torch.zeros(2, G * H, H, device=dev)
