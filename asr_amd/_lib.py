@@ -37,6 +37,7 @@ SIGNATURES = {
     "ds2_add_colstats_f32": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, vp, vp, vp, vp, f32, vp, sz, vp]),
     "ds2_colsum_f32": (i32, [vp, i32, i32, i32, vp, vp, vp, sz, vp]),
     "ds2_bn1d_apply_f32": (i32, [vp, i32, vp, i32, i32, i32, vp, vp, vp, vp, f32, vp]),
+    "ds2_bn1d_apply_bf16": (i32, [vp, i32, vp, i32, i32, i32, vp, vp, vp, vp, f32, vp]),
     "ds2_bn1d_bwd_f32": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, vp, vp, vp, f32, vp, vp, vp, sz, vp]),
     "ds2_chanreduce_workspace_bytes": (sz, [i32]),
     "ds2_bn2d_stats_f32": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp, f32, vp, sz, vp]),

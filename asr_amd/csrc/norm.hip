@@ -161,6 +161,30 @@ __global__ __launch_bounds__(256) void bn1d_apply_kernel(const float* __restrict
   }
 }
 
+// same, written as bf16 (row pitch ldy % 8 == 0, pad columns H..ldy zero): the bf16-mode input projection consumes it directly
+typedef __bf16 nbf16x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void bn1d_apply_bf16_kernel(const float* __restrict__ X, int ldx, __bf16* __restrict__ Y, int ldy, int M, int H,
+                                                              const float* __restrict__ mean, const float* __restrict__ var,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int vec) {
+  const int hq = ldy / 4;
+  const long long total = (long long)M * hq;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int r = i / hq, c0 = (i % hq) * 4;
+    const int valid = H - c0;                       // <= 0 in the pad columns
+    f32x4 y = {0.f, 0.f, 0.f, 0.f};
+    if (valid > 0) {
+      f32x4 x = ld4(X + (long long)r * ldx + c0, valid, vec);
+      f32x4 mu = ld4(mean + c0, valid, false), vv = ld4(var + c0, valid, false);
+      f32x4 g = ld4(gamma + c0, valid, false), b = ld4(beta + c0, valid, false);
+      y.x = (x.x - mu.x) * rsqrtf(vv.x + eps) * g.x + b.x;
+      y.y = valid > 1 ? (x.y - mu.y) * rsqrtf(vv.y + eps) * g.y + b.y : 0.f;
+      y.z = valid > 2 ? (x.z - mu.z) * rsqrtf(vv.z + eps) * g.z + b.z : 0.f;
+      y.w = valid > 3 ? (x.w - mu.w) * rsqrtf(vv.w + eps) * g.w + b.w : 0.f;
+    }
+    *reinterpret_cast<nbf16x4*>(Y + (long long)r * ldy + c0) = nbf16x4{(__bf16)y.x, (__bf16)y.y, (__bf16)y.z, (__bf16)y.w};
+  }
+}
+
 // dX = gamma*rstd * (dY - s0/M - xhat * s1/M) ; dgamma = s1 ; dbeta = s0 (written by block 0)
 __global__ __launch_bounds__(256) void bn1d_bwd_apply_kernel(const float* __restrict__ dY, int lddy, const float* __restrict__ X,
                                                              int ldx, float* __restrict__ dX, int lddx, int M, int H,
@@ -439,6 +463,21 @@ extern "C" int ds2_bn1d_apply_f32(const float* X, int ldx, float* Y, int ldy, in
   hipLaunchKernelGGL(bn1d_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, X, ldx, Y, ldy, M, H, mean, var, gamma,
                      beta, eps, vec);
   DS2_LAUNCH_CHECK("bn1d_apply_kernel");
+  return 0;
+}
+
+// Y (M, ldy) bf16 = BN(X) with zero pad columns; ldy % 8 == 0, ldy >= H
+extern "C" int ds2_bn1d_apply_bf16(const float* X, int ldx, void* Y, int ldy, int M, int H, const float* mean, const float* var,
+                                   const float* gamma, const float* beta, float eps, void* stream) {
+  DS2_REQUIRE(X && Y && mean && var && gamma && beta, "ds2_bn1d_apply_bf16: null pointer");
+  DS2_REQUIRE(ldy >= H && (ldy % 8) == 0, "ds2_bn1d_apply_bf16: bad output pitch %d", ldy);
+  const int vec = (ldx % 4 == 0) && ((uintptr_t)X % 16 == 0);
+  const long long total = (long long)M * (ldy / 4);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(bn1d_apply_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, X, ldx, (__bf16*)Y, ldy, M, H, mean, var, gamma,
+                     beta, eps, vec);
+  DS2_LAUNCH_CHECK("bn1d_apply_bf16_kernel");
   return 0;
 }
 

@@ -127,12 +127,13 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
             bp = f"rnns.{l}.batch_norm.module."
             if not training:
                 mean, var = W[bp + "running_mean"], W[bp + "running_var"]
-            xn = ops.bn1d_apply(xin, mean, var, W[bp + "weight"], W[bp + "bias"])
+            # bf16 mode: the normalised input exists only as the bf16 GEMM operand (kept for dW_ih in backward)
+            xn = (ops.bn1d_apply_bf16 if cfg.precision == "bf16" else ops.bn1d_apply)(xin, mean, var, W[bp + "weight"], W[bp + "bias"])
             lc.mean, lc.var = mean, var
         else:
-            xn = xin
+            xn = ops.cast_bf16(xin) if cfg.precision == "bf16" else xin
         if cfg.precision == "bf16":
-            gx = ops.gemm_bf16_nt(ops.cast_bf16(xn), ops.cast_bf16(W[f"rnns.{l}.wih_cat"]), bias=W[f"rnns.{l}.bih_cat"])
+            gx = ops.gemm_bf16_nt(xn, ops.cast_bf16(W[f"rnns.{l}.wih_cat"]), bias=W[f"rnns.{l}.bih_cat"])
         else:
             gx = ops.gemm(xn, W[f"rnns.{l}.wih_cat"], transB=True, bias=W[f"rnns.{l}.bih_cat"])  # (M, 2GH)
         bf = cfg.precision == "bf16"
@@ -251,7 +252,7 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
                 dwhh.zero_()
             # dW_ih (2GH, I) = dGx^T Xn
             if bf:
-                xnT = ops.cast_transpose_bf16(lc.xn)
+                xnT = ops.transpose_bf16(lc.xn[:, :W[f"rnns.{l}.wih_cat"].shape[1]])              # lc.xn is bf16 (M, pad8(I)) in this mode
                 ops.gemm_bf16_nt(dgxT, xnT, out=Gr[f"rnns.{l}.wih_cat"])
                 keep.append((dgxT, xnT))
             else:

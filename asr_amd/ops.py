@@ -237,6 +237,16 @@ def bn1d_apply(X: Tensor, mean: Tensor, var: Tensor, gamma: Tensor, beta: Tensor
     return Y
 
 
+def bn1d_apply_bf16(X: Tensor, mean: Tensor, var: Tensor, gamma: Tensor, beta: Tensor) -> Tensor:
+    """BN(X) written straight as bf16 (M, pad8(H)), pad columns zero."""
+    _chk_f32(X, mean, var, gamma, beta)
+    M, H = X.shape
+    Y = torch.empty(M, _pad8(H), dtype=torch.bfloat16, device=X.device)
+    _lib.check(_lib.load().ds2_bn1d_apply_bf16(X.data_ptr(), _row_pitch(X), Y.data_ptr(), Y.size(1), M, H, mean.data_ptr(), var.data_ptr(),
+                                               gamma.data_ptr(), beta.data_ptr(), BN_EPS, _stream()), "ds2_bn1d_apply_bf16")
+    return Y
+
+
 def bn1d_bwd(dY: Tensor, X: Tensor, mean: Tensor, var: Tensor, gamma: Tensor, dgamma: Tensor, dbeta: Tensor,
              dX: Optional[Tensor] = None) -> Tensor:
     _chk_f32(dY, X, mean, var, gamma, dgamma, dbeta, dX)

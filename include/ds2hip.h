@@ -74,6 +74,9 @@ int ds2_add_colstats_f32(const float* Xa, int lda, const float* Xb, int ldb, flo
 int ds2_colsum_f32(const float* X, int ldx, int M, int H, float* sum, float* sumsq, void* ws, size_t ws_bytes, void* stream);
 int ds2_bn1d_apply_f32(const float* X, int ldx, float* Y, int ldy, int M, int H, const float* mean, const float* var,
                        const float* gamma, const float* beta, float eps, void* stream);
+/* same, Y written as bf16 (M, ldy), ldy % 8 == 0, pad columns zero: feeds the bf16 input-projection GEMM without a cast pass */
+int ds2_bn1d_apply_bf16(const float* X, int ldx, void* Y, int ldy, int M, int H, const float* mean, const float* var, const float* gamma,
+                        const float* beta, float eps, void* stream);
 int ds2_bn1d_bwd_f32(const float* dY, int lddy, const float* X, int ldx, float* dX, int lddx, int M, int H, const float* mean,
                      const float* var, const float* gamma, float eps, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
                      void* stream);

@@ -122,6 +122,8 @@ def test_bn1d(dev, M, H):
     (y * dY).sum().backward()
     yd = ops.bn1d_apply(g(X, dev), mean, var, g(gam, dev), g(bet, dev))
     assert rel_l2(yd.cpu(), y.detach()) < 1e-5
+    yb = ops.bn1d_apply_bf16(g(X, dev), mean, var, g(gam, dev), g(bet, dev))       # bf16-mode operand: the fp32 result rounded once
+    assert yb.shape == (M, (H + 7) // 8 * 8) and torch.equal(yb[:, :H], yd.bfloat16()) and float(yb[:, H:].float().abs().sum()) == 0
     dgam, dbet = torch.empty(H, device=dev), torch.empty(H, device=dev)
     dX = ops.bn1d_bwd(g(dY.float(), dev), g(X, dev), mean, var, g(gam, dev), dgam, dbet)
     assert rel_l2(dX.cpu(), Xr.grad) < 2e-5
