@@ -139,49 +139,43 @@ __global__ __launch_bounds__(256) void col_finalize_kernel(const float* __restri
   }
 }
 
-// Y = (X - mean) * rstd * gamma + beta        (M,H) elementwise
-__global__ __launch_bounds__(256) void bn1d_apply_kernel(const float* __restrict__ X, int ldx, float* __restrict__ Y, int ldy,
-                                                         int M, int H, const float* __restrict__ mean,
-                                                         const float* __restrict__ var, const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, float eps, int vec) {
-  const int hq = (H + 3) / 4;
-  const long long total = (long long)M * hq;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int r = i / hq, c0 = (i % hq) * 4;
-    const int valid = H - c0;
-    f32x4 x = ld4(X + (long long)r * ldx + c0, valid, vec);
-    f32x4 mu = ld4(mean + c0, valid, false), vv = ld4(var + c0, valid, false);
-    f32x4 g = ld4(gamma + c0, valid, false), b = ld4(beta + c0, valid, false);
-    f32x4 y;
-    y.x = (x.x - mu.x) * rsqrtf(vv.x + eps) * g.x + b.x;
-    y.y = (x.y - mu.y) * rsqrtf(vv.y + eps) * g.y + b.y;
-    y.z = (x.z - mu.z) * rsqrtf(vv.z + eps) * g.z + b.z;
-    y.w = (x.w - mu.w) * rsqrtf(vv.w + eps) * g.w + b.w;
-    st4(Y + (long long)r * ldy + c0, y, valid, vec);
-  }
-}
-
-// same, written as bf16 (row pitch ldy % 8 == 0, pad columns H..ldy zero): the bf16-mode input projection consumes it directly
+// Y = (X - mean) * rstd * gamma + beta        (M,H) elementwise.
+// Thread = one fixed column quad (grid.x tiles the columns, grid.y the rows): the four per-column parameters are loaded and folded
+// into (scale, shift) ONCE, then the thread streams rows with one 16-byte load and one store each — the earlier form re-loaded
+// four parameter vectors per element quad and ran at a third of the HBM rate.  OUT_BF16: write the bf16 GEMM operand directly
+// (row pitch ldy % 8 == 0, pad columns H..ldy zero).
 typedef __bf16 nbf16x4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void bn1d_apply_bf16_kernel(const float* __restrict__ X, int ldx, __bf16* __restrict__ Y, int ldy, int M, int H,
-                                                              const float* __restrict__ mean, const float* __restrict__ var,
-                                                              const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int vec) {
-  const int hq = ldy / 4;
-  const long long total = (long long)M * hq;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int r = i / hq, c0 = (i % hq) * 4;
-    const int valid = H - c0;                       // <= 0 in the pad columns
+constexpr int BN_ROWS_PER_BLOCK = 32;
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256) void bn1d_apply_kernel(const float* __restrict__ X, int ldx, void* __restrict__ Yv, int ldy, int M, int H,
+                                                         const float* __restrict__ mean, const float* __restrict__ var,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int vec) {
+  const int c0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const int wcols = OUT_BF16 ? ldy : H;                       // columns written (bf16: incl. the zero pad)
+  if (c0 >= wcols) return;
+  const int valid = H - c0;                                   // <= 0 in the pad columns
+  f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
+  if (valid > 0) {
+    const f32x4 mu = ld4(mean + c0, valid, false), vv = ld4(var + c0, valid, false);
+    const f32x4 g = ld4(gamma + c0, valid, false), b = ld4(beta + c0, valid, false);
+    sc.x = rsqrtf(vv.x + eps) * g.x; sc.y = rsqrtf(vv.y + eps) * g.y; sc.z = rsqrtf(vv.z + eps) * g.z; sc.w = rsqrtf(vv.w + eps) * g.w;
+    sh = b - mu * sc;
+    if (valid < 4) {                                          // lanes past H produce exact zeros
+      if (valid < 2) { sc.y = 0.f; sh.y = 0.f; }
+      if (valid < 3) { sc.z = 0.f; sh.z = 0.f; }
+      sc.w = 0.f; sh.w = 0.f;
+    }
+  }
+  const int rend = min(M, (int)(blockIdx.y + 1) * BN_ROWS_PER_BLOCK);
+#pragma unroll 8
+  for (int r = blockIdx.y * BN_ROWS_PER_BLOCK; r < rend; ++r) {
     f32x4 y = {0.f, 0.f, 0.f, 0.f};
     if (valid > 0) {
-      f32x4 x = ld4(X + (long long)r * ldx + c0, valid, vec);
-      f32x4 mu = ld4(mean + c0, valid, false), vv = ld4(var + c0, valid, false);
-      f32x4 g = ld4(gamma + c0, valid, false), b = ld4(beta + c0, valid, false);
-      y.x = (x.x - mu.x) * rsqrtf(vv.x + eps) * g.x + b.x;
-      y.y = valid > 1 ? (x.y - mu.y) * rsqrtf(vv.y + eps) * g.y + b.y : 0.f;
-      y.z = valid > 2 ? (x.z - mu.z) * rsqrtf(vv.z + eps) * g.z + b.z : 0.f;
-      y.w = valid > 3 ? (x.w - mu.w) * rsqrtf(vv.w + eps) * g.w + b.w : 0.f;
+      const f32x4 x = ld4(X + (long long)r * ldx + c0, valid, vec);
+      y = x * sc + sh;                                        // (x - mu) * rstd * g + b with the per-column constants folded
     }
-    *reinterpret_cast<nbf16x4*>(Y + (long long)r * ldy + c0) = nbf16x4{(__bf16)y.x, (__bf16)y.y, (__bf16)y.z, (__bf16)y.w};
+    if (OUT_BF16) *reinterpret_cast<nbf16x4*>(reinterpret_cast<__bf16*>(Yv) + (long long)r * ldy + c0) = nbf16x4{(__bf16)y.x, (__bf16)y.y, (__bf16)y.z, (__bf16)y.w};
+    else st4(reinterpret_cast<float*>(Yv) + (long long)r * ldy + c0, y, valid, vec);
   }
 }
 
@@ -192,21 +186,24 @@ __global__ __launch_bounds__(256) void bn1d_bwd_apply_kernel(const float* __rest
                                                              const float* __restrict__ gamma, const float* __restrict__ s0,
                                                              const float* __restrict__ s1, float eps, float inv_count,
                                                              int vec) {
-  const int hq = (H + 3) / 4;
-  const long long total = (long long)M * hq;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int r = i / hq, c0 = (i % hq) * 4;
-    const int valid = H - c0;
-    f32x4 dy = ld4(dY + (long long)r * lddy + c0, valid, vec);
-    f32x4 x = ld4(X + (long long)r * ldx + c0, valid, vec);
-    f32x4 mu = ld4(mean + c0, valid, false), vv = ld4(var + c0, valid, false), g = ld4(gamma + c0, valid, false);
-    f32x4 a = ld4(s0 + c0, valid, false), b = ld4(s1 + c0, valid, false);
-    f32x4 o;
-    float rs;
-    rs = rsqrtf(vv.x + eps); o.x = g.x * rs * (dy.x - a.x * inv_count - (x.x - mu.x) * rs * b.x * inv_count);
-    rs = rsqrtf(vv.y + eps); o.y = g.y * rs * (dy.y - a.y * inv_count - (x.y - mu.y) * rs * b.y * inv_count);
-    rs = rsqrtf(vv.z + eps); o.z = g.z * rs * (dy.z - a.z * inv_count - (x.z - mu.z) * rs * b.z * inv_count);
-    rs = rsqrtf(vv.w + eps); o.w = g.w * rs * (dy.w - a.w * inv_count - (x.w - mu.w) * rs * b.w * inv_count);
+  // thread = one fixed column quad; per-column constants folded once:  dX = k1 * dY - k2 - k3 * (x - mu)
+  //   k1 = gamma * rstd ; k2 = k1 * s0 / M ; k3 = k1 * rstd * s1 / M
+  const int c0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const int valid = H - c0;
+  if (valid <= 0) return;
+  const f32x4 mu = ld4(mean + c0, valid, false), vv = ld4(var + c0, valid, false), g = ld4(gamma + c0, valid, false);
+  const f32x4 a = ld4(s0 + c0, valid, false), b = ld4(s1 + c0, valid, false);
+  f32x4 rs, k1, k2, k3;
+  rs.x = rsqrtf(vv.x + eps); rs.y = rsqrtf(vv.y + eps); rs.z = rsqrtf(vv.z + eps); rs.w = rsqrtf(vv.w + eps);
+  k1 = g * rs;
+  k2 = k1 * a * inv_count;
+  k3 = k1 * rs * b * inv_count;
+  const int rend = min(M, (int)(blockIdx.y + 1) * BN_ROWS_PER_BLOCK);
+#pragma unroll 8
+  for (int r = blockIdx.y * BN_ROWS_PER_BLOCK; r < rend; ++r) {
+    const f32x4 dy = ld4(dY + (long long)r * lddy + c0, valid, vec);
+    const f32x4 x = ld4(X + (long long)r * ldx + c0, valid, vec);
+    const f32x4 o = k1 * dy - k2 - k3 * (x - mu);
     st4(dX + (long long)r * lddx + c0, o, valid, vec);
   }
 }
@@ -457,11 +454,9 @@ extern "C" int ds2_bn1d_apply_f32(const float* X, int ldx, float* Y, int ldy, in
                                   const float* gamma, const float* beta, float eps, void* stream) {
   DS2_REQUIRE(X && Y && mean && var && gamma && beta, "ds2_bn1d_apply_f32: null pointer");
   const int vec = (ldx % 4 == 0) && (ldy % 4 == 0) && ((uintptr_t)X % 16 == 0) && ((uintptr_t)Y % 16 == 0);
-  const long long total = (long long)M * ((H + 3) / 4);
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(bn1d_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, X, ldx, Y, ldy, M, H, mean, var, gamma,
-                     beta, eps, vec);
+  dim3 grid(ceil_div(ceil_div(H, 4), 256), ceil_div(M, BN_ROWS_PER_BLOCK));
+  hipLaunchKernelGGL((bn1d_apply_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, X, ldx, (void*)Y, ldy, M, H, mean, var, gamma, beta,
+                     eps, vec);
   DS2_LAUNCH_CHECK("bn1d_apply_kernel");
   return 0;
 }
@@ -472,12 +467,9 @@ extern "C" int ds2_bn1d_apply_bf16(const float* X, int ldx, void* Y, int ldy, in
   DS2_REQUIRE(X && Y && mean && var && gamma && beta, "ds2_bn1d_apply_bf16: null pointer");
   DS2_REQUIRE(ldy >= H && (ldy % 8) == 0, "ds2_bn1d_apply_bf16: bad output pitch %d", ldy);
   const int vec = (ldx % 4 == 0) && ((uintptr_t)X % 16 == 0);
-  const long long total = (long long)M * (ldy / 4);
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(bn1d_apply_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, X, ldx, (__bf16*)Y, ldy, M, H, mean, var, gamma,
-                     beta, eps, vec);
-  DS2_LAUNCH_CHECK("bn1d_apply_bf16_kernel");
+  dim3 grid(ceil_div(ldy / 4, 256), ceil_div(M, BN_ROWS_PER_BLOCK));
+  hipLaunchKernelGGL((bn1d_apply_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, X, ldx, Y, ldy, M, H, mean, var, gamma, beta, eps, vec);
+  DS2_LAUNCH_CHECK("bn1d_apply_kernel<bf16>");
   return 0;
 }
 
@@ -491,10 +483,8 @@ extern "C" int ds2_bn1d_bwd_f32(const float* dY, int lddy, const float* X, int l
   if (rc) return rc;
   const int vec = (ldx % 4 == 0) && (lddy % 4 == 0) && (lddx % 4 == 0) && ((uintptr_t)X % 16 == 0) &&
                   ((uintptr_t)dY % 16 == 0) && ((uintptr_t)dX % 16 == 0);
-  const long long total = (long long)M * ((H + 3) / 4);
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(bn1d_bwd_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dY, lddy, X, ldx, dX, lddx, M, H, mean,
+  dim3 grid(ceil_div(ceil_div(H, 4), 256), ceil_div(M, BN_ROWS_PER_BLOCK));
+  hipLaunchKernelGGL(bn1d_bwd_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, dY, lddy, X, ldx, dX, lddx, M, H, mean,
                      var, gamma, (const float*)dbeta, (const float*)dgamma, eps, 1.0f / (float)M, vec);
   DS2_LAUNCH_CHECK("bn1d_bwd_apply_kernel");
   return 0;
