@@ -1,0 +1,345 @@
+// conv1 forward and weight gradient with bf16 MFMA operands (precision = "bf16"; conv.hip's fp32 kernels stay the parity path).
+// Conv2d(1, 32, (41, 11), stride (2, 2), padding (20, 5)), deepspeech.py:61:
+//     y1[b,co,o,t] = bias[co] + sum_{kd<41, kt<11} W[co,0,kd,kt] * x[b, 2o + kd - 20, 2t + kt - 5]
+//
+// One input channel gives the MFMA no channel axis to contract over, so the 11 time taps play that role: a gather pass builds,
+// from one read of the spectrogram, the two bf16 operand images
+//     X16 [b][f][t][16]   (tap-contiguous:  X16[..][t][c]  = x[b][f][2t + c - 5], c < 11, else 0)   -> forward  B operand
+//     X16T[b][f][16][Tp]  (time-contiguous: X16T[..][c][t] = same value)                              -> wgrad    B operand
+// (165 MB each at B = 64 x 10 s; the stride-2 / shift-by-tap addressing is paid once, here, instead of in every fragment read).
+//   forward: GEMM M = co (32), N = t, K = (kd, c) = 41 x 16.  block = (b, 8 output rows, 32 time steps); the 55 input rows the
+//            8 output rows touch and all 41 weight rows sit in LDS (96 KB); a wave owns 2 output rows and walks its 43 input rows
+//            once: one B fragment per row feeds both accumulators, the weight fragments rotate through three registers.
+//   wgrad:   GEMM M = co, N = (kd, c) = 656, K = t.  block = (b, 64 time steps) loops over the 81 output rows with a 44-slot LDS
+//            ring of input rows (two new rows per step, written while the step computes) and a double-buffered dY tile cast from
+//            fp32 on the fly; 21 accumulator tiles of 32 columns (= 2 kernel rows x 16 taps) over 4 waves; ordered reduction
+//            of the per-block partials afterwards (deterministic).
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int KD = 41, KTAPS = 11, PD = 20, PT = 5, CO = 32, NC = 16;
+
+__device__ __attribute__((aligned(16))) float g_zero_c1[4] = {0.f, 0.f, 0.f, 0.f};
+
+// ---- operand images --------------------------------------------------------------------------------------------------
+// thread = (b, f, 8 consecutive output steps): 25 input samples -> 8 X16 pixels (256 contiguous bytes) and one 16-byte run in
+// each of the 16 X16T rows
+__global__ __launch_bounds__(256) void conv1_gather_kernel(const float* __restrict__ x, __bf16* __restrict__ X16, __bf16* __restrict__ X16T,
+                                                           long long rows /* B*F */, int Tin, int T, int Tp) {
+  const int octs = Tp / 8;
+  const long long total = rows * octs;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / octs;
+    const int t0 = (int)(i % octs) * 8;
+    const float* xr = x + row * Tin;
+    float v[25];
+#pragma unroll
+    for (int j = 0; j < 25; ++j) {
+      const int ti = 2 * t0 - PT + j;
+      v[j] = (ti >= 0 && ti < Tin) ? xr[ti] : 0.f;
+    }
+    // pixel (t0 + e), tap c  <-  v[2e + c]
+    if (X16) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (t0 + e < T) {
+          bf16x8 lo, hi;
+#pragma unroll
+          for (int c = 0; c < 8; ++c) lo[c] = (__bf16)v[2 * e + c];
+#pragma unroll
+          for (int c = 0; c < 8; ++c) hi[c] = (c + 8 < KTAPS) ? (__bf16)v[2 * e + c + 8] : (__bf16)0.f;
+          __bf16* p = X16 + (row * T + t0 + e) * NC;
+          *reinterpret_cast<bf16x8*>(p) = lo;
+          *reinterpret_cast<bf16x8*>(p + 8) = hi;
+        }
+      }
+    }
+    if (X16T) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (c < KTAPS && t0 + e < T) ? (__bf16)v[2 * e + c] : (__bf16)0.f;
+        *reinterpret_cast<bf16x8*>(X16T + (row * NC + c) * Tp + t0) = o;
+      }
+    }
+  }
+}
+
+// W1 (32,1,41,11) fp32 -> Wp[kd][co][16] bf16 (taps 11..15 zero)
+__global__ void conv1_pack_kernel(const float* __restrict__ w, __bf16* __restrict__ wp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= KD * CO * NC) return;
+  const int c = i % NC, co = (i / NC) % CO, kd = i / (NC * CO);
+  wp[i] = (c < KTAPS) ? (__bf16)w[(co * KD + kd) * KTAPS + c] : (__bf16)0.f;
+}
+
+// ---- forward -----------------------------------------------------------------------------------------------------------
+constexpr int F_OG = 8, F_TT = 32;
+constexpr int F_ROWS = 2 * (F_OG - 1) + KD;        // 55 input rows per block
+constexpr int F_ROWB = F_TT * NC * 2;              // 1024 bytes per staged row
+constexpr int F_WB = KD * CO * NC * 2;             // 41984 bytes of weights
+constexpr int F_LDS = F_ROWS * F_ROWB + F_WB;      // 98304
+
+struct C1Args {
+  const __bf16* X16; const __bf16* wp; const float* bias; const int* lens; float* y;
+  int B, F, T, D1;
+};
+
+__global__ __launch_bounds__(256) void conv1_bf16_fwd_kernel(C1Args a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* rows = lds;
+  char* wl = lds + F_ROWS * F_ROWB;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int t0 = blockIdx.x * F_TT, o0 = blockIdx.y * F_OG, b = blockIdx.z;
+  const int len = a.lens ? min(a.lens[b], a.T) : a.T;
+  const int f0 = 2 * o0 - PD;
+  if (t0 < len) {
+    // stage the 55 input rows (32 pixels x 32 B each) and the packed weights
+    for (int c = tid; c < F_ROWS * (F_ROWB / 16); c += 256) {
+      const int r = c / (F_ROWB / 16), q = c % (F_ROWB / 16);       // q: 16-byte chunk inside the row = pixel*2 + half-pixel
+      const int f = f0 + r, t = t0 + (q >> 1);
+      const bool ok = f >= 0 && f < a.F && t < a.T;
+      const void* src = ok ? (const void*)(a.X16 + (((long long)b * a.F + f) * a.T + t) * NC + (q & 1) * 8) : (const void*)g_zero_c1;
+      *reinterpret_cast<u32x4*>(rows + r * F_ROWB + q * 16) = *reinterpret_cast<const u32x4*>(src);
+    }
+    for (int c = tid; c < F_WB / 16; c += 256) *reinterpret_cast<u32x4*>(wl + c * 16) = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(a.wp) + c * 16);
+  }
+  __syncthreads();
+  const int oa = o0 + 2 * wave, ob = oa + 1;
+  const int t = t0 + l31;
+  f32x16 acc_a, acc_b;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc_a[r] = 0.f; acc_b[r] = 0.f; }
+  if (t0 < len && oa < a.D1) {
+    // this wave's window: local rows 4*wave + r, r = 0..42; output row a uses kernel row r, output row b uses kernel row r - 2
+    const char* bp = rows + (4 * wave) * F_ROWB + l31 * (NC * 2) + half * 16;
+    const char* ap = wl + l31 * (NC * 2) + half * 16;
+    bf16x8 w0 = *reinterpret_cast<const bf16x8*>(ap), w1 = w0, w2 = w0;       // w0 = W[r], w1 = W[r-1], w2 = W[r-2]
+#pragma unroll
+    for (int r = 0; r < KD + 2; ++r) {
+      if (r < KD) w0 = *reinterpret_cast<const bf16x8*>(ap + r * (CO * NC * 2));
+      const bf16x8 xb = *reinterpret_cast<const bf16x8*>(bp + r * F_ROWB);
+      if (r < KD) acc_a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xb, acc_a, 0, 0, 0);
+      if (r >= 2) acc_b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, xb, acc_b, 0, 0, 0);
+      w2 = w1;
+      w1 = w0;
+    }
+  }
+  if (t < a.T) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const float bv = a.bias ? a.bias[co] : 0.f;
+      if (oa < a.D1) a.y[(((long long)b * CO + co) * a.D1 + oa) * a.T + t] = (t < len) ? acc_a[r] + bv : 0.f;
+      if (ob < a.D1) a.y[(((long long)b * CO + co) * a.D1 + ob) * a.T + t] = (t < len) ? acc_b[r] + bv : 0.f;
+    }
+  }
+}
+
+// ---- weight gradient -------------------------------------------------------------------------------------------------
+constexpr int W_TT = 64;                       // time steps (K) per block
+constexpr int W_PITCH = W_TT * 2 + 16;         // 144 bytes per (row, tap) / per co: conflict-free ds_read_b128
+constexpr int W_SLOT = NC * W_PITCH;           // 2304 bytes per input row
+constexpr int W_NR = 44;                       // ring slots (window 41 + 2 being written + 1)
+constexpr int W_DY = CO * W_PITCH;             // 4608 bytes per dY tile
+constexpr int W_LDS = (W_NR + 1) * W_SLOT + 2 * W_DY;   // ring + zero slot + 2 dY buffers = 112896
+constexpr int W_TILES = (KD + 1) / 2;          // 21 column tiles of 32 = 2 kernel rows x 16 taps
+constexpr int W_TPW = (W_TILES + 3) / 4;       // 6 tiles per wave at most
+
+struct C1WArgs {
+  const __bf16* X16T; const float* dy; const int* lens; float* part;
+  int B, F, T, Tp, D1;
+};
+
+__global__ __launch_bounds__(256) void conv1_bf16_wgrad_kernel(C1WArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* ring = lds;
+  char* zslot = lds + W_NR * W_SLOT;
+  char* dyl = zslot + W_SLOT;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int t0 = blockIdx.x * W_TT, b = blockIdx.y;
+  const int len = a.lens ? min(a.lens[b], a.T) : a.T;
+  float* out = a.part + ((long long)b * gridDim.x + blockIdx.x) * (CO * KD * KTAPS);
+
+  f32x16 acc[W_TPW];
+#pragma unroll
+  for (int i = 0; i < W_TPW; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  if (t0 < len) {                                  // dY is zero beyond the utterance: nothing to add from this tile otherwise
+    // one input row = 16 taps x 64 steps = 128 chunks of 16 bytes; thread tid < 128 owns chunk (c = tid >> 3, q = tid & 7)
+    auto row_src = [&](int f, int c, int q) -> const void* {
+      const bool ok = f >= 0 && f < a.F;
+      return ok ? (const void*)(a.X16T + (((long long)b * a.F + f) * NC + c) * a.Tp + t0 + q * 8) : (const void*)g_zero_c1;
+    };
+    auto dy_load = [&](int o, int k, f32x4& v) {    // chunk k (0..511): co = k >> 4, 4 steps at (k & 15) * 4
+      const int co = k >> 4, tq = t0 + (k & 15) * 4;
+      const float* p = a.dy + (((long long)b * CO + co) * a.D1 + o) * a.T + tq;
+      if (tq + 4 <= a.T && (((uintptr_t)p) & 15) == 0) v = *reinterpret_cast<const f32x4*>(p);
+      else { v.x = tq < a.T ? p[0] : 0.f; v.y = tq + 1 < a.T ? p[1] : 0.f; v.z = tq + 2 < a.T ? p[2] : 0.f; v.w = tq + 3 < a.T ? p[3] : 0.f; }
+    };
+    auto dy_store = [&](int buf, int k, const f32x4& v) {
+      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+      const int co = k >> 4, tq = (k & 15) * 4;
+      *reinterpret_cast<bf16x4*>(dyl + buf * W_DY + co * W_PITCH + tq * 2) = bf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    };
+    // ---- prologue: zero slot, window of o = 0 (rows f = -20 .. 20 -> slots 0 .. 40), dY tile of o = 0
+    for (int c = tid; c < W_SLOT / 16; c += 256) *reinterpret_cast<u32x4*>(zslot + c * 16) = u32x4{0u, 0u, 0u, 0u};
+    for (int c = tid; c < KD * 128; c += 256) {
+      const int r = c >> 7, k = c & 127;
+      *reinterpret_cast<u32x4*>(ring + r * W_SLOT + (k >> 3) * W_PITCH + (k & 7) * 16) = *reinterpret_cast<const u32x4*>(row_src(r - PD, k >> 3, k & 7));
+    }
+    {
+      f32x4 v0, v1;
+      dy_load(0, tid, v0);
+      dy_load(0, tid + 256, v1);
+      dy_store(0, tid, v0);
+      dy_store(0, tid + 256, v1);
+    }
+    __syncthreads();
+    for (int o = 0; o < a.D1; ++o) {
+      // ---- next step's data into registers: rows f = 2o + 21, 2o + 22 (256 chunks, one per thread) and dY tile o + 1
+      const bool more = o + 1 < a.D1;
+      u32x4 nr = {0u, 0u, 0u, 0u};
+      f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;
+      const int nrow = tid >> 7, nk = tid & 127;
+      if (more) {
+        nr = *reinterpret_cast<const u32x4*>(row_src(2 * o + 1 + nrow + PD, nk >> 3, nk & 7));
+        dy_load(o + 1, tid, d0);
+        dy_load(o + 1, tid + 256, d1);
+      }
+      // ---- MFMAs of step o: K = 64 steps, tiles j = wave, wave + 4, ...
+      const char* ap = dyl + (o & 1) * W_DY + l31 * W_PITCH + half * 16;
+      const int cl = l31 & 15, kdl = l31 >> 4;
+#pragma unroll
+      for (int i = 0; i < W_TPW; ++i) {
+        const int j = wave + 4 * i;
+        if (j < W_TILES) {                                  // wave-uniform
+          const int kd = 2 * j + kdl;                       // this lane's kernel row; input row f = 2o + kd - 20 -> slot (2o + kd) % 44
+          const char* bp = (kd < KD ? ring + ((2 * o + kd) % W_NR) * W_SLOT : zslot) + cl * W_PITCH + half * 16;
+#pragma unroll
+          for (int ks = 0; ks < W_TT / 16; ++ks) {
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(ap + ks * 32);
+            const bf16x8 bf = *reinterpret_cast<const bf16x8*>(bp + ks * 32);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[i], 0, 0, 0);
+          }
+        }
+      }
+      // ---- publish the next step's data (slots outside the current window, the other dY buffer), then one barrier
+      if (more) {
+        const int slot = (2 * o + 1 + nrow + 2 * PD) % W_NR;
+        *reinterpret_cast<u32x4*>(ring + slot * W_SLOT + (nk >> 3) * W_PITCH + (nk & 7) * 16) = nr;
+        dy_store((o + 1) & 1, tid, d0);
+        dy_store((o + 1) & 1, tid + 256, d1);
+      }
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < W_TPW; ++i) {
+    const int j = wave + 4 * i;
+    if (j < W_TILES) {
+      const int kd = 2 * j + (l31 >> 4), c = l31 & 15;
+      if (kd < KD && c < KTAPS) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
+          out[(co * KD + kd) * KTAPS + c] = acc[i][r];
+        }
+      }
+    }
+  }
+}
+
+__global__ void conv1_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW, int nblk) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= CO * KD * KTAPS) return;
+  float s = 0.f;
+  for (int k = 0; k < nblk; ++k) s += part[(long long)k * (CO * KD * KTAPS) + idx];
+  dW[idx] = s;
+}
+
+inline int pad64(int T) { return (T + 63) / 64 * 64; }
+
+}  // namespace
+
+// sizes (bytes): which = 0 packed weights, 1 X16 (forward operand image), 2 X16T (weight-gradient operand image)
+extern "C" size_t ds2_conv1_bf16_bytes(int which, int B, int F, int T) {
+  if (which == 0) return (size_t)KD * CO * NC * 2;
+  if (which == 1) return (size_t)B * F * T * NC * 2;
+  return (size_t)B * F * NC * pad64(T) * 2;
+}
+
+extern "C" int ds2_conv1_pack_bf16(const float* w1, void* wp, void* stream) {
+  DS2_REQUIRE(w1 && wp, "ds2_conv1_pack_bf16: null pointer");
+  hipLaunchKernelGGL(conv1_pack_kernel, dim3(ceil_div(KD * CO * NC, 256)), dim3(256), 0, (hipStream_t)stream, w1, (__bf16*)wp);
+  DS2_LAUNCH_CHECK("conv1_pack_kernel");
+  return 0;
+}
+
+// x (B,1,F,Tin) fp32 -> X16 and/or X16T (either may be NULL); T = output steps = (Tin + 2*5 - 11)/2 + 1
+extern "C" int ds2_conv1_gather_bf16(const float* x, void* X16, void* X16T, int B, int F, int Tin, void* stream) {
+  DS2_REQUIRE(x && (X16 || X16T) && B > 0 && F > 0 && Tin > 0, "ds2_conv1_gather_bf16: bad args");
+  const int T = (Tin + 2 * PT - KTAPS) / 2 + 1, Tp = pad64(T);
+  const long long total = (long long)B * F * (Tp / 8);
+  long long blocks = (total + 255) / 256;
+  if (blocks > 65535) blocks = 65535;
+  hipLaunchKernelGGL(conv1_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (__bf16*)X16, (__bf16*)X16T, (long long)B * F, Tin,
+                     T, Tp);
+  DS2_LAUNCH_CHECK("conv1_gather_kernel");
+  return 0;
+}
+
+// y1 (B,32,D1,T) fp32 = conv1(x) + bias, zero for t >= lens[b] (MaskConv).  X16 from ds2_conv1_gather_bf16, wp from ds2_conv1_pack_bf16.
+extern "C" int ds2_conv1_fwd_bf16(const void* X16, const void* wp, const float* bias, const int* lens_dev, float* y1, int B, int F, int Tin,
+                                  void* stream) {
+  DS2_REQUIRE(X16 && wp && y1, "ds2_conv1_fwd_bf16: null pointer");
+  C1Args a{};
+  a.X16 = (const __bf16*)X16; a.wp = (const __bf16*)wp; a.bias = bias; a.lens = lens_dev; a.y = y1;
+  a.B = B; a.F = F; a.T = (Tin + 2 * PT - KTAPS) / 2 + 1; a.D1 = (F + 2 * PD - KD) / 2 + 1;
+  static bool attr_set = false;
+  if (!attr_set) {
+    DS2_HIP(hipFuncSetAttribute((const void*)conv1_bf16_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv1_bf16_fwd_kernel, dim3(ceil_div(a.T, F_TT), ceil_div(a.D1, F_OG), B), dim3(256), F_LDS, (hipStream_t)stream, a);
+  DS2_LAUNCH_CHECK("conv1_bf16_fwd_kernel");
+  return 0;
+}
+
+extern "C" size_t ds2_conv1_wgrad_bf16_workspace_bytes(int B, int Tin) {
+  const int T = (Tin + 2 * PT - KTAPS) / 2 + 1;
+  return (size_t)B * ceil_div(T, W_TT) * CO * KD * KTAPS * sizeof(float);
+}
+
+// dW1 (32,1,41,11) fp32 from X16T (ds2_conv1_gather_bf16) and dY1 (B,32,D1,T) fp32 (already zero beyond each length)
+extern "C" int ds2_conv1_wgrad_bf16(const void* X16T, const float* dy1, const int* lens_dev, float* dW1, int B, int F, int Tin, void* ws,
+                                    size_t ws_bytes, void* stream) {
+  DS2_REQUIRE(X16T && dy1 && dW1 && ws, "ds2_conv1_wgrad_bf16: null pointer");
+  DS2_REQUIRE(ws_bytes >= ds2_conv1_wgrad_bf16_workspace_bytes(B, Tin), "ds2_conv1_wgrad_bf16: workspace too small");
+  C1WArgs a{};
+  a.X16T = (const __bf16*)X16T; a.dy = dy1; a.lens = lens_dev; a.part = (float*)ws;
+  a.B = B; a.F = F; a.T = (Tin + 2 * PT - KTAPS) / 2 + 1; a.Tp = pad64(a.T); a.D1 = (F + 2 * PD - KD) / 2 + 1;
+  static bool attr_set = false;
+  if (!attr_set) {
+    DS2_HIP(hipFuncSetAttribute((const void*)conv1_bf16_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS));
+    attr_set = true;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int ntt = ceil_div(a.T, W_TT);
+  hipLaunchKernelGGL(conv1_bf16_wgrad_kernel, dim3(ntt, B), dim3(256), W_LDS, s, a);
+  DS2_LAUNCH_CHECK("conv1_bf16_wgrad_kernel");
+  hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(ceil_div(CO * KD * KTAPS, 256)), dim3(256), 0, s, (const float*)ws, dW1, ntt * B);
+  DS2_LAUNCH_CHECK("conv1_wgrad_reduce_kernel");
+  return 0;
+}

@@ -72,6 +72,7 @@ class Ctx:
     st1: tuple = ()
     st2: tuple = ()
     packs: tuple = ()
+    x16t: Optional[Tensor] = None      # bf16 mode: conv1's time-contiguous operand image (kept for its weight gradient)
     layers: List[LayerCtx] = field(default_factory=list)
     y_last: Optional[Tensor] = None
     fc_xn: Optional[Tensor] = None
@@ -97,7 +98,14 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
     # ---- conv stack -----------------------------------------------------------------------------
     wpk1, wpk2, wpk2d = ops.conv_pack(W[cp + "0.weight"], W[cp + "3.weight"])
     ctx.packs = (wpk2d,)
-    y1 = ops.conv1_fwd(x, wpk1, W[cp + "0.bias"], lens_dev)
+    if cfg.precision == "bf16":
+        # conv1 on the bf16 matrix cores: operand images gathered once from the spectrogram (the time-contiguous one is kept
+        # for the weight gradient)
+        X16, ctx.x16t = ops.conv1_gather_bf16(x, want_fwd=True, want_wgrad=save)
+        y1 = ops.conv1_fwd_bf16(X16, ops.conv1_pack_bf16(W[cp + "0.weight"]), W[cp + "0.bias"], lens_dev, Tin)
+        del X16
+    else:
+        y1 = ops.conv1_fwd(x, wpk1, W[cp + "0.bias"], lens_dev)
     if training:
         m1, v1 = ops.bn2d_stats(y1, *run(cp + "1"))
     else:
@@ -288,7 +296,11 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
     dy1 = ops.bn2d_act_bwd(ctx.y1, da1, lens_dev, m1, v1, W[cp + "1.weight"], W[cp + "1.bias"], Gr[cp + "1.weight"], Gr[cp + "1.bias"])
     del da1
     Gr[cp + "0.bias"].copy_(ops.chan_sum(dy1))
-    ops.conv1_wgrad(ctx.x, dy1, lens_dev, Gr[cp + "0.weight"])
+    if cfg.precision == "bf16":
+        ops.conv1_wgrad_bf16(ctx.x16t, dy1, lens_dev, Gr[cp + "0.weight"], ctx.x.shape[3])
+        ctx.x16t = None
+    else:
+        ops.conv1_wgrad(ctx.x, dy1, lens_dev, Gr[cp + "0.weight"])
     done("conv")
     if side is not main:
         main.wait_stream(side)              # all weight gradients are final for whoever runs next on the main stream

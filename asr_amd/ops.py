@@ -390,6 +390,47 @@ def conv2_wgrad(a1: Tensor, dy2: Tensor, lens_dev: Tensor, dW2: Tensor):
                                        wsb, _stream()), "ds2_conv2_wgrad_f32")
 
 
+def conv1_pack_bf16(w1: Tensor) -> Tensor:
+    _chk_f32(w1)
+    lib = _lib.load()
+    wp = torch.empty(lib.ds2_conv1_bf16_bytes(0, 0, 0, 0), dtype=torch.uint8, device=w1.device)
+    _lib.check(lib.ds2_conv1_pack_bf16(w1.data_ptr(), wp.data_ptr(), _stream()), "ds2_conv1_pack_bf16")
+    return wp
+
+
+def conv1_gather_bf16(x: Tensor, want_fwd: bool = True, want_wgrad: bool = True):
+    """x (B,1,F,Tin) fp32 -> (X16 (B,F,T,16) bf16 | None, X16T (B,F,16,pad64(T)) bf16 | None): conv1's operand images."""
+    _chk_f32(x)
+    assert x.is_contiguous()
+    lib = _lib.load()
+    B, _, F, Tin = x.shape
+    _, _, T = _lib.conv_dims(F, Tin)
+    X16 = torch.empty(lib.ds2_conv1_bf16_bytes(1, B, F, T) // 2, dtype=torch.bfloat16, device=x.device).view(B, F, T, 16) if want_fwd else None
+    X16T = torch.empty(lib.ds2_conv1_bf16_bytes(2, B, F, T) // 2, dtype=torch.bfloat16, device=x.device).view(B, F, 16, -1) if want_wgrad else None
+    _lib.check(lib.ds2_conv1_gather_bf16(x.data_ptr(), _ptr(X16), _ptr(X16T), B, F, Tin, _stream()), "ds2_conv1_gather_bf16")
+    return X16, X16T
+
+
+def conv1_fwd_bf16(X16: Tensor, wp: Tensor, bias: Tensor, lens_dev: Tensor, Tin: int) -> Tensor:
+    B, F, T, _ = X16.shape
+    D1, _, T2 = _lib.conv_dims(F, Tin)
+    assert T2 == T
+    y1 = torch.empty(B, 32, D1, T, dtype=torch.float32, device=X16.device)
+    _lib.check(_lib.load().ds2_conv1_fwd_bf16(X16.data_ptr(), wp.data_ptr(), bias.data_ptr(), lens_dev.data_ptr(), y1.data_ptr(), B, F, Tin,
+                                              _stream()), "ds2_conv1_fwd_bf16")
+    return y1
+
+
+def conv1_wgrad_bf16(X16T: Tensor, dy1: Tensor, lens_dev: Tensor, dW1: Tensor, Tin: int):
+    _chk_f32(dy1, dW1)
+    lib = _lib.load()
+    B, F = X16T.shape[0], X16T.shape[1]
+    wsb = lib.ds2_conv1_wgrad_bf16_workspace_bytes(B, Tin)
+    ws = _ws(wsb, dy1.device)
+    _lib.check(lib.ds2_conv1_wgrad_bf16(X16T.data_ptr(), dy1.data_ptr(), lens_dev.data_ptr(), dW1.data_ptr(), B, F, Tin, ws.data_ptr(), wsb,
+                                        _stream()), "ds2_conv1_wgrad_bf16")
+
+
 def conv2_pack_bf16(w2: Tensor):
     _chk_f32(w2)
     lib = _lib.load()

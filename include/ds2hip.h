@@ -165,6 +165,19 @@ size_t ds2_greedy_decode_workspace_bytes(int B, int T);
 int ds2_greedy_decode_f32(const float* probs, long long ld_b, long long ld_t, int B, int T, int C, const int* sizes_dev, int blank,
                           int* ids, int* offs, int* out_len, void* ws, size_t ws_bytes, void* stream);
 
+/* conv1 in bf16 mode (Conv2d(1,32,(41,11),s=(2,2),p=(20,5)), deepspeech.py:61, forward + weight gradient; conv1 has no data
+ * gradient).  ds2_conv1_gather_bf16 builds the two bf16 operand images from one read of the spectrogram batch:
+ * X16 (B,F,T,16) tap-contiguous for the forward, X16T (B,F,16,pad64(T)) time-contiguous for the weight gradient (either may be
+ * NULL).  ds2_conv1_bf16_bytes(which = 0 packed weights | 1 X16 | 2 X16T, B, F, T) sizes the buffers. */
+size_t ds2_conv1_bf16_bytes(int which, int B, int F, int T);
+int ds2_conv1_pack_bf16(const float* w1, void* wp, void* stream);
+int ds2_conv1_gather_bf16(const float* x, void* X16, void* X16T, int B, int F, int Tin, void* stream);
+int ds2_conv1_fwd_bf16(const void* X16, const void* wp, const float* bias, const int* lens_dev, float* y1, int B, int F, int Tin,
+                       void* stream);
+size_t ds2_conv1_wgrad_bf16_workspace_bytes(int B, int Tin);
+int ds2_conv1_wgrad_bf16(const void* X16T, const float* dy1, const int* lens_dev, float* dW1, int B, int F, int Tin, void* ws,
+                         size_t ws_bytes, void* stream);
+
 /* ---- spectrogram front-end -------------------------------------------------------------
  * SpectrogramParser.parse_audio's arithmetic, data/parsers/spectrogram_parser.py:45-60, for a whole batch:
  * librosa.stft (centred frames, win_length = n_fft) -> |.| -> log1p -> optional (x - mean) / std(unbiased) per utterance,

@@ -248,6 +248,38 @@ def test_conv2_bf16(dev, B, Tin, lens_in):
     assert rel_l2(dW2.cpu(), w2r.grad) < 1e-5
 
 
+@pytest.mark.parametrize("B,Tin,lens_in", [(2, 40, [40, 21]), (3, 300, [300, 257, 90]), (2, 131, [131, 1])])
+def test_conv1_bf16(dev, B, Tin, lens_in):
+    """bf16-operand conv1 forward / weight gradient vs fp64 conv on the bf16-rounded operands (exact up to fp32 accumulation), plus
+    the gathered operand images themselves (bit-exact)."""
+    from asr_amd import ops
+    x, out_lens, w1, b1, w2, b2 = _conv_case(B, Tin, lens_in)
+    T = int((Tin + 1) // 2)
+    mask = (torch.arange(T).view(1, 1, 1, T) < out_lens.view(B, 1, 1, 1)).double()
+    xb = x.bfloat16().double()
+    w1r = w1.bfloat16().double().requires_grad_(True)
+    y1 = torch.nn.functional.conv2d(xb, w1r, b1.double(), stride=(2, 2), padding=(20, 5)) * mask
+    ld = g(out_lens, dev)
+    X16, X16T = ops.conv1_gather_bf16(g(x, dev))
+    assert X16.shape == (B, 161, T, 16) and X16T.shape[:3] == (B, 161, 16) and X16T.shape[3] % 64 == 0 and X16T.shape[3] >= T
+    xp = torch.nn.functional.pad(x[:, 0], (5, 2 * T + 16))                        # index 2t + c (- 5 + 5)
+    want = torch.stack([xp[:, :, c:c + 2 * T:2] for c in range(11)], dim=-1).bfloat16()   # (B, F, T, 11)
+    assert torch.equal(X16[..., :11].cpu(), want) and float(X16[..., 11:].float().abs().sum()) == 0
+    assert torch.equal(X16T[:, :, :11, :T].cpu(), want.permute(0, 1, 3, 2)) and float(X16T[:, :, :, T:].float().abs().sum()) == 0
+    y1d = ops.conv1_fwd_bf16(X16, ops.conv1_pack_bf16(g(w1, dev)), g(b1, dev), ld, Tin)
+    assert y1d.shape == y1.shape and rel_l2(y1d.cpu(), y1.detach()) < 5e-6
+    for i, n in enumerate(out_lens.tolist()):
+        assert float(y1d[i, :, :, n:].abs().sum()) == 0.0                        # MaskConv zeros
+    # weight gradient: bf16-rounded x and dY
+    dy1 = (T_(26, *y1.shape) * mask.float()).contiguous()
+    w1g = w1.double().requires_grad_(True)
+    yw = torch.nn.functional.conv2d(xb, w1g, None, stride=(2, 2), padding=(20, 5))
+    (yw * dy1.bfloat16().double()).sum().backward()
+    dW1 = torch.empty(32, 1, 41, 11, device=dev)
+    ops.conv1_wgrad_bf16(X16T, g(dy1, dev), ld, dW1, Tin)
+    assert rel_l2(dW1.cpu(), w1g.grad) < 1e-5
+
+
 # ---------------------------------------------------------------------------------------------- RNN
 @pytest.mark.parametrize("bf", [False, True])
 @pytest.mark.parametrize("kind,H,B,T,lens", [("gru", 32, 3, 9, [9, 6, 2]), ("lstm", 24, 3, 9, [9, 6, 2]), ("gru", 72, 20, 17, None),
