@@ -7,9 +7,10 @@
 //     X16 [b][f][t][16]   (tap-contiguous:  X16[..][t][c]  = x[b][f][2t + c - 5], c < 11, else 0)   -> forward  B operand
 //     X16T[b][f][16][Tp]  (time-contiguous: X16T[..][c][t] = same value)                              -> wgrad    B operand
 // (165 MB each at B = 64 x 10 s; the stride-2 / shift-by-tap addressing is paid once, here, instead of in every fragment read).
-//   forward: GEMM M = co (32), N = t, K = (kd, c) = 41 x 16.  block = (b, 8 output rows, 32 time steps); the 55 input rows the
-//            8 output rows touch and all 41 weight rows sit in LDS (96 KB); a wave owns 2 output rows and walks its 43 input rows
-//            once: one B fragment per row feeds both accumulators, the weight fragments rotate through three registers.
+//   forward: GEMM M = co (32), N = t, K = (kd, c) = 41 x 16.  block = (b, 8 output rows, half of the time axis), persistent over
+//            32-step tiles: all 41 weight rows are staged once, the 55 input rows a tile touches are DMA'd (global_load_lds, one
+//            1 KiB instruction per row) into a double buffer while the previous tile is multiplied; 8 waves, one output row each (two
+//            per SIMD so that one wave's DMA issue, fragment reads and stores hide under the other's MFMAs), two accumulator chains.
 //   wgrad:   GEMM M = co, N = (kd, c) = 656, K = t.  block = (b, 64 time steps) loops over the 81 output rows with a 44-slot LDS
 //            ring of input rows (two new rows per step, written while the step computes) and a double-buffered dY tile cast from
 //            fp32 on the fly; 21 accumulator tiles of 32 columns (= 2 kernel rows x 16 taps) over 4 waves; ordered reduction
@@ -70,75 +71,105 @@ __global__ __launch_bounds__(256) void conv1_gather_kernel(const float* __restri
   }
 }
 
-// W1 (32,1,41,11) fp32 -> Wp[kd][co][16] bf16 (taps 11..15 zero)
+// 32-byte records (one pixel / one output channel = 16 taps) read by 16-lane ds_read_b128 groups at record stride would hit
+// every bank row twice; swapping the two 16-byte halves of records 8..15 (mod 16) makes the 16 lanes of a group land on 16
+// distinct bank quads.  Applied to the packed weights here and, through the DMA source addresses, to the staged input rows.
+__device__ __forceinline__ int swz_half(int rec, int half) { return half ^ ((rec >> 3) & 1); }
+
+// W1 (32,1,41,11) fp32 -> Wp[kd][co][2 halves (swizzled)][8] bf16 (taps 11..15 zero)
 __global__ void conv1_pack_kernel(const float* __restrict__ w, __bf16* __restrict__ wp) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= KD * CO * NC) return;
   const int c = i % NC, co = (i / NC) % CO, kd = i / (NC * CO);
-  wp[i] = (c < KTAPS) ? (__bf16)w[(co * KD + kd) * KTAPS + c] : (__bf16)0.f;
+  const float v = (c < KTAPS) ? w[(co * KD + kd) * KTAPS + c] : 0.f;
+  wp[(kd * CO + co) * NC + swz_half(co, c >> 3) * 8 + (c & 7)] = (__bf16)v;
 }
 
 // ---- forward -----------------------------------------------------------------------------------------------------------
-constexpr int F_OG = 8, F_TT = 32;
+constexpr int F_OG = 8, F_TT = 32, F_SPLIT = 2;
 constexpr int F_ROWS = 2 * (F_OG - 1) + KD;        // 55 input rows per block
-constexpr int F_ROWB = F_TT * NC * 2;              // 1024 bytes per staged row
+constexpr int F_ROWB = F_TT * NC * 2;              // 1024 bytes per staged row = ONE global_load_lds wave-instruction
+constexpr int F_BUF = F_ROWS * F_ROWB;             // 56320
 constexpr int F_WB = KD * CO * NC * 2;             // 41984 bytes of weights
-constexpr int F_LDS = F_ROWS * F_ROWB + F_WB;      // 98304
+constexpr int F_LDS = 2 * F_BUF + F_WB;            // 154624: two row windows (double buffer) + all weights
 
 struct C1Args {
   const __bf16* X16; const __bf16* wp; const float* bias; const int* lens; float* y;
   int B, F, T, D1;
 };
 
-__global__ __launch_bounds__(256) void conv1_bf16_fwd_kernel(C1Args a) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  char* rows = lds;
-  char* wl = lds + F_ROWS * F_ROWB;
+typedef __attribute__((address_space(3))) void c1_lds_void;
+typedef const __attribute__((address_space(1))) void c1_gbl_void;
+
+// block = (half of the time axis, 8 output rows, b), persistent over its time tiles: the weights are staged once, the 55-row
+// input window of tile i+2 is DMA'd (one 1 KiB global_load_lds per row) while tiles i+1 / i are multiplied / stored.
+// 8 waves, one output row each (two per SIMD, so that one wave's DMA issue, fragment reads and stores hide under the other's MFMAs).
+__global__ __launch_bounds__(512) void conv1_bf16_fwd_kernel(C1Args a) {
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  char* wl = lds + 2 * F_BUF;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
-  const int t0 = blockIdx.x * F_TT, o0 = blockIdx.y * F_OG, b = blockIdx.z;
+  const int o0 = blockIdx.y * F_OG, b = blockIdx.z;
   const int len = a.lens ? min(a.lens[b], a.T) : a.T;
+  const int ntile = (a.T + F_TT - 1) / F_TT, per = (ntile + F_SPLIT - 1) / F_SPLIT;
+  const int tile_beg = blockIdx.x * per, tile_end = min(ntile, tile_beg + per);
   const int f0 = 2 * o0 - PD;
-  if (t0 < len) {
-    // stage the 55 input rows (32 pixels x 32 B each) and the packed weights
-    for (int c = tid; c < F_ROWS * (F_ROWB / 16); c += 256) {
-      const int r = c / (F_ROWB / 16), q = c % (F_ROWB / 16);       // q: 16-byte chunk inside the row = pixel*2 + half-pixel
-      const int f = f0 + r, t = t0 + (q >> 1);
+  const int o = o0 + wave;
+
+  // DMA of one tile's window: wave w moves rows w, w + 8, ...; lane i lands at byte 16 i of the row = pixel i >> 1, slot i & 1
+  const int pix = lane >> 1;
+  const int ghalf = swz_half(pix, lane & 1);
+  auto stage = [&](int buf, int t0) {
+    for (int r = wave; r < F_ROWS; r += 8) {
+      const int f = f0 + r, t = t0 + pix;
       const bool ok = f >= 0 && f < a.F && t < a.T;
-      const void* src = ok ? (const void*)(a.X16 + (((long long)b * a.F + f) * a.T + t) * NC + (q & 1) * 8) : (const void*)g_zero_c1;
-      *reinterpret_cast<u32x4*>(rows + r * F_ROWB + q * 16) = *reinterpret_cast<const u32x4*>(src);
+      const void* src = ok ? (const void*)(a.X16 + (((long long)b * a.F + f) * a.T + t) * NC + ghalf * 8) : (const void*)g_zero_c1;
+      __builtin_amdgcn_global_load_lds((c1_gbl_void*)src, (c1_lds_void*)(lds + buf * F_BUF + r * F_ROWB), 16, 0, 0);
     }
-    for (int c = tid; c < F_WB / 16; c += 256) *reinterpret_cast<u32x4*>(wl + c * 16) = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(a.wp) + c * 16);
+  };
+  const bool any = tile_beg < tile_end && tile_beg * F_TT < len;        // block-uniform
+  if (any) {
+    for (int c = tid; c < F_WB / 16; c += 512) *reinterpret_cast<u32x4*>(wl + c * 16) = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(a.wp) + c * 16);
+    stage(0, tile_beg * F_TT);
+    if (tile_beg + 1 < tile_end && (tile_beg + 1) * F_TT < len) stage(1, (tile_beg + 1) * F_TT);
   }
-  __syncthreads();
-  const int oa = o0 + 2 * wave, ob = oa + 1;
-  const int t = t0 + l31;
-  f32x16 acc_a, acc_b;
+  __syncthreads();                                                        // vmcnt(0) + barrier: weights and the first two windows are in LDS
+  const int rd = swz_half(l31, half) * 16;                                // this lane's 16-byte slot inside its 32-byte record
+  // biases of this lane's 16 output channels, loaded ONCE before any store is in flight: a load inside the store loop would make
+  // every s_waitcnt vmcnt(0) wait for all earlier stores (one memory counter), i.e. serialise the HBM write latency 16 times a tile
+  float bv[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { acc_a[r] = 0.f; acc_b[r] = 0.f; }
-  if (t0 < len && oa < a.D1) {
-    // this wave's window: local rows 4*wave + r, r = 0..42; output row a uses kernel row r, output row b uses kernel row r - 2
-    const char* bp = rows + (4 * wave) * F_ROWB + l31 * (NC * 2) + half * 16;
-    const char* ap = wl + l31 * (NC * 2) + half * 16;
-    bf16x8 w0 = *reinterpret_cast<const bf16x8*>(ap), w1 = w0, w2 = w0;       // w0 = W[r], w1 = W[r-1], w2 = W[r-2]
+  for (int r = 0; r < 16; ++r) bv[r] = a.bias ? a.bias[(r & 3) + 8 * (r >> 2) + 4 * half] : 0.f;
+  for (int tile = tile_beg; tile < tile_end; ++tile) {
+    const int t0 = tile * F_TT, buf = (tile - tile_beg) & 1;
+    const bool live = t0 < len;                                           // block-uniform; later tiles of a short utterance are all zero
+    // two independent accumulator chains (even / odd kernel rows): back-to-back MFMAs never wait on their own result
+    f32x16 acc0, acc1;
 #pragma unroll
-    for (int r = 0; r < KD + 2; ++r) {
-      if (r < KD) w0 = *reinterpret_cast<const bf16x8*>(ap + r * (CO * NC * 2));
-      const bf16x8 xb = *reinterpret_cast<const bf16x8*>(bp + r * F_ROWB);
-      if (r < KD) acc_a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xb, acc_a, 0, 0, 0);
-      if (r >= 2) acc_b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, xb, acc_b, 0, 0, 0);
-      w2 = w1;
-      w1 = w0;
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    if (live && o < a.D1) {
+      // output row o0 + wave reads local input rows 2*wave + kd, kd = 0..40
+      const char* bp = lds + buf * F_BUF + (2 * wave) * F_ROWB + l31 * (NC * 2) + rd;
+      const char* ap = wl + l31 * (NC * 2) + rd;
+#pragma unroll
+      for (int kd = 0; kd < KD; ++kd) {
+        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(ap + kd * (CO * NC * 2));
+        const bf16x8 xb = *reinterpret_cast<const bf16x8*>(bp + kd * F_ROWB);
+        if (kd & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xb, acc1, 0, 0, 0);
+        else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xb, acc0, 0, 0, 0);
+      }
     }
-  }
-  if (t < a.T) {
+    __syncthreads();            // everyone is done reading this window; the other window (DMA'd a whole tile ago) has landed
+    if (tile + 2 < tile_end && (tile + 2) * F_TT < len) stage(buf, (tile + 2) * F_TT);     // refill it two tiles ahead
+    // the stores of this tile drain under the next tile's MFMAs
+    const int t = t0 + l31;
+    if (t < a.T && o < a.D1) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
-      const float bv = a.bias ? a.bias[co] : 0.f;
-      if (oa < a.D1) a.y[(((long long)b * CO + co) * a.D1 + oa) * a.T + t] = (t < len) ? acc_a[r] + bv : 0.f;
-      if (ob < a.D1) a.y[(((long long)b * CO + co) * a.D1 + ob) * a.T + t] = (t < len) ? acc_b[r] + bv : 0.f;
+      for (int r = 0; r < 16; ++r) {
+        const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
+        a.y[(((long long)b * CO + co) * a.D1 + o) * a.T + t] = (t < len) ? acc0[r] + acc1[r] + bv[r] : 0.f;
+      }
     }
   }
 }
@@ -182,11 +213,17 @@ __global__ __launch_bounds__(256) void conv1_bf16_wgrad_kernel(C1WArgs a) {
       const bool ok = f >= 0 && f < a.F;
       return ok ? (const void*)(a.X16T + (((long long)b * a.F + f) * NC + c) * a.Tp + t0 + q * 8) : (const void*)g_zero_c1;
     };
+    // four scalar loads, no control flow (rows of dY are 4-byte aligned only; out-of-range steps read the zero page): a static
+    // number of loads per step lets the compiler wait for the OLDER register set with a counted vmcnt instead of vmcnt(0)
     auto dy_load = [&](int o, int k, f32x4& v) {    // chunk k (0..511): co = k >> 4, 4 steps at (k & 15) * 4
       const int co = k >> 4, tq = t0 + (k & 15) * 4;
-      const float* p = a.dy + (((long long)b * CO + co) * a.D1 + o) * a.T + tq;
-      if (tq + 4 <= a.T && (((uintptr_t)p) & 15) == 0) v = *reinterpret_cast<const f32x4*>(p);
-      else { v.x = tq < a.T ? p[0] : 0.f; v.y = tq + 1 < a.T ? p[1] : 0.f; v.z = tq + 2 < a.T ? p[2] : 0.f; v.w = tq + 3 < a.T ? p[3] : 0.f; }
+      const bool row_ok = o < a.D1;
+      const float* p = a.dy + (((long long)b * CO + co) * a.D1 + (row_ok ? o : 0)) * a.T + tq;
+      const float* z = g_zero_c1;
+      v.x = *((row_ok && tq < a.T) ? p : z);
+      v.y = *((row_ok && tq + 1 < a.T) ? p + 1 : z);
+      v.z = *((row_ok && tq + 2 < a.T) ? p + 2 : z);
+      v.w = *((row_ok && tq + 3 < a.T) ? p + 3 : z);
     };
     auto dy_store = [&](int buf, int k, const f32x4& v) {
       typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -206,43 +243,63 @@ __global__ __launch_bounds__(256) void conv1_bf16_wgrad_kernel(C1WArgs a) {
       dy_store(0, tid, v0);
       dy_store(0, tid + 256, v1);
     }
-    __syncthreads();
-    for (int o = 0; o < a.D1; ++o) {
-      // ---- next step's data into registers: rows f = 2o + 21, 2o + 22 (256 chunks, one per thread) and dY tile o + 1
-      const bool more = o + 1 < a.D1;
-      u32x4 nr = {0u, 0u, 0u, 0u};
-      f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;
-      const int nrow = tid >> 7, nk = tid & 127;
-      if (more) {
-        nr = *reinterpret_cast<const u32x4*>(row_src(2 * o + 1 + nrow + PD, nk >> 3, nk & 7));
-        dy_load(o + 1, tid, d0);
-        dy_load(o + 1, tid + 256, d1);
+    // Data of step o that is not in LDS yet = R(o): the two new rows f = 2o + 19, 2o + 20 (256 chunks, one per thread) and the
+    // dY tile of row o.  R(o + 2) is loaded into registers during step o and published at the end of step o + 1: two steps of
+    // MFMAs cover the HBM latency (one step's ~0.35 us of math does not).
+    struct Regs { u32x4 nr; f32x4 d0, d1; };
+    const int nrow = tid >> 7, nk = tid & 127;
+    auto fetch = [&](int o, Regs& r) {                   // loads R(o): exactly 9 loads, no branches (o >= D1 reads zeros)
+      r.nr = *reinterpret_cast<const u32x4*>(row_src(o < a.D1 ? 2 * o - 1 + nrow + PD : -1000, nk >> 3, nk & 7));
+      dy_load(o, tid, r.d0);
+      dy_load(o, tid + 256, r.d1);
+    };
+    auto publish = [&](int o, const Regs& r) {           // R(o) -> ring slots outside the window of step o - 1, dY buffer o & 1
+      if (o < a.D1) {
+        const int slot = (2 * o - 1 + nrow + 2 * PD) % W_NR;
+        *reinterpret_cast<u32x4*>(ring + slot * W_SLOT + (nk >> 3) * W_PITCH + (nk & 7) * 16) = r.nr;
+        dy_store(o & 1, tid, r.d0);
+        dy_store(o & 1, tid + 256, r.d1);
       }
-      // ---- MFMAs of step o: K = 64 steps, tiles j = wave, wave + 4, ...
+    };
+    auto compute = [&](int o) {                          // MFMAs of step o: K = 64 steps, tiles j = wave, wave + 4, ...
       const char* ap = dyl + (o & 1) * W_DY + l31 * W_PITCH + half * 16;
       const int cl = l31 & 15, kdl = l31 >> 4;
+      const int s0 = (2 * o + 2 * wave + kdl) % W_NR;     // ring slot of this lane's kernel row in tile i = 0; tile i adds 8 rows
+      const char* bp[W_TPW];
 #pragma unroll
       for (int i = 0; i < W_TPW; ++i) {
-        const int j = wave + 4 * i;
-        if (j < W_TILES) {                                  // wave-uniform
-          const int kd = 2 * j + kdl;                       // this lane's kernel row; input row f = 2o + kd - 20 -> slot (2o + kd) % 44
-          const char* bp = (kd < KD ? ring + ((2 * o + kd) % W_NR) * W_SLOT : zslot) + cl * W_PITCH + half * 16;
+        const int kd = 2 * (wave + 4 * i) + kdl;          // input row f = 2o + kd - 20 -> slot (2o + kd) % 44
+        int slot = s0 + 8 * i;
+        slot -= (slot >= W_NR) ? W_NR : 0;
+        slot -= (slot >= W_NR) ? W_NR : 0;
+        bp[i] = (kd < KD ? ring + slot * W_SLOT : zslot) + cl * W_PITCH + half * 16;
+      }
+      // k-step outer: the dY fragment is read once per k-step for all of the wave's tiles, and consecutive MFMAs go to different
+      // accumulators (no dependent-issue stalls)
 #pragma unroll
-          for (int ks = 0; ks < W_TT / 16; ++ks) {
-            const bf16x8 af = *reinterpret_cast<const bf16x8*>(ap + ks * 32);
-            const bf16x8 bf = *reinterpret_cast<const bf16x8*>(bp + ks * 32);
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[i], 0, 0, 0);
-          }
+      for (int ks = 0; ks < W_TT / 16; ++ks) {
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(ap + ks * 32);
+#pragma unroll
+        for (int i = 0; i < W_TPW; ++i) {                  // no branch: the 3 tile slots past the 21st read the zero slot (kd >= 41)
+          const bf16x8 bf = *reinterpret_cast<const bf16x8*>(bp[i] + ks * 32);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[i], 0, 0, 0);
         }
       }
-      // ---- publish the next step's data (slots outside the current window, the other dY buffer), then one barrier
-      if (more) {
-        const int slot = (2 * o + 1 + nrow + 2 * PD) % W_NR;
-        *reinterpret_cast<u32x4*>(ring + slot * W_SLOT + (nk >> 3) * W_PITCH + (nk & 7) * 16) = nr;
-        dy_store((o + 1) & 1, tid, d0);
-        dy_store((o + 1) & 1, tid + 256, d1);
-      }
+    };
+    Regs ra, rb;
+    fetch(1, rb);
+    __syncthreads();
+    for (int o = 0; o < a.D1; o += 2) {
+      fetch(o + 2, ra);
+      compute(o);
+      publish(o + 1, rb);
       __syncthreads();
+      if (o + 1 < a.D1) {
+        fetch(o + 3, rb);
+        compute(o + 1);
+        publish(o + 2, ra);
+        __syncthreads();
+      }
     }
   }
 #pragma unroll
@@ -261,12 +318,22 @@ __global__ __launch_bounds__(256) void conv1_bf16_wgrad_kernel(C1WArgs a) {
   }
 }
 
-__global__ void conv1_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW, int nblk) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= CO * KD * KTAPS) return;
+// dW[idx] = sum over blocks of part[k][idx]; block = 32 outputs x 8 groups of partials, combined in a fixed order
+__global__ __launch_bounds__(256) void conv1_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW, int nblk) {
+  __shared__ float red[8][32];
+  const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int idx = blockIdx.x * 32 + col;
   float s = 0.f;
-  for (int k = 0; k < nblk; ++k) s += part[(long long)k * (CO * KD * KTAPS) + idx];
-  dW[idx] = s;
+  if (idx < CO * KD * KTAPS)
+    for (int k = grp; k < nblk; k += 8) s += part[(long long)k * (CO * KD * KTAPS) + idx];
+  red[grp][col] = s;
+  __syncthreads();
+  if (grp == 0 && idx < CO * KD * KTAPS) {
+    s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) s += red[g][col];
+    dW[idx] = s;
+  }
 }
 
 inline int pad64(int T) { return (T + 63) / 64 * 64; }
@@ -312,7 +379,7 @@ extern "C" int ds2_conv1_fwd_bf16(const void* X16, const void* wp, const float* 
     DS2_HIP(hipFuncSetAttribute((const void*)conv1_bf16_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv1_bf16_fwd_kernel, dim3(ceil_div(a.T, F_TT), ceil_div(a.D1, F_OG), B), dim3(256), F_LDS, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(conv1_bf16_fwd_kernel, dim3(F_SPLIT, ceil_div(a.D1, F_OG), B), dim3(512), F_LDS, (hipStream_t)stream, a);
   DS2_LAUNCH_CHECK("conv1_bf16_fwd_kernel");
   return 0;
 }
@@ -339,7 +406,7 @@ extern "C" int ds2_conv1_wgrad_bf16(const void* X16T, const float* dy1, const in
   const int ntt = ceil_div(a.T, W_TT);
   hipLaunchKernelGGL(conv1_bf16_wgrad_kernel, dim3(ntt, B), dim3(256), W_LDS, s, a);
   DS2_LAUNCH_CHECK("conv1_bf16_wgrad_kernel");
-  hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(ceil_div(CO * KD * KTAPS, 256)), dim3(256), 0, s, (const float*)ws, dW1, ntt * B);
+  hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(ceil_div(CO * KD * KTAPS, 32)), dim3(256), 0, s, (const float*)ws, dW1, ntt * B);
   DS2_LAUNCH_CHECK("conv1_wgrad_reduce_kernel");
   return 0;
 }
