@@ -162,7 +162,12 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst_wave_base
   __builtin_amdgcn_global_load_lds((gbl_void*)gsrc, (lds_void*)lds_dst_wave_base, 16, 0, 0);
 }
 
-__global__ __launch_bounds__(512) void gemm_bf16_nt_glds_kernel(BArgs g, int ntx, int nty) {
+// WM x WN waves; each wave owns a (256/WM) x (256/WN) sub-tile.  2 x 4 (8 waves, 128 x 64 per wave) is the production shape.
+template <int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(BArgs g, int ntx, int nty) {
+  constexpr int NWV = WM * WN;
+  constexpr int NI = 8 / WM, NJ = 8 / WN;   // 32 x 32 MFMA tiles per wave along M / N
+  constexpr int NP = 32 / NWV;              // 8-row pieces per wave per operand tile
   extern __shared__ __attribute__((aligned(1024))) char ldsg[];
   const int z = blockIdx.z;
   const int zb = z / g.splitk, zs = z % g.splitk;
@@ -180,18 +185,18 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_glds_kernel(BArgs g, int ntx
   const int nkt = (kend - kbeg + BK - 1) / BK;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, half = lane >> 5;
 
   // staging: wave w moves pieces w, w+8, w+16, w+24 (8 rows each) of A and of B
   const int prow = lane >> 3;                       // row inside the piece
-  const __bf16* srcA[4];
-  const __bf16* srcB[4];
-  bool okA[4], okB[4];
-  int segk[4];                                      // k offset (elements) of the 16-byte segment this lane fetches
+  const __bf16* srcA[NP];
+  const __bf16* srcB[NP];
+  bool okA[NP], okB[NP];
+  int segk[NP];                                     // k offset (elements) of the 16-byte segment this lane fetches
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = (wave + 8 * i) * 8 + prow;        // row inside the 256-row tile
+  for (int i = 0; i < NP; ++i) {
+    const int r = (wave + NWV * i) * 8 + prow;        // row inside the 256-row tile
     segk[i] = (((lane & 7) ^ ((r >> 1) & 7)) << 3);
     okA[i] = m0 + r < g.M;
     okB[i] = n0 + r < g.N;
@@ -204,19 +209,19 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_glds_kernel(BArgs g, int ntx
     const bool kok = k0 + segk[i] + 8 <= kend;
     const void* pa = (okA[i] && kok) ? (const void*)(srcA[i] + k0) : (const void*)g_zero16;
     const void* pb = (okB[i] && kok) ? (const void*)(srcB[i] + k0) : (const void*)g_zero16;
-    glds16(pa, dA + (wave + 8 * i) * 1024);
-    glds16(pb, dB + (wave + 8 * i) * 1024);
+    glds16(pa, dA + (wave + NWV * i) * 1024);
+    glds16(pb, dB + (wave + NWV * i) * 1024);
   };
   auto stage = [&](int buf, int k0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) stage_part(buf, k0, i);
+    for (int i = 0; i < NP; ++i) stage_part(buf, k0, i);
   };
 
-  f32x16 acc[4][2];
+  f32x16 acc[NI][NJ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -225,8 +230,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_glds_kernel(BArgs g, int ntx
   int koff[4];
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) koff[kk] = (((kk * 2 + half) ^ sx) << 4);
-  const int arow = (wm * 128 + l31) * 128;
-  const int brow = G_TILE + (wn * 64 + l31) * 128;
+  const int arow = (wm * (NI * 32) + l31) * 128;
+  const int brow = G_TILE + (wn * (NJ * 32) + l31) * 128;
 
   stage(0, kbeg);
   for (int kt = 0; kt < nkt; ++kt) {
@@ -236,16 +241,19 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_glds_kernel(BArgs g, int ntx
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       // next tile's DMA is issued in four slices, each in the shadow of the previous k-step's MFMAs
-      if (more) stage_part((kt + 1) & 1, kbeg + (kt + 1) * BK, kk);
-      bf16x8 a[4], b[2];
+      if (more) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(base + arow + i * 32 * 128 + koff[kk]);
+        for (int i = (NP * kk) / 4; i < (NP * (kk + 1)) / 4; ++i) stage_part((kt + 1) & 1, kbeg + (kt + 1) * BK, i);
+      }
+      bf16x8 a[NI], b[NJ];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8*>(base + brow + j * 32 * 128 + koff[kk]);
+      for (int i = 0; i < NI; ++i) a[i] = *reinterpret_cast<const bf16x8*>(base + arow + i * 32 * 128 + koff[kk]);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const bf16x8*>(base + brow + j * 32 * 128 + koff[kk]);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
   }
 
@@ -260,15 +268,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_glds_kernel(BArgs g, int ntx
     ldc = g.ldc;
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NI; ++i) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = n0 + wn * 64 + j * 32 + l31;
+    for (int j = 0; j < NJ; ++j) {
+      const int col = n0 + wn * (NJ * 32) + j * 32 + l31;
       if (col >= g.N) continue;
       const float bv = (!partial && g.bias) ? g.bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int row = m0 + wm * (NI * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (row < g.M) {
           float v = acc[i][j][r] + bv;
           float* p = C + (long long)row * ldc + col;
@@ -454,11 +462,17 @@ extern "C" int ds2_gemm_bf16_nt(int M, int N, int K, const void* A, int lda, lon
   if (use_glds) {
     static bool attr_set = false;
     if (!attr_set) {
-      DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_nt_glds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
+      DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_nt_glds_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
+      DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_nt_glds_kernel<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
       attr_set = true;
     }
     const int ntx = ceil_div(N, 256), nty = ceil_div(M, 256);
-    hipLaunchKernelGGL(gemm_bf16_nt_glds_kernel, dim3(ntx * nty, 1, batch * splitk), dim3(512), G_LDS, s, g, ntx, nty);
+    // short reductions are dominated by the C write-out: 16 waves (64 x 64 per wave, 4 per SIMD) overlap it better (+5-10 % on the
+    // K = 1024 forward projection); long reductions run the k-loop faster with 8 waves (128 x 64 per wave: fewer LDS reads per MFMA)
+    static const char* wv = getenv("DS2_GEMM_WAVES");      // "8" | "16": tuning override
+    const bool w16 = wv ? (wv[0] == '1') : (kchunk <= 2048);
+    if (w16) hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<4, 4>), dim3(ntx * nty, 1, batch * splitk), dim3(1024), G_LDS, s, g, ntx, nty);
+    else hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<2, 4>), dim3(ntx * nty, 1, batch * splitk), dim3(512), G_LDS, s, g, ntx, nty);
     DS2_LAUNCH_CHECK("gemm_bf16_nt_glds_kernel");
   } else {
     dim3 grid(ceil_div(N, BN), ceil_div(M, BM), batch * splitk);
