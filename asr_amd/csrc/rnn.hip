@@ -58,11 +58,26 @@ struct RnnArgs {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// Timeline probe (scripts/probe_rnn_timeline.hip builds this file with -DDS2_RNN_TRACE; compiled out of the library): lane 0 of
+// every wave of workgroup (0,0,0) stamps s_memtime at phase boundaries of the forward step kernel.
+#ifdef DS2_RNN_TRACE
+__device__ unsigned long long* g_rnn_trace = nullptr;   // [step][wave][8]
+#define RNN_TRACE(step, k)                                                                                     \
+  do {                                                                                                         \
+    if (g_rnn_trace && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (threadIdx.x & 63) == 0)         \
+      g_rnn_trace[((long long)(step) * NW + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_amdgcn_s_memtime();       \
+  } while (0)
+#else
+#define RNN_TRACE(step, k) do { } while (0)
+#endif
+
 // Pin every pointer argument into SGPRs at kernel entry: the compiler otherwise sinks the s_load of pointers that are first
 // used inside a branch (lens, bhh) to that branch, which costs a second dependent scalar-load round trip (~0.3 us) before
 // the first global load of every step kernel can issue.
 __device__ __forceinline__ void hoist_kernargs(const RnnArgs& a) {
-  asm volatile("" ::"s"(a.gx), "s"(a.aux), "s"(a.hbuf), "s"(a.wp), "s"(a.bhh), "s"(a.dy), "s"(a.pk), "s"(a.dcar), "s"(a.lens), "s"(a.dgx_bf));
+  // ("memory": also a compiler barrier, so that the operand loads issued before this point stay before the epilogue loads after it)
+  asm volatile("" ::"s"(a.gx), "s"(a.aux), "s"(a.hbuf), "s"(a.wp), "s"(a.bhh), "s"(a.dy), "s"(a.pk), "s"(a.dcar), "s"(a.lens), "s"(a.dgx_bf)
+               : "memory");
 }
 
 // element (row r, column k) of a packed [tiles][chunks][64 lanes][16 bytes] operand.
@@ -91,9 +106,11 @@ __device__ __forceinline__ void dgx_store(float* gx, __bf16* gb, int off, float 
 // acc[i][j] += A-tile i (16 rows) x B-tile j (16 rows)^T over `nch` packed chunks.
 // pa + i*sa / pb + j*sb point at this lane's float4 of chunk 0; consecutive chunks are 256 floats apart.
 // Chunk c belongs to wave (c % NW); each wave keeps PF chunks of loads in flight.
-template <bool BF, int MB, int NB, int PF>
+// `after_prefetch` runs right after the first PF chunks of operand loads have been issued: the step kernels wait for their
+// memory-resident kernel arguments and issue the epilogue-operand loads there, i.e. UNDER the operand fetch instead of before it.
+template <bool BF, int MB, int NB, int PF, typename F>
 __device__ __forceinline__ void mfma_packed(f32x4 (&acc)[MB][NB], int nch, int wave, const float* __restrict__ pa, long long sa,
-                                            const float* __restrict__ pb, long long sb) {
+                                            const float* __restrict__ pb, long long sb, F&& after_prefetch) {
   f32x4 fa[PF][MB], fb[PF][NB];
   auto load = [&](f32x4(&a)[MB], f32x4(&b)[NB], int c) {
     if (c < nch) {   // wave-uniform
@@ -106,6 +123,7 @@ __device__ __forceinline__ void mfma_packed(f32x4 (&acc)[MB][NB], int nch, int w
   int c = wave;
 #pragma unroll
   for (int p = 0; p < PF; ++p) load(fa[p], fb[p], c + p * NW);
+  after_prefetch();
   for (; c < nch; c += NW * PF) {
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
@@ -143,56 +161,64 @@ __device__ __forceinline__ void mfma_packed(f32x4 (&acc)[MB][NB], int nch, int w
 // directions) of one slice index sit a multiple of nsl blocks apart, i.e. on the
 // same XCD when nsl % 8 == 0, so each XCD's L2 holds every slice once.
 // ------------------------------------------------------------------------------------------
+// The first five parameters are PRELOADED into SGPRs by the command processor (-mllvm -amdgpu-kernarg-preload-count, Makefile):
+// everything the operand fetch needs (packed-operand bases, step, H, tile count, ablation flags) is there at wave launch, so the
+// W_hh / h loads issue immediately instead of behind a ~0.5 us scalar load of the kernel-argument segment
+// (profiles/r01_probe_rnn_timeline.txt); the rest of the arguments (RnnArgs) arrives while those loads are in flight.
 template <int G, int MB, bool BF>
-__global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(RnnArgs a, int s) {
+__global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(const float* pk, const float* wp, int s, int H, int nbt16_dbg, RnnArgs a) {
   __shared__ __attribute__((aligned(16))) f32x4 red[NW][MB * G][64];
   constexpr int NTHR = NW * 64;
   constexpr int PAIRS = (MB * 256 + NTHR - 1) / NTHR;   // (b, j) pairs per thread
   const int dir = blockIdx.z;
-  const int nsl = a.nsl;
   const int slice = blockIdx.x, bt = blockIdx.y;
-  hoist_kernargs(a);
+  RNN_TRACE(s, 0);
+  const int nbt16 = nbt16_dbg & 0xffff, dbg = nbt16_dbg >> 16;
+  const int nsl = (H + 15) >> 4;
   const int j0 = slice * 16, b0 = bt * (16 * MB);
-  const int T = a.T, B = a.B, H = a.H;
   const int nch = (H + kchunk<BF>() - 1) / kchunk<BF>();
-  const int t = dir == 0 ? s : T - 1 - s;
-  const int tp = dir == 0 ? t - 1 : t + 1;
   const bool has_prev = s > 0;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform
-  float* pk_out = a.pk + ((long long)((s & 1) * 2 + dir) * a.nbt16) * nch * 256;
-  const float* pk_in = a.pk + ((long long)(((s + 1) & 1) * 2 + dir) * a.nbt16) * nch * 256;
+  float* pk_out = const_cast<float*>(pk) + ((long long)((s & 1) * 2 + dir) * nbt16) * nch * 256;
+  const float* pk_in = pk + ((long long)(((s + 1) & 1) * 2 + dir) * nbt16) * nch * 256;
 
-  // ---- epilogue operands: issue their (HBM-latency) loads first, consume after the GEMM --------
-  // Nothing here depends on a loaded value (the length mask is applied after the GEMM), so the loads below and the
-  // GEMM's operand loads all issue back to back without an intervening s_waitcnt.
+  // ---- epilogue operands: loaded under the GEMM's operand fetch (see mfma_packed), consumed after the GEMM.
+  // Nothing here depends on a loaded value (the length mask is applied after the GEMM).
   float pgx[PAIRS][G], pb[PAIRS][G], pprev[PAIRS];
   int plen[PAIRS];
   bool pact[PAIRS];
+  auto issue_epilogue_loads = [&]() {
+    hoist_kernargs(a);
+    RNN_TRACE(s, 1);
+    const int T = a.T, B = a.B;
+    const int t = dir == 0 ? s : T - 1 - s;
+    const int tp = dir == 0 ? t - 1 : t + 1;
 #pragma unroll
-  for (int i = 0; i < PAIRS; ++i) {
-    const int q = threadIdx.x + i * NTHR;
-    const int jl = q & 15, brow = (q >> 4) & 15, mb = q >> 8;
-    const int b = b0 + mb * 16 + brow, j = j0 + jl;
-    pact[i] = (mb < MB) && b < B && j < H;
-    plen[i] = 0;
-    pprev[i] = 0.f;
+    for (int i = 0; i < PAIRS; ++i) {
+      const int q = threadIdx.x + i * NTHR;
+      const int jl = q & 15, brow = (q >> 4) & 15, mb = q >> 8;
+      const int b = b0 + mb * 16 + brow, j = j0 + jl;
+      pact[i] = (mb < MB) && b < B && j < H;
+      plen[i] = 0;
+      pprev[i] = 0.f;
 #pragma unroll
-    for (int g = 0; g < G; ++g) { pgx[i][g] = 0.f; pb[i][g] = 0.f; }
-    if (pact[i]) {
-      plen[i] = a.lens[b];
-      const long long row = ((long long)t * B + b) * 2 + dir;
+      for (int g = 0; g < G; ++g) { pgx[i][g] = 0.f; pb[i][g] = 0.f; }
+      if (pact[i]) {
+        plen[i] = a.lens[b];
+        const long long row = ((long long)t * B + b) * 2 + dir;
 #pragma unroll
-      for (int g = 0; g < G; ++g) {
-        pgx[i][g] = ldnt(&a.gx[row * G * H + g * H + j]);
-        pb[i][g] = a.bhh[(dir * G + g) * H + j];
-      }
-      if (has_prev) {
-        const long long prow = ((long long)tp * B + b) * 2 + dir;
-        pprev[i] = (G == 3) ? a.hbuf[prow * H + j] : a.aux[prow * H + j];
+        for (int g = 0; g < G; ++g) {
+          pgx[i][g] = ldnt(&a.gx[row * G * H + g * H + j]);
+          pb[i][g] = a.bhh[(dir * G + g) * H + j];
+        }
+        if (has_prev) {
+          const long long prow = ((long long)tp * B + b) * 2 + dir;
+          pprev[i] = (G == 3) ? a.hbuf[prow * H + j] : a.aux[prow * H + j];
+        }
       }
     }
-  }
+  };
 
   f32x4 acc[MB][G];
 #pragma unroll
@@ -200,17 +226,24 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(RnnArgs a, int s)
 #pragma unroll
     for (int g = 0; g < G; ++g) acc[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (has_prev && !(a.dbg & 1)) {
+  {
+    // one code path (no GEMM at s == 0 / under ablation = zero chunks): the compiler must not merge the epilogue loads of two
+    // branches back in front of the operand loads
+    const int nch_eff = (has_prev && !(dbg & 1)) ? nch : 0;
     const float* pa = pk_in + ((long long)(bt * MB) * nch) * 256 + lane * 4;                      // + mb*nch*256 + c*256
-    const float* pw = a.wp + ((((long long)dir * nsl + slice) * G) * nch) * 256 + lane * 4;         // + g*nch*256 + c*256
-    mfma_packed<BF, MB, G, 4>(acc, nch, wave, pa, (long long)nch * 256, pw, (long long)nch * 256);
+    const float* pw = wp + ((((long long)dir * nsl + slice) * G) * nch) * 256 + lane * 4;           // + g*nch*256 + c*256
+    mfma_packed<BF, MB, G, 4>(acc, nch_eff, wave, pa, (long long)nch * 256, pw, (long long)nch * 256, issue_epilogue_loads);
   }
+  const int T = a.T, B = a.B;
+  const int t = dir == 0 ? s : T - 1 - s;
+  RNN_TRACE(s, 2);
 #pragma unroll
   for (int i = 0; i < MB; ++i)
 #pragma unroll
     for (int g = 0; g < G; ++g) red[wave][i * G + g][lane] = acc[i][g];
   __syncthreads();
-  if (a.dbg & 2) return;
+  RNN_TRACE(s, 3);
+  if (dbg & 2) return;
 
 #pragma unroll
   for (int i = 0; i < PAIRS; ++i) {
@@ -261,77 +294,88 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(RnnArgs a, int s)
     *ho = hnew;
     packed_store<BF>(pk_out, hpi, hnew);
   }
+  RNN_TRACE(s, 4);
+#ifdef DS2_RNN_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  RNN_TRACE(s, 5);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
 // backward step (same grid mapping).  carry[b][j] = sum_k dGh[tq][b][k] * W_hh[k][j]
 // ------------------------------------------------------------------------------------------
 template <int G, int MB, bool BF>
-__global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(RnnArgs a, int s) {
+__global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(const float* pk, const float* wp, int s, int H, int nbt16_dbg, RnnArgs a) {
   __shared__ __attribute__((aligned(16))) f32x4 red[NW][MB][64];
   constexpr int NTHR = NW * 64;
   constexpr int PAIRS = (MB * 256 + NTHR - 1) / NTHR;
   const int dir = blockIdx.z;
-  const int nsl = a.nsl;
   const int slice = blockIdx.x, bt = blockIdx.y;
-  hoist_kernargs(a);
+  const int nbt16 = nbt16_dbg & 0xffff, dbg = nbt16_dbg >> 16;      // preloaded arguments: see rnn_fwd_step_kernel
+  const int nsl = (H + 15) >> 4;
   const int j0 = slice * 16, b0 = bt * (16 * MB);
-  const int T = a.T, B = a.B, H = a.H;
   const int nchb = (G * H + kchunk<BF>() - 1) / kchunk<BF>();
-  const int t = dir == 0 ? T - 1 - s : s;          // reverse of the forward order
-  const int tpf = dir == 0 ? t - 1 : t + 1;        // previous step in FORWARD order (h_{prev}, c_{prev})
   const bool has_q = s > 0;                        // a step was processed before us: its d-gates feed our carry
-  const bool has_pf = dir == 0 ? (t > 0) : (t < T - 1);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const float* dcar_in = a.dcar + ((long long)(((s + 1) & 1) * 2 + dir)) * B * H;
-  float* dcar_out = a.dcar + ((long long)((s & 1) * 2 + dir)) * B * H;
-  float* pk_out = a.pk + ((long long)((s & 1) * 2 + dir) * a.nbt16) * nchb * 256;
-  const float* pk_in = a.pk + ((long long)(((s + 1) & 1) * 2 + dir) * a.nbt16) * nchb * 256;
+  float* pk_out = const_cast<float*>(pk) + ((long long)((s & 1) * 2 + dir) * nbt16) * nchb * 256;
+  const float* pk_in = pk + ((long long)(((s + 1) & 1) * 2 + dir) * nbt16) * nchb * 256;
 
-  // ---- epilogue operands first ----------------------------------------------------------------
+  // ---- epilogue operands: loaded under the GEMM's operand fetch (see mfma_packed) ------------------------------------------
   // (no load below depends on a loaded value: the length mask is applied after the GEMM)
   float pg[PAIRS][G], pax[PAIRS], pprev[PAIRS], pdy[PAIRS], pdc[PAIRS];
   int plen[PAIRS];
   bool pact[PAIRS];
+  auto issue_epilogue_loads = [&]() {
+    hoist_kernargs(a);
+    const int T = a.T, B = a.B;
+    const int t = dir == 0 ? T - 1 - s : s;          // reverse of the forward order
+    const int tpf = dir == 0 ? t - 1 : t + 1;        // previous step in FORWARD order (h_{prev}, c_{prev})
+    const bool has_pf = dir == 0 ? (t > 0) : (t < T - 1);
+    const float* dcar_in = a.dcar + ((long long)(((s + 1) & 1) * 2 + dir)) * B * H;
 #pragma unroll
-  for (int i = 0; i < PAIRS; ++i) {
-    const int q = threadIdx.x + i * NTHR;
-    const int jl = q & 15, brow = (q >> 4) & 15, mb = q >> 8;
-    const int b = b0 + mb * 16 + brow, j = j0 + jl;
-    pact[i] = (mb < MB) && b < B && j < H;
-    plen[i] = 0;
-    pax[i] = pprev[i] = pdy[i] = pdc[i] = 0.f;
+    for (int i = 0; i < PAIRS; ++i) {
+      const int q = threadIdx.x + i * NTHR;
+      const int jl = q & 15, brow = (q >> 4) & 15, mb = q >> 8;
+      const int b = b0 + mb * 16 + brow, j = j0 + jl;
+      pact[i] = (mb < MB) && b < B && j < H;
+      plen[i] = 0;
+      pax[i] = pprev[i] = pdy[i] = pdc[i] = 0.f;
 #pragma unroll
-    for (int g = 0; g < G; ++g) pg[i][g] = 0.f;
-    if (pact[i]) {
-      plen[i] = a.lens[b];
-      const long long row = ((long long)t * B + b) * 2 + dir;
+      for (int g = 0; g < G; ++g) pg[i][g] = 0.f;
+      if (pact[i]) {
+        plen[i] = a.lens[b];
+        const long long row = ((long long)t * B + b) * 2 + dir;
 #pragma unroll
-      for (int g = 0; g < G; ++g) pg[i][g] = ldnt(&a.gx[row * G * H + g * H + j]);
-      pax[i] = ldnt(&a.aux[row * H + j]);
-      pdy[i] = ldnt(&a.dy[((long long)t * B + b) * a.lddy + j]);
-      if (has_q) pdc[i] = dcar_in[(long long)b * H + j];
-      if (has_pf) {
-        const long long prow = ((long long)tpf * B + b) * 2 + dir;
-        pprev[i] = (G == 3) ? a.hbuf[prow * H + j] : a.aux[prow * H + j];
+        for (int g = 0; g < G; ++g) pg[i][g] = ldnt(&a.gx[row * G * H + g * H + j]);
+        pax[i] = ldnt(&a.aux[row * H + j]);
+        pdy[i] = ldnt(&a.dy[((long long)t * B + b) * a.lddy + j]);
+        if (has_q) pdc[i] = dcar_in[(long long)b * H + j];
+        if (has_pf) {
+          const long long prow = ((long long)tpf * B + b) * 2 + dir;
+          pprev[i] = (G == 3) ? a.hbuf[prow * H + j] : a.aux[prow * H + j];
+        }
       }
     }
-  }
+  };
 
   f32x4 acc[MB][1];
 #pragma unroll
   for (int i = 0; i < MB; ++i) acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (has_q && !(a.dbg & 1)) {
+  {
+    const int nch_eff = (has_q && !(dbg & 1)) ? nchb : 0;            // one code path, see the forward kernel
     const float* pa = pk_in + ((long long)(bt * MB) * nchb) * 256 + lane * 4;
-    const float* pw = a.wp + (((long long)dir * nsl + slice) * nchb) * 256 + lane * 4;
-    mfma_packed<BF, MB, 1, 6>(acc, nchb, wave, pa, (long long)nchb * 256, pw, 0);
+    const float* pw = wp + (((long long)dir * nsl + slice) * nchb) * 256 + lane * 4;
+    mfma_packed<BF, MB, 1, 6>(acc, nch_eff, wave, pa, (long long)nchb * 256, pw, 0, issue_epilogue_loads);
   }
+  const int T = a.T, B = a.B;
+  const int t = dir == 0 ? T - 1 - s : s;
+  float* dcar_out = a.dcar + ((long long)((s & 1) * 2 + dir)) * B * H;
 #pragma unroll
   for (int i = 0; i < MB; ++i) red[wave][i][lane] = acc[i][0];
   __syncthreads();
-  if (a.dbg & 2) return;
+  if (dbg & 2) return;
 
 #pragma unroll
   for (int i = 0; i < PAIRS; ++i) {
@@ -435,13 +479,17 @@ int launch_steps(bool bwd, RnnArgs a, hipStream_t st) {
   a.nsl = ceil_div(a.H, 16);
   a.nbt16 = nbt * mb;
   dim3 grid(a.nsl, nbt, 2), block(NW * 64);
+  if (a.nbt16 > 0xffff) return ds2_set_error("rnn: batch too large (%d 16-row tiles)", a.nbt16);
+  const int packed = a.nbt16 | (a.dbg << 16);                       // one preloaded dword: tile count + ablation flags
+  const float* pk = a.pk;
+  const float* wp = a.wp;
   for (int s = 0; s < a.T; ++s) {
     if (!bwd) {
-      if (mb == 2) hipLaunchKernelGGL((rnn_fwd_step_kernel<G, 2, BF>), grid, block, 0, st, a, s);
-      else hipLaunchKernelGGL((rnn_fwd_step_kernel<G, 1, BF>), grid, block, 0, st, a, s);
+      if (mb == 2) hipLaunchKernelGGL((rnn_fwd_step_kernel<G, 2, BF>), grid, block, 0, st, pk, wp, s, a.H, packed, a);
+      else hipLaunchKernelGGL((rnn_fwd_step_kernel<G, 1, BF>), grid, block, 0, st, pk, wp, s, a.H, packed, a);
     } else {
-      if (mb == 2) hipLaunchKernelGGL((rnn_bwd_step_kernel<G, 2, BF>), grid, block, 0, st, a, s);
-      else hipLaunchKernelGGL((rnn_bwd_step_kernel<G, 1, BF>), grid, block, 0, st, a, s);
+      if (mb == 2) hipLaunchKernelGGL((rnn_bwd_step_kernel<G, 2, BF>), grid, block, 0, st, pk, wp, s, a.H, packed, a);
+      else hipLaunchKernelGGL((rnn_bwd_step_kernel<G, 1, BF>), grid, block, 0, st, pk, wp, s, a.H, packed, a);
     }
   }
   hipError_t e = hipGetLastError();
