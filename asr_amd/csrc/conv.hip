@@ -138,11 +138,14 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
     }
   }
+  float bias_r[16];                               // all bias loads before the first store (one in-order memory counter)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bias_r[r] = a.bias ? a.bias[(r & 3) + 8 * (r >> 2) + 4 * half] : 0.f;
   if (t < a.Tout) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
-      float v = acc[r] + (a.bias ? a.bias[co] : 0.f);
+      float v = acc[r] + bias_r[r];
       if (t >= len) v = 0.f;
       a.out[(((long long)b * CO + co) * a.Dtot + orow) * a.Tout + t] = v;
     }

@@ -116,11 +116,16 @@ __global__ __launch_bounds__(256) void conv2_bf16_kernel(CArgs a) {
       }
     }
   }
+  // biases first, all 16 before any store: a load inside the store loop would put an s_waitcnt vmcnt(0) — which also waits for
+  // every earlier store — in front of each store (one in-order memory counter), i.e. 16 serialised HBM write round trips
+  float bv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bv[r] = a.bias ? a.bias[(r & 3) + 8 * (r >> 2) + 4 * half] : 0.f;
   if (t < a.T) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
-      float v = acc[r] + (a.bias ? a.bias[co] : 0.f);
+      float v = acc[r] + bv[r];
       if (t >= len) v = 0.f;
       a.out[(((long long)b * CH + co) * a.Dtot + orow) * a.T + t] = v;
     }

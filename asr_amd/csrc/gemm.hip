@@ -186,13 +186,20 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g, int vecA, int
     C = g.C + (long long)zb * g.sC;
     ldc = g.ldc;
   }
+  // bias loads before the first store: a load between stores waits for all earlier stores (one in-order vmcnt)
+  float bvj[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+    bvj[j] = (!partial && g.bias && col < g.N) ? g.bias[col] : 0.f;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = n0 + wn * 64 + j * 32 + (lane & 31);
       if (col >= g.N) continue;
-      const float bv = (!partial && g.bias) ? g.bias[col] : 0.f;
+      const float bv = bvj[j];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;

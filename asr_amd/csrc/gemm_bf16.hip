@@ -124,13 +124,19 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(BArgs g) {
     C = g.C + (long long)zb * g.sC;
     ldc = g.ldc;
   }
+  float bvj[2];                                   // bias loads before the first store (see the 256-tile kernel)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wn * 64 + j * 32 + l31;
+    bvj[j] = (!partial && g.bias && col < g.N) ? g.bias[col] : 0.f;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = n0 + wn * 64 + j * 32 + l31;
       if (col >= g.N) continue;
-      const float bv = (!partial && g.bias) ? g.bias[col] : 0.f;
+      const float bv = bvj[j];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -267,13 +273,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(BArgs g
     C = g.C + (long long)zb * g.sC;
     ldc = g.ldc;
   }
+  // bias values of this lane's NJ columns, loaded BEFORE the first store: a load between stores would wait (vmcnt is one in-order
+  // counter) for every store issued so far — a serialised HBM write round trip per (i, j) tile of the epilogue
+  float bvj[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int col = n0 + wn * (NJ * 32) + j * 32 + l31;
+    bvj[j] = (!partial && g.bias && col < g.N) ? g.bias[col] : 0.f;
+  }
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int col = n0 + wn * (NJ * 32) + j * 32 + l31;
       if (col >= g.N) continue;
-      const float bv = (!partial && g.bias) ? g.bias[col] : 0.f;
+      const float bv = bvj[j];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * (NI * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
