@@ -161,39 +161,42 @@ __device__ __forceinline__ void mfma_packed(f32x4 (&acc)[MB][NB], int nch, int w
 // directions) of one slice index sit a multiple of nsl blocks apart, i.e. on the
 // same XCD when nsl % 8 == 0, so each XCD's L2 holds every slice once.
 // ------------------------------------------------------------------------------------------
-// The first five parameters are PRELOADED into SGPRs by the command processor (-mllvm -amdgpu-kernarg-preload-count, Makefile):
-// everything the operand fetch needs (packed-operand bases, step, H, tile count, ablation flags) is there at wave launch, so the
-// W_hh / h loads issue immediately instead of behind a ~0.5 us scalar load of the kernel-argument segment
-// (profiles/r01_probe_rnn_timeline.txt); the rest of the arguments (RnnArgs) arrives while those loads are in flight.
+// The leading parameters (13 dwords) are PRELOADED into SGPRs by the command processor (-mllvm -amdgpu-kernarg-preload-count,
+// Makefile): the operand fetch AND the HBM-latency epilogue loads (gate pre-activations, previous state, bias) need nothing from
+// memory to compute their addresses, so they all issue at wave launch instead of behind a scalar load of the kernel-argument
+// segment that measured 0.6-2 us (profiles/r01_probe_rnn_timeline.txt).  The remaining arguments (RnnArgs) arrive under them.
+//   prev = h buffer (GRU) / cell-state buffer (LSTM);  s_H = s | H << 16;  T_B = T | B << 16;  nbt16_dbg = tiles | flags << 16
 template <int G, int MB, bool BF>
-__global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(const float* pk, const float* wp, int s, int H, int nbt16_dbg, RnnArgs a) {
+__global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(const float* pk, const float* wp, float* gxbase, const float* prev,
+                                                               const float* bhh, int s_H, int T_B, int nbt16_dbg, RnnArgs a) {
   __shared__ __attribute__((aligned(16))) f32x4 red[NW][MB * G][64];
   constexpr int NTHR = NW * 64;
   constexpr int PAIRS = (MB * 256 + NTHR - 1) / NTHR;   // (b, j) pairs per thread
   const int dir = blockIdx.z;
   const int slice = blockIdx.x, bt = blockIdx.y;
+  const int s = s_H & 0xffff, H = (int)((unsigned)s_H >> 16);
+  const int T = T_B & 0xffff, B = (int)((unsigned)T_B >> 16);
   RNN_TRACE(s, 0);
   const int nbt16 = nbt16_dbg & 0xffff, dbg = nbt16_dbg >> 16;
   const int nsl = (H + 15) >> 4;
   const int j0 = slice * 16, b0 = bt * (16 * MB);
   const int nch = (H + kchunk<BF>() - 1) / kchunk<BF>();
   const bool has_prev = s > 0;
+  const int t = dir == 0 ? s : T - 1 - s;
+  const int tp = dir == 0 ? t - 1 : t + 1;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform
   float* pk_out = const_cast<float*>(pk) + ((long long)((s & 1) * 2 + dir) * nbt16) * nch * 256;
   const float* pk_in = pk + ((long long)(((s + 1) & 1) * 2 + dir) * nbt16) * nch * 256;
 
-  // ---- epilogue operands: loaded under the GEMM's operand fetch (see mfma_packed), consumed after the GEMM.
+  // ---- epilogue operands and store addresses: computed / loaded under the GEMM's operand fetch (see mfma_packed), used after it.
   // Nothing here depends on a loaded value (the length mask is applied after the GEMM).
   float pgx[PAIRS][G], pb[PAIRS][G], pprev[PAIRS];
   int plen[PAIRS];
   bool pact[PAIRS];
+  float* gxp[PAIRS];             // this pair's gate row in gx
+  long long rowH[PAIRS], hpi[PAIRS];
   auto issue_epilogue_loads = [&]() {
-    hoist_kernargs(a);
-    RNN_TRACE(s, 1);
-    const int T = a.T, B = a.B;
-    const int t = dir == 0 ? s : T - 1 - s;
-    const int tp = dir == 0 ? t - 1 : t + 1;
 #pragma unroll
     for (int i = 0; i < PAIRS; ++i) {
       const int q = threadIdx.x + i * NTHR;
@@ -202,21 +205,29 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(const float* pk, 
       pact[i] = (mb < MB) && b < B && j < H;
       plen[i] = 0;
       pprev[i] = 0.f;
+      const long long row = ((long long)t * B + b) * 2 + dir;
+      gxp[i] = gxbase + row * G * H + j;
+      rowH[i] = row * H + j;
+      hpi[i] = packed_index<BF>(b, j, nch);
 #pragma unroll
       for (int g = 0; g < G; ++g) { pgx[i][g] = 0.f; pb[i][g] = 0.f; }
       if (pact[i]) {
-        plen[i] = a.lens[b];
-        const long long row = ((long long)t * B + b) * 2 + dir;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-          pgx[i][g] = ldnt(&a.gx[row * G * H + g * H + j]);
-          pb[i][g] = a.bhh[(dir * G + g) * H + j];
+          pgx[i][g] = ldnt(gxp[i] + g * H);
+          pb[i][g] = bhh[(dir * G + g) * H + j];
         }
-        if (has_prev) {
-          const long long prow = ((long long)tp * B + b) * 2 + dir;
-          pprev[i] = (G == 3) ? a.hbuf[prow * H + j] : a.aux[prow * H + j];
-        }
+        if (has_prev) pprev[i] = prev[(((long long)tp * B + b) * 2 + dir) * H + j];
       }
+    }
+    // the memory-resident arguments are needed from here on (lengths now, output pointers after the barrier)
+    hoist_kernargs(a);
+    RNN_TRACE(s, 1);
+#pragma unroll
+    for (int i = 0; i < PAIRS; ++i) {
+      const int q = threadIdx.x + i * NTHR;
+      const int b = b0 + (q >> 8) * 16 + ((q >> 4) & 15);
+      if (pact[i]) plen[i] = a.lens[b];
     }
   };
 
@@ -234,8 +245,6 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(const float* pk, 
     const float* pw = wp + ((((long long)dir * nsl + slice) * G) * nch) * 256 + lane * 4;           // + g*nch*256 + c*256
     mfma_packed<BF, MB, G, 4>(acc, nch_eff, wave, pa, (long long)nch * 256, pw, (long long)nch * 256, issue_epilogue_loads);
   }
-  const int T = a.T, B = a.B;
-  const int t = dir == 0 ? s : T - 1 - s;
   RNN_TRACE(s, 2);
 #pragma unroll
   for (int i = 0; i < MB; ++i)
@@ -251,18 +260,15 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(const float* pk, 
     const int q = threadIdx.x + i * NTHR;
     const int jl = q & 15, brow = (q >> 4) & 15, mb = q >> 8;
     const int src_lane = (brow >> 2) * 16 + jl, reg = brow & 3;
-    const int b = b0 + mb * 16 + brow, j = j0 + jl;
-    const long long row = ((long long)t * B + b) * 2 + dir;
-    float* gx = a.gx + row * G * H + j;
-    float* ho = a.hbuf + row * H + j;
-    float* ax = a.aux + row * H + j;
-    const long long hpi = packed_index<BF>(b, j, nch);
+    float* gx = gxp[i];
+    float* ho = a.hbuf + rowH[i];
+    float* ax = a.aux + rowH[i];
     if (!(t < plen[i])) {
 #pragma unroll
       for (int g = 0; g < G; ++g) stnt(&gx[g * H], 0.f);
       stnt(ho, 0.f);
       stnt(ax, 0.f);
-      packed_store<BF>(pk_out, hpi, 0.f);
+      packed_store<BF>(pk_out, hpi[i], 0.f);
       continue;
     }
     float gh[G];
@@ -273,6 +279,12 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(const float* pk, 
       for (int w = 0; w < NW; ++w) sum += red[w][mb * G + g][src_lane][reg];
       gh[g] = sum + pb[i][g];
     }
+#ifdef DS2_RNN_TRACE
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    RNN_TRACE(s, 6);                                   // partial sums read back from LDS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RNN_TRACE(s, 7);                                   // epilogue operands (gate pre-activations, bias, h_prev) have landed
+#endif
     float hnew;
     if constexpr (G == 3) {
       const float r = sigmoidf_(pgx[i][0] + gh[0]);
@@ -292,7 +304,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(const float* pk, 
       hnew = og * tanhf_(c);
     }
     *ho = hnew;
-    packed_store<BF>(pk_out, hpi, hnew);
+    packed_store<BF>(pk_out, hpi[i], hnew);
   }
   RNN_TRACE(s, 4);
 #ifdef DS2_RNN_TRACE
@@ -304,35 +316,39 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(const float* pk, 
 // ------------------------------------------------------------------------------------------
 // backward step (same grid mapping).  carry[b][j] = sum_k dGh[tq][b][k] * W_hh[k][j]
 // ------------------------------------------------------------------------------------------
+// Preloaded arguments as in the forward kernel: operand bases + the three HBM-streamed epilogue inputs (saved gates, aux, dy).
+//   s_H = s | H << 16;  T_B = T | B << 16;  nbt16_dbg = tiles | flags << 16
 template <int G, int MB, bool BF>
-__global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(const float* pk, const float* wp, int s, int H, int nbt16_dbg, RnnArgs a) {
+__global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(const float* pk, const float* wp, float* gxbase, float* auxbase, const float* dy,
+                                                               int s_H, int T_B, int nbt16_dbg, int lddy, RnnArgs a) {
   __shared__ __attribute__((aligned(16))) f32x4 red[NW][MB][64];
   constexpr int NTHR = NW * 64;
   constexpr int PAIRS = (MB * 256 + NTHR - 1) / NTHR;
   const int dir = blockIdx.z;
   const int slice = blockIdx.x, bt = blockIdx.y;
-  const int nbt16 = nbt16_dbg & 0xffff, dbg = nbt16_dbg >> 16;      // preloaded arguments: see rnn_fwd_step_kernel
+  const int s = s_H & 0xffff, H = (int)((unsigned)s_H >> 16);
+  const int T = T_B & 0xffff, B = (int)((unsigned)T_B >> 16);
+  const int nbt16 = nbt16_dbg & 0xffff, dbg = nbt16_dbg >> 16;
   const int nsl = (H + 15) >> 4;
   const int j0 = slice * 16, b0 = bt * (16 * MB);
   const int nchb = (G * H + kchunk<BF>() - 1) / kchunk<BF>();
   const bool has_q = s > 0;                        // a step was processed before us: its d-gates feed our carry
+  const int t = dir == 0 ? T - 1 - s : s;          // reverse of the forward order
+  const int tpf = dir == 0 ? t - 1 : t + 1;        // previous step in FORWARD order (h_{prev}, c_{prev})
+  const bool has_pf = dir == 0 ? (t > 0) : (t < T - 1);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float* pk_out = const_cast<float*>(pk) + ((long long)((s & 1) * 2 + dir) * nbt16) * nchb * 256;
   const float* pk_in = pk + ((long long)(((s + 1) & 1) * 2 + dir) * nbt16) * nchb * 256;
 
-  // ---- epilogue operands: loaded under the GEMM's operand fetch (see mfma_packed) ------------------------------------------
+  // ---- epilogue operands and store addresses: computed / loaded under the GEMM's operand fetch (see mfma_packed) ------------
   // (no load below depends on a loaded value: the length mask is applied after the GEMM)
   float pg[PAIRS][G], pax[PAIRS], pprev[PAIRS], pdy[PAIRS], pdc[PAIRS];
   int plen[PAIRS];
   bool pact[PAIRS];
+  float* gxp[PAIRS];
+  long long rowH[PAIRS], bH[PAIRS];
   auto issue_epilogue_loads = [&]() {
-    hoist_kernargs(a);
-    const int T = a.T, B = a.B;
-    const int t = dir == 0 ? T - 1 - s : s;          // reverse of the forward order
-    const int tpf = dir == 0 ? t - 1 : t + 1;        // previous step in FORWARD order (h_{prev}, c_{prev})
-    const bool has_pf = dir == 0 ? (t > 0) : (t < T - 1);
-    const float* dcar_in = a.dcar + ((long long)(((s + 1) & 1) * 2 + dir)) * B * H;
 #pragma unroll
     for (int i = 0; i < PAIRS; ++i) {
       const int q = threadIdx.x + i * NTHR;
@@ -341,19 +357,32 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(const float* pk, 
       pact[i] = (mb < MB) && b < B && j < H;
       plen[i] = 0;
       pax[i] = pprev[i] = pdy[i] = pdc[i] = 0.f;
+      const long long row = ((long long)t * B + b) * 2 + dir;
+      gxp[i] = gxbase + row * G * H + j;
+      rowH[i] = row * H + j;
+      bH[i] = (long long)b * H + j;
 #pragma unroll
       for (int g = 0; g < G; ++g) pg[i][g] = 0.f;
       if (pact[i]) {
-        plen[i] = a.lens[b];
-        const long long row = ((long long)t * B + b) * 2 + dir;
 #pragma unroll
-        for (int g = 0; g < G; ++g) pg[i][g] = ldnt(&a.gx[row * G * H + g * H + j]);
-        pax[i] = ldnt(&a.aux[row * H + j]);
-        pdy[i] = ldnt(&a.dy[((long long)t * B + b) * a.lddy + j]);
-        if (has_q) pdc[i] = dcar_in[(long long)b * H + j];
+        for (int g = 0; g < G; ++g) pg[i][g] = ldnt(gxp[i] + g * H);
+        pax[i] = ldnt(auxbase + rowH[i]);
+        pdy[i] = ldnt(&dy[((long long)t * B + b) * lddy + j]);
+      }
+    }
+    // the memory-resident arguments from here on: lengths, the carry of the previous step, h_{prev} / c_{prev}
+    hoist_kernargs(a);
+    const float* dcar_in = a.dcar + ((long long)(((s + 1) & 1) * 2 + dir)) * B * H;
+#pragma unroll
+    for (int i = 0; i < PAIRS; ++i) {
+      if (pact[i]) {
+        const int q = threadIdx.x + i * NTHR;
+        const int b = b0 + (q >> 8) * 16 + ((q >> 4) & 15);
+        plen[i] = a.lens[b];
+        if (has_q) pdc[i] = dcar_in[bH[i]];
         if (has_pf) {
           const long long prow = ((long long)tpf * B + b) * 2 + dir;
-          pprev[i] = (G == 3) ? a.hbuf[prow * H + j] : a.aux[prow * H + j];
+          pprev[i] = (G == 3) ? a.hbuf[prow * H + (j0 + (q & 15))] : auxbase[prow * H + (j0 + (q & 15))];
         }
       }
     }
@@ -369,8 +398,6 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(const float* pk, 
     const float* pw = wp + (((long long)dir * nsl + slice) * nchb) * 256 + lane * 4;
     mfma_packed<BF, MB, 1, 6>(acc, nch_eff, wave, pa, (long long)nchb * 256, pw, 0, issue_epilogue_loads);
   }
-  const int T = a.T, B = a.B;
-  const int t = dir == 0 ? T - 1 - s : s;
   float* dcar_out = a.dcar + ((long long)((s & 1) * 2 + dir)) * B * H;
 #pragma unroll
   for (int i = 0; i < MB; ++i) red[wave][i][lane] = acc[i][0];
@@ -384,12 +411,11 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(const float* pk, 
     const int jl = q & 15, brow = (q >> 4) & 15, mb = q >> 8;
     const int src_lane = (brow >> 2) * 16 + jl, reg = brow & 3;
     const int b = b0 + mb * 16 + brow, j = j0 + jl;
-    const long long row = ((long long)t * B + b) * 2 + dir;
-    float* gx = a.gx + row * G * H + j;
-    float* ax = a.aux + row * H + j;
-    float* dco = dcar_out + (long long)b * H + j;
+    float* gx = gxp[i];
+    float* ax = auxbase + rowH[i];
+    float* dco = dcar_out + bH[i];
     float dgh[G];
-    __bf16* gb = a.dgx_bf ? a.dgx_bf + row * G * H + j : nullptr;            // wave-uniform choice of the dGx destination
+    __bf16* gb = a.dgx_bf ? a.dgx_bf + (gxp[i] - gxbase) : nullptr;          // wave-uniform choice of the dGx destination
     if (!(t < plen[i])) {
 #pragma unroll
       for (int g = 0; g < G; ++g) { dgx_store(gx, gb, g * H, 0.f); dgh[g] = 0.f; }
@@ -479,17 +505,21 @@ int launch_steps(bool bwd, RnnArgs a, hipStream_t st) {
   a.nsl = ceil_div(a.H, 16);
   a.nbt16 = nbt * mb;
   dim3 grid(a.nsl, nbt, 2), block(NW * 64);
-  if (a.nbt16 > 0xffff) return ds2_set_error("rnn: batch too large (%d 16-row tiles)", a.nbt16);
-  const int packed = a.nbt16 | (a.dbg << 16);                       // one preloaded dword: tile count + ablation flags
+  if (a.nbt16 > 0xffff || a.T > 0xffff || a.B > 0xffff || a.H > 0xffff)
+    return ds2_set_error("rnn: T, B, H and the tile count must fit 16 bits (T=%d B=%d H=%d)", a.T, a.B, a.H);
+  const int packed = a.nbt16 | (a.dbg << 16);                       // preloaded dwords: tile count + ablation flags, T | B, s | H
+  const int T_B = a.T | (a.B << 16);
   const float* pk = a.pk;
   const float* wp = a.wp;
+  const float* prev = G == 3 ? a.hbuf : a.aux;                      // previous hidden (GRU) / cell (LSTM) state
   for (int s = 0; s < a.T; ++s) {
+    const int s_H = s | (a.H << 16);
     if (!bwd) {
-      if (mb == 2) hipLaunchKernelGGL((rnn_fwd_step_kernel<G, 2, BF>), grid, block, 0, st, pk, wp, s, a.H, packed, a);
-      else hipLaunchKernelGGL((rnn_fwd_step_kernel<G, 1, BF>), grid, block, 0, st, pk, wp, s, a.H, packed, a);
+      if (mb == 2) hipLaunchKernelGGL((rnn_fwd_step_kernel<G, 2, BF>), grid, block, 0, st, pk, wp, a.gx, prev, a.bhh, s_H, T_B, packed, a);
+      else hipLaunchKernelGGL((rnn_fwd_step_kernel<G, 1, BF>), grid, block, 0, st, pk, wp, a.gx, prev, a.bhh, s_H, T_B, packed, a);
     } else {
-      if (mb == 2) hipLaunchKernelGGL((rnn_bwd_step_kernel<G, 2, BF>), grid, block, 0, st, pk, wp, s, a.H, packed, a);
-      else hipLaunchKernelGGL((rnn_bwd_step_kernel<G, 1, BF>), grid, block, 0, st, pk, wp, s, a.H, packed, a);
+      if (mb == 2) hipLaunchKernelGGL((rnn_bwd_step_kernel<G, 2, BF>), grid, block, 0, st, pk, wp, a.gx, a.aux, a.dy, s_H, T_B, packed, a.lddy, a);
+      else hipLaunchKernelGGL((rnn_bwd_step_kernel<G, 1, BF>), grid, block, 0, st, pk, wp, a.gx, a.aux, a.dy, s_H, T_B, packed, a.lddy, a);
     }
   }
   hipError_t e = hipGetLastError();

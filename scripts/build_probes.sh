@@ -3,4 +3,4 @@
 cd "$(dirname "$0")"
 mkdir -p build
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 probe_step_exchange.hip -o build/probe_step_exchange
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../include -I../asr_amd/csrc -DDS2_RNN_TRACE -mllvm -amdgpu-kernarg-preload-count=5 -x hip probe_rnn_timeline.hip ../asr_amd/csrc/api.cpp -o build/probe_rnn_timeline
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../include -I../asr_amd/csrc -DDS2_RNN_TRACE -mllvm -amdgpu-kernarg-preload-count=9 -x hip probe_rnn_timeline.hip ../asr_amd/csrc/api.cpp -o build/probe_rnn_timeline

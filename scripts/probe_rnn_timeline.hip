@@ -48,32 +48,36 @@ int main() {
   float ms;
   CK(hipEventElapsedTime(&ms, e0, e1));
   const double us_per_step = ms * 1e3 / T;
-  double span[6] = {0, 0, 0, 0, 0, 0}, period = 0;
+  double span[8] = {0, 0, 0, 0, 0, 0, 0, 0}, period = 0;
   int n = 0;
   for (int s = 50; s < T - 1; ++s) {
-    unsigned long long mn[6], mx[6];
-    for (int k = 0; k < 6; ++k) { mn[k] = ~0ull; mx[k] = 0; }
+    unsigned long long mn[8], mx[8];
+    for (int k = 0; k < 8; ++k) { mn[k] = ~0ull; mx[k] = 0; }
     for (int w = 0; w < NW; ++w)
-      for (int k = 0; k < 6; ++k) {
+      for (int k = 0; k < 8; ++k) {
         const unsigned long long v = tr[((size_t)s * NW + w) * 8 + k];
         if (v < mn[k]) mn[k] = v;
         if (v > mx[k]) mx[k] = v;
       }
     unsigned long long next0 = ~0ull;
     for (int w = 0; w < NW; ++w) { const unsigned long long v = tr[((size_t)(s + 1) * NW + w) * 8 + 0]; if (v < next0) next0 = v; }
-    span[0] += (double)(mx[1] - mn[0]);   // entry -> args
-    span[1] += (double)(mx[2] - mx[1]);   // args -> MFMAs done
+    span[0] += (double)(mx[1] - mn[0]);   // entry -> operand loads issued, args in SGPRs
+    span[1] += (double)(mx[2] - mx[1]);   // -> MFMAs done
     span[2] += (double)(mx[3] - mx[2]);   // -> barrier passed
-    span[3] += (double)(mx[4] - mx[3]);   // -> stores issued
-    span[4] += (double)(mx[5] - mx[4]);   // -> stores acknowledged
-    span[5] += (double)(next0 - mx[5]);   // -> next launch's first wave enters
+    span[3] += (double)(mx[6] - mx[3]);   // -> partial sums read back
+    span[4] += (double)(mx[7] - mx[6]);   // -> epilogue operands landed
+    span[5] += (double)(mx[4] - mx[7]);   // -> gate math done, stores issued
+    span[6] += (double)(mx[5] - mx[4]);   // -> stores acknowledged
+    span[7] += (double)(next0 - mx[5]);   // -> next launch's first wave enters
     period += (double)(next0 - mn[0]);
     ++n;
   }
   const double tick_us = us_per_step / (period / n);
   printf("period per step: %.2f us (HIP events, traced build) = %.1f ticks -> 1 tick = %.4f us\n", us_per_step, period / n, tick_us);
-  const char* names[6] = {"entry -> kernel args in SGPRs", "args -> MFMAs done (operand loads + MFMA)", "-> partial sums in LDS, barrier passed",
-                          "-> gate math done, stores issued", "-> stores acknowledged (vmcnt 0)", "-> next launch's first wave enters (boundary)"};
-  for (int k = 0; k < 6; ++k) printf("  %-52s %6.2f us\n", names[k], span[k] / n * tick_us);
+  const char* names[8] = {"entry -> operand loads issued + kernel args in SGPRs", "-> MFMAs done (operand loads consumed)",
+                          "-> partial sums in LDS, barrier passed", "-> partial sums read back from LDS",
+                          "-> epilogue operands landed (vmcnt 0)", "-> gate math done, stores issued",
+                          "-> stores acknowledged (vmcnt 0)", "-> next launch's first wave enters (boundary)"};
+  for (int k = 0; k < 8; ++k) printf("  %-56s %6.2f us\n", names[k], span[k] / n * tick_us);
   return 0;
 }
