@@ -234,12 +234,12 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
                 hT = ops.cast_transpose_bf16(lc.hbuf)                                             # (2H, M)
                 auxT = ops.cast_transpose_bf16(lc.aux) if G == 3 else None
                 rows = 2 * H if G == 3 else 4 * H
-                for d in range(2):
-                    ka = slice(B, M) if d == 0 else slice(0, M - B)      # rows t of dGh
-                    kb = slice(0, M - B) if d == 0 else slice(B, M)      # rows t-1 (fwd) / t+1 (reverse) of h
-                    ops.gemm_bf16_nt(dgxT[d * G * H:d * G * H + rows, ka], hT[d * H:(d + 1) * H, kb], out=dwhh[d, :rows])
-                    if G == 3:
-                        ops.gemm_bf16_nt(auxT[d * H:(d + 1) * H, ka], hT[d * H:(d + 1) * H, kb], out=dwhh[d, 2 * H:])
+                # both directions per launch: direction 0 pairs rows t of dGh with h[t-1], direction 1 rows t with h[t+1]
+                ka = (slice(B, M), slice(0, M - B))
+                kb = (slice(0, M - B), slice(B, M))
+                ops.gemm_bf16_nt_pair(dgxT[0:rows, ka[0]], dgxT[G * H:G * H + rows, ka[1]], hT[0:H, kb[0]], hT[H:2 * H, kb[1]], dwhh[:, :rows])
+                if G == 3:
+                    ops.gemm_bf16_nt_pair(auxT[0:H, ka[0]], auxT[H:2 * H, ka[1]], hT[0:H, kb[0]], hT[H:2 * H, kb[1]], dwhh[:, 2 * H:])
                 keep.append((dgxT, hT, auxT))
             elif T > 1:
                 K = (T - 1) * B

@@ -183,6 +183,29 @@ def gemm_bf16_nt(A: Tensor, B: Tensor, bias: Optional[Tensor] = None, out: Optio
     return out
 
 
+def gemm_bf16_nt_pair(A0: Tensor, A1: Tensor, B0: Tensor, B1: Tensor, out: Tensor):
+    """Two equal-shape NT products in ONE launch (batch = 2): out[d] (M, N) = A_d (M, K) @ B_d (N, K)^T.  A0/A1 (and B0/B1) must be
+    views of one bf16 buffer with equal pitches; out (2, M, N) fp32 with equal-pitch slices.  Used for the two directions of dW_hh:
+    twice the tiles per launch means half the split-K factor (and half the partial-slab traffic) for the same chip fill."""
+    for t in (A0, A1, B0, B1):
+        assert t.dtype == torch.bfloat16 and t.is_cuda and t.dim() == 2 and t.stride(1) == 1
+    assert A0.shape == A1.shape and B0.shape == B1.shape and A0.stride(0) == A1.stride(0) and B0.stride(0) == B1.stride(0)
+    M, K = A0.shape
+    N = B0.size(0)
+    assert B0.size(1) == K and K % 8 == 0 and out.dim() == 3 and out.size(0) == 2 and tuple(out.shape[1:]) == (M, N) and out.stride(2) == 1
+    sA, sB = (A1.data_ptr() - A0.data_ptr()) // 2, (B1.data_ptr() - B0.data_ptr()) // 2
+    assert (A1.data_ptr() - A0.data_ptr()) % 16 == 0 and (B1.data_ptr() - B0.data_ptr()) % 16 == 0
+    lib = _lib.load()
+    splitk = _pick_splitk(M, 2 * N, K)                 # chip fill is decided by the tiles of both products together
+    ws, wsb = None, 0
+    if splitk > 1:
+        wsb = lib.ds2_gemm_bf16_workspace_bytes(M, N, 2, splitk)
+        ws = _ws(wsb, A0.device)
+    _lib.check(lib.ds2_gemm_bf16_nt(M, N, K, A0.data_ptr(), A0.stride(0), sA, B0.data_ptr(), B0.stride(0), sB, out.data_ptr(), out.stride(1),
+                                    out.stride(0), None, 0, 2, splitk, _ptr(ws), wsb, _stream()), "ds2_gemm_bf16_nt")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # BatchNorm1d family on (M, H)
 # ------------------------------------------------------------------------------------------------
