@@ -50,6 +50,8 @@ struct RnnArgs {
   float* pk;          // packed moving operand, ping-pong: [2 parity][2 dir][nbt16][nchK][256]  (h fwd / dGh bwd)
   float* dcar;        // (2 parity, 2 dir, B, H) bwd carry: GRU dh*z ; LSTM dc*f
   __bf16* dgx_bf;     // bwd, optional: (T,B,2,G*H) bf16 — d(pre-activations) go HERE instead of overwriting gx (fp32)
+  __bf16* gates_bf;   // optional (T,B,2,H,4) bf16: saved-for-backward record per hidden unit, ONE 8-byte store in forward and ONE load
+                      // in backward instead of four each — GRU [r, z, n, hn], LSTM [i, f, g, o]; gx / (GRU) aux are then not written
   const int* lens;    // (B) valid output frames per sample
   int T, B, H, lddy;
   int nsl, nbt16;     // hidden slices of 16 ; allocated 16-row batch tiles (multiple of MB)
@@ -57,6 +59,7 @@ struct RnnArgs {
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
 
 // Timeline probe (scripts/probe_rnn_timeline.hip builds this file with -DDS2_RNN_TRACE; compiled out of the library): lane 0 of
 // every wave of workgroup (0,0,0) stamps s_memtime at phase boundaries of the forward step kernel.
@@ -76,7 +79,7 @@ __device__ unsigned long long* g_rnn_trace = nullptr;   // [step][wave][8]
 // the first global load of every step kernel can issue.
 __device__ __forceinline__ void hoist_kernargs(const RnnArgs& a) {
   // ("memory": also a compiler barrier, so that the operand loads issued before this point stay before the epilogue loads after it)
-  asm volatile("" ::"s"(a.gx), "s"(a.aux), "s"(a.hbuf), "s"(a.wp), "s"(a.bhh), "s"(a.dy), "s"(a.pk), "s"(a.dcar), "s"(a.lens), "s"(a.dgx_bf)
+  asm volatile("" ::"s"(a.gx), "s"(a.aux), "s"(a.hbuf), "s"(a.wp), "s"(a.bhh), "s"(a.dy), "s"(a.pk), "s"(a.dcar), "s"(a.lens), "s"(a.dgx_bf), "s"(a.gates_bf)
                : "memory");
 }
 
@@ -264,10 +267,15 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(const float* pk, 
     float* ho = a.hbuf + rowH[i];
     float* ax = a.aux + rowH[i];
     if (!(t < plen[i])) {
+      if (a.gates_bf) {
+        __builtin_nontemporal_store(bf16x4_{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f}, reinterpret_cast<bf16x4_*>(a.gates_bf) + rowH[i]);
+        if (G == 4) stnt(ax, 0.f);
+      } else {
 #pragma unroll
-      for (int g = 0; g < G; ++g) stnt(&gx[g * H], 0.f);
+        for (int g = 0; g < G; ++g) stnt(&gx[g * H], 0.f);
+        stnt(ax, 0.f);
+      }
       stnt(ho, 0.f);
-      stnt(ax, 0.f);
       packed_store<BF>(pk_out, hpi[i], 0.f);
       continue;
     }
@@ -290,8 +298,12 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(const float* pk, 
       const float r = sigmoidf_(pgx[i][0] + gh[0]);
       const float z = sigmoidf_(pgx[i][1] + gh[1]);
       const float n = tanhf_(pgx[i][2] + r * gh[2]);
-      stnt(&gx[0], r); stnt(&gx[H], z); stnt(&gx[2 * H], n);
-      stnt(ax, gh[2]);
+      if (a.gates_bf) {
+        __builtin_nontemporal_store(bf16x4_{(__bf16)r, (__bf16)z, (__bf16)n, (__bf16)gh[2]}, reinterpret_cast<bf16x4_*>(a.gates_bf) + rowH[i]);
+      } else {
+        stnt(&gx[0], r); stnt(&gx[H], z); stnt(&gx[2 * H], n);
+        stnt(ax, gh[2]);
+      }
       hnew = (1.f - z) * n + z * pprev[i];
     } else {
       const float ig = sigmoidf_(pgx[i][0] + gh[0]);
@@ -299,7 +311,11 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(const float* pk, 
       const float gg = tanhf_(pgx[i][2] + gh[2]);
       const float og = sigmoidf_(pgx[i][G - 1] + gh[G - 1]);
       const float c = fg * pprev[i] + ig * gg;
-      stnt(&gx[0], ig); stnt(&gx[H], fg); stnt(&gx[2 * H], gg); stnt(&gx[(G - 1) * H], og);
+      if (a.gates_bf) {
+        __builtin_nontemporal_store(bf16x4_{(__bf16)ig, (__bf16)fg, (__bf16)gg, (__bf16)og}, reinterpret_cast<bf16x4_*>(a.gates_bf) + rowH[i]);
+      } else {
+        stnt(&gx[0], ig); stnt(&gx[H], fg); stnt(&gx[2 * H], gg); stnt(&gx[(G - 1) * H], og);
+      }
       *ax = c;                       // c_{t} is re-read by the next step (same block): keep it cacheable
       hnew = og * tanhf_(c);
     }
@@ -321,6 +337,8 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(const float* pk, 
 template <int G, int MB, bool BF>
 __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(const float* pk, const float* wp, float* gxbase, float* auxbase, const float* dy,
                                                                int s_H, int T_B, int nbt16_dbg, int lddy, RnnArgs a) {
+  // bit 2 of the flags: gxbase is really the packed bf16 gate-record buffer (RnnArgs::gates_bf), preloaded in gx's place
+  const __bf16* gates_bf = ((nbt16_dbg >> 16) & 4) ? reinterpret_cast<const __bf16*>(gxbase) : nullptr;
   __shared__ __attribute__((aligned(16))) f32x4 red[NW][MB][64];
   constexpr int NTHR = NW * 64;
   constexpr int PAIRS = (MB * 256 + NTHR - 1) / NTHR;
@@ -358,15 +376,22 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(const float* pk, 
       plen[i] = 0;
       pax[i] = pprev[i] = pdy[i] = pdc[i] = 0.f;
       const long long row = ((long long)t * B + b) * 2 + dir;
-      gxp[i] = gxbase + row * G * H + j;
+      gxp[i] = (gates_bf ? (float*)nullptr : gxbase) + row * G * H + j;   // with packed gate records only the offset is used
       rowH[i] = row * H + j;
       bH[i] = (long long)b * H + j;
 #pragma unroll
       for (int g = 0; g < G; ++g) pg[i][g] = 0.f;
       if (pact[i]) {
+        if (gates_bf) {                                   // packed record: one 8-byte load (wave-uniform choice, preloaded pointer)
+          const bf16x4_ rec = __builtin_nontemporal_load(reinterpret_cast<const bf16x4_*>(gates_bf) + rowH[i]);
+          pg[i][0] = (float)rec[0]; pg[i][1] = (float)rec[1]; pg[i][2] = (float)rec[2];
+          if (G == 3) pax[i] = (float)rec[3];
+          else { pg[i][G - 1] = (float)rec[3]; pax[i] = ldnt(auxbase + rowH[i]); }
+        } else {
 #pragma unroll
-        for (int g = 0; g < G; ++g) pg[i][g] = ldnt(gxp[i] + g * H);
-        pax[i] = ldnt(auxbase + rowH[i]);
+          for (int g = 0; g < G; ++g) pg[i][g] = ldnt(gxp[i] + g * H);
+          pax[i] = ldnt(auxbase + rowH[i]);
+        }
         pdy[i] = ldnt(&dy[((long long)t * B + b) * lddy + j]);
       }
     }
@@ -415,7 +440,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(const float* pk, 
     float* ax = auxbase + rowH[i];
     float* dco = dcar_out + bH[i];
     float dgh[G];
-    __bf16* gb = a.dgx_bf ? a.dgx_bf + (gxp[i] - gxbase) : nullptr;          // wave-uniform choice of the dGx destination
+    __bf16* gb = a.dgx_bf ? a.dgx_bf + (gxp[i] - (gates_bf ? (float*)nullptr : gxbase)) : nullptr;   // wave-uniform dGx destination
     if (!(t < plen[i])) {
 #pragma unroll
       for (int g = 0; g < G; ++g) { dgx_store(gx, gb, g * H, 0.f); dgh[g] = 0.f; }
@@ -507,7 +532,8 @@ int launch_steps(bool bwd, RnnArgs a, hipStream_t st) {
   dim3 grid(a.nsl, nbt, 2), block(NW * 64);
   if (a.nbt16 > 0xffff || a.T > 0xffff || a.B > 0xffff || a.H > 0xffff)
     return ds2_set_error("rnn: T, B, H and the tile count must fit 16 bits (T=%d B=%d H=%d)", a.T, a.B, a.H);
-  const int packed = a.nbt16 | (a.dbg << 16);                       // preloaded dwords: tile count + ablation flags, T | B, s | H
+  const int packed = a.nbt16 | ((a.dbg | ((bwd && a.gates_bf) ? 4 : 0)) << 16);   // preloaded dwords: tile count + flags, T | B, s | H
+  float* gx_or_rec = (bwd && a.gates_bf) ? reinterpret_cast<float*>(a.gates_bf) : a.gx;
   const int T_B = a.T | (a.B << 16);
   const float* pk = a.pk;
   const float* wp = a.wp;
@@ -518,8 +544,8 @@ int launch_steps(bool bwd, RnnArgs a, hipStream_t st) {
       if (mb == 2) hipLaunchKernelGGL((rnn_fwd_step_kernel<G, 2, BF>), grid, block, 0, st, pk, wp, a.gx, prev, a.bhh, s_H, T_B, packed, a);
       else hipLaunchKernelGGL((rnn_fwd_step_kernel<G, 1, BF>), grid, block, 0, st, pk, wp, a.gx, prev, a.bhh, s_H, T_B, packed, a);
     } else {
-      if (mb == 2) hipLaunchKernelGGL((rnn_bwd_step_kernel<G, 2, BF>), grid, block, 0, st, pk, wp, a.gx, a.aux, a.dy, s_H, T_B, packed, a.lddy, a);
-      else hipLaunchKernelGGL((rnn_bwd_step_kernel<G, 1, BF>), grid, block, 0, st, pk, wp, a.gx, a.aux, a.dy, s_H, T_B, packed, a.lddy, a);
+      if (mb == 2) hipLaunchKernelGGL((rnn_bwd_step_kernel<G, 2, BF>), grid, block, 0, st, pk, wp, gx_or_rec, a.aux, a.dy, s_H, T_B, packed, a.lddy, a);
+      else hipLaunchKernelGGL((rnn_bwd_step_kernel<G, 1, BF>), grid, block, 0, st, pk, wp, gx_or_rec, a.aux, a.dy, s_H, T_B, packed, a.lddy, a);
     }
   }
   hipError_t e = hipGetLastError();
@@ -567,7 +593,7 @@ extern "C" size_t ds2_rnn_fwd_workspace_bytes(int B, int H, int bf16) { return p
 //   hbuf   (T,B,2,H) out: h per direction (0 beyond each sample's length)
 //   aux    (T,B,2,H) out: GRU W_hn h + b_hn ; LSTM cell state
 extern "C" int ds2_rnn_fwd(int gates, float* gx, const void* wp_fwd, const float* bhh, float* hbuf, float* aux, const int* lens_dev, int T,
-                           int B, int H, int bf16, void* ws, size_t ws_bytes, void* stream) {
+                           int B, int H, int bf16, void* gates_bf16, void* ws, size_t ws_bytes, void* stream) {
   DS2_REQUIRE(gates == 3 || gates == 4, "ds2_rnn_fwd: gates must be 3 (GRU) or 4 (LSTM)");
   DS2_REQUIRE(gx && wp_fwd && bhh && hbuf && aux && lens_dev, "ds2_rnn_fwd: null pointer");
   DS2_REQUIRE(T > 0 && B > 0 && H > 0 && (H % 4) == 0, "ds2_rnn_fwd: need H %% 4 == 0 (H=%d)", H);
@@ -575,7 +601,7 @@ extern "C" int ds2_rnn_fwd(int gates, float* gx, const void* wp_fwd, const float
   DS2_HIP(hipMemsetAsync(ws, 0, ds2_rnn_fwd_workspace_bytes(B, H, bf16), (hipStream_t)stream));   // zero padding rows / columns
   RnnArgs a{};
   a.gx = gx; a.aux = aux; a.hbuf = hbuf; a.wp = (const float*)wp_fwd; a.bhh = bhh; a.pk = (float*)ws; a.lens = lens_dev;
-  a.T = T; a.B = B; a.H = H;
+  a.T = T; a.B = B; a.H = H; a.gates_bf = (__bf16*)gates_bf16;
   return bf16 ? dispatch<true>(gates, false, a, (hipStream_t)stream) : dispatch<false>(gates, false, a, (hipStream_t)stream);
 }
 
@@ -586,12 +612,15 @@ extern "C" size_t ds2_rnn_bwd_workspace_bytes(int gates, int B, int H, int bf16)
 //   dy     (T,B,H) pitch lddy: grad wrt y = h_fwd + h_bwd
 //   gx     in: gates from fwd ; out: grad wrt the x-projections (T,B,2,G*H)  (= dGx, feeds dW_ih, db_ih, dX)
 //   dgx_bf16  optional (T,B,2,G*H) bf16: when given, dGx is written THERE (rounded to bf16) and gx keeps the gates
+//   gates_bf16 optional (T,B,2,H,4) bf16 packed gate records written by ds2_rnn_fwd(gates_bf16): read instead of gx (+ GRU aux)
 //   aux    GRU: in hn, out d(hn) [so that dGh = (dGx_r, dGx_z, aux)] ; LSTM: cell state (unchanged; dGh = dGx)
 //   wp_bwd packed W_hh^T (ds2_rnn_pack_whh)
 extern "C" int ds2_rnn_bwd(int gates, const float* dy, int lddy, float* gx, float* aux, const float* hbuf, const void* wp_bwd,
-                           const int* lens_dev, int T, int B, int H, int bf16, void* dgx_bf16, void* ws, size_t ws_bytes, void* stream) {
+                           const int* lens_dev, int T, int B, int H, int bf16, void* dgx_bf16, const void* gates_bf16, void* ws, size_t ws_bytes,
+                           void* stream) {
   DS2_REQUIRE(gates == 3 || gates == 4, "ds2_rnn_bwd: gates must be 3 (GRU) or 4 (LSTM)");
-  DS2_REQUIRE(dy && gx && aux && hbuf && wp_bwd && lens_dev, "ds2_rnn_bwd: null pointer");
+  DS2_REQUIRE(dy && aux && hbuf && wp_bwd && lens_dev, "ds2_rnn_bwd: null pointer");
+  DS2_REQUIRE(gx || (gates_bf16 && dgx_bf16), "ds2_rnn_bwd: gx may only be NULL with both gates_bf16 and dgx_bf16 given");
   DS2_REQUIRE(T > 0 && B > 0 && H > 0 && (H % 4) == 0, "ds2_rnn_bwd: need H %% 4 == 0 (H=%d)", H);
   DS2_REQUIRE(ws && ws_bytes >= ds2_rnn_bwd_workspace_bytes(gates, B, H, bf16), "ds2_rnn_bwd: workspace too small");
   DS2_HIP(hipMemsetAsync(ws, 0, ds2_rnn_bwd_workspace_bytes(gates, B, H, bf16), (hipStream_t)stream));
@@ -599,6 +628,7 @@ extern "C" int ds2_rnn_bwd(int gates, const float* dy, int lddy, float* gx, floa
   a.gx = gx; a.aux = aux; a.hbuf = const_cast<float*>(hbuf); a.wp = (const float*)wp_bwd; a.dy = dy; a.lddy = lddy;
   a.dcar = (float*)ws; a.pk = (float*)ws + (size_t)4 * B * H;
   a.dgx_bf = (__bf16*)dgx_bf16;
+  a.gates_bf = (__bf16*)const_cast<void*>(gates_bf16);
   a.lens = lens_dev; a.T = T; a.B = B; a.H = H;
   return bf16 ? dispatch<true>(gates, true, a, (hipStream_t)stream) : dispatch<false>(gates, true, a, (hipStream_t)stream);
 }

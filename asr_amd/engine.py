@@ -56,6 +56,8 @@ class LayerCtx:
     mean: Optional[Tensor] = None    # BN batch stats of this layer's INPUT (layers >= 1)
     var: Optional[Tensor] = None
     wpb: Optional[Tensor] = None     # W_hh^T in fragment order for the backward recurrence
+    rec: Optional[Tensor] = None     # bf16 training: packed saved-gate records (M, 2H, 4) instead of gates in gx
+    gshape: tuple = ()               # (M, 2GH) when gx itself was released
 
 
 @dataclass
@@ -146,7 +148,15 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
             gx = ops.gemm(xn, W[f"rnns.{l}.wih_cat"], transB=True, bias=W[f"rnns.{l}.bih_cat"])  # (M, 2GH)
         bf = cfg.precision == "bf16"
         wpf, wpb = ops.rnn_pack(G, W[f"rnns.{l}.whh_cat"], bf16=bf)
-        hbuf, aux = ops.rnn_fwd(G, gx, wpf, W[f"rnns.{l}.bhh_cat"], lens_dev, T, B, H, bf16=bf)
+        # bf16 training (B % 8 == 0, the condition of the bf16 dGx path in backward): the saved gates are ONE packed bf16 record per
+        # hidden unit; the fp32 x-projection buffer is then dead after the recurrence
+        pack = bf and save and B % 8 == 0
+        if pack:
+            hbuf, aux, rec = ops.rnn_fwd(G, gx, wpf, W[f"rnns.{l}.bhh_cat"], lens_dev, T, B, H, bf16=True, packed_gates=True)
+            gx = None
+            lc.rec, lc.gshape = rec, (M, 2 * G * H)
+        else:
+            hbuf, aux = ops.rnn_fwd(G, gx, wpf, W[f"rnns.{l}.bhh_cat"], lens_dev, T, B, H, bf16=bf)
         lc.wpb = wpb
         nxt = f"rnns.{l + 1}.batch_norm.module" if l + 1 < L else "fc.0.module.0"
         y, mean, var = ops.add_colstats(hbuf[:, :H], hbuf[:, H:], *run(nxt))
@@ -202,8 +212,10 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
         # bf16 mode: the step kernels write dGx in bf16 (row-major) into a side buffer that the GEMMs consume directly (needs
         # B % 8 == 0 for the 16-byte aligned time-shifted operand views below; other batch sizes keep fp32 dGx + a cast pass)
         bfd = bf and B % 8 == 0
-        dgx_bf = torch.empty(lc.gx.shape, dtype=torch.bfloat16, device=lc.gx.device) if bfd else None
-        ops.rnn_bwd(G, dy, lc.gx, lc.aux, lc.hbuf, lc.wpb, lens_dev, T, B, H, bf16=bf, dgx_bf16=dgx_bf)
+        gshape = lc.gshape if lc.rec is not None else lc.gx.shape
+        dgx_bf = torch.empty(gshape, dtype=torch.bfloat16, device=dy.device) if bfd else None
+        ops.rnn_bwd(G, dy, lc.gx, lc.aux, lc.hbuf, lc.wpb, lens_dev, T, B, H, bf16=bf, dgx_bf16=dgx_bf, gates_bf16=lc.rec)
+        lc.rec = None
         dgx = dgx_bf if bfd else lc.gx                                                            # dGx (M, 2GH)
         # ---- critical path: dXn = dGx W_ih (feeds the next layer's backward) ---------------------------------------
         dgxT = None

@@ -526,31 +526,40 @@ def rnn_pack(gates: int, whh: Tensor, bf16: bool = False):
     return wpf, wpb
 
 
-def rnn_fwd(gates: int, gx: Tensor, wp_fwd: Tensor, bhh: Tensor, lens_dev: Tensor, T: int, B: int, H: int, bf16: bool = False):
-    """gx (T*B, 2*G*H) in/out; returns (hbuf (T*B, 2H), aux (T*B, 2H))."""
+def rnn_fwd(gates: int, gx: Tensor, wp_fwd: Tensor, bhh: Tensor, lens_dev: Tensor, T: int, B: int, H: int, bf16: bool = False,
+            packed_gates: bool = False):
+    """gx (T*B, 2*G*H) in/out; returns (hbuf (T*B, 2H), aux (T*B, 2H)[, gates_bf (T*B, 2H, 4) bf16]).
+    packed_gates: the saved-for-backward gates go to one 8-byte bf16 record per hidden unit (gx keeps the x-projections; GRU aux
+    is not written) — pass the returned buffer to rnn_bwd."""
     _chk_f32(gx, bhh)
     assert gx.is_contiguous() and bhh.is_contiguous()
     lib = _lib.load()
     hbuf = torch.empty(T * B, 2 * H, dtype=torch.float32, device=gx.device)
     aux = torch.empty_like(hbuf)
+    rec = torch.empty(T * B, 2 * H, 4, dtype=torch.bfloat16, device=gx.device) if packed_gates else None
     wsb = lib.ds2_rnn_fwd_workspace_bytes(B, H, int(bf16))
     ws = _ws(wsb, gx.device)
     _lib.check(lib.ds2_rnn_fwd(gates, gx.data_ptr(), wp_fwd.data_ptr(), bhh.data_ptr(), hbuf.data_ptr(), aux.data_ptr(),
-                               lens_dev.data_ptr(), T, B, H, int(bf16), ws.data_ptr(), wsb, _stream()), "ds2_rnn_fwd")
-    return hbuf, aux
+                               lens_dev.data_ptr(), T, B, H, int(bf16), _ptr(rec), ws.data_ptr(), wsb, _stream()), "ds2_rnn_fwd")
+    return (hbuf, aux, rec) if packed_gates else (hbuf, aux)
 
 
-def rnn_bwd(gates: int, dy: Tensor, gx: Tensor, aux: Tensor, hbuf: Tensor, wp_bwd: Tensor, lens_dev: Tensor, T: int, B: int, H: int,
-            bf16: bool = False, dgx_bf16: Optional[Tensor] = None):
-    """dgx_bf16: optional (T*B, 2*G*H) bf16 buffer that receives dGx (then `gx` keeps the gates)."""
+def rnn_bwd(gates: int, dy: Tensor, gx: Optional[Tensor], aux: Tensor, hbuf: Tensor, wp_bwd: Tensor, lens_dev: Tensor, T: int, B: int, H: int,
+            bf16: bool = False, dgx_bf16: Optional[Tensor] = None, gates_bf16: Optional[Tensor] = None):
+    """dgx_bf16: optional (T*B, 2*G*H) bf16 buffer that receives dGx (then `gx` keeps the gates).
+    gates_bf16: the packed records of rnn_fwd(packed_gates=True), read instead of gx / GRU aux (gx may then be None)."""
     _chk_f32(dy, gx, aux, hbuf)
     if dgx_bf16 is not None:
-        assert dgx_bf16.dtype == torch.bfloat16 and dgx_bf16.is_contiguous() and dgx_bf16.numel() == gx.numel()
+        assert dgx_bf16.dtype == torch.bfloat16 and dgx_bf16.is_contiguous() and dgx_bf16.numel() == T * B * 2 * gates * H
+    if gates_bf16 is not None:
+        assert gates_bf16.dtype == torch.bfloat16 and gates_bf16.is_contiguous() and gates_bf16.numel() == T * B * 2 * H * 4
+    assert gx is not None or (dgx_bf16 is not None and gates_bf16 is not None)
     lib = _lib.load()
     wsb = lib.ds2_rnn_bwd_workspace_bytes(gates, B, H, int(bf16))
-    ws = _ws(wsb, gx.device)
-    _lib.check(lib.ds2_rnn_bwd(gates, dy.data_ptr(), _row_pitch(dy), gx.data_ptr(), aux.data_ptr(), hbuf.data_ptr(), wp_bwd.data_ptr(),
-                               lens_dev.data_ptr(), T, B, H, int(bf16), _ptr(dgx_bf16), ws.data_ptr(), wsb, _stream()), "ds2_rnn_bwd")
+    ws = _ws(wsb, dy.device)
+    _lib.check(lib.ds2_rnn_bwd(gates, dy.data_ptr(), _row_pitch(dy), _ptr(gx), aux.data_ptr(), hbuf.data_ptr(), wp_bwd.data_ptr(),
+                               lens_dev.data_ptr(), T, B, H, int(bf16), _ptr(dgx_bf16), _ptr(gates_bf16), ws.data_ptr(), wsb, _stream()),
+               "ds2_rnn_bwd")
 
 
 # ------------------------------------------------------------------------------------------------

@@ -228,12 +228,13 @@ def main():
     lens = torch.full((B,), T, dtype=torch.int32, device=dev)
     bf = dtype == "bf16"
     wpf, _ = ops.rnn_pack(G, whh, bf16=bf)
-    ops.rnn_fwd(G, gx.clone(), wpf, bhh, lens, T, B, H, bf16=bf)
+    pack = bf and B % 8 == 0                              # the train step's own mode (engine.forward)
+    ops.rnn_fwd(G, gx.clone(), wpf, bhh, lens, T, B, H, bf16=bf, packed_gates=pack)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     gx2 = gx.clone()
     torch.cuda.synchronize()
     e0.record()
-    ops.rnn_fwd(G, gx2, wpf, bhh, lens, T, B, H, bf16=bf)
+    ops.rnn_fwd(G, gx2, wpf, bhh, lens, T, B, H, bf16=bf, packed_gates=pack)
     e1.record()
     torch.cuda.synchronize()
     us_per_launch = e0.elapsed_time(e1) * 1e3 / T
@@ -245,7 +246,7 @@ def main():
     traffic = 21.9e6 if (args.workload == "c3" and bf and B == 64) else None
     roofline = {"kernel": "rnn_fwd_step_kernel", "bound": "mfma", "achieved": achieved, "peak": peak,
                 "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-                "algorithmic_hbm_bytes_per_launch": (8 * B * 2 * H * 4 + B * 2 * H * (2 if bf else 4)),
+                "algorithmic_hbm_bytes_per_launch": ((3 * 4 + 8 + 4 + 2 if pack else 8 * 4 + (2 if bf else 4)) * B * 2 * H),
                 "us_per_launch": us_per_launch, "launches_per_step": 2 * T * L}
 
     if args.breakdown and rank == 0:

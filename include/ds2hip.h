@@ -137,13 +137,17 @@ size_t ds2_rnn_packed_bytes(int gates, int H, int which /*0: forward operand, 1:
  * (once per optimizer step) */
 int ds2_rnn_pack_whh(int gates, const float* whh, void* wp_fwd, void* wp_bwd, int H, int bf16, void* stream);
 size_t ds2_rnn_fwd_workspace_bytes(int B, int H, int bf16);
+/* gates_bf16: NULL, or a (T,B,2,H,4) bf16 buffer that receives the saved-for-backward record of every hidden unit as ONE 8-byte
+ * store — GRU [r, z, n, W_hn h + b_hn], LSTM [i, f, g, o] — instead of four fp32 stores into gx / aux (gx is then left untouched
+ * and, for GRU, aux is not written).  Pass the same buffer to ds2_rnn_bwd. */
 int ds2_rnn_fwd(int gates, float* gx, const void* wp_fwd, const float* bhh, float* hbuf, float* aux, const int* lens_dev, int T, int B,
-                int H, int bf16, void* ws, size_t ws_bytes, void* stream);
+                int H, int bf16, void* gates_bf16, void* ws, size_t ws_bytes, void* stream);
 size_t ds2_rnn_bwd_workspace_bytes(int gates, int B, int H, int bf16);
 /* dgx_bf16: NULL, or a (T,B,2,G*H) bf16 buffer that receives the gradient wrt the x-projections instead of gx (which then keeps
- * the gates): the bf16-mode GEMMs consume it directly. */
+ * the gates): the bf16-mode GEMMs consume it directly.  gates_bf16: NULL, or the packed records written by ds2_rnn_fwd — read
+ * instead of gx (and, for GRU, instead of aux, which is then output only: d(W_hn h + b_hn)); gx may be NULL when both are given. */
 int ds2_rnn_bwd(int gates, const float* dy, int lddy, float* gx, float* aux, const float* hbuf, const void* wp_bwd, const int* lens_dev,
-                int T, int B, int H, int bf16, void* dgx_bf16, void* ws, size_t ws_bytes, void* stream);
+                int T, int B, int H, int bf16, void* dgx_bf16, const void* gates_bf16, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- log-softmax + CTC loss + gradient ---------------------------------------------------------
  * out.float().log_softmax(2) + torch.nn.CTCLoss(reduction="sum") and their backward,

@@ -316,6 +316,7 @@ def test_rnn_fwd_bwd(dev, kind, H, B, T, lens, bf):
     assert rel_l2(ysum.view(T, B, H).cpu(), y.detach()) < e1
     if bf:
         # bf16 mode's side buffer: dGx lands in bf16 and the fp32 buffer keeps the gates; must equal the fp32 result rounded to bf16
+        aux_fwd = aux.clone()
         gates_saved, aux2, side_buf = gxd.clone(), aux.clone(), torch.empty(T * B, 2 * G * H, dtype=torch.bfloat16, device=dev)
         ops.rnn_bwd(G, g(dy.float().reshape(T * B, H), dev), gates_saved, aux2, hbuf, wpb, ld, T, B, H, bf16=True, dgx_bf16=side_buf)
         assert torch.equal(gates_saved, gxd)
@@ -323,6 +324,21 @@ def test_rnn_fwd_bwd(dev, kind, H, B, T, lens, bf):
     assert rel_l2(gxd.view(T, B, 2, G * H).cpu(), gx.grad) < e2          # dGx
     if bf:
         assert torch.equal(side_buf, gxd.bfloat16()) and torch.equal(aux2, aux)
+        # packed saved-gate records (bf16 training path): one 8-byte record per hidden unit from forward, read back in backward;
+        # gx keeps the x-projections, GRU aux becomes output-only, gx need not exist in backward
+        xproj = g(gx.detach().float().reshape(T * B, 2 * G * H), dev).clone()
+        keep_x = xproj.clone()
+        hb3, aux3, rec = ops.rnn_fwd(G, xproj, wpf, bhd, ld, T, B, H, bf16=True, packed_gates=True)
+        assert torch.equal(xproj, keep_x) and torch.equal(hb3, hbuf)              # same forward, gx untouched
+        gates_ref = torch.stack([gates_saved.view(T * B, 2, G, H)[:, :, k] for k in range(3)] +
+                                [(aux_fwd if G == 3 else gates_saved.view(T * B, 2, G, H)[:, :, 3].reshape(T * B, 2 * H)).view(T * B, 2, H)], dim=-1)
+        assert torch.equal(rec.view(T * B, 2, H, 4), gates_ref.bfloat16())
+        side3 = torch.empty(T * B, 2 * G * H, dtype=torch.bfloat16, device=dev)
+        aux_in = aux3 if G == 4 else torch.full_like(aux3, float("nan"))          # GRU: aux must not be read
+        ops.rnn_bwd(G, g(dy.float().reshape(T * B, H), dev), None, aux_in, hb3, wpb, ld, T, B, H, bf16=True, dgx_bf16=side3, gates_bf16=rec)
+        assert rel_l2(side3.float().view(T, B, 2, G * H).cpu(), gx.grad) < e2     # gates rounded to bf16: same stated tolerance
+        if G == 3:
+            assert bool(torch.isfinite(aux_in).all()) and rel_l2(aux_in.cpu(), aux.cpu()) < 2e-2
         tT, cs = ops.transpose_bf16(side_buf, colsum=True)
         assert torch.equal(tT[:, :T * B].cpu(), side_buf.t().contiguous().cpu()) and float(tT[:, T * B:].float().abs().sum()) == 0
         assert rel_l2(cs.cpu(), side_buf.double().sum(0).cpu()) < 1e-5
