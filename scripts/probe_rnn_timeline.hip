@@ -34,7 +34,7 @@ int main() {
   CK(hipMemset(trace, 0, (size_t)T * NW * 8 * 8));
   CK(hipMemcpyToSymbol(HIP_SYMBOL(g_rnn_trace), &trace, sizeof(trace)));
   for (int rep = 0; rep < 2; ++rep)
-    if (ds2_rnn_fwd(G, gx, wpf, bhh, hbuf, aux, lens, T, B, H, bf, ws, wsb, nullptr)) { printf("fwd failed: %s\n", ds2_last_error()); return 1; }
+    if (ds2_rnn_fwd(G, gx, wpf, bhh, hbuf, aux, lens, T, B, H, bf, nullptr, ws, wsb, nullptr)) { printf("fwd failed: %s\n", ds2_last_error()); return 1; }
   CK(hipDeviceSynchronize());
   std::vector<unsigned long long> tr((size_t)T * NW * 8);
   CK(hipMemcpy(tr.data(), trace, tr.size() * 8, hipMemcpyDeviceToHost));
@@ -42,7 +42,7 @@ int main() {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   CK(hipEventRecord(e0));
-  ds2_rnn_fwd(G, gx, wpf, bhh, hbuf, aux, lens, T, B, H, bf, ws, wsb, nullptr);
+  ds2_rnn_fwd(G, gx, wpf, bhh, hbuf, aux, lens, T, B, H, bf, nullptr, ws, wsb, nullptr);
   CK(hipEventRecord(e1));
   CK(hipDeviceSynchronize());
   float ms;
