@@ -288,3 +288,37 @@ def test_bf16_loss_matches_fp32_on_the_metric_config():
     l32, l16 = res["fp32"][0], res["bf16"][0]
     assert np.isfinite(l32) and abs(l16 - l32) <= 1e-3 * abs(l32), (l32, l16)
     assert rel_l2(res["bf16"][1].numpy(), res["fp32"][1].numpy()) < 2e-2
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("rnn,t_ins", [("gru", [2, 1, 1]), ("lstm", [5, 3, 1, 1])])
+def test_shortest_utterances(rnn, t_ins, precision):
+    """Edge of the length range: 1-2 input frames -> T = 1 output frame (no recurrent weight gradient, the reverse direction starts
+    and ends on the same frame), up to 5 frames -> T = 3.  Whole step vs the fp64 oracle; targets of length <= T so that CTC is
+    feasible for the longest row and the single-frame rows carry one label."""
+    cfg = dict(rnn=rnn, hidden=24, layers=2, classes=7, t_ins=t_ins)
+    sd, x, targets, pct, tsz = model_inputs(cfg, well_conditioned=False)
+    lens = O.lengths_from_percentages(pct, x.size(3))
+    out_lens = O.seq_lens_after_conv(lens)
+    tsz = torch.minimum(tsz, out_lens.to(tsz.dtype)).clamp(min=1)
+    targets = torch.cat([targets[:1].expand(int(n)).clone() * 0 + 1 + (i % 5) for i, n in enumerate(tsz.tolist())]).to(targets.dtype)
+    ref = O.fit_and_grads(sd, x, targets, pct, tsz, dtype=torch.float64)
+    model = make_model(cfg, sd)
+    model.precision = precision
+    out, out_lens_d = model.forward(x.cuda(), lens)
+    assert out.shape[1] == int(out_lens.max()) and torch.equal(out_lens_d.cpu(), out_lens.cpu())
+    from asr_amd import CTCLoss
+    loss = CTCLoss(reduction="sum")(out.transpose(0, 1), targets, out_lens_d, tsz) / len(t_ins)
+    loss.backward()
+    tol_o, tol_g = (TOL, TOL) if precision == "fp32" else (2e-2, 1.5e-1)
+    assert np.isfinite(float(loss.detach())) and abs(float(loss.detach()) - ref["loss"]) <= tol_o * abs(ref["loss"])
+    assert rel_l2(out.detach().cpu().numpy(), ref["logits"].numpy()) < tol_o
+    # a bias in front of a train-mode BatchNorm has an exactly-zero gradient (reference: 1e-15 round-off): compare such tensors on
+    # the scale of the largest gradient in the model instead of their own (degenerate) norm
+    gmax = max(float(np.linalg.norm(v.numpy())) for v in ref["grads"].values())
+    for k, p in model.named_parameters():
+        gref = ref["grads"][k].numpy()
+        assert bool(torch.isfinite(p.grad).all()), k
+        err = np.linalg.norm(p.grad.cpu().numpy().astype(np.float64) - gref)
+        assert err <= tol_g * max(np.linalg.norm(gref), 1e-4 * gmax), (k, err, np.linalg.norm(gref), gmax)
+    model.precision = "fp32"
