@@ -235,7 +235,7 @@ extern "C" int ds2_conv2_dgrad_bf16(const void* dy2_nhwc, const void* wd0, const
 // 2-byte offset; instead the dY tile is staged in LDS as 8 copies pre-shifted by r = 0..7 elements, and tap s reads
 // copy (s mod 8) — every ds_read_b128 stays 16-byte aligned, no funnel shifts in the MFMA loop.
 //   K runs over the INPUT time t' in [t0-8, t0+72):  D[co][ci] += dYcopy_r[co][t' - s] * A1[ci][t']
-// block = (group of 3 kernel rows, chunk of (b,o) pairs); 4 waves split the 33 taps; accumulators live in registers
+// block = (group of 3 kernel rows, chunk of (b,o) pairs); 4 waves split the 11 time taps (x 3 kernel rows each); accumulators live in registers
 // across the whole (b,o,t) loop; ordered reduction over chunks afterwards (deterministic).
 // =============================================================================================================
 namespace {
@@ -351,30 +351,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     t0 += WT;
     have = settle();
     if (have) load_tile();                      // next tile's global loads fly behind this tile's MFMAs
-    // ---- MFMA: wave w owns taps w, w+4, ...
+    // ---- MFMA: wave w owns the time taps kt = w, w+4, w+8 (< 11) for all three kernel rows of the group: 9 accumulators
+    // (slot i = q * 3 + kdl).  Per k-step the dY fragment of a tap is shared by its 3 kernel rows and the A1 fragment of a kernel
+    // row by the wave's taps: 6 LDS reads feed 9 MFMAs (18 before); no control flow in the loop (the missing 12th tap of wave 3
+    // multiplies a valid-but-unused copy and is never stored).
+    const char* ap[3];
 #pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-      const int tap = wave + 4 * i;
-      if (tap < TAPS) {                                  // wave-uniform
-        const int kdl = tap / KT, kt = tap % KT;
-        const int s = kt - PT;                            // dY index = t' - s
-        const int r = s & 7;                              // copy
-        const int joff = (s < 0) ? 8 : 0;                 // j = 16*ks + 8*half + joff
-        const char* ap = dy_lds + (r * 32 + l31) * WPITCH + (8 * half + joff) * 2;
-        const char* bp = a1_lds + (kdl * 32 + l31) * WPITCH + (8 * half) * 2;
+    for (int q = 0; q < 3; ++q) {
+      const int kt = min(wave + 4 * q, KT - 1);
+      const int s = kt - PT;                              // dY index = t' - s
+      const int r = s & 7;                                // copy
+      const int joff = (s < 0) ? 8 : 0;                   // j = 16*ks + 8*half + joff
+      ap[q] = dy_lds + (r * 32 + l31) * WPITCH + (8 * half + joff) * 2;
+    }
+    const char* bp = a1_lds + l31 * WPITCH + (8 * half) * 2;
 #pragma unroll
-        for (int ks = 0; ks < WK / 16; ++ks) {
-          const bf16x8 af = *reinterpret_cast<const bf16x8*>(ap + ks * 32);
-          const bf16x8 bf = *reinterpret_cast<const bf16x8*>(bp + ks * 32);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[i], 0, 0, 0);
-        }
-      }
+    for (int ks = 0; ks < WK / 16; ++ks) {
+      bf16x8 af[3], bfr[KDG];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) af[q] = *reinterpret_cast<const bf16x8*>(ap[q] + ks * 32);
+#pragma unroll
+      for (int kdl = 0; kdl < KDG; ++kdl) bfr[kdl] = *reinterpret_cast<const bf16x8*>(bp + kdl * 32 * WPITCH + ks * 32);
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int kdl = 0; kdl < KDG; ++kdl) acc[q * KDG + kdl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[q], bfr[kdl], acc[q * KDG + kdl], 0, 0, 0);
     }
   }
 #pragma unroll
   for (int i = 0; i < TPW; ++i) {
-    const int tap = wave + 4 * i;
-    if (tap < TAPS) {
+    const int kt = wave + 4 * (i / KDG), kdl = i % KDG;
+    if (kt < KT) {
+      const int tap = kdl * KT + kt;
       float* out = a.part + ((((long long)chunk * gridDim.x + grp) * TAPS + tap) * 32) * 32;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
