@@ -241,9 +241,10 @@ def main():
     flops_per_launch = 2.0 * 2 * B * H * G * H           # both directions, one time step
     achieved = flops_per_launch / (us_per_launch * 1e-6) / 1e12
     peak = BF16_MFMA_PEAK_TFLOPS if bf else FP32_MFMA_PEAK_TFLOPS
-    # HBM-side bytes per launch from rocprofv3 PMC passes (profiles/r01_pmc/: FETCH_SIZE 9283.5 KB x2 gfx950 correction
-    # + WRITE_SIZE 2816 KB), measured for exactly this shape (c3, bf16 operands); null for other shapes.
-    traffic = 21.9e6 if (args.workload == "c3" and bf and B == 64) else None
+    # HBM-side bytes per launch from rocprofv3 PMC passes (profiles/r01_pmc/: FETCH_SIZE 9281 KB x2 gfx950 correction
+    # + WRITE_SIZE 1792 KB = the algorithmic writes), measured for exactly this shape and mode (c3, bf16 operands, packed gate
+    # records); null for other shapes.
+    traffic = 20.84e6 if (args.workload == "c3" and bf and B == 64) else None
     roofline = {"kernel": "rnn_fwd_step_kernel", "bound": "mfma", "achieved": achieved, "peak": peak,
                 "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                 "algorithmic_hbm_bytes_per_launch": ((3 * 4 + 8 + 4 + 2 if pack else 8 * 4 + (2 if bf else 4)) * B * 2 * H),

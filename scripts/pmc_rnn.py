@@ -10,6 +10,6 @@ whh = (torch.rand(2, G * H, H, device=dev) * 2 - 1) / H ** 0.5
 bhh = torch.zeros(2, G * H, device=dev)
 lens = torch.full((B,), T, dtype=torch.int32, device=dev)
 wpf, wpb = ops.rnn_pack(G, whh, bf16=bf)
-hbuf, aux = ops.rnn_fwd(G, gx, wpf, bhh, lens, T, B, H, bf16=bf)
+out = ops.rnn_fwd(G, gx, wpf, bhh, lens, T, B, H, bf16=bf, packed_gates=bf)     # the train step's own mode
 torch.cuda.synchronize()
 print("done", T, "launches")
