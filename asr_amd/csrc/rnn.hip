@@ -485,31 +485,42 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(const float* pk, 
 
 // W_hh (2, G*H, H) -> fwd-packed [2][nsl][G][nch][64 lanes][16 B] and bwd-packed [2][nsl][nchb][64 lanes][16 B]
 template <bool BF>
-__global__ void rnn_pack_kernel(const float* __restrict__ whh, void* __restrict__ wpf, void* __restrict__ wpb, int G, int H) {
+__global__ __launch_bounds__(256) void rnn_pack_kernel(const float* __restrict__ whh, void* __restrict__ wpf, void* __restrict__ wpb, int G, int H) {
   constexpr int KC = kchunk<BF>();
-  constexpr int EPL = BF ? 8 : 4;                 // elements per lane
+  constexpr int EPL = BF ? 8 : 4;                 // elements per lane = one 16-byte store per thread
   const int nsl = (H + 15) >> 4, nch = (H + KC - 1) / KC, nchb = (G * H + KC - 1) / KC;
-  const long long nf = (long long)2 * nsl * G * nch * 64 * EPL, nb = (long long)2 * nsl * nchb * 64 * EPL;
+  const long long nf = (long long)2 * nsl * G * nch * 64, nb = (long long)2 * nsl * nchb * 64;     // lane vectors
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nf + nb; i += stride) {
     const bool fwd = i < nf;
     const long long ii = fwd ? i : i - nf;
-    const int e = ii % EPL, lane = (ii / EPL) & 63;
-    long long r = ii / (64 * EPL);
-    float v;
+    const int lane = (int)(ii & 63);
+    long long r = ii >> 6;
+    float v[EPL];
     if (fwd) {
       const int c = r % nch; r /= nch;
       const int g = r % G; r /= G;
       const int slice = r % nsl, dir = r / nsl;
-      const int j = slice * 16 + (lane & 15), k = c * KC + (lane >> 4) * EPL + e;
-      v = (j < H && k < H) ? whh[((long long)dir * G * H + g * H + j) * H + k] : 0.f;
+      const int j = slice * 16 + (lane & 15), k0 = c * KC + (lane >> 4) * EPL;
+      const float* src = whh + ((long long)dir * G * H + g * H + j) * H + k0;          // EPL consecutive k of row (g, j)
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) v[e] = (j < H && k0 + e < H) ? src[e] : 0.f;
     } else {
       const int c = r % nchb; r /= nchb;
       const int slice = r % nsl, dir = r / nsl;
-      const int j = slice * 16 + (lane & 15), k = c * KC + (lane >> 4) * EPL + e;   // k = gate-unit row of W_hh
-      v = (j < H && k < G * H) ? whh[((long long)dir * G * H + k) * H + j] : 0.f;
+      const int j = slice * 16 + (lane & 15), k0 = c * KC + (lane >> 4) * EPL;          // k = gate-unit row of W_hh
+      const float* src = whh + ((long long)dir * G * H + k0) * H + j;                  // EPL rows, column j
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) v[e] = (j < H && k0 + e < G * H) ? src[(long long)e * H] : 0.f;
     }
-    packed_store<BF>(fwd ? wpf : wpb, ii, v);
+    if constexpr (BF) {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+      reinterpret_cast<bf16x8*>(fwd ? wpf : wpb)[ii] = o;
+    } else {
+      reinterpret_cast<f32x4*>(fwd ? wpf : wpb)[ii] = f32x4{v[0], v[1], v[2], v[3]};
+    }
   }
 }
 
