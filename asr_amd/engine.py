@@ -222,7 +222,7 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
         if bfd:
             dxn = ops.gemm_bf16_nt(dgx_bf, ops.cast_transpose_bf16(W[f"rnns.{l}.wih_cat"]))
             # dW = dGx^T [Xn | h] needs the transposed copy; the same read gives db_ih = column sums of dGx
-            dgxT, dbih_sum = ops.transpose_bf16(dgx_bf, colsum=True)
+            dgxT, dbih_sum = ops.transpose_bf16(dgx_bf, colsum=Gr[f"rnns.{l}.bih_cat"].view(-1))       # sums land in the gradient buffer
         elif bf:
             dgx_r, dgxT, dbih_sum = ops.cast_bf16_both(dgx, colsum=True)
             dxn = ops.gemm_bf16_nt(dgx_r, ops.cast_transpose_bf16(W[f"rnns.{l}.wih_cat"]))
@@ -234,7 +234,8 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
         keep.append((dgx, lc.aux, lc.hbuf, lc.xn))
         with torch.cuda.stream(side):
             dbih = Gr[f"rnns.{l}.bih_cat"]
-            dbih.copy_(dbih_sum if bf else ops.colsum(dgx))
+            if not bfd:
+                dbih.copy_(dbih_sum if bf else ops.colsum(dgx))
             dbhh = Gr[f"rnns.{l}.bhh_cat"]                                                        # (2, GH)
             dbhh.copy_(dbih.view(2, G * H))
             if G == 3:

@@ -124,20 +124,22 @@ def cast_bf16_both(src: Tensor, colsum: bool = False):
     return (dst_r, dst_t, cs) if colsum else (dst_r, dst_t)
 
 
-def transpose_bf16(src: Tensor, colsum: bool = False):
-    """(R, C) bf16 row-major -> bf16 (C, pad8(R)) = src^T [, fp32 column sums (C)] from one read; pads zero."""
+def transpose_bf16(src: Tensor, colsum=False):
+    """(R, C) bf16 row-major -> bf16 (C, pad8(R)) = src^T [, fp32 column sums (C)] from one read; pads zero.
+    colsum: False | True (new tensor) | a contiguous fp32 tensor of C elements that receives the sums (e.g. a bias-gradient slice)."""
     assert src.dtype == torch.bfloat16 and src.is_cuda and src.dim() == 2 and src.stride(1) == 1 and src.stride(0) % 8 == 0
     R, Cc = src.shape
     lib = _lib.load()
     dst_t = torch.empty(Cc, _pad8(R), dtype=torch.bfloat16, device=src.device)
     cs, ws, wsb = None, None, 0
-    if colsum:
-        cs = torch.empty(Cc, dtype=torch.float32, device=src.device)
+    if colsum is not False and colsum is not None:
+        cs = torch.empty(Cc, dtype=torch.float32, device=src.device) if colsum is True else colsum
+        assert cs.dtype == torch.float32 and cs.is_cuda and cs.is_contiguous() and cs.numel() == Cc
         wsb = lib.ds2_cast_bf16_both_workspace_bytes(R, Cc)
         ws = _ws(wsb, src.device)
     _lib.check(lib.ds2_transpose_bf16(src.data_ptr(), src.stride(0), dst_t.data_ptr(), dst_t.size(1), R, Cc, _ptr(cs), _ptr(ws), wsb,
                                       _stream()), "ds2_transpose_bf16")
-    return (dst_t, cs) if colsum else dst_t
+    return (dst_t, cs) if cs is not None else dst_t
 
 
 def _pick_splitk(M: int, N: int, K: int) -> int:
