@@ -169,8 +169,12 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst_wave_base
 }
 
 // WM x WN waves; each wave owns a (256/WM) x (256/WN) sub-tile.  2 x 4 (8 waves, 128 x 64 per wave) is the production shape.
-template <int WM, int WN>
+// PP (ping-pong, 2 x 4 waves only): the two wave groups (rows 0-127 / 128-255 of the tile = one wave per SIMD each) run the k-steps
+// half a step out of phase, held there by two raw barriers per k-step: while one group issues its 8 MFMAs the other reads its next
+// fragments and issues DMA, so the matrix pipe of every SIMD always has a wave in its MFMA cluster.
+template <int WM, int WN, bool PP = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(BArgs g, int ntx, int nty) {
+  static_assert(!PP || (WM == 2 && WN == 4), "ping-pong schedule is written for 2 x 4 waves");
   constexpr int NWV = WM * WN;
   constexpr int NI = 8 / WM, NJ = 8 / WN;   // 32 x 32 MFMA tiles per wave along M / N
   constexpr int NP = 32 / NWV;              // 8-row pieces per wave per operand tile
@@ -240,6 +244,49 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(BArgs g
   const int brow = G_TILE + (wn * (NJ * 32) + l31) * 128;
 
   stage(0, kbeg);
+  if constexpr (PP) {
+    // Schedule per k-step (kk):  [read fragments kk | DMA slice | waits]  BARRIER  [8 MFMAs]  BARRIER.  Group B (wm = 1) runs one
+    // barrier behind group A, so A's MFMA section always coincides with B's read section and vice versa.
+    //  * fragments of a k-step are complete (lgkmcnt 0) before its first barrier, so a buffer is dead once both groups have passed
+    //    that barrier of the tile's last k-step -> the DMA of tile kt+1 (into the other buffer) may start in k-step 0 of tile kt;
+    //  * every wave waits for its own DMA of tile kt+1 (vmcnt 0) in k-step 3 of tile kt, before its first barrier: when group A
+    //    passes the last barrier of tile kt, all eight waves have done so.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();          // phase offset of group B
+    for (int kt = 0; kt < nkt; ++kt) {
+      const bool more = kt + 1 < nkt;                   // block-uniform
+      const char* base = ldsg + (kt & 1) * 2 * G_TILE;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        bf16x8 a[NI], b[NJ];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) a[i] = *reinterpret_cast<const bf16x8*>(base + arow + i * 32 * 128 + koff[kk]);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const bf16x8*>(base + brow + j * 32 * 128 + koff[kk]);
+        if (more) {
+          if (kk == 0) { stage_part((kt + 1) & 1, kbeg + (kt + 1) * BK, 0); stage_part((kt + 1) & 1, kbeg + (kt + 1) * BK, 1); }
+          if (kk == 1) stage_part((kt + 1) & 1, kbeg + (kt + 1) * BK, 2);
+          if (kk == 2) stage_part((kt + 1) & 1, kbeg + (kt + 1) * BK, 3);
+          if (kk == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();          // group A catches the barrier group B is one behind on
+  } else {
   for (int kt = 0; kt < nkt; ++kt) {
     __syncthreads();            // (vmcnt(0) + barrier): tile kt has landed for every wave; buffer (kt+1)&1 is no longer read
     const bool more = kt + 1 < nkt;                   // block-uniform
@@ -261,6 +308,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(BArgs g
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
+  }
   }
 
   float* C;
@@ -483,9 +531,17 @@ extern "C" int ds2_gemm_bf16_nt(int M, int N, int K, const void* A, int lda, lon
     const int ntx = ceil_div(N, 256), nty = ceil_div(M, 256);
     // short reductions are dominated by the C write-out: 16 waves (64 x 64 per wave, 4 per SIMD) overlap it better (+5-10 % on the
     // K = 1024 forward projection); long reductions run the k-loop faster with 8 waves (128 x 64 per wave: fewer LDS reads per MFMA)
-    static const char* wv = getenv("DS2_GEMM_WAVES");      // "8" | "16": tuning override
+    static const char* wv = getenv("DS2_GEMM_WAVES");      // "8" | "16" | "pp": tuning override
     const bool w16 = wv ? (wv[0] == '1') : (kchunk <= 2048);
-    if (w16) hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<4, 4>), dim3(ntx * nty, 1, batch * splitk), dim3(1024), G_LDS, s, g, ntx, nty);
+    const bool pp = wv && wv[0] == 'p';
+    if (pp) {
+      static bool pp_attr = false;
+      if (!pp_attr) {
+        DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_nt_glds_kernel<2, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
+        pp_attr = true;
+      }
+      hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<2, 4, true>), dim3(ntx * nty, 1, batch * splitk), dim3(512), G_LDS, s, g, ntx, nty);
+    } else if (w16) hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<4, 4>), dim3(ntx * nty, 1, batch * splitk), dim3(1024), G_LDS, s, g, ntx, nty);
     else hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<2, 4>), dim3(ntx * nty, 1, batch * splitk), dim3(512), G_LDS, s, g, ntx, nty);
     DS2_LAUNCH_CHECK("gemm_bf16_nt_glds_kernel");
   } else {
