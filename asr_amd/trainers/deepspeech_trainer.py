@@ -54,7 +54,11 @@ class DeepSpeechTrainer:
         self._epoch = getattr(self._epochs, "current", 0)
         self._model_path, self._checkpoint_path = model_path, checkpoint_path
         self.criterion = criterion
-        self.mixed_precision = mixed_precision
+        # reference: mixed_precision -> torch autocast + GradScaler around fit/backward (deepspeech_trainer.py:72-91).  The MI355X path's
+        # reduced-precision mode is bf16 MFMA operands with fp32 accumulation/state, which needs no loss scaling: the flag selects it.
+        self.mixed_precision = bool(mixed_precision)
+        if self.mixed_precision and hasattr(model, "precision"):
+            model.precision = "bf16"
         self.output_file = output_file
         self.overwrite_lr = overwrite_lr
         self._reducer = None

@@ -250,7 +250,9 @@ def test_checkpoint_wire_format_and_finetune(tmp_path):
     m2 = make("gru", 16, 2, 7)
     assert not torch.equal(m2.state_dict()["fc.0.module.1.weight"], m.state_dict()["fc.0.module.1.weight"])
     opt2 = torch.optim.AdamW(m2.parameters(), lr=1.0)
-    tr2 = DeepSpeechTrainer(m2, None, 5, None, opt2, path, None, "cpu", "cpu", False, None, overwrite_lr=7e-5)
+    assert m.precision == "fp32"
+    tr2 = DeepSpeechTrainer(m2, None, 5, None, opt2, path, None, "cpu", "cpu", True, None, overwrite_lr=7e-5)
+    assert m2.precision == "bf16"                       # mixed_precision=True selects the bf16-operand mode (no GradScaler needed)
     assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
     assert tr2._epochs.start == tr2._epochs.current == 2 and tr2._metrics.test.best.cer == 12.5
     assert opt2.param_groups[0]["lr"] == 7e-5 and opt2.param_groups[0]["betas"] == (0.9, 0.999)
