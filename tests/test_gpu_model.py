@@ -322,3 +322,87 @@ def test_shortest_utterances(rnn, t_ins, precision):
         err = np.linalg.norm(p.grad.cpu().numpy().astype(np.float64) - gref)
         assert err <= tol_g * max(np.linalg.norm(gref), 1e-4 * gmax), (k, err, np.linalg.norm(gref), gmax)
     model.precision = "fp32"
+
+
+DP_STEP_WORKER = r'''
+import os, sys, json, tempfile
+import numpy as np, torch, torch.distributed as dist
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests")); sys.path.insert(0, os.path.join(root, "tests", "golden"))
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)          # two ranks share the one GPU: gloo moves the CUDA buckets
+from helpers import model_inputs
+from test_gpu_model import make_model
+from asr_amd import CTCLoss, FusedAdamW
+from asr_amd.trainers import DeepSpeechTrainer
+cfg = json.loads(sys.argv[2])
+cfg["t_ins"] = cfg["shards"][rank]
+cfg["seed"] = 11 + 2 * rank                                              # each rank its own shard of the global batch
+sd, x, targets, pct, tsz = model_inputs(cfg)
+model = make_model(cfg, sd)
+opt = FusedAdamW(model, lr=1.5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5)
+tr = DeepSpeechTrainer(model, CTCLoss(reduction="sum"), 1, None, opt, None, None, "cuda", "cuda", False, None)
+valid, lv = tr.step((x, targets, pct.clone(), tsz))
+assert valid and tr._get_reducer().world == 2
+flat, flat_grad = model.flat_parameters()
+assert abs(opt.grad_scale - 1.0 / world) < 1e-12                         # the mean over ranks is folded into the optimizer
+np.save(sys.argv[3] + f".rank{rank}.npy", flat.detach().cpu().numpy())
+Gr = model._flat.tensors(model, grads=True)
+np.savez(sys.argv[3] + f".grads.rank{rank}.npz", **{n: Gr[n].detach().cpu().numpy() for n, _ in model.named_parameters()})
+names = [n for n, _ in model.named_parameters()]
+np.save(sys.argv[3] + f".p0.rank{rank}.npy", np.concatenate([model.state_dict()[n].detach().cpu().numpy().ravel() for n in names]))
+dist.barrier()
+dist.destroy_process_group()
+print("OK", rank, lv)
+'''
+
+
+def test_data_parallel_step_matches_sharded_oracle(tmp_path):
+    """SURVEY §8(e): N-GPU parity = run the CPU oracle on each rank's shard with the same weights, average the gradients, apply
+    AdamW once.  Two ranks (sharing this box's single GPU through the gloo backend — the reducer is backend-agnostic) run
+    `trainer.step` on different shards: both must end with identical parameters, equal to the oracle's averaged-gradient update."""
+    import json
+    import subprocess
+    import sys
+    cfg = dict(rnn="gru", hidden=24, layers=2, classes=7, shards=[[40, 33, 21], [38, 30, 12]])
+    out = str(tmp_path / "dp")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = str(tmp_path / "w.py")
+    open(script, "w").write(DP_STEP_WORKER)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29537")
+        procs.append(subprocess.Popen([sys.executable, script, root, json.dumps(cfg), out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    p_rank = [np.load(out + f".rank{r}.npy") for r in range(2)]
+    assert np.array_equal(p_rank[0], p_rank[1])                                  # replicas stay bit-identical
+    # oracle: per-shard gradients (fp64), averaged over ranks, one AdamW step from the common initial weights
+    grads, sd0 = [], None
+    for r in range(2):
+        c = dict(cfg, t_ins=cfg["shards"][r], seed=11 + 2 * r)
+        sd, x, targets, pct, tsz = model_inputs(c)
+        sd0 = sd
+        grads.append(O.fit_and_grads(sd, x, targets, pct, tsz, dtype=torch.float64)["grads"])
+    model = make_model(dict(cfg, t_ins=cfg["shards"][0]), sd0)
+    model._ensure_flat(torch.device("cuda:0"))
+    flat, _ = model.flat_parameters()
+    got = {}
+    views = model._flat.tensors(model)
+    flat.copy_(torch.from_numpy(p_rank[0]).cuda())
+    gsum = np.load(out + ".grads.rank0.npz")
+    gsum1 = np.load(out + ".grads.rank1.npz")
+    gmax = max(float(np.linalg.norm(grads[0][k].numpy() + grads[1][k].numpy())) for k in grads[0])
+    for k, p in model.named_parameters():
+        # the reduced buffer holds the SUM over ranks of each rank's d(sum_shard CTC / B_local), identical on both ranks
+        want_sum = grads[0][k].numpy() + grads[1][k].numpy()
+        assert np.array_equal(gsum[k], gsum1[k]), k
+        err = np.linalg.norm(gsum[k].astype(np.float64) - want_sum)
+        assert err <= TOL * max(np.linalg.norm(want_sum), 1e-4 * gmax), (k, err)
+        g = (grads[0][k].numpy() + grads[1][k].numpy()) / 2.0
+        p0 = sd0[k].double().numpy()
+        want, _, _ = O.adamw_step_np(p0, g, np.zeros_like(p0), np.zeros_like(p0), 1)
+        # first AdamW step moves every weight by ~lr * sign(g): compare the UPDATE, not the weight
+        upd_got, upd_want = p.detach().cpu().double().numpy() - p0, want - p0
+        big = np.abs(g) > 1e-3 * np.abs(g).max()                                 # where the sign of g is well determined
+        assert np.allclose(upd_got[big], upd_want[big], rtol=2e-2, atol=1e-7), k
