@@ -17,6 +17,8 @@ for it in range(n):
     H = int(rng.choice([8, 12, 20, 36, 44, 64, 100]))
     L = int(rng.randint(1, 4))
     B = int(rng.randint(1, 19))
+    if len(sys.argv) > 3 and sys.argv[3] == "b8":      # exercise the bf16 training path's packed records / bf16 dGx (needs B % 8 == 0)
+        B = int(rng.choice([8, 16, 24, 40]))
     tmax = int(rng.randint(2, 70))
     t_ins = sorted([int(v) for v in rng.randint(1, tmax + 1, size=B)], reverse=True)
     t_ins[0] = tmax
