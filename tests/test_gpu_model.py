@@ -231,6 +231,56 @@ def test_full_size_properties():
     assert ls[-1] < ls[0], ls
 
 
+def test_full_size_properties_bf16_training_path():
+    """The bench's own configuration (5x1024 GRU, B=64, 10 s, ragged, bf16 mode, mixed_precision=True -> packed gate records, bf16 dGx,
+    bf16 conv1/conv2) through the fused step: bit-identical reruns from the same state, exact zeros beyond every length in the saved
+    hidden states, finite gradients in every parameter, loss going down, and the first step's loss within 1e-3 of the fp32 path's."""
+    from asr_amd import CTCLoss, FusedAdamW, engine
+    from asr_amd.trainers import DeepSpeechTrainer
+    cfg = dict(rnn="gru", hidden=1024, layers=5, classes=29)
+    B, tmax = 64, 1001
+    t_ins = sorted([int(v) for v in det.randint((B,), 62, 300, tmax + 1)], reverse=True)
+    t_ins[0] = tmax
+    cfg["t_ins"] = t_ins
+    torch.manual_seed(0)
+    model = make_model(cfg)
+    x, targets, pct, tsz = det.batch(B, t_ins, 29, seed=3)
+    x, targets, pct, tsz = map(torch.from_numpy, (x, targets, pct, tsz))
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    runs = []
+    for _ in range(2):
+        model.load_state_dict(sd0)
+        opt = FusedAdamW(model, lr=3e-4)
+        tr = DeepSpeechTrainer(model, CTCLoss(reduction="sum"), 1, None, opt, None, None, "cuda", "cuda", True, None)
+        assert model.precision == "bf16"
+        ls = [tr.step((x, targets, pct.clone(), tsz))[1] for _ in range(3)]
+        flat, flat_grad = model.flat_parameters()
+        assert bool(torch.isfinite(flat_grad).all()) and bool(torch.isfinite(flat).all())
+        runs.append((ls, flat.clone()))
+    assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])     # deterministic, incl. the optimizer updates
+    assert runs[0][0][-1] < runs[0][0][0], runs[0][0]
+    model.load_state_dict(sd0)
+    model.precision = "fp32"
+    opt = FusedAdamW(model, lr=3e-4)
+    l32 = DeepSpeechTrainer(model, CTCLoss(reduction="sum"), 1, None, opt, None, None, "cuda", "cuda", False, None).step((x, targets, pct.clone(), tsz))[1]
+    assert abs(runs[0][0][0] - l32) <= 1e-3 * abs(l32), (runs[0][0][0], l32)
+    # masking invariants on the bf16 path's saved state
+    model.load_state_dict(sd0)
+    model.precision = "bf16"
+    lens = O.lengths_from_percentages(pct, tmax)
+    out_lens = O.seq_lens_after_conv(lens)
+    W = model._flat.tensors(model)
+    with torch.no_grad():
+        logits, ctx = engine.forward(W, model._cfg, x.cuda(), out_lens.cuda(), training=True, save=True)
+    T = logits.shape[0]
+    tmask = (torch.arange(T).view(T, 1) >= out_lens.view(1, B)).cuda()
+    for lc in ctx.layers:
+        assert lc.gx is None and lc.rec is not None                              # packed records, x-projections released
+        assert float(lc.hbuf.view(T, B, -1)[tmask].abs().max()) == 0.0
+        assert float(lc.rec.view(T, B, -1)[tmask].float().abs().max()) == 0.0
+    model.precision = "fp32"
+
+
 def test_evaluate_loop_decodes_on_gpu():
     """DeepSpeech.evaluate (deepspeech.py:161-273): eval forward -> softmax -> greedy decode -> WER/CER.  The
     transcripts must equal a numpy greedy decode of the CPU oracle's eval-mode probabilities wherever the
