@@ -94,6 +94,23 @@ def test_gemm_bf16_and_casts(dev, M, N, K):
         assert torch.equal(vr.cpu(), ops.cast_bf16(view).cpu()) and torch.equal(vt.cpu(), ops.cast_transpose_bf16(view).cpu())
 
 
+@pytest.mark.parametrize("M,N,K,splitk", [(3000, 2990, 4104, 1), (3000, 2990, 4104, 3), (2500, 2600, 520, 1)])
+def test_gemm_bf16_large_tiles(dev, M, N, K, splitk):
+    """The 256x256 LDS-DMA kernel in both wave layouts (8 waves for K > 2048, 16 waves below) with ragged M / N edges, a k range that
+    is not a multiple of the 64-deep tile (4104 = 64*64 + 8) and deterministic split-K; bias on the un-split calls."""
+    from asr_amd import ops
+    A, B, bias = T_(4, M, K), T_(5, N, K), T_(6, N)
+    Ab, Bb = ops.cast_bf16(g(A, dev)), ops.cast_bf16(g(B, dev))
+    ref = Ab.double() @ Bb.double().t()                                        # fp64 on the GPU (torch), same rounded operands
+    if splitk == 1:
+        out = ops.gemm_bf16_nt(Ab, Bb, bias=g(bias, dev), splitk=1)
+        assert rel_l2(out.cpu(), (ref + g(bias, dev).double()).cpu()) < 3e-6
+    else:
+        out = ops.gemm_bf16_nt(Ab, Bb, splitk=splitk)
+        out2 = ops.gemm_bf16_nt(Ab, Bb, splitk=splitk)
+        assert torch.equal(out, out2) and rel_l2(out.cpu(), ref.cpu()) < 3e-6
+
+
 # ---------------------------------------------------------------------------------------------- BN1d
 @pytest.mark.parametrize("M,H", [(50, 24), (1000, 96), (333, 1312), (64, 5)])
 def test_bn1d(dev, M, H):
