@@ -1,8 +1,10 @@
-// Measurement probe (not product code): do the per-XCD L2s keep a read-only working set across dependent kernel launches when the
-// dispatch packet asks for NO acquire fence?  HIP always uses agent (or system) scope, which invalidates the L2s of a multi-XCD
-// device at every kernel start — that is why the recurrent step kernels re-stream 12.6 MB of packed W_hh per launch
-// (profiles/r01_pmc).  Here 256 workgroups stream 128 slices of 98 KB (the C3 geometry) from their own AQL queue with barrier-bit
-// packets whose acquire scope is AGENT or NONE; the time per launch is the answer.
+// Measurement probe (not product code): what does one launch of the recurrent step kernel pay to read (a) its read-only
+// operand (packed W_hh: 128 slices x 96 KB, the C3 geometry) and (b) FRESH data written by the previous launch from all XCDs
+// (the packed h_t / dGh operand)?  256 workgroups are dispatched from an own AQL queue with barrier-bit packets whose acquire
+// scope is AGENT (what HIP uses) or NONE, so that the cost of the launch-boundary L2 invalidate can be separated.
+//   usage: probe_l2_residency <hsaco> <slice KB> <exchange 0|1> <fresh KB> <mode>      (modes: see probe_l2_kernel.hip)
+// Findings on MI355X (profiles/r01_probe_l2_residency.txt): the read-only set STAYS L2-resident across launches (acquire
+// AGENT costs 0.14 us more than NONE); the fresh cross-XCD read is the long pole (+2.4 us for 64 KB per workgroup).
 #include <hip/hip_runtime.h>
 #include <hsa/hsa.h>
 #include <cstdio>

@@ -1,0 +1,10 @@
+#!/bin/bash
+# runs the L2 residency / fresh-data probe over its configurations (on the GPU box) -> gpurun_out/probe_l2_residency.txt
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+P=scripts/build/probe_l2_residency; K=scripts/build/probe_l2_kernel.hsaco
+{
+  echo "== read-only operand only (96 KB slice per workgroup)"; timeout 60 $P $K 96 0
+  for kb in 1 16 64; do echo "== + ${kb} KB fresh per workgroup, every workgroup reads it (mode 0)"; timeout 60 $P $K 96 1 $kb 0; done
+  for m in 1 2 3 4; do echo "== + 64 KB fresh, mode $m"; timeout 60 $P $K 96 1 64 $m; done
+} 2>&1 | grep -v amdgpu.ids | tee gpurun_out/probe_l2_residency.txt
