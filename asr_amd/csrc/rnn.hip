@@ -334,21 +334,21 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(const float* pk, 
 // ------------------------------------------------------------------------------------------
 // Preloaded arguments as in the forward kernel: operand bases + the three HBM-streamed epilogue inputs (saved gates, aux, dy).
 //   s_H = s | H << 16;  T_B = T | B << 16;  nbt16_dbg = tiles | flags << 16
-template <int G, int MB, bool BF>
+template <int G, int MB, int NS, bool BF>
 __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(const float* pk, const float* wp, float* gxbase, float* auxbase, const float* dy,
                                                                int s_H, int T_B, int nbt16_dbg, int lddy, RnnArgs a) {
   // bit 2 of the flags: gxbase is really the packed bf16 gate-record buffer (RnnArgs::gates_bf), preloaded in gx's place
   const __bf16* gates_bf = ((nbt16_dbg >> 16) & 4) ? reinterpret_cast<const __bf16*>(gxbase) : nullptr;
-  __shared__ __attribute__((aligned(16))) f32x4 red[NW][MB][64];
+  __shared__ __attribute__((aligned(16))) f32x4 red[NW][MB * NS][64];
   constexpr int NTHR = NW * 64;
-  constexpr int PAIRS = (MB * 256 + NTHR - 1) / NTHR;
+  constexpr int PAIRS = (MB * NS * 256 + NTHR - 1) / NTHR;
   const int dir = blockIdx.z;
   const int slice = blockIdx.x, bt = blockIdx.y;
   const int s = s_H & 0xffff, H = (int)((unsigned)s_H >> 16);
   const int T = T_B & 0xffff, B = (int)((unsigned)T_B >> 16);
   const int nbt16 = nbt16_dbg & 0xffff, dbg = nbt16_dbg >> 16;
   const int nsl = (H + 15) >> 4;
-  const int j0 = slice * 16, b0 = bt * (16 * MB);
+  const int j0 = slice * (16 * NS), b0 = bt * (16 * MB);   // slice = blockIdx.x = NS consecutive 16-unit slices
   const int nchb = (G * H + kchunk<BF>() - 1) / kchunk<BF>();
   const bool has_q = s > 0;                        // a step was processed before us: its d-gates feed our carry
   const int t = dir == 0 ? T - 1 - s : s;          // reverse of the forward order
@@ -370,9 +370,9 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(const float* pk, 
 #pragma unroll
     for (int i = 0; i < PAIRS; ++i) {
       const int q = threadIdx.x + i * NTHR;
-      const int jl = q & 15, brow = (q >> 4) & 15, mb = q >> 8;
-      const int b = b0 + mb * 16 + brow, j = j0 + jl;
-      pact[i] = (mb < MB) && b < B && j < H;
+      const int jl = q & 15, brow = (q >> 4) & 15, sub = q >> 8, mb = sub / NS, ns = sub % NS;
+      const int b = b0 + mb * 16 + brow, j = j0 + ns * 16 + jl;
+      pact[i] = (sub < MB * NS) && b < B && j < H;
       plen[i] = 0;
       pax[i] = pprev[i] = pdy[i] = pdc[i] = 0.f;
       const long long row = ((long long)t * B + b) * 2 + dir;
@@ -402,30 +402,35 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(const float* pk, 
     for (int i = 0; i < PAIRS; ++i) {
       if (pact[i]) {
         const int q = threadIdx.x + i * NTHR;
-        const int b = b0 + (q >> 8) * 16 + ((q >> 4) & 15);
+        const int b = b0 + ((q >> 8) / NS) * 16 + ((q >> 4) & 15);
         plen[i] = a.lens[b];
         if (has_q) pdc[i] = dcar_in[bH[i]];
         if (has_pf) {
           const long long prow = ((long long)tpf * B + b) * 2 + dir;
-          pprev[i] = (G == 3) ? a.hbuf[prow * H + (j0 + (q & 15))] : auxbase[prow * H + (j0 + (q & 15))];
+          const int jj = j0 + ((q >> 8) % NS) * 16 + (q & 15);
+          pprev[i] = (G == 3) ? a.hbuf[prow * H + jj] : auxbase[prow * H + jj];
         }
       }
     }
   };
 
-  f32x4 acc[MB][1];
+  f32x4 acc[MB][NS];
 #pragma unroll
-  for (int i = 0; i < MB; ++i) acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int n = 0; n < NS; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   {
     const int nch_eff = (has_q && !(dbg & 1)) ? nchb : 0;            // one code path, see the forward kernel
     const float* pa = pk_in + ((long long)(bt * MB) * nchb) * 256 + lane * 4;
-    const float* pw = wp + (((long long)dir * nsl + slice) * nchb) * 256 + lane * 4;
-    mfma_packed<BF, MB, 1, 6>(acc, nch_eff, wave, pa, (long long)nchb * 256, pw, 0, issue_epilogue_loads);
+    const float* pw = wp + (((long long)dir * nsl + slice * NS) * nchb) * 256 + lane * 4;
+    mfma_packed<BF, MB, NS, (MB * NS > 2 ? 4 : 6)>(acc, nch_eff, wave, pa, (long long)nchb * 256, pw, (long long)nchb * 256, issue_epilogue_loads);
   }
   float* dcar_out = a.dcar + ((long long)((s & 1) * 2 + dir)) * B * H;
 #pragma unroll
-  for (int i = 0; i < MB; ++i) red[wave][i][lane] = acc[i][0];
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int n = 0; n < NS; ++n) red[wave][i * NS + n][lane] = acc[i][n];
   __syncthreads();
   if (dbg & 2) return;
 
@@ -433,9 +438,9 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(const float* pk, 
   for (int i = 0; i < PAIRS; ++i) {
     if (!pact[i]) continue;
     const int q = threadIdx.x + i * NTHR;
-    const int jl = q & 15, brow = (q >> 4) & 15, mb = q >> 8;
+    const int jl = q & 15, brow = (q >> 4) & 15, sub = q >> 8;
     const int src_lane = (brow >> 2) * 16 + jl, reg = brow & 3;
-    const int b = b0 + mb * 16 + brow, j = j0 + jl;
+    const int b = b0 + (sub / NS) * 16 + brow, j = j0 + (sub % NS) * 16 + jl;
     float* gx = gxp[i];
     float* ax = auxbase + rowH[i];
     float* dco = dcar_out + bH[i];
@@ -449,7 +454,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(const float* pk, 
     } else {
       float carry = 0.f;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) carry += red[w][mb][src_lane][reg];
+      for (int w = 0; w < NW; ++w) carry += red[w][sub][src_lane][reg];
       if constexpr (G == 3) {
         const float dh = pdy[i] + carry + pdc[i];
         const float r = pg[i][0], z = pg[i][1], n = pg[i][2], hn = pax[i];
@@ -536,11 +541,16 @@ inline int pick_mb(int B, int H) {
 template <int G, bool BF>
 int launch_steps(bool bwd, RnnArgs a, hipStream_t st) {
   a.dbg = g_ds2_debug_flags;
-  const int mb = pick_mb(a.B, a.H);
-  const int nbt = ceil_div(a.B, 16 * mb);
+  int mb = pick_mb(a.B, a.H);
   a.nsl = ceil_div(a.H, 16);
-  a.nbt16 = nbt * mb;
-  dim3 grid(a.nsl, nbt, 2), block(NW * 64);
+  // backward: the moving operand (dGh, G*H wide, FRESH from the previous launch = through the fabric) costs about twice as much
+  // per byte as the L2-resident W_hh^T slice (profiles/r01_probe_l2_residency.txt), so where the forward kernel takes 32 batch
+  // rows x 16 units per workgroup, the backward kernel takes 16 rows x 32 units: half the fresh bytes, twice the cached ones.
+  const int ns = (bwd && mb == 2 && (a.nsl % 2) == 0 && !(a.dbg & 8)) ? 2 : 1;
+  if (ns == 2) mb = 1;
+  const int nbt = ceil_div(a.B, 16 * mb);
+  a.nbt16 = ceil_div(a.B, 32) * 2;                                   // tile rows of the packed exchange buffers (pk_floats)
+  dim3 grid(a.nsl / ns, nbt, 2), block(NW * 64);
   if (a.nbt16 > 0xffff || a.T > 0xffff || a.B > 0xffff || a.H > 0xffff)
     return ds2_set_error("rnn: T, B, H and the tile count must fit 16 bits (T=%d B=%d H=%d)", a.T, a.B, a.H);
   const int packed = a.nbt16 | ((a.dbg | ((bwd && a.gates_bf) ? 4 : 0)) << 16);   // preloaded dwords: tile count + flags, T | B, s | H
@@ -555,8 +565,9 @@ int launch_steps(bool bwd, RnnArgs a, hipStream_t st) {
       if (mb == 2) hipLaunchKernelGGL((rnn_fwd_step_kernel<G, 2, BF>), grid, block, 0, st, pk, wp, a.gx, prev, a.bhh, s_H, T_B, packed, a);
       else hipLaunchKernelGGL((rnn_fwd_step_kernel<G, 1, BF>), grid, block, 0, st, pk, wp, a.gx, prev, a.bhh, s_H, T_B, packed, a);
     } else {
-      if (mb == 2) hipLaunchKernelGGL((rnn_bwd_step_kernel<G, 2, BF>), grid, block, 0, st, pk, wp, gx_or_rec, a.aux, a.dy, s_H, T_B, packed, a.lddy, a);
-      else hipLaunchKernelGGL((rnn_bwd_step_kernel<G, 1, BF>), grid, block, 0, st, pk, wp, gx_or_rec, a.aux, a.dy, s_H, T_B, packed, a.lddy, a);
+      if (ns == 2) hipLaunchKernelGGL((rnn_bwd_step_kernel<G, 1, 2, BF>), grid, block, 0, st, pk, wp, gx_or_rec, a.aux, a.dy, s_H, T_B, packed, a.lddy, a);
+      else if (mb == 2) hipLaunchKernelGGL((rnn_bwd_step_kernel<G, 2, 1, BF>), grid, block, 0, st, pk, wp, gx_or_rec, a.aux, a.dy, s_H, T_B, packed, a.lddy, a);
+      else hipLaunchKernelGGL((rnn_bwd_step_kernel<G, 1, 1, BF>), grid, block, 0, st, pk, wp, gx_or_rec, a.aux, a.dy, s_H, T_B, packed, a.lddy, a);
     }
   }
   hipError_t e = hipGetLastError();
@@ -565,8 +576,7 @@ int launch_steps(bool bwd, RnnArgs a, hipStream_t st) {
 }
 
 size_t pk_floats(int B, int H, int kdim, int bf16) {   // size in 4-byte units (1 chunk = 1 KiB = 256 units in both precisions)
-  const int mb = pick_mb(B, H);
-  const int nbt16 = ceil_div(B, 16 * mb) * mb;
+  const int nbt16 = ceil_div(B, 32) * 2;
   return (size_t)2 * 2 * nbt16 * ceil_div(kdim, bf16 ? 32 : 16) * 256;
 }
 
