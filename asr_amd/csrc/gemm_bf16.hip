@@ -17,6 +17,8 @@
 // before the MFMAs of tile k and parked in registers; out-of-range rows / k-segments read a zero page
 // (pointer select before the load, no control flow in the loop).
 #include "common.h"
+#include <type_traits>
+#include <cstdint>
 #include <stdlib.h>
 
 namespace {
@@ -243,8 +245,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(BArgs g
   const int arow = (wm * (NI * 32) + l31) * 128;
   const int brow = G_TILE + (wn * (NJ * 32) + l31) * 128;
 
-  stage(0, kbeg);
   if constexpr (PP) {
+    stage(0, kbeg);
     // Schedule per k-step (kk):  [read fragments kk | DMA slice | waits]  BARRIER  [8 MFMAs]  BARRIER.  Group B (wm = 1) runs one
     // barrier behind group A, so A's MFMA section always coincides with B's read section and vice versa.
     //  * fragments of a k-step are complete (lgkmcnt 0) before its first barrier, so a buffer is dead once both groups have passed
@@ -287,28 +289,124 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(BArgs g
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();          // group A catches the barrier group B is one behind on
   } else {
-  for (int kt = 0; kt < nkt; ++kt) {
-    __syncthreads();            // (vmcnt(0) + barrier): tile kt has landed for every wave; buffer (kt+1)&1 is no longer read
-    const bool more = kt + 1 < nkt;                   // block-uniform
-    const char* base = ldsg + (kt & 1) * 2 * G_TILE;
+    // ---- software-pipelined main loop, ONE barrier per k-tile.  The fragments of k-step kk+1 (for kk = 3: of the NEXT tile's
+    // k-step 0) are read while the MFMAs of k-step kk issue, so the matrix pipe never waits for an LDS round trip; the barrier sits in
+    // front of the last k-step, behind 8 MFMAs that are still executing, and the DMA of tile kt+2 goes out right behind it into the
+    // buffer whose last fragment read that barrier has just retired.  Two tiles of DMA are in flight at any time.
+    //   order per tile:  R(1) M(0) | R(2) M(1) | R(3) M(2) | wait own DMA + own reads, BARRIER | DMA(kt+2) R(next 0) M(3)
+    // LDS-DMA visibility: a tile is read only after every wave's vmcnt(0) AND a barrier (guide: "one barrier after the wait").
+    const char* zp = reinterpret_cast<const char*>(g_zero16);
+    // rows beyond M / N are CLAMPED to the last valid row instead of zero-filled: they only feed C rows / columns that are never stored
+    const char* qA[NP];
+    const char* qB[NP];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      // next tile's DMA is issued in four slices, each in the shadow of the previous k-step's MFMAs
-      if (more) {
-#pragma unroll
-        for (int i = (NP * kk) / 4; i < (NP * (kk + 1)) / 4; ++i) stage_part((kt + 1) & 1, kbeg + (kt + 1) * BK, i);
-      }
-      bf16x8 a[NI], b[NJ];
-#pragma unroll
-      for (int i = 0; i < NI; ++i) a[i] = *reinterpret_cast<const bf16x8*>(base + arow + i * 32 * 128 + koff[kk]);
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const bf16x8*>(base + brow + j * 32 * 128 + koff[kk]);
-#pragma unroll
-      for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    for (int i = 0; i < NP; ++i) {
+      const int r = (wave + NWV * i) * 8 + prow;
+      qA[i] = reinterpret_cast<const char*>(A + (long long)min(m0 + r, g.M - 1) * g.lda + segk[i] + kbeg);
+      qB[i] = reinterpret_cast<const char*>(B + (long long)min(n0 + r, g.N - 1) * g.ldb + segk[i] + kbeg);
     }
-  }
+    const int nfull = (g.nt_store & 2) ? 1 : (kend - kbeg) / BK;       // tiles that lie completely inside [kbeg, kend)  (bit 1: timing experiment)
+    // piece i (8 rows of A + 8 rows of B per wave) of tile kt -> buffer buf.  Tiles are staged in order, so the pointers just advance.
+    auto stage_piece = [&](int buf, int kt, int i) {
+      char* dA = ldsg + buf * 2 * G_TILE + (wave + NWV * i) * 1024;
+      if (kt < nfull) {
+        glds16(qA[i], dA);
+        glds16(qB[i], dA + G_TILE);
+        qA[i] += BK * 2;
+        qB[i] += BK * 2;
+      } else if (!(g.nt_store & 2)) {                 // the K tail: per-segment bounds (the pointers already stand on this tile)
+        const bool kok = kbeg + kt * BK + segk[i] + 8 <= kend;
+        glds16(kok ? qA[i] : zp, dA);
+        glds16(kok ? qB[i] : zp, dA + G_TILE);
+      }
+    };
+    auto stage_tile = [&](int buf, int kt) {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) stage_piece(buf, kt, i);
+    };
+    // The fragment reads and their waits are inline asm, and every read is issued in the execution shadow of an MFMA (one read
+    // behind each of the first NI + NJ MFMAs of a k-step): a 32x32x16 MFMA occupies the matrix pipe for 32 cycles during which its
+    // wave is free to issue other instructions, whereas reads issued in a block in front of the MFMAs cost ~20 % of the loop when the
+    // two waves of a SIMD run in step.  Left to the compiler, every wait for an LDS read also becomes lgkmcnt(0) in FRONT of the MFMAs.
+    // Each wait names the registers it retires as in/out operands, so the MFMAs that consume them cannot be scheduled above it.
+    f32x4 fa[2][NI], fb[2][NJ];
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void*)ldsg;
+    unsigned ra[4], rb[4];                              // byte address of this lane's fragment slot per k-step, buffer 0
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) { ra[kk] = lds0 + arow + koff[kk]; rb[kk] = lds0 + brow + koff[kk]; }
+    static_assert(NI + NJ <= NI * NJ + 2 && NI <= 4 && NJ <= 2, "interleave below");
+    constexpr int NR = NI + NJ;                          // fragment reads per k-step
+    // read r of a k-step, in the order the next k-step consumes them: A0, B0 .. B(NJ-1), A1 .. A(NI-1)
+#define G_ISA(r_) ((r_) == 0 || (r_) > NJ)
+#define G_IDX(r_) ((r_) == 0 ? 0 : (r_) <= NJ ? (r_) - 1 : (r_) - NJ)
+#define G_RD1(set, bufoff, kk, r_)                                                                                                    \
+  do {                                                                                                                                \
+    if ((r_) < NR && G_ISA(r_))                                                                                                       \
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[set][(r_) < NR && G_ISA(r_) ? G_IDX(r_) : 0]) : "v"(ra[kk] + (bufoff)), \
+                   "n"(((r_) < NR && G_ISA(r_) ? G_IDX(r_) : 0) * 4096));                                                             \
+    else if ((r_) < NR)                                                                                                               \
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[set][(r_) < NR && !G_ISA(r_) ? G_IDX(r_) : 0]) : "v"(rb[kk] + (bufoff)), \
+                   "n"(((r_) < NR && !G_ISA(r_) ? G_IDX(r_) : 0) * 4096));                                                            \
+  } while (0)
+    // every LDS read of this wave has returned (both fragment sets complete); WAITSTR may add vmcnt(0)
+#define G_RETIRE_ALL(WAITSTR)                                                                                                         \
+  asm volatile(WAITSTR " lgkmcnt(0)"                                                                                                  \
+               : "+v"(fa[0][0]), "+v"(fa[0][NI > 1 ? 1 : 0]), "+v"(fa[0][NI > 2 ? 2 : 0]), "+v"(fa[0][NI > 3 ? 3 : 0]),               \
+                 "+v"(fb[0][0]), "+v"(fb[0][NJ > 1 ? 1 : 0]),                                                                         \
+                 "+v"(fa[1][0]), "+v"(fa[1][NI > 1 ? 1 : 0]), "+v"(fa[1][NI > 2 ? 2 : 0]), "+v"(fa[1][NI > 3 ? 3 : 0]),               \
+                 "+v"(fb[1][0]), "+v"(fb[1][NJ > 1 ? 1 : 0])                                                                          \
+               :                                                                                                                      \
+               : "memory")
+    // One k-step: the MFMAs of fragment set `cur` row by row; behind MFMA m goes read m of k-step kk_n (buffer offset off_n) into set
+    // `nxt` and — when DMA is true — piece m of tile kt+2.  Before row i a COUNTED wait retires exactly the fragments that row needs
+    // (A_i, for i = 0 also every B): of the previous step's NR reads NI-1-i may still be in flight, plus the min(i*NJ, NR) reads this
+    // step has issued so far — every fragment gets 6 to 9 MFMA times (190-290 cycles) between its issue and its first use.
+#define G_STEP(cur, nxt, off_n, kk_n, DMA)                                                                                            \
+  do {                                                                                                                                \
+    _Pragma("unroll") for (int m_ = 0; m_ < NI * NJ; ++m_) {                                                                          \
+      if (m_ % NJ == 0)                                                                                                               \
+        asm volatile("s_waitcnt lgkmcnt(%3)"                                                                                          \
+                     : "+v"(fa[cur][m_ / NJ]), "+v"(fb[cur][0]), "+v"(fb[cur][NJ - 1])                                                \
+                     : "n"(NI - 1 - m_ / NJ + ((m_ / NJ) * NJ < NR ? (m_ / NJ) * NJ : NR))                                            \
+                     : "memory");                                                                                                     \
+      acc[m_ / NJ][m_ % NJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[cur][m_ / NJ]),                   \
+                                                                     __builtin_bit_cast(bf16x8, fb[cur][m_ % NJ]), acc[m_ / NJ][m_ % NJ], 0, 0, 0); \
+      __builtin_amdgcn_sched_barrier(0);                                                                                              \
+      G_RD1(nxt, off_n, kk_n, m_);                                                                                                    \
+      if ((DMA) && m_ < NP && kt + 2 < nkt) stage_piece(kt & 1, kt + 2, m_);                                                          \
+      __builtin_amdgcn_sched_barrier(0);                                                                                              \
+    }                                                                                                                                 \
+  } while (0)
+    stage_tile(0, 0);
+    if (nkt > 1) {
+      stage_tile(1, 1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");   // tile 0 has landed; tile 1 may still be in flight
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) G_RD1(0, 0u, 0, r);
+    for (int kt = 0; kt < nkt; ++kt) {
+      const unsigned boff = (kt & 1) * 2 * G_TILE, noff = ((kt + 1) & 1) * 2 * G_TILE;
+      __builtin_amdgcn_sched_barrier(0);
+      G_STEP(0, 1, boff, 1, false);
+      G_STEP(1, 0, boff, 2, false);
+      G_STEP(0, 1, boff, 3, false);
+      // own DMA of tile kt+1 has landed and own reads of buffer kt&1 are complete; past the barrier that holds for every wave:
+      // tile kt+1 may be read, buffer kt&1 may be refilled (the last k-step's MFMAs still run from registers)
+      G_RETIRE_ALL("s_waitcnt vmcnt(0)");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      G_STEP(1, 0, noff, 0, true);                     // (after the last tile: harmless reads of stale LDS, retired below)
+    }
+    G_RETIRE_ALL("s_waitcnt");
+#undef G_RD1
+#undef G_ISA
+#undef G_IDX
+#undef G_RETIRE_ALL
+#undef G_STEP
   }
 
   float* C;
@@ -516,6 +614,7 @@ extern "C" int ds2_gemm_bf16_nt(int M, int N, int K, const void* A, int lda, lon
   g.splitk = splitk; g.kchunk = kchunk; g.accumulate = accumulate; g.partial = (float*)workspace;
   static const char* nt_env = getenv("DS2_GEMM_NT");       // tuning override, default on
   g.nt_store = nt_env ? (nt_env[0] != '0') : 1;
+  if (const char* d = getenv("DS2_GEMM_DBG")) g.nt_store |= atoi(d) << 1;   // timing experiments only (wrong results)
   hipStream_t s = (hipStream_t)stream;
   // 256 x 256 LDS-DMA kernel whenever its tiles cover at least half the chip; the 128 x 128 kernel for everything smaller
   const long long tiles256 = (long long)ceil_div(N, 256) * ceil_div(M, 256) * batch * splitk;

@@ -1,0 +1,3 @@
+for cfg in "" "DS2_OVERLAP=1" "DS2_GEMM_TILE=128" "DS2_OVERLAP=1 DS2_GEMM_TILE=128"; do
+  echo "== [$cfg]"; env $cfg timeout 300 python bench.py --workload c3 --steps 8 --warmup 3 --no-cpu-baseline 2>&1 | grep -o '"ms_per_step": [0-9.]*'
+done
