@@ -684,16 +684,16 @@ extern "C" int ds2_cast_transpose_bf16(const float* src, int ld_src, void* dst, 
   return launch_cast_transpose(src, ld_src, dst, ld_dst, nullptr, 0, R, Cc, nullptr, stream);
 }
 
-// Both bf16 copies from one read of src (R, C) fp32: dst_r (R, ld_r) row-major and dst_t (C, ld_t) transposed; pads zero.
+// Both bf16 copies from one read of src (R, C) fp32: dst_r (R, ld_r) row-major (may be NULL: not produced) and dst_t (C, ld_t) transposed; pads zero.
 // ld_r % 8 == 0, C <= ld_r < C + 8 ; ld_t % 8 == 0, ld_t >= R.  colsum (C) fp32, optional: column sums of src from the same
 // read (the bias gradient), needs ws of ds2_cast_bf16_both_workspace_bytes(R, C).
 extern "C" size_t ds2_cast_bf16_both_workspace_bytes(int R, int Cc) { return (size_t)ceil_div(R, 64) * Cc * 2 * sizeof(float); }
 
 extern "C" int ds2_cast_bf16_both(const float* src, int ld_src, void* dst_r, int ld_r, void* dst_t, int ld_t, int R, int Cc, float* colsum,
                                   void* ws, size_t ws_bytes, void* stream) {
-  DS2_REQUIRE(src && dst_r && dst_t && R > 0 && Cc > 0, "ds2_cast_bf16_both: bad args");
-  DS2_REQUIRE(ld_t >= R && (ld_t % 8) == 0 && ld_r >= Cc && ld_r < Cc + 8 && (ld_r % 8) == 0, "ds2_cast_bf16_both: bad pitches (ld_r=%d ld_t=%d)",
-              ld_r, ld_t);
+  DS2_REQUIRE(src && dst_t && R > 0 && Cc > 0, "ds2_cast_bf16_both: bad args");
+  DS2_REQUIRE(ld_t >= R && (ld_t % 8) == 0 && (!dst_r || (ld_r >= Cc && ld_r < Cc + 8 && (ld_r % 8) == 0)),
+              "ds2_cast_bf16_both: bad pitches (ld_r=%d ld_t=%d)", ld_r, ld_t);
   if (colsum) DS2_REQUIRE(ws && ws_bytes >= ds2_cast_bf16_both_workspace_bytes(R, Cc), "ds2_cast_bf16_both: workspace too small");
   int rc = launch_cast_transpose(src, ld_src, dst_t, ld_t, dst_r, ld_r, R, Cc, colsum ? (float*)ws : nullptr, stream);
   if (rc || !colsum) return rc;

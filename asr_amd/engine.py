@@ -238,14 +238,19 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
                 dbih.copy_(dbih_sum if bf else ops.colsum(dgx))
             dbhh = Gr[f"rnns.{l}.bhh_cat"]                                                        # (2, GH)
             dbhh.copy_(dbih.view(2, G * H))
-            if G == 3:
+            auxT = None
+            if G == 3 and T > 1 and bfd:
+                # d(b_hn) = column sums of d(hn): taken from the read that produces the transposed bf16 copy for dW_hh below
+                dbn = torch.empty(2 * H, dtype=torch.float32, device=dy.device)
+                auxT = ops.cast_transpose_bf16(lc.aux, colsum=dbn)
+                dbhh[:, 2 * H:] = dbn.view(2, H)
+            elif G == 3:
                 dbhh[:, 2 * H:] = ops.colsum(lc.aux).view(2, H)
             # dW_hh[dir] = sum_t dGh[t]^T h_prev[t]  (h_prev = h[t-1] fwd / h[t+1] reverse)
             dwhh = Gr[f"rnns.{l}.whh_cat"]                                                        # (2, GH, H)
             if T > 1 and bfd:
                 # bf16 MFMA path: transposed bf16 copies (dgxT: (2GH, M)), the time shift is a column offset of B elements
                 hT = ops.cast_transpose_bf16(lc.hbuf)                                             # (2H, M)
-                auxT = ops.cast_transpose_bf16(lc.aux) if G == 3 else None
                 rows = 2 * H if G == 3 else 4 * H
                 # both directions per launch: direction 0 pairs rows t of dGh with h[t-1], direction 1 rows t with h[t+1]
                 ka = (slice(B, M), slice(0, M - B))

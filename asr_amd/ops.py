@@ -97,13 +97,22 @@ def cast_bf16(src: Tensor) -> Tensor:
     return dst
 
 
-def cast_transpose_bf16(src: Tensor) -> Tensor:
-    """(R, C) fp32 row-major view -> (C, pad8(R)) bf16 = src^T, pad columns zero."""
+def cast_transpose_bf16(src: Tensor, colsum: Optional[Tensor] = None) -> Tensor:
+    """(R, C) fp32 row-major view -> (C, pad8(R)) bf16 = src^T, pad columns zero.
+    colsum: optional contiguous fp32 tensor of C elements that receives the column sums of src from the same read."""
     _chk_f32(src)
     R, Cc = src.shape
+    lib = _lib.load()
     dst = torch.empty(Cc, _pad8(R), dtype=torch.bfloat16, device=src.device)
-    _lib.check(_lib.load().ds2_cast_transpose_bf16(src.data_ptr(), _row_pitch(src), dst.data_ptr(), dst.size(1), R, Cc, _stream()),
-               "ds2_cast_transpose_bf16")
+    if colsum is None:
+        _lib.check(lib.ds2_cast_transpose_bf16(src.data_ptr(), _row_pitch(src), dst.data_ptr(), dst.size(1), R, Cc, _stream()),
+                   "ds2_cast_transpose_bf16")
+        return dst
+    assert colsum.dtype == torch.float32 and colsum.is_cuda and colsum.is_contiguous() and colsum.numel() == Cc
+    wsb = lib.ds2_cast_bf16_both_workspace_bytes(R, Cc)
+    ws = _ws(wsb, src.device)
+    _lib.check(lib.ds2_cast_bf16_both(src.data_ptr(), _row_pitch(src), 0, 0, dst.data_ptr(), dst.size(1), R, Cc, colsum.data_ptr(),
+                                      ws.data_ptr(), wsb, _stream()), "ds2_cast_bf16_both")
     return dst
 
 

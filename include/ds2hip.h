@@ -50,7 +50,7 @@ int ds2_gemm_bf16_nt(int M, int N, int K, const void* A, int lda, long long stri
                      size_t workspace_bytes, void* stream);
 int ds2_cast_bf16(const float* src, int ld_src, void* dst, int ld_dst, int R, int Cc, void* stream);
 int ds2_cast_transpose_bf16(const float* src, int ld_src, void* dst, int ld_dst, int R, int Cc, void* stream);
-/* both copies from ONE read of src: dst_r (R, ld_r) = bf16(src), dst_t (C, ld_t) = bf16(src)^T, pads zero
+/* both copies from ONE read of src: dst_r (R, ld_r) = bf16(src) (NULL: skipped), dst_t (C, ld_t) = bf16(src)^T, pads zero
  * (ld_r % 8 == 0, C <= ld_r < C + 8; ld_t % 8 == 0, ld_t >= R); colsum (C) optional: column sums of src from the same read
  * (the bias gradient db_ih = sum_rows dGx), then ws >= ds2_cast_bf16_both_workspace_bytes(R, C) */
 size_t ds2_cast_bf16_both_workspace_bytes(int R, int Cc);
