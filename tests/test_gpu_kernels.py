@@ -300,7 +300,10 @@ def test_conv1_bf16(dev, B, Tin, lens_in):
 # ---------------------------------------------------------------------------------------------- RNN
 @pytest.mark.parametrize("bf", [False, True])
 @pytest.mark.parametrize("kind,H,B,T,lens", [("gru", 32, 3, 9, [9, 6, 2]), ("lstm", 24, 3, 9, [9, 6, 2]), ("gru", 72, 20, 17, None),
-                                             ("lstm", 40, 37, 11, None), ("gru", 16, 1, 5, [5])])
+                                             ("lstm", 40, 37, 11, None), ("gru", 16, 1, 5, [5]),
+                                             # wide layers: more 16x16 tiles than CUs -> 32-row tiles forward, 16 rows x 32 units backward
+                                             # (even slice count) or 32 x 16 backward (odd slice count); ragged last batch tile
+                                             ("gru", 1056, 33, 4, None), ("lstm", 1056, 20, 3, None), ("gru", 1040, 33, 3, None)])
 def test_rnn_fwd_bwd(dev, kind, H, B, T, lens, bf):
     tol = 3e-2 if bf else 1.0      # bf16 operands in the h W_hh product: separately stated tolerance (x the fp32 asserts' 2e-5..5e-5 -> 2e-2)
     from asr_amd import ops
