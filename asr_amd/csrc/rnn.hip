@@ -169,12 +169,12 @@ __device__ __forceinline__ void mfma_packed(f32x4 (&acc)[MB][NB], int nch, int w
 // memory to compute their addresses, so they all issue at wave launch instead of behind a scalar load of the kernel-argument
 // segment that measured 0.6-2 us (profiles/r01_probe_rnn_timeline.txt).  The remaining arguments (RnnArgs) arrive under them.
 //   prev = h buffer (GRU) / cell-state buffer (LSTM);  s_H = s | H << 16;  T_B = T | B << 16;  nbt16_dbg = tiles | flags << 16
-template <int G, int MB, bool BF>
+template <int G, int MB, int NS, bool BF>
 __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(const float* pk, const float* wp, float* gxbase, const float* prev,
                                                                const float* bhh, int s_H, int T_B, int nbt16_dbg, RnnArgs a) {
-  __shared__ __attribute__((aligned(16))) f32x4 red[NW][MB * G][64];
+  __shared__ __attribute__((aligned(16))) f32x4 red[NW][MB * NS * G][64];
   constexpr int NTHR = NW * 64;
-  constexpr int PAIRS = (MB * 256 + NTHR - 1) / NTHR;   // (b, j) pairs per thread
+  constexpr int PAIRS = (MB * NS * 256 + NTHR - 1) / NTHR;   // (b, j) pairs per thread
   const int dir = blockIdx.z;
   const int slice = blockIdx.x, bt = blockIdx.y;
   const int s = s_H & 0xffff, H = (int)((unsigned)s_H >> 16);
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(const float* pk, 
   RNN_TRACE(s, 0);
   const int nbt16 = nbt16_dbg & 0xffff, dbg = nbt16_dbg >> 16;
   const int nsl = (H + 15) >> 4;
-  const int j0 = slice * 16, b0 = bt * (16 * MB);
+  const int j0 = slice * (16 * NS), b0 = bt * (16 * MB);   // slice = blockIdx.x = NS consecutive 16-unit slices
   const int nch = (H + kchunk<BF>() - 1) / kchunk<BF>();
   const bool has_prev = s > 0;
   const int t = dir == 0 ? s : T - 1 - s;
@@ -203,9 +203,9 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(const float* pk, 
 #pragma unroll
     for (int i = 0; i < PAIRS; ++i) {
       const int q = threadIdx.x + i * NTHR;
-      const int jl = q & 15, brow = (q >> 4) & 15, mb = q >> 8;
-      const int b = b0 + mb * 16 + brow, j = j0 + jl;
-      pact[i] = (mb < MB) && b < B && j < H;
+      const int jl = q & 15, brow = (q >> 4) & 15, sub = q >> 8, mb = sub / NS, ns = sub % NS;
+      const int b = b0 + mb * 16 + brow, j = j0 + ns * 16 + jl;
+      pact[i] = (sub < MB * NS) && b < B && j < H;
       plen[i] = 0;
       pprev[i] = 0.f;
       const long long row = ((long long)t * B + b) * 2 + dir;
@@ -229,30 +229,30 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(const float* pk, 
 #pragma unroll
     for (int i = 0; i < PAIRS; ++i) {
       const int q = threadIdx.x + i * NTHR;
-      const int b = b0 + (q >> 8) * 16 + ((q >> 4) & 15);
+      const int b = b0 + ((q >> 8) / NS) * 16 + ((q >> 4) & 15);
       if (pact[i]) plen[i] = a.lens[b];
     }
   };
 
-  f32x4 acc[MB][G];
+  f32x4 acc[MB][NS * G];
 #pragma unroll
   for (int i = 0; i < MB; ++i)
 #pragma unroll
-    for (int g = 0; g < G; ++g) acc[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < NS * G; ++g) acc[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   {
     // one code path (no GEMM at s == 0 / under ablation = zero chunks): the compiler must not merge the epilogue loads of two
     // branches back in front of the operand loads
     const int nch_eff = (has_prev && !(dbg & 1)) ? nch : 0;
     const float* pa = pk_in + ((long long)(bt * MB) * nch) * 256 + lane * 4;                      // + mb*nch*256 + c*256
-    const float* pw = wp + ((((long long)dir * nsl + slice) * G) * nch) * 256 + lane * 4;           // + g*nch*256 + c*256
-    mfma_packed<BF, MB, G, 4>(acc, nch_eff, wave, pa, (long long)nch * 256, pw, (long long)nch * 256, issue_epilogue_loads);
+    const float* pw = wp + ((((long long)dir * nsl + slice * NS) * G) * nch) * 256 + lane * 4;      // + (n*G+g)*nch*256 + c*256
+    mfma_packed<BF, MB, NS * G, (MB * NS * G > 6 ? 3 : 4)>(acc, nch_eff, wave, pa, (long long)nch * 256, pw, (long long)nch * 256, issue_epilogue_loads);
   }
   RNN_TRACE(s, 2);
 #pragma unroll
   for (int i = 0; i < MB; ++i)
 #pragma unroll
-    for (int g = 0; g < G; ++g) red[wave][i * G + g][lane] = acc[i][g];
+    for (int g = 0; g < NS * G; ++g) red[wave][i * NS * G + g][lane] = acc[i][g];
   __syncthreads();
   RNN_TRACE(s, 3);
   if (dbg & 2) return;
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(const float* pk, 
   for (int i = 0; i < PAIRS; ++i) {
     if (!pact[i]) continue;
     const int q = threadIdx.x + i * NTHR;
-    const int jl = q & 15, brow = (q >> 4) & 15, mb = q >> 8;
+    const int jl = q & 15, brow = (q >> 4) & 15, sub = q >> 8;
     const int src_lane = (brow >> 2) * 16 + jl, reg = brow & 3;
     float* gx = gxp[i];
     float* ho = a.hbuf + rowH[i];
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(const float* pk, 
     for (int g = 0; g < G; ++g) {
       float sum = 0.f;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) sum += red[w][mb * G + g][src_lane][reg];
+      for (int w = 0; w < NW; ++w) sum += red[w][sub * G + g][src_lane][reg];
       gh[g] = sum + pb[i][g];
     }
 #ifdef DS2_RNN_TRACE
@@ -546,7 +546,7 @@ int launch_steps(bool bwd, RnnArgs a, hipStream_t st) {
   // backward: the moving operand (dGh, G*H wide, FRESH from the previous launch = through the fabric) costs about twice as much
   // per byte as the L2-resident W_hh^T slice (profiles/r01_probe_l2_residency.txt), so where the forward kernel takes 32 batch
   // rows x 16 units per workgroup, the backward kernel takes 16 rows x 32 units: half the fresh bytes, twice the cached ones.
-  const int ns = (bwd && mb == 2 && (a.nsl % 2) == 0 && !(a.dbg & 8)) ? 2 : 1;
+  const int ns = (mb == 2 && (a.nsl % 2) == 0 && ((bwd && !(a.dbg & 8)) || (!bwd && (a.dbg & 16)))) ? 2 : 1;
   if (ns == 2) mb = 1;
   const int nbt = ceil_div(a.B, 16 * mb);
   a.nbt16 = ceil_div(a.B, 32) * 2;                                   // tile rows of the packed exchange buffers (pk_floats)
@@ -562,8 +562,9 @@ int launch_steps(bool bwd, RnnArgs a, hipStream_t st) {
   for (int s = 0; s < a.T; ++s) {
     const int s_H = s | (a.H << 16);
     if (!bwd) {
-      if (mb == 2) hipLaunchKernelGGL((rnn_fwd_step_kernel<G, 2, BF>), grid, block, 0, st, pk, wp, a.gx, prev, a.bhh, s_H, T_B, packed, a);
-      else hipLaunchKernelGGL((rnn_fwd_step_kernel<G, 1, BF>), grid, block, 0, st, pk, wp, a.gx, prev, a.bhh, s_H, T_B, packed, a);
+      if (ns == 2) hipLaunchKernelGGL((rnn_fwd_step_kernel<G, 1, 2, BF>), grid, block, 0, st, pk, wp, a.gx, prev, a.bhh, s_H, T_B, packed, a);
+      else if (mb == 2) hipLaunchKernelGGL((rnn_fwd_step_kernel<G, 2, 1, BF>), grid, block, 0, st, pk, wp, a.gx, prev, a.bhh, s_H, T_B, packed, a);
+      else hipLaunchKernelGGL((rnn_fwd_step_kernel<G, 1, 1, BF>), grid, block, 0, st, pk, wp, a.gx, prev, a.bhh, s_H, T_B, packed, a);
     } else {
       if (ns == 2) hipLaunchKernelGGL((rnn_bwd_step_kernel<G, 1, 2, BF>), grid, block, 0, st, pk, wp, gx_or_rec, a.aux, a.dy, s_H, T_B, packed, a.lddy, a);
       else if (mb == 2) hipLaunchKernelGGL((rnn_bwd_step_kernel<G, 2, 1, BF>), grid, block, 0, st, pk, wp, gx_or_rec, a.aux, a.dy, s_H, T_B, packed, a.lddy, a);
