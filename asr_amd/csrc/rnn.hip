@@ -246,7 +246,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(const float* pk, 
     const int nch_eff = (has_prev && !(dbg & 1)) ? nch : 0;
     const float* pa = pk_in + ((long long)(bt * MB) * nch) * 256 + lane * 4;                      // + mb*nch*256 + c*256
     const float* pw = wp + ((((long long)dir * nsl + slice * NS) * G) * nch) * 256 + lane * 4;      // + (n*G+g)*nch*256 + c*256
-    mfma_packed<BF, MB, NS * G, (MB * NS * G > 6 ? 3 : 4)>(acc, nch_eff, wave, pa, (long long)nch * 256, pw, (long long)nch * 256, issue_epilogue_loads);
+    mfma_packed<BF, MB, NS * G, (NS == 2 ? 3 : 4)>(acc, nch_eff, wave, pa, (long long)nch * 256, pw, (long long)nch * 256, issue_epilogue_loads);
   }
   RNN_TRACE(s, 2);
 #pragma unroll
