@@ -437,9 +437,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(BArgs g
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * (NI * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (row < g.M) {
+        if (row < g.M && !((g.nt_store & 32) && r != 0)) {      // (bit 5: timing experiment, 1/16 of the stores)
           float v = acc[i][j][r] + bv;
           float* p = C + (long long)row * ldc + col;
+          if (g.nt_store & 64) p = C + (long long)((blockIdx.x % 120) * 256 + (row & 255)) * ldc + (col & 255);   // timing experiment: L2-resident target
           if (!partial && g.accumulate) v += *p;
           // final C is streamed out once (788 MB for the forward Gx) -> non-temporal; split-K slabs are re-read right away -> cached
           if (partial || !g.nt_store) *p = v;
@@ -614,7 +615,9 @@ extern "C" int ds2_gemm_bf16_nt(int M, int N, int K, const void* A, int lda, lon
   g.splitk = splitk; g.kchunk = kchunk; g.accumulate = accumulate; g.partial = (float*)workspace;
   static const char* nt_env = getenv("DS2_GEMM_NT");       // tuning override, default on
   g.nt_store = nt_env ? (nt_env[0] != '0') : 1;
-  if (const char* d = getenv("DS2_GEMM_DBG")) g.nt_store |= atoi(d) << 1;   // timing experiments only (wrong results)
+  // timing experiments only (WRONG RESULTS; scripts/ab_gemm_dbg.sh): 1 = no operand DMA after the first k-tile, 16 = 1/16 of the C
+  // stores, 32 = C stores aimed at an L2-resident region
+  if (const char* d = getenv("DS2_GEMM_DBG")) g.nt_store |= atoi(d) << 1;
   hipStream_t s = (hipStream_t)stream;
   // 256 x 256 LDS-DMA kernel whenever its tiles cover at least half the chip; the 128 x 128 kernel for everything smaller
   const long long tiles256 = (long long)ceil_div(N, 256) * ceil_div(M, 256) * batch * splitk;

@@ -1,1 +1,1 @@
-for d in ${DBGS:-0 1 5}; do echo "== DS2_GEMM_DBG=$d"; DS2_GEMM_DBG=$d timeout 200 python scripts/bench_gemm_square.py 2>&1 | grep TF | head -2; DS2_GEMM_DBG=$d timeout 200 python scripts/bench_gemm.py 2>&1 | grep -E "dXn"; done
+for d in ${DBGS:-0 32}; do for nt in 1 0; do echo "== DS2_GEMM_DBG=$d NT=$nt"; DS2_GEMM_NT=$nt DS2_GEMM_DBG=$d timeout 200 python scripts/bench_gemm.py 2>&1 | grep -E "fwd"; done; done
