@@ -24,9 +24,19 @@ extern "C" __global__ __launch_bounds__(512) void read_w_exchange(const u32x4* _
   // mode (fresh_vec >> 20): 0 = every workgroup reads the fresh data first | 1 = only one workgroup per (XCD, group) reads it at all |
   // 2 = that one reads it first, the other seven of its XCD read W first and the fresh data afterwards (from the XCD's L2, if the
   // fetcher's lines have landed by then)
-  const int mode = fresh_vec >> 20, nfresh = fresh_vec & 0xfffff;
+  const int mode_all = fresh_vec >> 20, nfresh = fresh_vec & 0xfffff;
+  const int mode = mode_all & 7;
   const bool fetcher = (blockIdx.x % 64) < 8;                       // workgroup ids go round-robin over the 8 XCDs
-  auto read_fresh = [&]() { for (int i = threadIdx.x; i < nfresh; i += 512) acc ^= xin[i]; };
+  // all (up to 8) loads of a thread issued before the first use — a plain `for (...) acc ^= xin[i]` loop with a run-time trip count
+  // is NOT unrolled and pays one fabric round trip per iteration (mode bit 3 keeps that serialised form for comparison)
+  auto read_fresh = [&]() {
+    if (mode_all & 8) { for (int i = threadIdx.x; i < nfresh; i += 512) acc ^= xin[i]; return; }
+    u32x4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int idx = threadIdx.x + j * 512; v[j] = xin[min(idx, nfresh - 1)]; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (threadIdx.x + j * 512 < nfresh) acc ^= v[j];
+  };
   auto read_w_all = [&]() {
     for (int i = threadIdx.x; i < vec_per_wg; i += 512 * 4) {
       u32x4 a = p[i], b = p[min(i + 512, vec_per_wg - 1)], c = p[min(i + 1024, vec_per_wg - 1)], d = p[min(i + 1536, vec_per_wg - 1)];

@@ -4,7 +4,8 @@
 // scope is AGENT (what HIP uses) or NONE, so that the cost of the launch-boundary L2 invalidate can be separated.
 //   usage: probe_l2_residency <hsaco> <slice KB> <exchange 0|1> <fresh KB> <mode>      (modes: see probe_l2_kernel.hip)
 // Findings on MI355X (profiles/r01_probe_l2_residency.txt): the read-only set STAYS L2-resident across launches (acquire
-// AGENT costs 0.14 us more than NONE); the fresh cross-XCD read is the long pole (+2.4 us for 64 KB per workgroup).
+// AGENT costs 0.15 us more than NONE); one fresh cross-XCD round trip costs ~0.9 us, 64 KB per workgroup ~1.6 us on top of the
+// read-only slice when every load is in flight at once.
 #include <hip/hip_runtime.h>
 #include <hsa/hsa.h>
 #include <cstdio>
