@@ -617,7 +617,8 @@ extern "C" int ds2_gemm_bf16_nt(int M, int N, int K, const void* A, int lda, lon
   g.nt_store = nt_env ? (nt_env[0] != '0') : 1;
   // timing experiments only (WRONG RESULTS; scripts/ab_gemm_dbg.sh): 1 = no operand DMA after the first k-tile, 16 = 1/16 of the C
   // stores, 32 = C stores aimed at an L2-resident region
-  if (const char* d = getenv("DS2_GEMM_DBG")) g.nt_store |= atoi(d) << 1;
+  static const int dbg_bits = getenv("DS2_GEMM_DBG") ? atoi(getenv("DS2_GEMM_DBG")) << 1 : 0;
+  g.nt_store |= dbg_bits;
   hipStream_t s = (hipStream_t)stream;
   // 256 x 256 LDS-DMA kernel whenever its tiles cover at least half the chip; the 128 x 128 kernel for everything smaller
   const long long tiles256 = (long long)ceil_div(N, 256) * ceil_div(M, 256) * batch * splitk;
