@@ -11,7 +11,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libds2hip.so")
+LIB_PATH = os.environ.get("DS2_LIB_PATH") or os.path.join(_HERE, "lib", "libds2hip.so")   # (override: same-box A/B of two builds)
 
 _lib: Optional[C.CDLL] = None
 

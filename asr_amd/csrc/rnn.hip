@@ -199,7 +199,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(const float* pk, 
   bool pact[PAIRS];
   float* gxp[PAIRS];             // this pair's gate row in gx
   long long rowH[PAIRS], hpi[PAIRS];
-  auto issue_epilogue_loads = [&]() {
+  auto issue_hbm_loads = [&]() {
 #pragma unroll
     for (int i = 0; i < PAIRS; ++i) {
       const int q = threadIdx.x + i * NTHR;
@@ -223,6 +223,8 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(const float* pk, 
         if (has_prev) pprev[i] = prev[(((long long)tp * B + b) * 2 + dir) * H + j];
       }
     }
+  };
+  auto issue_epilogue_loads = [&]() {
     // the memory-resident arguments are needed from here on (lengths now, output pointers after the barrier)
     hoist_kernargs(a);
     RNN_TRACE(s, 1);
@@ -243,6 +245,11 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(const float* pk, 
   {
     // one code path (no GEMM at s == 0 / under ablation = zero chunks): the compiler must not merge the epilogue loads of two
     // branches back in front of the operand loads
+    // The HBM-latency epilogue operands (gate pre-activations, bias, previous state) go out FIRST: they need only preloaded arguments, cost
+    // ~0.1 us of issue in front of the operand fetch, and their 1-2 us HBM round trip then ends long before the gate math needs them
+    // (issued behind the operand loads they queued behind 160 KB in the in-order memory pipe and were ~0.3 us late: 5.9 -> 5.65 us/step).
+    issue_hbm_loads();
+    asm volatile("" ::: "memory");
     const int nch_eff = (has_prev && !(dbg & 1)) ? nch : 0;
     const float* pa = pk_in + ((long long)(bt * MB) * nch) * 256 + lane * 4;                      // + mb*nch*256 + c*256
     const float* pw = wp + ((((long long)dir * nsl + slice * NS) * G) * nch) * 256 + lane * 4;      // + (n*G+g)*nch*256 + c*256
@@ -396,6 +403,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(const float* pk, 
       }
     }
     // the memory-resident arguments from here on: lengths, the carry of the previous step, h_{prev} / c_{prev}
+    // (issuing the loads above in FRONT of the operand fetch, as the forward kernel does, measured no gain here: +0.4 ms per train step)
     hoist_kernargs(a);
     const float* dcar_in = a.dcar + ((long long)(((s + 1) & 1) * 2 + dir)) * B * H;
 #pragma unroll
