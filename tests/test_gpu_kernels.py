@@ -88,6 +88,10 @@ def test_gemm_bf16_and_casts(dev, M, N, K):
     Ar, At2, cs = ops.cast_bf16_both(g(A, dev), colsum=True)
     assert torch.equal(Ar.cpu(), Ab.cpu()) and torch.equal(At2.cpu(), ops.cast_transpose_bf16(g(A, dev)).cpu())
     assert rel_l2(cs.cpu(), A.double().sum(0)) < 1e-6                  # fp32 column sums of the fp32 source (the bias gradient)
+    # transposed copy + column sums without the row-major copy (d(b_hn) from the pass that builds the dW_hh operand)
+    cs2 = torch.full((K,), float("nan"), device=dev)
+    At3 = ops.cast_transpose_bf16(g(A, dev), colsum=cs2)
+    assert torch.equal(At3.cpu(), At2.cpu()) and torch.equal(cs2.cpu(), cs.cpu())
     if K >= 16:
         view = g(A, dev)[:, 4:K - 3]
         vr, vt = ops.cast_bf16_both(view)
