@@ -160,6 +160,11 @@ __global__ __launch_bounds__(512) void conv1_bf16_fwd_kernel(C1Args a) {
         else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xb, acc0, 0, 0, 0);
       }
     }
+    // The wait must be EXPLICIT: the compiler does not put a vmcnt wait in front of this loop's barrier (it emits a bare s_barrier:
+    // the LDS-DMA issued one iteration ago is not something its fence lowering tracks across the back edge), and without it
+    // the next tile's ds_reads could overtake a still-landing window row — measured as run-to-run differences in ~1 % of forward
+    // passes (scripts/det_check_fwd.py).  vmcnt(0) also covers the previous tile's stores, issued a whole tile ago.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();            // everyone is done reading this window; the other window (DMA'd a whole tile ago) has landed
     if (tile + 2 < tile_end && (tile + 2) * F_TT < len) stage(buf, (tile + 2) * F_TT);     // refill it two tiles ahead
     // the stores of this tile drain under the next tile's MFMAs

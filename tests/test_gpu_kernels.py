@@ -301,6 +301,28 @@ def test_conv1_bf16(dev, B, Tin, lens_in):
     assert rel_l2(dW1.cpu(), w1g.grad) < 1e-5
 
 
+def test_lds_dma_kernels_rerun_bit_identical(dev):
+    """Race screen for the kernels that stage operands with LDS-DMA (global_load_lds): nothing orders a ds_read behind a landing DMA
+    except an explicit vmcnt wait + barrier, and a missing wait only shows as RARE wrong tiles (conv1 forward had one: ~1 % of full-size
+    passes).  Full-size conv1 forward and both wave layouts of the 256-tile GEMM, 300 reruns each, must be bit-identical."""
+    from asr_amd import ops
+    B, Tin = 64, 1001
+    x = torch.randn(B, 1, 161, Tin, device=dev)
+    lens = torch.randint(200, (Tin + 1) // 2 + 1, (B,), dtype=torch.int32, device=dev)
+    lens[0] = (Tin + 1) // 2
+    w1, b1 = torch.randn(32, 1, 41, 11, device=dev) * 0.05, torch.randn(32, device=dev)
+    X16, _ = ops.conv1_gather_bf16(x)
+    wp = ops.conv1_pack_bf16(w1)
+    ref = ops.conv1_fwd_bf16(X16, wp, b1, lens, Tin).clone()
+    for _ in range(300):
+        assert torch.equal(ops.conv1_fwd_bf16(X16, wp, b1, lens, Tin), ref)
+    for (M, N, K) in [(4096, 2048, 1024), (2304, 1024, 6144)]:            # K <= 2048: 16 waves; longer: 8 waves
+        A, Bm = torch.randn(M, K, device=dev).bfloat16(), torch.randn(N, K, device=dev).bfloat16()
+        ref = ops.gemm_bf16_nt(A, Bm).clone()
+        for _ in range(300):
+            assert torch.equal(ops.gemm_bf16_nt(A, Bm), ref)
+
+
 # ---------------------------------------------------------------------------------------------- RNN
 @pytest.mark.parametrize("bf", [False, True])
 @pytest.mark.parametrize("kind,H,B,T,lens", [("gru", 32, 3, 9, [9, 6, 2]), ("lstm", 24, 3, 9, [9, 6, 2]), ("gru", 72, 20, 17, None),
