@@ -9,13 +9,14 @@ from asr_amd import CTCLoss, DeepSpeech, FusedAdamW
 from asr_amd.trainers import DeepSpeechTrainer
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 dev = torch.device("cuda:0")
-rnn, H, L, C, B, tin = bench.WORKLOADS["c3"]
+WL = os.environ.get("WL", "c3")
+rnn, H, L, C, B, tin = bench.WORKLOADS[WL]
 torch.manual_seed(0)
 with tempfile.TemporaryDirectory() as tmp:
     model = DeepSpeech(audio_conf=bench.audio_conf(), decoder=None, label_path=bench.label_file(tmp, C), rnn_type=rnn, rnn_hidden_size=H,
                        rnn_hidden_layers=L, bidirectional=True)
 model.to(dev).train()
-model.precision = "bf16"
+model.precision = os.environ.get("PREC", "bf16")
 x, targets, pct, tsz = bench.synthetic_batch(B, tin, C, 1, ragged=True)
 x = x.to(dev)
 sd0 = {k: v.clone() for k, v in model.state_dict().items()}

@@ -7,7 +7,8 @@ import bench
 from asr_amd import DeepSpeech, engine
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 dev = torch.device("cuda:0")
-rnn, H, L, C, B, tin = bench.WORKLOADS["c3"]
+WL = os.environ.get("WL", "c3")
+rnn, H, L, C, B, tin = bench.WORKLOADS[WL]
 torch.manual_seed(0)
 with tempfile.TemporaryDirectory() as tmp:
     model = DeepSpeech(audio_conf=bench.audio_conf(), decoder=None, label_path=bench.label_file(tmp, C), rnn_type=rnn, rnn_hidden_size=H,

@@ -1,7 +1,6 @@
 cd "$(dirname "$0")/.."
 N=${N:-40}
-echo "== default"; timeout 600 python scripts/det_check.py $N 2>&1 | grep -v amdgpu.ids | cut -c1-200 | tail -4
-echo "== DS2_GEMM_TILE=128"; DS2_GEMM_TILE=128 timeout 600 python scripts/det_check.py $N 2>&1 | grep -v amdgpu.ids | cut -c1-200 | tail -4
-echo "== DS2_GEMM_WAVES=8"; DS2_GEMM_WAVES=8 timeout 600 python scripts/det_check.py $N 2>&1 | grep -v amdgpu.ids | cut -c1-200 | tail -4
-echo "== DS2_GEMM_WAVES=16"; DS2_GEMM_WAVES=16 timeout 600 python scripts/det_check.py $N 2>&1 | grep -v amdgpu.ids | cut -c1-200 | tail -4
-echo "== DS2_GEMM_WAVES=pp"; DS2_GEMM_WAVES=pp timeout 600 python scripts/det_check.py $N 2>&1 | grep -v amdgpu.ids | cut -c1-200 | tail -4
+for cfg in "c3 bf16" "c3 fp32" "c2 bf16" "c4 bf16" "c4 fp32" "c5 bf16" "c1 bf16"; do
+  set -- $cfg
+  echo "== $1 $2"; WL=$1 PREC=$2 timeout 600 python scripts/det_check.py $N 2>&1 | grep -v amdgpu.ids | cut -c1-300 | tail -3
+done
