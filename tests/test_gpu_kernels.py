@@ -316,7 +316,8 @@ def test_lds_dma_kernels_rerun_bit_identical(dev):
     ref = ops.conv1_fwd_bf16(X16, wp, b1, lens, Tin).clone()
     for _ in range(300):
         assert torch.equal(ops.conv1_fwd_bf16(X16, wp, b1, lens, Tin), ref)
-    for (M, N, K) in [(4096, 2048, 1024), (2304, 1024, 6144)]:            # K <= 2048: 16 waves; longer: 8 waves
+    # K <= 2048: 16 waves; longer: 8 waves; K = 1312: a K tail (20.5 k-tiles); 32064: deterministic split-K; odd M/N: clamped edge rows
+    for (M, N, K) in [(4096, 2048, 1024), (2304, 1024, 6144), (4000, 1000, 1312), (3072, 1024, 32064)]:
         A, Bm = torch.randn(M, K, device=dev).bfloat16(), torch.randn(N, K, device=dev).bfloat16()
         ref = ops.gemm_bf16_nt(A, Bm).clone()
         for _ in range(300):
