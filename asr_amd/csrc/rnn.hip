@@ -403,7 +403,8 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(const float* pk, 
       }
     }
     // the memory-resident arguments from here on: lengths, the carry of the previous step, h_{prev} / c_{prev}
-    // (issuing the loads above in FRONT of the operand fetch, as the forward kernel does, measured no gain here: +0.4 ms per train step)
+    // (issuing these loads in FRONT of the operand fetch, as the forward kernel does — the first group alone, or all of them behind an
+    // up-front kernel-argument wait — measured no gain here: this kernel is bound by its 290 KB operand fetch, not by epilogue latency)
     hoist_kernargs(a);
     const float* dcar_in = a.dcar + ((long long)(((s + 1) & 1) * 2 + dir)) * B * H;
 #pragma unroll
