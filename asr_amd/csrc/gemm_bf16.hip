@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(BArgs g) {
 // lane-linearly, so the LDS image has 128-B rows with NO padding; bank conflicts of the fragment reads are removed by
 // an XOR swizzle applied on the per-lane SOURCE address and again on the read: the 16-byte slot p of row r holds
 // k-segment p ^ ((r >> 1) & 7), which puts the 16 rows of every ds_read_b128 lane group on 16 distinct bank quads.
-// The DMA of tile k+1 is issued right after the barrier that publishes tile k and flies during its 32 MFMAs per wave.
+// Main loop: one barrier per k-tile, two tiles of DMA in flight, fragment reads one k-step ahead in the MFMA shadows (see the loop).
 constexpr int G_TILE = 256 * 128;                 // bytes of one operand tile (256 rows x 64 bf16)
 constexpr int G_LDS = 4 * G_TILE;                 // [2 buffers][A | B] = 128 KiB
 

@@ -159,10 +159,10 @@ __device__ __forceinline__ void mfma_packed(f32x4 (&acc)[MB][NB], int nch, int w
 }
 
 // ------------------------------------------------------------------------------------------
-// forward step.  grid = (nsl * nbt, 2 dirs), block = NW waves.
-// grid = (slice, batch tile, direction): the linear workgroup id is slice + nsl * (bt + nbt * dir), so the batch tiles (and
-// directions) of one slice index sit a multiple of nsl blocks apart, i.e. on the
-// same XCD when nsl % 8 == 0, so each XCD's L2 holds every slice once.
+// forward step.  block = NW waves = MB 16-row batch tiles x NS 16-unit slices x all gates, K split over the waves.
+// grid = (slice group, batch tile, direction): the linear workgroup id is x + gridDim.x * (bt + nbt * dir), so the batch tiles (and
+// directions) of one slice index sit a multiple of gridDim.x blocks apart, i.e. on the same XCD when gridDim.x % 8 == 0: each XCD's L2
+// holds every W_hh slice once, and keeps it across launches (profiles/r01_probe_l2_residency.txt).
 // ------------------------------------------------------------------------------------------
 // The leading parameters (13 dwords) are PRELOADED into SGPRs by the command processor (-mllvm -amdgpu-kernarg-preload-count,
 // Makefile): the operand fetch AND the HBM-latency epilogue loads (gate pre-activations, previous state, bias) need nothing from
