@@ -367,8 +367,23 @@ def test_rnn_fwd_bwd(dev, kind, H, B, T, lens, bf):
         gates_saved, aux2, side_buf = gxd.clone(), aux.clone(), torch.empty(T * B, 2 * G * H, dtype=torch.bfloat16, device=dev)
         ops.rnn_bwd(G, g(dy.float().reshape(T * B, H), dev), gates_saved, aux2, hbuf, wpb, ld, T, B, H, bf16=True, dgx_bf16=side_buf)
         assert torch.equal(gates_saved, gxd)
+    if H >= 1024 and H % 32 == 0:
+        # the alternative tile shapes of the wide-layer kernels (debug flags 16: forward 16 rows x 32 units, 8: backward 32 x 16) split
+        # the same reduction over the same 8 waves in the same order: results must be bit-identical to the default shapes
+        from asr_amd import _lib
+        lib = _lib.load()
+        gx_alt = g(gx.detach().float().reshape(T * B, 2 * G * H), dev).clone()
+        lib.ds2_debug_flags(16)
+        hb_alt, aux_alt = ops.rnn_fwd(G, gx_alt, wpf, bhd, ld, T, B, H, bf16=bf)
+        lib.ds2_debug_flags(8)
+        aux_b = aux.clone()
+        ops.rnn_bwd(G, g(dy.float().reshape(T * B, H), dev), gx_alt, aux_b, hbuf, wpb, ld, T, B, H, bf16=bf)
+        lib.ds2_debug_flags(0)
+        assert torch.equal(hb_alt, hbuf) and torch.equal(aux_alt, aux)
     ops.rnn_bwd(G, g(dy.float().reshape(T * B, H), dev), gxd, aux, hbuf, wpb, ld, T, B, H, bf16=bf)
     assert rel_l2(gxd.view(T, B, 2, G * H).cpu(), gx.grad) < e2          # dGx
+    if H >= 1024 and H % 32 == 0:
+        assert torch.equal(gx_alt, gxd) and torch.equal(aux_b, aux)
     if bf:
         assert torch.equal(side_buf, gxd.bfloat16()) and torch.equal(aux2, aux)
         # packed saved-gate records (bf16 training path): one 8-byte record per hidden unit from forward, read back in backward;
