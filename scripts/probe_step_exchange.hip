@@ -45,6 +45,35 @@ __global__ __launch_bounds__(512) void exchange_kernel(char* buf, unsigned* flag
   __syncthreads();
   for (int s = 0; s < steps; ++s) {
     char* pb = buf + (((size_t)(s & 1) * NGROUPS + group) * NSL) * PIECE;
+    if (with_payload == 2) {
+      // tag-polling variant: no flags, no store drain — the producer fires its tagged 1 KB piece and every consumer wave re-reads its
+      // 8 pieces until each 16-byte chunk carries this step's tag (the payload IS the flag)
+      if (wave == 0) {
+        u32x4 v = {(unsigned)s, (unsigned)slice, (unsigned)lane, 0x5eed0000u + (unsigned)group};
+        store16_sc1(pb + slice * PIECE + lane * 16, v);
+      }
+      u32x4 v[8];
+      int spins = 0;
+      while (true) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = load16_sc1(pb + (wave * 8 + i) * PIECE + lane * 16);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])::"memory");
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ok = ok && (v[i].x == (unsigned)s);
+        if (__ballot(ok) == ~0ull) break;
+        if (++spins > (1 << 16)) { if (lane == 0) s_abort = 1; break; }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        bad += (v[i].y != (unsigned)(wave * 8 + i)) || (v[i].z != (unsigned)lane);
+        acc += v[i].w;
+      }
+      *reinterpret_cast<u32x4*>(lds + (wave * 8) * PIECE + lane * 16) = v[0];
+      __syncthreads();          // (the consumer's MFMA phase would start here; also keeps a fast wave from lapping the buffer parity)
+      if (s_abort) break;
+      continue;
+    }
     if (wave == 0) {
       // produce: one wave-store of 1 KB, tagged with the step
       u32x4 v = {(unsigned)s, (unsigned)slice, (unsigned)lane, 0x5eed0000u + (unsigned)group};
@@ -108,12 +137,12 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
-  for (int with_payload = 0; with_payload < 2; ++with_payload) {
+  for (int with_payload = 0; with_payload < 3; ++with_payload) {
     for (int rep = 0; rep < 3; ++rep) {
       CHECK(hipMemset(flags, 0, NGROUPS * NSL * sizeof(unsigned)));
       CHECK(hipMemset(err, 0, 4));
       CHECK(hipMemset(abort_flag, 0, 4));
-      CHECK(hipMemset(buf, 0xff, (size_t)2 * NGROUPS * NSL * PIECE));
+      CHECK(hipMemset(buf, 0xee, (size_t)2 * NGROUPS * NSL * PIECE));
       CHECK(hipDeviceSynchronize());
       CHECK(hipEventRecord(e0));
       hipLaunchKernelGGL(exchange_kernel, dim3(nwg), dim3(512), lds_bytes, 0, buf, flags, steps, with_payload, err, abort_flag, sink);
