@@ -304,20 +304,20 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(const float* pk, 
     if constexpr (G == 3) {
       const float r = sigmoidf_(pgx[i][0] + gh[0]);
       const float z = sigmoidf_(pgx[i][1] + gh[1]);
-      const float n = tanhf_(pgx[i][2] + r * gh[2]);
+      const float n = tanhf_(__builtin_fmaf(r, gh[2], pgx[i][2]));      // explicit fma: the persistent kernel must contract identically
       if (a.gates_bf) {
         __builtin_nontemporal_store(bf16x4_{(__bf16)r, (__bf16)z, (__bf16)n, (__bf16)gh[2]}, reinterpret_cast<bf16x4_*>(a.gates_bf) + rowH[i]);
       } else {
         stnt(&gx[0], r); stnt(&gx[H], z); stnt(&gx[2 * H], n);
         stnt(ax, gh[2]);
       }
-      hnew = (1.f - z) * n + z * pprev[i];
+      hnew = __builtin_fmaf(z, pprev[i], (1.f - z) * n);
     } else {
       const float ig = sigmoidf_(pgx[i][0] + gh[0]);
       const float fg = sigmoidf_(pgx[i][1] + gh[1]);
       const float gg = tanhf_(pgx[i][2] + gh[2]);
       const float og = sigmoidf_(pgx[i][G - 1] + gh[G - 1]);
-      const float c = fg * pprev[i] + ig * gg;
+      const float c = __builtin_fmaf(fg, pprev[i], ig * gg);
       if (a.gates_bf) {
         __builtin_nontemporal_store(bf16x4_{(__bf16)ig, (__bf16)fg, (__bf16)gg, (__bf16)og}, reinterpret_cast<bf16x4_*>(a.gates_bf) + rowH[i]);
       } else {
@@ -334,6 +334,236 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(const float* pk, 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   RNN_TRACE(s, 5);
 #endif
+}
+
+// ------------------------------------------------------------------------------------------
+// PERSISTENT forward (bf16 operands): the whole recurrence of one layer in ONE launch.
+//
+// Same decomposition as the step kernel (workgroup = 16 hidden units x all gates x MB batch tiles of one direction, K split over the 8
+// waves), but the workgroups stay resident for all T steps, so that
+//   * the W_hh slice is read ONCE and lives in REGISTERS (NCW chunks x G gates x 16 B per lane = 96 KB per workgroup at H = 1024):
+//     per step a CU moves the 64 KB moving operand only, not 160 KB (the step kernel's bound, profiles/r01_pmc_rnn_mempath.txt);
+//   * there is no launch boundary (1.3-1.7 us per step); the all-to-all of h_t is done with TAGGED PAYLOAD POLLING: every 16-byte
+//     chunk of the packed h_t buffer is pre-set to a sentinel no bf16 pair of finite values can produce (0xFFFFFFFF = two NaNs), the
+//     producer fires its piece with system-coherent (sc1) 16-byte stores and every consumer wave re-reads its own chunks with sc1
+//     loads until no dword is the sentinel — the payload is the flag.  Measured 2.64 us per step for the complete 64 KB exchange
+//     against 5.6 us with separate flags and 5.65 us for the step kernel's whole step (scripts/probe_step_exchange.hip).
+// Buffers: FOUR packed h buffers used round-robin (h_s lives in buffer s & 3).  At step s a workgroup whose eight waves have all gathered
+// h_{s-1} (each wave polls only its own 8 of the 64 producers, so this needs the workgroup barrier) knows that every member of its group
+// has FINISHED gathering h_{s-2}; it resets its own piece of that buffer ((s+2) & 3) to the sentinel, two steps before h_{s+2} is due
+// there, and makes sure the previous reset has been acknowledged before h_s goes out (see the loop).  Spins are bounded: a wave that never sees its operand records who it is and leaves (the others
+// then starve and leave too); the host checks that record at the train step's sync point and raises.  The launcher only takes this
+// path when every workgroup can be co-resident (grid <= CU count; nothing else runs on the device during a forward pass).
+// Results are bit-identical to the step kernels: same K split, same accumulation and reduction order (tests/test_gpu_kernels.py).
+// ------------------------------------------------------------------------------------------
+typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16_sc1(void* p, u32x4_ v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ u32x4_ load16_sc1(const void* p) {
+  u32x4_ v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+constexpr unsigned PSENT = 0xffffffffu;
+__device__ int g_persist_dbg[8];      // first starved wave of a persistent launch: {set, block x, y, z, step, wave, ok-mask lo, hi}
+
+template <int G, int MB, int NCW>
+__global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, char* xbuf, int spin_limit) {
+  static_assert(MB * 256 <= NW * 64, "one (row, unit) pair per thread");
+  __shared__ __attribute__((aligned(16))) f32x4 red[NW][MB * G][64];
+  __shared__ __attribute__((aligned(16))) __bf16 stage[MB * 32 * 8];          // this workgroup's piece of packed h_t (MB x 512 B)
+  const int dir = blockIdx.z, slice = blockIdx.x, bt = blockIdx.y;
+  const int T = a.T, B = a.B, H = a.H;
+  const int nsl = (H + 15) >> 4, nch = (H + 31) >> 5;
+  const int j0 = slice * 16, b0 = bt * (16 * MB);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long long bufbytes = (long long)2 * a.nbt16 * nch * 1024;            // one packed h buffer: [dir][tile][chunk][64 lanes][16 B]
+  const long long dirbase = (long long)dir * a.nbt16 * nch * 1024;
+
+  // ---- W_hh slice -> registers (once)
+  f32x4 wreg[NCW][G];
+  bool cval[NCW];
+#pragma unroll
+  for (int k = 0; k < NCW; ++k) {
+    const int c = wave + NW * k;
+    cval[k] = c < nch;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+      wreg[k][g] = cval[k] ? *reinterpret_cast<const f32x4*>(a.wp + (((((long long)dir * nsl + slice) * G + g) * nch + c) * 256) + lane * 4)
+                           : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  // lanes of a chunk whose 8 hidden units lie beyond H are never written by anybody: ignored by the poll, zero in the product
+  bool lval[NCW];
+#pragma unroll
+  for (int k = 0; k < NCW; ++k) lval[k] = cval[k] && ((wave + NW * k) * 32 + (lane >> 4) * 8) < H;
+
+  // ---- this thread's (batch row, hidden unit) pair: fixed for the whole layer, so the previous state stays in a register
+  const int q = threadIdx.x;
+  const int jl = q & 15, brow = (q >> 4) & 15, mb = q >> 8;
+  const int b = b0 + mb * 16 + brow, j = j0 + jl;
+  const bool pact = (mb < MB) && b < B && j < H;
+  const int src_lane = (brow >> 2) * 16 + jl, reg = brow & 3;
+  const int plen = pact ? a.lens[b] : 0;
+  float pb[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) pb[g] = pact ? a.bhh[(dir * G + g) * H + j] : 0.f;
+  float pprev = 0.f;                                                         // h_{t-1} (GRU) / c_{t-1} (LSTM)
+  const int lg0 = (j0 & 31) >> 3;                                            // first of this slice's two lane groups inside its chunk
+  const int stage_idx = ((mb * 2 + (((j & 31) >> 3) - lg0)) * 16 + brow) * 8 + (j & 7);
+  // piece address of lane l of the publishing wave: tile bt*MB + (l >> 5), chunk j0 >> 5, lanes lg0*16 + (l & 31)
+  const long long piece_off = dirbase + ((((long long)(bt * MB + (lane >> 5)) * nch + (j0 >> 5)) * 64) + lg0 * 16 + (lane & 31)) * 16;
+  const bool piece_lane = (lane >> 5) < MB;
+
+  auto gx_row = [&](int t) { return a.gx + (((long long)t * B + b) * 2 + dir) * G * H + j; };
+  float pgx[G], pgx_next[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) { pgx[g] = 0.f; pgx_next[g] = 0.f; }
+  if (pact) {
+    const float* p0 = gx_row(dir == 0 ? 0 : T - 1);
+#pragma unroll
+    for (int g = 0; g < G; ++g) pgx[g] = ldnt(p0 + g * H);
+  }
+
+  for (int s = 0; s < T; ++s) {
+    const int t = dir == 0 ? s : T - 1 - s;
+    f32x4 acc[MB][G];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int g = 0; g < G; ++g) acc[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (s > 0) {
+      // ---- gather h_{s-1}: poll this wave's chunks until none carries the sentinel
+      const char* xin = xbuf + (long long)((s - 1) & 3) * bufbytes + dirbase;
+      u32x4_ av[NCW][MB];
+#pragma unroll
+      for (int k = 0; k < NCW; ++k)
+#pragma unroll
+        for (int i = 0; i < MB; ++i) av[k][i] = u32x4_{0u, 0u, 0u, 0u};
+      int spins = 0;
+      while (true) {
+#pragma unroll
+        for (int k = 0; k < NCW; ++k)
+#pragma unroll
+          for (int i = 0; i < MB; ++i)
+            if (cval[k]) av[k][i] = load16_sc1(xin + ((((long long)(bt * MB + i) * nch + (wave + NW * k)) * 64) + lane) * 16);
+        // the wait names every destination register: without that tie the compiler may test the registers before the loads have landed
+#pragma unroll
+        for (int k = 0; k < NCW; ++k)
+#pragma unroll
+          for (int i = 0; i < MB; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(av[k][i])::"memory");
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < NCW; ++k)
+#pragma unroll
+          for (int i = 0; i < MB; ++i)
+            if (lval[k]) ok = ok && av[k][i].x != PSENT && av[k][i].y != PSENT && av[k][i].z != PSENT && av[k][i].w != PSENT;
+        if (__ballot(ok) == ~0ull) break;
+        if (++spins > spin_limit) {
+          // record who starved and on what (first failure only), then fail loudly
+          // (no __builtin_trap here: hipcc sinks the trap to the kernel's common exit block, where it then fires on NORMAL completion
+          //  too — measured: spurious HSA_STATUS_ERROR_EXCEPTION at the end of correct runs.  The host reads this record at the
+          //  train step's sync point and raises: ds2_rnn_persistent_status / asr_amd.ops.rnn_persistent_check)
+          if (lane == 0 && atomicCAS(&g_persist_dbg[0], 0, 1) == 0) {
+            g_persist_dbg[1] = blockIdx.x; g_persist_dbg[2] = blockIdx.y; g_persist_dbg[3] = blockIdx.z; g_persist_dbg[4] = s; g_persist_dbg[5] = wave;
+            unsigned long long m = __ballot(ok);
+            g_persist_dbg[6] = (int)(m & 0xffffffffu); g_persist_dbg[7] = (int)(m >> 32);
+            __threadfence_system();
+          }
+          return;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < NCW; ++k)
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+          const u32x4_ v = lval[k] ? av[k][i] : u32x4_{0u, 0u, 0u, 0u};
+#pragma unroll
+          for (int g = 0; g < G; ++g)
+            acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v), __builtin_bit_cast(bf16x8, wreg[k][g]), acc[i][g], 0, 0, 0);
+        }
+    }
+    // ---- next step's gate pre-activations: HBM latency hidden under this step (the publishing wave issues its own after the publish)
+    const bool more = s + 1 < T;
+    if (more && pact && wave != NW - 1) {
+      const float* pn = gx_row(dir == 0 ? s + 1 : T - 2 - s);
+#pragma unroll
+      for (int g = 0; g < G; ++g) pgx_next[g] = ldnt(pn + g * H);
+    }
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int g = 0; g < G; ++g) red[wave][i * G + g][lane] = acc[i][g];
+    __syncthreads();
+
+    // ---- gate math (identical to the step kernel's epilogue)
+    float out_g[4] = {0.f, 0.f, 0.f, 0.f}, out_aux = 0.f, hnew = 0.f;
+    const bool live = pact && t < plen;
+    if (live) {
+      float gh[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) sum += red[w][mb * G + g][src_lane][reg];
+        gh[g] = sum + pb[g];
+      }
+      if constexpr (G == 3) {
+        const float r = sigmoidf_(pgx[0] + gh[0]);
+        const float z = sigmoidf_(pgx[1] + gh[1]);
+        const float n = tanhf_(__builtin_fmaf(r, gh[2], pgx[2]));
+        out_g[0] = r; out_g[1] = z; out_g[2] = n; out_g[3] = gh[2];
+        out_aux = gh[2];
+        hnew = __builtin_fmaf(z, pprev, (1.f - z) * n);
+        pprev = hnew;
+      } else {
+        const float ig = sigmoidf_(pgx[0] + gh[0]);
+        const float fg = sigmoidf_(pgx[1] + gh[1]);
+        const float gg = tanhf_(pgx[2] + gh[2]);
+        const float og = sigmoidf_(pgx[G - 1] + gh[G - 1]);
+        const float c = __builtin_fmaf(fg, pprev, ig * gg);
+        out_g[0] = ig; out_g[1] = fg; out_g[2] = gg; out_g[3] = og;
+        out_aux = c;
+        hnew = og * tanhf_(c);
+        pprev = c;
+      }
+    } else {
+      pprev = 0.f;                                      // beyond the sample's length: state is zero (what the step kernels re-read)
+    }
+    if (mb < MB) stage[stage_idx] = (__bf16)hnew;       // rows beyond B / units beyond H publish zeros: consumers wait for every piece
+    if (wave == NW - 2) {
+      // ALL waves of this workgroup are past this step's gather (barrier above), so all 64 workgroups of the group have published
+      // h_{s-1}, i.e. have finished gathering h_{s-2}: its buffer ((s+2) & 3) can be reset for h_{s+2}.  The wait in front makes sure
+      // the PREVIOUS reset (buffer (s+1) & 3, where h_{s+1} goes) was acknowledged before the barrier below lets h_s out: whoever has
+      // seen h_s can then no longer find a stale h_{s-3} piece where it will poll for h_{s+1}.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (piece_lane) store16_sc1(xbuf + (long long)((s + 2) & 3) * bufbytes + piece_off, u32x4_{PSENT, PSENT, PSENT, PSENT});
+    }
+    __syncthreads();
+    if (wave == NW - 1) {
+      if (piece_lane) store16_sc1(xbuf + (long long)(s & 3) * bufbytes + piece_off, *reinterpret_cast<const u32x4_*>(&stage[(lane >> 5) * 256 + (lane & 31) * 8]));
+      if (more && pact) {
+        const float* pn = gx_row(dir == 0 ? s + 1 : T - 2 - s);
+#pragma unroll
+        for (int g = 0; g < G; ++g) pgx_next[g] = ldnt(pn + g * H);
+      }
+    }
+    // ---- saved-for-backward outputs (after the publish: nothing on the exchange's critical path waits for HBM write acks)
+    if (pact) {
+      const long long rowH = (((long long)t * B + b) * 2 + dir) * H + j;
+      if (a.gates_bf) {
+        __builtin_nontemporal_store(bf16x4_{(__bf16)out_g[0], (__bf16)out_g[1], (__bf16)out_g[2], (__bf16)out_g[3]}, reinterpret_cast<bf16x4_*>(a.gates_bf) + rowH);
+        if (G == 4) a.aux[rowH] = out_aux;
+      } else {
+        float* gx = const_cast<float*>(gx_row(t));
+        stnt(&gx[0], out_g[0]); stnt(&gx[H], out_g[1]); stnt(&gx[2 * H], out_g[2]);
+        if (G == 4) { stnt(&gx[3 * H], out_g[3]); a.aux[rowH] = out_aux; }
+        else stnt(a.aux + rowH, live ? out_aux : 0.f);
+      }
+      a.hbuf[rowH] = hnew;
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) pgx[g] = pgx_next[g];
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -547,6 +777,54 @@ inline int pick_mb(int B, int H) {
   return ((long long)nsl * ceil_div(B, 32) * 2 >= 200) ? 2 : 1;
 }
 
+// bytes of ONE packed h buffer of the forward recurrence ([2 dirs][tiles][chunks][1 KiB]); the persistent kernel uses four
+size_t fwd_xbuf_bytes(int B, int H, int bf16) { return (size_t)2 * (ceil_div(B, 32) * 2) * ceil_div(H, bf16 ? 32 : 16) * 1024; }
+
+int cu_count() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+    if (n <= 0) n = 1;
+  }
+  return n;
+}
+
+// Forward recurrence in one persistent launch (bf16 operands).  Returns 1 if launched, 0 if the shape / device does not qualify
+// (the caller then runs the step kernels), < 0 on error.
+template <int G>
+int try_launch_persistent_fwd(RnnArgs a, hipStream_t st) {
+  static const char* env = getenv("DS2_RNN_PERSISTENT");          // "0" = always the step kernels (A/B runs, debugging)
+  if (env && env[0] == '0') return 0;
+  if (a.dbg) return 0;                                            // the ablation flags belong to the step kernels
+  if ((a.H % 16) != 0 || a.T < 2) return 0;
+  const int mb = pick_mb(a.B, a.H);
+  const int nsl = a.H / 16, nbt = ceil_div(a.B, 16 * mb);
+  const int nch = ceil_div(a.H, 32), ncw = ceil_div(nch, NW);
+  if (ncw > 5) return 0;
+  // every workgroup must be resident at once: one per CU (96-144 KB of registers + up to 65 KB of LDS each)
+  if ((long long)nsl * nbt * 2 > cu_count()) return 0;
+  a.nsl = nsl;
+  a.nbt16 = ceil_div(a.B, 32) * 2;
+  char* xbuf = reinterpret_cast<char*>(a.pk);
+  DS2_HIP(hipMemsetAsync(xbuf, 0xff, 4 * fwd_xbuf_bytes(a.B, a.H, 1), st));      // every 16-byte chunk = the "not yet published" sentinel
+  dim3 grid(nsl, nbt, 2), block(NW * 64);
+  static const char* sl = getenv("DS2_RNN_SPIN_LIMIT");
+  const int spin_limit = sl ? atoi(sl) : (1 << 20);              // ~1 s of polling: a missing workgroup traps instead of hanging the queue
+#define DS2_PLAUNCH(MB_, NCW_) hipLaunchKernelGGL((rnn_fwd_persistent_kernel<G, MB_, NCW_>), grid, block, 0, st, a, xbuf, spin_limit)
+#define DS2_PCASE(NCW_) case NCW_: if (mb == 2) DS2_PLAUNCH(2, NCW_); else DS2_PLAUNCH(1, NCW_); break;
+  switch (ncw) {
+    DS2_PCASE(1) DS2_PCASE(2) DS2_PCASE(3) DS2_PCASE(4) DS2_PCASE(5)
+    default: return 0;
+  }
+#undef DS2_PCASE
+#undef DS2_PLAUNCH
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ds2_set_error("rnn persistent launch failed: %s", hipGetErrorString(e));
+  return 1;
+}
+
 template <int G, bool BF>
 int launch_steps(bool bwd, RnnArgs a, hipStream_t st) {
   a.dbg = g_ds2_debug_flags;
@@ -615,7 +893,21 @@ extern "C" int ds2_rnn_pack_whh(int gates, const float* whh, void* wp_fwd, void*
   return 0;
 }
 
-extern "C" size_t ds2_rnn_fwd_workspace_bytes(int B, int H, int bf16) { return pk_floats(B, H, H, bf16) * sizeof(float); }
+// status of the persistent forward kernel since the last call: 8 ints {starved, block x, y, z, step, wave, ok-mask lo, hi}; out8[0] != 0
+// if a wave ever gave up polling for its operand (results of that launch are then invalid).  Synchronises the device, clears the record.
+extern "C" int ds2_rnn_persistent_status(int* out8) {
+  DS2_HIP(hipDeviceSynchronize());
+  DS2_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_persist_dbg), 8 * sizeof(int)));
+  int zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  DS2_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_persist_dbg), zero, sizeof(zero)));
+  return 0;
+}
+
+extern "C" size_t ds2_rnn_fwd_workspace_bytes(int B, int H, int bf16) {
+  const size_t step = pk_floats(B, H, H, bf16) * sizeof(float);                 // two ping-pong buffers of the step kernels
+  const size_t pers = bf16 ? 4 * fwd_xbuf_bytes(B, H, 1) : 0;                    // four round-robin buffers of the persistent kernel
+  return step > pers ? step : pers;
+}
 
 // gates: 3 = GRU (r,z,n), 4 = LSTM (i,f,g,o).  bf16 = 1: the h W_hh^T product uses bf16 MFMA operands (fp32 accumulate;
 // h, c, gates stay fp32) and wp_fwd must have been packed with bf16 = 1.
@@ -633,6 +925,11 @@ extern "C" int ds2_rnn_fwd(int gates, float* gx, const void* wp_fwd, const float
   RnnArgs a{};
   a.gx = gx; a.aux = aux; a.hbuf = hbuf; a.wp = (const float*)wp_fwd; a.bhh = bhh; a.pk = (float*)ws; a.lens = lens_dev;
   a.T = T; a.B = B; a.H = H; a.gates_bf = (__bf16*)gates_bf16;
+  if (bf16) {
+    a.dbg = g_ds2_debug_flags;
+    const int rc = gates == 3 ? try_launch_persistent_fwd<3>(a, (hipStream_t)stream) : try_launch_persistent_fwd<4>(a, (hipStream_t)stream);
+    if (rc != 0) return rc < 0 ? rc : 0;
+  }
   return bf16 ? dispatch<true>(gates, false, a, (hipStream_t)stream) : dispatch<false>(gates, false, a, (hipStream_t)stream);
 }
 

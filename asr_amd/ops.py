@@ -537,6 +537,17 @@ def rnn_pack(gates: int, whh: Tensor, bf16: bool = False):
     return wpf, wpb
 
 
+def rnn_persistent_check() -> None:
+    """Raise if a persistent forward-recurrence launch starved since the last call (a workgroup never saw its operand: the launch
+    needs every workgroup resident at once).  Call at a point where the device is idle anyway (the train step's loss sync)."""
+    rec = (C.c_int * 8)()
+    _lib.check(_lib.load().ds2_rnn_persistent_status(C.cast(rec, C.c_void_p)), "ds2_rnn_persistent_status")
+    if rec[0]:
+        raise _lib.DS2LibraryError(f"persistent recurrence starved: block ({rec[1]}, {rec[2]}, {rec[3]}) step {rec[4]} wave {rec[5]} never received its "
+                                   f"operand (lanes ok {rec[7] & 0xffffffff:08x}{rec[6] & 0xffffffff:08x}); the results of that step are invalid. "
+                                   f"Set DS2_RNN_PERSISTENT=0 to use the one-launch-per-step kernels.")
+
+
 def rnn_fwd(gates: int, gx: Tensor, wp_fwd: Tensor, bhh: Tensor, lens_dev: Tensor, T: int, B: int, H: int, bf16: bool = False,
             packed_gates: bool = False):
     """gx (T*B, 2*G*H) in/out; returns (hbuf (T*B, 2H), aux (T*B, 2H)[, gates_bf (T*B, 2H, 4) bf16]).

@@ -120,6 +120,8 @@ class DeepSpeechTrainer:
         loss = self.criterion(float_out, targets, output_sizes, target_sizes).to(self._device)
         loss = loss / inputs.size(0)
         loss_value = loss.item()
+        if getattr(self._model, "precision", "fp32") == "bf16":
+            ops.rnn_persistent_check()
         valid_loss, _ = check_loss(loss, loss_value)
         return valid_loss, loss, loss_value
 
@@ -151,6 +153,8 @@ class DeepSpeechTrainer:
             engine.backward(W, Gr, model._cfg, ctx, dlogits, on_bucket=red.on_bucket)
             red.finish()
             loss_value = loss.item()                                         # the step's single host sync
+            if model.precision == "bf16":
+                ops.rnn_persistent_check()                                   # the device is idle here: a starved persistent launch raises
             valid_loss, _ = check_loss(loss, loss_value)
             valid_loss = red.all_valid(valid_loss, inputs.device)
             if valid_loss:

@@ -136,6 +136,12 @@ size_t ds2_rnn_packed_bytes(int gates, int H, int which /*0: forward operand, 1:
 /* re-pack W_hh = [weight_hh_l0 ; weight_hh_l0_reverse] (2,G*H,H) fp32 into MFMA-fragment order, fp32 or bf16 fragments
  * (once per optimizer step) */
 int ds2_rnn_pack_whh(int gates, const float* whh, void* wp_fwd, void* wp_bwd, int H, int bf16, void* stream);
+/* Status of the persistent forward recurrence (bf16 mode runs a layer's whole recurrence in ONE launch whose workgroups exchange h_t
+ * through memory; it needs every workgroup resident at once).  out8 = {starved, block x, y, z, step, wave, ok-mask lo, hi}: starved != 0
+ * means a wave gave up polling for its operand since the last call (DS2_RNN_SPIN_LIMIT polls, default 2^20 ~ 1 s) and the results
+ * of that launch are invalid — the caller must treat the step as failed.  Synchronises the device and clears the record.
+ * DS2_RNN_PERSISTENT=0 selects the one-launch-per-step kernels instead. */
+int ds2_rnn_persistent_status(int* out8);
 size_t ds2_rnn_fwd_workspace_bytes(int B, int H, int bf16);
 /* gates_bf16: NULL, or a (T,B,2,H,4) bf16 buffer that receives the saved-for-backward record of every hidden unit as ONE 8-byte
  * store — GRU [r, z, n, W_hn h + b_hn], LSTM [i, f, g, o] — instead of four fp32 stores into gx / aux (gx is then left untouched
