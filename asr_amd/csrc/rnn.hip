@@ -357,7 +357,9 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(const float* pk, 
 // Results are bit-identical to the step kernels: same K split, same accumulation and reduction order (tests/test_gpu_kernels.py).
 // ------------------------------------------------------------------------------------------
 typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void store16_sc1(void* p, u32x4_ v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+// (the trailing s_nop: a > 64-bit VMEM store needs wait states before its data VGPRs may be overwritten; the compiler inserts them for its
+//  own stores but cannot see inside inline asm, and back-to-back publishes then shipped partly overwritten payloads)
+__device__ __forceinline__ void store16_sc1(void* p, u32x4_ v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" ::"v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ u32x4_ load16_sc1(const void* p) {
   u32x4_ v;
   asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
@@ -727,6 +729,212 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(const float* pk, 
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// PERSISTENT backward (bf16 training path: packed gate records in, bf16 dGx out): the same construction as the persistent forward
+// kernel.  Per step a CU then moves only the moving operand (dGh_{t+1}: 16 rows x G*H bf16 = 98 KB at H = 1024) instead of 290 KB, the
+// W_hh^T slice (32 units x G*H bf16 = 192 KB) lives in registers (96 per lane), there is no launch boundary, and the carry
+// (dh*z / dc*f) never leaves its thread.  Exchange protocol, buffers, starvation handling: see rnn_fwd_persistent_kernel.
+// ------------------------------------------------------------------------------------------
+template <int G, int MB, int NS, int NCW>
+__global__ __launch_bounds__(NW * 64) void rnn_bwd_persistent_kernel(RnnArgs a, char* xbuf, int spin_limit) {
+  static_assert(MB * NS * 256 <= NW * 64, "one (row, unit) pair per thread");
+  constexpr int PL = 32 * NS;                                                 // lanes of one published run (one gate, one tile)
+  __shared__ __attribute__((aligned(16))) f32x4 red[NW][MB * NS][64];
+  __shared__ __attribute__((aligned(16))) __bf16 stage[MB * G * PL * 8];
+  const int dir = blockIdx.z, slice = blockIdx.x, bt = blockIdx.y;
+  const int T = a.T, B = a.B, H = a.H, lddy = a.lddy;
+  const int nsl = (H + 15) >> 4, nchb = (G * H + 31) >> 5;
+  const int j0 = slice * (16 * NS), b0 = bt * (16 * MB);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long long bufbytes = (long long)2 * a.nbt16 * nchb * 1024;
+  const long long dirbase = (long long)dir * a.nbt16 * nchb * 1024;
+
+  f32x4 wreg[NCW][NS];
+  bool cval[NCW], lval[NCW];
+#pragma unroll
+  for (int k = 0; k < NCW; ++k) {
+    const int c = wave + NW * k;
+    cval[k] = c < nchb;
+    lval[k] = cval[k] && (c * 32 + (lane >> 4) * 8) < G * H;
+#pragma unroll
+    for (int n = 0; n < NS; ++n)
+      wreg[k][n] = cval[k] ? *reinterpret_cast<const f32x4*>(a.wp + ((((long long)dir * nsl + slice * NS + n) * nchb + c) * 256) + lane * 4)
+                           : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  const int q = threadIdx.x;
+  const int jl = q & 15, brow = (q >> 4) & 15, sub = q >> 8, mb = sub / NS, ns = sub % NS;
+  const int b = b0 + mb * 16 + brow, j = j0 + ns * 16 + jl;
+  const bool pair = sub < MB * NS;
+  const bool pact = pair && b < B && j < H;
+  const int src_lane = (brow >> 2) * 16 + jl, reg = brow & 3;
+  const int plen = pact ? a.lens[b] : 0;
+  const __bf16* gates_bf = a.gates_bf;
+  float dcar = 0.f;                                                           // GRU dh*z / LSTM dc*f of the step before (own pair)
+
+  // operands of the gate-derivative math for one time step: independent of the recurrence, so they are fetched one step ahead
+  struct Ops { float g0, g1, g2, g3, ax, dy, prev; };
+  auto fetch = [&](int step) {
+    Ops o{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (!pact) return o;
+    const int t = dir == 0 ? T - 1 - step : step;
+    const long long rowH = (((long long)t * B + b) * 2 + dir) * H + j;
+    const bf16x4_ rec = __builtin_nontemporal_load(reinterpret_cast<const bf16x4_*>(gates_bf) + rowH);
+    o.g0 = (float)rec[0]; o.g1 = (float)rec[1]; o.g2 = (float)rec[2]; o.g3 = (float)rec[3];
+    if (G == 4) o.ax = ldnt(a.aux + rowH);
+    o.dy = ldnt(&a.dy[((long long)t * B + b) * lddy + j]);
+    const int tpf = dir == 0 ? t - 1 : t + 1;
+    if (dir == 0 ? (t > 0) : (t < T - 1)) {
+      const long long prow = (((long long)tpf * B + b) * 2 + dir) * H + j;
+      o.prev = (G == 3) ? a.hbuf[prow] : a.aux[prow];
+    }
+    return o;
+  };
+  Ops cur = fetch(0), nxt = cur;
+
+  // where this pair's G values go inside the staged piece, and the address of the piece's runs in a packed buffer
+  int stg[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const int k = g * H + j, lg0 = ((g * H + j0) & 31) >> 3;
+    stg[g] = (((mb * G + g) * PL) + ((((k & 31) >> 3) - lg0) * 16 + brow)) * 8 + (k & 7);
+  }
+  // run r = mb * G + g of the piece: tile bt*MB + mb, chunk (g*H + j0) >> 5, lanes lg0*16 .. + PL
+  auto run_off = [&](int r) {
+    const int m = r / G, g = r % G;
+    const int k0 = g * H + j0;
+    return dirbase + ((((long long)(bt * MB + m) * nchb + (k0 >> 5)) * 64) + ((k0 & 31) >> 3) * 16 + lane) * 16;
+  };
+
+  for (int s = 0; s < T; ++s) {
+    const int t = dir == 0 ? T - 1 - s : s;
+    f32x4 acc[MB][NS];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int n = 0; n < NS; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (s > 0) {
+      const char* xin = xbuf + (long long)((s - 1) & 3) * bufbytes + dirbase;
+      u32x4_ av[NCW][MB];
+#pragma unroll
+      for (int k = 0; k < NCW; ++k)
+#pragma unroll
+        for (int i = 0; i < MB; ++i) av[k][i] = u32x4_{0u, 0u, 0u, 0u};
+      int spins = 0;
+      while (true) {
+#pragma unroll
+        for (int k = 0; k < NCW; ++k)
+#pragma unroll
+          for (int i = 0; i < MB; ++i)
+            if (cval[k]) av[k][i] = load16_sc1(xin + ((((long long)(bt * MB + i) * nchb + (wave + NW * k)) * 64) + lane) * 16);
+#pragma unroll
+        for (int k = 0; k < NCW; ++k)
+#pragma unroll
+          for (int i = 0; i < MB; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(av[k][i])::"memory");
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < NCW; ++k)
+#pragma unroll
+          for (int i = 0; i < MB; ++i)
+            if (lval[k]) ok = ok && av[k][i].x != PSENT && av[k][i].y != PSENT && av[k][i].z != PSENT && av[k][i].w != PSENT;
+        if (__ballot(ok) == ~0ull) break;
+        if (++spins > spin_limit) {
+          if (lane == 0 && atomicCAS(&g_persist_dbg[0], 0, 2) == 0) {
+            g_persist_dbg[1] = blockIdx.x; g_persist_dbg[2] = blockIdx.y; g_persist_dbg[3] = blockIdx.z; g_persist_dbg[4] = s; g_persist_dbg[5] = wave;
+            unsigned long long m = __ballot(ok);
+            g_persist_dbg[6] = (int)(m & 0xffffffffu); g_persist_dbg[7] = (int)(m >> 32);
+            __threadfence_system();
+          }
+          return;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < NCW; ++k)
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+          const u32x4_ v = lval[k] ? av[k][i] : u32x4_{0u, 0u, 0u, 0u};
+#pragma unroll
+          for (int n = 0; n < NS; ++n)
+            acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v), __builtin_bit_cast(bf16x8, wreg[k][n]), acc[i][n], 0, 0, 0);
+        }
+    }
+    const bool more = s + 1 < T;
+    if (more && wave < NW - 2) nxt = fetch(s + 1);      // (the resetting / publishing waves fetch after their sc1 stores)
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int n = 0; n < NS; ++n) red[wave][i * NS + n][lane] = acc[i][n];
+    __syncthreads();
+
+    float dgh[G], dgx[G], dax = 0.f;
+#pragma unroll
+    for (int g = 0; g < G; ++g) { dgh[g] = 0.f; dgx[g] = 0.f; }
+    if (pact && t < plen) {
+      float carry = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) carry += red[w][sub][src_lane][reg];
+      if constexpr (G == 3) {
+        const float dh = cur.dy + carry + dcar;
+        const float r = cur.g0, z = cur.g1, n = cur.g2, hn = cur.g3;
+        const float dn_ = dh * (1.f - z);
+        const float dz = dh * (cur.prev - n);
+        const float dpn = dn_ * (1.f - n * n);
+        const float dr = dpn * hn;
+        dgh[0] = dr * r * (1.f - r);
+        dgh[1] = dz * z * (1.f - z);
+        dgh[2] = dpn * r;
+        dgx[0] = dgh[0]; dgx[1] = dgh[1]; dgx[2] = dpn;
+        dax = dgh[2];
+        dcar = dh * z;
+      } else {
+        const float dh = cur.dy + carry;
+        const float ig = cur.g0, fg = cur.g1, gg = cur.g2, og = cur.g3;
+        const float tc = tanhf_(cur.ax);
+        const float dc = dcar + dh * og * (1.f - tc * tc);
+        dgh[0] = dc * gg * ig * (1.f - ig);
+        dgh[1] = dc * cur.prev * fg * (1.f - fg);
+        dgh[2] = dc * ig * (1.f - gg * gg);
+        dgh[G - 1] = dh * tc * og * (1.f - og);
+#pragma unroll
+        for (int g = 0; g < G; ++g) dgx[g] = dgh[g];
+        dcar = dc * fg;
+      }
+    } else {
+      dcar = 0.f;
+    }
+    if (pair) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) stage[stg[g]] = (__bf16)dgh[g];
+    }
+    if (wave == NW - 2) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the previous reset is acknowledged before this step's barrier
+      if (lane < PL) {
+#pragma unroll
+        for (int r = 0; r < MB * G; ++r) store16_sc1(xbuf + (long long)((s + 2) & 3) * bufbytes + run_off(r), u32x4_{PSENT, PSENT, PSENT, PSENT});
+      }
+      if (more) nxt = fetch(s + 1);
+    }
+    __syncthreads();
+    if (wave == NW - 1) {
+      if (lane < PL) {
+#pragma unroll
+        for (int r = 0; r < MB * G; ++r)
+          store16_sc1(xbuf + (long long)(s & 3) * bufbytes + run_off(r), *reinterpret_cast<const u32x4_*>(&stage[(r * PL + lane) * 8]));
+      }
+      if (more) nxt = fetch(s + 1);
+    }
+    if (pact) {
+      const long long row = ((long long)t * B + b) * 2 + dir;
+      __bf16* gb = a.dgx_bf + row * G * H + j;
+#pragma unroll
+      for (int g = 0; g < G; ++g) __builtin_nontemporal_store((__bf16)dgx[g], gb + g * H);
+      if (G == 3) stnt(a.aux + row * H + j, dax);
+    }
+    cur = nxt;
+  }
+}
+
 // W_hh (2, G*H, H) -> fwd-packed [2][nsl][G][nch][64 lanes][16 B] and bwd-packed [2][nsl][nchb][64 lanes][16 B]
 template <bool BF>
 __global__ __launch_bounds__(256) void rnn_pack_kernel(const float* __restrict__ whh, void* __restrict__ wpf, void* __restrict__ wpb, int G, int H) {
@@ -777,6 +985,10 @@ inline int pick_mb(int B, int H) {
   return ((long long)nsl * ceil_div(B, 32) * 2 >= 200) ? 2 : 1;
 }
 
+// which persistent kernels may be used (ds2_rnn_persistent_enable): the backward one must be switched off by a caller that runs
+// collectives on another stream during backward, because a persistent launch needs every one of its workgroups resident at once
+int g_persist_fwd = 1, g_persist_bwd = 1;
+
 // bytes of ONE packed h buffer of the forward recurrence ([2 dirs][tiles][chunks][1 KiB]); the persistent kernel uses four
 size_t fwd_xbuf_bytes(int B, int H, int bf16) { return (size_t)2 * (ceil_div(B, 32) * 2) * ceil_div(H, bf16 ? 32 : 16) * 1024; }
 
@@ -798,7 +1010,7 @@ int try_launch_persistent_fwd(RnnArgs a, hipStream_t st) {
   static const char* env = getenv("DS2_RNN_PERSISTENT");          // "0" = always the step kernels (A/B runs, debugging)
   if (env && env[0] == '0') return 0;
   if (a.dbg) return 0;                                            // the ablation flags belong to the step kernels
-  if ((a.H % 16) != 0 || a.T < 2) return 0;
+  if (!g_persist_fwd || (a.H % 16) != 0 || a.T < 2) return 0;
   const int mb = pick_mb(a.B, a.H);
   const int nsl = a.H / 16, nbt = ceil_div(a.B, 16 * mb);
   const int nch = ceil_div(a.H, 32), ncw = ceil_div(nch, NW);
@@ -822,6 +1034,43 @@ int try_launch_persistent_fwd(RnnArgs a, hipStream_t st) {
 #undef DS2_PLAUNCH
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ds2_set_error("rnn persistent launch failed: %s", hipGetErrorString(e));
+  return 1;
+}
+
+size_t bwd_xbuf_bytes(int gates, int B, int H, int bf16) { return (size_t)2 * (ceil_div(B, 32) * 2) * ceil_div(gates * H, bf16 ? 32 : 16) * 1024; }
+
+// Backward recurrence in one persistent launch (bf16 training path).  1 = launched, 0 = not eligible, < 0 = error.
+template <int G>
+int try_launch_persistent_bwd(RnnArgs a, hipStream_t st) {
+  static const char* env = getenv("DS2_RNN_PERSISTENT");
+  if ((env && env[0] == '0') || !g_persist_bwd || a.dbg) return 0;
+  if (!a.gates_bf || !a.dgx_bf || (a.H % 16) != 0 || a.T < 2) return 0;
+  int mb = pick_mb(a.B, a.H);
+  const int nsl = a.H / 16;
+  const int ns = (mb == 2 && (nsl % 2) == 0) ? 2 : 1;                 // same tile choice as the step kernels
+  if (ns == 2) mb = 1;
+  const int nbt = ceil_div(a.B, 16 * mb);
+  const int nchb = ceil_div(G * a.H, 32);
+  const int ncw = ceil_div(ceil_div(nchb, NW), 3) * 3;                // instantiated: 3, 6, 9, 12 chunks per wave
+  if (ncw > 12) return 0;
+  if ((long long)(nsl / ns) * nbt * 2 > cu_count()) return 0;
+  a.nsl = nsl;
+  a.nbt16 = ceil_div(a.B, 32) * 2;
+  char* xbuf = reinterpret_cast<char*>(a.pk);
+  DS2_HIP(hipMemsetAsync(xbuf, 0xff, 4 * bwd_xbuf_bytes(G, a.B, a.H, 1), st));
+  dim3 grid(nsl / ns, nbt, 2), block(NW * 64);
+  static const char* sl = getenv("DS2_RNN_SPIN_LIMIT");
+  const int spin_limit = sl ? atoi(sl) : (1 << 20);
+#define DS2_PB(MB_, NS_, NCW_) hipLaunchKernelGGL((rnn_bwd_persistent_kernel<G, MB_, NS_, NCW_>), grid, block, 0, st, a, xbuf, spin_limit)
+#define DS2_PBCASE(NCW_) case NCW_: if (ns == 2) DS2_PB(1, 2, NCW_); else if (mb == 2) DS2_PB(2, 1, NCW_); else DS2_PB(1, 1, NCW_); break;
+  switch (ncw) {
+    DS2_PBCASE(3) DS2_PBCASE(6) DS2_PBCASE(9) DS2_PBCASE(12)
+    default: return 0;
+  }
+#undef DS2_PBCASE
+#undef DS2_PB
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ds2_set_error("rnn persistent backward launch failed: %s", hipGetErrorString(e));
   return 1;
 }
 
@@ -934,7 +1183,18 @@ extern "C" int ds2_rnn_fwd(int gates, float* gx, const void* wp_fwd, const float
 }
 
 extern "C" size_t ds2_rnn_bwd_workspace_bytes(int gates, int B, int H, int bf16) {
-  return ((size_t)4 * B * H + pk_floats(B, H, gates * H, bf16)) * sizeof(float);
+  const size_t step = pk_floats(B, H, gates * H, bf16) * sizeof(float);          // two ping-pong buffers of the step kernels
+  const size_t pers = bf16 ? 4 * bwd_xbuf_bytes(gates, B, H, 1) : 0;              // four round-robin buffers of the persistent kernel
+  return (size_t)4 * B * H * sizeof(float) + (step > pers ? step : pers);
+}
+
+// Which recurrences may run as ONE persistent launch (bf16 mode; default: both).  A persistent launch needs all of its workgroups resident
+// at once, so a caller that runs other kernels concurrently on the device during backward (collectives on a communication stream)
+// must switch the backward one off.  DS2_RNN_PERSISTENT=0 in the environment switches both off.
+extern "C" int ds2_rnn_persistent_enable(int forward, int backward) {
+  g_persist_fwd = forward != 0;
+  g_persist_bwd = backward != 0;
+  return 0;
 }
 
 //   dy     (T,B,H) pitch lddy: grad wrt y = h_fwd + h_bwd
@@ -958,5 +1218,10 @@ extern "C" int ds2_rnn_bwd(int gates, const float* dy, int lddy, float* gx, floa
   a.dgx_bf = (__bf16*)dgx_bf16;
   a.gates_bf = (__bf16*)const_cast<void*>(gates_bf16);
   a.lens = lens_dev; a.T = T; a.B = B; a.H = H;
+  if (bf16) {
+    a.dbg = g_ds2_debug_flags;
+    const int rc = gates == 3 ? try_launch_persistent_bwd<3>(a, (hipStream_t)stream) : try_launch_persistent_bwd<4>(a, (hipStream_t)stream);
+    if (rc != 0) return rc < 0 ? rc : 0;
+  }
   return bf16 ? dispatch<true>(gates, true, a, (hipStream_t)stream) : dispatch<false>(gates, true, a, (hipStream_t)stream);
 }

@@ -537,6 +537,12 @@ def rnn_pack(gates: int, whh: Tensor, bf16: bool = False):
     return wpf, wpb
 
 
+def rnn_persistent_enable(forward: bool = True, backward: bool = True) -> None:
+    """Which bf16 recurrences may run as one persistent launch.  A persistent launch needs all of its workgroups resident at once, so
+    the backward one must be off while collectives run on a communication stream during backward (data-parallel training)."""
+    _lib.check(_lib.load().ds2_rnn_persistent_enable(int(bool(forward)), int(bool(backward))), "ds2_rnn_persistent_enable")
+
+
 def rnn_persistent_check() -> None:
     """Raise if a persistent forward-recurrence launch starved since the last call (a workgroup never saw its operand: the launch
     needs every workgroup resident at once).  Call at a point where the device is idle anyway (the train step's loss sync)."""

@@ -130,6 +130,9 @@ class DeepSpeechTrainer:
         flat, grad = self._model.flat_parameters()
         if self._reducer is None or self._reducer.flat_grad.data_ptr() != grad.data_ptr():
             self._reducer = BucketedAllReducer(grad, self._model._flat.layer_buckets())
+            # gradient buckets are all-reduced on a communication stream WHILE backward runs: the persistent backward recurrence (which
+            # needs every workgroup resident at once) is only used single-GPU; the forward one never overlaps a collective
+            ops.rnn_persistent_enable(True, self._reducer.world == 1 or os.environ.get("DS2_RNN_PERSISTENT_BWD_DP", "0") == "1")
         return self._reducer
 
     def step(self, data):

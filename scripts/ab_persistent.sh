@@ -1,16 +1,35 @@
 #!/bin/bash
-# same-box A/B: persistent forward recurrence (default) vs one launch per step (DS2_RNN_PERSISTENT=0)
+# same-box A/B: persistent recurrences (default) vs one launch per step (DS2_RNN_PERSISTENT=0), micro-benchmark (packed bf16 training mode) + c3 bench
 cd "$(dirname "$0")/.."
 for rep in 1 2; do for p in 1 0; do
   echo "== DS2_RNN_PERSISTENT=$p (rep $rep)"
-  DS2_RNN_PERSISTENT=$p ABLATE_SKIP=1 timeout 200 python - <<'PY' 2>&1 | grep -v amdgpu.ids
-import sys
-sys.path.insert(0, "scripts")
-from ablate_rnn import run
+  DS2_RNN_PERSISTENT=$p timeout 200 python - <<'PY' 2>&1 | grep -v amdgpu.ids
+import sys, torch
+sys.path.insert(0, ".")
+from asr_amd import ops
+dev = torch.device("cuda:0")
+def run(G, H, B, T=501):
+    M = T * B
+    gx = torch.randn(M, 2 * G * H, device=dev) * 0.5
+    whh = (torch.rand(2, G * H, H, device=dev) * 2 - 1) / H ** 0.5
+    bhh = torch.zeros(2, G * H, device=dev)
+    lens = torch.full((B,), T, dtype=torch.int32, device=dev)
+    wpf, wpb = ops.rnn_pack(G, whh, bf16=True)
+    dy = torch.randn(M, H, device=dev)
+    best = [1e9, 1e9]
+    for _ in range(3):
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        torch.cuda.synchronize(); e[0].record()
+        hb, aux, rec = ops.rnn_fwd(G, gx, wpf, bhh, lens, T, B, H, bf16=True, packed_gates=True)
+        e[1].record()
+        side = torch.empty(M, 2 * G * H, dtype=torch.bfloat16, device=dev)
+        ops.rnn_bwd(G, dy, None, aux, hb, wpb, lens, T, B, H, bf16=True, dgx_bf16=side, gates_bf16=rec)
+        e[2].record(); torch.cuda.synchronize()
+        best = [min(best[0], e[0].elapsed_time(e[1]) * 1e3 / T), min(best[1], e[1].elapsed_time(e[2]) * 1e3 / T)]
+    return best
 for (name, G, H, B) in [("c3", 3, 1024, 64), ("c2", 3, 768, 32), ("c4", 4, 1280, 32), ("c5", 3, 1024, 32)]:
-    f = min(run(G, H, B, 501, False, 0, True) for _ in range(3))
-    print(f"{name} bf16 fwd {f:6.2f} us/step", flush=True)
+    f, b = run(G, H, B)
+    print(f"{name} bf16 fwd {f:6.2f} bwd {b:6.2f} us/step", flush=True)
 PY
   DS2_RNN_PERSISTENT=$p timeout 300 python bench.py --workload c3 --steps 8 --warmup 3 --no-cpu-baseline 2>&1 | grep -o '"ms_per_step": [0-9.]*'
 done; done
-timeout 300 python scripts/det_check.py 40 2>&1 | grep -v amdgpu.ids | cut -c1-200 | tail -3
