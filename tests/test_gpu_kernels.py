@@ -330,7 +330,9 @@ def test_lds_dma_kernels_rerun_bit_identical(dev):
                                              ("lstm", 40, 37, 11, None), ("gru", 16, 1, 5, [5]),
                                              # wide layers: more 16x16 tiles than CUs -> 32-row tiles forward, 16 rows x 32 units backward
                                              # (even slice count) or 32 x 16 backward (odd slice count); ragged last batch tile
-                                             ("gru", 1056, 33, 4, None), ("lstm", 1056, 20, 3, None), ("gru", 1040, 33, 3, None)])
+                                             ("gru", 1056, 33, 4, None), ("lstm", 1056, 20, 3, None), ("gru", 1040, 33, 3, None),
+                                             # the metric configuration's own layer shape (persistent kernels with 256 workgroups), ragged tiles
+                                             ("gru", 1024, 61, 5, None), ("lstm", 768, 40, 4, None)])
 def test_rnn_fwd_bwd(dev, kind, H, B, T, lens, bf):
     tol = 3e-2 if bf else 1.0      # bf16 operands in the h W_hh product: separately stated tolerance (x the fp32 asserts' 2e-5..5e-5 -> 2e-2)
     from asr_amd import ops
@@ -399,6 +401,17 @@ def test_rnn_fwd_bwd(dev, kind, H, B, T, lens, bf):
         aux_in = aux3 if G == 4 else torch.full_like(aux3, float("nan"))          # GRU: aux must not be read
         ops.rnn_bwd(G, g(dy.float().reshape(T * B, H), dev), None, aux_in, hb3, wpb, ld, T, B, H, bf16=True, dgx_bf16=side3, gates_bf16=rec)
         assert rel_l2(side3.float().view(T, B, 2, G * H).cpu(), gx.grad) < e2     # gates rounded to bf16: same stated tolerance
+        # the persistent kernels (one launch per layer, taken whenever the shape qualifies) against the one-launch-per-step kernels
+        # (any debug flag selects those): same K split, same accumulation order -> bit-identical forward and backward
+        from asr_amd import _lib
+        _lib.load().ds2_debug_flags(64)
+        hb4, aux4, rec4 = ops.rnn_fwd(G, keep_x.clone(), wpf, bhd, ld, T, B, H, bf16=True, packed_gates=True)
+        side4 = torch.empty_like(side3)
+        aux_in4 = aux4.clone() if G == 4 else torch.full_like(aux4, float("nan"))
+        ops.rnn_bwd(G, g(dy.float().reshape(T * B, H), dev), None, aux_in4, hb4, wpb, ld, T, B, H, bf16=True, dgx_bf16=side4, gates_bf16=rec4)
+        _lib.load().ds2_debug_flags(0)
+        assert torch.equal(hb4, hb3) and torch.equal(rec4, rec) and torch.equal(side4, side3) and torch.equal(aux_in4, aux_in)
+        ops.rnn_persistent_check()                                                # no persistent launch starved
         if G == 3:
             assert bool(torch.isfinite(aux_in).all()) and rel_l2(aux_in.cpu(), aux.cpu()) < 2e-2
         tT, cs = ops.transpose_bf16(side_buf, colsum=True)
