@@ -237,18 +237,38 @@ def main():
     ops.rnn_fwd(G, gx2, wpf, bhh, lens, T, B, H, bf16=bf, packed_gates=pack)
     e1.record()
     torch.cuda.synchronize()
-    us_per_launch = e0.elapsed_time(e1) * 1e3 / T
-    flops_per_launch = 2.0 * 2 * B * H * G * H           # both directions, one time step
+    layer_us = e0.elapsed_time(e1) * 1e3                 # one layer's whole forward recurrence (T time steps, both directions)
+    # bf16 mode runs the recurrence as ONE persistent launch per layer (rnn_fwd_persistent_kernel) when every workgroup can be resident at
+    # once (grid <= CU count) — what ds2_rnn_fwd decides; otherwise (and in fp32) it is one rnn_fwd_step_kernel launch per time step.
+    def pick_mb(b, h):                                   # mirrors rnn.hip: 16-row batch tiles per workgroup
+        nsl = -(-h // 16)
+        if b <= 16:
+            return 1
+        if nsl * -(-b // 16) * 2 > 256:
+            return 2
+        return 2 if nsl * -(-b // 32) * 2 >= 200 else 1
+    mbt = pick_mb(B, H)
+    persistent = (bf and H % 16 == 0 and -(-H // 32) <= 40 and os.environ.get("DS2_RNN_PERSISTENT", "1") != "0"
+                  and (H // 16) * -(-B // (16 * mbt)) * 2 <= torch.cuda.get_device_properties(dev).multi_processor_count)
+    launches = 1 if persistent else T
+    us_per_launch = layer_us / launches
+    flops_per_launch = 2.0 * 2 * B * H * G * H * (T if persistent else 1)      # both directions; all T steps in the persistent launch
     achieved = flops_per_launch / (us_per_launch * 1e-6) / 1e12
     peak = BF16_MFMA_PEAK_TFLOPS if bf else FP32_MFMA_PEAK_TFLOPS
-    # HBM-side bytes per launch from rocprofv3 PMC passes (profiles/r01_pmc/: FETCH_SIZE 9281 KB x2 gfx950 correction
-    # + WRITE_SIZE 1792 KB = the algorithmic writes), measured for exactly this shape and mode (c3, bf16 operands, packed gate
-    # records); null for other shapes.
-    traffic = 20.84e6 if (args.workload == "c3" and bf and B == 64) else None
-    roofline = {"kernel": "rnn_fwd_step_kernel", "bound": "mfma", "achieved": achieved, "peak": peak,
-                "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-                "algorithmic_hbm_bytes_per_launch": ((3 * 4 + 8 + 4 + 2 if pack else 8 * 4 + (2 if bf else 4)) * B * 2 * H),
-                "us_per_launch": us_per_launch, "launches_per_step": 2 * T * L}
+    # HBM-side bytes from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), measured for exactly this shape and mode
+    # (c3, bf16 operands, packed gate records): 7.53 MB per time step in the persistent kernel (profiles/r01_pmc_persistent/), 20.84 MB
+    # per launch of the step kernel (profiles/r01_pmc/); null for other shapes.
+    traffic = None
+    if args.workload == "c3" and bf and B == 64:
+        traffic = 7.53e6 * T if persistent else 20.84e6
+    alg_bytes_step = (3 * 4 + 8 + 4 + 2 if pack else 8 * 4 + (2 if bf else 4)) * B * 2 * H
+    roofline = {"kernel": "rnn_fwd_persistent_kernel" if persistent else "rnn_fwd_step_kernel", "bound": "mfma", "achieved": achieved,
+                "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                "algorithmic_hbm_bytes_per_launch": alg_bytes_step * (T if persistent else 1),
+                "us_per_launch": us_per_launch, "us_per_time_step": layer_us / T, "launches_per_step": 2 * launches * L if not persistent else None}
+    if persistent:
+        # forward recurrences are persistent launches (L per train step); backward ones too on a single GPU
+        roofline["launches_per_step"] = 2 * L
 
     if args.breakdown and rank == 0:
         breakdown(model, tr, x, targets, pct, tsz)
