@@ -11,7 +11,7 @@ from typing import Optional
 import torch
 from torch import nn
 
-from .. import _lib, engine
+from .. import _lib, engine, ops
 from ..device import resolve_device
 from ..params import FlatParams
 from ..vars import resolve_rnn_type
@@ -217,6 +217,8 @@ class DeepSpeech(nn.Module):
                     offset += size
                 out, output_sizes = self.forward(inputs, input_sizes)
                 decoded_output, _ = decoder.decode(out, output_sizes)
+                if self.precision == "bf16":
+                    ops.rnn_persistent_check()          # decode has synchronised the device: a starved persistent recurrence raises here
                 target_strings = decoder.convert_to_strings(split_targets)
                 if output_file is not None:
                     output_data.append((out.detach().cpu().numpy(), output_sizes.numpy(), target_strings))
