@@ -1147,8 +1147,13 @@ extern "C" int ds2_rnn_pack_whh(int gates, const float* whh, void* wp_fwd, void*
 extern "C" int ds2_rnn_persistent_status(int* out8) {
   DS2_HIP(hipDeviceSynchronize());
   DS2_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_persist_dbg), 8 * sizeof(int)));
-  int zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  DS2_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_persist_dbg), zero, sizeof(zero)));
+  if (out8[0]) {
+    // a launch starved (not every workgroup could be resident, or something else held CUs): stay on the one-launch-per-step kernels from
+    // here on, so that the caller's retry / next step works; the step that starved is invalid and must be reported as failed
+    g_persist_fwd = g_persist_bwd = 0;
+    int zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    DS2_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_persist_dbg), zero, sizeof(zero)));
+  }
   return 0;
 }
 

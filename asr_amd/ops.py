@@ -551,7 +551,7 @@ def rnn_persistent_check() -> None:
     if rec[0]:
         raise _lib.DS2LibraryError(f"persistent recurrence starved: block ({rec[1]}, {rec[2]}, {rec[3]}) step {rec[4]} wave {rec[5]} never received its "
                                    f"operand (lanes ok {rec[7] & 0xffffffff:08x}{rec[6] & 0xffffffff:08x}); the results of that step are invalid. "
-                                   f"Set DS2_RNN_PERSISTENT=0 to use the one-launch-per-step kernels.")
+                                   f"The library has switched to the one-launch-per-step kernels for the rest of the process (DS2_RNN_PERSISTENT=0 selects them from the start).")
 
 
 def rnn_fwd(gates: int, gx: Tensor, wp_fwd: Tensor, bhh: Tensor, lens_dev: Tensor, T: int, B: int, H: int, bf16: bool = False,

@@ -442,6 +442,41 @@ def test_rnn_fwd_bwd(dev, kind, H, B, T, lens, bf):
     assert rel_l2(dbhh.cpu(), bhh.grad) < e2
 
 
+STARVE_WORKER = r"""
+import os, sys, torch
+sys.path.insert(0, os.environ["REPO"])
+from asr_amd import ops, _lib
+G, H, B, T = 3, 256, 32, 40
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+gx = torch.randn(T * B, 2 * G * H, device=dev) * 0.5
+whh = (torch.rand(2, G * H, H, device=dev) * 2 - 1) / H ** 0.5
+bhh = torch.zeros(2, G * H, device=dev)
+lens = torch.full((B,), T, dtype=torch.int32, device=dev)
+wpf, _ = ops.rnn_pack(G, whh, bf16=True)
+h1 = ops.rnn_fwd(G, gx.clone(), wpf, bhh, lens, T, B, H, bf16=True)[0]          # persistent launch that gives up at its first failed poll
+try:
+    ops.rnn_persistent_check()
+    print("NO-RAISE")
+except _lib.DS2LibraryError as e:
+    print("RAISED", "starved" in str(e))
+h2 = ops.rnn_fwd(G, gx.clone(), wpf, bhh, lens, T, B, H, bf16=True)[0]          # the library has fallen back to the step kernels
+ops.rnn_persistent_check()
+_lib.load().ds2_debug_flags(64)
+h3 = ops.rnn_fwd(G, gx.clone(), wpf, bhh, lens, T, B, H, bf16=True)[0]          # step kernels, explicitly
+print("FALLBACK-EQUAL", bool(torch.equal(h2, h3)))
+"""
+
+
+def test_persistent_recurrence_starvation_is_loud_and_falls_back(dev):
+    """A persistent launch whose waves give up polling (forced here with a poll limit of 0) must be reported: the status check raises,
+    and the library then runs the one-launch-per-step kernels for the rest of the process."""
+    import os, subprocess, sys as _sys
+    env = dict(os.environ, DS2_RNN_SPIN_LIMIT="0", REPO=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([_sys.executable, "-c", STARVE_WORKER], env=env, capture_output=True, text=True, timeout=300).stdout
+    assert "RAISED True" in out and "FALLBACK-EQUAL True" in out, out
+
+
 # ---------------------------------------------------------------------------------------------- CTC
 @pytest.mark.parametrize("case", ["a", "b", "c"])
 def test_ctc_golden(dev, case):
