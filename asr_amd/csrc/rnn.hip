@@ -428,6 +428,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
 
   for (int s = 0; s < T; ++s) {
     const int t = dir == 0 ? s : T - 1 - s;
+    RNN_TRACE(s, 0);
     f32x4 acc[MB][G];
 #pragma unroll
     for (int i = 0; i < MB; ++i)
@@ -474,6 +475,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
           return;
         }
       }
+      RNN_TRACE(s, 1);
 #pragma unroll
       for (int k = 0; k < NCW; ++k)
 #pragma unroll
@@ -495,7 +497,9 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
     for (int i = 0; i < MB; ++i)
 #pragma unroll
       for (int g = 0; g < G; ++g) red[wave][i * G + g][lane] = acc[i][g];
+    RNN_TRACE(s, 2);
     __syncthreads();
+    RNN_TRACE(s, 3);
 
     // ---- gate math (identical to the step kernel's epilogue)
     float out_g[4] = {0.f, 0.f, 0.f, 0.f}, out_aux = 0.f, hnew = 0.f;
@@ -531,6 +535,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
     } else {
       pprev = 0.f;                                      // beyond the sample's length: state is zero (what the step kernels re-read)
     }
+    RNN_TRACE(s, 6);
     if (mb < MB) stage[stage_idx] = (__bf16)hnew;       // rows beyond B / units beyond H publish zeros: consumers wait for every piece
     if (wave == NW - 2) {
       // ALL waves of this workgroup are past this step's gather (barrier above), so all 64 workgroups of the group have published
@@ -541,6 +546,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
       if (piece_lane) store16_sc1(xbuf + (long long)((s + 2) & 3) * bufbytes + piece_off, u32x4_{PSENT, PSENT, PSENT, PSENT});
     }
     __syncthreads();
+    RNN_TRACE(s, 7);
     if (wave == NW - 1) {
       if (piece_lane) store16_sc1(xbuf + (long long)(s & 3) * bufbytes + piece_off, *reinterpret_cast<const u32x4_*>(&stage[(lane >> 5) * 256 + (lane & 31) * 8]));
       if (more && pact) {
@@ -563,6 +569,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
       }
       a.hbuf[rowH] = hnew;
     }
+    RNN_TRACE(s, 4);
 #pragma unroll
     for (int g = 0; g < G; ++g) pgx[g] = pgx_next[g];
   }

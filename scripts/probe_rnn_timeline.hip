@@ -61,23 +61,24 @@ int main() {
       }
     unsigned long long next0 = ~0ull;
     for (int w = 0; w < NW; ++w) { const unsigned long long v = tr[((size_t)(s + 1) * NW + w) * 8 + 0]; if (v < next0) next0 = v; }
-    span[0] += (double)(mx[1] - mn[0]);   // entry -> operand loads issued, args in SGPRs
-    span[1] += (double)(mx[2] - mx[1]);   // -> MFMAs done
-    span[2] += (double)(mx[3] - mx[2]);   // -> barrier passed
-    span[3] += (double)(mx[6] - mx[3]);   // -> partial sums read back
-    span[4] += (double)(mx[7] - mx[6]);   // -> epilogue operands landed
-    span[5] += (double)(mx[4] - mx[7]);   // -> gate math done, stores issued
-    span[6] += (double)(mx[5] - mx[4]);   // -> stores acknowledged
-    span[7] += (double)(next0 - mx[5]);   // -> next launch's first wave enters
+    // persistent kernel stamps: 0 step start, 1 gather done (operand polled in), 2 MFMAs done + partial sums written, 3 barrier A passed,
+    // 6 LDS sums + gate math done, 7 barrier B passed (piece staged), 4 end of the step's stores (next step starts)
+    span[0] += (double)(mx[1] - mn[0]);
+    span[1] += (double)(mx[2] - mx[1]);
+    span[2] += (double)(mx[3] - mx[2]);
+    span[3] += (double)(mx[6] - mx[3]);
+    span[4] += (double)(mx[7] - mx[6]);
+    span[5] += (double)(mx[4] - mx[7]);
+    span[6] += 0;
+    span[7] += (double)(next0 - mx[4]);
     period += (double)(next0 - mn[0]);
     ++n;
   }
   const double tick_us = us_per_step / (period / n);
   printf("period per step: %.2f us (HIP events, traced build) = %.1f ticks -> 1 tick = %.4f us\n", us_per_step, period / n, tick_us);
-  const char* names[8] = {"entry -> operand loads issued + kernel args in SGPRs", "-> MFMAs done (operand loads consumed)",
-                          "-> partial sums in LDS, barrier passed", "-> partial sums read back from LDS",
-                          "-> epilogue operands landed (vmcnt 0)", "-> gate math done, stores issued",
-                          "-> stores acknowledged (vmcnt 0)", "-> next launch's first wave enters (boundary)"};
+  const char* names[8] = {"step start -> operand gathered (tag polling)", "-> MFMAs done, partial sums written", "-> barrier A passed",
+                          "-> LDS sums + gate math done", "-> piece staged, barrier B passed", "-> publish + HBM stores issued",
+                          "(unused)", "-> next step starts"};
   for (int k = 0; k < 8; ++k) printf("  %-56s %6.2f us\n", names[k], span[k] / n * tick_us);
   return 0;
 }
