@@ -371,8 +371,8 @@ __device__ int g_persist_dbg[8];      // first starved wave of a persistent laun
 template <int G, int MB, int NCW>
 __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, char* xbuf, int spin_limit) {
   static_assert(MB * 256 <= NW * 64, "one (row, unit) pair per thread");
-  __shared__ __attribute__((aligned(16))) f32x4 red[NW][MB * G][64];
-  __shared__ __attribute__((aligned(16))) __bf16 stage[MB * 32 * 8];          // this workgroup's piece of packed h_t (MB x 512 B)
+  __shared__ __attribute__((aligned(16))) f32x4 red[2][NW][MB * G][64];       // double-buffered: ONE workgroup barrier per time step
+  __shared__ __attribute__((aligned(16))) __bf16 stage[NW][64];               // wave-private: a wave's 64 (row, unit) pairs = 8 complete 16-byte chunks
   const int dir = blockIdx.z, slice = blockIdx.x, bt = blockIdx.y;
   const int T = a.T, B = a.B, H = a.H;
   const int nsl = (H + 15) >> 4, nch = (H + 31) >> 5;
@@ -411,11 +411,10 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
   for (int g = 0; g < G; ++g) pb[g] = pact ? a.bhh[(dir * G + g) * H + j] : 0.f;
   float pprev = 0.f;                                                         // h_{t-1} (GRU) / c_{t-1} (LSTM)
   const int lg0 = (j0 & 31) >> 3;                                            // first of this slice's two lane groups inside its chunk
-  const int stage_idx = ((mb * 2 + (((j & 31) >> 3) - lg0)) * 16 + brow) * 8 + (j & 7);
-  // piece address of lane l of the publishing wave: tile bt*MB + (l >> 5), chunk j0 >> 5, lanes lg0*16 + (l & 31)
-  const long long piece_off = dirbase + ((((long long)(bt * MB + (lane >> 5)) * nch + (j0 >> 5)) * 64) + lg0 * 16 + (lane & 31)) * 16;
-  const bool piece_lane = (lane >> 5) < MB;
-
+  // A wave's 64 threads are 4 batch rows x 16 units = 8 complete 16-byte chunks of the packed buffer (chunk = one row, 8 units), so every
+  // wave publishes (and resets) its own chunks — no workgroup-wide staging.  Lane p < 8 handles row (wave & 3) * 4 + (p & 3), unit group p >> 2.
+  const bool pub_lane = lane < 8 && (wave >> 2) < MB;
+  const long long pub_off = dirbase + ((((long long)(bt * MB + (wave >> 2)) * nch + (j0 >> 5)) * 64) + (lg0 + (lane >> 2)) * 16 + (wave & 3) * 4 + (lane & 3)) * 16;
   auto gx_row = [&](int t) { return a.gx + (((long long)t * B + b) * 2 + dir) * G * H + j; };
   float pgx[G], pgx_next[G];
 #pragma unroll
@@ -486,17 +485,11 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
             acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v), __builtin_bit_cast(bf16x8, wreg[k][g]), acc[i][g], 0, 0, 0);
         }
     }
-    // ---- next step's gate pre-activations: HBM latency hidden under this step (the publishing wave issues its own after the publish)
     const bool more = s + 1 < T;
-    if (more && pact && wave != NW - 1) {
-      const float* pn = gx_row(dir == 0 ? s + 1 : T - 2 - s);
-#pragma unroll
-      for (int g = 0; g < G; ++g) pgx_next[g] = ldnt(pn + g * H);
-    }
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
-      for (int g = 0; g < G; ++g) red[wave][i * G + g][lane] = acc[i][g];
+      for (int g = 0; g < G; ++g) red[s & 1][wave][i * G + g][lane] = acc[i][g];
     RNN_TRACE(s, 2);
     __syncthreads();
     RNN_TRACE(s, 3);
@@ -510,7 +503,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
       for (int g = 0; g < G; ++g) {
         float sum = 0.f;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) sum += red[w][mb * G + g][src_lane][reg];
+        for (int w = 0; w < NW; ++w) sum += red[s & 1][w][mb * G + g][src_lane][reg];
         gh[g] = sum + pb[g];
       }
       if constexpr (G == 3) {
@@ -536,24 +529,23 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
       pprev = 0.f;                                      // beyond the sample's length: state is zero (what the step kernels re-read)
     }
     RNN_TRACE(s, 6);
-    if (mb < MB) stage[stage_idx] = (__bf16)hnew;       // rows beyond B / units beyond H publish zeros: consumers wait for every piece
-    if (wave == NW - 2) {
-      // ALL waves of this workgroup are past this step's gather (barrier above), so all 64 workgroups of the group have published
-      // h_{s-1}, i.e. have finished gathering h_{s-2}: its buffer ((s+2) & 3) can be reset for h_{s+2}.  The wait in front makes sure
-      // the PREVIOUS reset (buffer (s+1) & 3, where h_{s+1} goes) was acknowledged before the barrier below lets h_s out: whoever has
-      // seen h_s can then no longer find a stale h_{s-3} piece where it will poll for h_{s+1}.
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (piece_lane) store16_sc1(xbuf + (long long)((s + 2) & 3) * bufbytes + piece_off, u32x4_{PSENT, PSENT, PSENT, PSENT});
+    // ---- publish h_s: wave-local assembly of this wave's 8 chunks, then ONE 16-byte sc1 store per publishing lane.
+    // Order per wave and step: [wait: my previous reset (and everything older) is acknowledged] publish(s) -> reset(s) -> HBM stores ->
+    // next step's HBM loads.  The wait costs nothing (everything outstanding was issued a whole step ago), and it is what makes "a
+    // consumer that has seen my chunk of h_s finds the sentinel, not my stale h_{s-3}, where it will poll for h_{s+1}" true.
+    // The reset of buffer (s+2) & 3 is safe here: this wave is past the step's barrier, so all 64 workgroups of the group have published
+    // h_{s-1}, i.e. have finished gathering h_{s-2}.
+    stage[wave][lane] = (__bf16)hnew;                   // rows beyond B / units beyond H publish zeros: consumers wait for every chunk
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (pub_lane) {
+      store16_sc1(xbuf + (long long)(s & 3) * bufbytes + pub_off, *reinterpret_cast<const u32x4_*>(&stage[wave][(lane & 3) * 16 + (lane >> 2) * 8]));
+      store16_sc1(xbuf + (long long)((s + 2) & 3) * bufbytes + pub_off, u32x4_{PSENT, PSENT, PSENT, PSENT});
     }
-    __syncthreads();
     RNN_TRACE(s, 7);
-    if (wave == NW - 1) {
-      if (piece_lane) store16_sc1(xbuf + (long long)(s & 3) * bufbytes + piece_off, *reinterpret_cast<const u32x4_*>(&stage[(lane >> 5) * 256 + (lane & 31) * 8]));
-      if (more && pact) {
-        const float* pn = gx_row(dir == 0 ? s + 1 : T - 2 - s);
+    if (more && pact) {
+      const float* pn = gx_row(dir == 0 ? s + 1 : T - 2 - s);
 #pragma unroll
-        for (int g = 0; g < G; ++g) pgx_next[g] = ldnt(pn + g * H);
-      }
+      for (int g = 0; g < G; ++g) pgx_next[g] = ldnt(pn + g * H);
     }
     // ---- saved-for-backward outputs (after the publish: nothing on the exchange's critical path waits for HBM write acks)
     if (pact) {
@@ -745,9 +737,8 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(const float* pk, 
 template <int G, int MB, int NS, int NCW>
 __global__ __launch_bounds__(NW * 64) void rnn_bwd_persistent_kernel(RnnArgs a, char* xbuf, int spin_limit) {
   static_assert(MB * NS * 256 <= NW * 64, "one (row, unit) pair per thread");
-  constexpr int PL = 32 * NS;                                                 // lanes of one published run (one gate, one tile)
-  __shared__ __attribute__((aligned(16))) f32x4 red[NW][MB * NS][64];
-  __shared__ __attribute__((aligned(16))) __bf16 stage[MB * G * PL * 8];
+  __shared__ __attribute__((aligned(16))) f32x4 red[2][NW][MB * NS][64];      // double-buffered: one workgroup barrier per time step
+  __shared__ __attribute__((aligned(16))) __bf16 stage[NW][G][64];             // wave-private: 8 complete 16-byte chunks per gate
   const int dir = blockIdx.z, slice = blockIdx.x, bt = blockIdx.y;
   const int T = a.T, B = a.B, H = a.H, lddy = a.lddy;
   const int nsl = (H + 15) >> 4, nchb = (G * H + 31) >> 5;
@@ -800,19 +791,15 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_persistent_kernel(RnnArgs a, 
   };
   Ops cur = fetch(0), nxt = cur;
 
-  // where this pair's G values go inside the staged piece, and the address of the piece's runs in a packed buffer
-  int stg[G];
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    const int k = g * H + j, lg0 = ((g * H + j0) & 31) >> 3;
-    stg[g] = (((mb * G + g) * PL) + ((((k & 31) >> 3) - lg0) * 16 + brow)) * 8 + (k & 7);
+  // A wave's 64 threads are 4 batch rows x 16 units: per gate 8 complete 16-byte chunks of the packed dGh buffer.  Lane p < 8 * G publishes
+  // (and resets) chunk (gate p / 8, row (wave & 3) * 4 + (p & 3), unit group (p >> 2) & 1) of this wave's (tile, slice) = wave >> 2.
+  const int pg = lane >> 3, pp = lane & 7;
+  const bool pub_lane = lane < 8 * G && (wave >> 2) < MB * NS;
+  long long pub_off = 0;
+  {
+    const int wsub = wave >> 2, k0 = pg * H + j0 + (wsub % NS) * 16;            // first k of this wave's units in gate pg
+    pub_off = dirbase + ((((long long)(bt * MB + wsub / NS) * nchb + (k0 >> 5)) * 64) + (((k0 & 31) >> 3) + (pp >> 2)) * 16 + (wave & 3) * 4 + (pp & 3)) * 16;
   }
-  // run r = mb * G + g of the piece: tile bt*MB + mb, chunk (g*H + j0) >> 5, lanes lg0*16 .. + PL
-  auto run_off = [&](int r) {
-    const int m = r / G, g = r % G;
-    const int k0 = g * H + j0;
-    return dirbase + ((((long long)(bt * MB + m) * nchb + (k0 >> 5)) * 64) + ((k0 & 31) >> 3) * 16 + lane) * 16;
-  };
 
   for (int s = 0; s < T; ++s) {
     const int t = dir == 0 ? T - 1 - s : s;
@@ -867,11 +854,10 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_persistent_kernel(RnnArgs a, 
         }
     }
     const bool more = s + 1 < T;
-    if (more && wave < NW - 2) nxt = fetch(s + 1);      // (the resetting / publishing waves fetch after their sc1 stores)
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
-      for (int n = 0; n < NS; ++n) red[wave][i * NS + n][lane] = acc[i][n];
+      for (int n = 0; n < NS; ++n) red[s & 1][wave][i * NS + n][lane] = acc[i][n];
     __syncthreads();
 
     float dgh[G], dgx[G], dax = 0.f;
@@ -880,7 +866,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_persistent_kernel(RnnArgs a, 
     if (pact && t < plen) {
       float carry = 0.f;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) carry += red[w][sub][src_lane][reg];
+      for (int w = 0; w < NW; ++w) carry += red[s & 1][w][sub][src_lane][reg];
       if constexpr (G == 3) {
         const float dh = cur.dy + carry + dcar;
         const float r = cur.g0, z = cur.g1, n = cur.g2, hn = cur.g3;
@@ -910,27 +896,15 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_persistent_kernel(RnnArgs a, 
     } else {
       dcar = 0.f;
     }
-    if (pair) {
+    // ---- publish dGh_s (see the forward kernel): wave-local assembly, wait for my previous reset, publish, reset two steps ahead
 #pragma unroll
-      for (int g = 0; g < G; ++g) stage[stg[g]] = (__bf16)dgh[g];
+    for (int g = 0; g < G; ++g) stage[wave][g][lane] = (__bf16)dgh[g];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (pub_lane) {
+      store16_sc1(xbuf + (long long)(s & 3) * bufbytes + pub_off, *reinterpret_cast<const u32x4_*>(&stage[wave][pg][(pp & 3) * 16 + (pp >> 2) * 8]));
+      store16_sc1(xbuf + (long long)((s + 2) & 3) * bufbytes + pub_off, u32x4_{PSENT, PSENT, PSENT, PSENT});
     }
-    if (wave == NW - 2) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the previous reset is acknowledged before this step's barrier
-      if (lane < PL) {
-#pragma unroll
-        for (int r = 0; r < MB * G; ++r) store16_sc1(xbuf + (long long)((s + 2) & 3) * bufbytes + run_off(r), u32x4_{PSENT, PSENT, PSENT, PSENT});
-      }
-      if (more) nxt = fetch(s + 1);
-    }
-    __syncthreads();
-    if (wave == NW - 1) {
-      if (lane < PL) {
-#pragma unroll
-        for (int r = 0; r < MB * G; ++r)
-          store16_sc1(xbuf + (long long)(s & 3) * bufbytes + run_off(r), *reinterpret_cast<const u32x4_*>(&stage[(r * PL + lane) * 8]));
-      }
-      if (more) nxt = fetch(s + 1);
-    }
+    if (more) nxt = fetch(s + 1);
     if (pact) {
       const long long row = ((long long)t * B + b) * 2 + dir;
       __bf16* gb = a.dgx_bf + row * G * H + j;
