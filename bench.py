@@ -256,11 +256,11 @@ def main():
     achieved = flops_per_launch / (us_per_launch * 1e-6) / 1e12
     peak = BF16_MFMA_PEAK_TFLOPS if bf else FP32_MFMA_PEAK_TFLOPS
     # HBM-side bytes from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), measured for exactly this shape and mode
-    # (c3, bf16 operands, packed gate records): 7.53 MB per time step in the persistent kernel (profiles/r01_pmc_persistent/), 20.84 MB
+    # (c3, bf16 operands, packed gate records): 7.47 MB per time step in the persistent kernel (profiles/r01_pmc_persistent/), 20.84 MB
     # per launch of the step kernel (profiles/r01_pmc/); null for other shapes.
     traffic = None
     if args.workload == "c3" and bf and B == 64:
-        traffic = 7.53e6 * T if persistent else 20.84e6
+        traffic = 7.47e6 * T if persistent else 20.84e6
     alg_bytes_step = (3 * 4 + 8 + 4 + 2 if pack else 8 * 4 + (2 if bf else 4)) * B * 2 * H
     roofline = {"kernel": "rnn_fwd_persistent_kernel" if persistent else "rnn_fwd_step_kernel", "bound": "mfma", "achieved": achieved,
                 "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
