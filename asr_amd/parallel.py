@@ -1,5 +1,11 @@
-"""Single-node data parallelism: one process per GPU, RCCL all-reduce of the flat gradient buffer
-in per-layer buckets launched in backward order on a side stream (overlaps the remaining backward).
+"""Single-node data parallelism: one process per GPU, RCCL all-reduce of the flat gradient buffer in per-layer buckets launched in
+backward order.  Two schedules (DS2_DP_MODE):
+  * "serial" (default): every bucket's all-reduce is ordered INTO the compute stream right where its gradients become final.  Nothing
+    overlaps, but nothing ever runs beside the persistent recurrence kernels either (they need every workgroup resident at once), so
+    backward keeps them: 188 MB of all-reduce per step (~1-2.5 ms on 8 GPUs over xGMI) is cheaper than the 7.5 ms the per-step
+    backward kernels cost.
+  * "overlap": buckets are reduced on a side stream while the rest of backward runs; the trainer then switches the persistent BACKWARD
+    recurrence off (ds2_rnn_persistent_enable(1, 0)).
 
 The reference has no live distributed code; semantics defined in SURVEY §8(e):
 per-rank BatchNorm statistics (plain DDP), gradients = mean over ranks of each rank's
@@ -24,7 +30,8 @@ class BucketedAllReducer:
         # DS2_FORCE_ALLREDUCE=1: run the bucketed all-reduce even with a single rank (exercises the RCCL / side-stream
         # path on a 1-GPU box; a 1-rank SUM is the identity)
         self.force = dist.is_initialized() and os.environ.get("DS2_FORCE_ALLREDUCE") == "1"
-        self.use_stream = flat_grad.is_cuda
+        self.mode = os.environ.get("DS2_DP_MODE", "serial")
+        self.use_stream = flat_grad.is_cuda and self.mode == "overlap"
         self.comm_stream = torch.cuda.Stream(device=flat_grad.device) if self.use_stream else None
         self._pending = []
         self.launched: List[str] = []
@@ -44,7 +51,11 @@ class BucketedAllReducer:
                 work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._pending.append(work)
         else:
-            self._pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if view.is_cuda:
+                work.wait()          # stream-level: the compute stream waits for the collective, the host does not
+            else:
+                self._pending.append(work)
 
     def finish(self):
         """Block the compute stream until every bucket is reduced.  Gradients hold the SUM over ranks;

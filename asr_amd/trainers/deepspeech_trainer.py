@@ -130,9 +130,10 @@ class DeepSpeechTrainer:
         flat, grad = self._model.flat_parameters()
         if self._reducer is None or self._reducer.flat_grad.data_ptr() != grad.data_ptr():
             self._reducer = BucketedAllReducer(grad, self._model._flat.layer_buckets())
-            # gradient buckets are all-reduced on a communication stream WHILE backward runs: the persistent backward recurrence (which
-            # needs every workgroup resident at once) is only used single-GPU; the forward one never overlaps a collective
-            ops.rnn_persistent_enable(True, self._reducer.world == 1 or os.environ.get("DS2_RNN_PERSISTENT_BWD_DP", "0") == "1")
+            # "overlap" schedule: buckets are all-reduced on a communication stream WHILE backward runs, so the persistent backward recurrence
+            # (which needs every workgroup resident at once) must be off; "serial" (default) orders the collectives into the compute stream
+            # and keeps it.  The forward recurrence never overlaps a collective in either schedule.
+            ops.rnn_persistent_enable(True, self._reducer.world == 1 or not self._reducer.use_stream)
         return self._reducer
 
     def step(self, data):
