@@ -2,10 +2,11 @@
 // pack_padded_sequence -> aten::gru/lstm -> pad_packed_sequence (blocks.py:87-89) and its backward.
 //
 // The input projections X W_ih^T + b_ih for all t and both directions are one big MFMA GEMM
-// (gemm.hip); this file is the strictly sequential part.  One launch per time step and BOTH
-// directions per launch (dir 0 walks t = s, dir 1 walks t = T-1-s): a kernel boundary is the
-// cheapest all-to-all seam on MI355X (measured launch floor 2.7 us/step; an in-kernel grid barrier
-// costs 4-7 us), and the W_hh slices a block re-reads every step stay in its XCD's L2.
+// (gemm.hip); this file is the strictly sequential part, in two kernel families with bit-identical results:
+//   * STEP kernels: one launch per time step and BOTH directions per launch (dir 0 walks t = s, dir 1 walks t = T-1-s); the kernel
+//     boundary is the all-to-all seam, the W_hh slices a block re-reads every step stay in its XCD's L2.  fp32 mode, and the fallback.
+//   * PERSISTENT kernels (bf16 mode, further down): one launch per layer, W_hh slice in registers, h_t exchanged between the resident
+//     workgroups by tagged-payload polling, one workgroup barrier per time step.  5.8 -> 3.5 us (forward) / 6.9 -> 3.9 us (backward) per step.
 //
 // Step kernel = [h_{t-1} (BT x H) @ W_hh^T slice] on the f32 matrix cores (v_mfma_f32_16x16x4_f32)
 // fused with the gate non-linearities, the per-sample length mask and the state write-back.
