@@ -26,6 +26,7 @@
 // or the cell state c (LSTM); h per direction.  Rows t >= len[b] hold zeros everywhere, which is
 // what makes the reverse direction start at each sample's own last frame.
 #include "common.h"
+#include <type_traits>
 
 extern int g_ds2_debug_flags;
 
@@ -369,14 +370,16 @@ __device__ __forceinline__ u32x4_ load16_sc1(const void* p) {
 constexpr unsigned PSENT = 0xffffffffu;
 __device__ int g_persist_dbg[8];      // first starved wave of a persistent launch: {set, block x, y, z, step, wave, ok-mask lo, hi}
 
-template <int G, int MB, int NCW>
+template <int G, int MB, int NCW, bool BF>
 __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, char* xbuf, int spin_limit) {
   static_assert(MB * 256 <= NW * 64, "one (row, unit) pair per thread");
   __shared__ __attribute__((aligned(16))) f32x4 red[2][NW][MB * G][64];       // double-buffered: ONE workgroup barrier per time step
-  __shared__ __attribute__((aligned(16))) __bf16 stage[NW][64];               // wave-private: a wave's 64 (row, unit) pairs = 8 complete 16-byte chunks
+  constexpr int KC = kchunk<BF>(), EPL = KC / 4;                              // units per chunk (32 | 16) and per 16-byte lane vector (8 | 4)
+  using elem_t = typename std::conditional<BF, __bf16, float>::type;
+  __shared__ __attribute__((aligned(16))) elem_t stage[NW][64];               // wave-private: a wave's 64 (row, unit) pairs = 64 / EPL complete 16-byte chunks
   const int dir = blockIdx.z, slice = blockIdx.x, bt = blockIdx.y;
   const int T = a.T, B = a.B, H = a.H;
-  const int nsl = (H + 15) >> 4, nch = (H + 31) >> 5;
+  const int nsl = (H + 15) >> 4, nch = (H + KC - 1) / KC;
   const int j0 = slice * 16, b0 = bt * (16 * MB);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -398,7 +401,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
   // lanes of a chunk whose 8 hidden units lie beyond H are never written by anybody: ignored by the poll, zero in the product
   bool lval[NCW];
 #pragma unroll
-  for (int k = 0; k < NCW; ++k) lval[k] = cval[k] && ((wave + NW * k) * 32 + (lane >> 4) * 8) < H;
+  for (int k = 0; k < NCW; ++k) lval[k] = cval[k] && ((wave + NW * k) * KC + (lane >> 4) * EPL) < H;
 
   // ---- this thread's (batch row, hidden unit) pair: fixed for the whole layer, so the previous state stays in a register
   const int q = threadIdx.x;
@@ -411,11 +414,16 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
 #pragma unroll
   for (int g = 0; g < G; ++g) pb[g] = pact ? a.bhh[(dir * G + g) * H + j] : 0.f;
   float pprev = 0.f;                                                         // h_{t-1} (GRU) / c_{t-1} (LSTM)
-  const int lg0 = (j0 & 31) >> 3;                                            // first of this slice's two lane groups inside its chunk
-  // A wave's 64 threads are 4 batch rows x 16 units = 8 complete 16-byte chunks of the packed buffer (chunk = one row, 8 units), so every
-  // wave publishes (and resets) its own chunks — no workgroup-wide staging.  Lane p < 8 handles row (wave & 3) * 4 + (p & 3), unit group p >> 2.
-  const bool pub_lane = lane < 8 && (wave >> 2) < MB;
-  const long long pub_off = dirbase + ((((long long)(bt * MB + (wave >> 2)) * nch + (j0 >> 5)) * 64) + (lg0 + (lane >> 2)) * 16 + (wave & 3) * 4 + (lane & 3)) * 16;
+  // A wave's 64 threads are 4 batch rows x 16 units = 64 / EPL complete 16-byte chunks of the packed buffer (chunk = one row, EPL units), so
+  // every wave publishes (and resets) its own chunks — no workgroup-wide staging.  Lane p < 64 / EPL handles row (wave & 3) * 4 + (p & 3) and
+  // unit group p >> 2 of this slice.
+  constexpr int NPUB = 64 / EPL;
+  const bool pub_lane = lane < NPUB && (wave >> 2) < MB;
+  long long pub_off;
+  {
+    const int ju = j0 + (lane >> 2) * EPL;                                    // first unit of this lane's group
+    pub_off = dirbase + ((((long long)(bt * MB + (wave >> 2)) * nch + ju / KC) * 64) + ((ju % KC) / EPL) * 16 + (wave & 3) * 4 + (lane & 3)) * 16;
+  }
   auto gx_row = [&](int t) { return a.gx + (((long long)t * B + b) * 2 + dir) * G * H + j; };
   float pgx[G], pgx_next[G];
 #pragma unroll
@@ -481,9 +489,17 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
           const u32x4_ v = lval[k] ? av[k][i] : u32x4_{0u, 0u, 0u, 0u};
+          if constexpr (BF) {
 #pragma unroll
-          for (int g = 0; g < G; ++g)
-            acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v), __builtin_bit_cast(bf16x8, wreg[k][g]), acc[i][g], 0, 0, 0);
+            for (int g = 0; g < G; ++g)
+              acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v), __builtin_bit_cast(bf16x8, wreg[k][g]), acc[i][g], 0, 0, 0);
+          } else {
+            const f32x4 vf = __builtin_bit_cast(f32x4, v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)                   // same element order as the step kernel (mfma_packed): bit-identical sums
+#pragma unroll
+              for (int g = 0; g < G; ++g) acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[e], wreg[k][g][e], acc[i][g], 0, 0, 0);
+          }
         }
     }
     const bool more = s + 1 < T;
@@ -536,10 +552,10 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
     // consumer that has seen my chunk of h_s finds the sentinel, not my stale h_{s-3}, where it will poll for h_{s+1}" true.
     // The reset of buffer (s+2) & 3 is safe here: this wave is past the step's barrier, so all 64 workgroups of the group have published
     // h_{s-1}, i.e. have finished gathering h_{s-2}.
-    stage[wave][lane] = (__bf16)hnew;                   // rows beyond B / units beyond H publish zeros: consumers wait for every chunk
+    stage[wave][lane] = (elem_t)hnew;                   // rows beyond B / units beyond H publish zeros: consumers wait for every chunk
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (pub_lane) {
-      store16_sc1(xbuf + (long long)(s & 3) * bufbytes + pub_off, *reinterpret_cast<const u32x4_*>(&stage[wave][(lane & 3) * 16 + (lane >> 2) * 8]));
+      store16_sc1(xbuf + (long long)(s & 3) * bufbytes + pub_off, *reinterpret_cast<const u32x4_*>(&stage[wave][(lane & 3) * 16 + (lane >> 2) * EPL]));
       store16_sc1(xbuf + (long long)((s + 2) & 3) * bufbytes + pub_off, u32x4_{PSENT, PSENT, PSENT, PSENT});
     }
     RNN_TRACE(s, 7);
@@ -987,7 +1003,7 @@ int cu_count() {
 
 // Forward recurrence in one persistent launch (bf16 operands).  Returns 1 if launched, 0 if the shape / device does not qualify
 // (the caller then runs the step kernels), < 0 on error.
-template <int G>
+template <int G, bool BF>
 int try_launch_persistent_fwd(RnnArgs a, hipStream_t st) {
   static const char* env = getenv("DS2_RNN_PERSISTENT");          // "0" = always the step kernels (A/B runs, debugging)
   if (env && env[0] == '0') return 0;
@@ -995,22 +1011,32 @@ int try_launch_persistent_fwd(RnnArgs a, hipStream_t st) {
   if (!g_persist_fwd || (a.H % 16) != 0 || a.T < 2) return 0;
   const int mb = pick_mb(a.B, a.H);
   const int nsl = a.H / 16, nbt = ceil_div(a.B, 16 * mb);
-  const int nch = ceil_div(a.H, 32), ncw = ceil_div(nch, NW);
-  if (ncw > 5) return 0;
-  // every workgroup must be resident at once: one per CU (96-144 KB of registers + up to 65 KB of LDS each)
+  const int nch = ceil_div(a.H, kchunk<BF>());
+  int ncw = ceil_div(nch, NW);
+  if (!BF) ncw = ceil_div(ncw, 2) * 2;                            // fp32 instantiations: 2, 4, 6, 8 chunks per wave
+  // registers: W_hh fragments ncw * G + operand ncw * mb lane vectors of 4 VGPRs, next to ~70 for everything else
+  if (ncw > (BF ? 5 : 8) || ncw * (G + mb) * 4 > 176) return 0;
+  // every workgroup must be resident at once: one per CU (up to 160 KB of registers + up to 129 KB of LDS each)
   if ((long long)nsl * nbt * 2 > cu_count()) return 0;
   a.nsl = nsl;
   a.nbt16 = ceil_div(a.B, 32) * 2;
   char* xbuf = reinterpret_cast<char*>(a.pk);
-  DS2_HIP(hipMemsetAsync(xbuf, 0xff, 4 * fwd_xbuf_bytes(a.B, a.H, 1), st));      // every 16-byte chunk = the "not yet published" sentinel
+  DS2_HIP(hipMemsetAsync(xbuf, 0xff, 4 * fwd_xbuf_bytes(a.B, a.H, BF ? 1 : 0), st));      // every 16-byte chunk = the "not yet published" sentinel
   dim3 grid(nsl, nbt, 2), block(NW * 64);
   static const char* sl = getenv("DS2_RNN_SPIN_LIMIT");
-  const int spin_limit = sl ? atoi(sl) : (1 << 20);              // ~1 s of polling: a missing workgroup traps instead of hanging the queue
-#define DS2_PLAUNCH(MB_, NCW_) hipLaunchKernelGGL((rnn_fwd_persistent_kernel<G, MB_, NCW_>), grid, block, 0, st, a, xbuf, spin_limit)
+  const int spin_limit = sl ? atoi(sl) : (1 << 20);              // ~1 s of polling: a missing workgroup is reported instead of hanging the queue
+#define DS2_PLAUNCH(MB_, NCW_) hipLaunchKernelGGL((rnn_fwd_persistent_kernel<G, MB_, NCW_, BF>), grid, block, 0, st, a, xbuf, spin_limit)
 #define DS2_PCASE(NCW_) case NCW_: if (mb == 2) DS2_PLAUNCH(2, NCW_); else DS2_PLAUNCH(1, NCW_); break;
-  switch (ncw) {
-    DS2_PCASE(1) DS2_PCASE(2) DS2_PCASE(3) DS2_PCASE(4) DS2_PCASE(5)
-    default: return 0;
+  if constexpr (BF) {
+    switch (ncw) {
+      DS2_PCASE(1) DS2_PCASE(2) DS2_PCASE(3) DS2_PCASE(4) DS2_PCASE(5)
+      default: return 0;
+    }
+  } else {
+    switch (ncw) {
+      DS2_PCASE(2) DS2_PCASE(4) DS2_PCASE(6) DS2_PCASE(8)
+      default: return 0;
+    }
   }
 #undef DS2_PCASE
 #undef DS2_PLAUNCH
@@ -1141,7 +1167,7 @@ extern "C" int ds2_rnn_persistent_status(int* out8) {
 
 extern "C" size_t ds2_rnn_fwd_workspace_bytes(int B, int H, int bf16) {
   const size_t step = pk_floats(B, H, H, bf16) * sizeof(float);                 // two ping-pong buffers of the step kernels
-  const size_t pers = bf16 ? 4 * fwd_xbuf_bytes(B, H, 1) : 0;                    // four round-robin buffers of the persistent kernel
+  const size_t pers = 4 * fwd_xbuf_bytes(B, H, bf16);                            // four round-robin buffers of the persistent kernel
   return step > pers ? step : pers;
 }
 
@@ -1161,9 +1187,11 @@ extern "C" int ds2_rnn_fwd(int gates, float* gx, const void* wp_fwd, const float
   RnnArgs a{};
   a.gx = gx; a.aux = aux; a.hbuf = hbuf; a.wp = (const float*)wp_fwd; a.bhh = bhh; a.pk = (float*)ws; a.lens = lens_dev;
   a.T = T; a.B = B; a.H = H; a.gates_bf = (__bf16*)gates_bf16;
-  if (bf16) {
+  {
     a.dbg = g_ds2_debug_flags;
-    const int rc = gates == 3 ? try_launch_persistent_fwd<3>(a, (hipStream_t)stream) : try_launch_persistent_fwd<4>(a, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = bf16 ? (gates == 3 ? try_launch_persistent_fwd<3, true>(a, st) : try_launch_persistent_fwd<4, true>(a, st))
+                        : (gates == 3 ? try_launch_persistent_fwd<3, false>(a, st) : try_launch_persistent_fwd<4, false>(a, st));
     if (rc != 0) return rc < 0 ? rc : 0;
   }
   return bf16 ? dispatch<true>(gates, false, a, (hipStream_t)stream) : dispatch<false>(gates, false, a, (hipStream_t)stream);
