@@ -584,6 +584,31 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
   }
 }
 
+// Gate-derivative math of one (row, unit) pair, shared by the step and the persistent backward kernels.  Contraction is switched OFF:
+// left to the compiler, a*b + c fuses or not depending on the surrounding code, and the two kernel families must agree to the bit.
+__device__ __forceinline__ void gru_bwd_point(float dh, float r, float z, float n, float hn, float hprev, float (&dgh)[3], float& dpn, float& carry) {
+#pragma clang fp contract(off)
+  const float dn_ = dh * (1.f - z);
+  const float dz = dh * (hprev - n);
+  dpn = dn_ * (1.f - n * n);
+  const float dr = dpn * hn;
+  dgh[0] = dr * r * (1.f - r);
+  dgh[1] = dz * z * (1.f - z);
+  dgh[2] = dpn * r;                  // d(hn): the n-gate row of dGh
+  carry = dh * z;
+}
+__device__ __forceinline__ void lstm_bwd_point(float dh, float dcar_in, float ig, float fg, float gg, float og, float c, float cprev, float (&dgh)[4],
+                                               float& carry) {
+#pragma clang fp contract(off)
+  const float tc = tanhf_(c);
+  const float dc = dcar_in + dh * og * (1.f - tc * tc);
+  dgh[0] = dc * gg * ig * (1.f - ig);
+  dgh[1] = dc * cprev * fg * (1.f - fg);
+  dgh[2] = dc * ig * (1.f - gg * gg);
+  dgh[3] = dh * tc * og * (1.f - og);
+  carry = dc * fg;
+}
+
 // ------------------------------------------------------------------------------------------
 // backward step (same grid mapping).  carry[b][j] = sum_k dGh[tq][b][k] * W_hh[k][j]
 // ------------------------------------------------------------------------------------------
@@ -714,30 +739,18 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(const float* pk, 
       for (int w = 0; w < NW; ++w) carry += red[w][sub][src_lane][reg];
       if constexpr (G == 3) {
         const float dh = pdy[i] + carry + pdc[i];
-        const float r = pg[i][0], z = pg[i][1], n = pg[i][2], hn = pax[i];
-        const float dn_ = dh * (1.f - z);
-        const float dz = dh * (pprev[i] - n);
-        const float dpn = dn_ * (1.f - n * n);
-        const float dr = dpn * hn;
-        dgh[0] = dr * r * (1.f - r);
-        dgh[1] = dz * z * (1.f - z);
-        dgh[2] = dpn * r;                  // d(hn): the n-gate row of dGh
+        float dpn, car;
+        gru_bwd_point(dh, pg[i][0], pg[i][1], pg[i][2], pax[i], pprev[i], dgh, dpn, car);
         dgx_store(gx, gb, 0, dgh[0]); dgx_store(gx, gb, H, dgh[1]); dgx_store(gx, gb, 2 * H, dpn);
         stnt(ax, dgh[2]);
-        *dco = dh * z;
+        *dco = car;
       } else {
         const float dh = pdy[i] + carry;
-        const float ig = pg[i][0], fg = pg[i][1], gg = pg[i][2], og = pg[i][G - 1];
-        const float c = pax[i];
-        const float tc = tanhf_(c);
-        const float dc = pdc[i] + dh * og * (1.f - tc * tc);
-        dgh[0] = dc * gg * ig * (1.f - ig);
-        dgh[1] = dc * pprev[i] * fg * (1.f - fg);
-        dgh[2] = dc * ig * (1.f - gg * gg);
-        dgh[G - 1] = dh * tc * og * (1.f - og);
+        float car;
+        lstm_bwd_point(dh, pdc[i], pg[i][0], pg[i][1], pg[i][2], pg[i][G - 1], pax[i], pprev[i], dgh, car);
 #pragma unroll
         for (int g = 0; g < G; ++g) dgx_store(gx, gb, g * H, dgh[g]);
-        *dco = dc * fg;
+        *dco = car;
       }
     }
 #pragma unroll
@@ -751,14 +764,16 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(const float* pk, 
 // W_hh^T slice (32 units x G*H bf16 = 192 KB) lives in registers (96 per lane), there is no launch boundary, and the carry
 // (dh*z / dc*f) never leaves its thread.  Exchange protocol, buffers, starvation handling: see rnn_fwd_persistent_kernel.
 // ------------------------------------------------------------------------------------------
-template <int G, int MB, int NS, int NCW>
+template <int G, int MB, int NS, int NCW, bool BF>
 __global__ __launch_bounds__(NW * 64) void rnn_bwd_persistent_kernel(RnnArgs a, char* xbuf, int spin_limit) {
   static_assert(MB * NS * 256 <= NW * 64, "one (row, unit) pair per thread");
   __shared__ __attribute__((aligned(16))) f32x4 red[2][NW][MB * NS][64];      // double-buffered: one workgroup barrier per time step
-  __shared__ __attribute__((aligned(16))) __bf16 stage[NW][G][64];             // wave-private: 8 complete 16-byte chunks per gate
+  constexpr int KC = kchunk<BF>(), EPL = KC / 4, NPUB = 64 / EPL;             // units per chunk / per 16-byte lane vector; chunks per wave and gate
+  using elem_t = typename std::conditional<BF, __bf16, float>::type;
+  __shared__ __attribute__((aligned(16))) elem_t stage[NW][G][64];             // wave-private: NPUB complete 16-byte chunks per gate
   const int dir = blockIdx.z, slice = blockIdx.x, bt = blockIdx.y;
   const int T = a.T, B = a.B, H = a.H, lddy = a.lddy;
-  const int nsl = (H + 15) >> 4, nchb = (G * H + 31) >> 5;
+  const int nsl = (H + 15) >> 4, nchb = (G * H + KC - 1) / KC;
   const int j0 = slice * (16 * NS), b0 = bt * (16 * MB);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -771,7 +786,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_persistent_kernel(RnnArgs a, 
   for (int k = 0; k < NCW; ++k) {
     const int c = wave + NW * k;
     cval[k] = c < nchb;
-    lval[k] = cval[k] && (c * 32 + (lane >> 4) * 8) < G * H;
+    lval[k] = cval[k] && (c * KC + (lane >> 4) * EPL) < G * H;
 #pragma unroll
     for (int n = 0; n < NS; ++n)
       wreg[k][n] = cval[k] ? *reinterpret_cast<const f32x4*>(a.wp + ((((long long)dir * nsl + slice * NS + n) * nchb + c) * 256) + lane * 4)
@@ -795,9 +810,16 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_persistent_kernel(RnnArgs a, 
     if (!pact) return o;
     const int t = dir == 0 ? T - 1 - step : step;
     const long long rowH = (((long long)t * B + b) * 2 + dir) * H + j;
-    const bf16x4_ rec = __builtin_nontemporal_load(reinterpret_cast<const bf16x4_*>(gates_bf) + rowH);
-    o.g0 = (float)rec[0]; o.g1 = (float)rec[1]; o.g2 = (float)rec[2]; o.g3 = (float)rec[3];
-    if (G == 4) o.ax = ldnt(a.aux + rowH);
+    if (gates_bf) {                                       // packed 8-byte record (bf16 training path)
+      const bf16x4_ rec = __builtin_nontemporal_load(reinterpret_cast<const bf16x4_*>(gates_bf) + rowH);
+      o.g0 = (float)rec[0]; o.g1 = (float)rec[1]; o.g2 = (float)rec[2]; o.g3 = (float)rec[3];
+      if (G == 4) o.ax = ldnt(a.aux + rowH);
+    } else {                                              // plain buffers: gates in gx (overwritten with dGx at this row's own step), hn / c in aux
+      const float* gp = a.gx + (((long long)t * B + b) * 2 + dir) * G * H + j;
+      o.g0 = ldnt(gp); o.g1 = ldnt(gp + H); o.g2 = ldnt(gp + 2 * H);
+      if (G == 4) { o.g3 = ldnt(gp + 3 * H); o.ax = ldnt(a.aux + rowH); }
+      else o.g3 = ldnt(a.aux + rowH);
+    }
     o.dy = ldnt(&a.dy[((long long)t * B + b) * lddy + j]);
     const int tpf = dir == 0 ? t - 1 : t + 1;
     if (dir == 0 ? (t > 0) : (t < T - 1)) {
@@ -808,14 +830,14 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_persistent_kernel(RnnArgs a, 
   };
   Ops cur = fetch(0), nxt = cur;
 
-  // A wave's 64 threads are 4 batch rows x 16 units: per gate 8 complete 16-byte chunks of the packed dGh buffer.  Lane p < 8 * G publishes
-  // (and resets) chunk (gate p / 8, row (wave & 3) * 4 + (p & 3), unit group (p >> 2) & 1) of this wave's (tile, slice) = wave >> 2.
-  const int pg = lane >> 3, pp = lane & 7;
-  const bool pub_lane = lane < 8 * G && (wave >> 2) < MB * NS;
+  // A wave's 64 threads are 4 batch rows x 16 units: per gate NPUB complete 16-byte chunks of the packed dGh buffer.  Lane p < NPUB * G
+  // publishes (and resets) chunk (gate p / NPUB, row (wave & 3) * 4 + (p & 3), unit group (p % NPUB) >> 2) of this wave's (tile, slice) = wave >> 2.
+  const int pg = lane / NPUB, pp = lane % NPUB;
+  const bool pub_lane = lane < NPUB * G && (wave >> 2) < MB * NS;
   long long pub_off = 0;
   {
-    const int wsub = wave >> 2, k0 = pg * H + j0 + (wsub % NS) * 16;            // first k of this wave's units in gate pg
-    pub_off = dirbase + ((((long long)(bt * MB + wsub / NS) * nchb + (k0 >> 5)) * 64) + (((k0 & 31) >> 3) + (pp >> 2)) * 16 + (wave & 3) * 4 + (pp & 3)) * 16;
+    const int wsub = wave >> 2, ku = pg * H + j0 + (wsub % NS) * 16 + (pp >> 2) * EPL;      // first k of this lane's unit group in gate pg
+    pub_off = dirbase + ((((long long)(bt * MB + wsub / NS) * nchb + ku / KC) * 64) + ((ku % KC) / EPL) * 16 + (wave & 3) * 4 + (pp & 3)) * 16;
   }
 
   for (int s = 0; s < T; ++s) {
@@ -865,9 +887,17 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_persistent_kernel(RnnArgs a, 
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
           const u32x4_ v = lval[k] ? av[k][i] : u32x4_{0u, 0u, 0u, 0u};
+          if constexpr (BF) {
 #pragma unroll
-          for (int n = 0; n < NS; ++n)
-            acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v), __builtin_bit_cast(bf16x8, wreg[k][n]), acc[i][n], 0, 0, 0);
+            for (int n = 0; n < NS; ++n)
+              acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v), __builtin_bit_cast(bf16x8, wreg[k][n]), acc[i][n], 0, 0, 0);
+          } else {
+            const f32x4 vf = __builtin_bit_cast(f32x4, v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int n = 0; n < NS; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[e], wreg[k][n][e], acc[i][n], 0, 0, 0);
+          }
         }
     }
     const bool more = s + 1 < T;
@@ -886,47 +916,41 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_persistent_kernel(RnnArgs a, 
       for (int w = 0; w < NW; ++w) carry += red[s & 1][w][sub][src_lane][reg];
       if constexpr (G == 3) {
         const float dh = cur.dy + carry + dcar;
-        const float r = cur.g0, z = cur.g1, n = cur.g2, hn = cur.g3;
-        const float dn_ = dh * (1.f - z);
-        const float dz = dh * (cur.prev - n);
-        const float dpn = dn_ * (1.f - n * n);
-        const float dr = dpn * hn;
-        dgh[0] = dr * r * (1.f - r);
-        dgh[1] = dz * z * (1.f - z);
-        dgh[2] = dpn * r;
+        float dpn;
+        gru_bwd_point(dh, cur.g0, cur.g1, cur.g2, cur.g3, cur.prev, dgh, dpn, dcar);
         dgx[0] = dgh[0]; dgx[1] = dgh[1]; dgx[2] = dpn;
         dax = dgh[2];
-        dcar = dh * z;
       } else {
         const float dh = cur.dy + carry;
-        const float ig = cur.g0, fg = cur.g1, gg = cur.g2, og = cur.g3;
-        const float tc = tanhf_(cur.ax);
-        const float dc = dcar + dh * og * (1.f - tc * tc);
-        dgh[0] = dc * gg * ig * (1.f - ig);
-        dgh[1] = dc * cur.prev * fg * (1.f - fg);
-        dgh[2] = dc * ig * (1.f - gg * gg);
-        dgh[G - 1] = dh * tc * og * (1.f - og);
+        float car;
+        lstm_bwd_point(dh, dcar, cur.g0, cur.g1, cur.g2, cur.g3, cur.ax, cur.prev, dgh, car);
+        dcar = car;
 #pragma unroll
         for (int g = 0; g < G; ++g) dgx[g] = dgh[g];
-        dcar = dc * fg;
       }
     } else {
       dcar = 0.f;
     }
     // ---- publish dGh_s (see the forward kernel): wave-local assembly, wait for my previous reset, publish, reset two steps ahead
 #pragma unroll
-    for (int g = 0; g < G; ++g) stage[wave][g][lane] = (__bf16)dgh[g];
+    for (int g = 0; g < G; ++g) stage[wave][g][lane] = (elem_t)dgh[g];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (pub_lane) {
-      store16_sc1(xbuf + (long long)(s & 3) * bufbytes + pub_off, *reinterpret_cast<const u32x4_*>(&stage[wave][pg][(pp & 3) * 16 + (pp >> 2) * 8]));
+      store16_sc1(xbuf + (long long)(s & 3) * bufbytes + pub_off, *reinterpret_cast<const u32x4_*>(&stage[wave][pg][(pp & 3) * 16 + (pp >> 2) * EPL]));
       store16_sc1(xbuf + (long long)((s + 2) & 3) * bufbytes + pub_off, u32x4_{PSENT, PSENT, PSENT, PSENT});
     }
     if (more) nxt = fetch(s + 1);
     if (pact) {
       const long long row = ((long long)t * B + b) * 2 + dir;
-      __bf16* gb = a.dgx_bf + row * G * H + j;
+      if (a.dgx_bf) {
+        __bf16* gb = a.dgx_bf + row * G * H + j;
 #pragma unroll
-      for (int g = 0; g < G; ++g) __builtin_nontemporal_store((__bf16)dgx[g], gb + g * H);
+        for (int g = 0; g < G; ++g) __builtin_nontemporal_store((__bf16)dgx[g], gb + g * H);
+      } else {
+        float* gp = a.gx + row * G * H + j;                // in place: the gates of this row were consumed (fetched one step ago)
+#pragma unroll
+        for (int g = 0; g < G; ++g) stnt(gp + g * H, dgx[g]);
+      }
       if (G == 3) stnt(a.aux + row * H + j, dax);
     }
     cur = nxt;
@@ -1048,32 +1072,48 @@ int try_launch_persistent_fwd(RnnArgs a, hipStream_t st) {
 size_t bwd_xbuf_bytes(int gates, int B, int H, int bf16) { return (size_t)2 * (ceil_div(B, 32) * 2) * ceil_div(gates * H, bf16 ? 32 : 16) * 1024; }
 
 // Backward recurrence in one persistent launch (bf16 training path).  1 = launched, 0 = not eligible, < 0 = error.
-template <int G>
+template <int G, bool BF>
 int try_launch_persistent_bwd(RnnArgs a, hipStream_t st) {
   static const char* env = getenv("DS2_RNN_PERSISTENT");
   if ((env && env[0] == '0') || !g_persist_bwd || a.dbg) return 0;
-  if (!a.gates_bf || !a.dgx_bf || (a.H % 16) != 0 || a.T < 2) return 0;
+  // buffers: either the bf16 training path's (packed gate records in, bf16 dGx out) or the plain ones (gates in gx, dGx in place)
+  if (!((a.gates_bf && a.dgx_bf) || (!a.gates_bf && !a.dgx_bf && a.gx))) return 0;
+  if ((a.H % 16) != 0 || a.T < 2) return 0;
   int mb = pick_mb(a.B, a.H);
   const int nsl = a.H / 16;
   const int ns = (mb == 2 && (nsl % 2) == 0) ? 2 : 1;                 // same tile choice as the step kernels
   if (ns == 2) mb = 1;
   const int nbt = ceil_div(a.B, 16 * mb);
-  const int nchb = ceil_div(G * a.H, 32);
-  const int ncw = ceil_div(ceil_div(nchb, NW), 3) * 3;                // instantiated: 3, 6, 9, 12 chunks per wave
-  if (ncw > 12) return 0;
+  const int nchb = ceil_div(G * a.H, kchunk<BF>());
+  const int q = BF ? 3 : 6;                                           // instantiated chunks per wave: bf16 3, 6, 9, 12 ; fp32 6, 12, 18
+  const int ncw = ceil_div(ceil_div(nchb, NW), q) * q;
+  if (ncw > (BF ? 12 : 18) || ncw * (ns + mb) * 4 > 192) return 0;    // W_hh^T fragments + operand lane vectors must fit the registers
   if ((long long)(nsl / ns) * nbt * 2 > cu_count()) return 0;
   a.nsl = nsl;
   a.nbt16 = ceil_div(a.B, 32) * 2;
   char* xbuf = reinterpret_cast<char*>(a.pk);
-  DS2_HIP(hipMemsetAsync(xbuf, 0xff, 4 * bwd_xbuf_bytes(G, a.B, a.H, 1), st));
+  DS2_HIP(hipMemsetAsync(xbuf, 0xff, 4 * bwd_xbuf_bytes(G, a.B, a.H, BF ? 1 : 0), st));
   dim3 grid(nsl / ns, nbt, 2), block(NW * 64);
   static const char* sl = getenv("DS2_RNN_SPIN_LIMIT");
   const int spin_limit = sl ? atoi(sl) : (1 << 20);
-#define DS2_PB(MB_, NS_, NCW_) hipLaunchKernelGGL((rnn_bwd_persistent_kernel<G, MB_, NS_, NCW_>), grid, block, 0, st, a, xbuf, spin_limit)
+#define DS2_PB(MB_, NS_, NCW_)                                                                                                      \
+  do {                                                                                                                              \
+    if constexpr (NCW_ * (NS_ + MB_) * 4 <= 192)                                                                                    \
+      hipLaunchKernelGGL((rnn_bwd_persistent_kernel<G, MB_, NS_, NCW_, BF>), grid, block, 0, st, a, xbuf, spin_limit);               \
+    else                                                                                                                            \
+      return 0;                                                                                                                     \
+  } while (0)
 #define DS2_PBCASE(NCW_) case NCW_: if (ns == 2) DS2_PB(1, 2, NCW_); else if (mb == 2) DS2_PB(2, 1, NCW_); else DS2_PB(1, 1, NCW_); break;
-  switch (ncw) {
-    DS2_PBCASE(3) DS2_PBCASE(6) DS2_PBCASE(9) DS2_PBCASE(12)
-    default: return 0;
+  if constexpr (BF) {
+    switch (ncw) {
+      DS2_PBCASE(3) DS2_PBCASE(6) DS2_PBCASE(9) DS2_PBCASE(12)
+      default: return 0;
+    }
+  } else {
+    switch (ncw) {
+      DS2_PBCASE(6) DS2_PBCASE(12) DS2_PBCASE(18)
+      default: return 0;
+    }
   }
 #undef DS2_PBCASE
 #undef DS2_PB
@@ -1199,7 +1239,7 @@ extern "C" int ds2_rnn_fwd(int gates, float* gx, const void* wp_fwd, const float
 
 extern "C" size_t ds2_rnn_bwd_workspace_bytes(int gates, int B, int H, int bf16) {
   const size_t step = pk_floats(B, H, gates * H, bf16) * sizeof(float);          // two ping-pong buffers of the step kernels
-  const size_t pers = bf16 ? 4 * bwd_xbuf_bytes(gates, B, H, 1) : 0;              // four round-robin buffers of the persistent kernel
+  const size_t pers = 4 * bwd_xbuf_bytes(gates, B, H, bf16);                      // four round-robin buffers of the persistent kernel
   return (size_t)4 * B * H * sizeof(float) + (step > pers ? step : pers);
 }
 
@@ -1233,9 +1273,11 @@ extern "C" int ds2_rnn_bwd(int gates, const float* dy, int lddy, float* gx, floa
   a.dgx_bf = (__bf16*)dgx_bf16;
   a.gates_bf = (__bf16*)const_cast<void*>(gates_bf16);
   a.lens = lens_dev; a.T = T; a.B = B; a.H = H;
-  if (bf16) {
+  {
     a.dbg = g_ds2_debug_flags;
-    const int rc = gates == 3 ? try_launch_persistent_bwd<3>(a, (hipStream_t)stream) : try_launch_persistent_bwd<4>(a, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = bf16 ? (gates == 3 ? try_launch_persistent_bwd<3, true>(a, st) : try_launch_persistent_bwd<4, true>(a, st))
+                        : (gates == 3 ? try_launch_persistent_bwd<3, false>(a, st) : try_launch_persistent_bwd<4, false>(a, st));
     if (rc != 0) return rc < 0 ? rc : 0;
   }
   return bf16 ? dispatch<true>(gates, true, a, (hipStream_t)stream) : dispatch<false>(gates, true, a, (hipStream_t)stream);
