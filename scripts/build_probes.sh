@@ -7,3 +7,4 @@ mkdir -p build
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 --cuda-device-only probe_l2_kernel.hip -o build/probe_l2_kernel.bundle
 /opt/rocm/lib/llvm/bin/clang-offload-bundler --unbundle --type=o --input=build/probe_l2_kernel.bundle --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --output=build/probe_l2_kernel.hsaco
 /opt/rocm/bin/hipcc -O2 -std=c++17 probe_l2_residency.cpp -o build/probe_l2_residency -L/opt/rocm/lib -lhsa-runtime64
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 probe_xcd_exchange.hip -o build/probe_xcd_exchange
