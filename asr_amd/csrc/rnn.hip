@@ -370,32 +370,39 @@ __device__ __forceinline__ u32x4_ load16_sc1(const void* p) {
 constexpr unsigned PSENT = 0xffffffffu;
 __device__ int g_persist_dbg[8];      // first starved wave of a persistent launch: {set, block x, y, z, step, wave, ok-mask lo, hi}
 
-template <int G, int MB, int NCW, bool BF>
+template <int G, int MB, int NS, int NCW, bool BF>
 __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, char* xbuf, int spin_limit) {
-  static_assert(MB * 256 <= NW * 64, "one (row, unit) pair per thread");
-  __shared__ __attribute__((aligned(16))) f32x4 red[2][NW][MB * G][64];       // double-buffered: ONE workgroup barrier per time step
+  static_assert(MB * NS * 256 <= NW * 64, "one (row, unit) pair per thread");
+  __shared__ __attribute__((aligned(16))) f32x4 red[2][NW][MB * NS * G][64];       // double-buffered: ONE workgroup barrier per time step
   constexpr int KC = kchunk<BF>(), EPL = KC / 4;                              // units per chunk (32 | 16) and per 16-byte lane vector (8 | 4)
   using elem_t = typename std::conditional<BF, __bf16, float>::type;
   __shared__ __attribute__((aligned(16))) elem_t stage[NW][64];               // wave-private: a wave's 64 (row, unit) pairs = 64 / EPL complete 16-byte chunks
-  const int dir = blockIdx.z, slice = blockIdx.x, bt = blockIdx.y;
+  // grid = (direction x batch tile, slice): the linear workgroup id is group + ngroups * slice, so with 8 groups (c3: 4 tiles of 16 rows x 2
+  // directions) every group — the set of workgroups that exchange h_t with each other — sits on ONE XCD under the round-robin placement
+  // (measured 1.58 vs 1.72 us per exchange, profiles/r01_probe_xcd_exchange.txt; correctness does not depend on it)
+  // (used when there are exactly 8 groups; other shapes keep the slice-major grid (slice, tile, direction), which measured better there)
+  const bool group_major = gridDim.z == 1;
+  const int nbt_ = gridDim.x >> 1;
+  const int dir = group_major ? blockIdx.x / nbt_ : blockIdx.z, bt = group_major ? blockIdx.x % nbt_ : blockIdx.y;
+  const int slice = group_major ? blockIdx.y : blockIdx.x;
   const int T = a.T, B = a.B, H = a.H;
   const int nsl = (H + 15) >> 4, nch = (H + KC - 1) / KC;
-  const int j0 = slice * 16, b0 = bt * (16 * MB);
+  const int j0 = slice * (16 * NS), b0 = bt * (16 * MB);      // slice = NS consecutive 16-unit slices
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long long bufbytes = (long long)2 * a.nbt16 * nch * 1024;            // one packed h buffer: [dir][tile][chunk][64 lanes][16 B]
   const long long dirbase = (long long)dir * a.nbt16 * nch * 1024;
 
   // ---- W_hh slice -> registers (once)
-  f32x4 wreg[NCW][G];
+  f32x4 wreg[NCW][NS * G];
   bool cval[NCW];
 #pragma unroll
   for (int k = 0; k < NCW; ++k) {
     const int c = wave + NW * k;
     cval[k] = c < nch;
 #pragma unroll
-    for (int g = 0; g < G; ++g)
-      wreg[k][g] = cval[k] ? *reinterpret_cast<const f32x4*>(a.wp + (((((long long)dir * nsl + slice) * G + g) * nch + c) * 256) + lane * 4)
+    for (int g = 0; g < NS * G; ++g)                    // (slice * NS + n, gate g') are consecutive 1 KiB-chunk rows of the packed W_hh
+      wreg[k][g] = cval[k] ? *reinterpret_cast<const f32x4*>(a.wp + (((((long long)dir * nsl + slice * NS) * G + g) * nch + c) * 256) + lane * 4)
                            : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   // lanes of a chunk whose 8 hidden units lie beyond H are never written by anybody: ignored by the poll, zero in the product
@@ -405,9 +412,9 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
 
   // ---- this thread's (batch row, hidden unit) pair: fixed for the whole layer, so the previous state stays in a register
   const int q = threadIdx.x;
-  const int jl = q & 15, brow = (q >> 4) & 15, mb = q >> 8;
-  const int b = b0 + mb * 16 + brow, j = j0 + jl;
-  const bool pact = (mb < MB) && b < B && j < H;
+  const int jl = q & 15, brow = (q >> 4) & 15, sub = q >> 8, mb = sub / NS, ns = sub % NS;
+  const int b = b0 + mb * 16 + brow, j = j0 + ns * 16 + jl;
+  const bool pact = (sub < MB * NS) && b < B && j < H;
   const int src_lane = (brow >> 2) * 16 + jl, reg = brow & 3;
   const int plen = pact ? a.lens[b] : 0;
   float pb[G];
@@ -418,11 +425,11 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
   // every wave publishes (and resets) its own chunks — no workgroup-wide staging.  Lane p < 64 / EPL handles row (wave & 3) * 4 + (p & 3) and
   // unit group p >> 2 of this slice.
   constexpr int NPUB = 64 / EPL;
-  const bool pub_lane = lane < NPUB && (wave >> 2) < MB;
+  const bool pub_lane = lane < NPUB && (wave >> 2) < MB * NS;
   long long pub_off;
   {
-    const int ju = j0 + (lane >> 2) * EPL;                                    // first unit of this lane's group
-    pub_off = dirbase + ((((long long)(bt * MB + (wave >> 2)) * nch + ju / KC) * 64) + ((ju % KC) / EPL) * 16 + (wave & 3) * 4 + (lane & 3)) * 16;
+    const int wsub = wave >> 2, ju = j0 + (wsub % NS) * 16 + (lane >> 2) * EPL;   // first unit of this lane's group
+    pub_off = dirbase + ((((long long)(bt * MB + wsub / NS) * nch + ju / KC) * 64) + ((ju % KC) / EPL) * 16 + (wave & 3) * 4 + (lane & 3)) * 16;
   }
   auto gx_row = [&](int t) { return a.gx + (((long long)t * B + b) * 2 + dir) * G * H + j; };
   float pgx[G], pgx_next[G];
@@ -437,11 +444,11 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
   for (int s = 0; s < T; ++s) {
     const int t = dir == 0 ? s : T - 1 - s;
     RNN_TRACE(s, 0);
-    f32x4 acc[MB][G];
+    f32x4 acc[MB][NS * G];
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
-      for (int g = 0; g < G; ++g) acc[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int g = 0; g < NS * G; ++g) acc[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (s > 0) {
       // ---- gather h_{s-1}: poll this wave's chunks until none carries the sentinel
       const char* xin = xbuf + (long long)((s - 1) & 3) * bufbytes + dirbase;
@@ -475,7 +482,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
           //  too — measured: spurious HSA_STATUS_ERROR_EXCEPTION at the end of correct runs.  The host reads this record at the
           //  train step's sync point and raises: ds2_rnn_persistent_status / asr_amd.ops.rnn_persistent_check)
           if (lane == 0 && atomicCAS(&g_persist_dbg[0], 0, 1) == 0) {
-            g_persist_dbg[1] = blockIdx.x; g_persist_dbg[2] = blockIdx.y; g_persist_dbg[3] = blockIdx.z; g_persist_dbg[4] = s; g_persist_dbg[5] = wave;
+            g_persist_dbg[1] = slice; g_persist_dbg[2] = bt; g_persist_dbg[3] = dir; g_persist_dbg[4] = s; g_persist_dbg[5] = wave;
             unsigned long long m = __ballot(ok);
             g_persist_dbg[6] = (int)(m & 0xffffffffu); g_persist_dbg[7] = (int)(m >> 32);
             __threadfence_system();
@@ -491,14 +498,14 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
           const u32x4_ v = lval[k] ? av[k][i] : u32x4_{0u, 0u, 0u, 0u};
           if constexpr (BF) {
 #pragma unroll
-            for (int g = 0; g < G; ++g)
+            for (int g = 0; g < NS * G; ++g)
               acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v), __builtin_bit_cast(bf16x8, wreg[k][g]), acc[i][g], 0, 0, 0);
           } else {
             const f32x4 vf = __builtin_bit_cast(f32x4, v);
 #pragma unroll
             for (int e = 0; e < 4; ++e)                   // same element order as the step kernel (mfma_packed): bit-identical sums
 #pragma unroll
-              for (int g = 0; g < G; ++g) acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[e], wreg[k][g][e], acc[i][g], 0, 0, 0);
+              for (int g = 0; g < NS * G; ++g) acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[e], wreg[k][g][e], acc[i][g], 0, 0, 0);
           }
         }
     }
@@ -506,7 +513,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
-      for (int g = 0; g < G; ++g) red[s & 1][wave][i * G + g][lane] = acc[i][g];
+      for (int g = 0; g < NS * G; ++g) red[s & 1][wave][i * NS * G + g][lane] = acc[i][g];
     RNN_TRACE(s, 2);
     __syncthreads();
     RNN_TRACE(s, 3);
@@ -520,7 +527,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
       for (int g = 0; g < G; ++g) {
         float sum = 0.f;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) sum += red[s & 1][w][mb * G + g][src_lane][reg];
+        for (int w = 0; w < NW; ++w) sum += red[s & 1][w][sub * G + g][src_lane][reg];
         gh[g] = sum + pb[g];
       }
       if constexpr (G == 3) {
@@ -771,7 +778,10 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_persistent_kernel(RnnArgs a, 
   constexpr int KC = kchunk<BF>(), EPL = KC / 4, NPUB = 64 / EPL;             // units per chunk / per 16-byte lane vector; chunks per wave and gate
   using elem_t = typename std::conditional<BF, __bf16, float>::type;
   __shared__ __attribute__((aligned(16))) elem_t stage[NW][G][64];             // wave-private: NPUB complete 16-byte chunks per gate
-  const int dir = blockIdx.z, slice = blockIdx.x, bt = blockIdx.y;
+  const bool group_major = gridDim.z == 1;                                    // grid = (direction x batch tile, slice) | (slice, tile, direction): see the forward kernel
+  const int nbt_ = gridDim.x >> 1;
+  const int dir = group_major ? blockIdx.x / nbt_ : blockIdx.z, bt = group_major ? blockIdx.x % nbt_ : blockIdx.y;
+  const int slice = group_major ? blockIdx.y : blockIdx.x;
   const int T = a.T, B = a.B, H = a.H, lddy = a.lddy;
   const int nsl = (H + 15) >> 4, nchb = (G * H + KC - 1) / KC;
   const int j0 = slice * (16 * NS), b0 = bt * (16 * MB);
@@ -874,7 +884,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_persistent_kernel(RnnArgs a, 
         if (__ballot(ok) == ~0ull) break;
         if (++spins > spin_limit) {
           if (lane == 0 && atomicCAS(&g_persist_dbg[0], 0, 2) == 0) {
-            g_persist_dbg[1] = blockIdx.x; g_persist_dbg[2] = blockIdx.y; g_persist_dbg[3] = blockIdx.z; g_persist_dbg[4] = s; g_persist_dbg[5] = wave;
+            g_persist_dbg[1] = slice; g_persist_dbg[2] = bt; g_persist_dbg[3] = dir; g_persist_dbg[4] = s; g_persist_dbg[5] = wave;
             unsigned long long m = __ballot(ok);
             g_persist_dbg[6] = (int)(m & 0xffffffffu); g_persist_dbg[7] = (int)(m >> 32);
             __threadfence_system();
@@ -1033,24 +1043,41 @@ int try_launch_persistent_fwd(RnnArgs a, hipStream_t st) {
   if (env && env[0] == '0') return 0;
   if (a.dbg) return 0;                                            // the ablation flags belong to the step kernels
   if (!g_persist_fwd || (a.H % 16) != 0 || a.T < 2) return 0;
-  const int mb = pick_mb(a.B, a.H);
-  const int nsl = a.H / 16, nbt = ceil_div(a.B, 16 * mb);
+  const int nsl = a.H / 16;
   const int nch = ceil_div(a.H, kchunk<BF>());
   int ncw = ceil_div(nch, NW);
   if (!BF) ncw = ceil_div(ncw, 2) * 2;                            // fp32 instantiations: 2, 4, 6, 8 chunks per wave
-  // registers: W_hh fragments ncw * G + operand ncw * mb lane vectors of 4 VGPRs, next to ~70 for everything else
-  if (ncw > (BF ? 5 : 8) || ncw * (G + mb) * 4 > 176) return 0;
+  if (ncw > (BF ? 5 : 8)) return 0;
+  // Tile shape.  The exchange is what a time step costs, and it is priced by the size of the gather and the number of producers
+  // (64 producers / 64 KB: 2.64 us, 32 / 32 KB: 1.6-1.7 us, profiles/r01_probe_xcd_exchange.txt) — the W_hh slice sits in registers either
+  // way.  So: 16 batch rows x 32 units per workgroup where the registers allow it (W_hh fragments ncw * 2G + operand ncw lane vectors of
+  // 4 VGPRs) and the alternative would be a 32-row tile; else the step kernels' 16|32 rows x 16 units (with 16-row tiles the gather
+  // is the same size either way and twice as many, half as big workgroups measured slightly faster).
+  int mb = 1, ns = 2;
+  if (pick_mb(a.B, a.H) != 2 || (nsl % 2) != 0 || ncw * (2 * G + 1) * 4 > 176 || (long long)(nsl / 2) * ceil_div(a.B, 16) * 2 > cu_count()) {
+    ns = 1;
+    mb = pick_mb(a.B, a.H);
+    if (ncw * (G + mb) * 4 > 176) return 0;
+  }
+  const int nbt = ceil_div(a.B, 16 * mb);
   // every workgroup must be resident at once: one per CU (up to 160 KB of registers + up to 129 KB of LDS each)
-  if ((long long)nsl * nbt * 2 > cu_count()) return 0;
+  if ((long long)(nsl / ns) * nbt * 2 > cu_count()) return 0;
   a.nsl = nsl;
   a.nbt16 = ceil_div(a.B, 32) * 2;
   char* xbuf = reinterpret_cast<char*>(a.pk);
   DS2_HIP(hipMemsetAsync(xbuf, 0xff, 4 * fwd_xbuf_bytes(a.B, a.H, BF ? 1 : 0), st));      // every 16-byte chunk = the "not yet published" sentinel
-  dim3 grid(nsl, nbt, 2), block(NW * 64);
+  dim3 grid(nsl / ns, nbt, 2), block(NW * 64);
+  if (nbt * 2 == 8) grid = dim3(8, nsl / ns, 1);                  // 8 groups: one per XCD (group-major grid)
   static const char* sl = getenv("DS2_RNN_SPIN_LIMIT");
   const int spin_limit = sl ? atoi(sl) : (1 << 20);              // ~1 s of polling: a missing workgroup is reported instead of hanging the queue
-#define DS2_PLAUNCH(MB_, NCW_) hipLaunchKernelGGL((rnn_fwd_persistent_kernel<G, MB_, NCW_, BF>), grid, block, 0, st, a, xbuf, spin_limit)
-#define DS2_PCASE(NCW_) case NCW_: if (mb == 2) DS2_PLAUNCH(2, NCW_); else DS2_PLAUNCH(1, NCW_); break;
+#define DS2_PLAUNCH(MB_, NS_, NCW_)                                                                                                   \
+  do {                                                                                                                                \
+    if constexpr (NCW_ * (NS_ * G + MB_) * 4 <= 176)                                                                                  \
+      hipLaunchKernelGGL((rnn_fwd_persistent_kernel<G, MB_, NS_, NCW_, BF>), grid, block, 0, st, a, xbuf, spin_limit);                 \
+    else                                                                                                                              \
+      return 0;                                                                                                                       \
+  } while (0)
+#define DS2_PCASE(NCW_) case NCW_: if (ns == 2) DS2_PLAUNCH(1, 2, NCW_); else if (mb == 2) DS2_PLAUNCH(2, 1, NCW_); else DS2_PLAUNCH(1, 1, NCW_); break;
   if constexpr (BF) {
     switch (ncw) {
       DS2_PCASE(1) DS2_PCASE(2) DS2_PCASE(3) DS2_PCASE(4) DS2_PCASE(5)
@@ -1094,6 +1121,7 @@ int try_launch_persistent_bwd(RnnArgs a, hipStream_t st) {
   char* xbuf = reinterpret_cast<char*>(a.pk);
   DS2_HIP(hipMemsetAsync(xbuf, 0xff, 4 * bwd_xbuf_bytes(G, a.B, a.H, BF ? 1 : 0), st));
   dim3 grid(nsl / ns, nbt, 2), block(NW * 64);
+  if (nbt * 2 == 8) grid = dim3(8, nsl / ns, 1);                      // 8 groups: one per XCD (group-major grid)
   static const char* sl = getenv("DS2_RNN_SPIN_LIMIT");
   const int spin_limit = sl ? atoi(sl) : (1 << 20);
 #define DS2_PB(MB_, NS_, NCW_)                                                                                                      \
