@@ -25,6 +25,7 @@ SIGNATURES = {
     "ds2_debug_flags": (i32, [i32]),
     "ds2_rnn_persistent_status": (i32, [vp]),
     "ds2_rnn_persistent_enable": (i32, [i32, i32]),
+    "ds2_rnn_last_path": (i32, []),
     "ds2_gemm_f32_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "ds2_gemm_f32": (i32, [i32, i32, i32, i32, i32, vp, i32, i64, vp, i32, i64, vp, i32, i64, vp, i32, i32, i32, vp, sz, vp]),
     "ds2_gemm_bf16_workspace_bytes": (sz, [i32, i32, i32, i32]),

@@ -1020,6 +1020,7 @@ inline int pick_mb(int B, int H) {
 // which persistent kernels may be used (ds2_rnn_persistent_enable): the backward one must be switched off by a caller that runs
 // collectives on another stream during backward, because a persistent launch needs every one of its workgroups resident at once
 int g_persist_fwd = 1, g_persist_bwd = 1;
+int g_last_path = 0;                    // bit 0 / bit 1: the last ds2_rnn_fwd / ds2_rnn_bwd call took the persistent kernel
 
 // bytes of ONE packed h buffer of the forward recurrence ([2 dirs][tiles][chunks][1 KiB]); the persistent kernel uses four
 size_t fwd_xbuf_bytes(int B, int H, int bf16) { return (size_t)2 * (ceil_div(B, 32) * 2) * ceil_div(H, bf16 ? 32 : 16) * 1024; }
@@ -1260,6 +1261,7 @@ extern "C" int ds2_rnn_fwd(int gates, float* gx, const void* wp_fwd, const float
     hipStream_t st = (hipStream_t)stream;
     const int rc = bf16 ? (gates == 3 ? try_launch_persistent_fwd<3, true>(a, st) : try_launch_persistent_fwd<4, true>(a, st))
                         : (gates == 3 ? try_launch_persistent_fwd<3, false>(a, st) : try_launch_persistent_fwd<4, false>(a, st));
+    g_last_path = (g_last_path & ~1) | (rc == 1 ? 1 : 0);
     if (rc != 0) return rc < 0 ? rc : 0;
   }
   return bf16 ? dispatch<true>(gates, false, a, (hipStream_t)stream) : dispatch<false>(gates, false, a, (hipStream_t)stream);
@@ -1274,6 +1276,9 @@ extern "C" size_t ds2_rnn_bwd_workspace_bytes(int gates, int B, int H, int bf16)
 // Which recurrences may run as ONE persistent launch (bf16 mode; default: both).  A persistent launch needs all of its workgroups resident
 // at once, so a caller that runs other kernels concurrently on the device during backward (collectives on a communication stream)
 // must switch the backward one off.  DS2_RNN_PERSISTENT=0 in the environment switches both off.
+// which kernel family the last recurrence calls used: bit 0 = ds2_rnn_fwd, bit 1 = ds2_rnn_bwd took the persistent kernel (reporting only)
+extern "C" int ds2_rnn_last_path(void) { return g_last_path; }
+
 extern "C" int ds2_rnn_persistent_enable(int forward, int backward) {
   g_persist_fwd = forward != 0;
   g_persist_bwd = backward != 0;
@@ -1306,6 +1311,7 @@ extern "C" int ds2_rnn_bwd(int gates, const float* dy, int lddy, float* gx, floa
     hipStream_t st = (hipStream_t)stream;
     const int rc = bf16 ? (gates == 3 ? try_launch_persistent_bwd<3, true>(a, st) : try_launch_persistent_bwd<4, true>(a, st))
                         : (gates == 3 ? try_launch_persistent_bwd<3, false>(a, st) : try_launch_persistent_bwd<4, false>(a, st));
+    g_last_path = (g_last_path & ~2) | (rc == 1 ? 2 : 0);
     if (rc != 0) return rc < 0 ? rc : 0;
   }
   return bf16 ? dispatch<true>(gates, true, a, (hipStream_t)stream) : dispatch<false>(gates, true, a, (hipStream_t)stream);

@@ -227,48 +227,65 @@ def main():
     bhh = torch.zeros(2, G * H, device=dev)
     lens = torch.full((B,), T, dtype=torch.int32, device=dev)
     bf = dtype == "bf16"
-    wpf, _ = ops.rnn_pack(G, whh, bf16=bf)
+    wpf, wpb_probe = ops.rnn_pack(G, whh, bf16=bf)
     pack = bf and B % 8 == 0                              # the train step's own mode (engine.forward)
     ops.rnn_fwd(G, gx.clone(), wpf, bhh, lens, T, B, H, bf16=bf, packed_gates=pack)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
     gx2 = gx.clone()
+    dyp = torch.randn(M, H, device=dev)
+    side = torch.empty(M, 2 * G * H, dtype=torch.bfloat16, device=dev) if pack else None
     torch.cuda.synchronize()
     e0.record()
-    ops.rnn_fwd(G, gx2, wpf, bhh, lens, T, B, H, bf16=bf, packed_gates=pack)
+    fwd_out = ops.rnn_fwd(G, gx2, wpf, bhh, lens, T, B, H, bf16=bf, packed_gates=pack)
     e1.record()
+    # the same layer's backward recurrence on the state just saved, in the train step's own mode
+    if pack:
+        ops.rnn_bwd(G, dyp, None, fwd_out[1], fwd_out[0], wpb_probe, lens, T, B, H, bf16=True, dgx_bf16=side, gates_bf16=fwd_out[2])
+    else:
+        ops.rnn_bwd(G, dyp, gx2, fwd_out[1], fwd_out[0], wpb_probe, lens, T, B, H, bf16=bf)
+    e2.record()
     torch.cuda.synchronize()
+    bwd_layer_us = e1.elapsed_time(e2) * 1e3
+    from asr_amd import _lib as _ds2lib
+    path_bits = _ds2lib.load().ds2_rnn_last_path()
     layer_us = e0.elapsed_time(e1) * 1e3                 # one layer's whole forward recurrence (T time steps, both directions)
     # bf16 mode runs the recurrence as ONE persistent launch per layer (rnn_fwd_persistent_kernel) when every workgroup can be resident at
     # once (grid <= CU count) — what ds2_rnn_fwd decides; otherwise (and in fp32) it is one rnn_fwd_step_kernel launch per time step.
-    def pick_mb(b, h):                                   # mirrors rnn.hip: 16-row batch tiles per workgroup
-        nsl = -(-h // 16)
-        if b <= 16:
-            return 1
-        if nsl * -(-b // 16) * 2 > 256:
-            return 2
-        return 2 if nsl * -(-b // 32) * 2 >= 200 else 1
-    mbt = pick_mb(B, H)
-    persistent = (bf and H % 16 == 0 and -(-H // 32) <= 40 and os.environ.get("DS2_RNN_PERSISTENT", "1") != "0"
-                  and (H // 16) * -(-B // (16 * mbt)) * 2 <= torch.cuda.get_device_properties(dev).multi_processor_count)
+    persistent = bool(path_bits & 1)                     # what ds2_rnn_fwd actually did (ds2_rnn_last_path)
     launches = 1 if persistent else T
     us_per_launch = layer_us / launches
     flops_per_launch = 2.0 * 2 * B * H * G * H * (T if persistent else 1)      # both directions; all T steps in the persistent launch
     achieved = flops_per_launch / (us_per_launch * 1e-6) / 1e12
     peak = BF16_MFMA_PEAK_TFLOPS if bf else FP32_MFMA_PEAK_TFLOPS
     # HBM-side bytes from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), measured for exactly this shape and mode
-    # (c3, bf16 operands, packed gate records): 7.47 MB per time step in the persistent kernel (profiles/r01_pmc_persistent/), 20.84 MB
+    # (c3, bf16 operands, packed gate records): 4.48 MB per time step in the persistent kernel (profiles/r01_pmc_persistent/), 20.84 MB
     # per launch of the step kernel (profiles/r01_pmc/); null for other shapes.
     traffic = None
     if args.workload == "c3" and bf and B == 64:
-        traffic = 7.47e6 * T if persistent else 20.84e6
+        traffic = 4.48e6 * T if persistent else 20.84e6
     alg_bytes_step = (3 * 4 + 8 + 4 + 2 if pack else 8 * 4 + (2 if bf else 4)) * B * 2 * H
     roofline = {"kernel": "rnn_fwd_persistent_kernel" if persistent else "rnn_fwd_step_kernel", "bound": "mfma", "achieved": achieved,
                 "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                 "algorithmic_hbm_bytes_per_launch": alg_bytes_step * (T if persistent else 1),
-                "us_per_launch": us_per_launch, "us_per_time_step": layer_us / T, "launches_per_step": 2 * launches * L if not persistent else None}
-    if persistent:
-        # forward recurrences are persistent launches (L per train step); backward ones too on a single GPU
-        roofline["launches_per_step"] = 2 * L
+                "us_per_launch": us_per_launch, "us_per_time_step": layer_us / T, "launches_per_step": (1 if persistent else T) * L}
+    # the backward recurrence (same FLOPs per time step): on a single GPU it is persistent too wherever its W_hh^T slice fits the
+    # registers.  Whichever of the two kernels takes longer per train step is THE dominant kernel and goes first.
+    bwd_persistent = bool(path_bits & 2)
+    bl = 1 if bwd_persistent else T
+    bl_steps = T if bwd_persistent else 1
+    b_ach = flops_per_launch / (T if persistent else 1) * (T if bwd_persistent else 1) / (bwd_layer_us / bl * 1e-6) / 1e12
+    bwd_traffic = None
+    if args.workload == "c3" and bf and B == 64 and bwd_persistent:
+        bwd_traffic = 6.71e6 * T                           # profiles/r01_pmc_persistent/: FETCH 1650 KB x2 + WRITE 3256 KB per time step
+    roofline_bwd = {"kernel": "rnn_bwd_persistent_kernel" if bwd_persistent else "rnn_bwd_step_kernel", "bound": "mfma", "achieved": b_ach,
+                    "peak": peak, "unit": "TFLOP/s", "frac": b_ach / peak, "traffic": bwd_traffic,
+                    # gate record 8 + previous state 4 + dGx 3 x 2 + d(hn) 4 bytes per hidden unit and direction, dy 4 bytes per unit (packed mode)
+                    "algorithmic_hbm_bytes_per_launch": ((8 + 4 + 2 * G + 4) * 2 + 4 if pack else (4 * G + 4 + 4 + 4 * G + 4) * 2 + 4) * B * H * bl_steps,
+                    "us_per_launch": bwd_layer_us / bl,
+                    "us_per_time_step": bwd_layer_us / T, "launches_per_step": bl * L}
+    if bwd_layer_us > layer_us:
+        roofline, roofline_bwd = roofline_bwd, roofline
+    roofline["second_kernel"] = roofline_bwd
 
     if args.breakdown and rank == 0:
         breakdown(model, tr, x, targets, pct, tsz)

@@ -145,6 +145,8 @@ int ds2_rnn_persistent_status(int* out8);
 /* Which recurrences may run as one persistent launch (default both).  Switch the backward one off when other kernels (collectives on a
  * communication stream) run on the device during backward: a persistent launch needs all of its workgroups resident at once. */
 int ds2_rnn_persistent_enable(int forward, int backward);
+/* reporting: bit 0 / bit 1 set if the last ds2_rnn_fwd / ds2_rnn_bwd call ran as a persistent launch (bench.py labels its roofline with it) */
+int ds2_rnn_last_path(void);
 size_t ds2_rnn_fwd_workspace_bytes(int B, int H, int bf16);
 /* gates_bf16: NULL, or a (T,B,2,H,4) bf16 buffer that receives the saved-for-backward record of every hidden unit as ONE 8-byte
  * store — GRU [r, z, n, W_hn h + b_hn], LSTM [i, f, g, o] — instead of four fp32 stores into gx / aux (gx is then left untouched

@@ -1,4 +1,4 @@
-"""Run ONLY the recurrent forward kernels at the bench shape (for rocprofv3 --pmc passes)."""
+"""Run ONLY the recurrent forward and backward kernels at the bench shape (for rocprofv3 --pmc passes)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from asr_amd import ops
@@ -11,5 +11,10 @@ bhh = torch.zeros(2, G * H, device=dev)
 lens = torch.full((B,), T, dtype=torch.int32, device=dev)
 wpf, wpb = ops.rnn_pack(G, whh, bf16=bf)
 out = ops.rnn_fwd(G, gx, wpf, bhh, lens, T, B, H, bf16=bf, packed_gates=bf)     # the train step's own mode
+if bf:
+    hb, aux, rec = out
+    dy = torch.randn(T * B, H, device=dev)
+    side = torch.empty(T * B, 2 * G * H, dtype=torch.bfloat16, device=dev)
+    ops.rnn_bwd(G, dy, None, aux, hb, wpb, lens, T, B, H, bf16=True, dgx_bf16=side, gates_bf16=rec)
 torch.cuda.synchronize()
 print("done", T, "launches")
