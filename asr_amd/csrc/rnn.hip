@@ -458,33 +458,37 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
 #pragma unroll
         for (int i = 0; i < MB; ++i) av[k][i] = u32x4_{0u, 0u, 0u, 0u};
       int spins = 0;
-      while (true) {
+      unsigned pend = 0;                                  // wave-uniform: chunks of this wave that have not been seen complete yet
+#pragma unroll
+      for (int k = 0; k < NCW; ++k)
+        if (cval[k]) pend |= ((1u << MB) - 1u) << (k * MB);
+      while (pend) {
+        // only the chunks that are still missing are read again: a blanket re-read of the whole operand by every waiting wave competes
+        // with the very stores it is waiting for
 #pragma unroll
         for (int k = 0; k < NCW; ++k)
 #pragma unroll
           for (int i = 0; i < MB; ++i)
-            if (cval[k]) av[k][i] = load16_sc1(xin + ((((long long)(bt * MB + i) * nch + (wave + NW * k)) * 64) + lane) * 16);
-        // the wait names every destination register: without that tie the compiler may test the registers before the loads have landed
+            if (pend & (1u << (k * MB + i))) av[k][i] = load16_sc1(xin + ((((long long)(bt * MB + i) * nch + (wave + NW * k)) * 64) + lane) * 16);
 #pragma unroll
         for (int k = 0; k < NCW; ++k)
 #pragma unroll
           for (int i = 0; i < MB; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(av[k][i])::"memory");
-        bool ok = true;
 #pragma unroll
         for (int k = 0; k < NCW; ++k)
 #pragma unroll
           for (int i = 0; i < MB; ++i)
-            if (lval[k]) ok = ok && av[k][i].x != PSENT && av[k][i].y != PSENT && av[k][i].z != PSENT && av[k][i].w != PSENT;
-        if (__ballot(ok) == ~0ull) break;
-        if (++spins > spin_limit) {
-          // record who starved and on what (first failure only), then fail loudly
-          // (no __builtin_trap here: hipcc sinks the trap to the kernel's common exit block, where it then fires on NORMAL completion
-          //  too — measured: spurious HSA_STATUS_ERROR_EXCEPTION at the end of correct runs.  The host reads this record at the
-          //  train step's sync point and raises: ds2_rnn_persistent_status / asr_amd.ops.rnn_persistent_check)
+            if (pend & (1u << (k * MB + i))) {
+              const bool ok = !lval[k] || (av[k][i].x != PSENT && av[k][i].y != PSENT && av[k][i].z != PSENT && av[k][i].w != PSENT);
+              if (__ballot(ok) == ~0ull) pend &= ~(1u << (k * MB + i));
+            }
+        pend = __builtin_amdgcn_readfirstlane(pend);
+        if (pend && ++spins > spin_limit) {
+          // record who starved and on what (first failure only); the host raises at the step's sync point (no __builtin_trap: hipcc sinks
+          // a trap to the kernel's common exit block, where it then fires on NORMAL completion too)
           if (lane == 0 && atomicCAS(&g_persist_dbg[0], 0, 1) == 0) {
             g_persist_dbg[1] = slice; g_persist_dbg[2] = bt; g_persist_dbg[3] = dir; g_persist_dbg[4] = s; g_persist_dbg[5] = wave;
-            unsigned long long m = __ballot(ok);
-            g_persist_dbg[6] = (int)(m & 0xffffffffu); g_persist_dbg[7] = (int)(m >> 32);
+            g_persist_dbg[6] = (int)pend; g_persist_dbg[7] = 0;
             __threadfence_system();
           }
           return;
@@ -865,28 +869,37 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_persistent_kernel(RnnArgs a, 
 #pragma unroll
         for (int i = 0; i < MB; ++i) av[k][i] = u32x4_{0u, 0u, 0u, 0u};
       int spins = 0;
-      while (true) {
+      unsigned pend = 0;                                  // wave-uniform: chunks of this wave that have not been seen complete yet
+#pragma unroll
+      for (int k = 0; k < NCW; ++k)
+        if (cval[k]) pend |= ((1u << MB) - 1u) << (k * MB);
+      while (pend) {
+        // only the chunks that are still missing are read again: a blanket re-read of the whole operand by every waiting wave competes
+        // with the very stores it is waiting for
 #pragma unroll
         for (int k = 0; k < NCW; ++k)
 #pragma unroll
           for (int i = 0; i < MB; ++i)
-            if (cval[k]) av[k][i] = load16_sc1(xin + ((((long long)(bt * MB + i) * nchb + (wave + NW * k)) * 64) + lane) * 16);
+            if (pend & (1u << (k * MB + i))) av[k][i] = load16_sc1(xin + ((((long long)(bt * MB + i) * nchb + (wave + NW * k)) * 64) + lane) * 16);
 #pragma unroll
         for (int k = 0; k < NCW; ++k)
 #pragma unroll
           for (int i = 0; i < MB; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(av[k][i])::"memory");
-        bool ok = true;
 #pragma unroll
         for (int k = 0; k < NCW; ++k)
 #pragma unroll
           for (int i = 0; i < MB; ++i)
-            if (lval[k]) ok = ok && av[k][i].x != PSENT && av[k][i].y != PSENT && av[k][i].z != PSENT && av[k][i].w != PSENT;
-        if (__ballot(ok) == ~0ull) break;
-        if (++spins > spin_limit) {
+            if (pend & (1u << (k * MB + i))) {
+              const bool ok = !lval[k] || (av[k][i].x != PSENT && av[k][i].y != PSENT && av[k][i].z != PSENT && av[k][i].w != PSENT);
+              if (__ballot(ok) == ~0ull) pend &= ~(1u << (k * MB + i));
+            }
+        pend = __builtin_amdgcn_readfirstlane(pend);
+        if (pend && ++spins > spin_limit) {
+          // record who starved and on what (first failure only); the host raises at the step's sync point (no __builtin_trap: hipcc sinks
+          // a trap to the kernel's common exit block, where it then fires on NORMAL completion too)
           if (lane == 0 && atomicCAS(&g_persist_dbg[0], 0, 2) == 0) {
             g_persist_dbg[1] = slice; g_persist_dbg[2] = bt; g_persist_dbg[3] = dir; g_persist_dbg[4] = s; g_persist_dbg[5] = wave;
-            unsigned long long m = __ballot(ok);
-            g_persist_dbg[6] = (int)(m & 0xffffffffu); g_persist_dbg[7] = (int)(m >> 32);
+            g_persist_dbg[6] = (int)pend; g_persist_dbg[7] = 0;
             __threadfence_system();
           }
           return;
