@@ -120,12 +120,24 @@ class DeepSpeechTrainer:
         loss = self.criterion(float_out, targets, output_sizes, target_sizes).to(self._device)
         loss = loss / inputs.size(0)
         loss_value = loss.item()
-        if getattr(self._model, "precision", "fp32") == "bf16":
-            ops.rnn_persistent_check()
+        starved = self._persistent_starved()
         valid_loss, _ = check_loss(loss, loss_value)
-        return valid_loss, loss, loss_value
+        return valid_loss and not starved, loss, loss_value
 
     # -- fused step ---------------------------------------------------------------------------------
+    @staticmethod
+    def _persistent_starved() -> bool:
+        """True if a persistent recurrence launch starved during this step (not every workgroup could be resident: something else held CUs).
+        The step's results are then invalid: it is reported, skipped like a non-finite loss, and the library has already switched to
+        the one-launch-per-step kernels for the rest of the process."""
+        try:
+            ops.rnn_persistent_check()
+            return False
+        except Exception as e:                                               # DS2LibraryError
+            import sys
+            print(f"[asr_amd] step skipped: {e}", file=sys.stderr, flush=True)
+            return True
+
     def _get_reducer(self):
         flat, grad = self._model.flat_parameters()
         if self._reducer is None or self._reducer.flat_grad.data_ptr() != grad.data_ptr():
@@ -157,9 +169,9 @@ class DeepSpeechTrainer:
             engine.backward(W, Gr, model._cfg, ctx, dlogits, on_bucket=red.on_bucket)
             red.finish()
             loss_value = loss.item()                                         # the step's single host sync
-            if model.precision == "bf16":
-                ops.rnn_persistent_check()                                   # the device is idle here: a starved persistent launch raises
+            starved = self._persistent_starved()                             # the device is idle here
             valid_loss, _ = check_loss(loss, loss_value)
+            valid_loss = valid_loss and not starved                          # a starved step is skipped like a non-finite loss (on every rank)
             valid_loss = red.all_valid(valid_loss, inputs.device)
             if valid_loss:
                 if isinstance(self._optimizer, FusedAdamW):
