@@ -1265,7 +1265,6 @@ extern "C" int ds2_rnn_fwd(int gates, float* gx, const void* wp_fwd, const float
   DS2_REQUIRE(gx && wp_fwd && bhh && hbuf && aux && lens_dev, "ds2_rnn_fwd: null pointer");
   DS2_REQUIRE(T > 0 && B > 0 && H > 0 && (H % 4) == 0, "ds2_rnn_fwd: need H %% 4 == 0 (H=%d)", H);
   DS2_REQUIRE(ws && ws_bytes >= ds2_rnn_fwd_workspace_bytes(B, H, bf16), "ds2_rnn_fwd: workspace too small");
-  DS2_HIP(hipMemsetAsync(ws, 0, ds2_rnn_fwd_workspace_bytes(B, H, bf16), (hipStream_t)stream));   // zero padding rows / columns
   RnnArgs a{};
   a.gx = gx; a.aux = aux; a.hbuf = hbuf; a.wp = (const float*)wp_fwd; a.bhh = bhh; a.pk = (float*)ws; a.lens = lens_dev;
   a.T = T; a.B = B; a.H = H; a.gates_bf = (__bf16*)gates_bf16;
@@ -1277,6 +1276,8 @@ extern "C" int ds2_rnn_fwd(int gates, float* gx, const void* wp_fwd, const float
     g_last_path = (g_last_path & ~1) | (rc == 1 ? 1 : 0);
     if (rc != 0) return rc < 0 ? rc : 0;
   }
+  // step kernels: zero padding rows / columns of the ping-pong buffers (the persistent path has filled its own with the sentinel)
+  DS2_HIP(hipMemsetAsync(ws, 0, ds2_rnn_fwd_workspace_bytes(B, H, bf16), (hipStream_t)stream));
   return bf16 ? dispatch<true>(gates, false, a, (hipStream_t)stream) : dispatch<false>(gates, false, a, (hipStream_t)stream);
 }
 
@@ -1312,7 +1313,6 @@ extern "C" int ds2_rnn_bwd(int gates, const float* dy, int lddy, float* gx, floa
   DS2_REQUIRE(gx || (gates_bf16 && dgx_bf16), "ds2_rnn_bwd: gx may only be NULL with both gates_bf16 and dgx_bf16 given");
   DS2_REQUIRE(T > 0 && B > 0 && H > 0 && (H % 4) == 0, "ds2_rnn_bwd: need H %% 4 == 0 (H=%d)", H);
   DS2_REQUIRE(ws && ws_bytes >= ds2_rnn_bwd_workspace_bytes(gates, B, H, bf16), "ds2_rnn_bwd: workspace too small");
-  DS2_HIP(hipMemsetAsync(ws, 0, ds2_rnn_bwd_workspace_bytes(gates, B, H, bf16), (hipStream_t)stream));
   RnnArgs a{};
   a.gx = gx; a.aux = aux; a.hbuf = const_cast<float*>(hbuf); a.wp = (const float*)wp_bwd; a.dy = dy; a.lddy = lddy;
   a.dcar = (float*)ws; a.pk = (float*)ws + (size_t)4 * B * H;
@@ -1327,5 +1327,6 @@ extern "C" int ds2_rnn_bwd(int gates, const float* dy, int lddy, float* gx, floa
     g_last_path = (g_last_path & ~2) | (rc == 1 ? 2 : 0);
     if (rc != 0) return rc < 0 ? rc : 0;
   }
+  DS2_HIP(hipMemsetAsync(ws, 0, ds2_rnn_bwd_workspace_bytes(gates, B, H, bf16), (hipStream_t)stream));   // step kernels: zero carry + padding
   return bf16 ? dispatch<true>(gates, true, a, (hipStream_t)stream) : dispatch<false>(gates, true, a, (hipStream_t)stream);
 }
