@@ -1,0 +1,54 @@
+"""Random-shape sweep: persistent recurrence kernels vs the one-launch-per-step kernels must agree to the bit (forward and backward, GRU and
+LSTM, bf16 and fp32, packed and plain buffers), over every template instance the launcher can pick.  Not part of pytest."""
+import os, sys, random, ctypes
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from asr_amd import ops, _lib
+lib = _lib.load()
+dev = torch.device("cuda:0")
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = took = 0
+for it in range(n):
+    G = rng.choice([3, 4])
+    H = 16 * rng.choice([1, 2, 3, 5, 8, 12, 16, 24, 32, 40, 48, 64, 65, 66, 80])
+    B = rng.choice([1, 3, 8, 16, 17, 24, 32, 40, 48, 61, 64])
+    T = rng.randint(2, 9)
+    bf = rng.random() < 0.6
+    packed = bf and rng.random() < 0.6
+    torch.manual_seed(it)
+    gx = torch.randn(T * B, 2 * G * H, device=dev) * 0.5
+    whh = (torch.rand(2, G * H, H, device=dev) * 2 - 1) / H ** 0.5
+    bhh = torch.randn(2, G * H, device=dev) * 0.1
+    lens = torch.randint(1, T + 1, (B,), dtype=torch.int32, device=dev); lens[0] = T
+    dy = torch.randn(T * B, H, device=dev)
+    wpf, wpb = ops.rnn_pack(G, whh, bf16=bf)
+    res = []
+    for flags in (0, 64):                      # 0: persistent where eligible ; 64: step kernels
+        lib.ds2_debug_flags(flags)
+        g = gx.clone()
+        out = ops.rnn_fwd(G, g, wpf, bhh, lens, T, B, H, bf16=bf, packed_gates=packed)
+        path = lib.ds2_rnn_last_path() & 1
+        if packed:
+            hb, aux, rec = out
+            side = torch.empty(T * B, 2 * G * H, dtype=torch.bfloat16, device=dev)
+            auxb = aux.clone() if G == 4 else torch.zeros_like(aux)
+            ops.rnn_bwd(G, dy, None, auxb, hb, wpb, lens, T, B, H, bf16=True, dgx_bf16=side, gates_bf16=rec)
+            outs = (hb, rec, side, auxb)
+        else:
+            hb, aux = out
+            auxb = aux.clone()
+            ops.rnn_bwd(G, dy, g, auxb, hb, wpb, lens, T, B, H, bf16=bf)
+            outs = (hb, aux, g, auxb)
+        path |= lib.ds2_rnn_last_path() & 2
+        torch.cuda.synchronize()
+        res.append((path, [o.clone() for o in outs]))
+    lib.ds2_debug_flags(0)
+    took += res[0][0] != 0
+    same = all(torch.equal(a.view(torch.uint8) if a.dtype == torch.bfloat16 else a, b.view(torch.uint8) if b.dtype == torch.bfloat16 else b)
+               for a, b in zip(res[0][1], res[1][1]))
+    if not same:
+        bad += 1
+        print(f"[{it}] MISMATCH G={G} H={H} B={B} T={T} bf16={bf} packed={packed} path={res[0][0]}", flush=True)
+ops.rnn_persistent_check()
+print(f"{n} cases, {took} took a persistent kernel, mismatches: {bad}")
