@@ -471,6 +471,18 @@ print("FALLBACK-EQUAL", bool(torch.equal(h2, h3)))
 """
 
 
+def test_persistent_vs_step_recurrence_random_shapes(dev):
+    """150 random (cell, H, B, T, precision, buffer mode) cases: whatever template instance the launcher picks, the persistent kernels and
+    the one-launch-per-step kernels agree to the bit in every output (scripts/fuzz_persistent.py)."""
+    import os, subprocess, sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([_sys.executable, os.path.join(root, "scripts", "fuzz_persistent.py"), "150", "3"], capture_output=True, text=True,
+                         timeout=600).stdout
+    assert "mismatches: 0" in out and "150 cases" in out, out[-2000:]
+    took = int(out.split("cases,")[1].split("took")[0])
+    assert took >= 100, out[-500:]                     # most shapes do qualify for the persistent path
+
+
 def test_persistent_recurrence_starvation_is_loud_and_falls_back(dev):
     """A persistent launch whose waves give up polling (forced here with a poll limit of 0) must be reported: the status check raises,
     and the library then runs the one-launch-per-step kernels for the rest of the process."""
