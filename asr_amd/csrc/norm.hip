@@ -106,10 +106,23 @@ __global__ __launch_bounds__(256) void col_finalize_kernel(const float* __restri
   const int c = blockIdx.x * 32 + cl;
   double a = 0.0, b = 0.0;
   if (c < H) {
-    for (int k = grp; k < chunks; k += 8) {
+    // four independent accumulator pairs: the loads of four partials are in flight together instead of one dependent load + add per trip
+    double a1 = 0.0, b1 = 0.0, a2 = 0.0, b2 = 0.0, a3 = 0.0, b3 = 0.0;
+    int k = grp;
+    for (; k + 24 < chunks; k += 32) {
+      const float2 p0 = *reinterpret_cast<const float2*>(part + ((long long)k * H + c) * 2);
+      const float2 p1 = *reinterpret_cast<const float2*>(part + ((long long)(k + 8) * H + c) * 2);
+      const float2 p2 = *reinterpret_cast<const float2*>(part + ((long long)(k + 16) * H + c) * 2);
+      const float2 p3 = *reinterpret_cast<const float2*>(part + ((long long)(k + 24) * H + c) * 2);
+      a += (double)p0.x; b += (double)p0.y; a1 += (double)p1.x; b1 += (double)p1.y;
+      a2 += (double)p2.x; b2 += (double)p2.y; a3 += (double)p3.x; b3 += (double)p3.y;
+    }
+    for (; k < chunks; k += 8) {
       a += (double)part[((long long)k * H + c) * 2 + 0];
       b += (double)part[((long long)k * H + c) * 2 + 1];
     }
+    a = (a + a1) + (a2 + a3);
+    b = (b + b1) + (b2 + b3);
   }
   red[grp][cl][0] = a;
   red[grp][cl][1] = b;
