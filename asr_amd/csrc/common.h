@@ -47,13 +47,14 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
-// Gate non-linearities on the hardware exp unit (v_exp_f32, <= 2 ulp) with one Newton-free reciprocal: ~1e-7 absolute error,
-// far inside the 1e-3 parity bar, and ~4x fewer instructions than libm expf/tanhf in the latency-critical epilogue.
-__device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+// Gate non-linearities on the hardware exp unit (v_exp_f32) and the hardware reciprocal (v_rcp_f32, 1 ulp; `__frcp_rn` expands to the
+// 10-instruction IEEE division sequence — three of them per GRU gate set sat on the recurrence's critical path): ~2e-7 absolute error,
+// far inside the 1e-3 parity bar.
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) {
   const float ax = fminf(fabsf(x), 15.0f);                 // tanh(15) == 1 in fp32; avoids exp overflow
   const float e = __expf(2.0f * ax);
-  const float t = 1.0f - 2.0f * __frcp_rn(e + 1.0f);
+  const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
   return copysignf(t, x);
 }
 

@@ -58,6 +58,8 @@ struct RnnArgs {
   int T, B, H, lddy;
   int nsl, nbt16;     // hidden slices of 16 ; allocated 16-row batch tiles (multiple of MB)
   int dbg;            // ablation flags (0 in production)
+  // persistent kernels only: batch tiles per direction, workgroups per exchange group (= hidden slices), XCD census on/off, CUs per XCD
+  int p_nbt, p_gs, p_census, p_cux;
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -72,8 +74,20 @@ __device__ unsigned long long* g_rnn_trace = nullptr;   // [step][wave][8]
     if (g_rnn_trace && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (threadIdx.x & 63) == 0)         \
       g_rnn_trace[((long long)(step) * NW + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_amdgcn_s_memtime();       \
   } while (0)
+// persistent kernels: per-wave sums of the spans between consecutive stamps (registers only: no memory traffic inside the time loop),
+// written out by workgroup 0 when the launch ends: g_rnn_trace[(kind * NW + wave) * 8 + k], kind 0 forward / 1 backward
+#define PTRACE_DECL unsigned long long pt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt_last = __builtin_amdgcn_s_memtime()
+#define PTRACE(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); pt_acc[k] += now_ - pt_last; pt_last = now_; } while (0)
+#define PTRACE_DUMP(kind)                                                                                                     \
+  do {                                                                                                                        \
+    if (g_rnn_trace && blockIdx.x == 0 && (threadIdx.x & 63) == 0)                                                              \
+      for (int k_ = 0; k_ < 8; ++k_) g_rnn_trace[((kind) * NW + (threadIdx.x >> 6)) * 8 + k_] = pt_acc[k_];                       \
+  } while (0)
 #else
 #define RNN_TRACE(step, k) do { } while (0)
+#define PTRACE_DECL do { } while (0)
+#define PTRACE(k) do { } while (0)
+#define PTRACE_DUMP(kind) do { } while (0)
 #endif
 
 // Pin every pointer argument into SGPRs at kernel entry: the compiler otherwise sinks the s_load of pointers that are first
@@ -362,29 +376,180 @@ typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
 // (the trailing s_nop: a > 64-bit VMEM store needs wait states before its data VGPRs may be overwritten; the compiler inserts them for its
 //  own stores but cannot see inside inline asm, and back-to-back publishes then shipped partly overwritten payloads)
 __device__ __forceinline__ void store16_sc1(void* p, u32x4_ v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" ::"v"(p), "v"(v) : "memory"); }
-__device__ __forceinline__ u32x4_ load16_sc1(const void* p) {
-  u32x4_ v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
 constexpr unsigned PSENT = 0xffffffffu;
 __device__ int g_persist_dbg[8];      // first starved wave of a persistent launch: {set, block x, y, z, step, wave, ok-mask lo, hi}
 
+// `s_waitcnt vmcnt(0)` in the form the compiler's own wait-insertion pass understands: after it, the scoreboard knows that every vector
+// load issued so far has landed.  Placed right behind the gather (whose asm statement has really waited, invisibly to the compiler) and in
+// front of the time loop, it keeps the pass from putting its own conservative vmcnt(0) — it cannot count outstanding operations across
+// the loop's back edge — behind the loads the step has JUST issued (observed: a full HBM round trip in front of every step's LDS writes).
+__device__ __forceinline__ void vm_drained() { __builtin_amdgcn_s_waitcnt(0x0f70); }   // vmcnt(0), expcnt / lgkmcnt untouched
+
+// L2-local flavour of the publish: a PLAIN 16-byte store stays in the storing XCD's L2 (an sc1 store is written through and DROPPED from it, so
+// that even a same-XCD reader then pays the fabric round trip).  Only used when the census below has put every member of an exchange group on
+// ONE XCD: that XCD's L2 is then the coherence point of the whole exchange (readers bypass their L1 with sc1 loads).
+// scripts/probe_xcd_local.hip: 32 KB gather 1.65 -> 1.06-1.38 us per step, 96 KB gather 2.54 -> 2.14-2.23 us.
+__device__ __forceinline__ void store16_l2(void* p, u32x4_ v) { asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 2" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void store16_x(void* p, u32x4_ v, bool l2_local) {
+  if (l2_local) store16_l2(p, v);
+  else store16_sc1(p, v);
+}
+
+// ---- gather: ONE asm statement per poll pass --------------------------------------------------------------------------------------------
+// An asynchronous load issued from inline asm leaves its destination registers unprotected until one's OWN s_waitcnt: between two asm
+// statements the compiler is free to copy them, and it does as soon as the surrounding code changes shape (seen in the probe: whole-array
+// v_mov copies right behind the load, i.e. of data that had not landed).  So the loads of one poll pass, their wave-uniform "chunk still
+// pending" predicates and the wait are ONE statement: its outputs are final when it ends.  Chunk K is read iff bit K of `pend` is set.
+#define DS2_PL(K) "s_bitcmp1_b32 %[pend], " #K "\n\ts_cbranch_scc0 .Lds2poll%=_" #K "\n\tglobal_load_dwordx4 %[d" #K "], %[o" #K "], %[base] sc1\n.Lds2poll%=_" #K ":\n\t"
+#define DS2_PD(K) [d##K] "+v"(v[K])
+#define DS2_PO(K) [o##K] "v"(off[K])
+#define DS2_PTAIL [base] "s"(base), [pend] "s"(pend) : "memory", "scc"
+template <int N> struct PollBlock;
+#define DS2_POLLBLOCK(N, LOADS, DSTS, OFFS)                                                                                          \
+  template <> struct PollBlock<N> {                                                                                                  \
+    static __device__ __forceinline__ void run(u32x4_* v, const unsigned* off, const char* base, unsigned pend) {                    \
+      asm volatile(LOADS "s_waitcnt vmcnt(0)" : DSTS : OFFS, DS2_PTAIL);                                                             \
+    }                                                                                                                                \
+  };
+#define DS2_C ,
+DS2_POLLBLOCK(1, DS2_PL(0),
+              DS2_PD(0),
+              DS2_PO(0))
+DS2_POLLBLOCK(2, DS2_PL(0) DS2_PL(1),
+              DS2_PD(0) DS2_C DS2_PD(1),
+              DS2_PO(0) DS2_C DS2_PO(1))
+DS2_POLLBLOCK(3, DS2_PL(0) DS2_PL(1) DS2_PL(2),
+              DS2_PD(0) DS2_C DS2_PD(1) DS2_C DS2_PD(2),
+              DS2_PO(0) DS2_C DS2_PO(1) DS2_C DS2_PO(2))
+DS2_POLLBLOCK(4, DS2_PL(0) DS2_PL(1) DS2_PL(2) DS2_PL(3),
+              DS2_PD(0) DS2_C DS2_PD(1) DS2_C DS2_PD(2) DS2_C DS2_PD(3),
+              DS2_PO(0) DS2_C DS2_PO(1) DS2_C DS2_PO(2) DS2_C DS2_PO(3))
+DS2_POLLBLOCK(5, DS2_PL(0) DS2_PL(1) DS2_PL(2) DS2_PL(3) DS2_PL(4),
+              DS2_PD(0) DS2_C DS2_PD(1) DS2_C DS2_PD(2) DS2_C DS2_PD(3) DS2_C DS2_PD(4),
+              DS2_PO(0) DS2_C DS2_PO(1) DS2_C DS2_PO(2) DS2_C DS2_PO(3) DS2_C DS2_PO(4))
+DS2_POLLBLOCK(6, DS2_PL(0) DS2_PL(1) DS2_PL(2) DS2_PL(3) DS2_PL(4) DS2_PL(5),
+              DS2_PD(0) DS2_C DS2_PD(1) DS2_C DS2_PD(2) DS2_C DS2_PD(3) DS2_C DS2_PD(4) DS2_C DS2_PD(5),
+              DS2_PO(0) DS2_C DS2_PO(1) DS2_C DS2_PO(2) DS2_C DS2_PO(3) DS2_C DS2_PO(4) DS2_C DS2_PO(5))
+DS2_POLLBLOCK(7, DS2_PL(0) DS2_PL(1) DS2_PL(2) DS2_PL(3) DS2_PL(4) DS2_PL(5) DS2_PL(6),
+              DS2_PD(0) DS2_C DS2_PD(1) DS2_C DS2_PD(2) DS2_C DS2_PD(3) DS2_C DS2_PD(4) DS2_C DS2_PD(5) DS2_C DS2_PD(6),
+              DS2_PO(0) DS2_C DS2_PO(1) DS2_C DS2_PO(2) DS2_C DS2_PO(3) DS2_C DS2_PO(4) DS2_C DS2_PO(5) DS2_C DS2_PO(6))
+DS2_POLLBLOCK(8, DS2_PL(0) DS2_PL(1) DS2_PL(2) DS2_PL(3) DS2_PL(4) DS2_PL(5) DS2_PL(6) DS2_PL(7),
+              DS2_PD(0) DS2_C DS2_PD(1) DS2_C DS2_PD(2) DS2_C DS2_PD(3) DS2_C DS2_PD(4) DS2_C DS2_PD(5) DS2_C DS2_PD(6) DS2_C DS2_PD(7),
+              DS2_PO(0) DS2_C DS2_PO(1) DS2_C DS2_PO(2) DS2_C DS2_PO(3) DS2_C DS2_PO(4) DS2_C DS2_PO(5) DS2_C DS2_PO(6) DS2_C DS2_PO(7))
+DS2_POLLBLOCK(9, DS2_PL(0) DS2_PL(1) DS2_PL(2) DS2_PL(3) DS2_PL(4) DS2_PL(5) DS2_PL(6) DS2_PL(7) DS2_PL(8),
+              DS2_PD(0) DS2_C DS2_PD(1) DS2_C DS2_PD(2) DS2_C DS2_PD(3) DS2_C DS2_PD(4) DS2_C DS2_PD(5) DS2_C DS2_PD(6) DS2_C DS2_PD(7) DS2_C DS2_PD(8),
+              DS2_PO(0) DS2_C DS2_PO(1) DS2_C DS2_PO(2) DS2_C DS2_PO(3) DS2_C DS2_PO(4) DS2_C DS2_PO(5) DS2_C DS2_PO(6) DS2_C DS2_PO(7) DS2_C DS2_PO(8))
+DS2_POLLBLOCK(10, DS2_PL(0) DS2_PL(1) DS2_PL(2) DS2_PL(3) DS2_PL(4) DS2_PL(5) DS2_PL(6) DS2_PL(7) DS2_PL(8) DS2_PL(9),
+              DS2_PD(0) DS2_C DS2_PD(1) DS2_C DS2_PD(2) DS2_C DS2_PD(3) DS2_C DS2_PD(4) DS2_C DS2_PD(5) DS2_C DS2_PD(6) DS2_C DS2_PD(7) DS2_C DS2_PD(8) DS2_C DS2_PD(9),
+              DS2_PO(0) DS2_C DS2_PO(1) DS2_C DS2_PO(2) DS2_C DS2_PO(3) DS2_C DS2_PO(4) DS2_C DS2_PO(5) DS2_C DS2_PO(6) DS2_C DS2_PO(7) DS2_C DS2_PO(8) DS2_C DS2_PO(9))
+DS2_POLLBLOCK(11, DS2_PL(0) DS2_PL(1) DS2_PL(2) DS2_PL(3) DS2_PL(4) DS2_PL(5) DS2_PL(6) DS2_PL(7) DS2_PL(8) DS2_PL(9) DS2_PL(10),
+              DS2_PD(0) DS2_C DS2_PD(1) DS2_C DS2_PD(2) DS2_C DS2_PD(3) DS2_C DS2_PD(4) DS2_C DS2_PD(5) DS2_C DS2_PD(6) DS2_C DS2_PD(7) DS2_C DS2_PD(8) DS2_C DS2_PD(9) DS2_C DS2_PD(10),
+              DS2_PO(0) DS2_C DS2_PO(1) DS2_C DS2_PO(2) DS2_C DS2_PO(3) DS2_C DS2_PO(4) DS2_C DS2_PO(5) DS2_C DS2_PO(6) DS2_C DS2_PO(7) DS2_C DS2_PO(8) DS2_C DS2_PO(9) DS2_C DS2_PO(10))
+DS2_POLLBLOCK(12, DS2_PL(0) DS2_PL(1) DS2_PL(2) DS2_PL(3) DS2_PL(4) DS2_PL(5) DS2_PL(6) DS2_PL(7) DS2_PL(8) DS2_PL(9) DS2_PL(10) DS2_PL(11),
+              DS2_PD(0) DS2_C DS2_PD(1) DS2_C DS2_PD(2) DS2_C DS2_PD(3) DS2_C DS2_PD(4) DS2_C DS2_PD(5) DS2_C DS2_PD(6) DS2_C DS2_PD(7) DS2_C DS2_PD(8) DS2_C DS2_PD(9) DS2_C DS2_PD(10) DS2_C DS2_PD(11),
+              DS2_PO(0) DS2_C DS2_PO(1) DS2_C DS2_PO(2) DS2_C DS2_PO(3) DS2_C DS2_PO(4) DS2_C DS2_PO(5) DS2_C DS2_PO(6) DS2_C DS2_PO(7) DS2_C DS2_PO(8) DS2_C DS2_PO(9) DS2_C DS2_PO(10) DS2_C DS2_PO(11))
+#undef DS2_C
+#undef DS2_POLLBLOCK
+// One poll pass over N chunks: blocks of <= 12 loads + their wait (N <= 12 is one statement = one round trip — every bf16 shape with 16-row
+// tiles; the few wider shapes pay one more round trip per further block, and only for blocks that still have something pending).
+template <int N>
+__device__ __forceinline__ void poll_pass(u32x4_* v, const unsigned* off, const char* base, unsigned pend) {
+  static_assert(N >= 1 && N <= 32, "pending mask is 32 bits");
+  // both are wave-uniform by construction; say so in a way the compiler can see ("s" operands must be in SGPRs)
+  pend = __builtin_amdgcn_readfirstlane(pend);
+  {
+    const unsigned long long u = reinterpret_cast<unsigned long long>(base);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)), lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u);
+    base = reinterpret_cast<const char*>(((unsigned long long)hi << 32) | (unsigned long long)lo);   // (the builtin returns a SIGNED int)
+  }
+  if constexpr (N <= 12) {
+    PollBlock<N>::run(v, off, base, pend);
+  } else {
+    if (pend & 0xfffu) PollBlock<12>::run(v, off, base, pend & 0xfffu);
+    if (pend >> 12) poll_pass<N - 12>(v + 12, off + 12, base, pend >> 12);
+  }
+}
+
+// ---- who am I: (direction, batch tile, hidden slice) of a persistent workgroup ------------------------------------------------------------
+// An exchange group = the p_gs workgroups (hidden slices) of one (direction, batch tile): they trade h_t / dGh_t with each other every time
+// step and with nobody else.  Census mode (p_census; the launcher starts one workgroup per CU then): every workgroup reads the id of the
+// XCD it REALLY runs on (HW_REG_XCC_ID), draws a slot on that XCD with one atomic, waits until the whole grid has arrived, and — if every
+// XCD holds enough workgroups for the groups assigned to it (group g lives on XCD g % 8) — takes the role (group, slice) its slot says, so
+// that a group provably shares one L2 and exchanges through it (`local`).  Workgroups left over exit.  Nothing is assumed about the
+// dispatcher's placement: an uneven census just selects the placement-independent protocol (sc1 stores) with roles by workgroup id.
+// All census words start at 0xffffffff (the launcher's single memset covers the exchange buffers' sentinel AND these counters).
+struct PRole { int dir, bt, slice, local, active; };
+__device__ __forceinline__ PRole persist_role(const RnnArgs& a, unsigned* census, int spin_limit, int kind) {
+  __shared__ int s_role[4];
+  const int nbt = a.p_nbt, gs = a.p_gs, ngroups = 2 * nbt, wg = blockIdx.x;
+  int group = -1, slice = 0, local = 0;
+  auto by_id = [&](int& g, int& sl) {
+    if (wg >= ngroups * gs) { g = -1; sl = 0; }
+    else if (ngroups == 8) { g = wg & 7; sl = wg >> 3; }     // 8 groups: group-major, one group per XCD under round-robin placement
+    else { sl = wg % gs; g = wg / gs; }                      // slice-major (measured better for the other shapes)
+  };
+  if (!a.p_census) {
+    by_id(group, slice);
+  } else {
+    if (threadIdx.x == 0) {
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      xcc &= 0xfu;
+      const unsigned slot = atomicAdd(&census[xcc & 7u], 1u) + 1u;
+      if (xcc > 7u) atomicAdd(&census[9], 1u);
+      atomicAdd(&census[8], 1u);
+      int spins = 0;
+      bool all = false;
+      while (!(all = __hip_atomic_load(&census[8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u >= gridDim.x) && ++spins <= spin_limit)
+        __builtin_amdgcn_s_sleep(1);
+      int g = -2, sl = 0, loc = 0;
+      if (all) {
+        const int gpx = a.p_cux / gs;                                            // groups one XCD can host
+        bool ok = __hip_atomic_load(&census[9], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0xffffffffu;
+        for (int x = 0; x < 8; ++x) {
+          const int need = (ngroups + 7 - x) / 8;
+          const unsigned cnt = __hip_atomic_load(&census[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+          ok = ok && need <= gpx && cnt >= (unsigned)(need * gs);
+        }
+        if (ok) {
+          loc = 1;
+          const int lg = (int)slot / gs, need_me = (ngroups + 7 - (int)xcc) / 8;
+          if (lg < need_me) { g = lg * 8 + (int)xcc; sl = (int)slot % gs; }
+          else g = -1;
+        } else {
+          by_id(g, sl);
+        }
+      } else if (atomicCAS(&g_persist_dbg[0], 0, 3) == 0) {     // the grid never became resident: record it (the host raises), leave
+        g_persist_dbg[1] = wg; g_persist_dbg[2] = (int)xcc; g_persist_dbg[3] = kind; g_persist_dbg[4] = -1; g_persist_dbg[5] = 0;
+        g_persist_dbg[6] = (int)__hip_atomic_load(&census[8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1; g_persist_dbg[7] = 0;
+        __threadfence_system();
+      }
+      s_role[0] = g; s_role[1] = sl; s_role[2] = loc;
+    }
+    __syncthreads();
+    group = s_role[0]; slice = s_role[1]; local = s_role[2];
+  }
+  PRole r;
+  r.active = group >= 0;
+  group = __builtin_amdgcn_readfirstlane(group < 0 ? 0 : group);
+  r.dir = group / nbt; r.bt = group % nbt;
+  r.slice = __builtin_amdgcn_readfirstlane(slice);
+  r.local = __builtin_amdgcn_readfirstlane(local);
+  return r;
+}
+
 template <int G, int MB, int NS, int NCW, bool BF>
-__global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, char* xbuf, int spin_limit) {
+__global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, char* xbuf, unsigned* census, int spin_limit) {
   static_assert(MB * NS * 256 <= NW * 64, "one (row, unit) pair per thread");
   __shared__ __attribute__((aligned(16))) f32x4 red[2][NW][MB * NS * G][64];       // double-buffered: ONE workgroup barrier per time step
   constexpr int KC = kchunk<BF>(), EPL = KC / 4;                              // units per chunk (32 | 16) and per 16-byte lane vector (8 | 4)
   using elem_t = typename std::conditional<BF, __bf16, float>::type;
   __shared__ __attribute__((aligned(16))) elem_t stage[NW][64];               // wave-private: a wave's 64 (row, unit) pairs = 64 / EPL complete 16-byte chunks
-  // grid = (direction x batch tile, slice): the linear workgroup id is group + ngroups * slice, so with 8 groups (c3: 4 tiles of 16 rows x 2
-  // directions) every group — the set of workgroups that exchange h_t with each other — sits on ONE XCD under the round-robin placement
-  // (measured 1.58 vs 1.72 us per exchange, profiles/r01_probe_xcd_exchange.txt; correctness does not depend on it)
-  // (used when there are exactly 8 groups; other shapes keep the slice-major grid (slice, tile, direction), which measured better there)
-  const bool group_major = gridDim.z == 1;
-  const int nbt_ = gridDim.x >> 1;
-  const int dir = group_major ? blockIdx.x / nbt_ : blockIdx.z, bt = group_major ? blockIdx.x % nbt_ : blockIdx.y;
-  const int slice = group_major ? blockIdx.y : blockIdx.x;
+  // 1-D grid; (direction, batch tile, slice) from the XCD census or from the workgroup id: persist_role
+  const PRole role = persist_role(a, census, spin_limit, 1);
+  if (!role.active) return;
+  const int dir = role.dir, bt = role.bt, slice = role.slice;
+  const bool l2_local = role.local != 0;
   const int T = a.T, B = a.B, H = a.H;
   const int nsl = (H + 15) >> 4, nch = (H + KC - 1) / KC;
   const int j0 = slice * (16 * NS), b0 = bt * (16 * MB);      // slice = NS consecutive 16-unit slices
@@ -441,45 +606,64 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
     for (int g = 0; g < G; ++g) pgx[g] = ldnt(p0 + g * H);
   }
 
+  // saved-for-backward outputs of one time step (written one step late, see the loop)
+  int so_t = 0;
+  float so_g[4] = {0.f, 0.f, 0.f, 0.f}, so_aux = 0.f, so_h = 0.f;
+  bool so_live = false;
+  auto store_outputs = [&](int t, const float (&og)[4], float oaux, float oh, bool live) {
+    if (!pact) return;
+    const long long rowH = (((long long)t * B + b) * 2 + dir) * H + j;
+    if (a.gates_bf) {
+      __builtin_nontemporal_store(bf16x4_{(__bf16)og[0], (__bf16)og[1], (__bf16)og[2], (__bf16)og[3]}, reinterpret_cast<bf16x4_*>(a.gates_bf) + rowH);
+      if (G == 4) a.aux[rowH] = oaux;
+    } else {
+      float* gx = const_cast<float*>(gx_row(t));
+      stnt(&gx[0], og[0]); stnt(&gx[H], og[1]); stnt(&gx[2 * H], og[2]);
+      if (G == 4) { stnt(&gx[3 * H], og[3]); a.aux[rowH] = oaux; }
+      else stnt(a.aux + rowH, live ? oaux : 0.f);
+    }
+    a.hbuf[rowH] = oh;
+  };
+
+  // this wave's chunks of the packed exchange buffer (byte offsets from the buffer's direction base) and the all-pending mask
+  unsigned goff[NCW * MB], pend0 = 0;
+#pragma unroll
+  for (int k = 0; k < NCW; ++k)
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+      goff[k * MB + i] = (unsigned)(((((long long)(bt * MB + i) * nch + (wave + NW * k)) * 64) + lane) * 16);
+      if (cval[k]) pend0 |= 1u << (k * MB + i);
+    }
+
+  PTRACE_DECL;
+  vm_drained();                                         // prologue loads (W_hh slice, biases, lengths, first x-projections) have landed
   for (int s = 0; s < T; ++s) {
     const int t = dir == 0 ? s : T - 1 - s;
-    RNN_TRACE(s, 0);
+    PTRACE(0);
     f32x4 acc[MB][NS * G];
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
       for (int g = 0; g < NS * G; ++g) acc[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (s > 0) {
-      // ---- gather h_{s-1}: poll this wave's chunks until none carries the sentinel
+      // ---- gather h_{s-1}: poll this wave's chunks until none carries the sentinel (one asm statement per pass: poll_pass)
       const char* xin = xbuf + (long long)((s - 1) & 3) * bufbytes + dirbase;
-      u32x4_ av[NCW][MB];
+      u32x4_ av[NCW * MB];
 #pragma unroll
-      for (int k = 0; k < NCW; ++k)
-#pragma unroll
-        for (int i = 0; i < MB; ++i) av[k][i] = u32x4_{0u, 0u, 0u, 0u};
+      for (int k = 0; k < NCW * MB; ++k) av[k] = u32x4_{0u, 0u, 0u, 0u};
       int spins = 0;
-      unsigned pend = 0;                                  // wave-uniform: chunks of this wave that have not been seen complete yet
-#pragma unroll
-      for (int k = 0; k < NCW; ++k)
-        if (cval[k]) pend |= ((1u << MB) - 1u) << (k * MB);
+      unsigned pend = pend0;                              // wave-uniform: chunks of this wave that have not been seen complete yet
       while (pend) {
         // only the chunks that are still missing are read again: a blanket re-read of the whole operand by every waiting wave competes
         // with the very stores it is waiting for
-#pragma unroll
-        for (int k = 0; k < NCW; ++k)
-#pragma unroll
-          for (int i = 0; i < MB; ++i)
-            if (pend & (1u << (k * MB + i))) av[k][i] = load16_sc1(xin + ((((long long)(bt * MB + i) * nch + (wave + NW * k)) * 64) + lane) * 16);
-#pragma unroll
-        for (int k = 0; k < NCW; ++k)
-#pragma unroll
-          for (int i = 0; i < MB; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(av[k][i])::"memory");
+        poll_pass<NCW * MB>(av, goff, xin, pend);
 #pragma unroll
         for (int k = 0; k < NCW; ++k)
 #pragma unroll
           for (int i = 0; i < MB; ++i)
             if (pend & (1u << (k * MB + i))) {
-              const bool ok = !lval[k] || (av[k][i].x != PSENT && av[k][i].y != PSENT && av[k][i].z != PSENT && av[k][i].w != PSENT);
+              const u32x4_ c = av[k * MB + i];
+              const bool ok = !lval[k] || (c.x != PSENT && c.y != PSENT && c.z != PSENT && c.w != PSENT);
               if (__ballot(ok) == ~0ull) pend &= ~(1u << (k * MB + i));
             }
         pend = __builtin_amdgcn_readfirstlane(pend);
@@ -488,18 +672,17 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
           // a trap to the kernel's common exit block, where it then fires on NORMAL completion too)
           if (lane == 0 && atomicCAS(&g_persist_dbg[0], 0, 1) == 0) {
             g_persist_dbg[1] = slice; g_persist_dbg[2] = bt; g_persist_dbg[3] = dir; g_persist_dbg[4] = s; g_persist_dbg[5] = wave;
-            g_persist_dbg[6] = (int)pend; g_persist_dbg[7] = 0;
+            g_persist_dbg[6] = (int)pend; g_persist_dbg[7] = l2_local;
             __threadfence_system();
           }
           return;
         }
       }
-      RNN_TRACE(s, 1);
 #pragma unroll
       for (int k = 0; k < NCW; ++k)
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
-          const u32x4_ v = lval[k] ? av[k][i] : u32x4_{0u, 0u, 0u, 0u};
+          const u32x4_ v = lval[k] ? av[k * MB + i] : u32x4_{0u, 0u, 0u, 0u};
           if constexpr (BF) {
 #pragma unroll
             for (int g = 0; g < NS * G; ++g)
@@ -513,14 +696,31 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
           }
         }
     }
+    vm_drained();                                       // (the gather has waited for everything; tell the compiler)
+    PTRACE(1);                                          // gather done
+    if (s > 0) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) pgx[g] = pgx_next[g];  // x-projections of THIS step: loaded one step ago, landed
+    }
+    // ---- HBM traffic of the step, issued HERE: the vector-memory counter retires in order, so whatever is outstanding when the next poll
+    // pass is issued delays it by its full latency.  Right behind the gather these loads and stores have the whole MFMA / reduce / gate-math
+    // phase to retire in (issued behind the publish, as the first version did, every step paid an HBM round trip in front of its gather):
+    //   * the saved-for-backward outputs of the PREVIOUS step (kept in registers for one step),
+    //   * the x-projections of the NEXT step.
     const bool more = s + 1 < T;
+    if (s > 0) store_outputs(so_t, so_g, so_aux, so_h, so_live);
+    if (more && pact) {
+      const float* pn = gx_row(dir == 0 ? s + 1 : T - 2 - s);
+#pragma unroll
+      for (int g = 0; g < G; ++g) pgx_next[g] = ldnt(pn + g * H);
+    }
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
       for (int g = 0; g < NS * G; ++g) red[s & 1][wave][i * NS * G + g][lane] = acc[i][g];
-    RNN_TRACE(s, 2);
+    PTRACE(2);                                          // HBM section + MFMAs issued, partial sums written
     __syncthreads();
-    RNN_TRACE(s, 3);
+    PTRACE(3);                                          // barrier passed
 
     // ---- gate math (identical to the step kernel's epilogue)
     float out_g[4] = {0.f, 0.f, 0.f, 0.f}, out_aux = 0.f, hnew = 0.f;
@@ -556,43 +756,25 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
     } else {
       pprev = 0.f;                                      // beyond the sample's length: state is zero (what the step kernels re-read)
     }
-    RNN_TRACE(s, 6);
-    // ---- publish h_s: wave-local assembly of this wave's 8 chunks, then ONE 16-byte sc1 store per publishing lane.
-    // Order per wave and step: [wait: my previous reset (and everything older) is acknowledged] publish(s) -> reset(s) -> HBM stores ->
-    // next step's HBM loads.  The wait costs nothing (everything outstanding was issued a whole step ago), and it is what makes "a
-    // consumer that has seen my chunk of h_s finds the sentinel, not my stale h_{s-3}, where it will poll for h_{s+1}" true.
-    // The reset of buffer (s+2) & 3 is safe here: this wave is past the step's barrier, so all 64 workgroups of the group have published
-    // h_{s-1}, i.e. have finished gathering h_{s-2}.
+    PTRACE(4);                                          // LDS sums + gate math
+    // ---- publish h_s: wave-local assembly of this wave's 8 chunks, then ONE 16-byte store per publishing lane, then the reset of the same
+    // chunks two buffers ahead.  "A consumer that has seen my chunk of h_s finds the sentinel, not my stale h_{s-3}, where it will poll for
+    // h_{s+1}" needs my reset of buffer (s+1) & 3 — issued at step s-1 — to be visible before this publish: this step's gather has waited
+    // for vmcnt(0) in between (at s = 0 the buffers still hold the launcher's fill).  The reset of buffer (s+2) & 3 is safe here: this wave
+    // is past the step's barrier, so every workgroup of the group has published h_{s-1}, i.e. has finished gathering h_{s-2}.
     stage[wave][lane] = (elem_t)hnew;                   // rows beyond B / units beyond H publish zeros: consumers wait for every chunk
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (pub_lane) {
-      store16_sc1(xbuf + (long long)(s & 3) * bufbytes + pub_off, *reinterpret_cast<const u32x4_*>(&stage[wave][(lane & 3) * 16 + (lane >> 2) * EPL]));
-      store16_sc1(xbuf + (long long)((s + 2) & 3) * bufbytes + pub_off, u32x4_{PSENT, PSENT, PSENT, PSENT});
+      store16_x(xbuf + (long long)(s & 3) * bufbytes + pub_off, *reinterpret_cast<const u32x4_*>(&stage[wave][(lane & 3) * 16 + (lane >> 2) * EPL]), l2_local);
+      store16_x(xbuf + (long long)((s + 2) & 3) * bufbytes + pub_off, u32x4_{PSENT, PSENT, PSENT, PSENT}, l2_local);
     }
-    RNN_TRACE(s, 7);
-    if (more && pact) {
-      const float* pn = gx_row(dir == 0 ? s + 1 : T - 2 - s);
+    PTRACE(5);                                          // publish issued
+    // the step's saved-for-backward outputs wait in registers for the next step's early HBM section
+    so_t = t; so_aux = out_aux; so_h = hnew; so_live = live;
 #pragma unroll
-      for (int g = 0; g < G; ++g) pgx_next[g] = ldnt(pn + g * H);
-    }
-    // ---- saved-for-backward outputs (after the publish: nothing on the exchange's critical path waits for HBM write acks)
-    if (pact) {
-      const long long rowH = (((long long)t * B + b) * 2 + dir) * H + j;
-      if (a.gates_bf) {
-        __builtin_nontemporal_store(bf16x4_{(__bf16)out_g[0], (__bf16)out_g[1], (__bf16)out_g[2], (__bf16)out_g[3]}, reinterpret_cast<bf16x4_*>(a.gates_bf) + rowH);
-        if (G == 4) a.aux[rowH] = out_aux;
-      } else {
-        float* gx = const_cast<float*>(gx_row(t));
-        stnt(&gx[0], out_g[0]); stnt(&gx[H], out_g[1]); stnt(&gx[2 * H], out_g[2]);
-        if (G == 4) { stnt(&gx[3 * H], out_g[3]); a.aux[rowH] = out_aux; }
-        else stnt(a.aux + rowH, live ? out_aux : 0.f);
-      }
-      a.hbuf[rowH] = hnew;
-    }
-    RNN_TRACE(s, 4);
-#pragma unroll
-    for (int g = 0; g < G; ++g) pgx[g] = pgx_next[g];
+    for (int g = 0; g < 4; ++g) so_g[g] = out_g[g];
   }
+  store_outputs(so_t, so_g, so_aux, so_h, so_live);      // the last step's outputs
+  PTRACE_DUMP(0);
 }
 
 // Gate-derivative math of one (row, unit) pair, shared by the step and the persistent backward kernels.  Contraction is switched OFF:
@@ -776,16 +958,16 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(const float* pk, 
 // (dh*z / dc*f) never leaves its thread.  Exchange protocol, buffers, starvation handling: see rnn_fwd_persistent_kernel.
 // ------------------------------------------------------------------------------------------
 template <int G, int MB, int NS, int NCW, bool BF>
-__global__ __launch_bounds__(NW * 64) void rnn_bwd_persistent_kernel(RnnArgs a, char* xbuf, int spin_limit) {
+__global__ __launch_bounds__(NW * 64) void rnn_bwd_persistent_kernel(RnnArgs a, char* xbuf, unsigned* census, int spin_limit) {
   static_assert(MB * NS * 256 <= NW * 64, "one (row, unit) pair per thread");
   __shared__ __attribute__((aligned(16))) f32x4 red[2][NW][MB * NS][64];      // double-buffered: one workgroup barrier per time step
   constexpr int KC = kchunk<BF>(), EPL = KC / 4, NPUB = 64 / EPL;             // units per chunk / per 16-byte lane vector; chunks per wave and gate
   using elem_t = typename std::conditional<BF, __bf16, float>::type;
   __shared__ __attribute__((aligned(16))) elem_t stage[NW][G][64];             // wave-private: NPUB complete 16-byte chunks per gate
-  const bool group_major = gridDim.z == 1;                                    // grid = (direction x batch tile, slice) | (slice, tile, direction): see the forward kernel
-  const int nbt_ = gridDim.x >> 1;
-  const int dir = group_major ? blockIdx.x / nbt_ : blockIdx.z, bt = group_major ? blockIdx.x % nbt_ : blockIdx.y;
-  const int slice = group_major ? blockIdx.y : blockIdx.x;
+  const PRole role = persist_role(a, census, spin_limit, 2);                  // 1-D grid; roles from the XCD census or the workgroup id
+  if (!role.active) return;
+  const int dir = role.dir, bt = role.bt, slice = role.slice;
+  const bool l2_local = role.local != 0;
   const int T = a.T, B = a.B, H = a.H, lddy = a.lddy;
   const int nsl = (H + 15) >> 4, nchb = (G * H + KC - 1) / KC;
   const int j0 = slice * (16 * NS), b0 = bt * (16 * MB);
@@ -818,15 +1000,16 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_persistent_kernel(RnnArgs a, 
   float dcar = 0.f;                                                           // GRU dh*z / LSTM dc*f of the step before (own pair)
 
   // operands of the gate-derivative math for one time step: independent of the recurrence, so they are fetched one step ahead
-  struct Ops { float g0, g1, g2, g3, ax, dy, prev; };
+  // (the packed record stays RAW until the step that uses it: converting it here would make the compiler wait for the load on the spot,
+  //  i.e. put an HBM round trip into every time step — it did, 0.6 us of the first version's 3.6)
+  struct Ops { bf16x4_ rec; float g0, g1, g2, g3, ax, dy, prev; };
   auto fetch = [&](int step) {
-    Ops o{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    Ops o{bf16x4_{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f}, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (!pact) return o;
     const int t = dir == 0 ? T - 1 - step : step;
     const long long rowH = (((long long)t * B + b) * 2 + dir) * H + j;
     if (gates_bf) {                                       // packed 8-byte record (bf16 training path)
-      const bf16x4_ rec = __builtin_nontemporal_load(reinterpret_cast<const bf16x4_*>(gates_bf) + rowH);
-      o.g0 = (float)rec[0]; o.g1 = (float)rec[1]; o.g2 = (float)rec[2]; o.g3 = (float)rec[3];
+      o.rec = __builtin_nontemporal_load(reinterpret_cast<const bf16x4_*>(gates_bf) + rowH);
       if (G == 4) o.ax = ldnt(a.aux + rowH);
     } else {                                              // plain buffers: gates in gx (overwritten with dGx at this row's own step), hn / c in aux
       const float* gp = a.gx + (((long long)t * B + b) * 2 + dir) * G * H + j;
@@ -854,8 +1037,40 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_persistent_kernel(RnnArgs a, 
     pub_off = dirbase + ((((long long)(bt * MB + wsub / NS) * nchb + ku / KC) * 64) + ((ku % KC) / EPL) * 16 + (wave & 3) * 4 + (pp & 3)) * 16;
   }
 
+  // results of one time step (written one step late, see the loop)
+  int so_t = 0;
+  float so_dgx[G], so_dax = 0.f;
+#pragma unroll
+  for (int g = 0; g < G; ++g) so_dgx[g] = 0.f;
+  auto store_results = [&](int t, const float (&dgx)[G], float dax) {
+    if (!pact) return;
+    const long long row = ((long long)t * B + b) * 2 + dir;
+    if (a.dgx_bf) {
+      __bf16* gb = a.dgx_bf + row * G * H + j;
+#pragma unroll
+      for (int g = 0; g < G; ++g) __builtin_nontemporal_store((__bf16)dgx[g], gb + g * H);
+    } else {
+      float* gp = a.gx + row * G * H + j;                  // in place: the gates of this row were consumed (fetched two steps ago)
+#pragma unroll
+      for (int g = 0; g < G; ++g) stnt(gp + g * H, dgx[g]);
+    }
+    if (G == 3) stnt(a.aux + row * H + j, dax);
+  };
+
+  unsigned goff[NCW * MB], pend0 = 0;                       // this wave's chunks of the packed exchange buffer, and the all-pending mask
+#pragma unroll
+  for (int k = 0; k < NCW; ++k)
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+      goff[k * MB + i] = (unsigned)(((((long long)(bt * MB + i) * nchb + (wave + NW * k)) * 64) + lane) * 16);
+      if (cval[k]) pend0 |= 1u << (k * MB + i);
+    }
+
+  PTRACE_DECL;
+  vm_drained();                                         // prologue loads have landed
   for (int s = 0; s < T; ++s) {
     const int t = dir == 0 ? T - 1 - s : s;
+    PTRACE(0);
     f32x4 acc[MB][NS];
 #pragma unroll
     for (int i = 0; i < MB; ++i)
@@ -863,43 +1078,29 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_persistent_kernel(RnnArgs a, 
       for (int n = 0; n < NS; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (s > 0) {
       const char* xin = xbuf + (long long)((s - 1) & 3) * bufbytes + dirbase;
-      u32x4_ av[NCW][MB];
+      u32x4_ av[NCW * MB];
 #pragma unroll
-      for (int k = 0; k < NCW; ++k)
-#pragma unroll
-        for (int i = 0; i < MB; ++i) av[k][i] = u32x4_{0u, 0u, 0u, 0u};
+      for (int k = 0; k < NCW * MB; ++k) av[k] = u32x4_{0u, 0u, 0u, 0u};
       int spins = 0;
-      unsigned pend = 0;                                  // wave-uniform: chunks of this wave that have not been seen complete yet
-#pragma unroll
-      for (int k = 0; k < NCW; ++k)
-        if (cval[k]) pend |= ((1u << MB) - 1u) << (k * MB);
+      unsigned pend = pend0;                              // wave-uniform: chunks of this wave that have not been seen complete yet
       while (pend) {
-        // only the chunks that are still missing are read again: a blanket re-read of the whole operand by every waiting wave competes
-        // with the very stores it is waiting for
-#pragma unroll
-        for (int k = 0; k < NCW; ++k)
-#pragma unroll
-          for (int i = 0; i < MB; ++i)
-            if (pend & (1u << (k * MB + i))) av[k][i] = load16_sc1(xin + ((((long long)(bt * MB + i) * nchb + (wave + NW * k)) * 64) + lane) * 16);
-#pragma unroll
-        for (int k = 0; k < NCW; ++k)
-#pragma unroll
-          for (int i = 0; i < MB; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(av[k][i])::"memory");
+        // only the chunks that are still missing are read again (one asm statement per pass: poll_pass)
+        poll_pass<NCW * MB>(av, goff, xin, pend);
 #pragma unroll
         for (int k = 0; k < NCW; ++k)
 #pragma unroll
           for (int i = 0; i < MB; ++i)
             if (pend & (1u << (k * MB + i))) {
-              const bool ok = !lval[k] || (av[k][i].x != PSENT && av[k][i].y != PSENT && av[k][i].z != PSENT && av[k][i].w != PSENT);
+              const u32x4_ c = av[k * MB + i];
+              const bool ok = !lval[k] || (c.x != PSENT && c.y != PSENT && c.z != PSENT && c.w != PSENT);
               if (__ballot(ok) == ~0ull) pend &= ~(1u << (k * MB + i));
             }
         pend = __builtin_amdgcn_readfirstlane(pend);
         if (pend && ++spins > spin_limit) {
-          // record who starved and on what (first failure only); the host raises at the step's sync point (no __builtin_trap: hipcc sinks
-          // a trap to the kernel's common exit block, where it then fires on NORMAL completion too)
+          // record who starved and on what (first failure only); the host raises at the step's sync point
           if (lane == 0 && atomicCAS(&g_persist_dbg[0], 0, 2) == 0) {
             g_persist_dbg[1] = slice; g_persist_dbg[2] = bt; g_persist_dbg[3] = dir; g_persist_dbg[4] = s; g_persist_dbg[5] = wave;
-            g_persist_dbg[6] = (int)pend; g_persist_dbg[7] = 0;
+            g_persist_dbg[6] = (int)pend; g_persist_dbg[7] = l2_local;
             __threadfence_system();
           }
           return;
@@ -909,7 +1110,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_persistent_kernel(RnnArgs a, 
       for (int k = 0; k < NCW; ++k)
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
-          const u32x4_ v = lval[k] ? av[k][i] : u32x4_{0u, 0u, 0u, 0u};
+          const u32x4_ v = lval[k] ? av[k * MB + i] : u32x4_{0u, 0u, 0u, 0u};
           if constexpr (BF) {
 #pragma unroll
             for (int n = 0; n < NS; ++n)
@@ -923,12 +1124,22 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_persistent_kernel(RnnArgs a, 
           }
         }
     }
+    vm_drained();                                       // (the gather has waited for everything; tell the compiler)
+    PTRACE(1);
+    if (s > 0) cur = nxt;                               // operands of THIS step: fetched one step ago, landed
+    if (gates_bf) { cur.g0 = (float)cur.rec[0]; cur.g1 = (float)cur.rec[1]; cur.g2 = (float)cur.rec[2]; cur.g3 = (float)cur.rec[3]; }
+    // ---- HBM traffic of the step goes out HERE, right behind the gather (see the forward kernel): the previous step's results, and the
+    // operands of the next step's gate-derivative math
     const bool more = s + 1 < T;
+    if (s > 0) store_results(so_t, so_dgx, so_dax);
+    if (more) nxt = fetch(s + 1);
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
       for (int n = 0; n < NS; ++n) red[s & 1][wave][i * NS + n][lane] = acc[i][n];
+    PTRACE(2);
     __syncthreads();
+    PTRACE(3);
 
     float dgh[G], dgx[G], dax = 0.f;
 #pragma unroll
@@ -954,30 +1165,22 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_persistent_kernel(RnnArgs a, 
     } else {
       dcar = 0.f;
     }
-    // ---- publish dGh_s (see the forward kernel): wave-local assembly, wait for my previous reset, publish, reset two steps ahead
+    PTRACE(4);
+    // ---- publish dGh_s (see the forward kernel): wave-local assembly, publish, reset two steps ahead (the previous reset was acknowledged
+    // inside this step's gather)
 #pragma unroll
     for (int g = 0; g < G; ++g) stage[wave][g][lane] = (elem_t)dgh[g];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (pub_lane) {
-      store16_sc1(xbuf + (long long)(s & 3) * bufbytes + pub_off, *reinterpret_cast<const u32x4_*>(&stage[wave][pg][(pp & 3) * 16 + (pp >> 2) * EPL]));
-      store16_sc1(xbuf + (long long)((s + 2) & 3) * bufbytes + pub_off, u32x4_{PSENT, PSENT, PSENT, PSENT});
+      store16_x(xbuf + (long long)(s & 3) * bufbytes + pub_off, *reinterpret_cast<const u32x4_*>(&stage[wave][pg][(pp & 3) * 16 + (pp >> 2) * EPL]), l2_local);
+      store16_x(xbuf + (long long)((s + 2) & 3) * bufbytes + pub_off, u32x4_{PSENT, PSENT, PSENT, PSENT}, l2_local);
     }
-    if (more) nxt = fetch(s + 1);
-    if (pact) {
-      const long long row = ((long long)t * B + b) * 2 + dir;
-      if (a.dgx_bf) {
-        __bf16* gb = a.dgx_bf + row * G * H + j;
+    PTRACE(5);
+    so_t = t; so_dax = dax;
 #pragma unroll
-        for (int g = 0; g < G; ++g) __builtin_nontemporal_store((__bf16)dgx[g], gb + g * H);
-      } else {
-        float* gp = a.gx + row * G * H + j;                // in place: the gates of this row were consumed (fetched one step ago)
-#pragma unroll
-        for (int g = 0; g < G; ++g) stnt(gp + g * H, dgx[g]);
-      }
-      if (G == 3) stnt(a.aux + row * H + j, dax);
-    }
-    cur = nxt;
+    for (int g = 0; g < G; ++g) so_dgx[g] = dgx[g];
   }
+  store_results(so_t, so_dgx, so_dax);                      // the last step's results
+  PTRACE_DUMP(1);
 }
 
 // W_hh (2, G*H, H) -> fwd-packed [2][nsl][G][nch][64 lanes][16 B] and bwd-packed [2][nsl][nchb][64 lanes][16 B]
@@ -1049,6 +1252,16 @@ int cu_count() {
   return n;
 }
 
+// XCD-local exchange (persist_role's census mode): possible when every exchange group (gs workgroups) fits one XCD and the groups fit the
+// chip, on the 8 x 32-CU part this library is written for.  DS2_RNN_XCD_LOCAL=0 keeps the placement-independent sc1 protocol (A/B runs).
+constexpr int XCDS = 8, CUS_PER_XCD = 32;
+bool xcd_local_fits(int gs, int ngroups) {
+  static const char* env = getenv("DS2_RNN_XCD_LOCAL");
+  if (env && env[0] == '0') return false;
+  return cu_count() == XCDS * CUS_PER_XCD && gs >= 1 && gs <= CUS_PER_XCD && ngroups <= XCDS * (CUS_PER_XCD / gs);
+}
+constexpr size_t CENSUS_BYTES = 64;                       // 8 per-XCD slot counters, the arrival counter, one "unexpected XCC id" flag
+
 // Forward recurrence in one persistent launch (bf16 operands).  Returns 1 if launched, 0 if the shape / device does not qualify
 // (the caller then runs the step kernels), < 0 on error.
 template <int G, bool BF>
@@ -1068,7 +1281,11 @@ int try_launch_persistent_fwd(RnnArgs a, hipStream_t st) {
   // 4 VGPRs) and the alternative would be a 32-row tile; else the step kernels' 16|32 rows x 16 units (with 16-row tiles the gather
   // is the same size either way and twice as many, half as big workgroups measured slightly faster).
   int mb = 1, ns = 2;
-  if (pick_mb(a.B, a.H) != 2 || (nsl % 2) != 0 || ncw * (2 * G + 1) * 4 > 176 || (long long)(nsl / 2) * ceil_div(a.B, 16) * 2 > cu_count()) {
+  const bool ns2_ok = (nsl % 2) == 0 && ncw * (2 * G + 1) * 4 <= 176 && (long long)(nsl / 2) * ceil_div(a.B, 16) * 2 <= cu_count();
+  // ... and 16 x 32 also where 16 x 16 would be chosen but only the wider slice lets an exchange group fit one XCD (L2-local exchange;
+  // bf16 only: in fp32 the doubled MFMA instruction count per workgroup costs more than the exchange saves, c2 5.4 -> 6.1 us per step)
+  const bool ns2_for_local = BF && ns2_ok && !xcd_local_fits(nsl, ceil_div(a.B, 16 * pick_mb(a.B, a.H)) * 2) && xcd_local_fits(nsl / 2, ceil_div(a.B, 16) * 2);
+  if (!ns2_ok || (pick_mb(a.B, a.H) != 2 && !ns2_for_local)) {
     ns = 1;
     mb = pick_mb(a.B, a.H);
     if (ncw * (G + mb) * 4 > 176) return 0;
@@ -1078,16 +1295,20 @@ int try_launch_persistent_fwd(RnnArgs a, hipStream_t st) {
   if ((long long)(nsl / ns) * nbt * 2 > cu_count()) return 0;
   a.nsl = nsl;
   a.nbt16 = ceil_div(a.B, 32) * 2;
+  a.p_nbt = nbt; a.p_gs = nsl / ns; a.p_cux = CUS_PER_XCD;
+  a.p_census = xcd_local_fits(a.p_gs, 2 * nbt) ? 1 : 0;
   char* xbuf = reinterpret_cast<char*>(a.pk);
-  DS2_HIP(hipMemsetAsync(xbuf, 0xff, 4 * fwd_xbuf_bytes(a.B, a.H, BF ? 1 : 0), st));      // every 16-byte chunk = the "not yet published" sentinel
-  dim3 grid(nsl / ns, nbt, 2), block(NW * 64);
-  if (nbt * 2 == 8) grid = dim3(8, nsl / ns, 1);                  // 8 groups: one per XCD (group-major grid)
+  const size_t xbytes = 4 * fwd_xbuf_bytes(a.B, a.H, BF ? 1 : 0);
+  DS2_HIP(hipMemsetAsync(xbuf, 0xff, xbytes + CENSUS_BYTES, st));      // every 16-byte chunk = the "not yet published" sentinel; census words = -1
+  unsigned* census = reinterpret_cast<unsigned*>(xbuf + xbytes);
+  // 1-D grid.  Census mode: one workgroup per CU of the whole chip, roles by real XCD id (surplus workgroups exit); else exactly the workgroups needed
+  dim3 grid(a.p_census ? cu_count() : a.p_gs * nbt * 2), block(NW * 64);
   static const char* sl = getenv("DS2_RNN_SPIN_LIMIT");
   const int spin_limit = sl ? atoi(sl) : (1 << 20);              // ~1 s of polling: a missing workgroup is reported instead of hanging the queue
 #define DS2_PLAUNCH(MB_, NS_, NCW_)                                                                                                   \
   do {                                                                                                                                \
     if constexpr (NCW_ * (NS_ * G + MB_) * 4 <= 176)                                                                                  \
-      hipLaunchKernelGGL((rnn_fwd_persistent_kernel<G, MB_, NS_, NCW_, BF>), grid, block, 0, st, a, xbuf, spin_limit);                 \
+      hipLaunchKernelGGL((rnn_fwd_persistent_kernel<G, MB_, NS_, NCW_, BF>), grid, block, 0, st, a, xbuf, census, spin_limit);                 \
     else                                                                                                                              \
       return 0;                                                                                                                       \
   } while (0)
@@ -1122,26 +1343,33 @@ int try_launch_persistent_bwd(RnnArgs a, hipStream_t st) {
   if ((a.H % 16) != 0 || a.T < 2) return 0;
   int mb = pick_mb(a.B, a.H);
   const int nsl = a.H / 16;
-  const int ns = (mb == 2 && (nsl % 2) == 0) ? 2 : 1;                 // same tile choice as the step kernels
-  if (ns == 2) mb = 1;
-  const int nbt = ceil_div(a.B, 16 * mb);
   const int nchb = ceil_div(G * a.H, kchunk<BF>());
   const int q = BF ? 3 : 6;                                           // instantiated chunks per wave: bf16 3, 6, 9, 12 ; fp32 6, 12, 18
   const int ncw = ceil_div(ceil_div(nchb, NW), q) * q;
+  int ns = (mb == 2 && (nsl % 2) == 0) ? 2 : 1;                       // same tile choice as the step kernels ...
+  // ... and 16 rows x 32 units also where that is what lets an exchange group fit one XCD (L2-local exchange)
+  if (BF && ns == 1 && mb == 1 && (nsl % 2) == 0 && ncw * (2 + 1) * 4 <= 192 && !xcd_local_fits(nsl, ceil_div(a.B, 16) * 2) &&
+      xcd_local_fits(nsl / 2, ceil_div(a.B, 16) * 2))
+    ns = 2;
+  if (ns == 2) mb = 1;
+  const int nbt = ceil_div(a.B, 16 * mb);
   if (ncw > (BF ? 12 : 18) || ncw * (ns + mb) * 4 > 192) return 0;    // W_hh^T fragments + operand lane vectors must fit the registers
   if ((long long)(nsl / ns) * nbt * 2 > cu_count()) return 0;
   a.nsl = nsl;
   a.nbt16 = ceil_div(a.B, 32) * 2;
+  a.p_nbt = nbt; a.p_gs = nsl / ns; a.p_cux = CUS_PER_XCD;
+  a.p_census = xcd_local_fits(a.p_gs, 2 * nbt) ? 1 : 0;
   char* xbuf = reinterpret_cast<char*>(a.pk);
-  DS2_HIP(hipMemsetAsync(xbuf, 0xff, 4 * bwd_xbuf_bytes(G, a.B, a.H, BF ? 1 : 0), st));
-  dim3 grid(nsl / ns, nbt, 2), block(NW * 64);
-  if (nbt * 2 == 8) grid = dim3(8, nsl / ns, 1);                      // 8 groups: one per XCD (group-major grid)
+  const size_t xbytes = 4 * bwd_xbuf_bytes(G, a.B, a.H, BF ? 1 : 0);
+  DS2_HIP(hipMemsetAsync(xbuf, 0xff, xbytes + CENSUS_BYTES, st));
+  unsigned* census = reinterpret_cast<unsigned*>(xbuf + xbytes);
+  dim3 grid(a.p_census ? cu_count() : a.p_gs * nbt * 2), block(NW * 64);   // see the forward launcher
   static const char* sl = getenv("DS2_RNN_SPIN_LIMIT");
   const int spin_limit = sl ? atoi(sl) : (1 << 20);
 #define DS2_PB(MB_, NS_, NCW_)                                                                                                      \
   do {                                                                                                                              \
     if constexpr (NCW_ * (NS_ + MB_) * 4 <= 192)                                                                                    \
-      hipLaunchKernelGGL((rnn_bwd_persistent_kernel<G, MB_, NS_, NCW_, BF>), grid, block, 0, st, a, xbuf, spin_limit);               \
+      hipLaunchKernelGGL((rnn_bwd_persistent_kernel<G, MB_, NS_, NCW_, BF>), grid, block, 0, st, a, xbuf, census, spin_limit);               \
     else                                                                                                                            \
       return 0;                                                                                                                     \
   } while (0)
@@ -1249,7 +1477,7 @@ extern "C" int ds2_rnn_persistent_status(int* out8) {
 
 extern "C" size_t ds2_rnn_fwd_workspace_bytes(int B, int H, int bf16) {
   const size_t step = pk_floats(B, H, H, bf16) * sizeof(float);                 // two ping-pong buffers of the step kernels
-  const size_t pers = 4 * fwd_xbuf_bytes(B, H, bf16);                            // four round-robin buffers of the persistent kernel
+  const size_t pers = 4 * fwd_xbuf_bytes(B, H, bf16) + 64;                       // four round-robin buffers of the persistent kernel + its census words
   return step > pers ? step : pers;
 }
 
@@ -1283,7 +1511,7 @@ extern "C" int ds2_rnn_fwd(int gates, float* gx, const void* wp_fwd, const float
 
 extern "C" size_t ds2_rnn_bwd_workspace_bytes(int gates, int B, int H, int bf16) {
   const size_t step = pk_floats(B, H, gates * H, bf16) * sizeof(float);          // two ping-pong buffers of the step kernels
-  const size_t pers = 4 * bwd_xbuf_bytes(gates, B, H, bf16);                      // four round-robin buffers of the persistent kernel
+  const size_t pers = 4 * bwd_xbuf_bytes(gates, B, H, bf16) + 64;                 // four round-robin buffers of the persistent kernel + its census words
   return (size_t)4 * B * H * sizeof(float) + (step > pers ? step : pers);
 }
 

@@ -8,3 +8,5 @@ mkdir -p build
 /opt/rocm/lib/llvm/bin/clang-offload-bundler --unbundle --type=o --input=build/probe_l2_kernel.bundle --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --output=build/probe_l2_kernel.hsaco
 /opt/rocm/bin/hipcc -O2 -std=c++17 probe_l2_residency.cpp -o build/probe_l2_residency -L/opt/rocm/lib -lhsa-runtime64
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 probe_xcd_exchange.hip -o build/probe_xcd_exchange
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 probe_xcd_local.hip -o build/probe_xcd_local
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../include -I../asr_amd/csrc -DDS2_RNN_TRACE -mllvm -amdgpu-kernarg-preload-count=9 -x hip probe_persist_timeline.hip ../asr_amd/csrc/api.cpp -o build/probe_persist_timeline
