@@ -1,5 +1,6 @@
 """Data-side API surface kept by name: SpectrogramDataset, BucketingSampler,
-DistributedBucketingSampler, AudioDataLoader, get_loader.  Host-side / I-O bound; not accelerated.
+DistributedBucketingSampler, AudioDataLoader, get_loader; plus the true length-bucketing samplers of SURVEY §8(f)4
+(LengthBucketingSampler, DistributedLengthBucketingSampler).  Host-side / I-O bound; not accelerated.
 
 `SpectrogramDataset` reads the reference's manifest CSV (`audio_filepath`, `text`).  Audio decoding:
 pre-computed spectrograms (`.npy` / `.pt`, shape (161, T)) are loaded as-is; `.wav` files go through a
@@ -69,6 +70,15 @@ class SpectrogramDataset(Dataset):
         self.labels_map = labels
         self.audio_conf, self.normalize, self.caching = audio_conf, normalize, caching
         self._cache = {}
+        # spectrogram_parser.py:29-44 / :64-80: noise injection, tempo/gain perturbation and SpecAugment are host-side augmentations of
+        # the reference's parser that this loader does not implement — say so instead of training silently without them
+        unsupported = [k for k, on in (("noise_dir", getattr(audio_conf, "noise_dir", None) is not None),
+                                       ("speed_volume_perturb", bool(getattr(audio_conf, "speed_volume_perturb", False))),
+                                       ("spec_augment", bool(spec_augment))) if on]
+        if unsupported:
+            import warnings
+            warnings.warn("asr_amd.data.SpectrogramDataset: augmentation(s) requested by audio_conf but not implemented here, ignored: "
+                          + ", ".join(unsupported))
 
     def parse_audio(self, path):
         if path.endswith(".npy"):
@@ -79,7 +89,10 @@ class SpectrogramDataset(Dataset):
             from scipy.io import wavfile
             sr, y = wavfile.read(path)
             if y.dtype.kind == "i":
-                y = y.astype(np.float32) / float(np.iinfo(y.dtype).max)
+                # soundfile (audio/functional.py:11) scales integer PCM by 2^(bits-1): int16 / 32768
+                y = y.astype(np.float32) / float(2 ** (8 * y.dtype.itemsize - 1))
+            elif y.dtype.kind == "u":
+                y = (y.astype(np.float32) - 128.0) / 128.0      # 8-bit WAV is unsigned
             if y.ndim > 1:
                 y = y.mean(axis=1)
             assert sr == self.audio_conf.sample_rate, f"expected {self.audio_conf.sample_rate} Hz audio"
@@ -161,6 +174,102 @@ class DistributedBucketingSampler(Sampler):
         self.bins = [self.bins[i] for i in order]
 
 
+def _durations_of(data_source, durations=None):
+    """Per-item lengths for bucketing: explicit sequence, else the manifest's `duration` column (etl/jsut_dataset.py:36-42,
+    etl/librispeech_dataset.py:100-103 write it), else the text length as a proxy."""
+    if durations is not None:
+        d = np.asarray(list(durations), dtype=np.float64)
+    else:
+        df = getattr(data_source, "df", None)
+        if df is not None and "duration" in df.columns:
+            d = df["duration"].to_numpy(dtype=np.float64)
+        elif df is not None and "text_size" in df.columns:
+            d = df["text_size"].to_numpy(dtype=np.float64)
+        else:
+            raise ValueError("length bucketing needs per-item durations: pass `durations=` or a manifest with a `duration` column")
+    if len(d) != len(data_source):
+        raise ValueError(f"{len(d)} durations for {len(data_source)} items")
+    return d
+
+
+class LengthBucketingSampler(Sampler):
+    """True length bucketing (BASELINE configs[3] "bucketed sampler" / configs[4] "length-sorted batching").
+
+    The reference's BucketingSampler (data/samplers/bucketing_sampler.py:5-25) only ASSUMES a manifest "in order of size" (its ETL merely
+    bounds the lengths, etl/__main__.py:48); this one establishes the order: items are sorted by duration (stable, ties by manifest
+    index), consecutive runs of `batch_size` form the bins, and the interface is the reference's — `__iter__` yields one bin per batch
+    (ids shuffled inside the bin like the reference; `_collate_fn` re-sorts a batch by length anyway), `__len__` = number of bins,
+    `shuffle()` permutes the bin ORDER (batches stay homogeneous in length, epochs see them in a different order)."""
+
+    def __init__(self, data_source, batch_size=1, durations=None, descending=False):
+        super().__init__()
+        self.data_source = data_source
+        self.batch_size = int(batch_size)
+        self.durations = _durations_of(data_source, durations)
+        order = np.argsort(-self.durations if descending else self.durations, kind="stable").tolist()
+        self.bins = [order[i:i + self.batch_size] for i in range(0, len(order), self.batch_size)]
+
+    def __iter__(self):
+        for ids in self.bins:
+            np.random.shuffle(ids)
+            yield ids
+
+    def __len__(self):
+        return len(self.bins)
+
+    def shuffle(self, epoch=None):
+        if epoch is None:
+            np.random.shuffle(self.bins)                 # the reference's call (bucketing_sampler.py:24-25)
+        else:
+            g = torch.Generator()
+            g.manual_seed(int(epoch))
+            self.bins = [self.bins[i] for i in torch.randperm(len(self.bins), generator=g).tolist()]
+
+    def bin_spread(self):
+        """max - min duration inside each bin (what bucketing minimises; used by the tests and the bench)."""
+        return [float(self.durations[b].max() - self.durations[b].min()) for b in self.bins]
+
+
+class DistributedLengthBucketingSampler(Sampler):
+    """Length bucketing for one-process-per-GPU data parallelism: the partition rule is the reference's (rank r takes every
+    `num_replicas`-th bin starting at r, distributed_bucketing_sampler.py:22-34), applied to LENGTH-SORTED bins, and the epoch shuffle
+    moves whole ROUNDS (the `num_replicas` bins that the ranks process concurrently) instead of single bins — so at every step all ranks
+    hold batches that are neighbours in length, and the gradient all-reduce does not wait for a straggler with a much longer T
+    ("for C5 sort by length first so concurrent ranks get similar T").  The tail is padded to a whole round with the
+    bins just before it (nearest in length), where the reference wraps around to the first bins (which here would put the SHORTEST
+    batches next to the LONGEST ones in the last round)."""
+
+    def __init__(self, data_source, batch_size=1, num_replicas=None, rank=None, durations=None, descending=False):
+        super().__init__()
+        if num_replicas is None:
+            num_replicas = torch.distributed.get_world_size()
+        if rank is None:
+            rank = torch.distributed.get_rank()
+        self.data_source, self.batch_size = data_source, int(batch_size)
+        self.num_replicas, self.rank = int(num_replicas), int(rank)
+        self.durations = _durations_of(data_source, durations)
+        order = np.argsort(-self.durations if descending else self.durations, kind="stable").tolist()
+        bins = [order[i:i + self.batch_size] for i in range(0, len(order), self.batch_size)]
+        self.num_samples = int(math.ceil(len(bins) / self.num_replicas))
+        self.total_size = self.num_samples * self.num_replicas
+        pad = self.total_size - len(bins)
+        if pad:
+            src = bins[-(pad + 1):-1] if len(bins) > pad else (bins * (pad // max(len(bins), 1) + 1))[:pad]
+            bins = bins + [list(b) for b in src]
+        self.rounds = [bins[i:i + self.num_replicas] for i in range(0, self.total_size, self.num_replicas)]
+
+    def __iter__(self):
+        return iter([r[self.rank] for r in self.rounds])
+
+    def __len__(self):
+        return self.num_samples
+
+    def shuffle(self, epoch):
+        g = torch.Generator()
+        g.manual_seed(int(epoch))
+        self.rounds = [self.rounds[i] for i in torch.randperm(len(self.rounds), generator=g).tolist()]
+
+
 class AudioDataLoader(DataLoader):
     """data/loaders/audio_data_loader.py:7-13."""
 
@@ -169,11 +278,17 @@ class AudioDataLoader(DataLoader):
         self.collate_fn = _collate_fn
 
 
-def get_loader(audio_conf, labels, manifest, batch_size, num_workers, caching=False):
-    """data/loaders/functional.py:6-24."""
+def get_loader(audio_conf, labels, manifest, batch_size, num_workers, caching=False, length_bucketing=False):
+    """data/loaders/functional.py:6-24.  `length_bucketing=True` (not in the reference) sorts the manifest by its `duration` column
+    before binning (LengthBucketingSampler; the distributed variant when torch.distributed is initialised)."""
     dataset = SpectrogramDataset(audio_conf=audio_conf, manifest_filepath=manifest, labels=labels, normalize=True,
                                  spec_augment=getattr(audio_conf, "spec_augment", False), caching=caching)
-    sampler = BucketingSampler(dataset, batch_size=batch_size)
+    if length_bucketing and torch.distributed.is_available() and torch.distributed.is_initialized():
+        sampler = DistributedLengthBucketingSampler(dataset, batch_size=batch_size)
+        loader = AudioDataLoader(dataset, num_workers=num_workers, batch_sampler=sampler)
+        sampler.shuffle(0)
+        return loader, sampler
+    sampler = (LengthBucketingSampler if length_bucketing else BucketingSampler)(dataset, batch_size=batch_size)
     loader = AudioDataLoader(dataset, num_workers=num_workers, batch_sampler=sampler)
     sampler.shuffle()
     return loader, sampler

@@ -4,22 +4,31 @@ import warnings
 import torch
 
 
+def _gpu_or_cpu(warn: bool) -> torch.device:
+    if torch.cuda.is_available():
+        return torch.device("cuda")
+    if warn:
+        warnings.warn("CUDA device requested but no GPU is available; falling back to CPU.", UserWarning, stacklevel=3)
+    return torch.device("cpu")
+
+
+# spelling -> how to resolve it.  Same accepted spellings, warning and error text as the reference's resolver (its
+# tests/test_device.py pins them): "cuda"/"gpu" degrade to the CPU with a warning, "auto"/None pick the GPU when there is one.
+_DEVICE_SPECS = {
+    "cpu": lambda: torch.device("cpu"),
+    "cuda": lambda: _gpu_or_cpu(warn=True),
+    "gpu": lambda: _gpu_or_cpu(warn=True),
+    "auto": lambda: _gpu_or_cpu(warn=False),
+}
+
+
 def resolve_device(spec="auto") -> torch.device:
-    if spec is None:
-        spec = "auto"
     if isinstance(spec, torch.device):
         return spec
-    key = str(spec).lower()
-    if key == "cpu":
-        return torch.device("cpu")
-    if key in ("cuda", "gpu"):
-        if torch.cuda.is_available():
-            return torch.device("cuda")
-        warnings.warn("CUDA device requested but no GPU is available; falling back to CPU.", UserWarning, stacklevel=2)
-        return torch.device("cpu")
-    if key == "auto":
-        return torch.device("cuda" if torch.cuda.is_available() else "cpu")
-    raise ValueError(f"Unknown device spec: {spec!r}")
+    resolver = _DEVICE_SPECS.get("auto" if spec is None else str(spec).lower())
+    if resolver is None:
+        raise ValueError(f"Unknown device spec: {spec!r}")
+    return resolver()
 
 
 def make_grad_scaler(device, enabled: bool = True) -> "torch.amp.GradScaler":

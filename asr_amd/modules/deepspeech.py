@@ -46,6 +46,11 @@ class _DS2Function(torch.autograd.Function):
         # overwrite it: compute into a scratch buffer and let autograd add.
         accumulating = any(p.grad is not None for p in model.parameters())
         if accumulating:
+            if model._on_bucket is not None:
+                # the data-parallel reducer all-reduces the flat gradient buffer bucket by bucket as backward fills it; gradients that
+                # autograd adds up outside that buffer would silently stay un-reduced
+                raise RuntimeError("asr_amd.DeepSpeech: gradient accumulation (p.grad still set when backward runs) is not supported "
+                                   "under data parallelism; call optimizer.zero_grad() (set_to_none=True) before every backward")
             keep, flat.flat_grad = flat.flat_grad, torch.empty_like(flat.flat_grad)
         try:
             Gr = flat.tensors(model, grads=True)
@@ -179,6 +184,11 @@ class DeepSpeech(nn.Module):
         else:
             W = self._flat.tensors(self)
             logits, _ = engine.forward(W, self._cfg, x, lens_dev, training=self.training, save=False)
+            if not self.training:
+                # inference has no later sync point of its own that checks this (the trainer's fit/step do): a persistent recurrence
+                # launch that could not get all of its workgroups resident leaves invalid activations — raise, never return them
+                # (fp32 shapes take the persistent kernels too)
+                ops.rnn_persistent_check()
         out = logits.transpose(0, 1)            # (B,T,C) view, like the reference's x.transpose(0, 1)
         out = self.inference_softmax(out)       # identity in train, HIP softmax in eval
         return out, output_lengths
@@ -216,9 +226,7 @@ class DeepSpeech(nn.Module):
                     split_targets.append(targets[offset:offset + size])
                     offset += size
                 out, output_sizes = self.forward(inputs, input_sizes)
-                decoded_output, _ = decoder.decode(out, output_sizes)
-                if self.precision == "bf16":
-                    ops.rnn_persistent_check()          # decode has synchronised the device: a starved persistent recurrence raises here
+                decoded_output, _ = decoder.decode(out, output_sizes)   # (forward has already checked the persistent recurrences)
                 target_strings = decoder.convert_to_strings(split_targets)
                 if output_file is not None:
                     output_data.append((out.detach().cpu().numpy(), output_sizes.numpy(), target_strings))

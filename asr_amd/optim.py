@@ -1,6 +1,11 @@
-"""FusedAdamW: torch.optim.AdamW semantics (trainers/__main__.py:41-47) as ONE HIP launch over the
+"""FusedAdamW: torch.optim.AdamW semantics (trainers/__main__.py:41-47) as HIP launches over the
 model's flat parameter buffer (asr_amd/params.py), reading gradients from the flat gradient buffer the
-backward kernels write.  `zero_grad()` is a no-op: the backward schedule overwrites, never accumulates."""
+backward kernels write.
+
+Like torch.optim.AdamW it leaves parameters without a gradient alone: a parameter with
+`requires_grad=False` (DeepSpeech.finetune_from freezes all but the last tensors, deepspeech.py:124-128)
+is neither decayed nor updated — the launch covers the contiguous spans of trainable parameters only
+(normally one span: the whole buffer)."""
 from __future__ import annotations
 
 import torch
@@ -17,12 +22,43 @@ class FusedAdamW:
 
     def _ensure_state(self):
         flat, _ = self.model.flat_parameters()
-        if self.state["exp_avg"] is None or self.state["exp_avg"].shape != flat.shape or self.state["exp_avg"].device != flat.device:
-            self.state["exp_avg"] = torch.zeros_like(flat)
-            self.state["exp_avg_sq"] = torch.zeros_like(flat)
+        for k in ("exp_avg", "exp_avg_sq"):
+            m = self.state[k]
+            if m is None or m.shape != flat.shape:
+                self.state[k] = torch.zeros_like(flat)        # first step, or a different model
+            elif m.device != flat.device or m.dtype != flat.dtype:
+                self.state[k] = m.to(device=flat.device, dtype=flat.dtype)   # restored from a checkpoint (map_location="cpu"): keep the moments
 
     def zero_grad(self, set_to_none: bool = True):
-        return None
+        """The fused schedule overwrites the flat gradient buffer, so there is nothing to clear for `step()`;
+        on the autograd path (`fit` -> `loss.backward()`) the parameters' `.grad` views must go, or the next
+        backward would ACCUMULATE into them (asr_amd/modules/deepspeech.py:_DS2Function.backward)."""
+        for p in self.model.parameters():
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+
+    def _trainable_spans(self):
+        """Contiguous [start, end) element ranges of the flat buffer that hold parameters with requires_grad."""
+        fp = self.model._flat
+        named = dict(self.model.named_parameters())
+        key = tuple(bool(named[n].requires_grad) for n in fp.order)
+        if getattr(self, "_span_key", None) != key:
+            spans, cur = [], None
+            for n, on in zip(fp.order, key):
+                o, sz = fp.offsets[n]
+                end = o + (sz + 3) // 4 * 4                    # params.ALIGN padding belongs to the tensor in front of it
+                if on:
+                    if cur is not None and cur[1] == o:
+                        cur[1] = end
+                    else:
+                        cur = [o, end]
+                        spans.append(cur)
+                else:
+                    cur = None
+            self._span_key, self._spans = key, [(a, min(b, fp.total)) for a, b in spans]
+        return self._spans
 
     @torch.no_grad()
     def step(self):
@@ -30,12 +66,27 @@ class FusedAdamW:
         flat, grad = self.model.flat_parameters()
         g = self.param_groups[0]
         self.state["step"] += 1
-        ops.adamw(flat, grad, self.state["exp_avg"], self.state["exp_avg_sq"], self.state["step"], g["lr"], g["betas"], g["eps"],
-                  g["weight_decay"], self.grad_scale)
+        for a, b in self._trainable_spans():
+            ops.adamw(flat[a:b], grad[a:b], self.state["exp_avg"][a:b], self.state["exp_avg_sq"][a:b], self.state["step"], g["lr"], g["betas"],
+                      g["eps"], g["weight_decay"], self.grad_scale)
 
     def state_dict(self):
         return {"state": {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.state.items()}, "param_groups": self.param_groups}
 
     def load_state_dict(self, sd):
-        self.param_groups = sd["param_groups"]
-        self.state = dict(sd["state"])
+        """Accepts what `state_dict()` wrote.  Anything else — e.g. a torch.optim.AdamW checkpoint written by the reference trainer
+        ({'state': {index: {...}}, 'param_groups': [...]}) — raises ValueError, which the trainer reports as "optimizer state not
+        restored" instead of failing at the first step."""
+        st = sd.get("state") if isinstance(sd, dict) else None
+        if not isinstance(st, dict) or set(st.keys()) != {"step", "exp_avg", "exp_avg_sq"}:
+            raise ValueError("not a FusedAdamW state_dict (expected state keys step / exp_avg / exp_avg_sq)")
+        m, v = st["exp_avg"], st["exp_avg_sq"]
+        if (m is None) != (v is None) or (m is not None and (not torch.is_tensor(m) or not torch.is_tensor(v) or m.shape != v.shape or m.dim() != 1)):
+            raise ValueError("FusedAdamW state_dict: exp_avg / exp_avg_sq must both be None or flat tensors of one shape")
+        if not isinstance(sd.get("param_groups"), (list, tuple)) or len(sd["param_groups"]) != 1:
+            raise ValueError("FusedAdamW state_dict: expected exactly one param group")
+        missing = {"lr", "betas", "eps", "weight_decay"} - set(sd["param_groups"][0])
+        if missing:
+            raise ValueError(f"FusedAdamW state_dict: param group lacks {sorted(missing)}")
+        self.param_groups = [dict(sd["param_groups"][0])]
+        self.state = {"step": int(st["step"]), "exp_avg": m, "exp_avg_sq": v}

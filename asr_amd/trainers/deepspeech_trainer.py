@@ -86,6 +86,7 @@ class DeepSpeechTrainer:
     def train(self, train_loader):
         self._model.train()
         self._model.to(self._device)
+        self.optimizer_to(self._optimizer, self._device)        # deepspeech_trainer.py:71 (a restored optimizer state sits on the CPU)
         current, best = self._metrics.train.current, self._metrics.train.best
         fused = isinstance(self._optimizer, FusedAdamW)
         for data in train_loader:
@@ -178,8 +179,8 @@ class DeepSpeechTrainer:
                     self._optimizer.grad_scale = 1.0 / red.world
                     self._optimizer.step()
                 else:
-                    for n, p in model.named_parameters():
-                        p.grad = Gr[n] if red.world == 1 else Gr[n] / red.world
+                    for n, p in model.named_parameters():       # torch AdamW skips parameters without a gradient: frozen ones get none
+                        p.grad = (Gr[n] if red.world == 1 else Gr[n] / red.world) if p.requires_grad else None
                     self._optimizer.step()
         return valid_loss, loss_value
 

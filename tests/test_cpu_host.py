@@ -115,9 +115,16 @@ def test_product_has_no_cpu_path():
         m.forward(torch.zeros(2, 1, 161, 40), torch.tensor([40, 20]))
     with pytest.raises(_lib.DS2LibraryError):
         CTCLoss(reduction="sum")(torch.zeros(5, 2, 7), torch.tensor([1, 2], dtype=torch.int32), torch.tensor([5, 5]), torch.tensor([1, 1]))
-    import asr_amd
-    src = "".join(open(os.path.join(ROOT, "asr_amd", f)).read() for f in os.listdir(os.path.join(ROOT, "asr_amd")) if f.endswith(".py"))
-    assert "import oracle" not in src and "from oracle" not in src
+    # nothing under asr_amd/ (sub-packages and native sources included) may import, include or dlopen the oracle
+    offenders = []
+    for d, _, files in os.walk(os.path.join(ROOT, "asr_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                src = open(os.path.join(d, f), errors="replace").read()
+                if re.search(r"^\s*(import\s+oracle|from\s+oracle)\b", src, re.M) or re.search(r"#include\s+[\"<][^\">]*oracle", src) \
+                        or re.search(r"(dlopen|CDLL)\([^)]*oracle", src):
+                    offenders.append(os.path.join(d, f))
+    assert not offenders, offenders
 
 
 def test_flat_params_layout_and_buckets():
@@ -304,3 +311,76 @@ def test_manifest_label_formats_and_loader(tmp_path):
     for inputs, targets, pct, tsz in batches:
         assert inputs.dim() == 4 and inputs.size(1) == 1 and inputs.size(2) == 161
         assert float(pct.max()) == 1.0 and int(tsz.sum()) == targets.numel()
+
+
+def test_length_bucketing_samplers_partition_and_order():
+    """SURVEY §8(f)4: bins are homogeneous in length, cover every item exactly once, keep the reference's bin/shuffle interface;
+    the distributed variant gives concurrent ranks neighbouring lengths (reference partition rule on length-sorted bins)."""
+    from asr_amd.data import BucketingSampler, DistributedLengthBucketingSampler, LengthBucketingSampler
+    rng = np.random.RandomState(0)
+    n, bs, world = 1003, 64, 8
+    dur = rng.uniform(3.0, 20.0, n)
+    ds = list(range(n))
+    s = LengthBucketingSampler(ds, bs, durations=dur)
+    assert len(s) == -(-n // bs) == len(BucketingSampler(ds, bs))
+    assert sorted(i for b in s for i in b) == ds                                   # a partition of the data set
+    edges = [(dur[b].min(), dur[b].max()) for b in s.bins]
+    assert all(edges[k][1] <= edges[k + 1][0] for k in range(len(edges) - 1))       # bins are consecutive runs of the sorted order
+    spread_sorted = max(s.bin_spread())
+    spread_manifest = max(float(dur[b].max() - dur[b].min()) for b in BucketingSampler(ds, bs).bins)
+    assert spread_sorted < 0.15 * spread_manifest                                  # what bucketing buys: ~1.4 s vs ~17 s here
+    before = [list(b) for b in s.bins]
+    s.shuffle(epoch=3)
+    assert sorted(map(sorted, s.bins)) == sorted(map(sorted, before)) and [sorted(b) for b in s.bins] != [sorted(b) for b in before]
+    t = LengthBucketingSampler(ds, bs, durations=dur)
+    t.shuffle(epoch=3)
+    assert [sorted(b) for b in t.bins] == [sorted(b) for b in s.bins]               # epoch-seeded: every process agrees
+    # distributed: same number of steps on every rank, every item covered, ranks of one step are neighbours in length
+    ranks = [DistributedLengthBucketingSampler(ds, bs, world, r, durations=dur) for r in range(world)]
+    for r in ranks:
+        r.shuffle(7)
+    its = [list(r) for r in ranks]
+    steps = len(ranks[0])
+    assert all(len(it) == steps for it in its) and steps == -(-len(s) // world)
+    assert set(i for it in its for b in it for i in b) == set(ds)
+    for k in range(steps):
+        longest = [dur[it[k]].max() for it in its]
+        assert max(longest) - min(longest) <= (world + 1) * spread_sorted + 1e-9     # within a round: adjacent bins of the sorted order
+    with pytest.raises(ValueError):
+        LengthBucketingSampler(ds, bs)                                              # no durations and no manifest to take them from
+
+
+def test_fused_adamw_state_handling():
+    """restored moments are moved, not re-zeroed; foreign state dicts are rejected; frozen parameters lie outside the
+    launched spans; zero_grad clears the autograd views."""
+    from asr_amd import FusedAdamW
+    from asr_amd.params import FlatParams
+    m = make("gru", 32, 2, 7)
+    m._flat = FlatParams(m, 2, "cpu")
+    opt = FusedAdamW(m)
+    assert opt._trainable_spans() == [(0, m._flat.total)]
+    for p in list(m.parameters())[:-1]:
+        p.requires_grad = False                                                     # finetune_from(nlayers=1) (deepspeech.py:124-128)
+    spans = opt._trainable_spans()
+    o, sz = m._flat.offsets["fc.0.module.1.weight"]
+    assert spans == [(o, o + (sz + 3) // 4 * 4)]
+    for p in m.parameters():
+        p.requires_grad = True
+    assert opt._trainable_spans() == [(0, m._flat.total)]
+    # restored state keeps its values
+    opt.state = {"step": 5, "exp_avg": torch.full((m._flat.total,), 0.25, dtype=torch.float64), "exp_avg_sq": torch.ones(m._flat.total, dtype=torch.float64)}
+    opt._ensure_state()
+    assert opt.state["exp_avg"].dtype == torch.float32 and float(opt.state["exp_avg"][0]) == 0.25 and float(opt.state["exp_avg_sq"][-1]) == 1.0
+    sd = opt.state_dict()
+    opt2 = FusedAdamW(m)
+    opt2.load_state_dict(sd)
+    assert opt2.state["step"] == 5 and torch.equal(opt2.state["exp_avg"], opt.state["exp_avg"])
+    ref_sd = torch.optim.AdamW(m.parameters(), lr=1e-3).state_dict()                # what the reference trainer checkpoints
+    with pytest.raises(ValueError):
+        opt2.load_state_dict(ref_sd)
+    with pytest.raises(ValueError):
+        opt2.load_state_dict({"state": {"step": 1, "exp_avg": torch.zeros(3), "exp_avg_sq": None}, "param_groups": opt.param_groups})
+    for p in m.parameters():
+        p.grad = torch.zeros_like(p)
+    opt.zero_grad()
+    assert all(p.grad is None for p in m.parameters())
