@@ -1,11 +1,14 @@
-"""Single-node data parallelism: one process per GPU, RCCL all-reduce of the flat gradient buffer in per-layer buckets launched in
-backward order.  Two schedules (DS2_DP_MODE):
-  * "serial" (default): every bucket's all-reduce is ordered INTO the compute stream right where its gradients become final.  Nothing
-    overlaps, but nothing ever runs beside the persistent recurrence kernels either (they need every workgroup resident at once), so
-    backward keeps them: 188 MB of all-reduce per step (~1-2.5 ms on 8 GPUs over xGMI) is cheaper than the 7.5 ms the per-step
-    backward kernels cost.
+"""Single-node data parallelism: one process per GPU, RCCL all-reduce of the flat gradient buffer, launched in backward order.
+Three schedules (DS2_DP_MODE):
+  * "conv" (default) — BASELINE's north_star schedule, "all-reduce overlapped with the backward conv": the fc and RNN buckets are held
+    back until the LAST recurrent layer's backward has been enqueued, then reduced as ONE collective over their contiguous span of the flat
+    buffer (~99.6 % of the gradient bytes; few large collectives are what the point-to-point xGMI links want) on a communication stream,
+    WHILE the conv-stack backward (BN2d/conv2 dgrad + wgrad/conv1 wgrad, ~3 ms at c3) runs on the compute stream; the small conv bucket
+    follows.  No collective ever runs beside a persistent recurrence kernel (those need every workgroup resident at once), so backward
+    keeps them.
+  * "serial": every bucket's all-reduce is ordered INTO the compute stream right where its gradients become final.  Nothing overlaps.
   * "overlap": buckets are reduced on a side stream while the rest of backward runs; the trainer then switches the persistent BACKWARD
-    recurrence off (ds2_rnn_persistent_enable(1, 0)).
+    recurrence off (ds2_rnn_persistent_enable(1, 0)), which costs more than the communication it hides.
 
 The reference has no live distributed code; semantics defined in SURVEY §8(e):
 per-rank BatchNorm statistics (plain DDP), gradients = mean over ranks of each rank's
@@ -30,19 +33,38 @@ class BucketedAllReducer:
         # DS2_FORCE_ALLREDUCE=1: run the bucketed all-reduce even with a single rank (exercises the RCCL / side-stream
         # path on a 1-GPU box; a 1-rank SUM is the identity)
         self.force = dist.is_initialized() and os.environ.get("DS2_FORCE_ALLREDUCE") == "1"
-        self.mode = os.environ.get("DS2_DP_MODE", "serial")
-        self.use_stream = flat_grad.is_cuda and self.mode == "overlap"
+        self.mode = os.environ.get("DS2_DP_MODE", "conv")
+        if self.mode not in ("conv", "serial", "overlap"):
+            raise ValueError(f"DS2_DP_MODE={self.mode!r}: expected conv, serial or overlap")
+        self.use_stream = flat_grad.is_cuda and self.mode in ("overlap", "conv")
+        # does a collective ever run while backward's recurrences are still being executed?  (only then must the persistent backward go)
+        self.overlaps_recurrence = flat_grad.is_cuda and self.mode == "overlap"
         self.comm_stream = torch.cuda.Stream(device=flat_grad.device) if self.use_stream else None
         self._pending = []
         self.launched: List[str] = []
+        self._held: List[str] = []
+        # "conv" schedule: the bucket whose completion releases the held ones = the first recurrent layer (last in backward order)
+        rnn_names = [n for n in self.buckets if n.startswith("rnns.")]
+        self._release_on = min(rnn_names, key=lambda n: int(n.split(".")[1])) if rnn_names else None
 
     def on_bucket(self, name: str):
         """Called by engine.backward when bucket `name`'s gradient kernels are enqueued."""
         if self.world == 1 and not self.force:
             return
-        a, b = self.buckets[name]
+        if self.mode == "conv" and name != "conv" and self._release_on is not None:
+            # fc / recurrent layers: hold until the last of them is final, then ONE all-reduce over their (contiguous) span
+            self._held.append(name)
+            if name != self._release_on:
+                return
+            a = min(self.buckets[n][0] for n in self._held)
+            b = max(self.buckets[n][1] for n in self._held)
+            assert sum(self.buckets[n][1] - self.buckets[n][0] for n in self._held) == b - a, "held buckets must be contiguous"
+            self.launched.append("+".join(self._held))
+            self._held = []
+        else:
+            a, b = self.buckets[name]
+            self.launched.append(name)
         view = self.flat_grad[a:b]
-        self.launched.append(name)
         if self.use_stream:
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream())
@@ -66,6 +88,7 @@ class BucketedAllReducer:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         self._pending = []
         self.launched = []
+        assert not self._held, f"buckets never released: {self._held}"
 
     def all_valid(self, valid: bool, device) -> bool:
         """Collective agreement on check_loss (every rank must skip the same steps)."""

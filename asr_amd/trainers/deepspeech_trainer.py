@@ -44,6 +44,8 @@ def asr_metrics():
 
 
 class DeepSpeechTrainer:
+    starved_steps = 0          # process-wide count of train steps skipped because a persistent recurrence launch starved (bench.py reports it)
+
     def __init__(self, model, criterion, epochs, metrics, optimizer, model_path, checkpoint_path, device, device_test,
                  mixed_precision, output_file, scheduler=None, overwrite_lr=None):
         self._device = resolve_device(device)
@@ -136,6 +138,7 @@ class DeepSpeechTrainer:
             return False
         except Exception as e:                                               # DS2LibraryError
             import sys
+            DeepSpeechTrainer.starved_steps += 1
             print(f"[asr_amd] step skipped: {e}", file=sys.stderr, flush=True)
             return True
 
@@ -143,10 +146,10 @@ class DeepSpeechTrainer:
         flat, grad = self._model.flat_parameters()
         if self._reducer is None or self._reducer.flat_grad.data_ptr() != grad.data_ptr():
             self._reducer = BucketedAllReducer(grad, self._model._flat.layer_buckets())
-            # "overlap" schedule: buckets are all-reduced on a communication stream WHILE backward runs, so the persistent backward recurrence
-            # (which needs every workgroup resident at once) must be off; "serial" (default) orders the collectives into the compute stream
-            # and keeps it.  The forward recurrence never overlaps a collective in either schedule.
-            ops.rnn_persistent_enable(True, self._reducer.world == 1 or not self._reducer.use_stream)
+            # "overlap" schedule: buckets are all-reduced on a communication stream WHILE backward's recurrences run, so the persistent backward
+            # recurrence (which needs every workgroup resident at once) must be off; "conv" (default: collectives only under the conv-stack
+            # backward) and "serial" keep it.  The forward recurrence never overlaps a collective in any schedule.
+            ops.rnn_persistent_enable(True, self._reducer.world == 1 or not self._reducer.overlaps_recurrence)
         return self._reducer
 
     def step(self, data):

@@ -41,6 +41,16 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0    # same guide: dense bf16 MFMA (the 5 PF market
 HBM_PEAK_GBS = 8000.0
 
 
+def load_pmc_summary():
+    """profiles/r02_pmc_persistent.json (written by scripts/pmc_summarize.py from the rocprofv3 PMC passes) or None."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_persistent.json")
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
 def train_flops_per_utt(rnn, H, L, C, T):
     """FLOPs(train) = 2*conv1 + 3*(conv2 + rnn + fc)."""
     G = 3 if rnn == "gru" else 4
@@ -65,7 +75,8 @@ def label_file(tmp, n):
 
 
 def synthetic_batch(B, tin, C, seed, ragged=False):
-    """Collated batch in the reference's contract (functional.py:9-32).  ragged: T_b ~ U{301..tin}, sorted descending."""
+    """Collated batch in the reference's contract (functional.py:9-32).  ragged: T_b ~ U{301..tin}, sorted descending
+    (one batch of mixed lengths: the CPU tests' shape; the bench's c4 / c5 batches come from the length-bucketing sampler)."""
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(B, 1, 161, tin, generator=g)
     if ragged:
@@ -73,6 +84,19 @@ def synthetic_batch(B, tin, C, seed, ragged=False):
         tb[0] = tin
     else:
         tb = torch.full((B,), tin)
+    for i in range(B):
+        x[i, :, :, int(tb[i]):] = 0.0
+    pct = torch.tensor([int(t) / float(tin) for t in tb], dtype=torch.float32)
+    tsz = (tb // 20).to(torch.int32)
+    targets = torch.randint(1, C, (int(tsz.sum()),), generator=torch.Generator().manual_seed(seed + 1), dtype=torch.int32)
+    return x, targets, pct, tsz
+
+
+def synthetic_batch_from_lengths(tb, C, seed):
+    """Collated batch (functional.py:9-32) for given per-utterance input frame counts: sorted descending, padded to the longest."""
+    tb = torch.as_tensor(tb).sort(descending=True).values
+    tin, B = int(tb[0]), int(tb.numel())
+    x = torch.randn(B, 1, 161, tin, generator=torch.Generator().manual_seed(seed))
     for i in range(B):
         x[i, :, :, int(tb[i]):] = 0.0
     pct = torch.tensor([int(t) / float(tin) for t in tb], dtype=torch.float32)
@@ -99,50 +123,67 @@ def _oracle_state(rnn, H, L, C):
     return sd
 
 
-def cpu_baseline_worker(rnn, H, L, C, tin):
-    """Runs in a child process (hard wall-clock limit enforced by the parent).  Times the CPU oracle
-    (oracle/ds2_oracle.py: padded+masked restatement of fit + backward) on B=1 of the same model and
-    utterance length.  The thread count is probed first: on many-core hosts the op mix of this model
-    (thousands of tiny per-frame ops) is SLOWER with all cores than with 8-32 threads."""
+def cpu_baseline_worker(rnn, H, L, C, tin, B):
+    """Runs in a child process (hard wall-clock limit enforced by the parent).  SURVEY §8(d): the reference's statement sequence
+    (fit -> zero_grad -> backward -> AdamW.step) in the reference's own PACKED formulation (oracle/ds2_packed.py:
+    pack_padded_sequence -> fused bidirectional gru/lstm -> pad_packed_sequence, blocks.py:87-89; validated against the goldens
+    generated from the imported reference, tests/test_oracle_golden.py), on a bounded sample of the same workload: the same model
+    and utterance length at the largest batch that fits the time budget.  The thread count is probed (this op mix gets slower
+    beyond a few dozen threads) and printed.  The padded + masked oracle (oracle/ds2_oracle.py, explicit time loops) is timed beside
+    it on B = 1."""
     from oracle import ds2_oracle as O
+    from oracle import ds2_packed as P
     cores = os.cpu_count() or 1
     sd = _oracle_state(rnn, H, L, C)
+    t_start = time.time()
 
-    def run(t_in, reps=1):
-        x, targets, pct, tsz = synthetic_batch(1, t_in, C, 1)
-        best = 1e30
-        for _ in range(reps):
-            t0 = time.time()
-            O.fit_and_grads(sd, x, targets, pct, tsz)
-            best = min(best, time.time() - t0)
-        return best
+    def packed_step(b, t_in):
+        params = P.leaf_params(sd)
+        opt = P.make_optimizer(params)
+        x, targets, pct, tsz = synthetic_batch(b, t_in, C, 1)
+        t0 = time.time()
+        P.train_step(params, opt, (x, targets, pct.clone(), tsz))
+        return time.time() - t0
 
-    cands = sorted({min(cores, 8), min(cores, 16)})   # larger teams only get slower on this op mix (measured)
     probe = {}
-    for n in cands:
+    for n in sorted({min(cores, c) for c in (8, 16, 32, 64, 128)}):
         torch.set_num_threads(n)
-        run(41)                       # warm-up (thread pool, allocator)
-        probe[n] = run(41)
+        packed_step(2, 101)                                    # warm-up (thread pool, allocator, oneDNN primitives)
+        probe[n] = packed_step(4, 201)
+        if probe[n] > 2.5 * min(probe.values()) or time.time() - t_start > 60:
+            break                                              # larger teams only get slower from here
     nthr = min(probe, key=probe.get)
     torch.set_num_threads(nthr)
-    t_small = run(201)
-    est_full = t_small * tin / 201.0
-    if est_full <= 45.0:
-        dt, sample_t = run(tin), tin
-    else:
-        dt, sample_t = est_full, 201
-    out = {"value": 1.0 / dt, "unit": "utterances/sec", "cores": nthr, "kind": "port", "host_cores": cores,
-           "sample": (f"CPU oracle fit+backward, B=1 of the same {L}x{H} {rnn} model, T_in={sample_t}"
-                      + ("" if sample_t == tin else f" scaled linearly to T_in={tin}")
-                      + f"; threads probed {probe} -> {nthr}")}
+    # largest batch whose full-length step is predicted to stay inside ~60 s (time is ~linear in B * T on this path)
+    per_utt_frame = probe[nthr] / (4 * 201)
+    b_s = max(1, min(B, 8, int(60.0 / max(per_utt_frame * tin, 1e-9))))
+    dt = packed_step(b_s, tin)
+    # padded + masked restatement (B = 1; T_in = 201 scaled linearly when the full length would not fit)
+    def padded(t_in):
+        x, targets, pct, tsz = synthetic_batch(1, t_in, C, 1)
+        t0 = time.time()
+        O.fit_and_grads(sd, x, targets, pct, tsz)
+        return time.time() - t0
+    padded(41)
+    t_small = padded(201)
+    est = t_small * tin / 201.0
+    left = 200.0 - (time.time() - t_start)
+    pd_t, pd_s = (padded(tin), tin) if est < min(45.0, left) else (est, 201)
+    out = {"value": b_s / dt, "unit": "utterances/sec", "cores": nthr, "kind": "port", "host_cores": cores,
+           "sample": (f"reference statement sequence in packed form (pack_padded_sequence -> aten gru/lstm -> pad_packed_sequence, CTC, backward, "
+                      f"torch AdamW), one full train step at B={b_s} of the config's {B}, same {L}x{H} {rnn} model, T_in={tin}; "
+                      f"threads probed on (B=4, T_in=201) {({k: round(v, 2) for k, v in probe.items()})} s -> {nthr}"),
+           "padded_port": {"value": 1.0 / pd_t, "unit": "utterances/sec", "cores": nthr,
+                           "sample": "padded+masked oracle (explicit time loops) fit+backward, no optimizer, B=1, T_in=" + str(pd_s)
+                                     + ("" if pd_s == tin else f" scaled linearly to T_in={tin}")}}
     print("CPU_BASELINE_JSON " + json.dumps(out), flush=True)
 
 
-def cpu_baseline(rnn, H, L, C, tin, limit_s=240):
+def cpu_baseline(rnn, H, L, C, tin, B, limit_s=240):
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", rnn, str(H), str(L), str(C), str(tin)]
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", rnn, str(H), str(L), str(C), str(tin), str(B)]
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=limit_s, env=dict(os.environ, HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS="16", MKL_NUM_THREADS="16"))
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=limit_s, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
         for line in r.stdout.splitlines():
             if line.startswith("CPU_BASELINE_JSON "):
                 return json.loads(line[len("CPU_BASELINE_JSON "):])
@@ -151,10 +192,27 @@ def cpu_baseline(rnn, H, L, C, tin, limit_s=240):
         return {"value": None, "unit": "utterances/sec", "cores": 0, "kind": "port", "sample": f"worker exceeded {limit_s}s"}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: re-run this command line as N ranks (one per GPU, RCCL) under
+    torch.distributed.run and pass rank 0's JSON line through.  Fails loudly when the node has fewer than N GPUs — it never
+    prints a 1-GPU number labelled as N."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        sys.exit(f"bench.py: --gpus {n} requested but this node exposes {have} GPU(s); refusing to run (a scaling point must use {n} devices)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return sys.exit(subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")).returncode)
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-baseline-worker":
-        rnn, H, L, C, tin = sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
-        return cpu_baseline_worker(rnn, H, L, C, tin)
+        rnn, H, L, C, tin, B = sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7])
+        return cpu_baseline_worker(rnn, H, L, C, tin, B)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -166,7 +224,11 @@ def main():
     ap.add_argument("--breakdown", action="store_true", help="print a per-section time breakdown to stderr")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return spawn_ranks(args.gpus)                   # `python bench.py --gpus N`: one rank per GPU under torch.distributed.run
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(args.gpus, 1):
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; they must agree")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
@@ -192,11 +254,34 @@ def main():
     model.precision = "bf16" if dtype == "bf16" else "fp32"
     opt = FusedAdamW(model, lr=1.5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5)
     tr = DeepSpeechTrainer(model, CTCLoss(reduction="sum"), 1, None, opt, None, None, dev, dev, False, None)
-    x, targets, pct, tsz = synthetic_batch(B, tin, C, 1 + rank, ragged=(args.workload == "c5"))
-    x = x.to(dev)                                     # inputs resident in HBM before the timed region
+    # batches resident in HBM before the timed region.  c1-c3: one fixed-length batch.  c4 / c5 (BASELINE configs[3] "bucketed sampler",
+    # configs[4] "length-sorted batching"): a synthetic manifest of 8 rounds x world x B utterance lengths goes through the product's
+    # DistributedLengthBucketingSampler (asr_amd/data) and the steps cycle through THIS rank's bins in the sampler's shuffled order —
+    # every batch is homogeneous in length and concurrent ranks hold neighbouring lengths.
+    sampler_note = None
+    if args.workload in ("c4", "c5"):
+        from asr_amd.data import DistributedLengthBucketingSampler
+        lo = 1201 if args.workload == "c4" else 301
+        n_items = 8 * world * B
+        frames = torch.randint(lo, tin + 1, (n_items,), generator=torch.Generator().manual_seed(1))
+        frames[0] = tin
+        smp = DistributedLengthBucketingSampler(list(range(n_items)), B, world, rank, durations=frames.tolist())
+        smp.shuffle(0)
+        batches = [synthetic_batch_from_lengths(frames[torch.tensor(ids)], C, 10 + 97 * k + rank) for k, ids in enumerate(smp)]
+        sampler_note = (f"DistributedLengthBucketingSampler over {n_items} synthetic lengths U{{{lo}..{tin}}} frames, {len(batches)} bins per rank cycled; "
+                        f"T_in per bin {[int(b[0].size(3)) for b in batches]}")
+    else:
+        batches = [synthetic_batch(B, tin, C, 1 + rank)]
+    batches = [(bx.to(dev), bt, bp, bs) for bx, bt, bp, bs in batches]
+    x, targets, pct, tsz = max(batches, key=lambda b: b[0].size(3))          # the longest batch: the roofline probe's layer shape
+    tin_probe = int(x.size(3))
+    step_no = [0]
+    starved_before = DeepSpeechTrainer.starved_steps
 
     def one_step():
-        return tr.step((x, targets, pct.clone(), tsz))
+        bx, bt, bp, bs = batches[step_no[0] % len(batches)]
+        step_no[0] += 1
+        return tr.step((bx, bt, bp.clone(), bs))
 
     for _ in range(args.warmup):
         valid, lv = one_step()
@@ -220,7 +305,7 @@ def main():
     # ---- roofline of the dominant kernel: the recurrent step kernel (fwd), timed live with HIP events on
     # torch's current stream, which is the stream libds2hip launches on.
     G = 3 if rnn == "gru" else 4
-    T = (tin + 1) // 2
+    T = (tin_probe + 1) // 2
     M = T * B
     gx = torch.randn(M, 2 * G * H, device=dev) * 0.5
     whh = (torch.rand(2, G * H, H, device=dev) * 2 - 1) / H ** 0.5
@@ -257,12 +342,18 @@ def main():
     flops_per_launch = 2.0 * 2 * B * H * G * H * (T if persistent else 1)      # both directions; all T steps in the persistent launch
     achieved = flops_per_launch / (us_per_launch * 1e-6) / 1e12
     peak = BF16_MFMA_PEAK_TFLOPS if bf else FP32_MFMA_PEAK_TFLOPS
-    # HBM-side bytes from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), measured for exactly this shape and mode
-    # (c3, bf16 operands, packed gate records): 4.48 MB per time step in the persistent kernel (profiles/r01_pmc_persistent/), 20.84 MB
-    # per launch of the step kernel (profiles/r01_pmc/); null for other shapes.
-    traffic = None
-    if args.workload == "c3" and bf and B == 64:
-        traffic = 4.48e6 * T if persistent else 20.84e6
+    # HBM-side bytes per launch from the committed rocprofv3 PMC summary (separate FETCH_SIZE / WRITE_SIZE passes, FETCH x2 gfx950
+    # correction: scripts/gpu_pmc_persistent.sh -> profiles/r02_pmc_persistent.json), collected for exactly this layer shape and mode
+    # (GRU H=1024 B=64, bf16 operands, packed gate records); null for any other shape or when the file is absent.
+    pmc = load_pmc_summary()
+    same_shape = args.workload in ("c3", "c5") and bf and B == 64 and G == 3 and H == 1024
+
+    def pmc_traffic(kernel, steps):
+        k = (pmc or {}).get("kernels", {}).get(kernel)
+        if not (same_shape and k):
+            return None
+        return k["hbm_bytes_per_time_step"] * steps if "persistent" in kernel else k["hbm_bytes_per_launch"]
+    traffic = pmc_traffic("rnn_fwd_persistent_kernel" if persistent else "rnn_fwd_step_kernel", T)
     alg_bytes_step = (3 * 4 + 8 + 4 + 2 if pack else 8 * 4 + (2 if bf else 4)) * B * 2 * H
     roofline = {"kernel": "rnn_fwd_persistent_kernel" if persistent else "rnn_fwd_step_kernel", "bound": "mfma", "achieved": achieved,
                 "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
@@ -274,9 +365,7 @@ def main():
     bl = 1 if bwd_persistent else T
     bl_steps = T if bwd_persistent else 1
     b_ach = flops_per_launch / (T if persistent else 1) * (T if bwd_persistent else 1) / (bwd_layer_us / bl * 1e-6) / 1e12
-    bwd_traffic = None
-    if args.workload == "c3" and bf and B == 64 and bwd_persistent:
-        bwd_traffic = 6.71e6 * T                           # profiles/r01_pmc_persistent/: FETCH 1650 KB x2 + WRITE 3256 KB per time step
+    bwd_traffic = pmc_traffic("rnn_bwd_persistent_kernel" if bwd_persistent else "rnn_bwd_step_kernel", T)
     roofline_bwd = {"kernel": "rnn_bwd_persistent_kernel" if bwd_persistent else "rnn_bwd_step_kernel", "bound": "mfma", "achieved": b_ach,
                     "peak": peak, "unit": "TFLOP/s", "frac": b_ach / peak, "traffic": bwd_traffic,
                     # gate record 8 + previous state 4 + dGx 3 x 2 + d(hn) 4 bytes per hidden unit and direction, dy 4 bytes per unit (packed mode)
@@ -291,7 +380,8 @@ def main():
         breakdown(model, tr, x, targets, pct, tsz)
 
     if rank == 0:
-        step_flops = sum(train_flops_per_utt(rnn, H, L, C, (int(round(float(p) * tin)) + 1) // 2) for p in pct)
+        used = [batches[k % len(batches)] for k in range(args.warmup, args.warmup + args.steps)]
+        step_flops = sum(sum(train_flops_per_utt(rnn, H, L, C, (int(round(float(p) * int(b[0].size(3)))) + 1) // 2) for p in b[2]) for b in used) / len(used)
         out = {
             "metric": "utterances/sec (10 s, 161-bin) DS2 5x1024 BiGRU CTC train step" if args.workload == "c3"
                       else f"utterances/sec DS2 {L}x{H} bi-{rnn} CTC train step",
@@ -299,14 +389,18 @@ def main():
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
             "data": "synthetic N(0,1) 161-bin spectrograms, random-init weights, random labels U=T_in/20",
             "config": {"workload": f"{args.workload}: DS2 {L}x{H} bi-{rnn.upper()} {dtype}, {tin} input frames ({tin // 100} s), "
-                                   f"batch {B}/GPU, {C} classes", "global_batch": B * world, "parallelism": f"dp{world}"},
+                                   f"batch {B}/GPU, {C} classes", "global_batch": B * world, "parallelism": f"dp{world}",
+                       **({"sampler": sampler_note} if sampler_note else {})},
             "loss": lv, "step_tflops": step_flops * world / (ms * 1e-3) / 1e12,
             "step_frac_of_fp32_mfma_peak": step_flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
             "step_frac_of_bf16_mfma_peak": step_flops / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
             "roofline": roofline,
+            # train steps of this run (warm-up included) in which a persistent recurrence launch starved and the step was skipped
+            "persistent_starved_steps": DeepSpeechTrainer.starved_steps - starved_before,
+            "valid_last_step": bool(valid),
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(rnn, H, L, C, tin)
+            out["cpu_baseline"] = cpu_baseline(rnn, H, L, C, tin, B)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

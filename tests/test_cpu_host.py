@@ -202,7 +202,10 @@ order = list(red.launched)
 red.finish()
 expect = torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world))
 assert torch.equal(g, expect), (g[:5], expect[:5])
-assert order == ["fc", "rnns.1", "rnns.0", "conv"]
+mode = os.environ.get("DS2_DP_MODE", "conv")
+assert red.mode == mode
+# "conv": fc + recurrent buckets are held and go out as ONE collective over their contiguous span once the last of them is final
+assert order == (["fc+rnns.1+rnns.0", "conv"] if mode == "conv" else ["fc", "rnns.1", "rnns.0", "conv"]), order
 assert red.all_valid(True, "cpu") is True
 assert red.all_valid(rank != 1, "cpu") is False       # one rank invalid -> everyone skips
 dist.destroy_process_group()
@@ -210,13 +213,15 @@ print("OK", rank)
 '''
 
 
-def test_bucketed_allreduce_gloo_world2():
+@pytest.mark.parametrize("mode", ["conv", "serial", "overlap"])
+def test_bucketed_allreduce_gloo_world2(mode):
     with tempfile.TemporaryDirectory() as tmp:
         script = os.path.join(tmp, "w.py")
         open(script, "w").write(DP_WORKER)
         procs = []
         for r in range(2):
-            env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29533 + ["conv", "serial", "overlap"].index(mode)),
+                       DS2_DP_MODE=mode)
             procs.append(subprocess.Popen([sys.executable, script, ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
         outs = [p.communicate(timeout=180)[0] for p in procs]
         assert all(p.returncode == 0 for p in procs), outs

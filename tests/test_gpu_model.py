@@ -132,10 +132,11 @@ def test_step_vs_oracle_larger(rnn, hidden, layers, B, tmax):
 @pytest.mark.parametrize("rnn,hidden,layers,B,tmax", [("gru", 128, 3, 16, 120), ("lstm", 96, 2, 9, 90)])
 def test_bf16_precision_vs_oracle(rnn, hidden, layers, B, tmax):
     """precision="bf16": bf16 MFMA operands for the GEMMs, the recurrent products and conv2 (fp32 accumulate, fp32 state,
-    BN, CTC).  Separately stated tolerance: logits/loss 2e-2, RNN/fc gradients 6e-2, conv-stack gradients
-    1.5e-1 relative to the fp64 oracle: bf16 rounding of conv2's operands perturbs its output by ~0.3 % of its std,
-    which flips the Hardtanh branch of ~0.1 % of the elements sitting next to the kink — uncorrelated gradient noise
-    of a few percent on the conv parameters (the reference's own fp16 autocast path has the same property)."""
+    BN, CTC).  Separately stated tolerance: logits/loss 2e-2, RNN/fc gradients 4e-2, conv-stack gradients
+    1.2e-1 relative to the fp64 oracle: bf16 rounding of the conv operands perturbs the BatchNorm2d outputs by ~0.3 % of their
+    std, which flips the Hardtanh branch of a fraction f ~ 1.5e-3 of the live elements (COUNTED in
+    test_gpu_configs.py::test_bf16_gradients_vs_fp32_path) — uncorrelated gradient noise of relative size ~sqrt(f) ~ 4e-2 on
+    the conv parameters, bounded at 3 sqrt(f) (the reference's own fp16 autocast path has the same property)."""
     cfg = dict(rnn=rnn, hidden=hidden, layers=layers, classes=29)
     t_ins = sorted([int(v) for v in det.randint((B,), 62, tmax // 2, tmax + 1)], reverse=True)
     t_ins[0] = tmax
@@ -155,7 +156,7 @@ def test_bf16_precision_vs_oracle(rnn, hidden, layers, B, tmax):
     for k, p in model.named_parameters():
         gref = ref["grads"][k].numpy()
         err = np.linalg.norm(p.grad.cpu().numpy().astype(np.float64) - gref)
-        tol = 1.5e-1 if k.startswith("conv.") else 6e-2
+        tol = 1.2e-1 if k.startswith("conv.") else 4e-2          # conv: 3 sqrt(f) for the counted flip fraction f ~ 1.5e-3 (test_gpu_configs.py)
         assert err <= tol * max(np.linalg.norm(gref), 1e-12), (k, err / np.linalg.norm(gref))
 
 
@@ -380,7 +381,12 @@ import numpy as np, torch, torch.distributed as dist
 root = sys.argv[1]
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests")); sys.path.insert(0, os.path.join(root, "tests", "golden"))
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-dist.init_process_group("gloo", rank=rank, world_size=world)          # two ranks share the one GPU: gloo moves the CUDA buckets
+backend = os.environ.get("DS2_TEST_BACKEND", "gloo")
+if backend == "nccl":
+    torch.cuda.set_device(rank)                                          # RCCL: one device per rank
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+else:
+    dist.init_process_group("gloo", rank=rank, world_size=world)          # two ranks share the one GPU: gloo moves the CUDA buckets
 from helpers import model_inputs
 from test_gpu_model import make_model
 from asr_amd import CTCLoss, FusedAdamW
@@ -391,9 +397,10 @@ cfg["seed"] = 11 + 2 * rank                                              # each 
 sd, x, targets, pct, tsz = model_inputs(cfg)
 model = make_model(cfg, sd)
 opt = FusedAdamW(model, lr=1.5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5)
-tr = DeepSpeechTrainer(model, CTCLoss(reduction="sum"), 1, None, opt, None, None, "cuda", "cuda", False, None)
+dev = torch.device("cuda", rank if backend == "nccl" else 0)
+tr = DeepSpeechTrainer(model, CTCLoss(reduction="sum"), 1, None, opt, None, None, dev, dev, False, None)
 valid, lv = tr.step((x, targets, pct.clone(), tsz))
-assert valid and tr._get_reducer().world == 2
+assert valid and tr._get_reducer().world == 2 and tr._get_reducer().mode == os.environ.get("DS2_DP_MODE", "conv")
 flat, flat_grad = model.flat_parameters()
 assert abs(opt.grad_scale - 1.0 / world) < 1e-12                         # the mean over ranks is folded into the optimizer
 np.save(sys.argv[3] + f".rank{rank}.npy", flat.detach().cpu().numpy())
@@ -407,13 +414,17 @@ print("OK", rank, lv)
 '''
 
 
-def test_data_parallel_step_matches_sharded_oracle(tmp_path):
+@pytest.mark.parametrize("backend,mode", [("gloo", "conv"), ("gloo", "serial"), ("gloo", "overlap"), ("nccl", "conv"), ("nccl", "serial")])
+def test_data_parallel_step_matches_sharded_oracle(tmp_path, backend, mode):
     """N-GPU parity = run the CPU oracle on each rank's shard with the same weights, average the gradients, apply
-    AdamW once.  Two ranks (sharing this box's single GPU through the gloo backend — the reducer is backend-agnostic) run
-    `trainer.step` on different shards: both must end with identical parameters, equal to the oracle's averaged-gradient update."""
+    AdamW once.  Two ranks run `trainer.step` on different shards: both must end with identical parameters, equal to the oracle's
+    averaged-gradient update — under every schedule of asr_amd/parallel.py.  "gloo": the two ranks share this box's single GPU (the
+    reducer is backend-agnostic); "nccl": RCCL with one device per rank, skipped on a box with fewer than two GPUs."""
     import json
     import subprocess
     import sys
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("RCCL world-2 needs two GPUs")
     cfg = dict(rnn="gru", hidden=24, layers=2, classes=7, shards=[[40, 33, 21], [38, 30, 12]])
     out = str(tmp_path / "dp")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -421,7 +432,8 @@ def test_data_parallel_step_matches_sharded_oracle(tmp_path):
     open(script, "w").write(DP_STEP_WORKER)
     procs = []
     for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29537")
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29537 + hash((backend, mode)) % 40),
+                   DS2_TEST_BACKEND=backend, DS2_DP_MODE=mode, HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, script, root, json.dumps(cfg), out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=300)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
