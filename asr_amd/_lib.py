@@ -24,6 +24,7 @@ SIGNATURES = {
     "ds2_device_info": (i32, [C.POINTER(i32), C.POINTER(i32), C.c_char_p, i32]),
     "ds2_debug_flags": (i32, [i32]),
     "ds2_rnn_persistent_status": (i32, [vp]),
+    "ds2_rnn_persistent_counters": (i32, [vp]),
     "ds2_rnn_persistent_enable": (i32, [i32, i32]),
     "ds2_rnn_last_path": (i32, []),
     "ds2_gemm_f32_workspace_bytes": (sz, [i32, i32, i32, i32]),

@@ -1237,6 +1237,18 @@ inline int pick_mb(int B, int H) {
 // collectives on another stream during backward, because a persistent launch needs every one of its workgroups resident at once
 int g_persist_fwd = 1, g_persist_bwd = 1;
 int g_last_path = 0;                    // bit 0 / bit 1: the last ds2_rnn_fwd / ds2_rnn_bwd call took the persistent kernel
+// After a starved launch (ds2_rnn_persistent_status) the next g_persist_cooldown recurrence calls take the one-launch-per-step kernels,
+// then the persistent kernels are armed again: a transient (another process or stream holding CUs for a moment) costs a few slow steps,
+// not the rest of the run.  DS2_RNN_REARM_CALLS sets the length (default 64 calls = 6 train steps of a 5-layer model; 0 = never re-arm).
+int g_persist_cooldown = 0;
+int g_persist_starved_total = 0;        // launches that starved since the library was loaded (reporting)
+bool persist_allowed(bool bwd) {
+  if (g_persist_cooldown != 0) {
+    if (g_persist_cooldown > 0) --g_persist_cooldown;
+    return false;
+  }
+  return bwd ? g_persist_bwd != 0 : g_persist_fwd != 0;
+}
 
 // bytes of ONE packed h buffer of the forward recurrence ([2 dirs][tiles][chunks][1 KiB]); the persistent kernel uses four
 size_t fwd_xbuf_bytes(int B, int H, int bf16) { return (size_t)2 * (ceil_div(B, 32) * 2) * ceil_div(H, bf16 ? 32 : 16) * 1024; }
@@ -1269,7 +1281,7 @@ int try_launch_persistent_fwd(RnnArgs a, hipStream_t st) {
   static const char* env = getenv("DS2_RNN_PERSISTENT");          // "0" = always the step kernels (A/B runs, debugging)
   if (env && env[0] == '0') return 0;
   if (a.dbg) return 0;                                            // the ablation flags belong to the step kernels
-  if (!g_persist_fwd || (a.H % 16) != 0 || a.T < 2) return 0;
+  if ((a.H % 16) != 0 || a.T < 2 || !persist_allowed(false)) return 0;
   const int nsl = a.H / 16;
   const int nch = ceil_div(a.H, kchunk<BF>());
   int ncw = ceil_div(nch, NW);
@@ -1337,10 +1349,10 @@ size_t bwd_xbuf_bytes(int gates, int B, int H, int bf16) { return (size_t)2 * (c
 template <int G, bool BF>
 int try_launch_persistent_bwd(RnnArgs a, hipStream_t st) {
   static const char* env = getenv("DS2_RNN_PERSISTENT");
-  if ((env && env[0] == '0') || !g_persist_bwd || a.dbg) return 0;
+  if ((env && env[0] == '0') || a.dbg) return 0;
   // buffers: either the bf16 training path's (packed gate records in, bf16 dGx out) or the plain ones (gates in gx, dGx in place)
   if (!((a.gates_bf && a.dgx_bf) || (!a.gates_bf && !a.dgx_bf && a.gx))) return 0;
-  if ((a.H % 16) != 0 || a.T < 2) return 0;
+  if ((a.H % 16) != 0 || a.T < 2 || !persist_allowed(true)) return 0;
   int mb = pick_mb(a.B, a.H);
   const int nsl = a.H / 16;
   const int nchb = ceil_div(G * a.H, kchunk<BF>());
@@ -1466,9 +1478,13 @@ extern "C" int ds2_rnn_persistent_status(int* out8) {
   DS2_HIP(hipDeviceSynchronize());
   DS2_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_persist_dbg), 8 * sizeof(int)));
   if (out8[0]) {
-    // a launch starved (not every workgroup could be resident, or something else held CUs): stay on the one-launch-per-step kernels from
-    // here on, so that the caller's retry / next step works; the step that starved is invalid and must be reported as failed
-    g_persist_fwd = g_persist_bwd = 0;
+    // a launch starved (not every workgroup could be resident, or something else held CUs): the step that starved is invalid and must be
+    // reported as failed; the next calls take the one-launch-per-step kernels so that the caller's retry / next steps work, then the
+    // persistent kernels are armed again (see g_persist_cooldown)
+    static const char* env = getenv("DS2_RNN_REARM_CALLS");
+    const int n = env ? atoi(env) : 64;
+    g_persist_cooldown = n > 0 ? n : -1;
+    ++g_persist_starved_total;
     int zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     DS2_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_persist_dbg), zero, sizeof(zero)));
   }
@@ -1524,6 +1540,13 @@ extern "C" int ds2_rnn_last_path(void) { return g_last_path; }
 extern "C" int ds2_rnn_persistent_enable(int forward, int backward) {
   g_persist_fwd = forward != 0;
   g_persist_bwd = backward != 0;
+  return 0;
+}
+
+// {launches that starved since load, recurrence calls left on the step kernels before the persistent ones are armed again (-1: never)}
+extern "C" int ds2_rnn_persistent_counters(int* out2) {
+  out2[0] = g_persist_starved_total;
+  out2[1] = g_persist_cooldown;
   return 0;
 }
 

@@ -217,6 +217,11 @@ class DeepSpeech(nn.Module):
             self.to(device)
             total_cer = total_wer = num_tokens = num_chars = 0
             output_data = []
+            # per-utterance report (deepspeech.py:224-244): best / last / worst transcript by CER and a 10-bucket CER histogram
+            hist = [0] * 10
+            best = (float("inf"), "")
+            worst = (-1.0, "")
+            last_str = ""
             for data in loader:
                 inputs, targets, input_percentages, target_sizes = data
                 input_sizes = input_percentages.mul_(int(inputs.size(3))).int()
@@ -232,17 +237,34 @@ class DeepSpeech(nn.Module):
                     output_data.append((out.detach().cpu().numpy(), output_sizes.numpy(), target_strings))
                 for i in range(len(target_strings)):
                     transcript, reference = decoded_output[i][0], target_strings[i][0]
-                    total_wer += decoder.wer(transcript, reference)
-                    total_cer += decoder.cer(transcript, reference)
-                    num_tokens += len(reference.split())
-                    num_chars += len(reference.replace(" ", ""))
+                    wer_inst, cer_inst = decoder.wer(transcript, reference), decoder.cer(transcript, reference)
+                    total_wer += wer_inst
+                    total_cer += cer_inst
+                    n_tok, n_chr = len(reference.split()), len(reference.replace(" ", ""))
+                    num_tokens += n_tok
+                    num_chars += n_chr
+                    wer_pct = min(100.0 * wer_inst / max(n_tok, 1), 100.0)
+                    cer_pct = min(100.0 * cer_inst / max(n_chr, 1), 100.0)
+                    hist[min(int(cer_pct // 10), 9)] += 1
+                    last_str = f"Ref:{reference.lower()}\nHyp:{transcript.lower()}\nWER:{wer_pct}  - CER:{cer_pct}"
+                    if cer_pct < best[0]:
+                        best = (cer_pct, last_str)
+                    if cer_pct > worst[0]:
+                        worst = (cer_pct, last_str)
                     if verbose:
-                        print(f"Ref:{reference.lower()}\nHyp:{transcript.lower()}")
+                        print(last_str)
             wer = float(total_wer) / max(num_tokens, 1)
             cer = float(total_cer) / max(num_chars, 1)
             if main_proc and output_file is not None:
+                # same sections as the reference's report (deepspeech.py:249-271); its histogram is drawn by the third-party ascii_graph
+                # package, this one by the loop below (same buckets and counts)
+                peak = max(max(hist), 1)
+                bars = [f"{k * 10:>3}-{k * 10 + 10:<3} | {'#' * round(40 * v / peak):<40} {v}" for k, v in enumerate(hist)]
                 with open(output_file, "w") as f:
-                    f.write(f"===== {wer * 100:.2f}/{cer * 100:.2f} =====\n")
+                    f.write("\n".join([f"===== {wer * 100:.2f}/{cer * 100:.2f} =====", "----- BEST -----", best[1], "----- LAST -----", last_str,
+                                       "----- WORST -----", worst[1], "CER histogram"] + bars
+                                      + ["=============================================\n"]))
+                print(f"saved output to {output_file}")
             return wer * 100, cer * 100, output_data
 
     def __call__(self, *args, **kwargs):

@@ -544,14 +544,25 @@ def rnn_persistent_enable(forward: bool = True, backward: bool = True) -> None:
 
 
 def rnn_persistent_check() -> None:
-    """Raise if a persistent forward-recurrence launch starved since the last call (a workgroup never saw its operand: the launch
-    needs every workgroup resident at once).  Call at a point where the device is idle anyway (the train step's loss sync)."""
+    """Raise if a persistent recurrence launch starved since the last call (a workgroup never saw its operand, or the launch never became
+    resident: it needs every workgroup on the chip at once).  Call at a point where the device is idle anyway (the train step's loss sync)."""
     rec = (C.c_int * 8)()
     _lib.check(_lib.load().ds2_rnn_persistent_status(C.cast(rec, C.c_void_p)), "ds2_rnn_persistent_status")
     if rec[0]:
-        raise _lib.DS2LibraryError(f"persistent recurrence starved: block ({rec[1]}, {rec[2]}, {rec[3]}) step {rec[4]} wave {rec[5]} never received its "
-                                   f"operand (lanes ok {rec[7] & 0xffffffff:08x}{rec[6] & 0xffffffff:08x}); the results of that step are invalid. "
-                                   f"The library has switched to the one-launch-per-step kernels for the rest of the process (DS2_RNN_PERSISTENT=0 selects them from the start).")
+        starved, left = rnn_persistent_counters()
+        what = {1: "forward", 2: "backward", 3: "census (launch never resident)"}.get(rec[0], str(rec[0]))
+        raise _lib.DS2LibraryError(
+            f"persistent recurrence starved ({what}): ids ({rec[1]}, {rec[2]}, {rec[3]}) step {rec[4]} wave {rec[5]} pending chunks {rec[6] & 0xffffffff:08x} "
+            f"(L2-local exchange: {rec[7]}); the results of that step are invalid.  The next {left if left >= 0 else 'ALL'} recurrence calls run on the "
+            f"one-launch-per-step kernels, then the persistent kernels are armed again (DS2_RNN_REARM_CALLS; DS2_RNN_PERSISTENT=0 selects the step "
+            f"kernels from the start).  Starved launches since load: {starved}.")
+
+
+def rnn_persistent_counters():
+    """(launches that starved since the library was loaded, recurrence calls left on the step kernels before re-arming)."""
+    out = (C.c_int * 2)()
+    _lib.check(_lib.load().ds2_rnn_persistent_counters(C.cast(out, C.c_void_p)), "ds2_rnn_persistent_counters")
+    return int(out[0]), int(out[1])
 
 
 def rnn_fwd(gates: int, gx: Tensor, wp_fwd: Tensor, bhh: Tensor, lens_dev: Tensor, T: int, B: int, H: int, bf16: bool = False,

@@ -136,12 +136,18 @@ size_t ds2_rnn_packed_bytes(int gates, int H, int which /*0: forward operand, 1:
 /* re-pack W_hh = [weight_hh_l0 ; weight_hh_l0_reverse] (2,G*H,H) fp32 into MFMA-fragment order, fp32 or bf16 fragments
  * (once per optimizer step) */
 int ds2_rnn_pack_whh(int gates, const float* whh, void* wp_fwd, void* wp_bwd, int H, int bf16, void* stream);
-/* Status of the persistent forward recurrence (bf16 mode runs a layer's whole recurrence in ONE launch whose workgroups exchange h_t
- * through memory; it needs every workgroup resident at once).  out8 = {starved, block x, y, z, step, wave, ok-mask lo, hi}: starved != 0
- * means a wave gave up polling for its operand since the last call (DS2_RNN_SPIN_LIMIT polls, default 2^20 ~ 1 s) and the results
- * of that launch are invalid — the caller must treat the step as failed.  Synchronises the device and clears the record.
- * DS2_RNN_PERSISTENT=0 selects the one-launch-per-step kernels instead. */
+/* Status of the persistent recurrences (a layer's whole recurrence in ONE launch whose workgroups exchange h_t / dGh_t through memory;
+ * it needs every workgroup resident at once).  out8 = {starved, slice | workgroup, tile | XCD, direction | kind, step, wave, pending
+ * chunk mask, L2-local exchange}: starved != 0 (1 forward, 2 backward, 3 the launch never became resident) means a wave gave up
+ * polling since the last call (DS2_RNN_SPIN_LIMIT polls, default 2^20 ~ 1 s) and the results of that launch are invalid — the caller
+ * must treat the step as failed.  Synchronises the device and clears the record.  After a starved launch the next DS2_RNN_REARM_CALLS
+ * (default 64) recurrence calls run on the one-launch-per-step kernels, then the persistent kernels are armed again.
+ * DS2_RNN_PERSISTENT=0 selects the one-launch-per-step kernels from the start; DS2_RNN_XCD_LOCAL=0 keeps the placement-independent
+ * (sc1) exchange instead of the exchange through the group's own L2 (asr_amd/csrc/rnn.hip: persist_role). */
 int ds2_rnn_persistent_status(int* out8);
+/* reporting: out2 = {launches that starved since the library was loaded, recurrence calls left before the persistent kernels are armed
+ * again (0 = armed, -1 = never)} */
+int ds2_rnn_persistent_counters(int* out2);
 /* Which recurrences may run as one persistent launch (default both).  Switch the backward one off when other kernels (collectives on a
  * communication stream) run on the device during backward: a persistent launch needs all of its workgroups resident at once. */
 int ds2_rnn_persistent_enable(int forward, int backward);

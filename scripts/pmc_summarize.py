@@ -4,7 +4,7 @@ JSON file: per persistent recurrence kernel, HBM-side bytes per launch and per t
 
     python scripts/pmc_summarize.py <dir with pmc_FETCH_SIZE_counter_collection.csv, pmc_WRITE_SIZE_...> <T> <out.json> [shape note]
 """
-import csv, json, os, sys
+import csv, json, os, re, sys
 
 d, T, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 note = sys.argv[4] if len(sys.argv) > 4 else ""
@@ -16,8 +16,8 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             name = row["Kernel_Name"]
             if "persistent_kernel" not in name and "_step_kernel" not in name:
                 continue
-            short = name.split("(")[0].split("::")[-1].strip()
-            key = short.split("<")[0]
+            m = re.search(r"(rnn_\w+_kernel)(<[^>]*>)?", name)
+            key, short = m.group(1), m.group(0)
             e = res.setdefault(key, {"kernel": short, "launches": {}, "grid": int(row["Grid_Size"]), "vgpr": int(row["VGPR_Count"])})
             e["launches"].setdefault(ctr, []).append(float(row["Counter_Value"]))
 summary = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over scripts/pmc_rnn.py", "time_steps_per_launch": T, "shape": note,

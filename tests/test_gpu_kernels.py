@@ -463,11 +463,25 @@ try:
     print("NO-RAISE")
 except _lib.DS2LibraryError as e:
     print("RAISED", "starved" in str(e))
-h2 = ops.rnn_fwd(G, gx.clone(), wpf, bhh, lens, T, B, H, bf16=True)[0]          # the library has fallen back to the step kernels
+lib = _lib.load()
+h2 = ops.rnn_fwd(G, gx.clone(), wpf, bhh, lens, T, B, H, bf16=True)[0]          # the library has fallen back to the step kernels ...
 ops.rnn_persistent_check()
-_lib.load().ds2_debug_flags(64)
-h3 = ops.rnn_fwd(G, gx.clone(), wpf, bhh, lens, T, B, H, bf16=True)[0]          # step kernels, explicitly
+print("COOLDOWN", lib.ds2_rnn_last_path() & 1, ops.rnn_persistent_counters())      # ... for DS2_RNN_REARM_CALLS = 3 calls: (1 starved, 2 left)
+lib.ds2_debug_flags(64)
+h3 = ops.rnn_fwd(G, gx.clone(), wpf, bhh, lens, T, B, H, bf16=True)[0]          # step kernels, explicitly (not a cooldown call: the flag decides first)
+lib.ds2_debug_flags(0)
 print("FALLBACK-EQUAL", bool(torch.equal(h2, h3)))
+for _ in range(2):
+    ops.rnn_fwd(G, gx.clone(), wpf, bhh, lens, T, B, H, bf16=True)
+ops.rnn_persistent_check()
+print("ARMED-AGAIN", ops.rnn_persistent_counters()[1] == 0)
+ops.rnn_fwd(G, gx.clone(), wpf, bhh, lens, T, B, H, bf16=True)                   # persistent again (and, with a poll limit of 0, starved again)
+took = lib.ds2_rnn_last_path() & 1
+try:
+    ops.rnn_persistent_check()
+    print("REARMED", False)
+except _lib.DS2LibraryError:
+    print("REARMED", took == 1 and ops.rnn_persistent_counters()[0] == 2)
 """
 
 
@@ -487,9 +501,53 @@ def test_persistent_recurrence_starvation_is_loud_and_falls_back(dev):
     """A persistent launch whose waves give up polling (forced here with a poll limit of 0) must be reported: the status check raises,
     and the library then runs the one-launch-per-step kernels for the rest of the process."""
     import os, subprocess, sys as _sys
-    env = dict(os.environ, DS2_RNN_SPIN_LIMIT="0", REPO=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, DS2_RNN_SPIN_LIMIT="0", DS2_RNN_REARM_CALLS="3", REPO=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     out = subprocess.run([_sys.executable, "-c", STARVE_WORKER], env=env, capture_output=True, text=True, timeout=300).stdout
     assert "RAISED True" in out and "FALLBACK-EQUAL True" in out, out
+    # ... and only for a while: after DS2_RNN_REARM_CALLS calls on the step kernels the persistent kernels are armed again
+    assert "COOLDOWN 0 (1, 2)" in out and "ARMED-AGAIN True" in out and "REARMED True" in out, out
+
+
+def test_persistent_recurrence_beside_a_busy_second_stream(dev):
+    """The persistent kernels need every workgroup resident at once.  With another stream keeping the chip busy (long GEMMs enqueued
+    first), a persistent launch has to wait for CUs: it must neither hang nor return wrong data — either it completes bit-identically to
+    the quiet run, or it reports starvation (the trainer then skips the step and the library re-arms later)."""
+    from asr_amd import _lib, ops
+    G, H, B, T = 3, 1024, 64, 60
+    torch.manual_seed(1)
+    gx = torch.randn(T * B, 2 * G * H, device=dev) * 0.5
+    whh = (torch.rand(2, G * H, H, device=dev) * 2 - 1) / H ** 0.5
+    bhh = torch.randn(2, G * H, device=dev) * 0.1
+    lens = torch.randint(T // 2, T + 1, (B,), dtype=torch.int32, device=dev)
+    lens[0] = T
+    wpf, wpb = ops.rnn_pack(G, whh, bf16=True)
+    dy = torch.randn(T * B, H, device=dev)
+
+    def run():
+        hb, aux, rec = ops.rnn_fwd(G, gx.clone(), wpf, bhh, lens, T, B, H, bf16=True, packed_gates=True)
+        side = torch.empty(T * B, 2 * G * H, dtype=torch.bfloat16, device=dev)
+        ops.rnn_bwd(G, dy, None, aux, hb, wpb, lens, T, B, H, bf16=True, dgx_bf16=side, gates_bf16=rec)
+        return hb, side
+    quiet = run()
+    torch.cuda.synchronize()
+    ops.rnn_persistent_check()
+    assert _lib.load().ds2_rnn_last_path() == 3, "the quiet run must take both persistent kernels"
+    a = torch.randn(8192, 8192, device=dev)
+    busy = torch.cuda.Stream(device=dev)
+    starved = 0
+    for rep in range(6):
+        with torch.cuda.stream(busy):
+            for _ in range(4 + rep):
+                a @ a                                      # ~1 ms of full-chip fp32 GEMM each, enqueued ahead of the recurrence
+        got = run()
+        torch.cuda.synchronize()
+        try:
+            ops.rnn_persistent_check()
+        except _lib.DS2LibraryError:
+            starved += 1
+            continue
+        assert torch.equal(got[0], quiet[0]) and torch.equal(got[1].view(torch.int16), quiet[1].view(torch.int16)), f"rep {rep}: wrong data, not reported"
+    print(f"busy second stream: {starved} of 6 runs reported starvation")
 
 
 # ---------------------------------------------------------------------------------------------- CTC

@@ -294,7 +294,16 @@ def test_evaluate_loop_decodes_on_gpu():
     sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
     probs_ref, out_lens_ref = O.forward(sd64, x.double(), lens, training=False)
     probs_ref = probs_ref.numpy()
-    wer, cer, output_data = model.evaluate(loader=[(x, targets, pct.clone(), tsz)], device="cuda", output_file=os.devnull)
+    report = os.path.join(tempfile.mkdtemp(), "eval.txt")
+    wer, cer, output_data = model.evaluate(loader=[(x, targets, pct.clone(), tsz)], device="cuda", output_file=report)
+    # the report has the reference's sections (deepspeech.py:249-271): header, BEST / LAST / WORST transcripts, 10-bucket CER histogram
+    text = open(report).read()
+    assert text.startswith(f"===== {wer:.2f}/{cer:.2f} =====") and text.rstrip().endswith("=" * 45)
+    for section in ("----- BEST -----", "----- LAST -----", "----- WORST -----", "CER histogram"):
+        assert section in text
+    assert text.count("Ref:") == 3 and text.count("Hyp:") == 3
+    rows = [ln for ln in text.splitlines() if " | " in ln]
+    assert len(rows) == 10 and sum(int(r.rsplit(" ", 1)[1]) for r in rows) == len(cfg["t_ins"])
     probs, out_sizes, target_strings = output_data[0]
     assert np.array_equal(np.asarray(out_sizes), np.asarray(out_lens_ref))
     assert rel_l2(probs, probs_ref) < TOL
