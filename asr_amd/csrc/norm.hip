@@ -338,6 +338,94 @@ __global__ __launch_bounds__(256) void bn2d_act_bwd_apply_kernel(const float* __
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// bf16-mode fusions of the BatchNorm2d passes with the layout casts that used to follow them.  One workgroup = the 32 channels x 64
+// frames tile of one (b, d) row: wave w streams channels w, w + 4, ... with 64 consecutive frames per wave-load (T = 501-style row
+// lengths leave the rows only 4-byte aligned, so the float4 path of the kernels above never triggered at the bench shapes — the plain
+// dword stream below is the coalesced form), and emits up to three copies of the result from that ONE read:
+//   f32  (B,32,D,T)   fp32      — what the fp32 consumers take (conv1's weight gradient casts dY1 on the fly)
+//   pad  (B,32,D,Tp)  bf16      — zero-padded rows (8 leading zeros, zero tail): operand of conv2_wgrad_bf16 (was ds2_padcast_bf16)
+//   nhwc (B,D,T,32)   bf16      — channels-last through LDS: operand of conv2 forward / dgrad (was ds2_nhwc_bf16_f32)
+// The backward form also leaves the per-channel sums of dY (= the conv bias gradient) as one ordered partial per workgroup
+// (deterministic two-stage reduction), instead of a further full pass over dY.
+// ------------------------------------------------------------------------------------------
+typedef __bf16 nbf16;
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn2d_tile_kernel(const float* __restrict__ Yraw, const float* __restrict__ dA, int Bn, int D, int T, int Tp,
+                                                        const int* __restrict__ lens, const float* __restrict__ mean, const float* __restrict__ var,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const float* __restrict__ s0, const float* __restrict__ s1, float eps, float inv_count,
+                                                        float* __restrict__ out_f32, nbf16* __restrict__ out_pad, nbf16* __restrict__ out_nhwc,
+                                                        float* __restrict__ chan_part) {
+  constexpr int CH = 32;
+  __shared__ float tile[CH][65];
+  const int t0 = blockIdx.x * 64, d = blockIdx.y, b = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t = t0 + lane;
+  const int len = min(lens[b], T);
+  const bool in_t = t < T, live = t < len;
+  float res[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = wave + 4 * i;
+    const long long row = ((long long)b * CH + c) * D + d;
+    const float mu = mean[c], rs = rsqrtf(var[c] + eps), ga = gamma[c], be = beta[c];
+    float r = 0.f;
+    if (in_t) {
+      const float y = Yraw[row * T + t];
+      if (!BWD) {
+        r = live ? fminf(fmaxf((y - mu) * (rs * ga) + be, 0.f), 20.f) : 0.f;
+      } else {
+        const float da = dA[row * T + t];
+        const float xh = (y - mu) * rs;
+        const float z = xh * ga + be;
+        const float dz = (live && z > 0.f && z < 20.f) ? da : 0.f;
+        r = live ? ga * rs * (dz - s0[c] * inv_count - xh * (s1[c] * inv_count)) : 0.f;
+      }
+      if (out_f32) out_f32[row * T + t] = r;
+      if (out_pad) out_pad[row * Tp + 8 + t] = (nbf16)r;
+    }
+    res[i] = r;
+    tile[c][lane] = r;
+    if (out_pad) {                                        // the row's zero frame: 8 leading zeros (first tile), tail (last tile)
+      if (blockIdx.x == 0 && lane < 8) out_pad[row * Tp + lane] = (nbf16)0.f;
+      if (blockIdx.x == gridDim.x - 1 && T + 8 + lane < Tp) out_pad[row * Tp + T + 8 + lane] = (nbf16)0.f;
+    }
+  }
+  if (BWD && chan_part) {
+    const long long blk = ((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float sum = wave_sum(res[i]);
+      if (lane == 0) chan_part[blk * CH + wave + 4 * i] = sum;
+    }
+  }
+  if (out_nhwc) {
+    __syncthreads();
+    const int c = threadIdx.x & 31, tq = threadIdx.x >> 5;   // 8 frames per pass, 32 channels = 64 contiguous bytes per frame
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int tl = tq + 8 * i, tt = t0 + tl;
+      if (tt < T) out_nhwc[(((long long)b * D + d) * T + tt) * CH + c] = (nbf16)tile[c][tl];
+    }
+  }
+}
+
+// out[c] = sum over n ordered partials part[k][c] (fp64 combine): the tile kernels' per-workgroup channel sums
+__global__ __launch_bounds__(256) void chan_part_finalize_kernel(const float* __restrict__ part, long long n, int C, float* __restrict__ out) {
+  __shared__ double red[256];
+  const int c = blockIdx.x;
+  double s = 0.0;
+  for (long long k = threadIdx.x; k < n; k += 256) s += (double)part[k * C + c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[c] = (float)red[0];
+}
+
 // (B, F, T) -> (T, B, F)  [dir 0]   or   (T, B, F) -> (B, F, T)  [dir 1] ; 32x32 LDS tiles
 __global__ __launch_bounds__(256) void transpose_bft_kernel(const float* __restrict__ src, float* __restrict__ dst, int Bn, int F, int T,
                                                             int dir) {
@@ -563,6 +651,46 @@ extern "C" int ds2_bn2d_act_bwd_f32(const float* Y, const float* dA, float* dY, 
   hipLaunchKernelGGL(bn2d_act_bwd_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, Y, dA, dY, B, C, D, T, lens_dev,
                      mean, var, gamma, beta, (const float*)dbeta, (const float*)dgamma, eps, 1.0f / ((float)B * D * T));
   DS2_LAUNCH_CHECK("bn2d_act_bwd_apply_kernel");
+  return 0;
+}
+
+// bf16-mode BatchNorm2d + Hardtanh + mask with the layout casts fused (bn2d_tile_kernel): any of a_f32 (B,32,D,T) fp32,
+// a_pad (B,32,D,Tp) bf16 [Tp = ds2_conv_padded_pitch(T)], a_nhwc (B,D,T,32) bf16 may be NULL.  C = 32 channels.
+extern "C" int ds2_bn2d_act_fwd_fused(const float* Y, int B, int D, int T, const int* lens_dev, const float* mean, const float* var,
+                                      const float* gamma, const float* beta, float eps, float* a_f32, void* a_pad, void* a_nhwc, void* stream) {
+  DS2_REQUIRE(Y && lens_dev && mean && var && gamma && beta && (a_f32 || a_pad || a_nhwc), "ds2_bn2d_act_fwd_fused: null pointer");
+  const int Tp = (T + 16 + 7) / 8 * 8;                     // = ds2_conv_padded_pitch(T) (conv_bf16.hip)
+  hipLaunchKernelGGL((bn2d_tile_kernel<false>), dim3(ceil_div(T, 64), D, B), dim3(256), 0, (hipStream_t)stream, Y, (const float*)nullptr, B, D, T, Tp,
+                     lens_dev, mean, var, gamma, beta, (const float*)nullptr, (const float*)nullptr, eps, 0.f, a_f32, (nbf16*)a_pad, (nbf16*)a_nhwc,
+                     (float*)nullptr);
+  DS2_LAUNCH_CHECK("bn2d_tile_kernel<fwd>");
+  return 0;
+}
+
+extern "C" size_t ds2_bn2d_act_bwd_fused_workspace_bytes(int B, int D, int T) {
+  return ds2_chanreduce_workspace_bytes(32) + (size_t)B * D * ceil_div(T, 64) * 32 * sizeof(float);
+}
+
+// Backward of the same block with the layout casts AND the conv bias gradient fused: dgamma, dbeta (32), dbias (32, = per-channel
+// sums of dY) and dY in any of the three forms (see ds2_bn2d_act_fwd_fused).
+extern "C" int ds2_bn2d_act_bwd_fused(const float* Y, const float* dA, int B, int D, int T, const int* lens_dev, const float* mean,
+                                      const float* var, const float* gamma, const float* beta, float eps, float* dgamma, float* dbeta,
+                                      float* dbias, float* dy_f32, void* dy_pad, void* dy_nhwc, void* ws, size_t ws_bytes, void* stream) {
+  DS2_REQUIRE(Y && dA && lens_dev && mean && var && gamma && beta && dgamma && dbeta && dbias, "ds2_bn2d_act_bwd_fused: null pointer");
+  DS2_REQUIRE(ws && ws_bytes >= ds2_bn2d_act_bwd_fused_workspace_bytes(B, D, T), "ds2_bn2d_act_bwd_fused: workspace too small");
+  const size_t red_bytes = ds2_chanreduce_workspace_bytes(32);
+  int rc = chan_reduce_launch(1, Y, dA, B, 32, D, T, lens_dev, mean, var, gamma, beta, eps, 1, dbeta, dgamma, nullptr, nullptr, 0.f, ws,
+                              red_bytes, (hipStream_t)stream);
+  if (rc) return rc;
+  float* part = reinterpret_cast<float*>(static_cast<char*>(ws) + red_bytes);
+  const int Tp = (T + 16 + 7) / 8 * 8;
+  const dim3 grid(ceil_div(T, 64), D, B);
+  hipLaunchKernelGGL((bn2d_tile_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, Y, dA, B, D, T, Tp, lens_dev, mean, var, gamma, beta,
+                     (const float*)dbeta, (const float*)dgamma, eps, 1.0f / ((float)B * D * T), dy_f32, (nbf16*)dy_pad, (nbf16*)dy_nhwc, part);
+  DS2_LAUNCH_CHECK("bn2d_tile_kernel<bwd>");
+  hipLaunchKernelGGL(chan_part_finalize_kernel, dim3(32), dim3(256), 0, (hipStream_t)stream, (const float*)part,
+                     (long long)grid.x * grid.y * grid.z, 32, dbias);
+  DS2_LAUNCH_CHECK("chan_part_finalize_kernel");
   return 0;
 }
 

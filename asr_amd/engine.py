@@ -69,7 +69,8 @@ class Ctx:
     x: Optional[Tensor] = None
     lens_dev: Optional[Tensor] = None
     y1: Optional[Tensor] = None
-    a1: Optional[Tensor] = None
+    a1: Optional[Tensor] = None      # fp32 Hardtanh(BN(conv1)) (fp32 mode; bf16 mode keeps only a1p)
+    a1p: Optional[Tensor] = None     # bf16 mode: its zero-padded bf16 copy, operand of conv2's weight gradient
     y2: Optional[Tensor] = None
     st1: tuple = ()
     st2: tuple = ()
@@ -81,7 +82,7 @@ class Ctx:
     fc_stats: tuple = ()
 
 
-def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, training: bool, save: bool = True):
+def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, training: bool, save: bool = True, debug_acts: bool = False):
     """x (B,1,F,Tin) fp32 GPU; lens_dev int32 (B,) GPU = output frame counts.  Returns (logits (T,B,C), ctx)."""
     if not x.is_cuda:
         raise _lib.DS2LibraryError("asr_amd.engine.forward needs a GPU tensor: the MI355X kernels are the only implementation "
@@ -112,12 +113,17 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
         m1, v1 = ops.bn2d_stats(y1, *run(cp + "1"))
     else:
         m1, v1 = W[cp + "1.running_mean"], W[cp + "1.running_var"]
-    a1 = ops.bn2d_act_fwd(y1, lens_dev, m1, v1, W[cp + "1.weight"], W[cp + "1.bias"])
     if cfg.precision == "bf16":
+        # one pass over y1 emits conv2's channels-last operand and (when backward follows) the zero-padded operand of conv2's weight
+        # gradient; the fp32 activation itself has no consumer in this mode (debug_acts keeps it for the tests that inspect it)
+        a1, a1p, a1n = ops.bn2d_act_fwd_fused(y1, lens_dev, m1, v1, W[cp + "1.weight"], W[cp + "1.bias"], want_f32=debug_acts, want_pad=save,
+                                              want_nhwc=True)
         cwf, cwd0, cwd1 = ops.conv2_pack_bf16(W[cp + "3.weight"])
         ctx.packs = (wpk2d, cwd0, cwd1)
-        y2 = ops.conv2_fwd_bf16(ops.nhwc_bf16(a1), cwf, W[cp + "3.bias"], lens_dev)
+        y2 = ops.conv2_fwd_bf16(a1n, cwf, W[cp + "3.bias"], lens_dev)
+        del a1n
     else:
+        a1, a1p = ops.bn2d_act_fwd(y1, lens_dev, m1, v1, W[cp + "1.weight"], W[cp + "1.bias"]), None
         y2 = ops.conv2_fwd(a1, wpk2, W[cp + "3.bias"], lens_dev)
     if training:
         m2, v2 = ops.bn2d_stats(y2, *run(cp + "4"))
@@ -127,7 +133,7 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
     xin = ops.transpose_bft(a2, B, 32 * D2, T, to_tbf=True).view(M, 32 * D2)   # (T*B, 1312), feature = c*D2 + d
     del a2
     if save:
-        ctx.y1, ctx.a1, ctx.y2, ctx.st1, ctx.st2 = y1, a1, y2, (m1, v1), (m2, v2)
+        ctx.y1, ctx.a1, ctx.a1p, ctx.y2, ctx.st1, ctx.st2 = y1, a1, a1p, y2, (m1, v1), (m2, v2)
 
     # ---- recurrent stack ------------------------------------------------------------------------
     mean = var = None
@@ -298,26 +304,33 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
     cp = "conv.seq_module."
     da2 = ops.transpose_bft(dy, B, 32 * D2, T, to_tbf=False).view(B, 32, D2, T)
     m2, v2 = ctx.st2
-    dy2 = ops.bn2d_act_bwd(ctx.y2, da2, lens_dev, m2, v2, W[cp + "4.weight"], W[cp + "4.bias"], Gr[cp + "4.weight"], Gr[cp + "4.bias"])
-    del da2
-    Gr[cp + "3.bias"].copy_(ops.chan_sum(dy2))
-    if cfg.precision == "bf16":
-        ops.conv2_wgrad_bf16(ops.padcast_bf16(ctx.a1), ops.padcast_bf16(dy2), lens_dev, Gr[cp + "3.weight"], T)
-    else:
-        ops.conv2_wgrad(ctx.a1, dy2, lens_dev, Gr[cp + "3.weight"])
-    if cfg.precision == "bf16":
-        da1 = ops.conv2_dgrad_bf16(ops.nhwc_bf16(dy2), ctx.packs[1], ctx.packs[2], D1)
-    else:
-        da1 = ops.conv2_dgrad(dy2, ctx.packs[0], D1)
-    del dy2
-    m1, v1 = ctx.st1
-    dy1 = ops.bn2d_act_bwd(ctx.y1, da1, lens_dev, m1, v1, W[cp + "1.weight"], W[cp + "1.bias"], Gr[cp + "1.weight"], Gr[cp + "1.bias"])
-    del da1
-    Gr[cp + "0.bias"].copy_(ops.chan_sum(dy1))
-    if cfg.precision == "bf16":
+    bf = cfg.precision == "bf16"
+    if bf:
+        # dY2 leaves the BatchNorm backward directly as the two bf16 operands conv2's weight gradient / input gradient take, together
+        # with conv2's bias gradient (its per-channel sums); conv1's stage keeps fp32 dY1 (cast on the fly by conv1's weight gradient)
+        _, dy2p, dy2n = ops.bn2d_act_bwd_fused(ctx.y2, da2, lens_dev, m2, v2, W[cp + "4.weight"], W[cp + "4.bias"], Gr[cp + "4.weight"],
+                                               Gr[cp + "4.bias"], Gr[cp + "3.bias"], want_pad=True, want_nhwc=True)
+        del da2
+        ops.conv2_wgrad_bf16(ctx.a1p, dy2p, lens_dev, Gr[cp + "3.weight"], T)
+        da1 = ops.conv2_dgrad_bf16(dy2n, ctx.packs[1], ctx.packs[2], D1)
+        del dy2p, dy2n
+        m1, v1 = ctx.st1
+        dy1, _, _ = ops.bn2d_act_bwd_fused(ctx.y1, da1, lens_dev, m1, v1, W[cp + "1.weight"], W[cp + "1.bias"], Gr[cp + "1.weight"],
+                                           Gr[cp + "1.bias"], Gr[cp + "0.bias"], want_f32=True)
+        del da1
         ops.conv1_wgrad_bf16(ctx.x16t, dy1, lens_dev, Gr[cp + "0.weight"], ctx.x.shape[3])
         ctx.x16t = None
     else:
+        dy2 = ops.bn2d_act_bwd(ctx.y2, da2, lens_dev, m2, v2, W[cp + "4.weight"], W[cp + "4.bias"], Gr[cp + "4.weight"], Gr[cp + "4.bias"])
+        del da2
+        Gr[cp + "3.bias"].copy_(ops.chan_sum(dy2))
+        ops.conv2_wgrad(ctx.a1, dy2, lens_dev, Gr[cp + "3.weight"])
+        da1 = ops.conv2_dgrad(dy2, ctx.packs[0], D1)
+        del dy2
+        m1, v1 = ctx.st1
+        dy1 = ops.bn2d_act_bwd(ctx.y1, da1, lens_dev, m1, v1, W[cp + "1.weight"], W[cp + "1.bias"], Gr[cp + "1.weight"], Gr[cp + "1.bias"])
+        del da1
+        Gr[cp + "0.bias"].copy_(ops.chan_sum(dy1))
         ops.conv1_wgrad(ctx.x, dy1, lens_dev, Gr[cp + "0.weight"])
     done("conv")
     if side is not main:

@@ -335,6 +335,40 @@ def bn2d_act_bwd(Y: Tensor, dA: Tensor, lens_dev: Tensor, mean, var, gamma, beta
     return dY
 
 
+def bn2d_act_fwd_fused(Y: Tensor, lens_dev: Tensor, mean, var, gamma, beta, want_f32=False, want_pad=False, want_nhwc=False):
+    """bf16 mode: BatchNorm2d + Hardtanh + mask with the layout casts fused (csrc/norm.hip: bn2d_tile_kernel).  Returns
+    (a_f32 (B,32,D,T) | None, a_pad (B,32,D,Tp) bf16 | None, a_nhwc (B,D,T,32) bf16 | None)."""
+    _chk_f32(Y, mean, var, gamma, beta)
+    lib = _lib.load()
+    B, Cc, D, T = Y.shape
+    assert Cc == 32 and Y.is_contiguous() and (want_f32 or want_pad or want_nhwc)
+    a32 = torch.empty_like(Y) if want_f32 else None
+    apad = torch.empty(B, 32, D, lib.ds2_conv_padded_pitch(T), dtype=torch.bfloat16, device=Y.device) if want_pad else None
+    anh = torch.empty(B, D, T, 32, dtype=torch.bfloat16, device=Y.device) if want_nhwc else None
+    _lib.check(lib.ds2_bn2d_act_fwd_fused(Y.data_ptr(), B, D, T, lens_dev.data_ptr(), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(),
+                                          beta.data_ptr(), BN_EPS, _ptr(a32), _ptr(apad), _ptr(anh), _stream()), "ds2_bn2d_act_fwd_fused")
+    return a32, apad, anh
+
+
+def bn2d_act_bwd_fused(Y: Tensor, dA: Tensor, lens_dev: Tensor, mean, var, gamma, beta, dgamma: Tensor, dbeta: Tensor, dbias: Tensor,
+                       want_f32=False, want_pad=False, want_nhwc=False):
+    """bf16 mode: backward of the same block; writes dgamma / dbeta / dbias (the bias gradient of the convolution in front) in place and
+    returns dY as (fp32 | None, zero-padded bf16 | None, channels-last bf16 | None)."""
+    _chk_f32(Y, dA, mean, var, gamma, beta, dgamma, dbeta, dbias)
+    lib = _lib.load()
+    B, Cc, D, T = Y.shape
+    assert Cc == 32 and Y.is_contiguous() and dA.is_contiguous() and dA.shape == Y.shape
+    d32 = torch.empty_like(Y) if want_f32 else None
+    dpad = torch.empty(B, 32, D, lib.ds2_conv_padded_pitch(T), dtype=torch.bfloat16, device=Y.device) if want_pad else None
+    dnh = torch.empty(B, D, T, 32, dtype=torch.bfloat16, device=Y.device) if want_nhwc else None
+    wsb = lib.ds2_bn2d_act_bwd_fused_workspace_bytes(B, D, T)
+    ws = _ws(wsb, Y.device)
+    _lib.check(lib.ds2_bn2d_act_bwd_fused(Y.data_ptr(), dA.data_ptr(), B, D, T, lens_dev.data_ptr(), mean.data_ptr(), var.data_ptr(),
+                                          gamma.data_ptr(), beta.data_ptr(), BN_EPS, dgamma.data_ptr(), dbeta.data_ptr(), dbias.data_ptr(),
+                                          _ptr(d32), _ptr(dpad), _ptr(dnh), ws.data_ptr(), wsb, _stream()), "ds2_bn2d_act_bwd_fused")
+    return d32, dpad, dnh
+
+
 def chan_sum(Y: Tensor) -> Tensor:
     """per-channel sum over (B, D, T) of a (B,C,D,T) tensor (bias gradients)."""
     mean, _ = bn2d_stats(Y)

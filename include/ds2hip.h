@@ -91,6 +91,17 @@ int ds2_bn2d_act_fwd_f32(const float* Y, float* A, int B, int C, int D, int T, c
 int ds2_bn2d_act_bwd_f32(const float* Y, const float* dA, float* dY, int B, int C, int D, int T, const int* lens_dev, const float* mean,
                          const float* var, const float* gamma, const float* beta, float eps, float* dgamma, float* dbeta, void* ws,
                          size_t ws_bytes, void* stream);
+
+/* bf16 mode: the same two blocks with the layout casts that follow them fused into the pass (deepspeech.py:62-66 + the operand
+ * preparation of conv2 forward / dgrad / wgrad): each result may be written as fp32 (B,32,D,T), as zero-padded bf16 rows
+ * (B,32,D,Tp), Tp = ds2_conv_padded_pitch(T), and as channels-last bf16 (B,D,T,32) — NULL skips a form.  The backward form also
+ * returns dbias (32) = per-channel sums of dY, the gradient of the bias of the convolution in front (deepspeech.py:61,64). */
+int ds2_bn2d_act_fwd_fused(const float* Y, int B, int D, int T, const int* lens_dev, const float* mean, const float* var,
+                           const float* gamma, const float* beta, float eps, float* a_f32, void* a_pad, void* a_nhwc, void* stream);
+size_t ds2_bn2d_act_bwd_fused_workspace_bytes(int B, int D, int T);
+int ds2_bn2d_act_bwd_fused(const float* Y, const float* dA, int B, int D, int T, const int* lens_dev, const float* mean,
+                           const float* var, const float* gamma, const float* beta, float eps, float* dgamma, float* dbeta,
+                           float* dbias, float* dy_f32, void* dy_pad, void* dy_nhwc, void* ws, size_t ws_bytes, void* stream);
 /* dir 0: (B,F,T) -> (T,B,F) = view+transpose+contiguous of modules/deepspeech.py:135-137; dir 1: inverse */
 int ds2_transpose_bft_f32(const float* src, float* dst, int B, int F, int T, int dir, void* stream);
 int ds2_transpose2d_f32(const float* src, int ld_src, long long stride_src, float* dst, int ld_dst, long long stride_dst, int R, int Cc,

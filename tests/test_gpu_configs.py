@@ -194,7 +194,7 @@ def _grads_of(model, precision, x, targets, pct, tsz, sd0):
     W = model._flat.tensors(model)
     Gr = model._flat.tensors(model, grads=True)
     with torch.no_grad():
-        logits, ctx = engine.forward(W, model._cfg, x.to(dev), lens_dev, training=True, save=True)
+        logits, ctx = engine.forward(W, model._cfg, x.to(dev), lens_dev, training=True, save=True, debug_acts=True)
         nll, dlogits = ops.ctc_loss(logits, tg, off, lens_dev, tl, max_u, 1.0 / B, want_grad=True)
         # Hardtanh outputs of the two conv stages (a2 in its (T*B, 1312) layout): exactly 0 or 20 where the branch was clamped
         a1, a2 = ctx.a1.clone(), ctx.layers[0].xin.clone()

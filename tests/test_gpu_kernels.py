@@ -176,6 +176,22 @@ def test_bn2d_act(dev, B, D, T, lens):
     assert rel_l2(dY.cpu(), Yr.grad) < 3e-5
     assert rel_l2(dg_.cpu(), gr.grad) < 2e-5 and rel_l2(db_.cpu(), br.grad) < 2e-5
     assert rel_l2(ops.chan_sum(g(Y.float(), dev)).cpu(), Y.sum((0, 2, 3))) < 1e-5
+    # bf16-mode fused forms (one tile pass emits fp32 / zero-padded bf16 / channels-last bf16 copies; backward adds the conv bias gradient):
+    # same values as the separate kernels, the bf16 copies = the fp32 result rounded once, the layouts those of padcast_bf16 / nhwc_bf16
+    Yd, dAd, gd, bd = g(Y.float(), dev), g(dA.float(), dev), g(gam.float(), dev), g(bet.float(), dev)
+    a32, apad, anh = ops.bn2d_act_fwd_fused(Yd, ld, mean, var, gd, bd, want_f32=True, want_pad=True, want_nhwc=True)
+    assert rel_l2(a32.cpu(), a.detach()) < 1e-5 and float((a32 - A).abs().max()) <= 1e-5
+    assert torch.equal(apad, ops.padcast_bf16(a32)) and torch.equal(anh, ops.nhwc_bf16(a32))
+    only_nhwc = ops.bn2d_act_fwd_fused(Yd, ld, mean, var, gd, bd, want_nhwc=True)
+    assert only_nhwc[0] is None and only_nhwc[1] is None and torch.equal(only_nhwc[2], anh)
+    dg2, db2, dbias = torch.empty(C, device=dev), torch.empty(C, device=dev), torch.empty(C, device=dev)
+    d32, dpad, dnh = ops.bn2d_act_bwd_fused(Yd, dAd, ld, mean, var, gd, bd, dg2, db2, dbias, want_f32=True, want_pad=True, want_nhwc=True)
+    assert rel_l2(d32.cpu(), Yr.grad) < 3e-5 and torch.equal(dg2, dg_) and torch.equal(db2, db_)
+    assert torch.equal(dpad, ops.padcast_bf16(d32)) and torch.equal(dnh, ops.nhwc_bf16(d32))
+    assert rel_l2(dbias.cpu(), Yr.grad.sum((0, 2, 3))) < 2e-5 * max(1.0, float(Yr.grad.abs().sum((0, 2, 3)).max() / Yr.grad.sum((0, 2, 3)).abs().max()))
+    dbias2 = torch.empty(C, device=dev)
+    ops.bn2d_act_bwd_fused(Yd, dAd, ld, mean, var, gd, bd, dg2, db2, dbias2, want_pad=True)
+    assert torch.equal(dbias2, dbias)                                   # ordered two-stage sums: run-to-run identical
 
 
 def test_transposes(dev):
