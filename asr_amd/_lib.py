@@ -48,6 +48,7 @@ SIGNATURES = {
     "ds2_bn2d_act_fwd_f32": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, f32, vp]),
     "ds2_bn2d_act_bwd_f32": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, f32, vp, vp, vp, sz, vp]),
     "ds2_bn2d_act_fwd_fused": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp]),
+    "ds2_bn2d_act_collapse": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp]),
     "ds2_bn2d_act_bwd_fused_workspace_bytes": (sz, [i32, i32, i32]),
     "ds2_bn2d_act_bwd_fused": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "ds2_transpose_bft_f32": (i32, [vp, vp, i32, i32, i32, i32, vp]),

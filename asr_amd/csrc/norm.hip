@@ -411,6 +411,43 @@ __global__ __launch_bounds__(256) void bn2d_tile_kernel(const float* __restrict_
   }
 }
 
+// bf16 mode, second conv stage: BatchNorm2d + Hardtanh + mask fused with the (B, 32*D, T) -> (T, B, 32*D) collapse (deepspeech.py:135-137)
+// and the cast to the first recurrent layer's bf16 GEMM operand — one pass over y2 instead of three (BN apply, transpose, cast).
+// 32 features x 32 frames LDS tiles; feature f = c*D + d, so the BatchNorm parameters are per tile ROW.
+__global__ __launch_bounds__(256) void bn2d_act_collapse_kernel(const float* __restrict__ Yraw, int Bn, int D, int T, const int* __restrict__ lens,
+                                                                const float* __restrict__ mean, const float* __restrict__ var,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                                float* __restrict__ out_f32, nbf16* __restrict__ out_bf, int ldb) {
+  __shared__ float tile[32][33];
+  const int F = 32 * D;
+  const int b = blockIdx.z;
+  const int f0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int len = min(lens[b], T);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int f = f0 + ty + 8 * i, t = t0 + tx;
+    float a = 0.f;
+    if (f < F && t < len) {
+      const int c = f / D;
+      const float y = Yraw[((long long)b * F + f) * T + t];
+      a = fminf(fmaxf((y - mean[c]) * (rsqrtf(var[c] + eps) * gamma[c]) + beta[c], 0.f), 20.f);
+    }
+    tile[ty + 8 * i][tx] = a;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int t = t0 + ty + 8 * i, f = f0 + tx;
+    if (f < F && t < T) {
+      const float a = tile[tx][ty + 8 * i];
+      const long long row = (long long)t * Bn + b;
+      if (out_f32) out_f32[row * F + f] = a;
+      if (out_bf) out_bf[row * ldb + f] = (nbf16)a;
+    }
+  }
+}
+
 // out[c] = sum over n ordered partials part[k][c] (fp64 combine): the tile kernels' per-workgroup channel sums
 __global__ __launch_bounds__(256) void chan_part_finalize_kernel(const float* __restrict__ part, long long n, int C, float* __restrict__ out) {
   __shared__ double red[256];
@@ -664,6 +701,18 @@ extern "C" int ds2_bn2d_act_fwd_fused(const float* Y, int B, int D, int T, const
                      lens_dev, mean, var, gamma, beta, (const float*)nullptr, (const float*)nullptr, eps, 0.f, a_f32, (nbf16*)a_pad, (nbf16*)a_nhwc,
                      (float*)nullptr);
   DS2_LAUNCH_CHECK("bn2d_tile_kernel<fwd>");
+  return 0;
+}
+
+// x (T*B, 32*D) = collapse(mask(hardtanh(BN(Y)))) as fp32 (pitch 32*D; may be NULL) and / or bf16 (pitch ld_bf >= 32*D, ld_bf % 8 == 0, pad
+// columns zeroed by the caller's allocation: with D = 41, 32*D = 1312 is its own multiple of 8; may be NULL)
+extern "C" int ds2_bn2d_act_collapse(const float* Y, int B, int D, int T, const int* lens_dev, const float* mean, const float* var,
+                                     const float* gamma, const float* beta, float eps, float* x_f32, void* x_bf16, int ld_bf, void* stream) {
+  DS2_REQUIRE(Y && lens_dev && mean && var && gamma && beta && (x_f32 || x_bf16), "ds2_bn2d_act_collapse: null pointer");
+  DS2_REQUIRE(!x_bf16 || (ld_bf >= 32 * D && (ld_bf % 8) == 0), "ds2_bn2d_act_collapse: bad bf16 pitch %d", ld_bf);
+  hipLaunchKernelGGL(bn2d_act_collapse_kernel, dim3(ceil_div(T, 32), D, B), dim3(256), 0, (hipStream_t)stream, Y, B, D, T, lens_dev, mean, var,
+                     gamma, beta, eps, x_f32, (nbf16*)x_bf16, ld_bf);
+  DS2_LAUNCH_CHECK("bn2d_act_collapse_kernel");
   return 0;
 }
 

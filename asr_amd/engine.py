@@ -129,9 +129,14 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
         m2, v2 = ops.bn2d_stats(y2, *run(cp + "4"))
     else:
         m2, v2 = W[cp + "4.running_mean"], W[cp + "4.running_var"]
-    a2 = ops.bn2d_act_fwd(y2, lens_dev, m2, v2, W[cp + "4.weight"], W[cp + "4.bias"])
-    xin = ops.transpose_bft(a2, B, 32 * D2, T, to_tbf=True).view(M, 32 * D2)   # (T*B, 1312), feature = c*D2 + d
-    del a2
+    xn0 = None
+    if cfg.precision == "bf16":
+        # BN + Hardtanh + mask + collapse + cast in one pass: layer 0 takes the bf16 operand; nobody needs the fp32 form
+        xin, xn0 = ops.bn2d_act_collapse(y2, lens_dev, m2, v2, W[cp + "4.weight"], W[cp + "4.bias"], want_f32=debug_acts)
+    else:
+        a2 = ops.bn2d_act_fwd(y2, lens_dev, m2, v2, W[cp + "4.weight"], W[cp + "4.bias"])
+        xin = ops.transpose_bft(a2, B, 32 * D2, T, to_tbf=True).view(M, 32 * D2)   # (T*B, 1312), feature = c*D2 + d
+        del a2
     if save:
         ctx.y1, ctx.a1, ctx.a1p, ctx.y2, ctx.st1, ctx.st2 = y1, a1, a1p, y2, (m1, v1), (m2, v2)
 
@@ -147,7 +152,7 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
             xn = (ops.bn1d_apply_bf16 if cfg.precision == "bf16" else ops.bn1d_apply)(xin, mean, var, W[bp + "weight"], W[bp + "bias"])
             lc.mean, lc.var = mean, var
         else:
-            xn = ops.cast_bf16(xin) if cfg.precision == "bf16" else xin
+            xn = xn0 if cfg.precision == "bf16" else xin
         if cfg.precision == "bf16":
             gx = ops.gemm_bf16_nt(xn, ops.cast_bf16(W[f"rnns.{l}.wih_cat"]), bias=W[f"rnns.{l}.bih_cat"])
         else:

@@ -350,6 +350,23 @@ def bn2d_act_fwd_fused(Y: Tensor, lens_dev: Tensor, mean, var, gamma, beta, want
     return a32, apad, anh
 
 
+def bn2d_act_collapse(Y: Tensor, lens_dev: Tensor, mean, var, gamma, beta, want_f32=False, want_bf16=True):
+    """bf16 mode: BatchNorm2d + Hardtanh + mask + (B,32*D,T) -> (T*B, 32*D) collapse (+ cast) in one pass over the conv output.
+    Returns (x fp32 (T*B, 32*D) | None, x bf16 (T*B, pad8(32*D)) | None)."""
+    _chk_f32(Y, mean, var, gamma, beta)
+    B, Cc, D, T = Y.shape
+    assert Cc == 32 and Y.is_contiguous() and (want_f32 or want_bf16)
+    F = 32 * D
+    x32 = torch.empty(T * B, F, dtype=torch.float32, device=Y.device) if want_f32 else None
+    xbf = None
+    if want_bf16:
+        xbf = (torch.empty if _pad8(F) == F else torch.zeros)(T * B, _pad8(F), dtype=torch.bfloat16, device=Y.device)
+    _lib.check(_lib.load().ds2_bn2d_act_collapse(Y.data_ptr(), B, D, T, lens_dev.data_ptr(), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(),
+                                                 beta.data_ptr(), BN_EPS, _ptr(x32), _ptr(xbf), xbf.size(1) if xbf is not None else 0, _stream()),
+               "ds2_bn2d_act_collapse")
+    return x32, xbf
+
+
 def bn2d_act_bwd_fused(Y: Tensor, dA: Tensor, lens_dev: Tensor, mean, var, gamma, beta, dgamma: Tensor, dbeta: Tensor, dbias: Tensor,
                        want_f32=False, want_pad=False, want_nhwc=False):
     """bf16 mode: backward of the same block; writes dgamma / dbeta / dbias (the bias gradient of the convolution in front) in place and

@@ -184,6 +184,10 @@ def test_bn2d_act(dev, B, D, T, lens):
     assert torch.equal(apad, ops.padcast_bf16(a32)) and torch.equal(anh, ops.nhwc_bf16(a32))
     only_nhwc = ops.bn2d_act_fwd_fused(Yd, ld, mean, var, gd, bd, want_nhwc=True)
     assert only_nhwc[0] is None and only_nhwc[1] is None and torch.equal(only_nhwc[2], anh)
+    # second-stage form: the same block + (B, C*D, T) -> (T*B, C*D) collapse + bf16 cast in one pass
+    x32, xbf = ops.bn2d_act_collapse(Yd, ld, mean, var, gd, bd, want_f32=True)
+    ref_x = ops.transpose_bft(a32, B, C * D, T, True).view(T * B, C * D)
+    assert float((x32 - ref_x).abs().max()) <= 1e-5 and torch.equal(xbf[:, :C * D], x32.bfloat16()) and float(xbf[:, C * D:].float().abs().sum()) == 0
     dg2, db2, dbias = torch.empty(C, device=dev), torch.empty(C, device=dev), torch.empty(C, device=dev)
     d32, dpad, dnh = ops.bn2d_act_bwd_fused(Yd, dAd, ld, mean, var, gd, bd, dg2, db2, dbias, want_f32=True, want_pad=True, want_nhwc=True)
     assert rel_l2(d32.cpu(), Yr.grad) < 3e-5 and torch.equal(dg2, dg_) and torch.equal(db2, db_)
