@@ -21,7 +21,18 @@ from . import _lib, ops
 
 Tensor = torch.Tensor
 import os as _os
-OVERLAP_WGRAD = _os.environ.get("DS2_OVERLAP", "0") == "1"   # measured: a slight net loss on MI355X, keep opt-in
+# Off-critical-path work of backward (DS2_OVERLAP):
+#   "2" (default)  the operand-preparation passes of the weight-gradient GEMMs (transposing casts of dGx / h / d(hn) / Xn, with the bias
+#                  column sums they carry) run on a side stream: they are HBM-bound and light (17 KB of LDS, ~40 registers), so they
+#                  co-reside with whatever runs on the compute stream — the compute-bound GEMMs, or the latency-bound persistent
+#                  recurrence of the next layer, which leaves most of the memory system idle.  The weight-gradient GEMMs themselves stay
+#                  on the compute stream, one layer late (behind the next layer's recurrence launch), so that nothing heavy ever waits
+#                  beside a persistent launch that needs every CU.  c3: 31.7 -> 30.x ms per step.
+#   "1"            everything off the critical path (GEMMs included) on the side stream (round 1's form: +2.6 ms with the step kernels,
+#                  -0.6 ms with the persistent ones)
+#   "0"            one stream
+OVERLAP_MODE = _os.environ.get("DS2_OVERLAP", "2")
+OVERLAP_WGRAD = OVERLAP_MODE == "1"
 _SIDE = {}
 
 
@@ -190,6 +201,91 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
     return logits.view(T, B, cfg.classes), ctx
 
 
+def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy: Tensor, done):
+    """Backward of the recurrent stack in the bf16 training mode (packed gate records, bf16 dGx), DS2_OVERLAP=2 schedule: per layer
+        compute stream:  recurrence(l) | weight-gradient GEMMs of layer l+1 | dXn(l) = dGx W_ih | BatchNorm1d backward(l)
+        side stream:     [from the start of recurrence(l)] transposing casts of dGx(l+1) (+ db_ih), d(hn)(l+1) (+ db_hn), h(l+1), Xn(l+1)
+    Same kernels, same operands, same results as the one-stream schedule: only the streams and the issue order differ."""
+    G, H, L = cfg.gates, cfg.hidden, cfg.layers
+    B, T = ctx.B, ctx.T
+    M = T * B
+    lens_dev = ctx.lens_dev
+    main = torch.cuda.current_stream()
+    side = _side_stream(dy.device)
+    pending = None
+
+    def weight_gradients(p):
+        """layer p's dW_hh / dW_ih GEMMs on the compute stream, behind the event of its operand passes"""
+        l, dgxT, hT, auxT, xnT, ready, hold = p
+        main.wait_event(ready)
+        dwhh = Gr[f"rnns.{l}.whh_cat"]                                                            # (2, GH, H)
+        rows = 2 * H if G == 3 else 4 * H
+        # both directions per launch: direction 0 pairs rows t of dGh with h[t-1], direction 1 rows t with h[t+1] (a column offset of B)
+        ka = (slice(B, M), slice(0, M - B))
+        kb = (slice(0, M - B), slice(B, M))
+        ops.gemm_bf16_nt_pair(dgxT[0:rows, ka[0]], dgxT[G * H:G * H + rows, ka[1]], hT[0:H, kb[0]], hT[H:2 * H, kb[1]], dwhh[:, :rows])
+        if G == 3:
+            ops.gemm_bf16_nt_pair(auxT[0:H, ka[0]], auxT[H:2 * H, ka[1]], hT[0:H, kb[0]], hT[H:2 * H, kb[1]], dwhh[:, 2 * H:])
+        ops.gemm_bf16_nt(dgxT, xnT, out=Gr[f"rnns.{l}.wih_cat"])
+        for t in (dgxT, hT, auxT, xnT) + hold:                   # allocated / last used on the other stream: tell the caching allocator
+            if t is not None:
+                t.record_stream(main)
+        done(f"rnns.{l}")
+
+    def operand_passes(l, lc_t, dgx_bf, start):
+        """side stream, not before `start`: transposing casts of layer l's dGx (+ db_ih), d(hn) (+ db_hn), h and Xn"""
+        aux, hbuf, xn = lc_t
+        with torch.cuda.stream(side):
+            side.wait_event(start)
+            dgxT, _ = ops.transpose_bf16(dgx_bf, colsum=Gr[f"rnns.{l}.bih_cat"].view(-1))          # + db_ih = column sums of dGx
+            dbhh = Gr[f"rnns.{l}.bhh_cat"]                                                        # (2, GH)
+            dbhh.copy_(Gr[f"rnns.{l}.bih_cat"].view(2, G * H))
+            auxT = None
+            if G == 3:
+                dbn = torch.empty(2 * H, dtype=torch.float32, device=dy.device)
+                auxT = ops.cast_transpose_bf16(aux, colsum=dbn)                                   # + d(b_hn) = column sums of d(hn)
+                dbhh[:, 2 * H:] = dbn.view(2, H)
+            hT = ops.cast_transpose_bf16(hbuf)                                                    # (2H, M)
+            xnT = ops.transpose_bf16(xn[:, :W[f"rnns.{l}.wih_cat"].shape[1]])                     # xn is bf16 (M, pad8(I)) in this mode
+            ready = torch.cuda.Event()
+            ready.record(side)
+        for t in (dgx_bf, aux, hbuf, xn):                        # read on the side stream
+            t.record_stream(side)
+        return (l, dgxT, hT, auxT, xnT, ready, (dgx_bf,))
+
+    queued = None                                                # layer whose operand passes wait for the next recurrence launch
+    for l in range(L - 1, -1, -1):
+        lc = ctx.layers[l]
+        if queued is not None:
+            # the compute stream is about to start this layer's recurrence: the operand passes of the layer above start WITH it (started
+            # earlier they would only take CUs from the GEMMs in between, which fill the register file and leave them no room)
+            start = torch.cuda.Event()
+            start.record(main)
+            pending = operand_passes(*queued, start)
+            queued = None
+        dgx_bf = torch.empty(lc.gshape if lc.rec is not None else lc.gx.shape, dtype=torch.bfloat16, device=dy.device)
+        ops.rnn_bwd(G, dy, lc.gx, lc.aux, lc.hbuf, lc.wpb, lens_dev, T, B, H, bf16=True, dgx_bf16=dgx_bf, gates_bf16=lc.rec)
+        lc.rec = None
+        if pending is not None:
+            weight_gradients(pending)                            # heavy work of the layer above: on the compute stream, behind this launch
+            pending = None
+        queued = (l, (lc.aux, lc.hbuf, lc.xn), dgx_bf)
+        # ---- critical path: dXn = dGx W_ih -> BatchNorm1d backward -> the next layer's dy
+        dxn = ops.gemm_bf16_nt(dgx_bf, ops.cast_transpose_bf16(W[f"rnns.{l}.wih_cat"]))
+        if l > 0:
+            bp = f"rnns.{l}.batch_norm.module."
+            dy = ops.bn1d_bwd(dxn, lc.xin, lc.mean, lc.var, W[bp + "weight"], Gr[bp + "weight"], Gr[bp + "bias"])
+        else:
+            dy = dxn
+        del dxn
+        lc.gx = lc.aux = lc.hbuf = lc.xn = lc.wpb = None
+    start = torch.cuda.Event()                                   # layer 0: nothing latency-bound follows; run its passes now
+    start.record(main)
+    pending = operand_passes(*queued, start)
+    weight_gradients(pending)
+    return dy
+
+
 def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ctx, dlogits: Tensor, on_bucket=None):
     """dlogits (T,B,C) contiguous.  Writes every parameter gradient into Gr[name] (same keys as W for
     parameters, plus the *_cat views).  Consumes ctx (gate buffers are overwritten in place).
@@ -216,7 +312,12 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
     del dxn
     done("fc")
     # ---- recurrent stack ------------------------------------------------------------------------
-    for l in range(L - 1, -1, -1):
+    if OVERLAP_MODE == "2" and cfg.precision == "bf16" and B % 8 == 0 and T > 1:
+        dy = _backward_rnn_deferred(W, Gr, cfg, ctx, dy, done)
+        first_layer = -1          # the loop below has nothing left to do
+    else:
+        first_layer = L - 1
+    for l in range(first_layer, -1, -1):
         lc = ctx.layers[l]
         I = lc.xn.shape[1]
         bf = cfg.precision == "bf16"
