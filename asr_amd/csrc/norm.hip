@@ -448,19 +448,29 @@ __global__ __launch_bounds__(256) void bn2d_act_collapse_kernel(const float* __r
   }
 }
 
-// out[c] = sum over n ordered partials part[k][c] (fp64 combine): the tile kernels' per-workgroup channel sums
-__global__ __launch_bounds__(256) void chan_part_finalize_kernel(const float* __restrict__ part, long long n, int C, float* __restrict__ out) {
-  __shared__ double red[256];
-  const int c = blockIdx.x;
+// out[c] = sum over n ordered partials part[k][c] (fp64 combine): the tile kernels' per-workgroup channel sums (C = 32).
+// Two ordered stages with coalesced reads: stage 0, block j sums rows [j*rpb, (j+1)*rpb) of the (n, 32) partial matrix into tmp[j][c]
+// (lanes = channels: every wave-load is one contiguous 128-byte row piece); stage 1, one block sums the tmp rows.
+__global__ __launch_bounds__(256) void chan_part_finalize_kernel(const float* __restrict__ part, long long n, long long rpb, double* __restrict__ tmp,
+                                                                 int nblk, float* __restrict__ out, int stage) {
+  __shared__ double red[8][32];
+  const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
   double s = 0.0;
-  for (long long k = threadIdx.x; k < n; k += 256) s += (double)part[k * C + c];
-  red[threadIdx.x] = s;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-    __syncthreads();
+  if (stage == 0) {
+    const long long k0 = (long long)blockIdx.x * rpb, k1 = k0 + rpb < n ? k0 + rpb : n;
+    for (long long k = k0 + r; k < k1; k += 8) s += (double)part[k * 32 + c];
+  } else {
+    for (int k = r; k < nblk; k += 8) s += tmp[(long long)k * 32 + c];
   }
-  if (threadIdx.x == 0) out[c] = (float)red[0];
+  red[r][c] = s;
+  __syncthreads();
+  if (r == 0) {
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += red[i][c];
+    if (stage == 0) tmp[(long long)blockIdx.x * 32 + c] = t;
+    else out[c] = (float)t;
+  }
 }
 
 // (B, F, T) -> (T, B, F)  [dir 0]   or   (T, B, F) -> (B, F, T)  [dir 1] ; 32x32 LDS tiles
@@ -716,8 +726,9 @@ extern "C" int ds2_bn2d_act_collapse(const float* Y, int B, int D, int T, const 
   return 0;
 }
 
+constexpr int CPF_BLOCKS = 128;                            // stage-0 blocks of chan_part_finalize_kernel
 extern "C" size_t ds2_bn2d_act_bwd_fused_workspace_bytes(int B, int D, int T) {
-  return ds2_chanreduce_workspace_bytes(32) + (size_t)B * D * ceil_div(T, 64) * 32 * sizeof(float);
+  return ds2_chanreduce_workspace_bytes(32) + align_up((size_t)B * D * ceil_div(T, 64) * 32 * sizeof(float), 16) + (size_t)CPF_BLOCKS * 32 * sizeof(double);
 }
 
 // Backward of the same block with the layout casts AND the conv bias gradient fused: dgamma, dbeta (32), dbias (32, = per-channel
@@ -737,8 +748,12 @@ extern "C" int ds2_bn2d_act_bwd_fused(const float* Y, const float* dA, int B, in
   hipLaunchKernelGGL((bn2d_tile_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, Y, dA, B, D, T, Tp, lens_dev, mean, var, gamma, beta,
                      (const float*)dbeta, (const float*)dgamma, eps, 1.0f / ((float)B * D * T), dy_f32, (nbf16*)dy_pad, (nbf16*)dy_nhwc, part);
   DS2_LAUNCH_CHECK("bn2d_tile_kernel<bwd>");
-  hipLaunchKernelGGL(chan_part_finalize_kernel, dim3(32), dim3(256), 0, (hipStream_t)stream, (const float*)part,
-                     (long long)grid.x * grid.y * grid.z, 32, dbias);
+  const long long nparts = (long long)grid.x * grid.y * grid.z;
+  double* tmp = reinterpret_cast<double*>(reinterpret_cast<char*>(part) + align_up((size_t)nparts * 32 * sizeof(float), 16));
+  const long long rpb = (nparts + CPF_BLOCKS - 1) / CPF_BLOCKS;
+  const int nblk = (int)((nparts + rpb - 1) / rpb);
+  hipLaunchKernelGGL(chan_part_finalize_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const float*)part, nparts, rpb, tmp, nblk, dbias, 0);
+  hipLaunchKernelGGL(chan_part_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)part, nparts, rpb, tmp, nblk, dbias, 1);
   DS2_LAUNCH_CHECK("chan_part_finalize_kernel");
   return 0;
 }
