@@ -60,6 +60,8 @@ MODELS = {
     "lstm_h24_l2": ("lstm", 24, 2, 7, [40, 33, 21]),
     "gru_h48_l3": ("gru", 48, 3, 29, [90, 77, 64, 50, 31]),
     "lstm_h40_l3": ("lstm", 40, 3, 29, [61, 61, 47, 22]),
+    # BASELINE.json configs[0] itself (C1: DS2-tiny 2x256 BiGRU, 29 labels, batch 4 of 2 s = 201 input frames)
+    "c1_gru_h256_l2": ("gru", 256, 2, 29, [201, 201, 201, 201]),
 }
 
 
@@ -261,6 +263,10 @@ def main():
     out = HERE
     if "--only-decode" in sys.argv:
         gen_decode(out)
+        return
+    if "--only-model" in sys.argv:                     # regenerate one model fixture without touching the others
+        with tempfile.TemporaryDirectory() as tmp:
+            gen_model(out, sys.argv[sys.argv.index("--only-model") + 1], DeepSpeech, tmp)
         return
     gen_decode(out)
     with tempfile.TemporaryDirectory() as tmp:

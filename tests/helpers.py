@@ -55,4 +55,14 @@ def model_inputs(cfg, device="cpu", well_conditioned=True):
     return sd, x, targets, pct, tsz
 
 
-MODEL_FIXTURES = ["gru_h32_l2", "lstm_h24_l2", "gru_h48_l3", "lstm_h40_l3"]
+MODEL_FIXTURES = ["gru_h32_l2", "lstm_h24_l2", "gru_h48_l3", "lstm_h40_l3", "c1_gru_h256_l2"]   # the last one = BASELINE configs[0] itself
+
+
+def noise_only_grads(cfg):
+    """Parameters whose gradient is ANALYTICALLY zero for this fixture: a conv bias sits in front of a BatchNorm, which removes any
+    per-channel constant — unless MaskConv zeroes some frames behind the conv, the bias gradient is exactly 0 and what either side
+    computes is summation round-off (1e-4 against O(1..1000) for the real gradients).  That noise cannot be compared relatively, and
+    AdamW turns it into a full-size +-lr step of arbitrary sign, so the final value of such a bias is not comparable either.  True when
+    every utterance of the batch has the full length (BASELINE configs[0]: four 2 s utterances)."""
+    t = cfg["t_ins"]
+    return {"conv.seq_module.0.bias", "conv.seq_module.3.bias"} if len(set(t)) == 1 else set()

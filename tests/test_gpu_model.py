@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import MODEL_FIXTURES, load_model_fixture, model_inputs, rel_l2, subsample
+from helpers import MODEL_FIXTURES, load_model_fixture, model_inputs, noise_only_grads, rel_l2, subsample
 import det
 from oracle import ds2_oracle as O
 
@@ -64,6 +64,9 @@ def test_fit_matches_reference_golden(name):
         if step == 0:
             out, out_lens = None, None
             for k, p in model.named_parameters():
+                if k in noise_only_grads(cfg):                  # analytically zero (helpers.noise_only_grads): round-off on both sides
+                    assert float(p.grad.double().norm()) <= 1e-5 * float(z["gradnorm_" + k.replace(".bias", ".weight")]), k
+                    continue
                 grad_check(k, p.grad.cpu().numpy(), z["grad_" + k], z["gradnorm_" + k])
             for k, v in model.state_dict().items():
                 if "running_" in k:
@@ -72,7 +75,8 @@ def test_fit_matches_reference_golden(name):
         losses.append(lv)
     assert np.allclose(losses, z["losses"], rtol=TOL), (losses, z["losses"])
     for k, p in model.named_parameters():
-        assert rel_l2(subsample(p.detach().cpu().numpy()), z["final_" + k]) < TOL, k
+        if k not in noise_only_grads(cfg):
+            assert rel_l2(subsample(p.detach().cpu().numpy()), z["final_" + k]) < TOL, k
     # eval-mode forward (softmax probabilities) after the 3 steps
     model.eval()
     with torch.no_grad():
@@ -103,7 +107,8 @@ def test_fused_step_matches_reference_golden(name):
         losses.append(lv)
     assert np.allclose(losses, z["losses"], rtol=TOL), (losses, z["losses"])
     for k, p in model.named_parameters():
-        assert rel_l2(subsample(p.detach().cpu().numpy()), z["final_" + k]) < TOL, k
+        if k not in noise_only_grads(cfg):
+            assert rel_l2(subsample(p.detach().cpu().numpy()), z["final_" + k]) < TOL, k
 
 
 @pytest.mark.parametrize("rnn,hidden,layers,B,tmax", [("gru", 72, 3, 6, 151), ("lstm", 56, 2, 5, 120), ("gru", 128, 2, 33, 90)])
