@@ -25,6 +25,7 @@ SIGNATURES = {
     "ds2_debug_flags": (i32, [i32]),
     "ds2_rnn_persistent_status": (i32, [vp]),
     "ds2_rnn_persistent_counters": (i32, [vp]),
+    "ds2_rnn_step_gate": (i32, [vp, vp, vp]),
     "ds2_rnn_persistent_enable": (i32, [i32, i32]),
     "ds2_rnn_last_path": (i32, []),
     "ds2_gemm_f32_workspace_bytes": (sz, [i32, i32, i32, i32]),
@@ -92,6 +93,7 @@ SIGNATURES = {
     "ds2_spectrogram_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "ds2_spectrogram_f32": (i32, [vp, i64, vp, i32, i32, i32, i32, vp, i32, i32, vp, vp, sz, vp]),
     "ds2_adamw_f32": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp]),
+    "ds2_adamw_gated_f32": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp, vp]),
     "ds2_scale_f32": (i32, [vp, i64, f32, vp]),
 }
 

@@ -9,7 +9,8 @@ namespace {
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
-                                                    float wd, float bc1, float bc2_sqrt, float gscale) {
+                                                    float wd, float bc1, float bc2_sqrt, float gscale, const int* __restrict__ apply) {
+  if (apply && *apply == 0) return;                     // device-side gate: the step was found invalid after this launch was enqueued
   const long long n4 = n / 4;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -48,8 +49,11 @@ __global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, long 
 }  // namespace
 
 // step is 1-based.  grad_scale multiplies g on the fly (e.g. 1/world_size after an all-reduce SUM).
-extern "C" int ds2_adamw_f32(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
-                             float weight_decay, int step, float grad_scale, void* stream) {
+// apply_flag: NULL, or a device int the kernel reads when it RUNS: 0 = leave everything untouched.  It lets the host enqueue the update
+// before it knows whether the step is valid (finite loss on every rank, no starved recurrence launch: ds2_rnn_step_gate), i.e. without
+// a host synchronisation between backward and the optimizer.
+extern "C" int ds2_adamw_gated_f32(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                                   float weight_decay, int step, float grad_scale, const int* apply_flag, void* stream) {
   DS2_REQUIRE(p && g && m && v && n >= 0 && step >= 1, "ds2_adamw_f32: bad args");
   DS2_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0,
               "ds2_adamw_f32: buffers must be 16-byte aligned");
@@ -60,9 +64,14 @@ extern "C" int ds2_adamw_f32(float* p, const float* g, float* m, float* v, long 
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
-                     weight_decay, bc1, (float)sqrt(bc2), grad_scale);
+                     weight_decay, bc1, (float)sqrt(bc2), grad_scale, apply_flag);
   DS2_LAUNCH_CHECK("adamw_kernel");
   return 0;
+}
+
+extern "C" int ds2_adamw_f32(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                             float weight_decay, int step, float grad_scale, void* stream) {
+  return ds2_adamw_gated_f32(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, nullptr, stream);
 }
 
 extern "C" int ds2_scale_f32(float* x, long long n, float s, void* stream) {

@@ -1537,6 +1537,23 @@ extern "C" size_t ds2_rnn_bwd_workspace_bytes(int gates, int B, int H, int bf16)
 // which kernel family the last recurrence calls used: bit 0 = ds2_rnn_fwd, bit 1 = ds2_rnn_bwd took the persistent kernel (reporting only)
 extern "C" int ds2_rnn_last_path(void) { return g_last_path; }
 
+namespace {
+__global__ void step_gate_kernel(const float* __restrict__ loss, int* __restrict__ flag) {
+  const float l = *loss;
+  *flag = (l == l && l != __builtin_inff() && l != -__builtin_inff() && l >= 0.f && g_persist_dbg[0] == 0) ? 1 : 0;
+}
+}  // namespace
+
+// flag[0] = 1 if the train step enqueued so far on `stream` is valid when this kernel RUNS: the loss (device scalar) is finite and
+// non-negative (functional.py:45-61) and no persistent recurrence launch has recorded starvation; else 0.  Consumed on the device by
+// ds2_adamw_gated_f32 (and, under data parallelism, all-reduced with MIN first), read back by the host whenever convenient.
+extern "C" int ds2_rnn_step_gate(const float* loss_dev, int* flag_dev, void* stream) {
+  DS2_REQUIRE(loss_dev && flag_dev, "ds2_rnn_step_gate: null pointer");
+  hipLaunchKernelGGL(step_gate_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, loss_dev, flag_dev);
+  DS2_LAUNCH_CHECK("step_gate_kernel");
+  return 0;
+}
+
 extern "C" int ds2_rnn_persistent_enable(int forward, int backward) {
   g_persist_fwd = forward != 0;
   g_persist_bwd = backward != 0;

@@ -14,6 +14,21 @@ import torch
 from . import _lib, ops
 
 
+def _prep_targets_host(targets, target_lengths):
+    """CPU int32 tensors (flat targets, per-utterance offsets, target lengths) and the longest target."""
+    tl = torch.as_tensor(target_lengths).to(torch.int32).cpu()
+    t = torch.as_tensor(targets).to(torch.int32).cpu()
+    if t.dim() == 2:  # padded (B, S) form of torch.nn.CTCLoss
+        t = torch.cat([t[i, : int(tl[i])] for i in range(t.size(0))]) if t.numel() else t.reshape(-1)
+    off = torch.zeros(tl.numel(), dtype=torch.int32)
+    if tl.numel() > 1:
+        off[1:] = torch.cumsum(tl, 0)[:-1].to(torch.int32)
+    max_u = int(tl.max()) if tl.numel() else 0
+    if t.numel() == 0:
+        t = torch.zeros(1, dtype=torch.int32)
+    return t, off, tl, max_u
+
+
 def _prep_targets(targets, target_lengths, device):
     tl = torch.as_tensor(target_lengths).to(torch.int32).cpu()
     t = torch.as_tensor(targets).to(torch.int32).cpu()

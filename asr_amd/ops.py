@@ -748,8 +748,19 @@ def spectrogram(audio: Tensor, n_samples: Tensor, n_fft: int, hop: int, window: 
 # optimizer
 # ------------------------------------------------------------------------------------------------
 def adamw(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float, betas=(0.9, 0.999), eps: float = 1e-8,
-          weight_decay: float = 1e-5, grad_scale: float = 1.0):
+          weight_decay: float = 1e-5, grad_scale: float = 1.0, apply_flag: Optional[Tensor] = None):
+    """apply_flag: optional int32 GPU tensor read by the kernel when it runs (0 = leave p, m, v untouched): step_gate()."""
     _chk_f32(p, g, m, v)
     assert p.is_contiguous() and g.is_contiguous() and m.is_contiguous() and v.is_contiguous()
-    _lib.check(_lib.load().ds2_adamw_f32(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, betas[0], betas[1],
-                                         eps, weight_decay, int(step), grad_scale, _stream()), "ds2_adamw_f32")
+    assert apply_flag is None or (apply_flag.dtype == torch.int32 and apply_flag.is_cuda)
+    _lib.check(_lib.load().ds2_adamw_gated_f32(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, betas[0], betas[1],
+                                               eps, weight_decay, int(step), grad_scale, _ptr(apply_flag), _stream()), "ds2_adamw_gated_f32")
+
+
+def step_gate(loss: Tensor) -> Tensor:
+    """int32 GPU tensor [1]: 1 if, when the stream gets there, `loss` (0-d / 1-element fp32 GPU tensor) is finite and non-negative and no
+    persistent recurrence launch has recorded starvation — the device-side form of check_loss + rnn_persistent_check."""
+    _chk_f32(loss)
+    flag = torch.empty(1, dtype=torch.int32, device=loss.device)
+    _lib.check(_lib.load().ds2_rnn_step_gate(loss.data_ptr(), flag.data_ptr(), _stream()), "ds2_rnn_step_gate")
+    return flag

@@ -61,14 +61,21 @@ class FusedAdamW:
         return self._spans
 
     @torch.no_grad()
-    def step(self):
+    def step(self, apply_flag=None):
+        """apply_flag: optional int32 GPU tensor (ops.step_gate) the kernels read when they RUN — 0 leaves parameters and moments
+        untouched.  The caller that passes one learns the outcome later and must call `undo_step_count()` if the update did not happen
+        (the bias corrections are computed on the host from the step count)."""
         self._ensure_state()
         flat, grad = self.model.flat_parameters()
         g = self.param_groups[0]
         self.state["step"] += 1
         for a, b in self._trainable_spans():
             ops.adamw(flat[a:b], grad[a:b], self.state["exp_avg"][a:b], self.state["exp_avg_sq"][a:b], self.state["step"], g["lr"], g["betas"],
-                      g["eps"], g["weight_decay"], self.grad_scale)
+                      g["eps"], g["weight_decay"], self.grad_scale, apply_flag=apply_flag)
+
+    def undo_step_count(self):
+        """A gated step() turned out to be a no-op on the device: take its count back."""
+        self.state["step"] = max(0, self.state["step"] - 1)
 
     def state_dict(self):
         return {"state": {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.state.items()}, "param_groups": self.param_groups}

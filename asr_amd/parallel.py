@@ -90,6 +90,15 @@ class BucketedAllReducer:
         self.launched = []
         assert not self._held, f"buckets never released: {self._held}"
 
+    def all_valid_device(self, flag: torch.Tensor) -> torch.Tensor:
+        """Device-side agreement: `flag` (int32 GPU tensor, 1 = this rank's step is valid) becomes the MIN over ranks, in stream order,
+        without a host synchronisation (the gated optimizer launch reads it)."""
+        if self.world == 1:
+            return flag
+        work = dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group, async_op=True)
+        work.wait()                                  # stream-level for CUDA tensors: the compute stream waits, the host does not
+        return flag
+
     def all_valid(self, valid: bool, device) -> bool:
         """Collective agreement on check_loss (every rank must skip the same steps)."""
         if self.world == 1:

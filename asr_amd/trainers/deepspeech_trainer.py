@@ -16,7 +16,7 @@ import torch
 import torch.distributed as dist
 
 from .. import engine, ops
-from ..ctc import CTCLoss, _prep_targets
+from ..ctc import CTCLoss, _prep_targets, _prep_targets_host
 from ..device import autocast, make_grad_scaler, resolve_device
 from ..functional import check_loss
 from ..optim import FusedAdamW
@@ -104,6 +104,8 @@ class DeepSpeechTrainer:
                 current.loss += loss_value
             else:
                 print("Loss non valid, skipped")
+        if fused:
+            self.synchronize()                                  # settle the last step's device verdict before the epoch's bookkeeping
         self.update(current, best, train_loader, update_best=False)
         if self._scheduler is not None:
             self._scheduler.step()
@@ -153,7 +155,118 @@ class DeepSpeechTrainer:
         return self._reducer
 
     def step(self, data):
-        """One full train step on the HIP kernels; returns (valid_loss, loss_value)."""
+        """One full train step on the HIP kernels; returns (valid_loss, loss_value).
+
+        The host waits for ONE thing: the loss value (the reference's `loss.item()`), which exists as soon as the CTC kernels have run —
+        it does not wait for backward or the optimizer.  Whether the update may be applied is decided on the DEVICE (ops.step_gate: loss
+        finite and non-negative, no starved persistent recurrence; under data parallelism the MIN over ranks) and the fused AdamW launch
+        reads that flag when it runs, so everything of the step is enqueued before the host blocks and the next step's host-side
+        preparation overlaps this step's backward.  `valid_loss` is `check_loss` of this rank's loss value; a step that the device gate
+        rejected for another reason (a starved launch, another rank's loss) is reported — and the optimizer's step count corrected — when
+        the next call (or `synchronize()`) reads the flag back."""
+        model = self._model
+        if not isinstance(self._optimizer, FusedAdamW):
+            return self._step_host_gated(data)
+        inputs, targets, input_percentages, target_sizes = data
+        input_sizes = input_percentages.mul_(int(inputs.size(3))).int()
+        inputs = inputs.to(self._device, non_blocking=True)
+        B = inputs.size(0)
+        output_sizes = model.get_seq_lens(input_sizes.cpu().int())
+        model._ensure_flat(inputs.device)
+        # every small integer operand of the step (output lengths, flat targets, their offsets and lengths) goes to the GPU in ONE
+        # asynchronous copy from pinned memory: a pageable `.to(device)` is stream-ordered AND blocks the host, i.e. it would make the host
+        # wait for the previous step's backward after all
+        t_h, off_h, tl_h, max_u = _prep_targets_host(targets, target_sizes)
+        lens_dev, tg, off, tl = self._stage_ints(inputs.device, output_sizes.to(torch.int32), t_h, off_h, tl_h)
+        main = torch.cuda.current_stream()
+        with torch.no_grad():
+            W = model._flat.tensors(model)
+            Gr = model._flat.tensors(model, grads=True)
+            logits, ctx = engine.forward(W, model._cfg, inputs, lens_dev, training=True, save=True)
+            nll, dlogits = ops.ctc_loss(logits, tg, off, lens_dev, tl, max_u, 1.0 / B, want_grad=True)
+            loss = (nll.sum() / B).reshape(1)
+            # the loss value travels to pinned host memory on a copy stream that waits for the CTC kernels only
+            pin = self._pinned()
+            have_loss = torch.cuda.Event()
+            have_loss.record(main)
+            with torch.cuda.stream(pin["stream"]):
+                pin["stream"].wait_event(have_loss)
+                pin["loss"].copy_(loss, non_blocking=True)
+                pin["loss_done"].record(pin["stream"])
+            loss.record_stream(pin["stream"])
+            red = self._get_reducer()
+            engine.backward(W, Gr, model._cfg, ctx, dlogits, on_bucket=red.on_bucket)
+            red.finish()
+            pin["loss_done"].synchronize()                                   # the step's single host wait: CTC done (backward is running)
+            loss_value = float(pin["loss"][0])
+            prev_starved = self._settle()                                    # the PREVIOUS step's device verdict is long available
+            valid_loss, _ = check_loss(None, loss_value)
+            gate = ops.step_gate(loss)                                       # device verdict of THIS step, behind backward in stream order
+            if prev_starved:
+                # this step's recurrences were launched before the starvation of the previous one was known (and the record it would have
+                # left has just been cleared with the other): do not trust them either
+                gate.zero_()
+                valid_loss = False
+            gate = red.all_valid_device(gate)                                # MIN over ranks (no-op for one rank)
+            self._optimizer.grad_scale = 1.0 / red.world
+            self._optimizer.step(apply_flag=gate)
+            gate_ready = torch.cuda.Event()
+            gate_ready.record(main)
+            with torch.cuda.stream(pin["stream"]):
+                pin["stream"].wait_event(gate_ready)
+                pin["gate"].copy_(gate, non_blocking=True)
+                pin["gate_done"].record(pin["stream"])
+            gate.record_stream(pin["stream"])
+            self._unsettled = valid_loss
+        return valid_loss, loss_value
+
+    def _stage_ints(self, device, *cpu_int32):
+        """One pinned staging buffer, one non-blocking H2D copy; returns device views (16-byte aligned starts).  The buffer is reused
+        every step: the host only gets here after it has seen the previous step's loss, i.e. after that step's copy has executed."""
+        sizes = [int(t.numel()) for t in cpu_int32]
+        starts, total = [], 0
+        for n in sizes:
+            starts.append(total)
+            total += (n + 3) // 4 * 4
+        if getattr(self, "_ints_pin", None) is None or self._ints_pin.numel() < total:
+            self._ints_pin = torch.empty(max(total, 4096), dtype=torch.int32).pin_memory()
+        for t, a, n in zip(cpu_int32, starts, sizes):
+            self._ints_pin[a:a + n].copy_(t.reshape(-1))
+        dev = torch.empty(total, dtype=torch.int32, device=device)
+        dev.copy_(self._ints_pin[:total], non_blocking=True)
+        return tuple(dev[a:a + n] for a, n in zip(starts, sizes))
+
+    def _pinned(self):
+        if getattr(self, "_pin", None) is None:
+            self._pin = {"stream": torch.cuda.Stream(device=self._device), "loss": torch.empty(1, dtype=torch.float32).pin_memory(),
+                         "gate": torch.empty(1, dtype=torch.int32).pin_memory(), "loss_done": torch.cuda.Event(), "gate_done": torch.cuda.Event()}
+        return self._pin
+
+    def _settle(self):
+        """Read back the device verdict of the last gated step (if any): a step this rank's loss check accepted but the device rejected
+        (starved persistent launch; another rank's loss) did not update the weights — report it and take the optimizer's count back."""
+        pending = getattr(self, "_unsettled", None)
+        if pending is None:
+            return False
+        self._unsettled = None
+        self._pin["gate_done"].synchronize()
+        applied = int(self._pin["gate"][0]) != 0
+        starved = False
+        if not applied:
+            self._optimizer.undo_step_count()
+            if pending:                                                      # not explained by this rank's own loss
+                starved = self._persistent_starved()                         # counted and printed there; the library re-arms later
+                if not starved:
+                    print("[asr_amd] step skipped on every rank: another rank's loss was not valid", flush=True)
+        return starved
+
+    def synchronize(self):
+        """Wait for everything enqueued by step() and settle the last step's device verdict (call before reading weights / counters)."""
+        self._settle()
+        torch.cuda.synchronize(self._device)
+
+    def _step_host_gated(self, data):
+        """step() for a torch optimizer (it cannot read a device flag): the host decides, with one full synchronisation per step."""
         model = self._model
         inputs, targets, input_percentages, target_sizes = data
         input_sizes = input_percentages.mul_(int(inputs.size(3))).int()
@@ -172,19 +285,15 @@ class DeepSpeechTrainer:
             red = self._get_reducer()
             engine.backward(W, Gr, model._cfg, ctx, dlogits, on_bucket=red.on_bucket)
             red.finish()
-            loss_value = loss.item()                                         # the step's single host sync
+            loss_value = loss.item()
             starved = self._persistent_starved()                             # the device is idle here
             valid_loss, _ = check_loss(loss, loss_value)
             valid_loss = valid_loss and not starved                          # a starved step is skipped like a non-finite loss (on every rank)
             valid_loss = red.all_valid(valid_loss, inputs.device)
             if valid_loss:
-                if isinstance(self._optimizer, FusedAdamW):
-                    self._optimizer.grad_scale = 1.0 / red.world
-                    self._optimizer.step()
-                else:
-                    for n, p in model.named_parameters():       # torch AdamW skips parameters without a gradient: frozen ones get none
-                        p.grad = (Gr[n] if red.world == 1 else Gr[n] / red.world) if p.requires_grad else None
-                    self._optimizer.step()
+                for n, p in model.named_parameters():                        # torch AdamW skips parameters without a gradient: frozen ones get none
+                    p.grad = (Gr[n] if red.world == 1 else Gr[n] / red.world) if p.requires_grad else None
+                self._optimizer.step()
         return valid_loss, loss_value
 
     # -- eval / bookkeeping (deepspeech_trainer.py:119-137) ----------------------------------------

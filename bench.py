@@ -295,6 +295,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    tr.synchronize()                                  # settle the last step's device-side verdict (starved-step counter)
     if use_dist:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

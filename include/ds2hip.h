@@ -163,6 +163,9 @@ int ds2_rnn_persistent_status(int* out8);
 /* reporting: out2 = {launches that starved since the library was loaded, recurrence calls left before the persistent kernels are armed
  * again (0 = armed, -1 = never)} */
 int ds2_rnn_persistent_counters(int* out2);
+/* device-side validity of the train step enqueued so far: flag_dev[0] = (loss finite and >= 0 [check_loss, functional.py:45-61]) and no
+ * persistent recurrence launch starved, evaluated when the kernel RUNS (stream order) */
+int ds2_rnn_step_gate(const float* loss_dev, int* flag_dev, void* stream);
 /* Which recurrences may run as one persistent launch (default both).  Switch the backward one off when other kernels (collectives on a
  * communication stream) run on the device during backward: a persistent launch needs all of its workgroups resident at once. */
 int ds2_rnn_persistent_enable(int forward, int backward);
@@ -229,6 +232,9 @@ int ds2_spectrogram_f32(const float* audio, long long ld_audio, const int* n_sam
  * torch.optim.AdamW.step over one flat parameter buffer, trainers/__main__.py:41-47. */
 int ds2_adamw_f32(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int step, float grad_scale, void* stream);
+/* the same update behind a device-side gate: apply_flag (device int, may be NULL = always) is read when the kernel runs, 0 = no-op */
+int ds2_adamw_gated_f32(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, int step, float grad_scale, const int* apply_flag, void* stream);
 int ds2_scale_f32(float* x, long long n, float s, void* stream);
 
 #ifdef __cplusplus
