@@ -33,6 +33,7 @@ import os as _os
 #   "0"            one stream
 OVERLAP_MODE = _os.environ.get("DS2_OVERLAP", "2")
 OVERLAP_WGRAD = OVERLAP_MODE == "1"
+_BWD_PERSISTENT = {}      # (gates, H, B) -> did the last backward recurrence of this shape run as a persistent launch?
 _SIDE = {}
 
 
@@ -232,11 +233,20 @@ def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy: Tensor, done):
                 t.record_stream(main)
         done(f"rnns.{l}")
 
+    # the side stream only pays beside a PERSISTENT recurrence (its resident workgroups leave registers and LDS for light kernels); beside
+    # one-launch-per-step kernels (shapes whose W_hh^T slice does not fit: LSTM H = 1280) co-running passes delay every launch
+    # (c4: 94.6 -> 99.5 ms per step), so there the passes stay on the compute stream.  What the library did for this shape is known from
+    # the previous call (ds2_rnn_last_path); the first call of a shape assumes persistent.
+    shape_key = (G, H, B)
+    lib = _lib.load()
+
     def operand_passes(l, lc_t, dgx_bf, start):
         """side stream, not before `start`: transposing casts of layer l's dGx (+ db_ih), d(hn) (+ db_hn), h and Xn"""
         aux, hbuf, xn = lc_t
-        with torch.cuda.stream(side):
-            side.wait_event(start)
+        on_side = _BWD_PERSISTENT.get(shape_key, True)
+        with torch.cuda.stream(side if on_side else main):
+            if on_side:
+                side.wait_event(start)
             dgxT, _ = ops.transpose_bf16(dgx_bf, colsum=Gr[f"rnns.{l}.bih_cat"].view(-1))          # + db_ih = column sums of dGx
             dbhh = Gr[f"rnns.{l}.bhh_cat"]                                                        # (2, GH)
             dbhh.copy_(Gr[f"rnns.{l}.bih_cat"].view(2, G * H))
@@ -248,9 +258,10 @@ def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy: Tensor, done):
             hT = ops.cast_transpose_bf16(hbuf)                                                    # (2H, M)
             xnT = ops.transpose_bf16(xn[:, :W[f"rnns.{l}.wih_cat"].shape[1]])                     # xn is bf16 (M, pad8(I)) in this mode
             ready = torch.cuda.Event()
-            ready.record(side)
-        for t in (dgx_bf, aux, hbuf, xn):                        # read on the side stream
-            t.record_stream(side)
+            ready.record(side if on_side else main)
+        if on_side:
+            for t in (dgx_bf, aux, hbuf, xn):                    # read on the side stream
+                t.record_stream(side)
         return (l, dgxT, hT, auxT, xnT, ready, (dgx_bf,))
 
     queued = None                                                # layer whose operand passes wait for the next recurrence launch
@@ -265,6 +276,7 @@ def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy: Tensor, done):
             queued = None
         dgx_bf = torch.empty(lc.gshape if lc.rec is not None else lc.gx.shape, dtype=torch.bfloat16, device=dy.device)
         ops.rnn_bwd(G, dy, lc.gx, lc.aux, lc.hbuf, lc.wpb, lens_dev, T, B, H, bf16=True, dgx_bf16=dgx_bf, gates_bf16=lc.rec)
+        _BWD_PERSISTENT[shape_key] = bool(lib.ds2_rnn_last_path() & 2)
         lc.rec = None
         if pending is not None:
             weight_gradients(pending)                            # heavy work of the layer above: on the compute stream, behind this launch
