@@ -31,6 +31,7 @@ SIGNATURES = {
     "ds2_gemm_f32_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "ds2_gemm_f32": (i32, [i32, i32, i32, i32, i32, vp, i32, i64, vp, i32, i64, vp, i32, i64, vp, i32, i32, i32, vp, sz, vp]),
     "ds2_gemm_bf16_workspace_bytes": (sz, [i32, i32, i32, i32]),
+    "ds2_gemm_bf16_tn": (i32, [i32, i32, i32, vp, i32, i64, vp, i32, i64, vp, i32, i64, i32, i32, i32, vp, sz, vp]),
     "ds2_gemm_bf16_nt": (i32, [i32, i32, i32, vp, i32, i64, vp, i32, i64, vp, i32, i64, vp, i32, i32, i32, vp, sz, vp]),
     "ds2_cast_bf16": (i32, [vp, i32, vp, i32, i32, i32, vp]),
     "ds2_cast_transpose_bf16": (i32, [vp, i32, vp, i32, i32, i32, vp]),

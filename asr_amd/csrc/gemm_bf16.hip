@@ -25,6 +25,7 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int PITCH = 144;                       // bytes per LDS tile row (128 + 16 pad)
@@ -451,6 +452,200 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(BArgs g
   }
 }
 
+// ---- "TN" form: C[M,N] (fp32) (+)= A[K,M]^T (bf16) * B[K,N] (bf16): BOTH operands row-major with the reduction index on the ROWS -------
+// This is the weight-gradient product of the recurrent layers (dW = dGx^T [Xn | h], K = T*B): with it the backward pass needs no
+// transposed copy of dGx, d(hn), h or Xn (four HBM passes per layer).  Same 256 x 256 x 64 tile, the same LDS-DMA double buffer and the
+// same software pipeline as the NT kernel above; what changes is the LDS image and the fragment read:
+//   * an operand tile is 64 k-rows x 256 columns = 64 rows of 512 B; one DMA wave-instruction lands two k-rows (1 KiB);
+//   * a 32x32x16 MFMA wants, per lane, 8 consecutive k of ONE column - a strided gather from that image.  ds_read_b64_tr_b16 does the
+//     gather in the LDS crossbar: inside a 16-lane group, lane i receives element (i & 3) of the 8-byte datum addressed by lane
+//     4j + (i >> 2), j = 0..3 (scripts/probe_tr_read.hip).  With lane p addressing row (p >> 2), columns 4 (p & 3) .. + 3 of a 4 x 16
+//     block, lane i ends up with rows 0..3 of column i: two such reads give the 8 k of one MFMA operand;
+//   * the four rows of a read sit 512 B apart (same banks): the 16-byte slot s of row r is stored at slot s ^ ((r & 3) << 2) (applied to
+//     the DMA source address and to the read address), which spreads a 32-lane read group over all 64 banks exactly once.
+__global__ __launch_bounds__(512) void gemm_bf16_tn_glds_kernel(BArgs g, int ntx, int nty) {
+  constexpr int WN = 4, NWV = 8, NI = 4, NJ = 2, NP = 4;
+  extern __shared__ __attribute__((aligned(1024))) char ldsg[];
+  const int z = blockIdx.z;
+  const int zb = z / g.splitk, zs = z % g.splitk;
+  const __bf16* A = g.A + (long long)zb * g.sA;
+  const __bf16* B = g.B + (long long)zb * g.sB;
+  const int nt = ntx * nty;
+  const int orig = blockIdx.x;
+  const int xcd = orig & 7, q8 = nt >> 3, r8 = nt & 7;
+  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  const int m0 = (tile / ntx) * 256, n0 = (tile % ntx) * 256;
+  const int kbeg = zs * g.kchunk;
+  const int kend = min(g.K, kbeg + g.kchunk);
+  const int nkt = (kend - kbeg + BK - 1) / BK;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, half = lane >> 5;
+
+  // staging: piece p = wave + 8 i holds k-rows 2p, 2p + 1; lane -> (k-row, physical 16-byte slot); columns past M / N are clamped
+  // to the last valid segment (they only feed C rows / columns that are never stored), k-rows past kend read the zero page
+  const char* zp = reinterpret_cast<const char*>(g_zero16);
+  const char* qA[NP];
+  const char* qB[NP];
+  int rowk[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int r = (wave + NWV * i) * 2 + (lane >> 5);
+    const int gs = (lane & 31) ^ ((r & 3) << 2);
+    rowk[i] = r;
+    qA[i] = reinterpret_cast<const char*>(A + (long long)(kbeg + r) * g.lda + min(m0 + gs * 8, g.M - 8));
+    qB[i] = reinterpret_cast<const char*>(B + (long long)(kbeg + r) * g.ldb + min(n0 + gs * 8, g.N - 8));
+  }
+  const long long stepA = (long long)g.lda * (BK * 2), stepB = (long long)g.ldb * (BK * 2);
+  const int nfull = (kend - kbeg) / BK;
+  auto stage_piece = [&](int buf, int kt, int i) {
+    char* dA = ldsg + buf * 2 * G_TILE + (wave + NWV * i) * 1024;
+    if (kt < nfull) {
+      glds16(qA[i], dA);
+      glds16(qB[i], dA + G_TILE);
+      qA[i] += stepA;
+      qB[i] += stepB;
+    } else {                                          // the K tail (the pointers already stand on this tile)
+      const bool kok = kbeg + kt * BK + rowk[i] < kend;
+      glds16(kok ? qA[i] : zp, dA);
+      glds16(kok ? qB[i] : zp, dA + G_TILE);
+    }
+  };
+  auto stage_tile = [&](int buf, int kt) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) stage_piece(buf, kt, i);
+  };
+
+  f32x16 acc[NI][NJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment read addresses (buffer 0, k-step 0, first of the two reads): lane p of a 16-lane group addresses row (p >> 2) of the
+  // 4-row block, columns 4 (p & 3) .. + 3 of the group's 16 columns; k-step kk and the second read are immediate offsets
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_void*)ldsg;
+  const int p16 = lane & 15, q4 = p16 >> 2, g16 = (lane >> 4) & 1;
+  const unsigned rowpart = (unsigned)((half * 8 + q4) * 512);
+  unsigned va[NI], vb[NJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int col = wm * 128 + i * 32 + g16 * 16 + 4 * (p16 & 3);
+    va[i] = lds0 + rowpart + ((((col >> 3) ^ (q4 << 2)) << 4) | (((col >> 2) & 1) << 3));
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int col = wn * 64 + j * 32 + g16 * 16 + 4 * (p16 & 3);
+    vb[j] = lds0 + G_TILE + rowpart + ((((col >> 3) ^ (q4 << 2)) << 4) | (((col >> 2) & 1) << 3));
+  }
+  // A fragment is two reads, each landing in one half of the 4-register MFMA operand.  The halves are joined (a register-tuple
+  // definition, no instruction) right behind the reads and the waits name the whole operand, as in the NT kernel; the build checks the
+  // generated code for this (scripts/check_tn_isa.py): a register copy between a read and its wait would move data that has not landed.
+  f32x4 fa[2][NI], fb[2][NJ];
+  constexpr int NR = NI + NJ;
+#define T_ISA(r_) ((r_) == 0 || (r_) > NJ)
+#define T_IDX(r_) ((r_) == 0 ? 0 : (r_) <= NJ ? (r_) - 1 : (r_) - NJ)
+#define T_RD2(dst, addr, off)                                                                                                         \
+  do {                                                                                                                                \
+    f32x2 lo_, hi_;                                                                                                                   \
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"                                        \
+                 : "=&v"(lo_), "=&v"(hi_)                                                                                             \
+                 : "v"(addr), "n"(off), "n"((off) + 2048));                                                                           \
+    dst = __builtin_shufflevector(lo_, hi_, 0, 1, 2, 3);                                                                              \
+  } while (0)
+#define T_RD1(set, bufoff, kk, r_)                                                                                                    \
+  do {                                                                                                                                \
+    if ((r_) < NR && T_ISA(r_))                                                                                                       \
+      T_RD2(fa[set][(r_) < NR && T_ISA(r_) ? T_IDX(r_) : 0], va[(r_) < NR && T_ISA(r_) ? T_IDX(r_) : 0] + (bufoff), (kk) * 8192);     \
+    else if ((r_) < NR)                                                                                                               \
+      T_RD2(fb[set][(r_) < NR && !T_ISA(r_) ? T_IDX(r_) : 0], vb[(r_) < NR && !T_ISA(r_) ? T_IDX(r_) : 0] + (bufoff), (kk) * 8192);   \
+  } while (0)
+#define T_RETIRE_ALL(WAITSTR)                                                                                                         \
+  asm volatile(WAITSTR " lgkmcnt(0)"                                                                                                  \
+               : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(fb[0][0]), "+v"(fb[0][1]),                      \
+                 "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[1][2]), "+v"(fa[1][3]), "+v"(fb[1][0]), "+v"(fb[1][1])                       \
+               :                                                                                                                      \
+               : "memory")
+  // the counted waits of the NT pipeline with every count doubled (a fragment is two reads here); the largest is 12 <= 15
+#define T_STEP(cur, nxt, off_n, kk_n, DMA)                                                                                            \
+  do {                                                                                                                                \
+    _Pragma("unroll") for (int m_ = 0; m_ < NI * NJ; ++m_) {                                                                          \
+      if (m_ % NJ == 0)                                                                                                               \
+        asm volatile("s_waitcnt lgkmcnt(%3)"                                                                                          \
+                     : "+v"(fa[cur][m_ / NJ]), "+v"(fb[cur][0]), "+v"(fb[cur][NJ - 1])                                                \
+                     : "n"(2 * (NI - 1 - m_ / NJ + ((m_ / NJ) * NJ < NR ? (m_ / NJ) * NJ : NR)))                                      \
+                     : "memory");                                                                                                     \
+      acc[m_ / NJ][m_ % NJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[cur][m_ / NJ]),                   \
+                                                                     __builtin_bit_cast(bf16x8, fb[cur][m_ % NJ]), acc[m_ / NJ][m_ % NJ], 0, 0, 0); \
+      __builtin_amdgcn_sched_barrier(0);                                                                                              \
+      T_RD1(nxt, off_n, kk_n, m_);                                                                                                    \
+      if ((DMA) && m_ < NP && kt + 2 < nkt) stage_piece(kt & 1, kt + 2, m_);                                                          \
+      __builtin_amdgcn_sched_barrier(0);                                                                                              \
+    }                                                                                                                                 \
+  } while (0)
+  stage_tile(0, 0);
+  if (nkt > 1) {
+    stage_tile(1, 1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int r = 0; r < NR; ++r) T_RD1(0, 0u, 0, r);
+  for (int kt = 0; kt < nkt; ++kt) {
+    const unsigned boff = (kt & 1) * 2 * G_TILE, noff = ((kt + 1) & 1) * 2 * G_TILE;
+    __builtin_amdgcn_sched_barrier(0);
+    T_STEP(0, 1, boff, 1, false);
+    T_STEP(1, 0, boff, 2, false);
+    T_STEP(0, 1, boff, 3, false);
+    T_RETIRE_ALL("s_waitcnt vmcnt(0)");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    T_STEP(1, 0, noff, 0, true);
+  }
+  T_RETIRE_ALL("s_waitcnt");
+#undef T_RD1
+#undef T_RD2
+#undef T_ISA
+#undef T_IDX
+#undef T_RETIRE_ALL
+#undef T_STEP
+
+  float* C;
+  long long ldc;
+  const bool partial = g.splitk > 1;
+  if (partial) {
+    C = g.partial + ((long long)zb * g.splitk + zs) * (long long)g.M * g.N;
+    ldc = g.N;
+  } else {
+    C = g.C + (long long)zb * g.sC;
+    ldc = g.ldc;
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int col = n0 + wn * (NJ * 32) + j * 32 + l31;
+      if (col >= g.N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * (NI * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (row < g.M) {
+          float v = acc[i][j][r];
+          float* p = C + (long long)row * ldc + col;
+          if (!partial && g.accumulate) v += *p;
+          *p = v;
+        }
+      }
+    }
+  }
+}
+
 __global__ void splitk_reduce_bf_kernel(const float* __restrict__ part, float* __restrict__ C, const float* __restrict__ bias, int M, int N,
                                         int ldc, long long sC, int splitk, int accumulate) {
   const long long zb = blockIdx.y;
@@ -655,6 +850,43 @@ extern "C" int ds2_gemm_bf16_nt(int M, int N, int K, const void* A, int lda, lon
   if (splitk > 1) {
     hipLaunchKernelGGL(splitk_reduce_bf_kernel, dim3(ceil_div(M * N, 256), batch), dim3(256), 0, s, (const float*)workspace, C, bias, M, N,
                        ldc, strideC, splitk, accumulate);
+    DS2_LAUNCH_CHECK("splitk_reduce_bf_kernel");
+  }
+  return 0;
+}
+
+// C[M,N] fp32 (+)= A[K,M]^T B[K,N]: A (K rows, pitch lda) and B (K rows, pitch ldb) bf16 row-major.  M, N, lda, ldb and the batch
+// strides multiples of 8, 16-byte aligned bases.  batch > 1: independent products at the given element strides (strides may be negative).
+extern "C" int ds2_gemm_bf16_tn(int M, int N, int K, const void* A, int lda, long long strideA, const void* B, int ldb, long long strideB,
+                                float* C, int ldc, long long strideC, int accumulate, int batch, int splitk, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+  DS2_REQUIRE(M >= 8 && N >= 8 && K > 0 && batch >= 1, "ds2_gemm_bf16_tn: bad dims M=%d N=%d K=%d", M, N, K);
+  DS2_REQUIRE(A && B && C, "ds2_gemm_bf16_tn: null pointer");
+  DS2_REQUIRE((M % 8) == 0 && (N % 8) == 0 && (lda % 8) == 0 && (ldb % 8) == 0 && (strideA % 8) == 0 && (strideB % 8) == 0,
+              "ds2_gemm_bf16_tn: M, N, lda, ldb, strides must be multiples of 8 (M=%d N=%d lda=%d ldb=%d)", M, N, lda, ldb);
+  DS2_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "ds2_gemm_bf16_tn: operands must be 16-byte aligned");
+  if (splitk < 1) splitk = 1;
+  int kchunk = ceil_div(ceil_div(K, splitk), BK) * BK;
+  splitk = ceil_div(K, kchunk);
+  if (splitk > 1)
+    DS2_REQUIRE(workspace && workspace_bytes >= ds2_gemm_bf16_workspace_bytes(M, N, batch, splitk), "ds2_gemm_bf16_tn: workspace too small");
+  BArgs g;
+  g.A = (const __bf16*)A; g.B = (const __bf16*)B; g.C = C; g.bias = nullptr;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.sA = strideA; g.sB = strideB; g.sC = strideC;
+  g.splitk = splitk; g.kchunk = kchunk; g.accumulate = accumulate; g.partial = (float*)workspace; g.nt_store = 0;
+  hipStream_t s = (hipStream_t)stream;
+  static bool attr_set = false;
+  if (!attr_set) {
+    DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_tn_glds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
+    attr_set = true;
+  }
+  const int ntx = ceil_div(N, 256), nty = ceil_div(M, 256);
+  hipLaunchKernelGGL(gemm_bf16_tn_glds_kernel, dim3(ntx * nty, 1, batch * splitk), dim3(512), G_LDS, s, g, ntx, nty);
+  DS2_LAUNCH_CHECK("gemm_bf16_tn_glds_kernel");
+  if (splitk > 1) {
+    hipLaunchKernelGGL(splitk_reduce_bf_kernel, dim3(ceil_div(M * N, 256), batch), dim3(256), 0, s, (const float*)workspace, C,
+                       (const float*)nullptr, M, N, ldc, strideC, splitk, accumulate);
     DS2_LAUNCH_CHECK("splitk_reduce_bf_kernel");
   }
   return 0;

@@ -217,6 +217,48 @@ def gemm_bf16_nt_pair(A0: Tensor, A1: Tensor, B0: Tensor, B1: Tensor, out: Tenso
     return out
 
 
+def gemm_bf16_tn(A: Tensor, B: Tensor, out: Optional[Tensor] = None, accumulate: bool = False, splitk: int = 0) -> Tensor:
+    """out[M,N] fp32 (+)= A[K,M]^T @ B[K,N]: A, B bf16 row-major views (column stride 1, any row pitch % 8 == 0) sharing the K rows."""
+    assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and A.is_cuda and B.is_cuda and A.stride(1) == 1 and B.stride(1) == 1
+    lib = _lib.load()
+    K, M = A.shape
+    Kb, N = B.shape
+    assert K == Kb, (A.shape, B.shape)
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    if splitk <= 0:
+        splitk = _pick_splitk(M, N, K)
+    ws, wsb = None, 0
+    if splitk > 1:
+        wsb = lib.ds2_gemm_bf16_workspace_bytes(M, N, 1, splitk)
+        ws = _ws(wsb, A.device)
+    _lib.check(lib.ds2_gemm_bf16_tn(M, N, K, A.data_ptr(), A.stride(0), 0, B.data_ptr(), B.stride(0), 0, out.data_ptr(), _row_pitch(out), 0,
+                                    int(accumulate), 1, splitk, _ptr(ws), wsb, _stream()), "ds2_gemm_bf16_tn")
+    return out
+
+
+def gemm_bf16_tn_pair(A0: Tensor, A1: Tensor, B0: Tensor, B1: Tensor, out: Tensor):
+    """Two equal-shape TN products in ONE launch: out[d] (M, N) = A_d (K, M)^T @ B_d (K, N).  A0/A1 (and B0/B1) are views of one bf16
+    buffer with equal pitches (the two directions of dW_hh: column blocks of dGx / h at row offsets of +-B)."""
+    for t in (A0, A1, B0, B1):
+        assert t.dtype == torch.bfloat16 and t.is_cuda and t.dim() == 2 and t.stride(1) == 1
+    assert A0.shape == A1.shape and B0.shape == B1.shape and A0.stride(0) == A1.stride(0) and B0.stride(0) == B1.stride(0)
+    K, M = A0.shape
+    N = B0.size(1)
+    assert B0.size(0) == K and out.dim() == 3 and out.size(0) == 2 and tuple(out.shape[1:]) == (M, N) and out.stride(2) == 1
+    dA, dB = A1.data_ptr() - A0.data_ptr(), B1.data_ptr() - B0.data_ptr()
+    assert dA % 16 == 0 and dB % 16 == 0
+    lib = _lib.load()
+    splitk = _pick_splitk(M, 2 * N, K)
+    ws, wsb = None, 0
+    if splitk > 1:
+        wsb = lib.ds2_gemm_bf16_workspace_bytes(M, N, 2, splitk)
+        ws = _ws(wsb, A0.device)
+    _lib.check(lib.ds2_gemm_bf16_tn(M, N, K, A0.data_ptr(), A0.stride(0), dA // 2, B0.data_ptr(), B0.stride(0), dB // 2, out.data_ptr(),
+                                    out.stride(1), out.stride(0), 0, 2, splitk, _ptr(ws), wsb, _stream()), "ds2_gemm_bf16_tn")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # BatchNorm1d family on (M, H)
 # ------------------------------------------------------------------------------------------------

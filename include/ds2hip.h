@@ -48,6 +48,12 @@ size_t ds2_gemm_bf16_workspace_bytes(int M, int N, int batch, int splitk);
 int ds2_gemm_bf16_nt(int M, int N, int K, const void* A, int lda, long long strideA, const void* B, int ldb, long long strideB, float* C,
                      int ldc, long long strideC, const float* bias, int accumulate, int batch, int splitk, void* workspace,
                      size_t workspace_bytes, void* stream);
+/* "TN" form: C[M,N] (+)= A[K,M]^T B[K,N], both operands bf16 row-major with the reduction index on the rows (pitches lda / ldb).
+ * The weight-gradient product of the recurrent layers (dW = dGx^T [Xn | h], K = T*B) without a transposed copy of any operand.
+ * M, N, lda, ldb, strides multiples of 8; batch > 1: independent products at the given element strides (may be negative). */
+int ds2_gemm_bf16_tn(int M, int N, int K, const void* A, int lda, long long strideA, const void* B, int ldb, long long strideB, float* C,
+                     int ldc, long long strideC, int accumulate, int batch, int splitk, void* workspace, size_t workspace_bytes,
+                     void* stream);
 int ds2_cast_bf16(const float* src, int ld_src, void* dst, int ld_dst, int R, int Cc, void* stream);
 int ds2_cast_transpose_bf16(const float* src, int ld_src, void* dst, int ld_dst, int R, int Cc, void* stream);
 /* both copies from ONE read of src: dst_r (R, ld_r) = bf16(src) (NULL: skipped), dst_t (C, ld_t) = bf16(src)^T, pads zero
