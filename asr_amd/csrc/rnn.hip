@@ -60,6 +60,11 @@ struct RnnArgs {
   int dbg;            // ablation flags (0 in production)
   // persistent kernels only: batch tiles per direction, workgroups per exchange group (= hidden slices), XCD census on/off, CUs per XCD
   int p_nbt, p_gs, p_census, p_cux;
+  // persistent kernels only, optional (NULL: not produced): operands of the TN-form weight-gradient GEMMs, so that the backward pass needs
+  // no cast / transpose pass over h, d(hn) or dGx
+  __bf16* h_bf;       // fwd: (T,B,2,H) bf16 copy of hbuf
+  __bf16* dhn_bf;     // bwd, GRU: (T,B,2,H) bf16 copy of d(hn) (aux)
+  float* bsum;        // bwd: (B,2,4,H) per-batch-row sums over time of [d r, d z, d n, d(hn)] (GRU) / [d i, d f, d g, d o] (LSTM): bias gradients
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -623,6 +628,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
       else stnt(a.aux + rowH, live ? oaux : 0.f);
     }
     a.hbuf[rowH] = oh;
+    if (a.h_bf) __builtin_nontemporal_store((__bf16)oh, a.h_bf + rowH);
   };
 
   // this wave's chunks of the packed exchange buffer (byte offsets from the buffer's direction base) and the all-pending mask
@@ -1054,8 +1060,12 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_persistent_kernel(RnnArgs a, 
 #pragma unroll
       for (int g = 0; g < G; ++g) stnt(gp + g * H, dgx[g]);
     }
-    if (G == 3) stnt(a.aux + row * H + j, dax);
+    if (G == 3) {
+      stnt(a.aux + row * H + j, dax);
+      if (a.dhn_bf) __builtin_nontemporal_store((__bf16)dax, a.dhn_bf + row * H + j);
+    }
   };
+  float bs[4] = {0.f, 0.f, 0.f, 0.f};                       // this thread's (batch row, unit) sums over time: the bias gradients' partials
 
   unsigned goff[NCW * MB], pend0 = 0;                       // this wave's chunks of the packed exchange buffer, and the all-pending mask
 #pragma unroll
@@ -1177,9 +1187,15 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_persistent_kernel(RnnArgs a, 
     PTRACE(5);
     so_t = t; so_dax = dax;
 #pragma unroll
-    for (int g = 0; g < G; ++g) so_dgx[g] = dgx[g];
+    for (int g = 0; g < G; ++g) { so_dgx[g] = dgx[g]; bs[g] += dgx[g]; }
+    if (G == 3) bs[3] += dax;
   }
   store_results(so_t, so_dgx, so_dax);                      // the last step's results
+  if (a.bsum && pact) {
+    float* o = a.bsum + (((long long)b * 2 + dir) * 4) * H + j;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) o[g * H] = bs[g];
+  }
   PTRACE_DUMP(1);
 }
 
@@ -1503,15 +1519,16 @@ extern "C" size_t ds2_rnn_fwd_workspace_bytes(int B, int H, int bf16) {
 //   wp_fwd packed W_hh (ds2_rnn_pack_whh), bhh (2,G*H) = [bias_hh_l0, bias_hh_l0_reverse]
 //   hbuf   (T,B,2,H) out: h per direction (0 beyond each sample's length)
 //   aux    (T,B,2,H) out: GRU W_hn h + b_hn ; LSTM cell state
-extern "C" int ds2_rnn_fwd(int gates, float* gx, const void* wp_fwd, const float* bhh, float* hbuf, float* aux, const int* lens_dev, int T,
-                           int B, int H, int bf16, void* gates_bf16, void* ws, size_t ws_bytes, void* stream) {
+//   h_bf16 optional (T,B,2,H) bf16: a bf16 copy of hbuf, written by a PERSISTENT launch only (ds2_rnn_last_path() & 1 after the call)
+extern "C" int ds2_rnn_fwd_ex(int gates, float* gx, const void* wp_fwd, const float* bhh, float* hbuf, float* aux, const int* lens_dev, int T,
+                              int B, int H, int bf16, void* gates_bf16, void* h_bf16, void* ws, size_t ws_bytes, void* stream) {
   DS2_REQUIRE(gates == 3 || gates == 4, "ds2_rnn_fwd: gates must be 3 (GRU) or 4 (LSTM)");
   DS2_REQUIRE(gx && wp_fwd && bhh && hbuf && aux && lens_dev, "ds2_rnn_fwd: null pointer");
   DS2_REQUIRE(T > 0 && B > 0 && H > 0 && (H % 4) == 0, "ds2_rnn_fwd: need H %% 4 == 0 (H=%d)", H);
   DS2_REQUIRE(ws && ws_bytes >= ds2_rnn_fwd_workspace_bytes(B, H, bf16), "ds2_rnn_fwd: workspace too small");
   RnnArgs a{};
   a.gx = gx; a.aux = aux; a.hbuf = hbuf; a.wp = (const float*)wp_fwd; a.bhh = bhh; a.pk = (float*)ws; a.lens = lens_dev;
-  a.T = T; a.B = B; a.H = H; a.gates_bf = (__bf16*)gates_bf16;
+  a.T = T; a.B = B; a.H = H; a.gates_bf = (__bf16*)gates_bf16; a.h_bf = (__bf16*)h_bf16;
   {
     a.dbg = g_ds2_debug_flags;
     hipStream_t st = (hipStream_t)stream;
@@ -1523,6 +1540,11 @@ extern "C" int ds2_rnn_fwd(int gates, float* gx, const void* wp_fwd, const float
   // step kernels: zero padding rows / columns of the ping-pong buffers (the persistent path has filled its own with the sentinel)
   DS2_HIP(hipMemsetAsync(ws, 0, ds2_rnn_fwd_workspace_bytes(B, H, bf16), (hipStream_t)stream));
   return bf16 ? dispatch<true>(gates, false, a, (hipStream_t)stream) : dispatch<false>(gates, false, a, (hipStream_t)stream);
+}
+
+extern "C" int ds2_rnn_fwd(int gates, float* gx, const void* wp_fwd, const float* bhh, float* hbuf, float* aux, const int* lens_dev, int T,
+                           int B, int H, int bf16, void* gates_bf16, void* ws, size_t ws_bytes, void* stream) {
+  return ds2_rnn_fwd_ex(gates, gx, wp_fwd, bhh, hbuf, aux, lens_dev, T, B, H, bf16, gates_bf16, nullptr, ws, ws_bytes, stream);
 }
 
 extern "C" size_t ds2_rnn_bwd_workspace_bytes(int gates, int B, int H, int bf16) {
@@ -1573,9 +1595,12 @@ extern "C" int ds2_rnn_persistent_counters(int* out2) {
 //   gates_bf16 optional (T,B,2,H,4) bf16 packed gate records written by ds2_rnn_fwd(gates_bf16): read instead of gx (+ GRU aux)
 //   aux    GRU: in hn, out d(hn) [so that dGh = (dGx_r, dGx_z, aux)] ; LSTM: cell state (unchanged; dGh = dGx)
 //   wp_bwd packed W_hh^T (ds2_rnn_pack_whh)
-extern "C" int ds2_rnn_bwd(int gates, const float* dy, int lddy, float* gx, float* aux, const float* hbuf, const void* wp_bwd,
-                           const int* lens_dev, int T, int B, int H, int bf16, void* dgx_bf16, const void* gates_bf16, void* ws, size_t ws_bytes,
-                           void* stream) {
+//   dhn_bf16  optional (T,B,2,H) bf16 (GRU): a bf16 copy of the d(hn) written into aux          } written by a PERSISTENT launch only
+//   bias_part optional (B,2,4,H) fp32: per-batch-row sums over time of [d r, d z, d n, d(hn)] (GRU)  } (ds2_rnn_last_path() & 2 after the
+//             / [d i, d f, d g, d o] (LSTM); their column sums over B are db_ih / db_hh             } call); untouched otherwise
+extern "C" int ds2_rnn_bwd_ex(int gates, const float* dy, int lddy, float* gx, float* aux, const float* hbuf, const void* wp_bwd,
+                              const int* lens_dev, int T, int B, int H, int bf16, void* dgx_bf16, const void* gates_bf16, void* dhn_bf16,
+                              float* bias_part, void* ws, size_t ws_bytes, void* stream) {
   DS2_REQUIRE(gates == 3 || gates == 4, "ds2_rnn_bwd: gates must be 3 (GRU) or 4 (LSTM)");
   DS2_REQUIRE(dy && aux && hbuf && wp_bwd && lens_dev, "ds2_rnn_bwd: null pointer");
   DS2_REQUIRE(gx || (gates_bf16 && dgx_bf16), "ds2_rnn_bwd: gx may only be NULL with both gates_bf16 and dgx_bf16 given");
@@ -1586,6 +1611,7 @@ extern "C" int ds2_rnn_bwd(int gates, const float* dy, int lddy, float* gx, floa
   a.dcar = (float*)ws; a.pk = (float*)ws + (size_t)4 * B * H;
   a.dgx_bf = (__bf16*)dgx_bf16;
   a.gates_bf = (__bf16*)const_cast<void*>(gates_bf16);
+  a.dhn_bf = (__bf16*)dhn_bf16; a.bsum = bias_part;
   a.lens = lens_dev; a.T = T; a.B = B; a.H = H;
   {
     a.dbg = g_ds2_debug_flags;
@@ -1597,4 +1623,11 @@ extern "C" int ds2_rnn_bwd(int gates, const float* dy, int lddy, float* gx, floa
   }
   DS2_HIP(hipMemsetAsync(ws, 0, ds2_rnn_bwd_workspace_bytes(gates, B, H, bf16), (hipStream_t)stream));   // step kernels: zero carry + padding
   return bf16 ? dispatch<true>(gates, true, a, (hipStream_t)stream) : dispatch<false>(gates, true, a, (hipStream_t)stream);
+}
+
+extern "C" int ds2_rnn_bwd(int gates, const float* dy, int lddy, float* gx, float* aux, const float* hbuf, const void* wp_bwd,
+                           const int* lens_dev, int T, int B, int H, int bf16, void* dgx_bf16, const void* gates_bf16, void* ws, size_t ws_bytes,
+                           void* stream) {
+  return ds2_rnn_bwd_ex(gates, dy, lddy, gx, aux, hbuf, wp_bwd, lens_dev, T, B, H, bf16, dgx_bf16, gates_bf16, nullptr, nullptr, ws, ws_bytes,
+                        stream);
 }

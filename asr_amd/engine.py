@@ -33,6 +33,11 @@ import os as _os
 #   "0"            one stream
 OVERLAP_MODE = _os.environ.get("DS2_OVERLAP", "2")
 OVERLAP_WGRAD = OVERLAP_MODE == "1"
+# Weight gradients of the recurrent layers in bf16 mode (DS2_WGRAD_TN, default 1): dW_ih / dW_hh as TN-form GEMMs straight from the row-major
+# bf16 buffers the recurrence kernels write (dGx, d(hn), h) and the forward pass kept (Xn), bias gradients from the per-row sums of the
+# backward recurrence — no cast / transpose pass at all.  Needs both recurrences of the layer to have run as persistent launches (they are
+# the ones that write the bf16 copies); a layer whose recurrences did not keeps the transposing-cast passes below.  0: always those passes.
+WGRAD_TN = _os.environ.get("DS2_WGRAD_TN", "1") != "0"
 _BWD_PERSISTENT = {}      # (gates, H, B) -> did the last backward recurrence of this shape run as a persistent launch?
 _SIDE = {}
 
@@ -69,6 +74,7 @@ class LayerCtx:
     var: Optional[Tensor] = None
     wpb: Optional[Tensor] = None     # W_hh^T in fragment order for the backward recurrence
     rec: Optional[Tensor] = None     # bf16 training: packed saved-gate records (M, 2H, 4) instead of gates in gx
+    h_bf: Optional[Tensor] = None    # bf16 training, persistent forward recurrence: (M, 2H) bf16 copy of hbuf (operand of the TN-form dW_hh)
     gshape: tuple = ()               # (M, 2GH) when gx itself was released
 
 
@@ -175,9 +181,12 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
         # hidden unit; the fp32 x-projection buffer is then dead after the recurrence
         pack = bf and save and B % 8 == 0
         if pack:
-            hbuf, aux, rec = ops.rnn_fwd(G, gx, wpf, W[f"rnns.{l}.bhh_cat"], lens_dev, T, B, H, bf16=True, packed_gates=True)
+            h_bf = torch.empty(M, 2 * H, dtype=torch.bfloat16, device=x.device) if (WGRAD_TN and OVERLAP_MODE == "2" and T > 1) else None
+            hbuf, aux, rec = ops.rnn_fwd(G, gx, wpf, W[f"rnns.{l}.bhh_cat"], lens_dev, T, B, H, bf16=True, packed_gates=True, h_bf16=h_bf)
             gx = None
             lc.rec, lc.gshape = rec, (M, 2 * G * H)
+            if h_bf is not None and (ops.rnn_last_path() & 1):
+                lc.h_bf = h_bf                                   # (only a persistent launch writes it)
         else:
             hbuf, aux = ops.rnn_fwd(G, gx, wpf, W[f"rnns.{l}.bhh_cat"], lens_dev, T, B, H, bf16=bf)
         lc.wpb = wpb
@@ -233,6 +242,33 @@ def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy: Tensor, done):
                 t.record_stream(main)
         done(f"rnns.{l}")
 
+    def weight_gradients_tn(l, dgx_bf, dhn_bf, h_bf, xn, bias_part):
+        """layer l's bias / weight gradients from the row-major bf16 buffers: TN-form GEMMs (reduction index T*B on the rows of both
+        operands), the time shift of dW_hh is a ROW offset of B"""
+        sums = ops.colsum(bias_part.view(B, 8 * H)).view(2, 4, H)                                 # over the batch rows
+        dbih, dbhh = Gr[f"rnns.{l}.bih_cat"].view(2, G * H), Gr[f"rnns.{l}.bhh_cat"]
+        if G == 3:
+            dbih.copy_(sums[:, :3].reshape(2, 3 * H))                                             # [d r, d z, d n]
+            dbhh[:, :2 * H] = sums[:, :2].reshape(2, 2 * H)
+            dbhh[:, 2 * H:] = sums[:, 3]                                                          # d(b_hn) = sum of d(hn)
+        else:
+            dbih.copy_(sums.reshape(2, 4 * H))
+            dbhh.copy_(dbih)
+        dwhh = Gr[f"rnns.{l}.whh_cat"]                                                            # (2, GH, H)
+        rows = 2 * H if G == 3 else 4 * H
+        # direction 0 pairs dGh[t] with h[t-1], direction 1 dGh[t] with h[t+1]
+        ra, rb = (slice(B, M), slice(0, M - B)), (slice(0, M - B), slice(B, M))
+        ops.gemm_bf16_tn_pair(dgx_bf[ra[0], 0:rows], dgx_bf[ra[1], G * H:G * H + rows], h_bf[rb[0], 0:H], h_bf[rb[1], H:2 * H], dwhh[:, :rows])
+        if G == 3:
+            ops.gemm_bf16_tn_pair(dhn_bf[ra[0], 0:H], dhn_bf[ra[1], H:2 * H], h_bf[rb[0], 0:H], h_bf[rb[1], H:2 * H], dwhh[:, 2 * H:])
+        dwih = Gr[f"rnns.{l}.wih_cat"]                                                            # (2GH, I)
+        I = dwih.shape[1]
+        if I % 8 == 0:
+            ops.gemm_bf16_tn(dgx_bf, xn[:, :I], out=dwih)
+        else:                                                    # xn is zero-padded to a multiple of 8 columns
+            dwih.copy_(ops.gemm_bf16_tn(dgx_bf, xn)[:, :I])
+        done(f"rnns.{l}")
+
     # the side stream only pays beside a PERSISTENT recurrence (its resident workgroups leave registers and LDS for light kernels); beside
     # one-launch-per-step kernels (shapes whose W_hh^T slice does not fit: LSTM H = 1280) co-running passes delay every launch
     # (c4: 94.6 -> 99.5 ms per step), so there the passes stay on the compute stream.  What the library did for this shape is known from
@@ -265,6 +301,7 @@ def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy: Tensor, done):
         return (l, dgxT, hT, auxT, xnT, ready, (dgx_bf,))
 
     queued = None                                                # layer whose operand passes wait for the next recurrence launch
+    queued_tn = None
     for l in range(L - 1, -1, -1):
         lc = ctx.layers[l]
         if queued is not None:
@@ -275,13 +312,21 @@ def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy: Tensor, done):
             pending = operand_passes(*queued, start)
             queued = None
         dgx_bf = torch.empty(lc.gshape if lc.rec is not None else lc.gx.shape, dtype=torch.bfloat16, device=dy.device)
-        ops.rnn_bwd(G, dy, lc.gx, lc.aux, lc.hbuf, lc.wpb, lens_dev, T, B, H, bf16=True, dgx_bf16=dgx_bf, gates_bf16=lc.rec)
+        want_tn = lc.h_bf is not None
+        dhn_bf = torch.empty(M, 2 * H, dtype=torch.bfloat16, device=dy.device) if (want_tn and G == 3) else None
+        bias_part = torch.empty(B, 2, 4, H, dtype=torch.float32, device=dy.device) if want_tn else None
+        ops.rnn_bwd(G, dy, lc.gx, lc.aux, lc.hbuf, lc.wpb, lens_dev, T, B, H, bf16=True, dgx_bf16=dgx_bf, gates_bf16=lc.rec, dhn_bf16=dhn_bf,
+                    bias_part=bias_part)
         _BWD_PERSISTENT[shape_key] = bool(lib.ds2_rnn_last_path() & 2)
+        tn = want_tn and _BWD_PERSISTENT[shape_key]              # (only a persistent launch writes d(hn) in bf16 and the bias sums)
         lc.rec = None
         if pending is not None:
             weight_gradients(pending)                            # heavy work of the layer above: on the compute stream, behind this launch
             pending = None
-        queued = (l, (lc.aux, lc.hbuf, lc.xn), dgx_bf)
+        if tn:
+            queued_tn = (l, dgx_bf, dhn_bf, lc.h_bf, lc.xn, bias_part)
+        else:
+            queued = (l, (lc.aux, lc.hbuf, lc.xn), dgx_bf)
         # ---- critical path: dXn = dGx W_ih -> BatchNorm1d backward -> the next layer's dy
         dxn = ops.gemm_bf16_nt(dgx_bf, ops.cast_transpose_bf16(W[f"rnns.{l}.wih_cat"]))
         if l > 0:
@@ -290,11 +335,15 @@ def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy: Tensor, done):
         else:
             dy = dxn
         del dxn
-        lc.gx = lc.aux = lc.hbuf = lc.xn = lc.wpb = None
-    start = torch.cuda.Event()                                   # layer 0: nothing latency-bound follows; run its passes now
-    start.record(main)
-    pending = operand_passes(*queued, start)
-    weight_gradients(pending)
+        if tn:
+            weight_gradients_tn(*queued_tn)                      # nothing to prepare: straight behind the critical-path work of the layer
+            queued_tn = None
+        lc.gx = lc.aux = lc.hbuf = lc.xn = lc.wpb = lc.h_bf = None
+    if queued is not None:
+        start = torch.cuda.Event()                               # layer 0: nothing latency-bound follows; run its passes now
+        start.record(main)
+        pending = operand_passes(*queued, start)
+        weight_gradients(pending)
     return dy
 
 

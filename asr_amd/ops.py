@@ -659,39 +659,55 @@ def rnn_persistent_counters():
 
 
 def rnn_fwd(gates: int, gx: Tensor, wp_fwd: Tensor, bhh: Tensor, lens_dev: Tensor, T: int, B: int, H: int, bf16: bool = False,
-            packed_gates: bool = False):
+            packed_gates: bool = False, h_bf16: Optional[Tensor] = None):
     """gx (T*B, 2*G*H) in/out; returns (hbuf (T*B, 2H), aux (T*B, 2H)[, gates_bf (T*B, 2H, 4) bf16]).
     packed_gates: the saved-for-backward gates go to one 8-byte bf16 record per hidden unit (gx keeps the x-projections; GRU aux
-    is not written) — pass the returned buffer to rnn_bwd."""
+    is not written) — pass the returned buffer to rnn_bwd.
+    h_bf16: optional (T*B, 2H) bf16 buffer that receives a bf16 copy of hbuf — by a persistent launch only (rnn_last_path() & 1)."""
     _chk_f32(gx, bhh)
     assert gx.is_contiguous() and bhh.is_contiguous()
+    if h_bf16 is not None:
+        assert h_bf16.dtype == torch.bfloat16 and h_bf16.is_contiguous() and h_bf16.numel() == T * B * 2 * H
     lib = _lib.load()
     hbuf = torch.empty(T * B, 2 * H, dtype=torch.float32, device=gx.device)
     aux = torch.empty_like(hbuf)
     rec = torch.empty(T * B, 2 * H, 4, dtype=torch.bfloat16, device=gx.device) if packed_gates else None
     wsb = lib.ds2_rnn_fwd_workspace_bytes(B, H, int(bf16))
     ws = _ws(wsb, gx.device)
-    _lib.check(lib.ds2_rnn_fwd(gates, gx.data_ptr(), wp_fwd.data_ptr(), bhh.data_ptr(), hbuf.data_ptr(), aux.data_ptr(),
-                               lens_dev.data_ptr(), T, B, H, int(bf16), _ptr(rec), ws.data_ptr(), wsb, _stream()), "ds2_rnn_fwd")
+    _lib.check(lib.ds2_rnn_fwd_ex(gates, gx.data_ptr(), wp_fwd.data_ptr(), bhh.data_ptr(), hbuf.data_ptr(), aux.data_ptr(),
+                                  lens_dev.data_ptr(), T, B, H, int(bf16), _ptr(rec), _ptr(h_bf16), ws.data_ptr(), wsb, _stream()),
+               "ds2_rnn_fwd")
     return (hbuf, aux, rec) if packed_gates else (hbuf, aux)
 
 
+def rnn_last_path() -> int:
+    """bit 0 / bit 1: the last rnn_fwd / rnn_bwd call ran as one persistent launch (and produced its optional outputs)"""
+    return _lib.load().ds2_rnn_last_path()
+
+
 def rnn_bwd(gates: int, dy: Tensor, gx: Optional[Tensor], aux: Tensor, hbuf: Tensor, wp_bwd: Tensor, lens_dev: Tensor, T: int, B: int, H: int,
-            bf16: bool = False, dgx_bf16: Optional[Tensor] = None, gates_bf16: Optional[Tensor] = None):
+            bf16: bool = False, dgx_bf16: Optional[Tensor] = None, gates_bf16: Optional[Tensor] = None, dhn_bf16: Optional[Tensor] = None,
+            bias_part: Optional[Tensor] = None):
     """dgx_bf16: optional (T*B, 2*G*H) bf16 buffer that receives dGx (then `gx` keeps the gates).
-    gates_bf16: the packed records of rnn_fwd(packed_gates=True), read instead of gx / GRU aux (gx may then be None)."""
-    _chk_f32(dy, gx, aux, hbuf)
+    gates_bf16: the packed records of rnn_fwd(packed_gates=True), read instead of gx / GRU aux (gx may then be None).
+    dhn_bf16 (GRU, (T*B, 2H) bf16 copy of d(hn)) and bias_part ((B, 2, 4, H) fp32 per-batch-row sums over time of the gate gradients):
+    optional outputs of a persistent launch only (rnn_last_path() & 2)."""
+    _chk_f32(dy, gx, aux, hbuf, bias_part)
     if dgx_bf16 is not None:
         assert dgx_bf16.dtype == torch.bfloat16 and dgx_bf16.is_contiguous() and dgx_bf16.numel() == T * B * 2 * gates * H
     if gates_bf16 is not None:
         assert gates_bf16.dtype == torch.bfloat16 and gates_bf16.is_contiguous() and gates_bf16.numel() == T * B * 2 * H * 4
+    if dhn_bf16 is not None:
+        assert dhn_bf16.dtype == torch.bfloat16 and dhn_bf16.is_contiguous() and dhn_bf16.numel() == T * B * 2 * H
+    if bias_part is not None:
+        assert bias_part.is_contiguous() and bias_part.numel() == B * 2 * 4 * H
     assert gx is not None or (dgx_bf16 is not None and gates_bf16 is not None)
     lib = _lib.load()
     wsb = lib.ds2_rnn_bwd_workspace_bytes(gates, B, H, int(bf16))
     ws = _ws(wsb, dy.device)
-    _lib.check(lib.ds2_rnn_bwd(gates, dy.data_ptr(), _row_pitch(dy), _ptr(gx), aux.data_ptr(), hbuf.data_ptr(), wp_bwd.data_ptr(),
-                               lens_dev.data_ptr(), T, B, H, int(bf16), _ptr(dgx_bf16), _ptr(gates_bf16), ws.data_ptr(), wsb, _stream()),
-               "ds2_rnn_bwd")
+    _lib.check(lib.ds2_rnn_bwd_ex(gates, dy.data_ptr(), _row_pitch(dy), _ptr(gx), aux.data_ptr(), hbuf.data_ptr(), wp_bwd.data_ptr(),
+                                  lens_dev.data_ptr(), T, B, H, int(bf16), _ptr(dgx_bf16), _ptr(gates_bf16), _ptr(dhn_bf16), _ptr(bias_part),
+                                  ws.data_ptr(), wsb, _stream()), "ds2_rnn_bwd")
 
 
 # ------------------------------------------------------------------------------------------------

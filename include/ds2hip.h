@@ -183,12 +183,23 @@ size_t ds2_rnn_fwd_workspace_bytes(int B, int H, int bf16);
  * and, for GRU, aux is not written).  Pass the same buffer to ds2_rnn_bwd. */
 int ds2_rnn_fwd(int gates, float* gx, const void* wp_fwd, const float* bhh, float* hbuf, float* aux, const int* lens_dev, int T, int B,
                 int H, int bf16, void* gates_bf16, void* ws, size_t ws_bytes, void* stream);
+/* ds2_rnn_fwd plus h_bf16: NULL, or a (T,B,2,H) bf16 buffer that receives a bf16 copy of hbuf (the K-row-major operand of the TN-form
+ * dW_hh GEMM).  Written by a PERSISTENT launch only: check ds2_rnn_last_path() & 1 after the call. */
+int ds2_rnn_fwd_ex(int gates, float* gx, const void* wp_fwd, const float* bhh, float* hbuf, float* aux, const int* lens_dev, int T, int B,
+                   int H, int bf16, void* gates_bf16, void* h_bf16, void* ws, size_t ws_bytes, void* stream);
 size_t ds2_rnn_bwd_workspace_bytes(int gates, int B, int H, int bf16);
 /* dgx_bf16: NULL, or a (T,B,2,G*H) bf16 buffer that receives the gradient wrt the x-projections instead of gx (which then keeps
  * the gates): the bf16-mode GEMMs consume it directly.  gates_bf16: NULL, or the packed records written by ds2_rnn_fwd — read
  * instead of gx (and, for GRU, instead of aux, which is then output only: d(W_hn h + b_hn)); gx may be NULL when both are given. */
 int ds2_rnn_bwd(int gates, const float* dy, int lddy, float* gx, float* aux, const float* hbuf, const void* wp_bwd, const int* lens_dev,
                 int T, int B, int H, int bf16, void* dgx_bf16, const void* gates_bf16, void* ws, size_t ws_bytes, void* stream);
+
+/* ds2_rnn_bwd plus two optional outputs of a PERSISTENT launch (check ds2_rnn_last_path() & 2 after the call; untouched otherwise):
+ * dhn_bf16 (GRU): (T,B,2,H) bf16 copy of d(W_hn h + b_hn); bias_part: (B,2,4,H) fp32 per-batch-row sums over time of
+ * [d r, d z, d n, d(hn)] (GRU) / [d i, d f, d g, d o] (LSTM) - their column sums over B are the bias gradients, so no pass over dGx. */
+int ds2_rnn_bwd_ex(int gates, const float* dy, int lddy, float* gx, float* aux, const float* hbuf, const void* wp_bwd, const int* lens_dev,
+                   int T, int B, int H, int bf16, void* dgx_bf16, const void* gates_bf16, void* dhn_bf16, float* bias_part, void* ws,
+                   size_t ws_bytes, void* stream);
 
 /* ---- log-softmax + CTC loss + gradient ---------------------------------------------------------
  * out.float().log_softmax(2) + torch.nn.CTCLoss(reduction="sum") and their backward,

@@ -254,3 +254,47 @@ def test_bf16_gradients_vs_fp32_path(rnn, hidden, layers, B, tmax):
     except OSError:
         pass
     assert worst_rnn <= 4e-2 and worst_conv <= bound_conv and min_cos >= 0.995, (worst_rnn, worst_conv, bound_conv, min_cos)
+
+
+@pytest.mark.parametrize("rnn,hidden,layers,B,tmax", [("gru", 128, 3, 16, 120), ("lstm", 64, 2, 8, 90), ("gru", 1024, 2, 64, 301)])
+def test_weight_gradients_tn_form_vs_transposing_cast_path(rnn, hidden, layers, B, tmax, monkeypatch):
+    """bf16 mode, recurrent layers: the TN-form weight-gradient GEMMs (row-major bf16 dGx / d(hn) / h written by the persistent recurrence
+    kernels, bias gradients from their per-row sums) against the transposing-cast path they replace (DS2_WGRAD_TN=0).  Same bf16 operand
+    values and the same accumulation order, so every weight gradient must be BIT-identical.  Bias gradients: the cast path sums the
+    bf16-ROUNDED dGx it reads back, the kernels sum the fp32 values before rounding (closer to the fp32 path) - they differ by the
+    rounding noise of T*B bf16 terms (a few 1e-3 of the norm; bound 1e-2); d(b_hn) is a sum of the same fp32 terms either way (1e-5)."""
+    from asr_amd import engine, ops
+    cfg = dict(rnn=rnn, hidden=hidden, layers=layers, classes=29)
+    t_ins = sorted([int(v) for v in det.randint((B,), 77, tmax // 3, tmax + 1)], reverse=True)
+    t_ins[0] = tmax
+    cfg["t_ins"] = t_ins
+    torch.manual_seed(0)
+    model = make_model(cfg)
+    x, targets, pct, tsz = map(torch.from_numpy, det.batch(B, t_ins, 29, seed=11))
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    calls = {"tn": 0}
+    real = ops.gemm_bf16_tn_pair
+
+    def counted(*a, **k):
+        calls["tn"] += 1
+        return real(*a, **k)
+
+    monkeypatch.setattr(ops, "gemm_bf16_tn_pair", counted)
+    monkeypatch.setattr(engine, "WGRAD_TN", True)
+    g_tn, l_tn, _ = _grads_of(model, "bf16", x, targets, pct, tsz, sd0)
+    assert calls["tn"] >= layers, "the TN-form path did not run (recurrences not persistent?)"
+    n_tn = calls["tn"]
+    monkeypatch.setattr(engine, "WGRAD_TN", False)
+    g_ct, l_ct, _ = _grads_of(model, "bf16", x, targets, pct, tsz, sd0)
+    assert calls["tn"] == n_tn
+    assert l_tn == l_ct
+    for n in g_tn:
+        a, b = g_tn[n], g_ct[n]
+        if n.startswith("rnns.") and ("bias_ih" in n or "bias_hh" in n):
+            err = float((a - b).norm() / b.norm().clamp_min(1e-30))
+            assert err <= 1e-2, (n, err)
+            if rnn == "gru" and "bias_hh" in n:
+                an, bn = a[2 * hidden:], b[2 * hidden:]
+                assert float((an - bn).norm() / bn.norm().clamp_min(1e-30)) <= 1e-5, n
+        else:
+            assert torch.equal(a, b), (n, float((a - b).abs().max()))
