@@ -420,6 +420,57 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(BArgs g
     C = g.C + (long long)zb * g.sC;
     ldc = g.ldc;
   }
+  // ---- epilogue, wide form (whenever the C rows are 16-byte addressable): every 32 x 32 accumulator tile goes through a wave-private LDS
+  // patch and leaves as 16-byte stores, 8 rows x 128 B per wave-instruction - a quarter of the store instructions of the lane-per-column
+  // form below (the address unit spends ~16 cycles on a wave-instruction whatever the width per lane: 256 KB of C per tile take
+  // ~16 B/clk with 4-byte lanes).  Patch pitch 40 floats: the two half-waves of a write (rows r, r + 4) land on disjoint bank halves.
+  {
+    const bool wide = (g.N % 4) == 0 && (ldc % 4) == 0 && ((uintptr_t)C % 16) == 0 && !(g.nt_store & (32 | 64 | 128)) &&
+                      (partial || !g.bias || ((uintptr_t)g.bias % 16) == 0);
+    if constexpr (NWV == 8) if (wide) {                // (the 16-wave variant sits at its 128-register cap: with this branch compiled in it spills accumulators inside the main loop)
+      constexpr int EP = 40;
+      __syncthreads();                                  // every wave is done with the operand tiles: the LDS is free
+      // everything the epilogue addresses with is derived from an opaque copy of the lane id made HERE: computed from `lane` the compiler
+      // hoists it above the main loop, and the 16-wave variant (128 registers) then spills accumulators inside the loop
+      int el = lane;
+      asm volatile("" : "+v"(el));
+      const int l31 = el & 31, half = el >> 5;
+      float* patch = reinterpret_cast<float*>(ldsg) + wave * (32 * EP);
+      const int prow = el >> 3, pc4 = (el & 7) * 4;
+      const bool stream_out = !partial && (g.nt_store & 1);
+      f32x4 bv[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int col = n0 + wn * (NJ * 32) + j * 32 + pc4;
+        bv[j] = (!partial && g.bias && col < g.N) ? *reinterpret_cast<const f32x4*>(g.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * half) * EP + l31] = acc[i][j][r];
+          __builtin_amdgcn_wave_barrier();              // (LDS executes a wave's instructions in order; this only pins the compiler)
+          const int col = n0 + wn * (NJ * 32) + j * 32 + pc4;
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const int rl = it * 8 + prow;
+            const int row = m0 + wm * (NI * 32) + i * 32 + rl;
+            f32x4 v = *reinterpret_cast<const f32x4*>(&patch[rl * EP + pc4]);
+            if (row < g.M && col < g.N) {
+              v += bv[j];
+              f32x4* pc = reinterpret_cast<f32x4*>(C + (long long)row * ldc + col);
+              if (!partial && g.accumulate) v += *pc;
+              if (stream_out) __builtin_nontemporal_store(v, pc);
+              else *pc = v;
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+      return;
+    }
+  }
   // bias values of this lane's NJ columns, loaded BEFORE the first store: a load between stores would wait (vmcnt is one in-order
   // counter) for every store issued so far — a serialised HBM write round trip per (i, j) tile of the epilogue
   float bvj[NJ];
@@ -626,6 +677,36 @@ __global__ __launch_bounds__(512) void gemm_bf16_tn_glds_kernel(BArgs g, int ntx
     C = g.C + (long long)zb * g.sC;
     ldc = g.ldc;
   }
+  // wide epilogue (see the NT kernel): 32 x 32 accumulator tiles through a wave-private LDS patch, 16-byte stores
+  if ((ldc % 4) == 0 && ((uintptr_t)C % 16) == 0 && !(g.nt_store & 128)) {
+    constexpr int EP = 40;
+    __syncthreads();
+    float* patch = reinterpret_cast<float*>(ldsg) + wave * (32 * EP);
+    const int prow = lane >> 3, pc4 = (lane & 7) * 4;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * half) * EP + l31] = acc[i][j][r];
+        __builtin_amdgcn_wave_barrier();
+        const int col = n0 + wn * (NJ * 32) + j * 32 + pc4;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int rl = it * 8 + prow;
+          const int row = m0 + wm * (NI * 32) + i * 32 + rl;
+          f32x4 v = *reinterpret_cast<const f32x4*>(&patch[rl * EP + pc4]);
+          if (row < g.M && col < g.N) {                 // (N % 8 == 0: a 4-column run never straddles the edge)
+            f32x4* pc = reinterpret_cast<f32x4*>(C + (long long)row * ldc + col);
+            if (!partial && g.accumulate) v += *pc;
+            *pc = v;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
 #pragma unroll
@@ -814,6 +895,8 @@ extern "C" int ds2_gemm_bf16_nt(int M, int N, int K, const void* A, int lda, lon
   // stores, 32 = C stores aimed at an L2-resident region
   static const int dbg_bits = getenv("DS2_GEMM_DBG") ? atoi(getenv("DS2_GEMM_DBG")) << 1 : 0;
   g.nt_store |= dbg_bits;
+  static const char* wide_env = getenv("DS2_GEMM_WIDE");  // "0": lane-per-column epilogue stores (A/B switch)
+  if (wide_env && wide_env[0] == '0') g.nt_store |= 128;
   hipStream_t s = (hipStream_t)stream;
   // 256 x 256 LDS-DMA kernel whenever its tiles cover at least half the chip; the 128 x 128 kernel for everything smaller
   const long long tiles256 = (long long)ceil_div(N, 256) * ceil_div(M, 256) * batch * splitk;
@@ -827,10 +910,12 @@ extern "C" int ds2_gemm_bf16_nt(int M, int N, int K, const void* A, int lda, lon
       attr_set = true;
     }
     const int ntx = ceil_div(N, 256), nty = ceil_div(M, 256);
-    // short reductions are dominated by the C write-out: 16 waves (64 x 64 per wave, 4 per SIMD) overlap it better (+5-10 % on the
-    // K = 1024 forward projection); long reductions run the k-loop faster with 8 waves (128 x 64 per wave: fewer LDS reads per MFMA)
+    // 8 waves (128 x 64 per wave) for every shape.  Short reductions are dominated by the C write-out; 16 waves (64 x 64 per wave, 4 per
+    // SIMD) used to overlap it better (+5-10 % on the K = 1024 forward projection), but with the wide (16-byte, LDS-staged) epilogue
+    // the 8-wave kernel is 13 % faster there on random operands (549 vs 630 us; whole c3 step, same box: 29.05 vs 29.27 ms) and the
+    // 16-wave variant has no registers left for it.
     static const char* wv = getenv("DS2_GEMM_WAVES");      // "8" | "16" | "pp": tuning override
-    const bool w16 = wv ? (wv[0] == '1') : (kchunk <= 2048);
+    const bool w16 = wv && wv[0] == '1';
     const bool pp = wv && wv[0] == 'p';
     if (pp) {
       static bool pp_attr = false;
@@ -875,6 +960,7 @@ extern "C" int ds2_gemm_bf16_tn(int M, int N, int K, const void* A, int lda, lon
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.sA = strideA; g.sB = strideB; g.sC = strideC;
   g.splitk = splitk; g.kchunk = kchunk; g.accumulate = accumulate; g.partial = (float*)workspace; g.nt_store = 0;
+  { static const char* wide_env = getenv("DS2_GEMM_WIDE"); if (wide_env && wide_env[0] == '0') g.nt_store |= 128; }
   hipStream_t s = (hipStream_t)stream;
   static bool attr_set = false;
   if (!attr_set) {

@@ -1,0 +1,100 @@
+"""Build-time checks on the generated gfx950 code of asr_amd/csrc/gemm_bf16.hip (no GPU needed: hipcc -S).
+
+1. No hot GEMM kernel spills registers (the 16-wave NT variant is allowed its 3 prologue dwords).
+2. TN kernel: the fragment reads (`ds_read_b64_tr_b16`, inline asm) and the `s_waitcnt lgkmcnt` that retires them are separate
+   statements; between a read and the wait that covers it NO instruction may touch the destination registers - a register copy there
+   would move data that has not landed (silently wrong results).  The C++ joins the two halves of an operand right behind the reads and
+   relies on the register coalescer to make that a no-op; this walks the main loop and proves it for the binary actually built.
+
+    python scripts/check_isa.py        -> prints a summary, exit code 1 on a violation
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "asr_amd", "csrc", "gemm_bf16.hip")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def compile_asm() -> str:
+    out = os.path.join(tempfile.mkdtemp(prefix="ds2isa"), "gemm_bf16.s")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-x", "hip", "--cuda-device-only", "-S", SRC,
+           "-o", out]
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
+def spill_table(asm: str):
+    names = re.findall(r"\.name:\s+(\S+)", asm)
+    spills = re.findall(r"\.vgpr_spill_count:\s+(\d+)", asm)
+    return {n: int(s) for n, s in zip(names, spills)}
+
+
+def _regs(tok: str):
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"v(\d+)", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def check_tn_loop(asm: str):
+    m = re.search(r"^(_ZN\S*gemm_bf16_tn_glds_kernel\w*):[^\n]*\n(.*?)s_endpgm", asm, re.S | re.M)
+    assert m, "TN kernel not found"
+    lines = [l.strip() for l in m.group(2).splitlines()]
+    lines = [l for l in lines if l and not l.startswith((";", "//")) and not (l.startswith(".") and not l.endswith(":"))]
+    pending = []          # destination register sets of LDS reads not yet covered by a wait, oldest first
+    reads = violations = 0
+    for l in lines:
+        op, _, rest = l.partition(" ")
+        if l.endswith(":") or op.startswith(("s_branch", "s_cbranch")):
+            pending = []                                      # basic-block boundary: the walk is per straight-line region (a copy the
+            continue                                          # compiler inserts sits in the block of the read or of the wait)
+        toks = [t.strip() for t in re.split(r"[ ,]+", rest) if t.strip()]
+        if op == "ds_read_b64_tr_b16":
+            reads += 1
+            busy = set().union(*pending) if pending else set()
+            if _regs(toks[1]) & busy:                       # address register still in flight
+                violations += 1
+            pending.append(_regs(toks[0]))
+            continue
+        if op == "s_waitcnt":
+            mm = re.search(r"lgkmcnt\((\d+)\)", rest)
+            if mm:
+                n = int(mm.group(1))
+                pending = pending[len(pending) - n:] if n else []
+            continue
+        if op.startswith("s_load"):                           # scalar loads share the counter and return out of order: the compiler waits
+            continue                                          # lgkmcnt(0) behind them, which the branch above handles
+        busy = set().union(*pending) if pending else set()
+        if busy:
+            used = set()
+            for t in toks:
+                used |= _regs(t)
+            if used & busy:
+                violations += 1
+                print("  touches in-flight fragment registers:", l)
+    return reads, violations
+
+
+def main() -> int:
+    asm = compile_asm()
+    bad = 0
+    for name, n in spill_table(asm).items():
+        if "gemm_bf16" not in name:
+            continue
+        allowed = 3 if "nt_glds_kernelILi4ELi4" in name else 0
+        flag = "" if n <= allowed else "   <-- SPILLS"
+        print(f"{name}: vgpr spills {n}{flag}")
+        bad += n > allowed
+    reads, viol = check_tn_loop(asm)
+    print(f"TN kernel: {reads} tr-reads walked, {viol} instruction(s) touching in-flight fragment registers")
+    bad += viol
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

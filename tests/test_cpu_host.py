@@ -389,3 +389,17 @@ def test_fused_adamw_state_handling():
         p.grad = torch.zeros_like(p)
     opt.zero_grad()
     assert all(p.grad is None for p in m.parameters())
+
+
+def test_gemm_isa_no_spills_and_no_copy_of_inflight_fragments():
+    """Generated gfx950 code of the bf16 GEMM kernels (hipcc -S, no GPU): no register spills in the hot kernels, and in the TN kernel no
+    instruction touches the destination of an inline-asm `ds_read_b64_tr_b16` before the wait that covers it (scripts/check_isa.py)."""
+    import shutil
+    import subprocess
+    import sys
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_isa.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 instruction(s) touching in-flight" in r.stdout
