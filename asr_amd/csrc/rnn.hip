@@ -1547,6 +1547,28 @@ extern "C" int ds2_rnn_fwd(int gates, float* gx, const void* wp_fwd, const float
   return ds2_rnn_fwd_ex(gates, gx, wp_fwd, bhh, hbuf, aux, lens_dev, T, B, H, bf16, gates_bf16, nullptr, ws, ws_bytes, stream);
 }
 
+// bias gradients from the per-batch-row sums of the persistent backward kernel: part (B,2,4,H) -> db_ih (2,G*H), db_hh (2,G*H).
+// GRU slots [d r, d z, d n, d(hn)]: db_ih = [r, z, n], db_hh = [r, z, hn].  LSTM: both = [i, f, g, o].  Rows summed in index order.
+__global__ void rnn_bias_finalize_kernel(const float* __restrict__ part, int B, int H, int G, float* __restrict__ dbih, float* __restrict__ dbhh) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;        // (dir, slot, j)
+  if (idx >= 2 * 4 * H) return;
+  const int j = idx % H, slot = (idx / H) & 3, dir = idx / (4 * H);
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += part[(long long)b * 8 * H + idx];
+  const long long o = (long long)dir * G * H + j;
+  if (G == 4) { dbih[o + slot * H] = s; dbhh[o + slot * H] = s; }
+  else if (slot < 2) { dbih[o + slot * H] = s; dbhh[o + slot * H] = s; }
+  else if (slot == 2) dbih[o + 2 * H] = s;
+  else dbhh[o + 2 * H] = s;
+}
+
+extern "C" int ds2_rnn_bias_grads(int gates, const float* bias_part, int B, int H, float* dbih, float* dbhh, void* stream) {
+  DS2_REQUIRE((gates == 3 || gates == 4) && bias_part && dbih && dbhh && B > 0 && H > 0, "ds2_rnn_bias_grads: bad args");
+  hipLaunchKernelGGL(rnn_bias_finalize_kernel, dim3(ceil_div(8 * H, 256)), dim3(256), 0, (hipStream_t)stream, bias_part, B, H, gates, dbih, dbhh);
+  DS2_LAUNCH_CHECK("rnn_bias_finalize_kernel");
+  return 0;
+}
+
 extern "C" size_t ds2_rnn_bwd_workspace_bytes(int gates, int B, int H, int bf16) {
   const size_t step = pk_floats(B, H, gates * H, bf16) * sizeof(float);          // two ping-pong buffers of the step kernels
   const size_t pers = 4 * bwd_xbuf_bytes(gates, B, H, bf16) + 64;                 // four round-robin buffers of the persistent kernel + its census words

@@ -245,15 +245,7 @@ def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy: Tensor, done):
     def weight_gradients_tn(l, dgx_bf, dhn_bf, h_bf, xn, bias_part):
         """layer l's bias / weight gradients from the row-major bf16 buffers: TN-form GEMMs (reduction index T*B on the rows of both
         operands), the time shift of dW_hh is a ROW offset of B"""
-        sums = ops.colsum(bias_part.view(B, 8 * H)).view(2, 4, H)                                 # over the batch rows
-        dbih, dbhh = Gr[f"rnns.{l}.bih_cat"].view(2, G * H), Gr[f"rnns.{l}.bhh_cat"]
-        if G == 3:
-            dbih.copy_(sums[:, :3].reshape(2, 3 * H))                                             # [d r, d z, d n]
-            dbhh[:, :2 * H] = sums[:, :2].reshape(2, 2 * H)
-            dbhh[:, 2 * H:] = sums[:, 3]                                                          # d(b_hn) = sum of d(hn)
-        else:
-            dbih.copy_(sums.reshape(2, 4 * H))
-            dbhh.copy_(dbih)
+        ops.rnn_bias_grads(G, bias_part, Gr[f"rnns.{l}.bih_cat"], Gr[f"rnns.{l}.bhh_cat"])           # sums over the batch rows
         dwhh = Gr[f"rnns.{l}.whh_cat"]                                                            # (2, GH, H)
         rows = 2 * H if G == 3 else 4 * H
         # direction 0 pairs dGh[t] with h[t-1], direction 1 dGh[t] with h[t+1]

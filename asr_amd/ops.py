@@ -710,6 +710,14 @@ def rnn_bwd(gates: int, dy: Tensor, gx: Optional[Tensor], aux: Tensor, hbuf: Ten
                                   ws.data_ptr(), wsb, _stream()), "ds2_rnn_bwd")
 
 
+def rnn_bias_grads(gates: int, bias_part: Tensor, dbih: Tensor, dbhh: Tensor):
+    """bias_part (B, 2, 4, H) of rnn_bwd -> dbih (2*G*H,) / dbhh (2, G*H) gradient buffers (contiguous)."""
+    _chk_f32(bias_part, dbih, dbhh)
+    B, _, _, H = bias_part.shape
+    assert bias_part.is_contiguous() and dbih.is_contiguous() and dbhh.is_contiguous() and dbih.numel() == 2 * gates * H == dbhh.numel()
+    _lib.check(_lib.load().ds2_rnn_bias_grads(gates, bias_part.data_ptr(), B, H, dbih.data_ptr(), dbhh.data_ptr(), _stream()), "ds2_rnn_bias_grads")
+
+
 # ------------------------------------------------------------------------------------------------
 # CTC
 # ------------------------------------------------------------------------------------------------

@@ -201,6 +201,10 @@ int ds2_rnn_bwd_ex(int gates, const float* dy, int lddy, float* gx, float* aux, 
                    int T, int B, int H, int bf16, void* dgx_bf16, const void* gates_bf16, void* dhn_bf16, float* bias_part, void* ws,
                    size_t ws_bytes, void* stream);
 
+/* bias gradients of one recurrent layer from ds2_rnn_bwd_ex's bias_part (B,2,4,H): db_ih (2,G*H) [bias_ih_l0 | bias_ih_l0_reverse] and
+ * db_hh (2,G*H); GRU: db_ih = [d r, d z, d n], db_hh = [d r, d z, d(hn)]; LSTM: both = [d i, d f, d g, d o]. */
+int ds2_rnn_bias_grads(int gates, const float* bias_part, int B, int H, float* dbih, float* dbhh, void* stream);
+
 /* ---- log-softmax + CTC loss + gradient ---------------------------------------------------------
  * out.float().log_softmax(2) + torch.nn.CTCLoss(reduction="sum") and their backward,
  * trainers/deepspeech_trainer.py:108-112, trainers/__main__.py:53.  blank = 0, zero_infinity = False. */
