@@ -115,6 +115,41 @@ def test_gemm_bf16_large_tiles(dev, M, N, K, splitk):
         assert torch.equal(out, out2) and rel_l2(out.cpu(), ref.cpu()) < 3e-6
 
 
+@pytest.mark.parametrize("form", ["nt", "tn"])
+@pytest.mark.parametrize("M,N,K,splitk,batch_bias", [(2048, 2048, 2056, 2, True), (4096, 1024, 8192, 4, False), (2056, 2048, 1400, 2, True)])
+def test_gemm_bf16_splitk_is_the_ordered_sum_of_slice_products(dev, form, M, N, K, splitk, batch_bias):
+    """Split-K of the 256 x 256 kernels (NT and TN): the result must be the ordered sum ((0 + p0) + p1) + ... (+ bias) (+ old C) of the
+    per-slice products - bit for bit, run after run.  Each p_k is produced here by an un-split call on that slice's k range (same kernel,
+    same accumulation order).  Shapes: >= 128 tile-slices, so that the NT call takes the 256 x 256 kernel.  (An in-launch combine by each
+    tile's last-arriving slice passed this test too and was 0.45 ms per c3 step SLOWER than the separate reduce kernel: DESIGN.md section 5.)"""
+    from asr_amd import ops
+    A, B, bias = T_(40, M, K), T_(41, N, K), T_(42, N)
+    Ab, Bb = ops.cast_bf16(g(A, dev)), ops.cast_bf16(g(B, dev))
+    Kp = Ab.shape[1]
+    kchunk = -(-(-(-Kp // splitk)) // 64) * 64
+    old = torch.randn(M, N, device=dev)
+    if form == "nt":
+        run = lambda a, b, **kw: ops.gemm_bf16_nt(a, b, **kw)
+        sl = lambda t, k0, k1: t[:, k0:k1]
+        opA, opB = Ab, Bb
+    else:
+        At, Bt = Ab.t().contiguous(), Bb.t().contiguous()          # (K, M), (K, N)
+        run = lambda a, b, **kw: ops.gemm_bf16_tn(a, b, **{k: v for k, v in kw.items() if k != "bias"})
+        sl = lambda t, k0, k1: t[k0:k1]
+        opA, opB = At, Bt
+    ref = torch.zeros(M, N, device=dev)
+    for k0 in range(0, Kp, kchunk):
+        ref = ref + run(sl(opA, k0, min(Kp, k0 + kchunk)), sl(opB, k0, min(Kp, k0 + kchunk)), splitk=1)
+    use_bias = batch_bias and form == "nt"
+    if use_bias:
+        ref = ref + g(bias, dev)
+    ref = ref + old
+    for _ in range(3):
+        out = old.clone()
+        run(opA, opB, out=out, accumulate=True, splitk=splitk, **({"bias": g(bias, dev)} if use_bias else {}))
+        assert torch.equal(out, ref), float((out - ref).abs().max())
+
+
 # ---------------------------------------------------------------------------------------------- BN1d
 @pytest.mark.parametrize("M,H", [(50, 24), (1000, 96), (333, 1312), (64, 5)])
 def test_bn1d(dev, M, H):
