@@ -320,13 +320,21 @@ def main():
     gx2 = gx.clone()
     dyp = torch.randn(M, H, device=dev)
     side = torch.empty(M, 2 * G * H, dtype=torch.bfloat16, device=dev) if pack else None
+    # the train step's own mode (engine.py): the persistent kernels also write the bf16 copies of h / d(hn) and the bias-gradient partial
+    # sums that the TN-form weight-gradient GEMMs consume
+    from asr_amd import engine as _engine
+    tn = pack and _engine.WGRAD_TN and _engine.OVERLAP_MODE == "2" and T > 1
+    h_bf = torch.empty(M, 2 * H, dtype=torch.bfloat16, device=dev) if tn else None
+    dhn_bf = torch.empty(M, 2 * H, dtype=torch.bfloat16, device=dev) if (tn and G == 3) else None
+    bias_part = torch.empty(B, 2, 4, H, device=dev) if tn else None
     torch.cuda.synchronize()
     e0.record()
-    fwd_out = ops.rnn_fwd(G, gx2, wpf, bhh, lens, T, B, H, bf16=bf, packed_gates=pack)
+    fwd_out = ops.rnn_fwd(G, gx2, wpf, bhh, lens, T, B, H, bf16=bf, packed_gates=pack, **({"h_bf16": h_bf} if pack else {}))
     e1.record()
     # the same layer's backward recurrence on the state just saved, in the train step's own mode
     if pack:
-        ops.rnn_bwd(G, dyp, None, fwd_out[1], fwd_out[0], wpb_probe, lens, T, B, H, bf16=True, dgx_bf16=side, gates_bf16=fwd_out[2])
+        ops.rnn_bwd(G, dyp, None, fwd_out[1], fwd_out[0], wpb_probe, lens, T, B, H, bf16=True, dgx_bf16=side, gates_bf16=fwd_out[2],
+                    dhn_bf16=dhn_bf, bias_part=bias_part)
     else:
         ops.rnn_bwd(G, dyp, gx2, fwd_out[1], fwd_out[0], wpb_probe, lens, T, B, H, bf16=bf)
     e2.record()
@@ -355,7 +363,8 @@ def main():
             return None
         return k["hbm_bytes_per_time_step"] * steps if "persistent" in kernel else k["hbm_bytes_per_launch"]
     traffic = pmc_traffic("rnn_fwd_persistent_kernel" if persistent else "rnn_fwd_step_kernel", T)
-    alg_bytes_step = (3 * 4 + 8 + 4 + 2 if pack else 8 * 4 + (2 if bf else 4)) * B * 2 * H
+    # x-projections 3 x 4 + gate record 8 + h 4 + packed h 2 (+ the bf16 copy of h 2) bytes per hidden unit and direction (packed mode)
+    alg_bytes_step = (3 * 4 + 8 + 4 + 2 + (2 if tn else 0) if pack else 8 * 4 + (2 if bf else 4)) * B * 2 * H
     roofline = {"kernel": "rnn_fwd_persistent_kernel" if persistent else "rnn_fwd_step_kernel", "bound": "mfma", "achieved": achieved,
                 "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                 "algorithmic_hbm_bytes_per_launch": alg_bytes_step * (T if persistent else 1),
@@ -370,7 +379,9 @@ def main():
     roofline_bwd = {"kernel": "rnn_bwd_persistent_kernel" if bwd_persistent else "rnn_bwd_step_kernel", "bound": "mfma", "achieved": b_ach,
                     "peak": peak, "unit": "TFLOP/s", "frac": b_ach / peak, "traffic": bwd_traffic,
                     # gate record 8 + previous state 4 + dGx 3 x 2 + d(hn) 4 bytes per hidden unit and direction, dy 4 bytes per unit (packed mode)
-                    "algorithmic_hbm_bytes_per_launch": ((8 + 4 + 2 * G + 4) * 2 + 4 if pack else (4 * G + 4 + 4 + 4 * G + 4) * 2 + 4) * B * H * bl_steps,
+                    # (+ the bf16 copy of d(hn) 2 bytes in the TN-form mode)
+                    "algorithmic_hbm_bytes_per_launch": ((8 + 4 + 2 * G + 4 + (2 if (tn and G == 3) else 0)) * 2 + 4 if pack
+                                                         else (4 * G + 4 + 4 + 4 * G + 4) * 2 + 4) * B * H * bl_steps,
                     "us_per_launch": bwd_layer_us / bl,
                     "us_per_time_step": bwd_layer_us / T, "launches_per_step": bl * L}
     if bwd_layer_us > layer_us:

@@ -10,11 +10,15 @@ whh = (torch.rand(2, G * H, H, device=dev) * 2 - 1) / H ** 0.5
 bhh = torch.zeros(2, G * H, device=dev)
 lens = torch.full((B,), T, dtype=torch.int32, device=dev)
 wpf, wpb = ops.rnn_pack(G, whh, bf16=bf)
-out = ops.rnn_fwd(G, gx, wpf, bhh, lens, T, B, H, bf16=bf, packed_gates=bf)     # the train step's own mode
+# the train step's own mode: packed gate records, bf16 copies of h / d(hn) and bias partial sums for the TN-form weight gradients
+h_bf = torch.empty(T * B, 2 * H, dtype=torch.bfloat16, device=dev) if bf else None
+out = ops.rnn_fwd(G, gx, wpf, bhh, lens, T, B, H, bf16=bf, packed_gates=bf, h_bf16=h_bf)
 if bf:
     hb, aux, rec = out
     dy = torch.randn(T * B, H, device=dev)
     side = torch.empty(T * B, 2 * G * H, dtype=torch.bfloat16, device=dev)
-    ops.rnn_bwd(G, dy, None, aux, hb, wpb, lens, T, B, H, bf16=True, dgx_bf16=side, gates_bf16=rec)
+    dhn = torch.empty(T * B, 2 * H, dtype=torch.bfloat16, device=dev)
+    bias_part = torch.empty(B, 2, 4, H, device=dev)
+    ops.rnn_bwd(G, dy, None, aux, hb, wpb, lens, T, B, H, bf16=True, dgx_bf16=side, gates_bf16=rec, dhn_bf16=dhn, bias_part=bias_part)
 torch.cuda.synchronize()
 print("done", T, "launches")
