@@ -285,6 +285,22 @@ def main():
 
     for _ in range(args.warmup):
         valid, lv = one_step()
+    # The dominant kernels (the two recurrences) are timed live INSIDE the timed region: a HIP event pair on the launch stream around every
+    # ops.rnn_fwd / ops.rnn_bwd call of the K steps (recording an event does not synchronise anything), read back after the final sync.
+    rnn_calls = {"fwd": [], "bwd": []}
+    orig_rnn = (ops.rnn_fwd, ops.rnn_bwd)
+
+    def with_events(fn, key, t_arg, bit):
+        def wrapped(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **k)
+            e1.record()
+            rnn_calls[key].append((e0, e1, int(a[t_arg]), bool(ops.rnn_last_path() & bit)))
+            return r
+        return wrapped
+
+    ops.rnn_fwd, ops.rnn_bwd = with_events(orig_rnn[0], "fwd", 5, 1), with_events(orig_rnn[1], "bwd", 7, 2)
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -295,6 +311,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    ops.rnn_fwd, ops.rnn_bwd = orig_rnn
     tr.synchronize()                                  # settle the last step's device-side verdict (starved-step counter)
     if use_dist:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -343,6 +360,19 @@ def main():
     from asr_amd import _lib as _ds2lib
     path_bits = _ds2lib.load().ds2_rnn_last_path()
     layer_us = e0.elapsed_time(e1) * 1e3                 # one layer's whole forward recurrence (T time steps, both directions)
+    probe = {"fwd_us_per_time_step": layer_us / T, "bwd_us_per_time_step": bwd_layer_us / T}     # (stand-alone probe, kept for reference)
+    timed_in_region = bool(rnn_calls["fwd"]) and bool(rnn_calls["bwd"])
+    if timed_in_region:
+        # averages over the calls of the timed region (per layer call); T = the mean number of time steps per call (c4 / c5 vary)
+        def avg(key):
+            calls = rnn_calls[key]
+            us = sum(a.elapsed_time(b) for a, b, _, _ in calls) * 1e3
+            return us / len(calls), sum(t for _, _, t, _ in calls) / len(calls), all(p for _, _, _, p in calls)
+        layer_us, T_f, p_f = avg("fwd")
+        bwd_layer_us, T_b, p_b = avg("bwd")
+        assert T_f == T_b
+        T = T_f
+        path_bits = (1 if p_f else 0) | (2 if p_b else 0)
     # bf16 mode runs the recurrence as ONE persistent launch per layer (rnn_fwd_persistent_kernel) when every workgroup can be resident at
     # once (grid <= CU count) — what ds2_rnn_fwd decides; otherwise (and in fp32) it is one rnn_fwd_step_kernel launch per time step.
     persistent = bool(path_bits & 1)                     # what ds2_rnn_fwd actually did (ds2_rnn_last_path)
@@ -387,6 +417,9 @@ def main():
     if bwd_layer_us > layer_us:
         roofline, roofline_bwd = roofline_bwd, roofline
     roofline["second_kernel"] = roofline_bwd
+    roofline["timing"] = (f"HIP event pairs around the {len(rnn_calls['fwd'])} + {len(rnn_calls['bwd'])} recurrence calls of the timed region"
+                          if timed_in_region else "stand-alone probe after the timed region")
+    roofline["standalone_probe_us_per_time_step"] = probe
 
     if args.breakdown and rank == 0:
         breakdown(model, tr, x, targets, pct, tsz)
