@@ -216,7 +216,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=None,
+                    help="untimed steps (default 3; c4 / c5: one per length bin, so that every batch shape has been seen - the caching "
+                         "allocator grows with a device synchronisation the first time a shape appears)")
     ap.add_argument("--workload", default="c3", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override per-GPU batch")
     ap.add_argument("--dtype", default="", choices=["", "f32", "bf16"], help="default: the config dtype (bf16 for c3 and c5, f32 otherwise)")
@@ -275,6 +277,8 @@ def main():
     batches = [(bx.to(dev), bt, bp, bs) for bx, bt, bp, bs in batches]
     x, targets, pct, tsz = max(batches, key=lambda b: b[0].size(3))          # the longest batch: the roofline probe's layer shape
     tin_probe = int(x.size(3))
+    if args.warmup is None:
+        args.warmup = max(3, len(batches) if len(batches) > 1 else 0)
     step_no = [0]
     starved_before = DeepSpeechTrainer.starved_steps
 
