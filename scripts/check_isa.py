@@ -1,6 +1,7 @@
 """Build-time checks on the generated gfx950 code of asr_amd/csrc/gemm_bf16.hip (no GPU needed: hipcc -S).
 
-1. No hot GEMM kernel spills registers (the 16-wave NT variant is allowed its 3 prologue dwords).
+1. No hot GEMM kernel spills registers (the 16-wave NT variant is allowed its 3 prologue dwords), and no instance of the persistent
+   recurrence kernels of asr_amd/csrc/rnn.hip does.
 2. TN kernel: the fragment reads (`ds_read_b64_tr_b16`, inline asm) and the `s_waitcnt lgkmcnt` that retires them are separate
    statements; between a read and the wait that covers it NO instruction may touch the destination registers - a register copy there
    would move data that has not landed (silently wrong results).  The C++ joins the two halves of an operand right behind the reads and
@@ -19,10 +20,10 @@ SRC = os.path.join(ROOT, "asr_amd", "csrc", "gemm_bf16.hip")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
-def compile_asm() -> str:
-    out = os.path.join(tempfile.mkdtemp(prefix="ds2isa"), "gemm_bf16.s")
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-x", "hip", "--cuda-device-only", "-S", SRC,
-           "-o", out]
+def compile_asm(src: str = SRC, extra=()) -> str:
+    out = os.path.join(tempfile.mkdtemp(prefix="ds2isa"), os.path.basename(src) + ".s")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), *extra, "-x", "hip", "--cuda-device-only",
+           "-S", src, "-o", out]
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return open(out).read()
 
@@ -90,6 +91,14 @@ def main() -> int:
         flag = "" if n <= allowed else "   <-- SPILLS"
         print(f"{name}: vgpr spills {n}{flag}")
         bad += n > allowed
+    # the persistent recurrence kernels (every template instance): a spill there sits inside the time loop
+    rnn = compile_asm(os.path.join(ROOT, "asr_amd", "csrc", "rnn.hip"), ("-mllvm", "-amdgpu-kernarg-preload-count=9"))
+    pers = {n: v for n, v in spill_table(rnn).items() if "persistent_kernel" in n}
+    spilled = {n: v for n, v in pers.items() if v}
+    print(f"rnn.hip: {len(pers)} persistent-kernel instances, {len(spilled)} with register spills")
+    for n, v in spilled.items():
+        print(f"  {n}: vgpr spills {v}   <-- SPILLS")
+    bad += len(spilled)
     reads, viol = check_tn_loop(asm)
     print(f"TN kernel: {reads} tr-reads walked, {viol} instruction(s) touching in-flight fragment registers")
     bad += viol

@@ -472,6 +472,36 @@ def test_rnn_fwd_bwd(dev, kind, H, B, T, lens, bf):
         ops.rnn_persistent_check()                                                # no persistent launch starved
         if G == 3:
             assert bool(torch.isfinite(aux_in).all()) and rel_l2(aux_in.cpu(), aux.cpu()) < 2e-2
+        # optional outputs of the persistent launches (the operands of the TN-form weight gradients): bf16 copies of h and d(hn), and the
+        # per-batch-row sums over time of the gate gradients; everything else must come out exactly as without them
+        nanb = lambda *shape: torch.full(shape, float("nan"), dtype=torch.bfloat16, device=dev)
+        h_bf = nanb(T * B, 2 * H)
+        hb5, aux5, rec5 = ops.rnn_fwd(G, keep_x.clone(), wpf, bhd, ld, T, B, H, bf16=True, packed_gates=True, h_bf16=h_bf)
+        took_fwd = ops.rnn_last_path() & 1
+        assert torch.equal(hb5, hb3) and torch.equal(rec5, rec)
+        if took_fwd:
+            assert torch.equal(h_bf, hb3.bfloat16())
+        dhn = nanb(T * B, 2 * H) if G == 3 else None
+        bpart = torch.full((B, 2, 4, H), float("nan"), device=dev)
+        side5 = torch.empty_like(side3)
+        aux_in5 = aux5.clone() if G == 4 else torch.full_like(aux5, float("nan"))
+        ops.rnn_bwd(G, g(dy.float().reshape(T * B, H), dev), None, aux_in5, hb5, wpb, ld, T, B, H, bf16=True, dgx_bf16=side5, gates_bf16=rec5,
+                    dhn_bf16=dhn, bias_part=bpart)
+        took_bwd = ops.rnn_last_path() & 2
+        assert torch.equal(side5, side3) and torch.equal(aux_in5, aux_in)
+        if took_bwd:
+            sums = side5.float().view(T, B, 2, G, H).sum(0)                        # (B, 2, G, H) from the bf16-ROUNDED dGx
+            assert rel_l2(bpart[:, :, :G].cpu(), sums.cpu()) < 1e-2                # the kernel sums before rounding
+            dbih, dbhh = torch.empty(2 * G * H, device=dev), torch.empty(2, G * H, device=dev)
+            ops.rnn_bias_grads(G, bpart, dbih, dbhh)
+            tot = bpart.sum(0)                                                     # (2, 4, H)
+            if G == 3:
+                assert torch.equal(dhn, aux_in5.bfloat16())
+                assert rel_l2(bpart[:, :, 3].cpu(), aux_in5.view(T, B, 2, H).sum(0).cpu()) < 1e-5
+                assert rel_l2(dbih.view(2, 3, H).cpu(), tot[:, :3].cpu()) < 1e-6
+                assert rel_l2(dbhh.view(2, 3, H).cpu(), torch.stack([tot[:, 0], tot[:, 1], tot[:, 3]], 1).cpu()) < 1e-6
+            else:
+                assert rel_l2(dbih.view(2, 4, H).cpu(), tot.cpu()) < 1e-6 and torch.equal(dbhh.view(-1), dbih)
         tT, cs = ops.transpose_bf16(side_buf, colsum=True)
         assert torch.equal(tT[:, :T * B].cpu(), side_buf.t().contiguous().cpu()) and float(tT[:, T * B:].float().abs().sum()) == 0
         assert rel_l2(cs.cpu(), side_buf.double().sum(0).cpu()) < 1e-5
