@@ -215,7 +215,10 @@ def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy: Tensor, done):
     """Backward of the recurrent stack in the bf16 training mode (packed gate records, bf16 dGx), DS2_OVERLAP=2 schedule: per layer
         compute stream:  recurrence(l) | weight-gradient GEMMs of layer l+1 | dXn(l) = dGx W_ih | BatchNorm1d backward(l)
         side stream:     [from the start of recurrence(l)] transposing casts of dGx(l+1) (+ db_ih), d(hn)(l+1) (+ db_hn), h(l+1), Xn(l+1)
-    Same kernels, same operands, same results as the one-stream schedule: only the streams and the issue order differ."""
+    Same kernels, same operands, same results as the one-stream schedule: only the streams and the issue order differ.
+    Layers whose two recurrences ran as persistent launches (the default for c2 / c3 / c5 shapes) need none of those passes: the kernels
+    wrote bf16 h / d(hn) / dGx and the bias partial sums themselves and the weight gradients are TN-form GEMMs on exactly those buffers
+    (`weight_gradients_tn`, DS2_WGRAD_TN) — one stream, nothing to overlap."""
     G, H, L = cfg.gates, cfg.hidden, cfg.layers
     B, T = ctx.B, ctx.T
     M = T * B
