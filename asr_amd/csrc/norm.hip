@@ -241,32 +241,47 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restric
   float mu = 0.f, rs = 0.f, ga = 0.f, be = 0.f;
   if (MODE == 1) { mu = mean[c]; rs = rsqrtf(var[c] + eps); ga = gamma[c]; be = beta[c]; }
   float s0 = 0.f, s1 = 0.f;
-  const bool vec = (T % 4) == 0;
-  const int tq = (T + 3) / 4;
-  for (int row = rbeg; row < rend; ++row) {
-    const int b = row / D, d = row % D;
-    const long long base = (((long long)b * C + c) * D + d) * T;
-    const int len = (MODE == 1) ? min(lens[b], T) : T;
-    for (int q = threadIdx.x; q < tq; q += 256) {
-      const int t0 = q * 4;
-      const int valid = T - t0;
-      f32x4 y = ld4(Yraw + base + t0, valid, vec);
-      if (MODE == 0) {
-        s0 += y.x + y.y + y.z + y.w;
-        s1 += y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w;
-      } else {
-        f32x4 da = ld4(dA + base + t0, valid, vec);
-        float yy[4] = {y.x, y.y, y.z, y.w}, dd[4] = {da.x, da.y, da.z, da.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float xh = (yy[j] - mu) * rs;
-          const float z = xh * ga + be;
-          const float dz = (t0 + j < len && z > 0.f && z < 20.f) ? dd[j] : 0.f;
-          s0 += dz;
-          s1 += dz * xh;
-        }
-      }
+  // one element of the stream: e = index inside the contiguous run (a multiple of T precedes it, so t = e mod T)
+  auto take = [&](float y, float da, int t, int len) {
+    if (MODE == 0) {
+      s0 += y;
+      s1 += y * y;
+    } else {
+      const float xh = (y - mu) * rs;
+      const float z = xh * ga + be;
+      const float dz = (t < len && z > 0.f && z < 20.f) ? da : 0.f;
+      s0 += dz;
+      s1 += dz * xh;
     }
+  };
+  // The rows d0 .. d0 + nd of one (b, c) plane are ONE contiguous run of nd * T floats: it is streamed linearly with aligned 16-byte
+  // loads (a scalar head up to the first aligned address, a scalar tail) instead of row by row - T = 501 made every row start
+  // misaligned, i.e. four scalar loads per thread and half the block idle (126 quads per row for 256 threads): 3.4 -> ~5 TB/s.
+  for (int row = rbeg; row < rend;) {
+    const int b = row / D, d0 = row - b * D;
+    const int nd = min(D - d0, rend - row);
+    const long long off = (((long long)b * C + c) * D + d0) * T;
+    const float* py = Yraw + off;
+    const float* pd = MODE == 1 ? dA + off : py;
+    const int n = nd * T;
+    const int len = (MODE == 1) ? min(lens[b], T) : T;
+    const bool same = ((reinterpret_cast<uintptr_t>(py) ^ reinterpret_cast<uintptr_t>(pd)) & 15) == 0;
+    const int head = same ? min(n, (int)(((16 - (reinterpret_cast<uintptr_t>(py) & 15)) & 15) >> 2)) : n;   // (unequal alignment: all scalar)
+    const int nq = (n - head) >> 2;
+    for (int e = threadIdx.x; e < head; e += 256) take(py[e], pd[e], e % T, len);
+    for (int i = threadIdx.x; i < nq; i += 256) {
+      const int e0 = head + 4 * i;
+      const f32x4 y = *reinterpret_cast<const f32x4*>(py + e0);
+      f32x4 da = y;
+      if (MODE == 1) da = *reinterpret_cast<const f32x4*>(pd + e0);
+      int t = e0 % T;
+      take(y.x, da.x, t, len); t = t + 1 == T ? 0 : t + 1;
+      take(y.y, da.y, t, len); t = t + 1 == T ? 0 : t + 1;
+      take(y.z, da.z, t, len); t = t + 1 == T ? 0 : t + 1;
+      take(y.w, da.w, t, len);
+    }
+    for (int e = head + 4 * nq + threadIdx.x; e < n; e += 256) take(py[e], pd[e], e % T, len);
+    row += nd;
   }
   s0 = wave_sum(s0);
   s1 = wave_sum(s1);
