@@ -197,6 +197,7 @@ __global__ __launch_bounds__(128) void ctc_grad_kernel(const float* __restrict__
   float* val = q + C;                   // [S]
   int* nxt = (int*)(val + Smax);        // [U]
   int* labs = nxt + (Smax / 2 + 1);     // [U]
+  int* hd = labs + (Smax / 2 + 1);      // [U] 1 = first occurrence of its label (the thread that sums the chain)
   const int* lab = targets + tgt_off[b];
   const int tid = threadIdx.x, nthr = blockDim.x;
   for (int u = tid; u < U; u += nthr) labs[u] = lab[u];
@@ -208,6 +209,10 @@ __global__ __launch_bounds__(128) void ctc_grad_kernel(const float* __restrict__
     for (int v = u + 1; v < U; ++v)
       if (labs[v] == l) { n = v; break; }
     nxt[u] = n;
+    int head = 1;                        // (was re-derived for every frame)
+    for (int v = 0; v < u; ++v)
+      if (labs[v] == l) { head = 0; break; }
+    hd[u] = head;
   }
   __syncthreads();
   const float* alpha = ab + (((long long)0 * Bn + b) * T) * Smax;
@@ -238,10 +243,7 @@ __global__ __launch_bounds__(128) void ctc_grad_kernel(const float* __restrict__
     // heads: u is a head if no earlier index has the same label
     for (int u = tid; u < U; u += nthr) {
       const int l = labs[u];
-      bool head = true;
-      for (int v = 0; v < u; ++v)
-        if (labs[v] == l) { head = false; break; }
-      if (head) {
+      if (hd[u]) {
         float sacc = 0.f;
         for (int v = u; v >= 0; v = nxt[v]) sacc += val[v];
         q[l] += sacc;  // single writer per class (l != 0 guaranteed for labels; blank handled below)
@@ -307,7 +309,7 @@ extern "C" int ds2_ctc_loss_f32(const float* logits, int ld, int T, int B, int C
                      in_lens_dev, tgt_lens_dev, (const float*)lse, ab, Smax, nll_dev);
   DS2_LAUNCH_CHECK("ctc_lattice_kernel");
   if (grad) {
-    const size_t lds2 = ((size_t)C + Smax) * sizeof(float) + 2 * ((size_t)Smax / 2 + 1) * sizeof(int);
+    const size_t lds2 = ((size_t)C + Smax) * sizeof(float) + 3 * ((size_t)Smax / 2 + 1) * sizeof(int);
     DS2_REQUIRE(lds2 <= 64 * 1024, "ds2_ctc_loss_f32: C/S too large for LDS (C=%d Smax=%d)", C, Smax);
     hipLaunchKernelGGL(ctc_grad_kernel, dim3(ceil_div(T, TCH), B), dim3(128), lds2, s, logits, ld, grad, ldg, T, B, C, targets_dev,
                        tgt_off_dev, in_lens_dev, tgt_lens_dev, (const float*)lse, (const float*)ab, Smax, (const float*)nll_dev,
