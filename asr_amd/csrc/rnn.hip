@@ -1553,8 +1553,17 @@ __global__ void rnn_bias_finalize_kernel(const float* __restrict__ part, int B, 
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;        // (dir, slot, j)
   if (idx >= 2 * 4 * H) return;
   const int j = idx % H, slot = (idx / H) & 3, dir = idx / (4 * H);
+  // eight independent loads in flight, added in row order (one dependent load per row made this 64 x 0.45 us = 29 us per call)
   float s = 0.f;
-  for (int b = 0; b < B; ++b) s += part[(long long)b * 8 * H + idx];
+  int b = 0;
+  for (; b + 8 <= B; b += 8) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = part[(long long)(b + k) * 8 * H + idx];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += v[k];
+  }
+  for (; b < B; ++b) s += part[(long long)b * 8 * H + idx];
   const long long o = (long long)dir * G * H + j;
   if (G == 4) { dbih[o + slot * H] = s; dbhh[o + slot * H] = s; }
   else if (slot < 2) { dbih[o + slot * H] = s; dbhh[o + slot * H] = s; }
