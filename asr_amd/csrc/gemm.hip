@@ -115,6 +115,10 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& g, const float* __
   const int arow = wm * 64 + (lane & 31);
   const int brow = wn * 64 + (lane & 31);
   const int khalf = lane >> 5;
+  // edge tiles only (FULL == false): a 32 x 32 MFMA tile that lies completely outside C is not computed (wave-uniform).  The fc block
+  // runs N = 29 classes through this 128-wide tile: 14 of the 16 MFMAs per k-step of a block only fed columns that are never stored.
+  const bool ua0 = FULL || m0 + wm * 64 < g.M, ua1 = FULL || m0 + wm * 64 + 32 < g.M;
+  const bool ub0 = FULL || n0 + wn * 64 < g.N, ub1 = FULL || n0 + wn * 64 + 32 < g.N;
   for (int kt = 0; kt < nkt; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nkt) {
@@ -131,10 +135,17 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& g, const float* __
       const float a1 = As[k * LDT + arow + 32];
       const float b0 = Bs[k * LDT + brow];
       const float b1 = Bs[k * LDT + brow + 32];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      if (FULL) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      } else {
+        if (ua0 && ub0) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        if (ua0 && ub1) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        if (ua1 && ub0) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        if (ua1 && ub1) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      }
     }
     if (kt + 1 < nkt) {
       TileLoader<!TA>::store(lds0 + ((cur ^ 1) * 2 + 0) * (BK * LDT), ra);

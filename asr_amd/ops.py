@@ -56,7 +56,10 @@ def gemm_raw(transA: bool, transB: bool, M: int, N: int, K: int, A_ptr: int, lda
     if splitk <= 0:
         tiles = ((M + 127) // 128) * ((N + 127) // 128) * batch
         splitk = 1
-        if tiles < 400 and K >= 2048:      # under-filled grid with a long reduction: aim at >= 2 blocks per CU
+        if M <= 32 and K >= 4096:          # skinny weight gradient (the fc block: dW = dlogits^T Xn, 29 classes, K = T*B): a block's k-loop is
+            # one HBM round trip per 16-deep tile with little else resident on its CU - more, shorter blocks hide it; the slabs are tiny
+            splitk = max(1, min((1024 + tiles - 1) // tiles, K // 256))
+        elif tiles < 400 and K >= 2048:      # under-filled grid with a long reduction: aim at >= 2 blocks per CU
             splitk = max(1, min((512 + tiles - 1) // tiles, K // 1024))
         elif tiles < 128 and K >= 1024:
             splitk = max(1, min((384 + tiles - 1) // tiles, K // 256))
