@@ -80,11 +80,46 @@ class FusedAdamW:
     def state_dict(self):
         return {"state": {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.state.items()}, "param_groups": self.param_groups}
 
+    def _from_torch_adamw(self, sd):
+        """A torch.optim.AdamW state_dict — what the reference trainer writes (trainers/deepspeech_trainer.py:176-188 with the optimizer
+        of trainers/__main__.py:41-47): {'state': {param index: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [{...}]} — converted
+        to the flat layout: parameter i of the group is the i-th of model.parameters() (same order as the reference's: the state_dict
+        key-order test pins it), its moments go to that tensor's span of the flat buffer."""
+        groups = sd.get("param_groups")
+        if not isinstance(groups, (list, tuple)) or len(groups) != 1:
+            raise ValueError("torch AdamW state_dict: expected exactly one param group")
+        g = groups[0]
+        if g.get("amsgrad") or g.get("maximize"):
+            raise ValueError("torch AdamW state_dict: amsgrad / maximize are not supported by FusedAdamW")
+        names = [n for n, _ in self.model.named_parameters()]
+        if "params" in g and len(g["params"]) != len(names):
+            raise ValueError(f"torch AdamW state_dict covers {len(g['params'])} parameters, the model has {len(names)}")
+        fp = self.model._ensure_flat(next(self.model.parameters()).device)
+        m = torch.zeros(fp.total, dtype=torch.float32)
+        v = torch.zeros(fp.total, dtype=torch.float32)
+        steps = set()
+        for i, n in enumerate(names):
+            st = sd["state"].get(i)
+            if st is None:                                   # a parameter that never had a gradient (frozen): no state, like here
+                continue
+            o, sz = fp.offsets[n]
+            if st["exp_avg"].numel() != sz:
+                raise ValueError(f"torch AdamW state_dict: parameter {i} ({n}) has {st['exp_avg'].numel()} elements, expected {sz}")
+            m[o:o + sz] = st["exp_avg"].detach().reshape(-1).float().cpu()
+            v[o:o + sz] = st["exp_avg_sq"].detach().reshape(-1).float().cpu()
+            steps.add(int(st["step"]))
+        if len(steps) > 1:
+            raise ValueError(f"torch AdamW state_dict: per-parameter step counts differ ({sorted(steps)}); one fused step count cannot represent that")
+        self.param_groups = [dict(lr=g["lr"], betas=tuple(g["betas"]), eps=g["eps"], weight_decay=g["weight_decay"])]
+        self.state = {"step": steps.pop() if steps else 0, "exp_avg": m, "exp_avg_sq": v}   # (moved to the device by _ensure_state)
+
     def load_state_dict(self, sd):
-        """Accepts what `state_dict()` wrote.  Anything else — e.g. a torch.optim.AdamW checkpoint written by the reference trainer
-        ({'state': {index: {...}}, 'param_groups': [...]}) — raises ValueError, which the trainer reports as "optimizer state not
+        """Accepts what `state_dict()` wrote, and a torch.optim.AdamW state_dict as the reference trainer checkpoints it (converted to
+        the flat layout, `_from_torch_adamw`).  Anything else raises ValueError, which the trainer reports as "optimizer state not
         restored" instead of failing at the first step."""
         st = sd.get("state") if isinstance(sd, dict) else None
+        if isinstance(st, dict) and (not st or all(isinstance(k, int) for k in st)) and "param_groups" in sd:
+            return self._from_torch_adamw(sd)
         if not isinstance(st, dict) or set(st.keys()) != {"step", "exp_avg", "exp_avg_sq"}:
             raise ValueError("not a FusedAdamW state_dict (expected state keys step / exp_avg / exp_avg_sq)")
         m, v = st["exp_avg"], st["exp_avg_sq"]

@@ -13,7 +13,11 @@ Outputs (committed, data only — expected outputs, never reference source):
     tests/golden/model_<name>.npz   whole model: logits, loss, grads (sub-sampled), BN running
                                     stats, 3 AdamW steps — reference statement sequence of
                                     DeepSpeechTrainer.fit + backward + AdamW.step
-Inputs/weights are NOT stored: they are regenerated from integer hashes (tests/golden/det.py).
+    tests/golden/ref_checkpoint_gru_16x2_c7.pth (+ _eval.npz)   a checkpoint in the reference trainer's wire format written from the
+                                    reference's own model / torch AdamW / StepLR after one optimizer step, the reference model's eval
+                                    probabilities and train-mode loss at those weights (`--only-checkpoint` regenerates it, byte-identical)
+Inputs/weights are NOT stored: they are regenerated from integer hashes (tests/golden/det.py) — the checkpoint fixture excepted, whose
+whole point is the file.
 """
 from __future__ import annotations
 
@@ -257,12 +261,53 @@ def gen_decode(out):
         json.dump(rec, f, indent=0)
 
 
+def gen_checkpoint(out, DeepSpeech, tmp):
+    """A checkpoint in the reference's own wire format (trainers/deepspeech_trainer.py:176-188: torch.save of {epoch, metrics, optimizer,
+    scheduler, state_dict}) written from the REFERENCE's model class with the optimizer / scheduler wiring of trainers/__main__.py:41-52
+    after one real optimizer step - plus the reference model's eval-mode output on a fixed batch, so that a loader can be checked end to
+    end.  (The trainer class itself derives from `sakura`, which is not installed: the five-key dict is assembled here as its save()
+    does; `metrics` is a plain dict.)"""
+    rnn, hidden, layers, classes, t_ins = "gru", 16, 2, 7, [41, 33, 25]
+    torch.manual_seed(11)
+    model = DeepSpeech(audio_conf=audio_conf(), decoder=None, label_path=label_csv(tmp, classes), rnn_type="nn.GRU", rnn_hidden_size=hidden,
+                       rnn_hidden_layers=layers, bidirectional=True)
+    opt = torch.optim.AdamW(model.parameters(), lr=1.5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5)
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=1, gamma=0.99)
+    x, targets, pct, tsz = det.batch(len(t_ins), t_ins, classes, seed=5)
+    inputs = torch.from_numpy(x)
+    sizes = torch.from_numpy(pct.copy()).mul_(int(inputs.size(3))).int()
+    model.train()
+    o, ol = model.forward(inputs, sizes)                      # (the reference overrides __call__ with its evaluation loop)
+    loss = torch.nn.CTCLoss(reduction="sum")(o.transpose(0, 1).float().log_softmax(2), torch.from_numpy(targets), ol, torch.from_numpy(tsz)) / len(t_ins)
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    sched.step()
+    ckpt = {"epoch": 3, "metrics": {"test": {"best": {"cer": 12.5, "wer": 40.0}}}, "optimizer": opt.state_dict(), "scheduler": sched,
+            "state_dict": model.state_dict()}
+    torch.save(ckpt, os.path.join(out, "ref_checkpoint_gru_16x2_c7.pth"))
+    model.eval()
+    with torch.no_grad():
+        probs, olens = model.forward(inputs, sizes)
+    model.train()                                            # (after the eval pass: this forward moves the BatchNorm running statistics)
+    o2, ol2 = model.forward(inputs, sizes)
+    loss2 = torch.nn.CTCLoss(reduction="sum")(o2.transpose(0, 1).float().log_softmax(2), torch.from_numpy(targets), ol2, torch.from_numpy(tsz)) / len(t_ins)
+    np.savez_compressed(os.path.join(out, "ref_checkpoint_gru_16x2_c7_eval.npz"), t_ins=np.asarray(t_ins), data_seed=np.asarray(5),
+                        classes=np.asarray(classes), eval_probs=probs.numpy(), output_sizes=olens.numpy(), train_loss=np.asarray(float(loss)),
+                        resume_loss=np.asarray(float(loss2)))
+    print("checkpoint fixture:", os.path.getsize(os.path.join(out, "ref_checkpoint_gru_16x2_c7.pth")), "bytes")
+
+
 def main():
     DeepSpeech, blocks, functional = import_reference()
     torch.set_num_threads(4)
     out = HERE
     if "--only-decode" in sys.argv:
         gen_decode(out)
+        return
+    if "--only-checkpoint" in sys.argv:
+        with tempfile.TemporaryDirectory() as tmp:
+            gen_checkpoint(out, DeepSpeech, tmp)
         return
     if "--only-model" in sys.argv:                     # regenerate one model fixture without touching the others
         with tempfile.TemporaryDirectory() as tmp:
@@ -275,6 +320,7 @@ def main():
         gen_manifest(out, DeepSpeech, tmp)
         for name in MODELS:
             gen_model(out, name, DeepSpeech, tmp)
+        gen_checkpoint(out, DeepSpeech, tmp)
     for f in sorted(os.listdir(out)):
         if f.endswith((".npz", ".json")):
             print(f, os.path.getsize(os.path.join(out, f)))

@@ -380,15 +380,52 @@ def test_fused_adamw_state_handling():
     opt2 = FusedAdamW(m)
     opt2.load_state_dict(sd)
     assert opt2.state["step"] == 5 and torch.equal(opt2.state["exp_avg"], opt.state["exp_avg"])
-    ref_sd = torch.optim.AdamW(m.parameters(), lr=1e-3).state_dict()                # what the reference trainer checkpoints
+    ref_sd = torch.optim.AdamW(m.parameters(), lr=1e-3).state_dict()                # what the reference trainer checkpoints: converted
+    opt2.load_state_dict(ref_sd)
+    assert opt2.state["step"] == 0 and opt2.param_groups[0]["lr"] == 1e-3 and float(opt2.state["exp_avg"].abs().sum()) == 0.0
+    ams = torch.optim.AdamW(m.parameters(), lr=1e-3, amsgrad=True).state_dict()
     with pytest.raises(ValueError):
-        opt2.load_state_dict(ref_sd)
+        opt2.load_state_dict(ams)
     with pytest.raises(ValueError):
         opt2.load_state_dict({"state": {"step": 1, "exp_avg": torch.zeros(3), "exp_avg_sq": None}, "param_groups": opt.param_groups})
     for p in m.parameters():
         p.grad = torch.zeros_like(p)
     opt.zero_grad()
     assert all(p.grad is None for p in m.parameters())
+
+
+def test_reference_written_checkpoint_resumes(tmp_path):
+    """SURVEY §8(f) rank 3 against a file the REFERENCE's classes wrote (tests/golden/make_golden.py::gen_checkpoint: the reference's
+    DeepSpeech + torch AdamW + StepLR after one real optimizer step, saved in the five-key layout of its trainer's save()): the trainer
+    restores the model bit for bit, and BOTH optimizer kinds resume from it - torch AdamW natively, FusedAdamW by conversion of the
+    per-parameter moments into its flat layout (same step count, same hyper-parameters)."""
+    from asr_amd import FusedAdamW
+    from asr_amd.trainers import DeepSpeechTrainer
+    path = f"{GOLDEN}/ref_checkpoint_gru_16x2_c7.pth"
+    raw = torch.load(path, map_location="cpu", weights_only=False)
+    assert set(raw) == {"epoch", "metrics", "optimizer", "scheduler", "state_dict"}
+    for kind in ("torch", "fused"):
+        torch.manual_seed(9)
+        m = make("gru", 16, 2, 7)
+        assert list(m.state_dict().keys()) == list(raw["state_dict"].keys())
+        opt = torch.optim.AdamW(m.parameters(), lr=1.0) if kind == "torch" else FusedAdamW(m, lr=1.0)
+        tr = DeepSpeechTrainer(m, None, 5, None, opt, path, None, "cpu", "cpu", False, None)
+        assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), raw["state_dict"].values()))
+        assert tr._epochs.start == 3 and tr._metrics["test"]["best"]["cer"] == 12.5
+        assert isinstance(tr._scheduler, torch.optim.lr_scheduler.StepLR) and tr._scheduler.optimizer is opt
+        g = opt.param_groups[0]
+        assert g["betas"] == (0.9, 0.999) and g["eps"] == 1e-8 and g["weight_decay"] == 1e-5
+        assert abs(g["lr"] - 1.5e-4 * 0.99) < 1e-12                                # one StepLR step had been taken
+        names = [n for n, _ in m.named_parameters()]
+        if kind == "torch":
+            st = opt.state_dict()["state"]
+            assert int(st[0]["step"]) == 1 and torch.equal(st[3]["exp_avg"], raw["optimizer"]["state"][3]["exp_avg"])
+        else:
+            assert opt.state["step"] == 1
+            for i, n in enumerate(names):
+                o, sz = m._flat.offsets[n]
+                assert torch.equal(opt.state["exp_avg"][o:o + sz], raw["optimizer"]["state"][i]["exp_avg"].reshape(-1)), n
+                assert torch.equal(opt.state["exp_avg_sq"][o:o + sz], raw["optimizer"]["state"][i]["exp_avg_sq"].reshape(-1)), n
 
 
 def test_gemm_isa_no_spills_and_no_copy_of_inflight_fragments():

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import MODEL_FIXTURES, load_model_fixture, model_inputs, noise_only_grads, rel_l2, subsample
+from helpers import GOLDEN, MODEL_FIXTURES, load_model_fixture, model_inputs, noise_only_grads, rel_l2, subsample
 import det
 from oracle import ds2_oracle as O
 
@@ -82,6 +82,35 @@ def test_fit_matches_reference_golden(name):
     with torch.no_grad():
         probs, _ = model.forward(x.cuda(), O.lengths_from_percentages(pct, x.size(3)))
     assert rel_l2(probs.cpu().numpy(), z["eval_probs"]) < TOL
+
+
+def test_reference_written_checkpoint_resumes_on_the_gpu(tmp_path):
+    """A checkpoint written by the reference's classes (tests/golden/ref_checkpoint_gru_16x2_c7.pth, make_golden.py::gen_checkpoint)
+    restored by the trainer: the eval-mode probabilities equal the ones the reference model produced from the same weights, and the
+    fused step resumes from the converted optimizer state (step count 2 after one step; its loss = the reference model's train-mode
+    loss at the restored weights)."""
+    import shutil
+    from asr_amd import CTCLoss, FusedAdamW
+    from asr_amd.trainers import DeepSpeechTrainer
+    z = np.load(f"{GOLDEN}/ref_checkpoint_gru_16x2_c7_eval.npz")
+    t_ins, classes = [int(v) for v in z["t_ins"]], int(z["classes"])
+    x, targets, pct, tsz = map(torch.from_numpy, det.batch(len(t_ins), t_ins, classes, seed=int(z["data_seed"])))
+    model = make_model(dict(rnn="gru", hidden=16, layers=2, classes=classes), device="cpu")
+    path = str(tmp_path / "model.pth")
+    shutil.copy(f"{GOLDEN}/ref_checkpoint_gru_16x2_c7.pth", path)
+    opt = FusedAdamW(model)
+    tr = DeepSpeechTrainer(model, CTCLoss(reduction="sum"), 1, None, opt, path, None, "cuda", "cuda", False, None)
+    assert opt.state["step"] == 1 and tr._epochs.start == 3
+    model.to("cuda")
+    model.eval()
+    with torch.no_grad():
+        probs, out_lens = model.forward(x.cuda(), O.lengths_from_percentages(pct, x.size(3)))
+    assert rel_l2(probs.cpu().numpy(), z["eval_probs"]) < TOL and out_lens.tolist() == z["output_sizes"].tolist()
+    model.train()
+    valid, lv = tr.step((x, targets, pct.clone(), tsz))
+    tr.synchronize()
+    assert valid and opt.state["step"] == 2 and opt.state["exp_avg"].is_cuda
+    assert abs(lv - float(z["resume_loss"])) <= TOL * float(z["resume_loss"])       # the reference model's own train-mode loss at these weights
 
 
 @pytest.mark.parametrize("name", MODEL_FIXTURES)
