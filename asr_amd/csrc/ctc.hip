@@ -95,6 +95,9 @@ __global__ __launch_bounds__(1024) void ctc_lattice_kernel(const float* __restri
   float* prev = row0;
   float* cur = row1;
   if (S <= nthr) {
+    // Hot loop, written for instruction count (one dependent lattice row per frame: every instruction here is on the critical path).
+    // Per-thread pointers advance by constant strides; emissions are loaded unconditionally 4 frames ahead from CLAMPED frame indices
+    // (no exec-mask branches, no per-frame index arithmetic); only the stores are predicated.
     const int s = threadIdx.x;
     const bool act = s < S;
     int cls = 0;
@@ -104,46 +107,37 @@ __global__ __launch_bounds__(1024) void ctc_lattice_kernel(const float* __restri
       if (dirn == 0) skip = (s >= 2) && (s & 1) && (lab[s >> 1] != lab[(s >> 1) - 1]);
       else skip = (s + 2 < S) && (s & 1) && (lab[s >> 1] != lab[(s >> 1) + 1]);
     }
-    float nx[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int i = 1 + j;
-      const int t = tfirst + step * i;
-      nx[j] = (act && i < Tb) ? logits[((long long)t * Bn + b) * ld + cls] - lse[t * Bn + b] : 0.f;
-    }
-    for (int i0 = 1; i0 < Tb; i0 += 4) {
-      float cv[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) cv[j] = nx[j];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int i = i0 + 4 + j;
-        const int t = tfirst + step * i;
-        nx[j] = (act && i < Tb) ? logits[((long long)t * Bn + b) * ld + cls] - lse[t * Bn + b] : 0.f;
+    const long long lg_stride = (long long)step * Bn * ld;
+    const int ls_stride = step * Bn, out_stride = step * Smax;
+    const float* lgp = logits + ((long long)tfirst * Bn + b) * ld + cls;        // frame tfirst, this state's class
+    const float* lsp = lse + (long long)tfirst * Bn + b;
+    float* op = out + (long long)tfirst * Smax + (act ? s : 0);
+    const int s1 = dirn == 0 ? (s >= 1 ? s - 1 : 0) : (s + 1 < S ? s + 1 : 0);    // neighbour indices, clamped into the row
+    const int s2 = dirn == 0 ? (s >= 2 ? s - 2 : 0) : (s + 2 < S ? s + 2 : 0);
+    const bool has1 = dirn == 0 ? (s >= 1) : (s + 1 < S);
+    const int last = Tb - 1;
+    auto emission = [&](int i) {                                                  // frame index clamped: always a valid address
+      const int ii = i < last ? i : last;
+      return lgp[(long long)ii * lg_stride] - lsp[(long long)ii * ls_stride];
+    };
+    float nx0 = emission(1), nx1 = emission(2), nx2 = emission(3), nx3 = emission(4);
+    const int sa = act ? s : 0;
+    for (int i = 1; i < Tb; ++i) {
+      const float lp = nx0;
+      nx0 = nx1; nx1 = nx2; nx2 = nx3;
+      nx3 = emission(i + 4);
+      op += out_stride;
+      const float a0 = prev[sa];
+      const float a1 = has1 ? prev[s1] : NEG_INF;
+      const float a2 = skip ? prev[s2] : NEG_INF;
+      const float m = lse3(a0, a1, a2);
+      const float v = (m == NEG_INF) ? NEG_INF : m + lp;
+      if (act) {
+        cur[s] = v;
+        *op = v;
       }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int i = i0 + j;
-        if (i < Tb) {
-          const int t = tfirst + step * i;
-          if (act) {
-            float a0 = prev[s], a1, a2;
-            if (dirn == 0) {
-              a1 = (s >= 1) ? prev[s - 1] : NEG_INF;
-              a2 = skip ? prev[s - 2] : NEG_INF;
-            } else {
-              a1 = (s + 1 < S) ? prev[s + 1] : NEG_INF;
-              a2 = skip ? prev[s + 2] : NEG_INF;
-            }
-            const float m = lse3(a0, a1, a2);
-            const float v = (m == NEG_INF) ? NEG_INF : m + cv[j];
-            cur[s] = v;
-            out[(long long)t * Smax + s] = v;
-          }
-          __syncthreads();
-          float* tmp = prev; prev = cur; cur = tmp;
-        }
-      }
+      __syncthreads();
+      float* tmp = prev; prev = cur; cur = tmp;
     }
   } else {
     for (int i = 1; i < Tb; ++i) {
