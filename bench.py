@@ -324,47 +324,17 @@ def main():
     ms = dt / args.steps * 1e3
     utts = world * B * args.steps / dt
 
-    # ---- roofline of the dominant kernel: the recurrent step kernel (fwd), timed live with HIP events on
-    # torch's current stream, which is the stream libds2hip launches on.
+    # ---- roofline of the dominant kernels (the two recurrences): timed live with HIP events on torch's current stream, which is the
+    # stream libds2hip launches on - inside the timed region (event pairs recorded above); a stand-alone probe only as a fallback.
     G = 3 if rnn == "gru" else 4
     T = (tin_probe + 1) // 2
     M = T * B
-    gx = torch.randn(M, 2 * G * H, device=dev) * 0.5
-    whh = (torch.rand(2, G * H, H, device=dev) * 2 - 1) / H ** 0.5
-    bhh = torch.zeros(2, G * H, device=dev)
-    lens = torch.full((B,), T, dtype=torch.int32, device=dev)
     bf = dtype == "bf16"
-    wpf, wpb_probe = ops.rnn_pack(G, whh, bf16=bf)
     pack = bf and B % 8 == 0                              # the train step's own mode (engine.forward)
-    ops.rnn_fwd(G, gx.clone(), wpf, bhh, lens, T, B, H, bf16=bf, packed_gates=pack)
-    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-    gx2 = gx.clone()
-    dyp = torch.randn(M, H, device=dev)
-    side = torch.empty(M, 2 * G * H, dtype=torch.bfloat16, device=dev) if pack else None
     # the train step's own mode (engine.py): the persistent kernels also write the bf16 copies of h / d(hn) and the bias-gradient partial
     # sums that the TN-form weight-gradient GEMMs consume
     from asr_amd import engine as _engine
     tn = pack and _engine.WGRAD_TN and _engine.OVERLAP_MODE == "2" and T > 1
-    h_bf = torch.empty(M, 2 * H, dtype=torch.bfloat16, device=dev) if tn else None
-    dhn_bf = torch.empty(M, 2 * H, dtype=torch.bfloat16, device=dev) if (tn and G == 3) else None
-    bias_part = torch.empty(B, 2, 4, H, device=dev) if tn else None
-    torch.cuda.synchronize()
-    e0.record()
-    fwd_out = ops.rnn_fwd(G, gx2, wpf, bhh, lens, T, B, H, bf16=bf, packed_gates=pack, **({"h_bf16": h_bf} if pack else {}))
-    e1.record()
-    # the same layer's backward recurrence on the state just saved, in the train step's own mode
-    if pack:
-        ops.rnn_bwd(G, dyp, None, fwd_out[1], fwd_out[0], wpb_probe, lens, T, B, H, bf16=True, dgx_bf16=side, gates_bf16=fwd_out[2],
-                    dhn_bf16=dhn_bf, bias_part=bias_part)
-    else:
-        ops.rnn_bwd(G, dyp, gx2, fwd_out[1], fwd_out[0], wpb_probe, lens, T, B, H, bf16=bf)
-    e2.record()
-    torch.cuda.synchronize()
-    bwd_layer_us = e1.elapsed_time(e2) * 1e3
-    from asr_amd import _lib as _ds2lib
-    path_bits = _ds2lib.load().ds2_rnn_last_path()
-    layer_us = e0.elapsed_time(e1) * 1e3                 # one layer's whole forward recurrence (T time steps, both directions)
-    probe = {"fwd_us_per_time_step": layer_us / T, "bwd_us_per_time_step": bwd_layer_us / T}     # (stand-alone probe, kept for reference)
     timed_in_region = bool(rnn_calls["fwd"]) and bool(rnn_calls["bwd"])
     if timed_in_region:
         # averages over the calls of the timed region (per layer call); T = the mean number of time steps per call (c4 / c5 vary)
@@ -377,6 +347,35 @@ def main():
         assert T_f == T_b
         T = T_f
         path_bits = (1 if p_f else 0) | (2 if p_b else 0)
+    else:
+        # fallback (no recurrence call was seen in the timed region): one layer's recurrences stand-alone, same shape and mode
+        gx = torch.randn(M, 2 * G * H, device=dev) * 0.5
+        whh = (torch.rand(2, G * H, H, device=dev) * 2 - 1) / H ** 0.5
+        bhh = torch.zeros(2, G * H, device=dev)
+        lens = torch.full((B,), T, dtype=torch.int32, device=dev)
+        wpf, wpb_probe = ops.rnn_pack(G, whh, bf16=bf)
+        ops.rnn_fwd(G, gx.clone(), wpf, bhh, lens, T, B, H, bf16=bf, packed_gates=pack)
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        gx2 = gx.clone()
+        dyp = torch.randn(M, H, device=dev)
+        side = torch.empty(M, 2 * G * H, dtype=torch.bfloat16, device=dev) if pack else None
+        h_bf = torch.empty(M, 2 * H, dtype=torch.bfloat16, device=dev) if tn else None
+        dhn_bf = torch.empty(M, 2 * H, dtype=torch.bfloat16, device=dev) if (tn and G == 3) else None
+        bias_part = torch.empty(B, 2, 4, H, device=dev) if tn else None
+        torch.cuda.synchronize()
+        e0.record()
+        fwd_out = ops.rnn_fwd(G, gx2, wpf, bhh, lens, T, B, H, bf16=bf, packed_gates=pack, **({"h_bf16": h_bf} if pack else {}))
+        e1.record()
+        if pack:
+            ops.rnn_bwd(G, dyp, None, fwd_out[1], fwd_out[0], wpb_probe, lens, T, B, H, bf16=True, dgx_bf16=side, gates_bf16=fwd_out[2],
+                        dhn_bf16=dhn_bf, bias_part=bias_part)
+        else:
+            ops.rnn_bwd(G, dyp, gx2, fwd_out[1], fwd_out[0], wpb_probe, lens, T, B, H, bf16=bf)
+        e2.record()
+        torch.cuda.synchronize()
+        bwd_layer_us = e1.elapsed_time(e2) * 1e3
+        layer_us = e0.elapsed_time(e1) * 1e3             # one layer's whole forward recurrence (T time steps, both directions)
+        path_bits = ops.rnn_last_path()
     # bf16 mode runs the recurrence as ONE persistent launch per layer (rnn_fwd_persistent_kernel) when every workgroup can be resident at
     # once (grid <= CU count) — what ds2_rnn_fwd decides; otherwise (and in fp32) it is one rnn_fwd_step_kernel launch per time step.
     persistent = bool(path_bits & 1)                     # what ds2_rnn_fwd actually did (ds2_rnn_last_path)
@@ -423,7 +422,6 @@ def main():
     roofline["second_kernel"] = roofline_bwd
     roofline["timing"] = (f"HIP event pairs around the {len(rnn_calls['fwd'])} + {len(rnn_calls['bwd'])} recurrence calls of the timed region"
                           if timed_in_region else "stand-alone probe after the timed region")
-    roofline["standalone_probe_us_per_time_step"] = probe
 
     if args.breakdown and rank == 0:
         breakdown(model, tr, x, targets, pct, tsz)
