@@ -393,14 +393,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
+// Threads follow the PARTIAL layout ([group][tap][co][ci], ci fastest): every wave-load is one contiguous 256-byte piece of a slab and
+// the scattered side is the 0.9 MB result.  (Indexed by the dW layout - kt fastest - each lane of a load hit its own cache line:
+// 73 slabs x 236 k lines, 100 us.)  Chunks are added in index order, eight loads in flight.
 __global__ void conv2_wgrad_bf16_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW, int chunks, int ngroups) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;       // (co, ci, kd, kt)
-  if (idx >= 32 * 32 * 21 * 11) return;
-  const int kt = idx % 11, kd = (idx / 11) % 21, ci = (idx / 231) % 32, co = idx / (231 * 32);
-  const int grp = kd / KDG, tap = (kd % KDG) * KT + kt;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;         // ((grp * TAPS + tap) * 32 + co) * 32 + ci
+  const int per_chunk = ngroups * TAPS * 32 * 32;
+  if (j >= per_chunk) return;
+  const int ci = j & 31, co = (j >> 5) & 31, tap = (j >> 10) % TAPS, grp = (j >> 10) / TAPS;
+  const int kd = grp * KDG + tap / KT, kt = tap % KT;
   float s = 0.f;
-  for (int c = 0; c < chunks; ++c) s += part[((((long long)c * ngroups + grp) * TAPS + tap) * 32 + co) * 32 + ci];
-  dW[idx] = s;
+  int c = 0;
+  for (; c + 8 <= chunks; c += 8) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = part[(long long)(c + k) * per_chunk + j];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += v[k];
+  }
+  for (; c < chunks; ++c) s += part[(long long)c * per_chunk + j];
+  if (kd < 21) dW[((co * 32 + ci) * 21 + kd) * 11 + kt] = s;
 }
 
 // dst[r][x] = bf16(src[r][x - 8]) for 8 <= x < T + 8, else 0 ; dst pitch Tp (multiple of 8, >= T + 16)
@@ -458,7 +470,7 @@ extern "C" int ds2_conv2_wgrad_bf16(const void* a1p, const void* dy2p, const int
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(conv2_wgrad_bf16_kernel, dim3(7, chunks), dim3(256), 0, s, a);
   DS2_LAUNCH_CHECK("conv2_wgrad_bf16_kernel");
-  hipLaunchKernelGGL(conv2_wgrad_bf16_reduce_kernel, dim3(ceil_div(32 * 32 * 21 * 11, 256)), dim3(256), 0, s, (const float*)ws, dW2, chunks, 7);
+  hipLaunchKernelGGL(conv2_wgrad_bf16_reduce_kernel, dim3(ceil_div(7 * TAPS * 32 * 32, 256)), dim3(256), 0, s, (const float*)ws, dW2, chunks, 7);
   DS2_LAUNCH_CHECK("conv2_wgrad_bf16_reduce_kernel");
   return 0;
 }
