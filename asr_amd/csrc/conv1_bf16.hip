@@ -329,8 +329,15 @@ __global__ __launch_bounds__(256) void conv1_wgrad_reduce_kernel(const float* __
   const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int idx = blockIdx.x * 32 + col;
   float s = 0.f;
-  if (idx < CO * KD * KTAPS)
-    for (int k = grp; k < nblk; k += 8) s += part[(long long)k * (CO * KD * KTAPS) + idx];
+  if (idx < CO * KD * KTAPS) {
+    int k = grp;
+    for (; k + 24 < nblk; k += 32) {                        // four loads in flight, added in order
+      const float v0 = part[(long long)k * (CO * KD * KTAPS) + idx], v1 = part[(long long)(k + 8) * (CO * KD * KTAPS) + idx];
+      const float v2 = part[(long long)(k + 16) * (CO * KD * KTAPS) + idx], v3 = part[(long long)(k + 24) * (CO * KD * KTAPS) + idx];
+      s += v0; s += v1; s += v2; s += v3;
+    }
+    for (; k < nblk; k += 8) s += part[(long long)k * (CO * KD * KTAPS) + idx];
+  }
   red[grp][col] = s;
   __syncthreads();
   if (grp == 0 && idx < CO * KD * KTAPS) {
