@@ -473,7 +473,12 @@ __global__ __launch_bounds__(256) void chan_part_finalize_kernel(const float* __
   double s = 0.0;
   if (stage == 0) {
     const long long k0 = (long long)blockIdx.x * rpb, k1 = k0 + rpb < n ? k0 + rpb : n;
-    for (long long k = k0 + r; k < k1; k += 8) s += (double)part[k * 32 + c];
+    long long k = k0 + r;
+    for (; k + 24 < k1; k += 32) {                          // four loads in flight, added in order
+      const float v0 = part[k * 32 + c], v1 = part[(k + 8) * 32 + c], v2 = part[(k + 16) * 32 + c], v3 = part[(k + 24) * 32 + c];
+      s += (double)v0; s += (double)v1; s += (double)v2; s += (double)v3;
+    }
+    for (; k < k1; k += 8) s += (double)part[k * 32 + c];
   } else {
     for (int k = r; k < nblk; k += 8) s += tmp[(long long)k * 32 + c];
   }
