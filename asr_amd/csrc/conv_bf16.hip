@@ -9,11 +9,12 @@
 // LDS-transposed pass.  Weights are pre-packed per kernel row as [kd][kt][kk][kgroup][m][8] bf16, i.e. already in
 // A-fragment order: staging is a straight copy and fragment reads are conflict-free linear 512-byte runs.
 //
-//   block = (b, output row o, 128 time steps); per kernel row kd: stage one input row (138 pixels x 64 B, 80-B pitch)
-//   and that row's 11x2 weight fragments in LDS, then 22 MFMAs per wave (32 co x 32 t tile).  Loads of row kd+1 are
-//   parked in registers while row kd is multiplied.
+//   block = (b, R output rows, 128 time steps); per kernel row kd: stage one input row (138 pixels x 64 B, 80-B pitch)
+//   and that row's 11x2 weight fragments in LDS, then 22 R MFMAs per wave (R tiles of 32 co x 32 t).  Loads of row kd+1 are
+//   parked in registers while row kd is multiplied.  (conv2_bf16_rows_kernel; the one-row conv2_bf16_kernel is the A/B reference.)
 // dgrad = the same kernel on dY (channels-last) with per-parity re-packed weights (as in conv.hip).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -132,6 +133,133 @@ __global__ __launch_bounds__(256) void conv2_bf16_kernel(CArgs a) {
   }
 }
 
+// R output rows (o0 .. o0 + R - 1) per block: they read the same kernel-row weights and input rows SD apart, so the input rows live in a
+// ring of (R - 1) SD + 1 LDS slots and every staged (input row, weight row) pair feeds 22 R MFMAs per wave instead of 22 - 1/R of the
+// weight staging (22.5 KB per kernel row was 2/3 of what a block moved into LDS), of the L2 reads and of the barriers per MFMA.  Same
+// accumulation order per output as the one-row kernel: bit-identical.
+template <int SD, int R>
+__global__ __launch_bounds__(256) void conv2_bf16_rows_kernel(CArgs a, int n_out) {
+  constexpr int RING = (R - 1) * SD + 1;                   // rows f0 + kd .. f0 + kd + (R - 1) SD are live at kernel row kd
+  constexpr int SLOT = NPIX * IPITCH;
+  __shared__ __attribute__((aligned(16))) char in_lds[RING * SLOT];
+  __shared__ __attribute__((aligned(16))) char w_lds[WROW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int t0 = blockIdx.x * TT, o0 = R * blockIdx.y, b = blockIdx.z;
+  const int len = a.lens ? min(a.lens[b], a.T) : a.T;
+  const int t = t0 + wave * 32 + l31;
+  auto out_ptr = [&](int o, int co) { return a.out + (((long long)b * CH + co) * a.Dtot + (a.OS * o + a.OO)) * a.T + t; };
+  if (t0 >= len) {   // whole tile masked (MaskConv): zeros
+    if (t < a.T) {
+#pragma unroll
+      for (int q = 0; q < R; ++q)
+        if (o0 + q < n_out) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) *out_ptr(o0 + q, (r & 3) + 8 * (r >> 2) + 4 * half) = 0.f;
+        }
+    }
+    return;
+  }
+  f32x16 acc[R];
+#pragma unroll
+  for (int q = 0; q < R; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+  const int f0 = SD * o0 - a.PD;                          // input row of (o0, kd = 0); (o0 + q, kd) reads row f0 + kd + q SD
+  f32x4 ri[IN_IT], rw[W_IT];
+  auto load_in = [&](int f) {
+    const bool rowok = f >= 0 && f < a.Din;
+    const char* rowp = reinterpret_cast<const char*>(a.in + (((long long)b * a.Din + (rowok ? f : 0)) * a.T) * CH);
+#pragma unroll
+    for (int u = 0; u < IN_IT; ++u) {
+      const int c = tid + 256 * u;
+      const int pix = c >> 2, q = c & 3;
+      const int tt = t0 - PT + pix;
+      const bool ok = rowok && c < IN_CHUNKS && tt >= 0 && tt < a.T;
+      const void* p = ok ? (const void*)(rowp + ((long long)tt * CH) * 2 + q * 16) : (const void*)g_zero_cb;
+      ri[u] = *reinterpret_cast<const f32x4*>(p);
+    }
+  };
+  auto store_in = [&](int slot) {
+#pragma unroll
+    for (int u = 0; u < IN_IT; ++u) {
+      const int c = tid + 256 * u;
+      if (c < IN_CHUNKS) *reinterpret_cast<f32x4*>(in_lds + slot * SLOT + (c >> 2) * IPITCH + (c & 3) * 16) = ri[u];
+    }
+  };
+  auto load_w = [&](int kd) {
+    const char* wp = reinterpret_cast<const char*>(a.wpk) + (long long)kd * WROW;
+#pragma unroll
+    for (int u = 0; u < W_IT; ++u) {
+      const int c = tid + 256 * u;
+      rw[u] = *reinterpret_cast<const f32x4*>(wp + (c < W_CHUNKS ? c : 0) * 16);
+    }
+  };
+  auto store_w = [&]() {
+#pragma unroll
+    for (int u = 0; u < W_IT; ++u) {
+      const int c = tid + 256 * u;
+      if (c < W_CHUNKS) *reinterpret_cast<f32x4*>(w_lds + c * 16) = rw[u];
+    }
+  };
+#pragma unroll
+  for (int j = 0; j < RING - 1; ++j) {                     // the rows that are older than the one kernel row 0 brings in
+    load_in(f0 + j);
+    store_in(j);
+  }
+  load_in(f0 + RING - 1);
+  load_w(0);
+  const int pix_off = (wave * 32 + l31) * IPITCH + half * 16;
+  const char* abase = w_lds + half * (32 * 16) + l31 * 16;
+  int slot0 = 0;                                           // ring slot of row f0 + kd
+  for (int kd = 0; kd < a.KD; ++kd) {
+    __syncthreads();
+    {
+      int snew = slot0 + RING - 1;
+      if (snew >= RING) snew -= RING;
+      store_in(snew);
+    }
+    store_w();
+    __syncthreads();
+    if (kd + 1 < a.KD) {
+      load_in(f0 + kd + RING);
+      load_w(kd + 1);
+    }
+    const char* bq[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      int sl = slot0 + q * SD;
+      if (sl >= RING) sl -= RING;
+      bq[q] = in_lds + sl * SLOT + pix_off;
+    }
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(abase + (kt * 2 + kk) * (2 * 32 * 16));
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+          const bf16x8 x = *reinterpret_cast<const bf16x8*>(bq[q] + kt * IPITCH + kk * 32);
+          acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, x, acc[q], 0, 0, 0);
+        }
+      }
+    }
+    slot0 = slot0 + 1 == RING ? 0 : slot0 + 1;
+  }
+  float bv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bv[r] = a.bias ? a.bias[(r & 3) + 8 * (r >> 2) + 4 * half] : 0.f;
+  if (t < a.T) {
+#pragma unroll
+    for (int q = 0; q < R; ++q)
+      if (o0 + q < n_out) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) *out_ptr(o0 + q, (r & 3) + 8 * (r >> 2) + 4 * half) = t >= len ? 0.f : acc[q][r] + bv[r];
+      }
+  }
+}
+
 // (B, 32, D, T) fp32 -> (B, D, T, 32) bf16, 32 channels x 64 time steps per block through LDS
 __global__ __launch_bounds__(256) void nhwc_cast_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int Bn, int D, int T) {
   __shared__ float tile[CH][65];
@@ -205,7 +333,11 @@ extern "C" int ds2_conv2_fwd_bf16(const void* a1_nhwc, const void* wf, const flo
   CArgs a{};
   a.in = (const __bf16*)a1_nhwc; a.wpk = (const __bf16*)wf; a.bias = bias; a.out = y2; a.lens = lens_dev;
   a.B = B; a.Din = D1; a.T = T; a.Dtot = D2; a.KD = 21; a.SD = 2; a.PD = 10; a.OS = 1; a.OO = 0;
-  hipLaunchKernelGGL(conv2_bf16_kernel, dim3(ceil_div(T, TT), D2, B), dim3(256), 0, (hipStream_t)stream, a);
+  // three output rows per block (5 input-row slots + the weight row = 77 KB of LDS, two blocks per CU): 655 -> 561 us at c3; two rows
+  // 614, four rows (one block per CU) 767.  DS2_CONV2_ROWS=1: the one-row kernel (A/B switch)
+  static const char* rows_env = getenv("DS2_CONV2_ROWS");
+  if (rows_env && rows_env[0] == '1') hipLaunchKernelGGL(conv2_bf16_kernel, dim3(ceil_div(T, TT), D2, B), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((conv2_bf16_rows_kernel<2, 3>), dim3(ceil_div(T, TT), ceil_div(D2, 3), B), dim3(256), 0, (hipStream_t)stream, a, D2);
   DS2_LAUNCH_CHECK("conv2_bf16_kernel fwd");
   return 0;
 }
@@ -220,7 +352,10 @@ extern "C" int ds2_conv2_dgrad_bf16(const void* dy2_nhwc, const void* wd0, const
     CArgs a{};
     a.in = (const __bf16*)dy2_nhwc; a.wpk = (const __bf16*)(p == 0 ? wd0 : wd1); a.bias = nullptr; a.out = da1; a.lens = nullptr;
     a.B = B; a.Din = D2; a.T = T; a.Dtot = D1; a.KD = KDe; a.SD = 1; a.PD = KDe - 6; a.OS = 2; a.OO = p;
-    hipLaunchKernelGGL(conv2_bf16_kernel, dim3(ceil_div(T, TT), n_o, B), dim3(256), 0, (hipStream_t)stream, a);
+    // four output rows per block here (rows one apart: 4 input-row slots): 2 x 347 -> 2 x 290 us
+    static const char* rows_env = getenv("DS2_CONV2_ROWS");
+    if (rows_env && rows_env[0] == '1') hipLaunchKernelGGL(conv2_bf16_kernel, dim3(ceil_div(T, TT), n_o, B), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((conv2_bf16_rows_kernel<1, 4>), dim3(ceil_div(T, TT), ceil_div(n_o, 4), B), dim3(256), 0, (hipStream_t)stream, a, n_o);
   }
   DS2_LAUNCH_CHECK("conv2_bf16_kernel dgrad");
   return 0;
