@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("DS2_LIB_PATH") or os.path.join(_HERE, "lib", "libds2h
 
 _lib: Optional[C.CDLL] = None
 
-vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
+vp, i32, i64, f32, f64, sz = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_double, C.c_size_t
 
 # name -> (restype, argtypes)   — mirrors include/ds2hip.h one to one
 SIGNATURES = {
@@ -31,6 +31,12 @@ SIGNATURES = {
     "ds2_gemm_f32_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "ds2_gemm_f32": (i32, [i32, i32, i32, i32, i32, vp, i32, i64, vp, i32, i64, vp, i32, i64, vp, i32, i32, i32, vp, sz, vp]),
     "ds2_gemm_bf16_workspace_bytes": (sz, [i32, i32, i32, i32]),
+    "ds2_conv1_fwd_bf16_stat_blocks": (i32, [i32, i32, i32]),
+    "ds2_conv1_fwd_bf16_stats": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
+    "ds2_conv2_fwd_bf16_stat_blocks": (i32, [i32, i32, i32]),
+    "ds2_conv2_fwd_bf16_stats": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
+    "ds2_chanstats_from_partials_workspace_bytes": (sz, []),
+    "ds2_chanstats_from_partials": (i32, [vp, i32, i32, f64, vp, vp, vp, vp, f32, vp, sz, vp]),
     "ds2_gemm_bf16_tn": (i32, [i32, i32, i32, vp, i32, i64, vp, i32, i64, vp, i32, i64, i32, i32, i32, vp, sz, vp]),
     "ds2_gemm_bf16_nt": (i32, [i32, i32, i32, vp, i32, i64, vp, i32, i64, vp, i32, i64, vp, i32, i32, i32, vp, sz, vp]),
     "ds2_cast_bf16": (i32, [vp, i32, vp, i32, i32, i32, vp]),

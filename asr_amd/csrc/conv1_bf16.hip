@@ -104,7 +104,7 @@ typedef const __attribute__((address_space(1))) void c1_gbl_void;
 // block = (half of the time axis, 8 output rows, b), persistent over its time tiles: the weights are staged once, the 55-row
 // input window of tile i+2 is DMA'd (one 1 KiB global_load_lds per row) while tiles i+1 / i are multiplied / stored.
 // 8 waves, one output row each (two per SIMD, so that one wave's DMA issue, fragment reads and stores hide under the other's MFMAs).
-__global__ __launch_bounds__(512) void conv1_bf16_fwd_kernel(C1Args a) {
+__global__ __launch_bounds__(512) void conv1_bf16_fwd_kernel(C1Args a, float* __restrict__ stat_part) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   char* wl = lds + 2 * F_BUF;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -141,6 +141,9 @@ __global__ __launch_bounds__(512) void conv1_bf16_fwd_kernel(C1Args a) {
   float bv[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) bv[r] = a.bias ? a.bias[(r & 3) + 8 * (r >> 2) + 4 * half] : 0.f;
+  float s1[16], s2[16];                                    // BatchNorm statistics of what this lane stores (stat_part != NULL)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
   for (int tile = tile_beg; tile < tile_end; ++tile) {
     const int t0 = tile * F_TT, buf = (tile - tile_beg) & 1;
     const bool live = t0 < len;                                           // block-uniform; later tiles of a short utterance are all zero
@@ -173,8 +176,31 @@ __global__ __launch_bounds__(512) void conv1_bf16_fwd_kernel(C1Args a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
-        a.y[(((long long)b * CO + co) * a.D1 + o) * a.T + t] = (t < len) ? acc0[r] + acc1[r] + bv[r] : 0.f;
+        const float v = (t < len) ? acc0[r] + acc1[r] + bv[r] : 0.f;
+        a.y[(((long long)b * CO + co) * a.D1 + o) * a.T + t] = v;
+        s1[r] += v;
+        s2[r] += v * v;
       }
+    }
+  }
+  if (stat_part) {
+    // per-channel sums of the block: over the 32 lanes of a half-wave, then over the 8 waves (output rows) in order; the window
+    // buffers are dead here (every wave has passed the last tile's barrier)
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds);            // [8 waves][32 co][2]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+      for (int m = 1; m < 32; m <<= 1) { s1[r] += __shfl_xor(s1[r], m); s2[r] += __shfl_xor(s2[r], m); }
+      if (l31 == 0) { const int co = (r & 3) + 8 * (r >> 2) + 4 * half; red[(wave * 32 + co) * 2 + 0] = s1[r]; red[(wave * 32 + co) * 2 + 1] = s2[r]; }
+    }
+    __syncthreads();
+    if (tid < 64) {
+      float sum = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) sum += red[w * 64 + tid];
+      const long long blk = ((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      stat_part[blk * 64 + tid] = sum;                     // [blk][co][2]
     }
   }
 }
@@ -380,8 +406,15 @@ extern "C" int ds2_conv1_gather_bf16(const float* x, void* X16, void* X16T, int 
 }
 
 // y1 (B,32,D1,T) fp32 = conv1(x) + bias, zero for t >= lens[b] (MaskConv).  X16 from ds2_conv1_gather_bf16, wp from ds2_conv1_pack_bf16.
-extern "C" int ds2_conv1_fwd_bf16(const void* X16, const void* wp, const float* bias, const int* lens_dev, float* y1, int B, int F, int Tin,
-                                  void* stream) {
+extern "C" int ds2_conv1_fwd_bf16_stat_blocks(int B, int F, int Tin) {
+  (void)Tin;
+  return F_SPLIT * ceil_div((F + 2 * PD - KD) / 2 + 1, F_OG) * B;
+}
+
+// stat_part: NULL, or ds2_conv1_fwd_bf16_stat_blocks() x 32 x 2 floats: per-block (sum, sum of squares) of every output channel over what
+// the block stored (masked frames count as zeros: what BatchNorm2d sees) - finished by ds2_chanstats_from_partials
+extern "C" int ds2_conv1_fwd_bf16_stats(const void* X16, const void* wp, const float* bias, const int* lens_dev, float* y1, int B, int F, int Tin,
+                                        float* stat_part, void* stream) {
   DS2_REQUIRE(X16 && wp && y1, "ds2_conv1_fwd_bf16: null pointer");
   C1Args a{};
   a.X16 = (const __bf16*)X16; a.wp = (const __bf16*)wp; a.bias = bias; a.lens = lens_dev; a.y = y1;
@@ -391,9 +424,14 @@ extern "C" int ds2_conv1_fwd_bf16(const void* X16, const void* wp, const float* 
     DS2_HIP(hipFuncSetAttribute((const void*)conv1_bf16_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv1_bf16_fwd_kernel, dim3(F_SPLIT, ceil_div(a.D1, F_OG), B), dim3(512), F_LDS, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(conv1_bf16_fwd_kernel, dim3(F_SPLIT, ceil_div(a.D1, F_OG), B), dim3(512), F_LDS, (hipStream_t)stream, a, stat_part);
   DS2_LAUNCH_CHECK("conv1_bf16_fwd_kernel");
   return 0;
+}
+
+extern "C" int ds2_conv1_fwd_bf16(const void* X16, const void* wp, const float* bias, const int* lens_dev, float* y1, int B, int F, int Tin,
+                                  void* stream) {
+  return ds2_conv1_fwd_bf16_stats(X16, wp, bias, lens_dev, y1, B, F, Tin, nullptr, stream);
 }
 
 extern "C" size_t ds2_conv1_wgrad_bf16_workspace_bytes(int B, int Tin) {

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void conv2_bf16_kernel(CArgs a) {
 // weight staging (22.5 KB per kernel row was 2/3 of what a block moved into LDS), of the L2 reads and of the barriers per MFMA.  Same
 // accumulation order per output as the one-row kernel: bit-identical.
 template <int SD, int R>
-__global__ __launch_bounds__(256) void conv2_bf16_rows_kernel(CArgs a, int n_out) {
+__global__ __launch_bounds__(256) void conv2_bf16_rows_kernel(CArgs a, int n_out, float* __restrict__ stat_part) {
   constexpr int RING = (R - 1) * SD + 1;                   // rows f0 + kd .. f0 + kd + (R - 1) SD are live at kernel row kd
   constexpr int SLOT = NPIX * IPITCH;
   __shared__ __attribute__((aligned(16))) char in_lds[RING * SLOT];
@@ -250,13 +250,36 @@ __global__ __launch_bounds__(256) void conv2_bf16_rows_kernel(CArgs a, int n_out
   float bv[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) bv[r] = a.bias ? a.bias[(r & 3) + 8 * (r >> 2) + 4 * half] : 0.f;
-  if (t < a.T) {
+  float s1[16], s2[16];                                    // BatchNorm statistics of what this lane stores (stat_part != NULL)
 #pragma unroll
-    for (int q = 0; q < R; ++q)
-      if (o0 + q < n_out) {
+  for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) *out_ptr(o0 + q, (r & 3) + 8 * (r >> 2) + 4 * half) = t >= len ? 0.f : acc[q][r] + bv[r];
+  for (int q = 0; q < R; ++q)
+    if (o0 + q < n_out) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = (t >= len || t >= a.T) ? 0.f : acc[q][r] + bv[r];
+        if (t < a.T) *out_ptr(o0 + q, (r & 3) + 8 * (r >> 2) + 4 * half) = v;
+        s1[r] += v;
+        s2[r] += v * v;
       }
+    }
+  if (stat_part) {
+    // per-channel sums of the block: over the 32 lanes of a half-wave (xor shuffles stay inside it), then over the 4 waves in order
+    __shared__ float red[4][32][2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+      for (int m = 1; m < 32; m <<= 1) { s1[r] += __shfl_xor(s1[r], m); s2[r] += __shfl_xor(s2[r], m); }
+      if (l31 == 0) { const int co = (r & 3) + 8 * (r >> 2) + 4 * half; red[wave][co][0] = s1[r]; red[wave][co][1] = s2[r]; }
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const int co = tid >> 1, w = tid & 1;
+      const float sum = ((red[0][co][w] + red[1][co][w]) + red[2][co][w]) + red[3][co][w];
+      const long long blk = ((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      stat_part[(blk * 32 + co) * 2 + w] = sum;
+    }
   }
 }
 
@@ -326,8 +349,15 @@ extern "C" int ds2_nhwc_bf16_f32(const float* src, void* dst, int B, int D, int 
 }
 
 // y2 (B,32,D2,T) fp32 = mask(conv2(a1) + b2), a1 given channels-last bf16 (B,D1,T,32)
-extern "C" int ds2_conv2_fwd_bf16(const void* a1_nhwc, const void* wf, const float* bias, const int* lens_dev, float* y2, int B, int D1,
-                                  int T, void* stream) {
+extern "C" int ds2_conv2_fwd_bf16_stat_blocks(int B, int D1, int T) {
+  const int D2 = (D1 + 2 * 10 - 21) / 2 + 1;
+  return ceil_div(T, TT) * ceil_div(D2, 3) * B;
+}
+
+// stat_part: NULL, or ds2_conv2_fwd_bf16_stat_blocks() x 32 x 2 floats: per-block (sum, sum of squares) of every output channel over
+// what the block stored (masked frames count as zeros, exactly what BatchNorm2d sees) - ds2_chanstats_from_partials finishes them
+extern "C" int ds2_conv2_fwd_bf16_stats(const void* a1_nhwc, const void* wf, const float* bias, const int* lens_dev, float* y2, int B, int D1,
+                                        int T, float* stat_part, void* stream) {
   DS2_REQUIRE(a1_nhwc && wf && y2, "ds2_conv2_fwd_bf16: null pointer");
   const int D2 = (D1 + 2 * 10 - 21) / 2 + 1;
   CArgs a{};
@@ -336,10 +366,18 @@ extern "C" int ds2_conv2_fwd_bf16(const void* a1_nhwc, const void* wf, const flo
   // three output rows per block (5 input-row slots + the weight row = 77 KB of LDS, two blocks per CU): 655 -> 561 us at c3; two rows
   // 614, four rows (one block per CU) 767.  DS2_CONV2_ROWS=1: the one-row kernel (A/B switch)
   static const char* rows_env = getenv("DS2_CONV2_ROWS");
+  DS2_REQUIRE(!stat_part || !(rows_env && rows_env[0] == '1'), "ds2_conv2_fwd_bf16_stats: the one-row kernel (DS2_CONV2_ROWS=1) has no statistics epilogue");
+  // blocks of a fully masked tile return early: their slots must read as zeros
+  if (stat_part) DS2_HIP(hipMemsetAsync(stat_part, 0, (size_t)ds2_conv2_fwd_bf16_stat_blocks(B, D1, T) * 64 * sizeof(float), (hipStream_t)stream));
   if (rows_env && rows_env[0] == '1') hipLaunchKernelGGL(conv2_bf16_kernel, dim3(ceil_div(T, TT), D2, B), dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((conv2_bf16_rows_kernel<2, 3>), dim3(ceil_div(T, TT), ceil_div(D2, 3), B), dim3(256), 0, (hipStream_t)stream, a, D2);
+  else hipLaunchKernelGGL((conv2_bf16_rows_kernel<2, 3>), dim3(ceil_div(T, TT), ceil_div(D2, 3), B), dim3(256), 0, (hipStream_t)stream, a, D2, stat_part);
   DS2_LAUNCH_CHECK("conv2_bf16_kernel fwd");
   return 0;
+}
+
+extern "C" int ds2_conv2_fwd_bf16(const void* a1_nhwc, const void* wf, const float* bias, const int* lens_dev, float* y2, int B, int D1,
+                                  int T, void* stream) {
+  return ds2_conv2_fwd_bf16_stats(a1_nhwc, wf, bias, lens_dev, y2, B, D1, T, nullptr, stream);
 }
 
 // da1 (B,32,D1,T) fp32 = conv2^T(dy2), dy2 given channels-last bf16 (B,D2,T,32)
@@ -355,7 +393,7 @@ extern "C" int ds2_conv2_dgrad_bf16(const void* dy2_nhwc, const void* wd0, const
     // four output rows per block here (rows one apart: 4 input-row slots): 2 x 347 -> 2 x 290 us
     static const char* rows_env = getenv("DS2_CONV2_ROWS");
     if (rows_env && rows_env[0] == '1') hipLaunchKernelGGL(conv2_bf16_kernel, dim3(ceil_div(T, TT), n_o, B), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((conv2_bf16_rows_kernel<1, 4>), dim3(ceil_div(T, TT), ceil_div(n_o, 4), B), dim3(256), 0, (hipStream_t)stream, a, n_o);
+    else hipLaunchKernelGGL((conv2_bf16_rows_kernel<1, 4>), dim3(ceil_div(T, TT), ceil_div(n_o, 4), B), dim3(256), 0, (hipStream_t)stream, a, n_o, (float*)nullptr);
   }
   DS2_LAUNCH_CHECK("conv2_bf16_kernel dgrad");
   return 0;

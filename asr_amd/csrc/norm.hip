@@ -682,6 +682,74 @@ static int chan_reduce_launch(int mode, const float* Y, const float* dA, int Bn,
   return 0;
 }
 
+// Two ordered stages for MANY partial rows of 32 channels x (sum, sum of squares) (a conv epilogue writes one row per block: thousands):
+// stage 0, block j sums rows [j*rpb, (j+1)*rpb) into tmp[j][64] in fp64 (lanes = the 64 consecutive floats of a row: coalesced);
+// stage 1, one block sums the tmp rows and finishes mean / biased variance / running statistics.
+__global__ __launch_bounds__(256) void chanstats_partials_kernel(const float* __restrict__ part, int n, int rpb, double* __restrict__ tmp, int nblk,
+                                                                 double count, float* __restrict__ mean, float* __restrict__ var,
+                                                                 float* __restrict__ run_mean, float* __restrict__ run_var, float momentum, int stage) {
+  __shared__ double red[4][64];
+  const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
+  double s = 0.0;
+  if (stage == 0) {
+    const int k0 = blockIdx.x * rpb, k1 = min(n, k0 + rpb);
+    int k = k0 + r;
+    for (; k + 12 < k1; k += 16) {                          // four loads in flight, added in order
+      const float v0 = part[(long long)k * 64 + c], v1 = part[(long long)(k + 4) * 64 + c], v2 = part[(long long)(k + 8) * 64 + c],
+                  v3 = part[(long long)(k + 12) * 64 + c];
+      s += (double)v0; s += (double)v1; s += (double)v2; s += (double)v3;
+    }
+    for (; k < k1; k += 4) s += (double)part[(long long)k * 64 + c];
+  } else {
+    for (int k = r; k < nblk; k += 4) s += tmp[(long long)k * 64 + c];
+  }
+  red[r][c] = s;
+  __syncthreads();
+  if (r != 0) return;
+  const double t = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+  if (stage == 0) {
+    tmp[(long long)blockIdx.x * 64 + c] = t;
+    return;
+  }
+  red[0][c] = t;                                            // column c = channel (c >> 1), slot c & 1
+  __syncthreads();
+  if (c < 32) {
+    const double m = red[0][2 * c] / count;
+    double v = red[0][2 * c + 1] / count - m * m;
+    if (v < 0.0) v = 0.0;
+    mean[c] = (float)m;
+    var[c] = (float)v;
+    if (run_mean) {
+      const double unb = count > 1.0 ? v * count / (count - 1.0) : v;
+      run_mean[c] = (float)((1.0 - momentum) * (double)run_mean[c] + momentum * m);
+      run_var[c] = (float)((1.0 - momentum) * (double)run_var[c] + momentum * unb);
+    }
+  }
+}
+
+// mean / biased variance (+ running-stat update) of C channels from [nblk][C][2] (sum, sum of squares) partials written by a conv
+// forward epilogue (ds2_conv1_fwd_bf16_stats / ds2_conv2_fwd_bf16_stats); count = B*D*T elements per channel
+extern "C" size_t ds2_chanstats_from_partials_workspace_bytes(void) { return (size_t)128 * 64 * sizeof(double); }
+
+extern "C" int ds2_chanstats_from_partials(const float* part, int nblk, int C, double count, float* mean, float* var, float* run_mean,
+                                           float* run_var, float momentum, void* ws, size_t ws_bytes, void* stream) {
+  DS2_REQUIRE(part && mean && var && nblk > 0 && C > 0 && count > 0, "ds2_chanstats_from_partials: bad args");
+  if (C == 32 && nblk >= 512 && ws && ws_bytes >= ds2_chanstats_from_partials_workspace_bytes()) {
+    constexpr int SB = 128;
+    const int rpb = ceil_div(nblk, SB), nb = ceil_div(nblk, rpb);
+    hipLaunchKernelGGL(chanstats_partials_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, part, nblk, rpb, (double*)ws, nb, count, mean, var,
+                       run_mean, run_var, momentum, 0);
+    hipLaunchKernelGGL(chanstats_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part, nblk, rpb, (double*)ws, nb, count, mean, var,
+                       run_mean, run_var, momentum, 1);
+    DS2_LAUNCH_CHECK("chanstats_partials_kernel");
+    return 0;
+  }
+  hipLaunchKernelGGL(col_finalize_kernel, dim3(ceil_div(C, 32)), dim3(256), 0, (hipStream_t)stream, part, nblk, C, count, 0, mean, var, run_mean,
+                     run_var, momentum);
+  DS2_LAUNCH_CHECK("col_finalize_kernel");
+  return 0;
+}
+
 // per-channel batch statistics of the (already time-masked) conv output Y (B,C,D,T); count = B*D*T
 // (padding included).
 extern "C" int ds2_bn2d_stats_f32(const float* Y, int B, int C, int D, int T, float* mean, float* var, float* run_mean,

@@ -38,6 +38,8 @@ OVERLAP_WGRAD = OVERLAP_MODE == "1"
 # backward recurrence — no cast / transpose pass at all.  Needs both recurrences of the layer to have run as persistent launches (they are
 # the ones that write the bf16 copies); a layer whose recurrences did not keeps the transposing-cast passes below.  0: always those passes.
 WGRAD_TN = _os.environ.get("DS2_WGRAD_TN", "1") != "0"
+# bf16 mode: BatchNorm2d batch statistics from the conv forward epilogues; needs the rows-per-block conv2 kernel (DS2_CONV2_ROWS != 1)
+CONV_STATS = _os.environ.get("DS2_CONV_STATS", "1") != "0" and _os.environ.get("DS2_CONV2_ROWS", "") != "1"
 _BWD_PERSISTENT = {}      # (gates, H, B) -> did the last backward recurrence of this shape run as a persistent launch?
 _SIDE = {}
 
@@ -123,11 +125,18 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
         # conv1 on the bf16 matrix cores: operand images gathered once from the spectrogram (the time-contiguous one is kept
         # for the weight gradient)
         X16, ctx.x16t = ops.conv1_gather_bf16(x, want_fwd=True, want_wgrad=save)
-        y1 = ops.conv1_fwd_bf16(X16, ops.conv1_pack_bf16(W[cp + "0.weight"]), W[cp + "0.bias"], lens_dev, Tin)
+        # training: the BatchNorm2d statistics come out of the conv epilogues (per-block channel sums), not from another pass over y
+        y1 = ops.conv1_fwd_bf16(X16, ops.conv1_pack_bf16(W[cp + "0.weight"]), W[cp + "0.bias"], lens_dev, Tin, stats=training and CONV_STATS)
+        st_part1 = None
+        if training and CONV_STATS:
+            y1, st_part1 = y1
         del X16
     else:
         y1 = ops.conv1_fwd(x, wpk1, W[cp + "0.bias"], lens_dev)
-    if training:
+        st_part1 = None
+    if training and st_part1 is not None:
+        m1, v1 = ops.chanstats_from_partials(st_part1, B * D1 * T, *run(cp + "1"))
+    elif training:
         m1, v1 = ops.bn2d_stats(y1, *run(cp + "1"))
     else:
         m1, v1 = W[cp + "1.running_mean"], W[cp + "1.running_var"]
@@ -138,12 +147,18 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
                                               want_nhwc=True)
         cwf, cwd0, cwd1 = ops.conv2_pack_bf16(W[cp + "3.weight"])
         ctx.packs = (wpk2d, cwd0, cwd1)
-        y2 = ops.conv2_fwd_bf16(a1n, cwf, W[cp + "3.bias"], lens_dev)
+        y2 = ops.conv2_fwd_bf16(a1n, cwf, W[cp + "3.bias"], lens_dev, stats=training and CONV_STATS)
+        st_part2 = None
+        if training and CONV_STATS:
+            y2, st_part2 = y2
         del a1n
     else:
         a1, a1p = ops.bn2d_act_fwd(y1, lens_dev, m1, v1, W[cp + "1.weight"], W[cp + "1.bias"]), None
         y2 = ops.conv2_fwd(a1, wpk2, W[cp + "3.bias"], lens_dev)
-    if training:
+        st_part2 = None
+    if training and st_part2 is not None:
+        m2, v2 = ops.chanstats_from_partials(st_part2, B * D2 * T, *run(cp + "4"))
+    elif training:
         m2, v2 = ops.bn2d_stats(y2, *run(cp + "4"))
     else:
         m2, v2 = W[cp + "4.running_mean"], W[cp + "4.running_var"]

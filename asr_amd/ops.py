@@ -541,14 +541,31 @@ def conv1_gather_bf16(x: Tensor, want_fwd: bool = True, want_wgrad: bool = True)
     return X16, X16T
 
 
-def conv1_fwd_bf16(X16: Tensor, wp: Tensor, bias: Tensor, lens_dev: Tensor, Tin: int) -> Tensor:
+def conv1_fwd_bf16(X16: Tensor, wp: Tensor, bias: Tensor, lens_dev: Tensor, Tin: int, stats: bool = False):
+    """stats=True: also returns the per-block (sum, sum of squares) partials of y1's channels, taken in the epilogue (chanstats_from_partials)."""
     B, F, T, _ = X16.shape
     D1, _, T2 = _lib.conv_dims(F, Tin)
     assert T2 == T
+    lib = _lib.load()
     y1 = torch.empty(B, 32, D1, T, dtype=torch.float32, device=X16.device)
-    _lib.check(_lib.load().ds2_conv1_fwd_bf16(X16.data_ptr(), wp.data_ptr(), bias.data_ptr(), lens_dev.data_ptr(), y1.data_ptr(), B, F, Tin,
-                                              _stream()), "ds2_conv1_fwd_bf16")
-    return y1
+    part = torch.empty(lib.ds2_conv1_fwd_bf16_stat_blocks(B, F, Tin), 32, 2, dtype=torch.float32, device=X16.device) if stats else None
+    _lib.check(lib.ds2_conv1_fwd_bf16_stats(X16.data_ptr(), wp.data_ptr(), bias.data_ptr(), lens_dev.data_ptr(), y1.data_ptr(), B, F, Tin,
+                                            _ptr(part), _stream()), "ds2_conv1_fwd_bf16")
+    return (y1, part) if stats else y1
+
+
+def chanstats_from_partials(part: Tensor, count: int, run_mean: Optional[Tensor] = None, run_var: Optional[Tensor] = None):
+    """(nblk, C, 2) per-block channel sums of a conv forward epilogue -> (mean, biased var) over `count` elements per channel (+ running stats)."""
+    _chk_f32(part, run_mean, run_var)
+    nblk, Cc, _ = part.shape
+    mean = torch.empty(Cc, dtype=torch.float32, device=part.device)
+    var = torch.empty_like(mean)
+    lib = _lib.load()
+    wsb = lib.ds2_chanstats_from_partials_workspace_bytes()
+    ws = _ws(wsb, part.device)
+    _lib.check(lib.ds2_chanstats_from_partials(part.data_ptr(), nblk, Cc, float(count), mean.data_ptr(), var.data_ptr(), _ptr(run_mean),
+                                               _ptr(run_var), BN_MOMENTUM, ws.data_ptr(), wsb, _stream()), "ds2_chanstats_from_partials")
+    return mean, var
 
 
 def conv1_wgrad_bf16(X16T: Tensor, dy1: Tensor, lens_dev: Tensor, dW1: Tensor, Tin: int):
@@ -580,13 +597,15 @@ def nhwc_bf16(x: Tensor) -> Tensor:
     return out
 
 
-def conv2_fwd_bf16(a1_nhwc: Tensor, wf: Tensor, bias: Tensor, lens_dev: Tensor) -> Tensor:
+def conv2_fwd_bf16(a1_nhwc: Tensor, wf: Tensor, bias: Tensor, lens_dev: Tensor, stats: bool = False):
     B, D1, T, _ = a1_nhwc.shape
     D2 = (D1 + 20 - 21) // 2 + 1
+    lib = _lib.load()
     y2 = torch.empty(B, 32, D2, T, dtype=torch.float32, device=a1_nhwc.device)
-    _lib.check(_lib.load().ds2_conv2_fwd_bf16(a1_nhwc.data_ptr(), wf.data_ptr(), bias.data_ptr(), lens_dev.data_ptr(), y2.data_ptr(), B, D1, T,
-                                              _stream()), "ds2_conv2_fwd_bf16")
-    return y2
+    part = torch.empty(lib.ds2_conv2_fwd_bf16_stat_blocks(B, D1, T), 32, 2, dtype=torch.float32, device=a1_nhwc.device) if stats else None
+    _lib.check(lib.ds2_conv2_fwd_bf16_stats(a1_nhwc.data_ptr(), wf.data_ptr(), bias.data_ptr(), lens_dev.data_ptr(), y2.data_ptr(), B, D1, T,
+                                            _ptr(part), _stream()), "ds2_conv2_fwd_bf16")
+    return (y2, part) if stats else y2
 
 
 def conv2_dgrad_bf16(dy2_nhwc: Tensor, wd0: Tensor, wd1: Tensor, D1: int) -> Tensor:

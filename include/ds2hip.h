@@ -141,6 +141,12 @@ int ds2_conv2_pack_bf16(const float* w2, void* wf, void* wd0, void* wd1, void* s
 int ds2_nhwc_bf16_f32(const float* src, void* dst, int B, int D, int T, void* stream);
 int ds2_conv2_fwd_bf16(const void* a1_nhwc, const void* wf, const float* bias, const int* lens_dev, float* y2, int B, int D1, int T,
                        void* stream);
+int ds2_conv2_fwd_bf16_stat_blocks(int B, int D1, int T);
+int ds2_conv2_fwd_bf16_stats(const void* a1_nhwc, const void* wf, const float* bias, const int* lens_dev, float* y2, int B, int D1, int T,
+                             float* stat_part, void* stream);
+size_t ds2_chanstats_from_partials_workspace_bytes(void);
+int ds2_chanstats_from_partials(const float* part, int nblk, int C, double count, float* mean, float* var, float* run_mean, float* run_var,
+                                float momentum, void* ws, size_t ws_bytes, void* stream);
 int ds2_conv2_dgrad_bf16(const void* dy2_nhwc, const void* wd0, const void* wd1, float* da1, int B, int D1, int T, void* stream);
 
 /* conv2 weight gradient with bf16 MFMA operands: zero-padded bf16 copies (R, Tp) of the (B,32,D,T) tensors, Tp = ds2_conv_padded_pitch(T) */
@@ -234,6 +240,11 @@ int ds2_conv1_pack_bf16(const float* w1, void* wp, void* stream);
 int ds2_conv1_gather_bf16(const float* x, void* X16, void* X16T, int B, int F, int Tin, void* stream);
 int ds2_conv1_fwd_bf16(const void* X16, const void* wp, const float* bias, const int* lens_dev, float* y1, int B, int F, int Tin,
                        void* stream);
+/* ... with the BatchNorm2d statistics of y1 taken in the epilogue: stat_part = ds2_conv1_fwd_bf16_stat_blocks() x 32 x 2 floats of per-block
+ * (sum, sum of squares) per channel; ds2_chanstats_from_partials turns them into mean / biased var (+ running stats) - no pass over y1 */
+int ds2_conv1_fwd_bf16_stat_blocks(int B, int F, int Tin);
+int ds2_conv1_fwd_bf16_stats(const void* X16, const void* wp, const float* bias, const int* lens_dev, float* y1, int B, int F, int Tin,
+                             float* stat_part, void* stream);
 size_t ds2_conv1_wgrad_bf16_workspace_bytes(int B, int Tin);
 int ds2_conv1_wgrad_bf16(const void* X16T, const float* dy1, const int* lens_dev, float* dW1, int B, int F, int Tin, void* ws,
                          size_t ws_bytes, void* stream);

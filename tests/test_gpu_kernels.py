@@ -310,6 +310,14 @@ def test_conv2_bf16(dev, B, Tin, lens_in):
     a1n = ops.nhwc_bf16(g(a1, dev))
     assert torch.equal(a1n.cpu(), a1.bfloat16().permute(0, 2, 3, 1).contiguous())
     y2d = ops.conv2_fwd_bf16(a1n, wf, g(b2, dev), ld)
+    # the same launch with the BatchNorm2d statistics taken in its epilogue: identical output, statistics = those of a pass over it
+    y2s, part = ops.conv2_fwd_bf16(a1n, wf, g(b2, dev), ld, stats=True)
+    assert torch.equal(y2s, y2d)
+    rm, rv = torch.zeros(32, device=dev), torch.ones(32, device=dev)
+    rm2, rv2 = rm.clone(), rv.clone()
+    m_e, v_e = ops.chanstats_from_partials(part, y2d.numel() // 32, rm, rv)
+    m_p, v_p = ops.bn2d_stats(y2d, rm2, rv2)
+    assert rel_l2(m_e.cpu(), m_p.cpu()) < 1e-5 and rel_l2(v_e.cpu(), v_p.cpu()) < 1e-5 and rel_l2(rv.cpu(), rv2.cpu()) < 1e-5
     assert rel_l2(y2d.cpu(), y2.detach()) < 5e-6
     da1 = ops.conv2_dgrad_bf16(ops.nhwc_bf16(g(dy2, dev)), wd0, wd1, 81)
     assert rel_l2(da1.cpu(), a1r.grad) < 5e-6
@@ -343,6 +351,11 @@ def test_conv1_bf16(dev, B, Tin, lens_in):
     assert torch.equal(X16[..., :11].cpu(), want) and float(X16[..., 11:].float().abs().sum()) == 0
     assert torch.equal(X16T[:, :, :11, :T].cpu(), want.permute(0, 1, 3, 2)) and float(X16T[:, :, :, T:].float().abs().sum()) == 0
     y1d = ops.conv1_fwd_bf16(X16, ops.conv1_pack_bf16(g(w1, dev)), g(b1, dev), ld, Tin)
+    y1s, part = ops.conv1_fwd_bf16(X16, ops.conv1_pack_bf16(g(w1, dev)), g(b1, dev), ld, Tin, stats=True)      # statistics in the epilogue
+    assert torch.equal(y1s, y1d)
+    m_e, v_e = ops.chanstats_from_partials(part, y1d.numel() // 32)
+    m_p, v_p = ops.bn2d_stats(y1d)
+    assert rel_l2(m_e.cpu(), m_p.cpu()) < 1e-5 and rel_l2(v_e.cpu(), v_p.cpu()) < 1e-5
     assert y1d.shape == y1.shape and rel_l2(y1d.cpu(), y1.detach()) < 5e-6
     for i, n in enumerate(out_lens.tolist()):
         assert float(y1d[i, :, :, n:].abs().sum()) == 0.0                        # MaskConv zeros
