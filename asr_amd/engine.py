@@ -196,7 +196,9 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
         # hidden unit; the fp32 x-projection buffer is then dead after the recurrence
         pack = bf and save and B % 8 == 0
         if pack:
-            h_bf = torch.empty(M, 2 * H, dtype=torch.bfloat16, device=x.device) if (WGRAD_TN and OVERLAP_MODE == "2" and T > 1) else None
+            # (not for shapes whose backward recurrence is known to run one launch per step - LSTM H = 1280: nobody would read the copy)
+            h_bf = (torch.empty(M, 2 * H, dtype=torch.bfloat16, device=x.device)
+                    if (WGRAD_TN and OVERLAP_MODE == "2" and T > 1 and _BWD_PERSISTENT.get((G, H, B), True)) else None)
             hbuf, aux, rec = ops.rnn_fwd(G, gx, wpf, W[f"rnns.{l}.bhh_cat"], lens_dev, T, B, H, bf16=True, packed_gates=True, h_bf16=h_bf)
             gx = None
             lc.rec, lc.gshape = rec, (M, 2 * G * H)
