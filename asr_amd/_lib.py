@@ -23,6 +23,7 @@ SIGNATURES = {
     "ds2_last_error": (C.c_char_p, []),
     "ds2_device_info": (i32, [C.POINTER(i32), C.POINTER(i32), C.c_char_p, i32]),
     "ds2_debug_flags": (i32, [i32]),
+    "ds2_ablation_build": (i32, []),
     "ds2_rnn_persistent_status": (i32, [vp]),
     "ds2_rnn_persistent_counters": (i32, [vp]),
     "ds2_rnn_step_gate": (i32, [vp, vp, vp]),

@@ -27,7 +27,23 @@ extern "C" int ds2_device_info(int* cu_count, int* wave_size, char* arch, int ar
   return 0;
 }
 
-// Profiling/ablation switch (scripts/ablate_rnn.py only; 0 in production): bit0 = skip the h.W_hh GEMM,
-// bit1 = skip the gate epilogue, in the recurrent step kernels.
+// Kernel-family / tile-shape SELECTORS of the recurrence (every selection computes the full result): 8 / 16 = alternative tile shapes of the
+// wide step kernels, 64 = step kernels instead of the persistent ones, 128 = all-gather persistent backward instead of the K-split one.
+// Bits 1 / 2 (skip the h.W_hh product / the gate epilogue: scripts/ablate_rnn.py) SKIP WORK and exist only in a library built with
+// -DDS2_ABLATE (make ABLATE=1); the shipped library masks them off here and compiles the tests out of the kernels (rnn.hip).
 int g_ds2_debug_flags = 0;
-extern "C" int ds2_debug_flags(int flags) { int old = g_ds2_debug_flags; g_ds2_debug_flags = flags; return old; }
+extern "C" int ds2_debug_flags(int flags) {
+  int old = g_ds2_debug_flags;
+#ifndef DS2_ABLATE
+  flags &= ~3;
+#endif
+  g_ds2_debug_flags = flags;
+  return old;
+}
+extern "C" int ds2_ablation_build(void) {
+#ifdef DS2_ABLATE
+  return 1;
+#else
+  return 0;
+#endif
+}

@@ -26,7 +26,9 @@
 // or the cell state c (LSTM); h per direction.  Rows t >= len[b] hold zeros everywhere, which is
 // what makes the reverse direction start at each sample's own last frame.
 #include "common.h"
+#include "permlane.h"
 #include <type_traits>
+#include <algorithm>
 
 extern int g_ds2_debug_flags;
 
@@ -36,6 +38,15 @@ namespace {
 #define DS2_RNN_NW 8
 #endif
 constexpr int NW = DS2_RNN_NW;          // waves per block
+
+// Selector bits of ds2_debug_flags (include/ds2hip.h): 8 / 16 tile shapes of the wide step kernels, 64 step kernels instead of the persistent
+// ones, 128 all-gather persistent backward instead of the K-split one.  The WORK-SKIPPING bits 1 (no h W_hh product) and 2 (no gate
+// epilogue) of scripts/ablate_rnn.py exist only in a library built with -DDS2_ABLATE (make ABLATE=1); the shipped one ignores them.
+#ifdef DS2_ABLATE
+#define DS2_ABLATE_BIT(flags, bit) (((flags) & (bit)) != 0)
+#else
+#define DS2_ABLATE_BIT(flags, bit) false
+#endif
 
 // Streamed-once traffic (gate pre-activations in, gates / h / aux out, dy in) is marked non-temporal so that it does
 // not evict the per-XCD working set that IS re-read every step (W_hh slices 3.1 MB + packed h at H=1024) from the 4 MB L2.
@@ -271,7 +282,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(const float* pk, 
     // (issued behind the operand loads they queued behind 160 KB in the in-order memory pipe and were ~0.3 us late: 5.9 -> 5.65 us/step).
     issue_hbm_loads();
     asm volatile("" ::: "memory");
-    const int nch_eff = (has_prev && !(dbg & 1)) ? nch : 0;
+    const int nch_eff = (has_prev && !DS2_ABLATE_BIT(dbg, 1)) ? nch : 0;
     const float* pa = pk_in + ((long long)(bt * MB) * nch) * 256 + lane * 4;                      // + mb*nch*256 + c*256
     const float* pw = wp + ((((long long)dir * nsl + slice * NS) * G) * nch) * 256 + lane * 4;      // + (n*G+g)*nch*256 + c*256
     mfma_packed<BF, MB, NS * G, (NS == 2 ? 3 : 4)>(acc, nch_eff, wave, pa, (long long)nch * 256, pw, (long long)nch * 256, issue_epilogue_loads);
@@ -283,7 +294,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(const float* pk, 
     for (int g = 0; g < NS * G; ++g) red[wave][i * NS * G + g][lane] = acc[i][g];
   __syncthreads();
   RNN_TRACE(s, 3);
-  if (dbg & 2) return;
+  if (DS2_ABLATE_BIT(dbg, 2)) return;
 
 #pragma unroll
   for (int i = 0; i < PAIRS; ++i) {
@@ -398,6 +409,13 @@ __device__ __forceinline__ void store16_l2(void* p, u32x4_ v) { asm volatile("gl
 __device__ __forceinline__ void store16_x(void* p, u32x4_ v, bool l2_local) {
   if (l2_local) store16_l2(p, v);
   else store16_sc1(p, v);
+}
+// 8-byte granule of the K-split backward exchange (rnn_bwd_ksplit.h): naturally aligned, so the two dwords land together
+__device__ __forceinline__ void store8_x(void* p, unsigned lo, unsigned hi, bool l2_local) {
+  typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+  const u32x2_ v = {lo, hi};
+  if (l2_local) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+  else asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 }
 
 // ---- gather: ONE asm statement per poll pass --------------------------------------------------------------------------------------------
@@ -902,7 +920,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(const float* pk, 
     for (int n = 0; n < NS; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   {
-    const int nch_eff = (has_q && !(dbg & 1)) ? nchb : 0;            // one code path, see the forward kernel
+    const int nch_eff = (has_q && !DS2_ABLATE_BIT(dbg, 1)) ? nchb : 0;  // one code path, see the forward kernel
     const float* pa = pk_in + ((long long)(bt * MB) * nchb) * 256 + lane * 4;
     const float* pw = wp + (((long long)dir * nsl + slice * NS) * nchb) * 256 + lane * 4;
     mfma_packed<BF, MB, NS, (MB * NS > 2 ? 4 : 6)>(acc, nch_eff, wave, pa, (long long)nchb * 256, pw, (long long)nchb * 256, issue_epilogue_loads);
@@ -913,7 +931,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(const float* pk, 
 #pragma unroll
     for (int n = 0; n < NS; ++n) red[wave][i * NS + n][lane] = acc[i][n];
   __syncthreads();
-  if (dbg & 2) return;
+  if (DS2_ABLATE_BIT(dbg, 2)) return;
 
 #pragma unroll
   for (int i = 0; i < PAIRS; ++i) {
@@ -1252,7 +1270,8 @@ inline int pick_mb(int B, int H) {
 // which persistent kernels may be used (ds2_rnn_persistent_enable): the backward one must be switched off by a caller that runs
 // collectives on another stream during backward, because a persistent launch needs every one of its workgroups resident at once
 int g_persist_fwd = 1, g_persist_bwd = 1;
-int g_last_path = 0;                    // bit 0 / bit 1: the last ds2_rnn_fwd / ds2_rnn_bwd call took the persistent kernel
+int g_last_path = 0;                    // bit 0 / bit 1: the last ds2_rnn_fwd / ds2_rnn_bwd call took a persistent kernel; bit 2: the K-split one
+int g_last_bwd_kind = 0;                // 0 step kernels, 1 all-gather persistent, 2 K-split persistent
 // After a starved launch (ds2_rnn_persistent_status) the next g_persist_cooldown recurrence calls take the one-launch-per-step kernels,
 // then the persistent kernels are armed again: a transient (another process or stream holding CUs for a moment) costs a few slow steps,
 // not the rest of the run.  DS2_RNN_REARM_CALLS sets the length (default 64 calls = 6 train steps of a 5-layer model; 0 = never re-arm).
@@ -1296,7 +1315,7 @@ template <int G, bool BF>
 int try_launch_persistent_fwd(RnnArgs a, hipStream_t st) {
   static const char* env = getenv("DS2_RNN_PERSISTENT");          // "0" = always the step kernels (A/B runs, debugging)
   if (env && env[0] == '0') return 0;
-  if (a.dbg) return 0;                                            // the ablation flags belong to the step kernels
+  if (a.dbg & ~128) return 0;                                     // any selector but 128 (= no K-split backward) selects the step kernels
   if ((a.H % 16) != 0 || a.T < 2 || !persist_allowed(false)) return 0;
   const int nsl = a.H / 16;
   const int nch = ceil_div(a.H, kchunk<BF>());
@@ -1365,7 +1384,7 @@ size_t bwd_xbuf_bytes(int gates, int B, int H, int bf16) { return (size_t)2 * (c
 template <int G, bool BF>
 int try_launch_persistent_bwd(RnnArgs a, hipStream_t st) {
   static const char* env = getenv("DS2_RNN_PERSISTENT");
-  if ((env && env[0] == '0') || a.dbg) return 0;
+  if ((env && env[0] == '0') || (a.dbg & ~128)) return 0;
   // buffers: either the bf16 training path's (packed gate records in, bf16 dGx out) or the plain ones (gates in gx, dGx in place)
   if (!((a.gates_bf && a.dgx_bf) || (!a.gates_bf && !a.dgx_bf && a.gx))) return 0;
   if ((a.H % 16) != 0 || a.T < 2 || !persist_allowed(true)) return 0;
@@ -1419,6 +1438,8 @@ int try_launch_persistent_bwd(RnnArgs a, hipStream_t st) {
   if (e != hipSuccess) return ds2_set_error("rnn persistent backward launch failed: %s", hipGetErrorString(e));
   return 1;
 }
+
+#include "rnn_bwd_ksplit.h"
 
 template <int G, bool BF>
 int launch_steps(bool bwd, RnnArgs a, hipStream_t st) {
@@ -1580,7 +1601,8 @@ extern "C" int ds2_rnn_bias_grads(int gates, const float* bias_part, int B, int 
 
 extern "C" size_t ds2_rnn_bwd_workspace_bytes(int gates, int B, int H, int bf16) {
   const size_t step = pk_floats(B, H, gates * H, bf16) * sizeof(float);          // two ping-pong buffers of the step kernels
-  const size_t pers = 4 * bwd_xbuf_bytes(gates, B, H, bf16) + 64;                 // four round-robin buffers of the persistent kernel + its census words
+  size_t pers = 4 * bwd_xbuf_bytes(gates, B, H, bf16) + 64;                       // four round-robin buffers of the persistent kernel + its census words
+  if (bf16 && ksplit_shape_ok(H)) pers = std::max(pers, ksplit_xbuf_bytes(B, H) + 64);   // two slots of the K-split kernel + census
   return (size_t)4 * B * H * sizeof(float) + (step > pers ? step : pers);
 }
 
@@ -1647,10 +1669,16 @@ extern "C" int ds2_rnn_bwd_ex(int gates, const float* dy, int lddy, float* gx, f
   {
     a.dbg = g_ds2_debug_flags;
     hipStream_t st = (hipStream_t)stream;
-    const int rc = bf16 ? (gates == 3 ? try_launch_persistent_bwd<3, true>(a, st) : try_launch_persistent_bwd<4, true>(a, st))
-                        : (gates == 3 ? try_launch_persistent_bwd<3, false>(a, st) : try_launch_persistent_bwd<4, false>(a, st));
-    g_last_path = (g_last_path & ~2) | (rc == 1 ? 2 : 0);
-    if (rc != 0) return rc < 0 ? rc : 0;
+    // bf16: the K-split kernel where the shape qualifies (2 = it does, but a starved launch's cooldown is running: step kernels)
+    int rc = bf16 ? (gates == 3 ? try_launch_ksplit_bwd<3>(a, st) : try_launch_ksplit_bwd<4>(a, st)) : 0;
+    g_last_bwd_kind = rc == 1 ? 2 : 0;
+    if (rc == 0) {
+      rc = bf16 ? (gates == 3 ? try_launch_persistent_bwd<3, true>(a, st) : try_launch_persistent_bwd<4, true>(a, st))
+                : (gates == 3 ? try_launch_persistent_bwd<3, false>(a, st) : try_launch_persistent_bwd<4, false>(a, st));
+      g_last_bwd_kind = rc == 1 ? 1 : 0;
+    }
+    g_last_path = (g_last_path & ~6) | (rc == 1 ? 2 : 0) | (g_last_bwd_kind == 2 ? 4 : 0);
+    if (rc != 0 && rc != 2) return rc < 0 ? rc : 0;
   }
   DS2_HIP(hipMemsetAsync(ws, 0, ds2_rnn_bwd_workspace_bytes(gates, B, H, bf16), (hipStream_t)stream));   // step kernels: zero carry + padding
   return bf16 ? dispatch<true>(gates, true, a, (hipStream_t)stream) : dispatch<false>(gates, true, a, (hipStream_t)stream);

@@ -1,0 +1,332 @@
+// K-SPLIT persistent backward recurrence (bf16 training path) — textually included by rnn.hip inside its anonymous namespace.
+//
+// The all-gather form (rnn_bwd_persistent_kernel) gives a workgroup 32 OUTPUT units: it must read all of dGh_{t+1} of its 16 batch rows
+// (16 x G*H bf16 = 96 KB at H = 1024) every time step, and that read — 32 CUs x 96 KB out of one XCD's L2 — is what the step costs
+// (profiles/r02_probe_persist_timeline.txt: 1.85-2.3 of 3.3 us).  Here the product  dh_partial = dGh W_hh  is split along K instead:
+//
+//   * a workgroup owns 32 hidden units u of one (direction, 16-row batch tile): it does their gate-derivative math, so the G*32 columns
+//     k = g*H + u of dGh are born in its own registers;
+//   * it multiplies THOSE columns by the matching G*32 ROWS of W_hh (all H output columns; the same 192 KB of bf16 fragments per
+//     workgroup as before, resident in registers) — 16 x H partial sums of dh over its K slice — and publishes them as bf16;
+//   * the owner of 32 output units gathers the 16 x 32 partials of all H/32 producers (32 KB instead of 96 KB) and adds them in a fixed
+//     order in fp32.
+// Per CU and step 32 KB are read and 32 KB written (no reset traffic, see the tag below) against 96 KB + 6 KB before.  The sum over K is
+// now an fp32 sum of bf16-rounded partial sums: results differ from the step kernels' by one more bf16 rounding per partial (stated
+// tolerance in tests/test_gpu_kernels.py), they are still run-to-run bit-identical (fixed summation tree).
+//
+// Exchange format.  One 128-byte LINE per (consumer workgroup j', consumer wave w, producer p) = the partials of rows 2w, 2w+1 x the
+// consumer's 32 units: 16 granules of 8 bytes, granule c = [row 2w | row 2w+1] x [unit c | unit 16+c] as bf16.  A consumer wave's lines of
+// all producers are contiguous (gs x 128 B = 4 KB at H = 1024: four 1 KB wave loads), and a line has exactly ONE reader.
+// The payload is its own flag without any reset: bit 0 of every granule (the last mantissa bit of ONE of its four values, which is rounded
+// to 6 explicit bits instead of 7) carries a TAG = (step >> 1) & 1, two slots are used alternately (slot = step & 1), so what a slot holds
+// before step s lands has the opposite tag (the launcher fills both slots with 0xff: tag 1 before steps 0 / 1).  Granules are written by
+// naturally aligned 8-byte stores.  Slot reuse is safe: a producer publishes step s only after it has gathered step s-1 from every
+// member of its group, and a member publishes step s-1 only after all of its waves have read step s-2.
+//
+// The gather needs no LDS and no barrier: lane l of consumer wave w reads 16 bytes (two granules) of producer 8i + (l >> 3), i = 0..gs/8-1,
+// sums over i in registers (8 fp32 sums) and a 3-stage reduce-scatter over lane bits 5, 4, 3 (v_permlane32_swap, v_permlane16_swap, DPP
+// row_ror:8) leaves every lane with the complete sum of ONE (row, unit) pair — the pair whose gate math it then does.  One workgroup
+// barrier per step remains: the 16 x G*32 bf16 tile of dGh goes through LDS so that every wave can take it as its MFMA A operand.
+typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
+template <int G, int NT>
+__global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char* xbuf, unsigned* census, int spin_limit) {
+  static_assert(NW == 8 && NT >= 2 && (NT % 2) == 0, "8 waves: wave w owns output columns [w*H/8, (w+1)*H/8) = NT 16-column tiles");
+  constexpr int NL = NT / 2;                                  // 1 KB wave loads per gather = producers / 8
+  constexpr int AST = 40;                                     // bf16 per staged row (80 B pitch: conflict-free ds_read_b128)
+  __shared__ __attribute__((aligned(16))) __bf16 As[2][G][16][AST];   // dGh tile of this step, double-buffered: ONE barrier per step
+  const PRole role = persist_role(a, census, spin_limit, 2);
+  if (!role.active) return;
+  const int dir = role.dir, bt = role.bt, slice = role.slice;          // slice = my 32 units = my producer index
+  const bool l2_local = role.local != 0;
+  const int T = a.T, B = a.B, H = a.H, lddy = a.lddy;
+  const int gs = a.p_gs;                                                // workgroups per exchange group = H / 32 = 8 * NL
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nsl = H >> 4, nchb = (G * H) >> 5;
+  const long long groupbytes = (long long)gs * gs * 1024;               // [consumer][wave][producer][128 B]
+  const long long slotbytes = (long long)2 * a.p_nbt * groupbytes;
+  char* gbase = xbuf + (long long)(dir * a.p_nbt + bt) * groupbytes;
+
+  // ---- my K slice of W_hh (rows g*H + 32*slice .. +31, gate by gate) x this wave's NT column tiles -> registers (once).  The packed
+  // backward operand of the other kernels holds exactly these fragments: [dir][16-column slice][32-row chunk][lane] (rnn_pack_kernel).
+  f32x4 wreg[G][NT];
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      wreg[g][nt] = *reinterpret_cast<const f32x4*>(a.wp + ((((long long)dir * nsl + (wave * NT + nt)) * nchb + (g * (H >> 5) + slice)) * 256) + lane * 4);
+
+  // ---- this lane's (batch row, hidden unit) pair: where the reduce-scatter below leaves its complete sum
+  const int m = lane & 7, b3 = (lane >> 3) & 1, dsel = ((lane >> 5) << 1) | ((lane >> 4) & 1);
+  const int unit = (dsel & 1) * 16 + 2 * m + (dsel >> 1), row = 2 * wave + b3;
+  const int b = bt * 16 + row, j = slice * 32 + unit;
+  const bool pact = b < B;
+  const int plen = pact ? a.lens[b] : 0;
+  const __bf16* gates_bf = a.gates_bf;
+  float dcar = 0.f;                                                     // GRU dh*z / LSTM dc*f of the step before (own pair)
+
+  struct Ops { bf16x4_ rec; float g0, g1, g2, g3, ax, dy, prev; };       // see rnn_bwd_persistent_kernel: fetched one step ahead, kept raw
+  auto fetch = [&](int step) {
+    Ops o{bf16x4_{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f}, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (!pact) return o;
+    const int t = dir == 0 ? T - 1 - step : step;
+    const long long rowH = (((long long)t * B + b) * 2 + dir) * H + j;
+    if (gates_bf) {
+      o.rec = __builtin_nontemporal_load(reinterpret_cast<const bf16x4_*>(gates_bf) + rowH);
+      if (G == 4) o.ax = ldnt(a.aux + rowH);
+    } else {
+      const float* gp = a.gx + (((long long)t * B + b) * 2 + dir) * G * H + j;
+      o.g0 = ldnt(gp); o.g1 = ldnt(gp + H); o.g2 = ldnt(gp + 2 * H);
+      if (G == 4) { o.g3 = ldnt(gp + 3 * H); o.ax = ldnt(a.aux + rowH); }
+      else o.g3 = ldnt(a.aux + rowH);
+    }
+    o.dy = ldnt(&a.dy[((long long)t * B + b) * lddy + j]);
+    const int tpf = dir == 0 ? t - 1 : t + 1;
+    if (dir == 0 ? (t > 0) : (t < T - 1)) {
+      const long long prow = (((long long)tpf * B + b) * 2 + dir) * H + j;
+      o.prev = (G == 3) ? a.hbuf[prow] : a.aux[prow];
+    }
+    return o;
+  };
+  Ops cur = fetch(0), nxt = cur;
+
+  int so_t = 0;
+  float so_dgx[G], so_dax = 0.f;
+#pragma unroll
+  for (int g = 0; g < G; ++g) so_dgx[g] = 0.f;
+  auto store_results = [&](int t, const float (&dgx)[G], float dax) {
+    if (!pact) return;
+    const long long rw = ((long long)t * B + b) * 2 + dir;
+    if (a.dgx_bf) {
+      __bf16* gb = a.dgx_bf + rw * G * H + j;
+#pragma unroll
+      for (int g = 0; g < G; ++g) __builtin_nontemporal_store((__bf16)dgx[g], gb + g * H);
+    } else {
+      float* gp = a.gx + rw * G * H + j;
+#pragma unroll
+      for (int g = 0; g < G; ++g) stnt(gp + g * H, dgx[g]);
+    }
+    if (G == 3) {
+      stnt(a.aux + rw * H + j, dax);
+      if (a.dhn_bf) __builtin_nontemporal_store((__bf16)dax, a.dhn_bf + rw * H + j);
+    }
+  };
+  float bs[4] = {0.f, 0.f, 0.f, 0.f};
+
+  // gather: this wave's lines of all producers are contiguous; publish: lane (q = lane >> 4, c = lane & 15) of tile pair pr writes granule c
+  // of the line (consumer wave * NL + pr, consumer wave 2q + x, producer slice)
+  unsigned goff[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) goff[i] = (unsigned)((((slice * 8 + wave) * gs) * 128) + i * 1024 + lane * 16);
+  const unsigned pend0 = (1u << NL) - 1u;
+  const long long pub_off = ((long long)((wave * NL) * 8 + 2 * (lane >> 4)) * gs + slice) * 128 + (lane & 15) * 8;
+  const long long pub_step = (long long)gs * 128;                        // next consumer wave (x) ; 8 of them = next consumer (pr)
+
+  PTRACE_DECL;
+  vm_drained();
+  for (int s = 0; s < T; ++s) {
+    const int t = dir == 0 ? T - 1 - s : s;
+    PTRACE(0);
+    float carry = 0.f;
+    if (s > 0) {
+      const char* xin = gbase + (long long)((s - 1) & 1) * slotbytes;
+      const unsigned tagw = ((unsigned)(s - 1) >> 1) & 1u;
+      u32x4_ av[NL];
+#pragma unroll
+      for (int i = 0; i < NL; ++i) av[i] = u32x4_{0u, 0u, 0u, 0u};
+      int spins = 0;
+      unsigned pend = pend0;
+      while (pend) {
+        poll_pass<NL>(av, goff, xin, pend);
+#pragma unroll
+        for (int i = 0; i < NL; ++i)
+          if (pend & (1u << i)) {
+            const bool ok = (((av[i].x ^ tagw) | (av[i].z ^ tagw)) & 1u) == 0u;      // both granules of this lane carry the step's tag
+            if (__ballot(ok) == ~0ull) pend &= ~(1u << i);
+          }
+        pend = __builtin_amdgcn_readfirstlane(pend);
+        if (pend && ++spins > spin_limit) {
+          if (lane == 0 && atomicCAS(&g_persist_dbg[0], 0, 2) == 0) {
+            g_persist_dbg[1] = slice; g_persist_dbg[2] = bt; g_persist_dbg[3] = dir; g_persist_dbg[4] = s; g_persist_dbg[5] = wave;
+            g_persist_dbg[6] = (int)pend; g_persist_dbg[7] = l2_local;
+            __threadfence_system();
+          }
+          return;
+        }
+      }
+      // ---- sum over this lane's NL producers, then the reduce-scatter over the 8 producers of a load
+      float S[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // S[2 d + h]: dword d of the 16 bytes, h = 0 row 2w / 1 row 2w+1
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const u32x4_ c = av[i];
+        S[0] += __builtin_bit_cast(float, (c.x << 16) & 0xfffe0000u); S[1] += __builtin_bit_cast(float, c.x & 0xffff0000u);
+        S[2] += __builtin_bit_cast(float, c.y << 16);                 S[3] += __builtin_bit_cast(float, c.y & 0xffff0000u);
+        S[4] += __builtin_bit_cast(float, (c.z << 16) & 0xfffe0000u); S[5] += __builtin_bit_cast(float, c.z & 0xffff0000u);
+        S[6] += __builtin_bit_cast(float, c.w << 16);                 S[7] += __builtin_bit_cast(float, c.w & 0xffff0000u);
+      }
+      float R[4], Q[2];
+#ifndef DS2_KSPLIT_SHFL
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {        // lanes 0-31 keep sums 0..3, lanes 32-63 sums 4..7
+        const u32pair r = permlane32_swap(S[k], S[k + 4]);
+        R[k] = r.a + r.b;
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {        // even 16-lane rows keep 0..1, odd rows 2..3 of what the half kept
+        const u32pair r = permlane16_swap(R[k], R[k + 2]);
+        Q[k] = r.a + r.b;
+      }
+      {
+        const float keep = b3 ? Q[1] : Q[0], send = b3 ? Q[0] : Q[1];
+        const int got = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0x128 /* row_ror:8 */, 0xf, 0xf, false);
+        carry = keep + __builtin_bit_cast(float, got);
+      }
+#else   // reference form of the same tree with ds_bpermute shuffles (scripts/probe_ksplit_reduce.hip checks the two against each other)
+      const int b5 = lane >> 5, b4 = (lane >> 4) & 1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float mine = b5 ? S[k + 4] : S[k], give = b5 ? S[k] : S[k + 4];
+        const float got = __shfl_xor(give, 32, 64);
+        R[k] = b5 ? got + mine : mine + got;
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const float mine = b4 ? R[k + 2] : R[k], give = b4 ? R[k] : R[k + 2];
+        const float got = __shfl_xor(give, 16, 64);
+        Q[k] = b4 ? got + mine : mine + got;
+      }
+      {
+        const float keep = b3 ? Q[1] : Q[0], send = b3 ? Q[0] : Q[1];
+        carry = keep + __shfl_xor(send, 8, 64);
+      }
+#endif
+    }
+    vm_drained();
+    PTRACE(1);
+    if (s > 0) cur = nxt;
+    if (gates_bf) { cur.g0 = (float)cur.rec[0]; cur.g1 = (float)cur.rec[1]; cur.g2 = (float)cur.rec[2]; cur.g3 = (float)cur.rec[3]; }
+    // ---- HBM traffic of the step right behind the gather (it has the whole compute phase to retire before the next poll's wait)
+    const bool more = s + 1 < T;
+    if (s > 0) store_results(so_t, so_dgx, so_dax);
+    if (more) nxt = fetch(s + 1);
+    PTRACE(2);
+
+    float dgh[G], dgx[G], dax = 0.f;
+#pragma unroll
+    for (int g = 0; g < G; ++g) { dgh[g] = 0.f; dgx[g] = 0.f; }
+    if (pact && t < plen) {
+      if constexpr (G == 3) {
+        const float dh = cur.dy + carry + dcar;
+        float dpn;
+        gru_bwd_point(dh, cur.g0, cur.g1, cur.g2, cur.g3, cur.prev, dgh, dpn, dcar);
+        dgx[0] = dgh[0]; dgx[1] = dgh[1]; dgx[2] = dpn;
+        dax = dgh[2];
+      } else {
+        const float dh = cur.dy + carry;
+        float car;
+        lstm_bwd_point(dh, dcar, cur.g0, cur.g1, cur.g2, cur.g3, cur.ax, cur.prev, dgh, car);
+        dcar = car;
+#pragma unroll
+        for (int g = 0; g < G; ++g) dgx[g] = dgh[g];
+      }
+    } else {
+      dcar = 0.f;
+    }
+    so_t = t; so_dax = dax;
+#pragma unroll
+    for (int g = 0; g < G; ++g) { so_dgx[g] = dgx[g]; bs[g] += dgx[g]; }
+    if (G == 3) bs[3] += dax;
+    PTRACE(3);
+    if (!more) break;                                      // nobody reads the partials of the last step
+
+    // ---- my K slice of dGh_s -> LDS -> every wave's MFMA A operand (rows beyond B / beyond the sample's length are zeros)
+#pragma unroll
+    for (int g = 0; g < G; ++g) As[s & 1][g][row][unit] = (__bf16)dgh[g];
+    __syncthreads();
+    PTRACE(4);
+    bf16x8 af[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) af[g] = *reinterpret_cast<const bf16x8*>(&As[s & 1][g][lane & 15][(lane >> 4) * 8]);
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[g], __builtin_bit_cast(bf16x8, wreg[g][nt]), acc[nt], 0, 0, 0);
+    PTRACE(5);
+    // ---- publish: acc[nt][r] of lane (q, c) = row 4q + r, column tile nt; consumer wave 2q + x takes r = 2x, 2x + 1
+    {
+      char* xout = gbase + (long long)(s & 1) * slotbytes + pub_off;
+      const unsigned tagw = ((unsigned)s >> 1) & 1u;
+#pragma unroll
+      for (int pr = 0; pr < NL; ++pr)
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+          // granule = [unit c: row lo | row hi] [unit 16 + c: row lo | row hi]; the first value is rounded to 6 explicit mantissa bits
+          // (round to nearest even at bit 17) and gives its last bit to the tag
+          // (written as whole-vector conversions: hipcc 7.2 merged the scalar form of the two x iterations and shipped x = 0's rounded
+          //  value in x = 1's granule)
+          const f32x4 lo = acc[2 * pr], hi = acc[2 * pr + 1];
+          unsigned u0 = __builtin_bit_cast(unsigned, x == 0 ? lo[0] : lo[2]);
+          u0 = (u0 + 0xffffu + ((u0 >> 17) & 1u)) & 0xfffe0000u;
+          const f32x2_ v0 = {__builtin_bit_cast(float, u0), x == 0 ? lo[1] : lo[3]}, v1 = {x == 0 ? hi[0] : hi[2], x == 0 ? hi[1] : hi[3]};
+          const bf16x2_ p0 = __builtin_convertvector(v0, bf16x2_), p1 = __builtin_convertvector(v1, bf16x2_);
+          store8_x(xout + (long long)(pr * 8 + x) * pub_step, __builtin_bit_cast(unsigned, p0) | tagw, __builtin_bit_cast(unsigned, p1), l2_local);
+        }
+    }
+    PTRACE(6);
+  }
+  store_results(so_t, so_dgx, so_dax);
+  if (a.bsum && pact) {
+    float* o = a.bsum + (((long long)b * 2 + dir) * 4) * H + j;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) o[g * H] = bs[g];
+  }
+  PTRACE_DUMP(1);
+}
+
+// bytes of the two exchange slots: [2 slots][2 dirs x batch tiles][gs consumers][8 waves][gs producers][128 B]
+size_t ksplit_xbuf_bytes(int B, int H) { const size_t gs = (size_t)H / 32; return (size_t)2 * 2 * ceil_div(B, 16) * gs * gs * 1024; }
+bool ksplit_shape_ok(int H) { return H >= 256 && (H % 256) == 0 && H <= 1280; }
+
+// 1 = launched, 0 = not eligible (the caller tries the all-gather persistent kernel, then the step kernels), 2 = eligible but cooling
+// down after a starved launch (step kernels), < 0 = error
+template <int G>
+int try_launch_ksplit_bwd(RnnArgs a, hipStream_t st) {
+  static const char* env = getenv("DS2_RNN_PERSISTENT");
+  static const char* envk = getenv("DS2_RNN_KSPLIT");               // "0": keep the all-gather backward kernel (A/B runs)
+  if ((env && env[0] == '0') || (envk && envk[0] == '0') || a.dbg) return 0;   // any selector: not this kernel
+  if (!((a.gates_bf && a.dgx_bf) || (!a.gates_bf && !a.dgx_bf && a.gx))) return 0;
+  if (!ksplit_shape_ok(a.H) || a.T < 2) return 0;
+  const int gs = a.H / 32, nt = a.H / 128, nbt = ceil_div(a.B, 16);
+  if (nt * G * 4 > 176) return 0;                                    // W_hh fragments must leave room for the rest (256 registers per lane)
+  if ((long long)gs * nbt * 2 > cu_count()) return 0;
+  if (!persist_allowed(true)) return 2;                              // eligible, but a starved launch's cooldown is running
+  a.p_nbt = nbt; a.p_gs = gs; a.p_cux = CUS_PER_XCD;
+  a.p_census = xcd_local_fits(gs, 2 * nbt) ? 1 : 0;
+  char* xbuf = reinterpret_cast<char*>(a.pk);
+  const size_t xbytes = ksplit_xbuf_bytes(a.B, a.H);
+  DS2_HIP(hipMemsetAsync(xbuf, 0xff, xbytes + CENSUS_BYTES, st));     // both slots: tag 1 = "not the data of steps 0 / 1"; census words = -1
+  unsigned* census = reinterpret_cast<unsigned*>(xbuf + xbytes);
+  dim3 grid(a.p_census ? cu_count() : gs * nbt * 2), block(NW * 64);
+  static const char* sl = getenv("DS2_RNN_SPIN_LIMIT");
+  const int spin_limit = sl ? atoi(sl) : (1 << 20);
+  switch (nt) {
+#define DS2_KS(NT_)                                                                                                       \
+  case NT_:                                                                                                               \
+    if constexpr (NT_ * G * 4 <= 176)                                                                                     \
+      hipLaunchKernelGGL((rnn_bwd_ksplit_kernel<G, NT_>), grid, block, 0, st, a, xbuf, census, spin_limit);               \
+    else                                                                                                                  \
+      return 0;                                                                                                           \
+    break;
+    DS2_KS(2) DS2_KS(4) DS2_KS(6) DS2_KS(8) DS2_KS(10)
+#undef DS2_KS
+    default: return 0;
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ds2_set_error("rnn k-split backward launch failed: %s", hipGetErrorString(e));
+  return 1;
+}

@@ -28,8 +28,13 @@ extern "C" {
 const char* ds2_version(void);
 const char* ds2_last_error(void);
 int ds2_device_info(int* cu_count, int* wave_size, char* arch, int arch_len);
-/* profiling/ablation switch used by scripts/ablate_rnn.py; returns the previous value; 0 = production */
+/* Kernel-family selectors of the recurrence (every selection computes the full result; used by the parity tests and A/B scripts):
+ * 8 / 16 alternative tile shapes of the wide step kernels, 64 one launch per time step instead of the persistent kernels, 128 the
+ * all-gather persistent backward kernel instead of the K-split one.  Returns the previous value; 0 = production.  Bits 1 / 2 (skip the
+ * recurrent product / the gate epilogue, scripts/ablate_rnn.py) are honoured only by a library built with -DDS2_ABLATE
+ * (ds2_ablation_build() == 1); the shipped library masks them off. */
 int ds2_debug_flags(int flags);
+int ds2_ablation_build(void);
 
 /* ---- dense GEMM on the f32 matrix cores -------------------------------------------------------
  * C[M,N] (+)= op(A) op(B) (+ bias[N]);  transA: A stored (K,M);  transB: B stored (N,K).
