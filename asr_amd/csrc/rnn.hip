@@ -410,14 +410,6 @@ __device__ __forceinline__ void store16_x(void* p, u32x4_ v, bool l2_local) {
   if (l2_local) store16_l2(p, v);
   else store16_sc1(p, v);
 }
-// 8-byte granule of the K-split backward exchange (rnn_bwd_ksplit.h): naturally aligned, so the two dwords land together
-__device__ __forceinline__ void store8_x(void* p, unsigned lo, unsigned hi, bool l2_local) {
-  typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
-  const u32x2_ v = {lo, hi};
-  if (l2_local) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
-  else asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-}
-
 // ---- gather: ONE asm statement per poll pass --------------------------------------------------------------------------------------------
 // An asynchronous load issued from inline asm leaves its destination registers unprotected until one's OWN s_waitcnt: between two asm
 // statements the compiler is free to copy them, and it does as soon as the surrounding code changes shape (seen in the probe: whole-array
@@ -1437,6 +1429,17 @@ int try_launch_persistent_bwd(RnnArgs a, hipStream_t st) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ds2_set_error("rnn persistent backward launch failed: %s", hipGetErrorString(e));
   return 1;
+}
+
+// 16-byte exchange store with a wave-uniform 64-bit base (SGPR pair) + a per-lane 32-bit offset: no 64-bit vector address arithmetic per store
+// (s_nop: see store16_sc1)
+template <bool L2_LOCAL>
+__device__ __forceinline__ void store16_base(const char* base, unsigned off, u32x4_ v) {
+  const unsigned long long u = reinterpret_cast<unsigned long long>(base);
+  const unsigned bhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)), blo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u);
+  const unsigned long long sb = ((unsigned long long)bhi << 32) | (unsigned long long)blo;
+  if (L2_LOCAL) asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 2" ::"v"(off), "v"(v), "s"(sb) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 2" ::"v"(off), "v"(v), "s"(sb) : "memory");
 }
 
 #include "rnn_bwd_ksplit.h"

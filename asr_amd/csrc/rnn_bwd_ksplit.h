@@ -14,27 +14,36 @@
 // now an fp32 sum of bf16-rounded partial sums: results differ from the step kernels' by one more bf16 rounding per partial (stated
 // tolerance in tests/test_gpu_kernels.py), they are still run-to-run bit-identical (fixed summation tree).
 //
-// Exchange format.  One 128-byte LINE per (consumer workgroup j', consumer wave w, producer p) = the partials of rows 2w, 2w+1 x the
-// consumer's 32 units: 16 granules of 8 bytes, granule c = [row 2w | row 2w+1] x [unit c | unit 16+c] as bf16.  A consumer wave's lines of
-// all producers are contiguous (gs x 128 B = 4 KB at H = 1024: four 1 KB wave loads), and a line has exactly ONE reader.
-// The payload is its own flag without any reset: bit 0 of every granule (the last mantissa bit of ONE of its four values, which is rounded
-// to 6 explicit bits instead of 7) carries a TAG = (step >> 1) & 1, two slots are used alternately (slot = step & 1), so what a slot holds
-// before step s lands has the opposite tag (the launcher fills both slots with 0xff: tag 1 before steps 0 / 1).  Granules are written by
-// naturally aligned 8-byte stores.  Slot reuse is safe: a producer publishes step s only after it has gathered step s-1 from every
-// member of its group, and a member publishes step s-1 only after all of its waves have read step s-2.
+// What a step costs here is (a) the exchange latency and (b) INSTRUCTIONS: two waves share a SIMD, so every VALU instruction of the
+// dependent chain gather -> gate math -> MFMA -> publish costs 8 cycles of it, and all eight waves share ONE address unit that spends
+// ~16 cycles on a vector-memory wave-instruction whatever its width (160 such instructions per step in the first version = 1.1 us).  Hence:
+// every exchange access is 16 bytes per lane; results leave through LDS as 16-byte stores by four waves (4 instructions per step instead of
+// 40); addresses are stepped, not recomputed.
 //
-// The gather needs no LDS and no barrier: lane l of consumer wave w reads 16 bytes (two granules) of producer 8i + (l >> 3), i = 0..gs/8-1,
-// sums over i in registers (8 fp32 sums) and a 3-stage reduce-scatter over lane bits 5, 4, 3 (v_permlane32_swap, v_permlane16_swap, DPP
-// row_ror:8) leaves every lane with the complete sum of ONE (row, unit) pair — the pair whose gate math it then does.  One workgroup
-// barrier per step remains: the 16 x G*32 bf16 tile of dGh goes through LDS so that every wave can take it as its MFMA A operand.
+// Exchange format.  One 128-byte LINE per (consumer workgroup j', consumer wave w, producer p) = the partials of rows 2w, 2w+1 x the
+// consumer's 32 units: piece (h, q) of 16 bytes = row 2w + h, units [4q..4q+3 | 16+4q..16+4q+3] as bf16.  A consumer wave's lines of all
+// producers are contiguous (gs x 128 B = 4 KB at H = 1024: four 1 KB wave loads), and a line has exactly ONE reader.  The product is
+// computed TRANSPOSED (A = W_hh fragment, B = dGh fragment), so that a lane of the producer holds 4 consecutive units of one batch row per
+// 16-column tile: its 16-byte piece is two tiles' registers, one `global_store_dwordx4` per tile pair and wave covers eight lines.
+// The payload is its own flag without any reset: bit 0 of every 8-byte half of a piece (the last mantissa bit of its first value, which
+// stays part of the value: +-1 bf16 ulp, sign alternating with the tag) carries a TAG = (step >> 1) & 1, two slots are used alternately
+// (slot = step & 1), so what a slot holds before step s lands has the opposite tag (the launcher fills both slots with 0xff: tag 1 before
+// steps 0 / 1).  Slot reuse is safe: a producer publishes step s only after it has gathered step s-1 from every member of its group, and a
+// member publishes step s-1 only after all of its waves have read step s-2.
+//
+// The gather needs no LDS and no barrier: lane l of consumer wave w reads piece (l & 7) of producer 8i + (l >> 3), i = 0..gs/8-1, sums over i
+// in registers (8 fp32 sums) and a 3-stage reduce-scatter over lane bits 5, 4, 3 (v_permlane32_swap, v_permlane16_swap, DPP row_ror:8)
+// leaves every lane with the complete sum of ONE (row, unit) pair — the pair whose gate math it then does.  One workgroup barrier per step
+// remains: the 16 x G*32 bf16 tile of dGh goes through LDS so that every wave can take it as its MFMA operand (and leave through it).
 typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
 typedef float f32x2_ __attribute__((ext_vector_type(2)));
 template <int G, int NT>
 __global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char* xbuf, unsigned* census, int spin_limit) {
   static_assert(NW == 8 && NT >= 2 && (NT % 2) == 0, "8 waves: wave w owns output columns [w*H/8, (w+1)*H/8) = NT 16-column tiles");
-  constexpr int NL = NT / 2;                                  // 1 KB wave loads per gather = producers / 8
+  constexpr int NL = NT / 2;                                  // 1 KB wave loads per gather = producers / 8 = tile pairs per wave
   constexpr int AST = 40;                                     // bf16 per staged row (80 B pitch: conflict-free ds_read_b128)
-  __shared__ __attribute__((aligned(16))) __bf16 As[2][G][16][AST];   // dGh tile of this step, double-buffered: ONE barrier per step
+  // planes 0..G-1: dGh gate by gate (the MFMA operand); GRU plane 3: d(pre-activation of n) = the n column of dGx.  Double-buffered: ONE barrier per step
+  __shared__ __attribute__((aligned(16))) __bf16 As[2][4][16][AST];
   const PRole role = persist_role(a, census, spin_limit, 2);
   if (!role.active) return;
   const int dir = role.dir, bt = role.bt, slice = role.slice;          // slice = my 32 units = my producer index
@@ -57,71 +66,84 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char
     for (int nt = 0; nt < NT; ++nt)
       wreg[g][nt] = *reinterpret_cast<const f32x4*>(a.wp + ((((long long)dir * nsl + (wave * NT + nt)) * nchb + (g * (H >> 5) + slice)) * 256) + lane * 4);
 
-  // ---- this lane's (batch row, hidden unit) pair: where the reduce-scatter below leaves its complete sum
-  const int m = lane & 7, b3 = (lane >> 3) & 1, dsel = ((lane >> 5) << 1) | ((lane >> 4) & 1);
-  const int unit = (dsel & 1) * 16 + 2 * m + (dsel >> 1), row = 2 * wave + b3;
+  // ---- this lane's (batch row, hidden unit) pair: where the reduce-scatter below leaves its complete sum.  Lane = (b5, b4, b3, h, q):
+  // piece (h, q) of the line; of the 8 sums of a piece [dword d = 2 b5 + b4][half b3] it keeps unit (d >> 1) * 16 + 4q + (d & 1) * 2 + b3
+  const int q4 = lane & 3, hrow = (lane >> 2) & 1, b3 = (lane >> 3) & 1, b4 = (lane >> 4) & 1, b5 = lane >> 5;
+  const int unit = b5 * 16 + 4 * q4 + 2 * b4 + b3, row = 2 * wave + hrow;
   const int b = bt * 16 + row, j = slice * 32 + unit;
   const bool pact = b < B;
   const int plen = pact ? a.lens[b] : 0;
   const __bf16* gates_bf = a.gates_bf;
   float dcar = 0.f;                                                     // GRU dh*z / LSTM dc*f of the step before (own pair)
 
+  // Element offsets of this lane's pair at the step being processed, stepped by a wave-uniform stride per time step (one 64-bit add each instead
+  // of the multiply chains of a fresh index computation):
+  //   eH into the (T,B,2,H) tensors, eG into the (T,B,2,G*H) tensors, eY into dy
+  const int t0 = dir == 0 ? T - 1 : 0;
+  const long long dH = (dir == 0 ? -1LL : 1LL) * B * 2 * H, dG = dH * G, dY = (dir == 0 ? -1LL : 1LL) * B * lddy;
+  long long eH = (((long long)t0 * B + b) * 2 + dir) * H + j, eG = (((long long)t0 * B + b) * 2 + dir) * G * H + j, eY = ((long long)t0 * B + b) * lddy + j;
   struct Ops { bf16x4_ rec; float g0, g1, g2, g3, ax, dy, prev; };       // see rnn_bwd_persistent_kernel: fetched one step ahead, kept raw
-  auto fetch = [&](int step) {
+  // operands of the step whose offsets are (fH, fG, fY); has_prev: that step has a predecessor in FORWARD order (= the step processed after it)
+  auto fetch = [&](long long fH, long long fG, long long fY, bool has_prev) {
     Ops o{bf16x4_{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f}, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (!pact) return o;
-    const int t = dir == 0 ? T - 1 - step : step;
-    const long long rowH = (((long long)t * B + b) * 2 + dir) * H + j;
     if (gates_bf) {
-      o.rec = __builtin_nontemporal_load(reinterpret_cast<const bf16x4_*>(gates_bf) + rowH);
-      if (G == 4) o.ax = ldnt(a.aux + rowH);
+      o.rec = __builtin_nontemporal_load(reinterpret_cast<const bf16x4_*>(gates_bf) + fH);
+      if (G == 4) o.ax = ldnt(a.aux + fH);
     } else {
-      const float* gp = a.gx + (((long long)t * B + b) * 2 + dir) * G * H + j;
+      const float* gp = a.gx + fG;
       o.g0 = ldnt(gp); o.g1 = ldnt(gp + H); o.g2 = ldnt(gp + 2 * H);
-      if (G == 4) { o.g3 = ldnt(gp + 3 * H); o.ax = ldnt(a.aux + rowH); }
-      else o.g3 = ldnt(a.aux + rowH);
+      if (G == 4) { o.g3 = ldnt(gp + 3 * H); o.ax = ldnt(a.aux + fH); }
+      else o.g3 = ldnt(a.aux + fH);
     }
-    o.dy = ldnt(&a.dy[((long long)t * B + b) * lddy + j]);
-    const int tpf = dir == 0 ? t - 1 : t + 1;
-    if (dir == 0 ? (t > 0) : (t < T - 1)) {
-      const long long prow = (((long long)tpf * B + b) * 2 + dir) * H + j;
-      o.prev = (G == 3) ? a.hbuf[prow] : a.aux[prow];
-    }
+    o.dy = ldnt(a.dy + fY);
+    if (has_prev) o.prev = (G == 3) ? a.hbuf[fH + dH] : a.aux[fH + dH];     // h / c of the previous frame in forward order = the NEXT step's row
     return o;
   };
-  Ops cur = fetch(0), nxt = cur;
+  Ops cur = fetch(eH, eG, eY, T > 1), nxt = cur;
 
-  int so_t = 0;
-  float so_dgx[G], so_dax = 0.f;
-#pragma unroll
-  for (int g = 0; g < G; ++g) so_dgx[g] = 0.f;
-  auto store_results = [&](int t, const float (&dgx)[G], float dax) {
+  // Results.  bf16 training path (dgx_bf given): the bf16 values are in the LDS planes anyway — after the step's barrier, wave p < 4 sends
+  // plane p out with ONE 16-byte store per lane (lane = row (lane >> 2), 8 units (lane & 3)): GRU planes 0, 1, 3 -> dGx columns r, z, n and
+  // plane 2 -> the bf16 copy of d(hn); LSTM plane g -> dGx column g.  The fp32 d(hn) (aux) is written lane by lane only when nobody asked
+  // for the bf16 copy.  Plain fp32 buffers (tests) and the last step: lane by lane.
+  const bool lds_out = a.dgx_bf != nullptr;
+  const bool aux_f32 = G == 3 && !(lds_out && a.dhn_bf);
+  auto store_lane = [&](long long fH, long long fG, const float (&dgx)[G], float dax, bool all) {
     if (!pact) return;
-    const long long rw = ((long long)t * B + b) * 2 + dir;
-    if (a.dgx_bf) {
-      __bf16* gb = a.dgx_bf + rw * G * H + j;
+    if (all) {
+      if (a.dgx_bf) {
+        __bf16* gb = a.dgx_bf + fG;
 #pragma unroll
-      for (int g = 0; g < G; ++g) __builtin_nontemporal_store((__bf16)dgx[g], gb + g * H);
-    } else {
-      float* gp = a.gx + rw * G * H + j;
+        for (int g = 0; g < G; ++g) __builtin_nontemporal_store((__bf16)dgx[g], gb + g * H);
+      } else {
+        float* gp = a.gx + fG;
 #pragma unroll
-      for (int g = 0; g < G; ++g) stnt(gp + g * H, dgx[g]);
+        for (int g = 0; g < G; ++g) stnt(gp + g * H, dgx[g]);
+      }
+      if (G == 3 && a.dhn_bf) __builtin_nontemporal_store((__bf16)dax, a.dhn_bf + fH);
     }
-    if (G == 3) {
-      stnt(a.aux + rw * H + j, dax);
-      if (a.dhn_bf) __builtin_nontemporal_store((__bf16)dax, a.dhn_bf + rw * H + j);
-    }
+    if (aux_f32) stnt(a.aux + fH, dax);
   };
+  // plane store of wave p < 4: destination element offset of this lane's 8 units, stepped like eH / eG
+  const int srow = lane >> 2, sb = bt * 16 + srow;
+  const bool s_hn = G == 3 && wave == 2;                                    // this wave's plane is d(hn): (T,B,2,H) bf16 copy
+  const bool s_on = lds_out && wave < 4 && sb < B && !(s_hn && !a.dhn_bf);
+  __bf16* s_dst = s_hn ? a.dhn_bf : a.dgx_bf;
+  long long sE = s_hn ? (((long long)t0 * B + sb) * 2 + dir) * H + slice * 32 + (lane & 3) * 8
+                      : (((long long)t0 * B + sb) * 2 + dir) * G * H + (G == 3 ? (wave == 3 ? 2 : wave) : wave) * H + slice * 32 + (lane & 3) * 8;
+  const long long sD = s_hn ? dH : dG;
   float bs[4] = {0.f, 0.f, 0.f, 0.f};
 
-  // gather: this wave's lines of all producers are contiguous; publish: lane (q = lane >> 4, c = lane & 15) of tile pair pr writes granule c
-  // of the line (consumer wave * NL + pr, consumer wave 2q + x, producer slice)
+  // gather: this wave's lines of all producers are contiguous.  publish: lane (q = lane >> 4, c = lane & 15) holds, per tile pair, units
+  // [4q..4q+3 | 16+4q..] of batch row c: piece (c & 1, q) of the line of consumer wave c >> 1 — a wave-uniform base per store + one
+  // per-lane 32-bit offset
   unsigned goff[NL];
 #pragma unroll
   for (int i = 0; i < NL; ++i) goff[i] = (unsigned)((((slice * 8 + wave) * gs) * 128) + i * 1024 + lane * 16);
   const unsigned pend0 = (1u << NL) - 1u;
-  const long long pub_off = ((long long)((wave * NL) * 8 + 2 * (lane >> 4)) * gs + slice) * 128 + (lane & 15) * 8;
-  const long long pub_step = (long long)gs * 128;                        // next consumer wave (x) ; 8 of them = next consumer (pr)
+  const unsigned pub_lane_off = (unsigned)(((((lane & 15) >> 1) * gs + slice) * 128) + ((lane & 1) * 4 + (lane >> 4)) * 16);
+  const long long pub_wave_off = (long long)(wave * NL) * 8 * gs * 128;
+  const long long pub_step = (long long)8 * gs * 128;                    // next consumer workgroup (tile pair)
 
   PTRACE_DECL;
   vm_drained();
@@ -142,7 +164,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char
 #pragma unroll
         for (int i = 0; i < NL; ++i)
           if (pend & (1u << i)) {
-            const bool ok = (((av[i].x ^ tagw) | (av[i].z ^ tagw)) & 1u) == 0u;      // both granules of this lane carry the step's tag
+            const bool ok = (((av[i].x ^ tagw) | (av[i].z ^ tagw)) & 1u) == 0u;      // both halves of this lane's piece carry the step's tag
             if (__ballot(ok) == ~0ull) pend &= ~(1u << i);
           }
         pend = __builtin_amdgcn_readfirstlane(pend);
@@ -155,16 +177,18 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char
           return;
         }
       }
-      // ---- sum over this lane's NL producers, then the reduce-scatter over the 8 producers of a load
-      float S[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // S[2 d + h]: dword d of the 16 bytes, h = 0 row 2w / 1 row 2w+1
+      // ---- sum over this lane's NL producers (packed fp32 adds: S2[d] = the two bf16 of dword d), then the reduce-scatter over the 8
+      // producers of a load.  (Dwords 0 / 2 carry the tag in the last mantissa bit of their low half: it is part of the value.)
+      f32x2_ S2[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
         const u32x4_ c = av[i];
-        S[0] += __builtin_bit_cast(float, (c.x << 16) & 0xfffe0000u); S[1] += __builtin_bit_cast(float, c.x & 0xffff0000u);
-        S[2] += __builtin_bit_cast(float, c.y << 16);                 S[3] += __builtin_bit_cast(float, c.y & 0xffff0000u);
-        S[4] += __builtin_bit_cast(float, (c.z << 16) & 0xfffe0000u); S[5] += __builtin_bit_cast(float, c.z & 0xffff0000u);
-        S[6] += __builtin_bit_cast(float, c.w << 16);                 S[7] += __builtin_bit_cast(float, c.w & 0xffff0000u);
+        S2[0] += f32x2_{__builtin_bit_cast(float, c.x << 16), __builtin_bit_cast(float, c.x & 0xffff0000u)};
+        S2[1] += f32x2_{__builtin_bit_cast(float, c.y << 16), __builtin_bit_cast(float, c.y & 0xffff0000u)};
+        S2[2] += f32x2_{__builtin_bit_cast(float, c.z << 16), __builtin_bit_cast(float, c.z & 0xffff0000u)};
+        S2[3] += f32x2_{__builtin_bit_cast(float, c.w << 16), __builtin_bit_cast(float, c.w & 0xffff0000u)};
       }
+      const float S[8] = {S2[0][0], S2[0][1], S2[1][0], S2[1][1], S2[2][0], S2[2][1], S2[3][0], S2[3][1]};   // S[2 d + half]
       float R[4], Q[2];
 #ifndef DS2_KSPLIT_SHFL
 #pragma unroll
@@ -183,7 +207,6 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char
         carry = keep + __builtin_bit_cast(float, got);
       }
 #else   // reference form of the same tree with ds_bpermute shuffles (scripts/probe_ksplit_reduce.hip checks the two against each other)
-      const int b5 = lane >> 5, b4 = (lane >> 4) & 1;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const float mine = b5 ? S[k + 4] : S[k], give = b5 ? S[k] : S[k + 4];
@@ -202,15 +225,14 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char
       }
 #endif
     }
-    vm_drained();
+    vm_drained();                                          // (the gather has waited for everything; tell the compiler)
     PTRACE(1);
-    if (s > 0) cur = nxt;
-    if (gates_bf) { cur.g0 = (float)cur.rec[0]; cur.g1 = (float)cur.rec[1]; cur.g2 = (float)cur.rec[2]; cur.g3 = (float)cur.rec[3]; }
-    // ---- HBM traffic of the step right behind the gather (it has the whole compute phase to retire before the next poll's wait)
+    if (s > 0) cur = nxt;                                  // operands of THIS step: fetched one step ago, landed
+    // the NEXT step's gate-math operands: issued here, right behind the gather, so that they have a whole step to land (the next poll's
+    // wait retires them too: vmcnt is in order)
     const bool more = s + 1 < T;
-    if (s > 0) store_results(so_t, so_dgx, so_dax);
-    if (more) nxt = fetch(s + 1);
-    PTRACE(2);
+    if (more) nxt = fetch(eH + dH, eG + dG, eY + dY, s + 2 < T);
+    if (gates_bf) { cur.g0 = (float)cur.rec[0]; cur.g1 = (float)cur.rec[1]; cur.g2 = (float)cur.rec[2]; cur.g3 = (float)cur.rec[3]; }
 
     float dgh[G], dgx[G], dax = 0.f;
 #pragma unroll
@@ -233,53 +255,69 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char
     } else {
       dcar = 0.f;
     }
-    so_t = t; so_dax = dax;
 #pragma unroll
-    for (int g = 0; g < G; ++g) { so_dgx[g] = dgx[g]; bs[g] += dgx[g]; }
+    for (int g = 0; g < G; ++g) bs[g] += dgx[g];
     if (G == 3) bs[3] += dax;
-    PTRACE(3);
-    if (!more) break;                                      // nobody reads the partials of the last step
+    PTRACE(2);
+    if (!more) {                                           // nobody reads the partials of the last step
+      store_lane(eH, eG, dgx, dax, true);
+      break;
+    }
 
-    // ---- my K slice of dGh_s -> LDS -> every wave's MFMA A operand (rows beyond B / beyond the sample's length are zeros)
+    // ---- my K slice of dGh_s (+ the n column of dGx) -> LDS: every wave's MFMA operand, and the way the bf16 results leave
 #pragma unroll
     for (int g = 0; g < G; ++g) As[s & 1][g][row][unit] = (__bf16)dgh[g];
+    if (G == 3) As[s & 1][3][row][unit] = (__bf16)dgx[2];
     __syncthreads();
-    PTRACE(4);
+    PTRACE(3);
     bf16x8 af[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) af[g] = *reinterpret_cast<const bf16x8*>(&As[s & 1][g][lane & 15][(lane >> 4) * 8]);
+    u32x4_ outv = u32x4_{0u, 0u, 0u, 0u};
+    if (lds_out && wave < 4) outv = *reinterpret_cast<const u32x4_*>(&As[s & 1][wave][srow][(lane & 3) * 8]);
+    // transposed product: acc[nt][r] of lane (q, c) = partial dh of batch row c, output unit 16 nt + 4q + r.  Two groups of tile pairs, so
+    // that the first group's pieces can be converted and stored while the matrix pipe still works on the second
     f32x4 acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int NT1 = 2 * ((NL + 1) / 2);
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[g], __builtin_bit_cast(bf16x8, wreg[g][nt]), acc[nt], 0, 0, 0);
-    PTRACE(5);
-    // ---- publish: acc[nt][r] of lane (q, c) = row 4q + r, column tile nt; consumer wave 2q + x takes r = 2x, 2x + 1
+      for (int nt = 0; nt < NT1; ++nt)
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wreg[g][nt]), af[g], acc[nt], 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int nt = NT1; nt < NT; ++nt)
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wreg[g][nt]), af[g], acc[nt], 0, 0, 0);
+    PTRACE(4);
+    // ---- publish.  piece = [units 4q..4q+3 | 16+4q..16+4q+3] of batch row c as bf16 (round to nearest even); bit 0 of each 8-byte half —
+    // the last mantissa bit of its first value — is REPLACED by the tag and stays part of the value the consumer adds
     {
-      char* xout = gbase + (long long)(s & 1) * slotbytes + pub_off;
+      const char* xout = gbase + (long long)(s & 1) * slotbytes + pub_wave_off;
       const unsigned tagw = ((unsigned)s >> 1) & 1u;
+      auto publish = [&](auto local) {
 #pragma unroll
-      for (int pr = 0; pr < NL; ++pr)
-#pragma unroll
-        for (int x = 0; x < 2; ++x) {
-          // granule = [unit c: row lo | row hi] [unit 16 + c: row lo | row hi]; the first value is rounded to 6 explicit mantissa bits
-          // (round to nearest even at bit 17) and gives its last bit to the tag
-          // (written as whole-vector conversions: hipcc 7.2 merged the scalar form of the two x iterations and shipped x = 0's rounded
-          //  value in x = 1's granule)
+        for (int pr = 0; pr < NL; ++pr) {
           const f32x4 lo = acc[2 * pr], hi = acc[2 * pr + 1];
-          unsigned u0 = __builtin_bit_cast(unsigned, x == 0 ? lo[0] : lo[2]);
-          u0 = (u0 + 0xffffu + ((u0 >> 17) & 1u)) & 0xfffe0000u;
-          const f32x2_ v0 = {__builtin_bit_cast(float, u0), x == 0 ? lo[1] : lo[3]}, v1 = {x == 0 ? hi[0] : hi[2], x == 0 ? hi[1] : hi[3]};
-          const bf16x2_ p0 = __builtin_convertvector(v0, bf16x2_), p1 = __builtin_convertvector(v1, bf16x2_);
-          store8_x(xout + (long long)(pr * 8 + x) * pub_step, __builtin_bit_cast(unsigned, p0) | tagw, __builtin_bit_cast(unsigned, p1), l2_local);
+          const bf16x2_ p0 = __builtin_convertvector((f32x2_{lo[0], lo[1]}), bf16x2_), p1 = __builtin_convertvector((f32x2_{lo[2], lo[3]}), bf16x2_);
+          const bf16x2_ p2 = __builtin_convertvector((f32x2_{hi[0], hi[1]}), bf16x2_), p3 = __builtin_convertvector((f32x2_{hi[2], hi[3]}), bf16x2_);
+          store16_base<decltype(local)::value>(xout + (long long)pr * pub_step, pub_lane_off,
+                                               u32x4_{(__builtin_bit_cast(unsigned, p0) & ~1u) | tagw, __builtin_bit_cast(unsigned, p1),
+                                                      (__builtin_bit_cast(unsigned, p2) & ~1u) | tagw, __builtin_bit_cast(unsigned, p3)});
         }
+      };
+      if (l2_local) publish(std::true_type{});
+      else publish(std::false_type{});
     }
+    PTRACE(5);
+    // ---- this step's results go out LAST: their stores retire in the shadow of the exchange (nothing of the next step depends on them)
+    if (s_on) __builtin_nontemporal_store(outv, reinterpret_cast<u32x4_*>(s_dst + sE));
+    store_lane(eH, eG, dgx, dax, !lds_out);
+    eH += dH; eG += dG; eY += dY; sE += sD;
     PTRACE(6);
   }
-  store_results(so_t, so_dgx, so_dax);
   if (a.bsum && pact) {
     float* o = a.bsum + (((long long)b * 2 + dir) * 4) * H + j;
 #pragma unroll

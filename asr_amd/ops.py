@@ -703,7 +703,8 @@ def rnn_fwd(gates: int, gx: Tensor, wp_fwd: Tensor, bhh: Tensor, lens_dev: Tenso
 
 
 def rnn_last_path() -> int:
-    """bit 0 / bit 1: the last rnn_fwd / rnn_bwd call ran as one persistent launch (and produced its optional outputs)"""
+    """bit 0 / bit 1: the last rnn_fwd / rnn_bwd call ran as one persistent launch (and produced its optional outputs); bit 2: that
+    backward launch was the K-split kernel (bf16 partial-dh exchange; results within a stated tolerance of the step kernels')"""
     return _lib.load().ds2_rnn_last_path()
 
 

@@ -48,18 +48,22 @@ int main(int argc, char** argv) {
   }
   int st[8];
   ds2_rnn_persistent_status(st);
-  printf("paths taken: %d (3 = both persistent), starved %d\n", ds2_rnn_last_path(), st[0]);
+  printf("paths taken: %d (3 = both persistent, 7 = K-split backward), starved %d\n", ds2_rnn_last_path(), st[0]);
   std::vector<unsigned long long> tr(2 * NW * 8);
   CK(hipMemcpy(tr.data(), trace, tr.size() * 8, hipMemcpyDeviceToHost));
-  const char* names[6] = {"publish -> loop top", "gather (poll)", "HBM issue + MFMA + partials", "barrier", "LDS sums + gate math", "stage + publish"};
+  const char* names_ag[7] = {"publish -> loop top", "gather (poll)", "HBM issue + MFMA + partials", "barrier", "LDS sums + gate math", "stage + publish", "-"};
+  // K-split backward kernel (rnn_bwd_ksplit.h; the default where the shape qualifies, DS2_RNN_KSPLIT=0 selects the all-gather kernel)
+  const char* names_ks[7] = {"store issue -> loop top", "gather (poll) + reduce-scatter", "next fetch issued + gate math", "dGh -> LDS + barrier", "LDS read + MFMA issue",
+                             "MFMA drain + pack + publish", "result stores + offset step"};
   for (int kind = 0; kind < 2; ++kind) {
+    const char** names = (kind == 1 && (ds2_rnn_last_path() & 4)) ? names_ks : names_ag;
     const double us_step = (kind ? msb : msf) * 1e3 / T;
     double tot = 0;
-    for (int k = 0; k < 6; ++k) tot += (double)tr[(kind * NW + 0) * 8 + k];
+    for (int k = 0; k < 7; ++k) tot += (double)tr[(kind * NW + 0) * 8 + k];
     const double tick = us_step * T / tot;     // ticks -> us, from wave 0's total
     printf("%s: %.2f us/step (events, traced build); wave 0 total %.0f ticks -> %.4f ns/tick\n", kind ? "BACKWARD" : "FORWARD", us_step, tot, tick * 1e3);
-    for (int k = 0; k < 6; ++k) {
-      printf("  %-30s", names[k]);
+    for (int k = 0; k < 7; ++k) {
+      printf("  %-32s", names[k]);
       for (int w = 0; w < NW; ++w) printf(" %5.2f", (double)tr[(kind * NW + w) * 8 + k] / T * tick);
       printf("  us (waves 0..7)\n");
     }
