@@ -14,7 +14,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     with open(path, newline="") as f:
         for row in csv.DictReader(f):
             name = row["Kernel_Name"]
-            if "persistent_kernel" not in name and "_step_kernel" not in name:
+            if "persistent_kernel" not in name and "_step_kernel" not in name and "ksplit_kernel" not in name:
                 continue
             m = re.search(r"(rnn_\w+_kernel)(<[^>]*>)?", name)
             key, short = m.group(1), m.group(0)
@@ -25,7 +25,7 @@ summary = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate pa
 for key, e in res.items():
     f = e["launches"].get("FETCH_SIZE", [])
     w = e["launches"].get("WRITE_SIZE", [])
-    persistent = "persistent" in key
+    persistent = "persistent" in key or "ksplit" in key          # one launch covers all T time steps
     n = max(len(f), len(w), 1)
     fetch_b = (sum(f) / max(len(f), 1)) * 1024 * 2
     write_b = (sum(w) / max(len(w), 1)) * 1024
