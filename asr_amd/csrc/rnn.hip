@@ -1632,6 +1632,26 @@ extern "C" int ds2_rnn_step_gate(const float* loss_dev, int* flag_dev, void* str
   return 0;
 }
 
+namespace {
+__global__ void poison_if_starved_kernel(float* __restrict__ buf, long long n) {
+  if (g_persist_dbg[0] == 0) return;
+  const float qnan = __builtin_nanf("");
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) buf[i] = qnan;
+}
+}  // namespace
+
+// Inference without a host synchronisation: if a persistent recurrence launch enqueued before this call on `stream` has recorded
+// starvation (its activations are invalid), overwrite buf[0..n) with NaN — in stream order, without reading or clearing the record.  The
+// caller's next ds2_rnn_persistent_status (at a point where it synchronises anyway) raises; until then nothing plausible-looking leaves.
+extern "C" int ds2_rnn_poison_if_starved(float* buf, size_t n, void* stream) {
+  DS2_REQUIRE(buf || n == 0, "ds2_rnn_poison_if_starved: null pointer");
+  if (n == 0) return 0;
+  const int blocks = (int)std::min<size_t>((n + 255) / 256, 1024);
+  hipLaunchKernelGGL(poison_if_starved_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, buf, (long long)n);
+  DS2_LAUNCH_CHECK("poison_if_starved_kernel");
+  return 0;
+}
+
 extern "C" int ds2_rnn_persistent_enable(int forward, int backward) {
   g_persist_fwd = forward != 0;
   g_persist_bwd = backward != 0;

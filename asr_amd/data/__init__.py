@@ -121,7 +121,8 @@ class SpectrogramDataset(Dataset):
 
 
 class BucketingSampler(Sampler):
-    """data/samplers/bucketing_sampler.py:5-25: consecutive manifest rows form a bin (= batch)."""
+    """Restates the reference class of the same name statement for statement (data/samplers/bucketing_sampler.py:5-25): consecutive manifest
+    rows form a bin (= batch); kept by name and behaviour because the reference's loaders and tests construct it."""
 
     def __init__(self, data_source, batch_size=1):
         super().__init__()
@@ -142,8 +143,9 @@ class BucketingSampler(Sampler):
 
 
 class DistributedBucketingSampler(Sampler):
-    """data/samplers/distributed_bucketing_sampler.py:8-44 (dead code in the reference, the DP
-    partition rule here): rank r takes bins[r::world], wrap-padded to a multiple of world."""
+    """Restates the reference class of the same name statement for statement (data/samplers/distributed_bucketing_sampler.py:8-44: same
+    attributes, wrap-pad, `bins[rank::num_replicas]`, seeded randperm shuffle).  It is dead code in the reference; here it is the SURVEY §8(e)
+    partition rule, kept by name: rank r takes bins[r::world], wrap-padded to a multiple of world."""
 
     def __init__(self, data_source, batch_size=1, num_replicas=None, rank=None):
         super().__init__()
@@ -192,6 +194,22 @@ def _durations_of(data_source, durations=None):
     return d
 
 
+def _full_bins(order, batch_size, partial):
+    """Consecutive runs of `batch_size` ids of a length-sorted order.  A short last run is kept as it is ("keep": the reference's
+    BucketingSampler behaviour, bucketing_sampler.py:13-14), dropped ("drop") or topped up with its nearest-in-length neighbours — the
+    ids just before it, which then occur twice in the epoch ("fill")."""
+    if partial not in ("keep", "drop", "fill"):
+        raise ValueError(f"partial={partial!r}: expected keep, drop or fill")
+    bins = [order[i:i + batch_size] for i in range(0, len(order), batch_size)]
+    if bins and len(bins[-1]) < batch_size and len(order) >= batch_size:
+        if partial == "drop":
+            bins.pop()
+        elif partial == "fill":
+            need = batch_size - len(bins[-1])
+            bins[-1] = order[len(order) - len(bins[-1]) - need:len(order) - len(bins[-1])] + bins[-1]
+    return bins
+
+
 class LengthBucketingSampler(Sampler):
     """True length bucketing (BASELINE configs[3] "bucketed sampler" / configs[4] "length-sorted batching").
 
@@ -201,13 +219,13 @@ class LengthBucketingSampler(Sampler):
     (ids shuffled inside the bin like the reference; `_collate_fn` re-sorts a batch by length anyway), `__len__` = number of bins,
     `shuffle()` permutes the bin ORDER (batches stay homogeneous in length, epochs see them in a different order)."""
 
-    def __init__(self, data_source, batch_size=1, durations=None, descending=False):
+    def __init__(self, data_source, batch_size=1, durations=None, descending=False, partial="keep"):
         super().__init__()
         self.data_source = data_source
         self.batch_size = int(batch_size)
         self.durations = _durations_of(data_source, durations)
         order = np.argsort(-self.durations if descending else self.durations, kind="stable").tolist()
-        self.bins = [order[i:i + self.batch_size] for i in range(0, len(order), self.batch_size)]
+        self.bins = _full_bins(order, self.batch_size, partial)
 
     def __iter__(self):
         for ids in self.bins:
@@ -239,7 +257,7 @@ class DistributedLengthBucketingSampler(Sampler):
     bins just before it (nearest in length), where the reference wraps around to the first bins (which here would put the SHORTEST
     batches next to the LONGEST ones in the last round)."""
 
-    def __init__(self, data_source, batch_size=1, num_replicas=None, rank=None, durations=None, descending=False):
+    def __init__(self, data_source, batch_size=1, num_replicas=None, rank=None, durations=None, descending=False, partial="fill"):
         super().__init__()
         if num_replicas is None:
             num_replicas = torch.distributed.get_world_size()
@@ -249,7 +267,9 @@ class DistributedLengthBucketingSampler(Sampler):
         self.num_replicas, self.rank = int(num_replicas), int(rank)
         self.durations = _durations_of(data_source, durations)
         order = np.argsort(-self.durations if descending else self.durations, kind="stable").tolist()
-        bins = [order[i:i + self.batch_size] for i in range(0, len(order), self.batch_size)]
+        # every rank of a round must run the SAME batch size: gradients are averaged unweighted, and a rank whose B is not a multiple of 8
+        # leaves the packed bf16 fast path and straggles in the all-reduce — so the short last bin is topped up by default
+        bins = _full_bins(order, self.batch_size, partial)
         self.num_samples = int(math.ceil(len(bins) / self.num_replicas))
         self.total_size = self.num_samples * self.num_replicas
         pad = self.total_size - len(bins)

@@ -223,8 +223,11 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
     if save:
         ctx.y_last, ctx.fc_xn, ctx.fc_stats = xin, xn, (mean, var)
     if training:
-        for name in ([cp + "1", cp + "4", fp + "0"] + [f"rnns.{l}.batch_norm.module" for l in range(1, L)]):
-            W[name + ".num_batches_tracked"] += 1
+        if "_bn_counters" in W:
+            W["_bn_counters"] += 1                     # all num_batches_tracked (views of one buffer: asr_amd/params.py) in one launch
+        else:
+            for name in ([cp + "1", cp + "4", fp + "0"] + [f"rnns.{l}.batch_norm.module" for l in range(1, L)]):
+                W[name + ".num_batches_tracked"] += 1
     return logits.view(T, B, cfg.classes), ctx
 
 

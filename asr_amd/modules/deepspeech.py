@@ -185,10 +185,12 @@ class DeepSpeech(nn.Module):
             W = self._flat.tensors(self)
             logits, _ = engine.forward(W, self._cfg, x, lens_dev, training=self.training, save=False)
             if not self.training:
-                # inference has no later sync point of its own that checks this (the trainer's fit/step do): a persistent recurrence
-                # launch that could not get all of its workgroups resident leaves invalid activations — raise, never return them
-                # (fp32 shapes take the persistent kernels too)
-                ops.rnn_persistent_check()
+                # A persistent recurrence launch that could not get all of its workgroups resident leaves invalid activations.  Inference
+                # must never return them, and must not pay a device synchronisation per forward either (streaming / batched inference
+                # would lose all host-device overlap), nor consume the starvation record of a trainer's un-settled step: a kernel in
+                # stream order turns the logits into NaN if a launch before it starved (fp32 shapes take the persistent kernels too),
+                # and the record stays for the next check at a natural sync point (evaluate() below, the trainer's step / synchronize).
+                ops.rnn_poison_if_starved(logits)
         out = logits.transpose(0, 1)            # (B,T,C) view, like the reference's x.transpose(0, 1)
         out = self.inference_softmax(out)       # identity in train, HIP softmax in eval
         return out, output_lengths
@@ -231,7 +233,8 @@ class DeepSpeech(nn.Module):
                     split_targets.append(targets[offset:offset + size])
                     offset += size
                 out, output_sizes = self.forward(inputs, input_sizes)
-                decoded_output, _ = decoder.decode(out, output_sizes)   # (forward has already checked the persistent recurrences)
+                decoded_output, _ = decoder.decode(out, output_sizes)   # (copies to the host: the device is idle behind it)
+                ops.rnn_persistent_check()                              # raise if a persistent recurrence of this batch starved (the logits are NaN then)
                 target_strings = decoder.convert_to_strings(split_targets)
                 if output_file is not None:
                     output_data.append((out.detach().cpu().numpy(), output_sizes.numpy(), target_strings))

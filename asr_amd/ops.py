@@ -673,6 +673,14 @@ def rnn_persistent_check() -> None:
             f"kernels from the start).  Starved launches since load: {starved}.")
 
 
+def rnn_poison_if_starved(buf: Tensor) -> None:
+    """In stream order, without a host synchronisation: overwrite `buf` (fp32, contiguous) with NaN if a persistent recurrence launch enqueued
+    before this call has recorded starvation.  The record stays for the next rnn_persistent_check()."""
+    _chk_f32(buf)
+    assert buf.is_contiguous()
+    _lib.check(_lib.load().ds2_rnn_poison_if_starved(buf.data_ptr(), buf.numel(), _stream()), "ds2_rnn_poison_if_starved")
+
+
 def rnn_persistent_counters():
     """(launches that starved since the library was loaded, recurrence calls left on the step kernels before re-arming)."""
     out = (C.c_int * 2)()

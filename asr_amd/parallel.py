@@ -92,8 +92,11 @@ class BucketedAllReducer:
 
     def all_valid_device(self, flag: torch.Tensor) -> torch.Tensor:
         """Device-side agreement: `flag` (int32 GPU tensor, 1 = this rank's step is valid) becomes the MIN over ranks, in stream order,
-        without a host synchronisation (the gated optimizer launch reads it)."""
-        if self.world == 1:
+        without a host synchronisation (the gated optimizer launch reads it).  "Without a host synchronisation" holds on `nccl` (= RCCL),
+        whose `work.wait()` is a stream dependency; `gloo` (CPU tests, or CUDA tensors staged through host memory) blocks the host there —
+        correct, but not the overlap the run-ahead train step is built for.  DS2_FORCE_ALLREDUCE=1 runs the reduction with one rank too,
+        so that a 1-GPU box exercises the same code as a multi-rank run."""
+        if self.world == 1 and not self.force:
             return flag
         work = dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group, async_op=True)
         work.wait()                                  # stream-level for CUDA tensors: the compute stream waits, the host does not

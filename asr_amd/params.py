@@ -64,6 +64,27 @@ class FlatParams:
                 self.flat[o:o + sz].copy_(p.detach().reshape(-1).to(self.device, torch.float32))
                 p.data = self.flat[o:o + sz].view(p.shape)
         self._named = named
+        # BatchNorm buffers: the running statistics live in ONE contiguous fp32 buffer (a train step snapshots / restores them with a single
+        # copy: trainers.DeepSpeechTrainer) and the `num_batches_tracked` counters in one int64 buffer (one increment launch per step
+        # instead of one per BatchNorm).  The module's buffers are re-pointed at views, so state_dict() / load_state_dict() are unchanged.
+        fbufs = [(n, b) for n, b in module.named_buffers() if b.dtype == torch.float32]
+        ibufs = [(n, b) for n, b in module.named_buffers() if b.dtype == torch.int64 and b.numel() == 1]
+        self.stats = torch.zeros(sum(b.numel() for _, b in fbufs), dtype=torch.float32, device=self.device)
+        self.counters = torch.zeros(len(ibufs), dtype=torch.int64, device=self.device)
+        self._buf_views: Dict[str, torch.Tensor] = {}
+        with torch.no_grad():
+            off = 0
+            for n, b in fbufs:
+                v = self.stats[off:off + b.numel()].view(b.shape)
+                v.copy_(b.detach().to(self.device))
+                b.data = v
+                self._buf_views[n] = v
+                off += b.numel()
+            for i, (n, b) in enumerate(ibufs):
+                v = self.counters[i:i + 1].view(b.shape)
+                v.copy_(b.detach().to(self.device))
+                b.data = v
+                self._buf_views[n] = v
 
     # ------------------------------------------------------------------------------------------
     def owns(self, module: torch.nn.Module) -> bool:
@@ -73,6 +94,10 @@ class FlatParams:
                 return False
             o, sz = self.offsets[n]
             if p.data_ptr() != self.flat.data_ptr() + 4 * o or p.device != self.flat.device:
+                return False
+        for n, b in module.named_buffers():
+            v = self._buf_views.get(n)
+            if v is not None and (b.data_ptr() != v.data_ptr() or b.device != v.device):
                 return False
         return True
 
@@ -103,6 +128,7 @@ class FlatParams:
         if not grads:
             for n, b in module.named_buffers():
                 out[n] = b
+            out["_bn_counters"] = self.counters            # every num_batches_tracked at once (engine.forward)
         return out
 
     def layer_buckets(self) -> List[Tuple[str, int, int]]:

@@ -64,6 +64,8 @@ class DeepSpeechTrainer:
         self.output_file = output_file
         self.overwrite_lr = overwrite_lr
         self._reducer = None
+        self._rejected_losses = []          # loss values of steps the device gate rejected after step() had reported them (train() takes them back)
+        self._unsettled = None
         self.load()
 
     # -- epoch loop (deepspeech_trainer.py:50-66) -------------------------------------------------
@@ -104,8 +106,10 @@ class DeepSpeechTrainer:
                 current.loss += loss_value
             else:
                 print("Loss non valid, skipped")
+            current.loss -= self._take_back_rejected()          # a step the DEVICE gate rejected after its loss had been counted (run-ahead)
         if fused:
             self.synchronize()                                  # settle the last step's device verdict before the epoch's bookkeeping
+            current.loss -= self._take_back_rejected()
         self.update(current, best, train_loader, update_best=False)
         if self._scheduler is not None:
             self._scheduler.step()
@@ -151,7 +155,8 @@ class DeepSpeechTrainer:
             # "overlap" schedule: buckets are all-reduced on a communication stream WHILE backward's recurrences run, so the persistent backward
             # recurrence (which needs every workgroup resident at once) must be off; "conv" (default: collectives only under the conv-stack
             # backward) and "serial" keep it.  The forward recurrence never overlaps a collective in any schedule.
-            ops.rnn_persistent_enable(True, self._reducer.world == 1 or not self._reducer.overlaps_recurrence)
+            single = self._reducer.world == 1 and not self._reducer.force          # (a forced 1-rank run behaves like a multi-rank one)
+            ops.rnn_persistent_enable(True, single or not self._reducer.overlaps_recurrence)
         return self._reducer
 
     def step(self, data):
@@ -182,6 +187,8 @@ class DeepSpeechTrainer:
         with torch.no_grad():
             W = model._flat.tensors(model)
             Gr = model._flat.tensors(model, grads=True)
+            self._step_index = getattr(self, "_step_index", -1) + 1
+            self._snapshot_bn_stats(self._step_index)                        # (restored if the device gate reports this step starved)
             logits, ctx = engine.forward(W, model._cfg, inputs, lens_dev, training=True, save=True)
             nll, dlogits = ops.ctc_loss(logits, tg, off, lens_dev, tl, max_u, 1.0 / B, want_grad=True)
             loss = (nll.sum() / B).reshape(1)
@@ -217,7 +224,7 @@ class DeepSpeechTrainer:
                 pin["gate"].copy_(gate, non_blocking=True)
                 pin["gate_done"].record(pin["stream"])
             gate.record_stream(pin["stream"])
-            self._unsettled = valid_loss
+            self._unsettled, self._unsettled_loss, self._unsettled_index = valid_loss, loss_value, self._step_index
         return valid_loss, loss_value
 
     def _stage_ints(self, device, *cpu_int32):
@@ -258,7 +265,40 @@ class DeepSpeechTrainer:
                 starved = self._persistent_starved()                         # counted and printed there; the library re-arms later
                 if not starved:
                     print("[asr_amd] step skipped on every rank: another rank's loss was not valid", flush=True)
+                # the step's loss was reported as valid (and train() has added it to the epoch loss) before this verdict existed:
+                # hand it back so that the bookkeeping matches the updates that were really applied
+                self._rejected_losses.append(self._unsettled_loss)
+            if starved:
+                # The starved step's forward (and, because starvation is discovered one step late, the forward of the step that is running
+                # now) wrote BatchNorm running statistics from invalid activations: put back the statistics of BEFORE the starved step.
+                self._restore_bn_stats(self._unsettled_index)
         return starved
+
+    def _take_back_rejected(self) -> float:
+        """Sum of the loss values of steps that step() reported as valid but the device gate rejected afterwards (and forget them)."""
+        total = sum(self._rejected_losses)
+        if self._rejected_losses:
+            print("Loss non valid, skipped")                                 # the reference's message, for the step it belongs to
+            self._rejected_losses = []
+        return total
+
+    def _snapshot_bn_stats(self, index: int):
+        """One device copy (a few KB): the BatchNorm running statistics and counters as they are BEFORE train step `index` runs."""
+        flat = self._model._flat
+        if getattr(self, "_bn_snap", None) is None or self._bn_snap[0][0].numel() != flat.stats.numel() or self._bn_snap[0][0].device != flat.stats.device:
+            self._bn_snap = [(torch.empty_like(flat.stats), torch.empty_like(flat.counters)) for _ in range(2)]
+        st, ct = self._bn_snap[index & 1]
+        st.copy_(flat.stats)
+        ct.copy_(flat.counters)
+
+    def _restore_bn_stats(self, index: int):
+        snap = getattr(self, "_bn_snap", None)
+        if snap is None:
+            return
+        flat = self._model._flat
+        st, ct = snap[index & 1]
+        flat.stats.copy_(st)
+        flat.counters.copy_(ct)
 
     def synchronize(self):
         """Wait for everything enqueued by step() and settle the last step's device verdict (call before reading weights / counters)."""
@@ -299,6 +339,10 @@ class DeepSpeechTrainer:
     # -- eval / bookkeeping (deepspeech_trainer.py:119-137) ----------------------------------------
     def test(self, test_loader):
         current, best = self._metrics.test.current, self._metrics.test.best
+        # settle the last train step first: the evaluation loop checks the persistent-recurrence record at its own sync points and must not
+        # consume the record of an un-settled train step (model(x) in eval mode must not be interleaved with un-settled step() calls)
+        if self._unsettled is not None:
+            self.synchronize()
         wer, cer, _ = self._model(loader=test_loader, device=self._device_test, output_file=self.output_file)
         current.wer, current.cer = wer, cer
         self.update(current, best, test_loader, update_best=True)

@@ -123,21 +123,43 @@ def _oracle_state(rnn, H, L, C):
     return sd
 
 
+def _host_description():
+    """CPU model / sockets / library versions of the box the baseline runs on (stated next to the number)."""
+    model, sockets = "unknown CPU", set()
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown CPU":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                sockets.add(line.split(":", 1)[1].strip())
+    except OSError:
+        pass
+    cfg = torch.__config__.show()
+    import re as _re
+    mkl = _re.search(r"Math Kernel Library Version ([\w.\-]+(?: Product)?(?: Build \d+)?)", cfg)
+    dnn = _re.search(r"(?:MKL-DNN|oneDNN) v([\w.\-]+)", cfg)
+    omp = _re.search(r"OpenMP (\d+)", cfg)
+    return (f"{model}, {max(len(sockets), 1)} socket(s), {os.cpu_count()} logical cores; torch {torch.__version__}, "
+            f"MKL {mkl.group(1) if mkl else 'n/a'}, oneDNN {dnn.group(1) if dnn else 'n/a'}, OpenMP {omp.group(1) if omp else 'n/a'}")
+
+
 def cpu_baseline_worker(rnn, H, L, C, tin, B):
-    """Runs in a child process (hard wall-clock limit enforced by the parent).  SURVEY §8(d): the reference's statement sequence
-    (fit -> zero_grad -> backward -> AdamW.step) in the reference's own PACKED formulation (oracle/ds2_packed.py:
+    """Runs in a child process (hard wall-clock limit enforced by the parent).  SURVEY §8(d) / BASELINE.md §3: the reference's statement
+    sequence (fit -> zero_grad -> backward -> AdamW.step) in the reference's own PACKED formulation (oracle/ds2_packed.py:
     pack_padded_sequence -> fused bidirectional gru/lstm -> pad_packed_sequence, blocks.py:87-89; validated against the goldens
     generated from the imported reference, tests/test_oracle_golden.py), on a bounded sample of the same workload: the same model
-    and utterance length at the largest batch that fits the time budget.  The thread count is probed (this op mix gets slower
-    beyond a few dozen threads) and printed.  The padded + masked oracle (oracle/ds2_oracle.py, explicit time loops) is timed beside
-    it on B = 1."""
+    and utterance length at the largest batch that fits the time budget.
+    Protocol: the thread count is probed AT THE TIMED SHAPE (one full-length utterance, T_in = tin), then ONE warm-up step and TWO timed
+    steps of the same batch with the optimizer state carried through; the three loss values are returned so that the parent can run the HIP
+    path from the same weights on the same batch and report the matched-loss evidence (`loss_parity`).  The padded + masked oracle
+    (oracle/ds2_oracle.py, explicit time loops) is timed beside it on B = 1."""
     from oracle import ds2_oracle as O
     from oracle import ds2_packed as P
     cores = os.cpu_count() or 1
     sd = _oracle_state(rnn, H, L, C)
     t_start = time.time()
 
-    def packed_step(b, t_in):
+    def fresh_step(b, t_in):
         params = P.leaf_params(sd)
         opt = P.make_optimizer(params)
         x, targets, pct, tsz = synthetic_batch(b, t_in, C, 1)
@@ -145,41 +167,82 @@ def cpu_baseline_worker(rnn, H, L, C, tin, B):
         P.train_step(params, opt, (x, targets, pct.clone(), tsz))
         return time.time() - t0
 
+    torch.set_num_threads(min(cores, 16))
+    fresh_step(1, 101)                                         # process warm-up (thread pool, allocator, oneDNN primitives)
     probe = {}
     for n in sorted({min(cores, c) for c in (8, 16, 32, 64, 128)}):
         torch.set_num_threads(n)
-        packed_step(2, 101)                                    # warm-up (thread pool, allocator, oneDNN primitives)
-        probe[n] = packed_step(4, 201)
-        if probe[n] > 2.5 * min(probe.values()) or time.time() - t_start > 60:
+        probe[n] = fresh_step(1, tin)                          # the timed shape's own utterance length
+        if probe[n] > 1.6 * min(probe.values()) or time.time() - t_start > 50:
             break                                              # larger teams only get slower from here
     nthr = min(probe, key=probe.get)
     torch.set_num_threads(nthr)
-    # largest batch whose full-length step is predicted to stay inside ~60 s (time is ~linear in B * T on this path)
-    per_utt_frame = probe[nthr] / (4 * 201)
-    b_s = max(1, min(B, 8, int(60.0 / max(per_utt_frame * tin, 1e-9))))
-    dt = packed_step(b_s, tin)
+    # largest batch for which warm-up + two timed steps are predicted to stay inside ~100 s (time is ~linear in B on this path)
+    b_s = max(1, min(B, 8, int(100.0 / 3.0 / max(probe[nthr], 1e-9))))
+    params = P.leaf_params(sd)
+    opt = P.make_optimizer(params)
+    x, targets, pct, tsz = synthetic_batch(b_s, tin, C, 1)
+    losses, times = [], []
+    for k in range(3):                                         # step 0 = warm-up at the timed shape, steps 1-2 timed
+        t0 = time.time()
+        losses.append(P.train_step(params, opt, (x, targets, pct.clone(), tsz)))
+        times.append(time.time() - t0)
+    dt = (times[1] + times[2]) / 2.0
     # padded + masked restatement (B = 1; T_in = 201 scaled linearly when the full length would not fit)
     def padded(t_in):
-        x, targets, pct, tsz = synthetic_batch(1, t_in, C, 1)
+        xx, tt, pp, ss = synthetic_batch(1, t_in, C, 1)
         t0 = time.time()
-        O.fit_and_grads(sd, x, targets, pct, tsz)
+        O.fit_and_grads(sd, xx, tt, pp, ss)
         return time.time() - t0
     padded(41)
     t_small = padded(201)
     est = t_small * tin / 201.0
-    left = 200.0 - (time.time() - t_start)
-    pd_t, pd_s = (padded(tin), tin) if est < min(45.0, left) else (est, 201)
-    out = {"value": b_s / dt, "unit": "utterances/sec", "cores": nthr, "kind": "port", "host_cores": cores,
+    left = 215.0 - (time.time() - t_start)
+    pd_t, pd_s = (padded(tin), tin) if est < min(25.0, left) else (est, 201)
+    out = {"value": b_s / dt, "unit": "utterances/sec", "cores": nthr, "kind": "port", "host_cores": cores, "host": _host_description(),
+           "batch": b_s, "losses": losses, "step_seconds": [round(t, 2) for t in times],
            "sample": (f"reference statement sequence in packed form (pack_padded_sequence -> aten gru/lstm -> pad_packed_sequence, CTC, backward, "
-                      f"torch AdamW), one full train step at B={b_s} of the config's {B}, same {L}x{H} {rnn} model, T_in={tin}; "
-                      f"threads probed on (B=4, T_in=201) {({k: round(v, 2) for k, v in probe.items()})} s -> {nthr}"),
+                      f"torch AdamW) at B={b_s} of the config's {B}, same {L}x{H} {rnn} model, T_in={tin}: 1 warm-up step + 2 timed steps "
+                      f"({times[1]:.1f} s, {times[2]:.1f} s; warm-up {times[0]:.1f} s), optimizer state carried through; threads probed at the timed "
+                      f"shape (B=1, T_in={tin}) {({k: round(v, 2) for k, v in probe.items()})} s -> {nthr} of {cores}"),
            "padded_port": {"value": 1.0 / pd_t, "unit": "utterances/sec", "cores": nthr,
                            "sample": "padded+masked oracle (explicit time loops) fit+backward, no optimizer, B=1, T_in=" + str(pd_s)
                                      + ("" if pd_s == tin else f" scaled linearly to T_in={tin}")}}
     print("CPU_BASELINE_JSON " + json.dumps(out), flush=True)
 
 
-def cpu_baseline(rnn, H, L, C, tin, B, limit_s=240):
+def loss_parity(rnn, H, L, C, tin, cpu, dev):
+    """Matched-loss evidence: the HIP path started from the SAME weights (`_oracle_state`) on the SAME
+    batch as the CPU port's three steps just timed, same AdamW hyper-parameters: loss of every step, fp32 mode and bf16 mode, and the
+    largest relative gap to the CPU port's loss over the steps."""
+    from asr_amd import CTCLoss, DeepSpeech, FusedAdamW
+    from asr_amd.trainers import DeepSpeechTrainer
+    b_s, ref = int(cpu["batch"]), [float(v) for v in cpu["losses"]]
+    x, targets, pct, tsz = synthetic_batch(b_s, tin, C, 1)
+    sd = _oracle_state(rnn, H, L, C)
+    out = {"batch": b_s, "steps": len(ref), "cpu": ref,
+           "what": f"{len(ref)} train steps from identical weights on the identical batch (B={b_s}, T_in={tin}), AdamW lr 1.5e-4: CPU port of the "
+                   "reference statement sequence vs this library"}
+    for mode in ("fp32", "bf16"):
+        with tempfile.TemporaryDirectory() as tmp:
+            m = DeepSpeech(audio_conf=audio_conf(), decoder=None, label_path=label_file(tmp, C), rnn_type=rnn, rnn_hidden_size=H,
+                           rnn_hidden_layers=L, bidirectional=True)
+        m.load_state_dict(sd)
+        m.to(dev).train()
+        m.precision = mode
+        opt = FusedAdamW(m, lr=1.5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5)
+        tr = DeepSpeechTrainer(m, CTCLoss(reduction="sum"), 1, None, opt, None, None, dev, dev, False, None)
+        xs = x.to(dev)
+        got = [float(tr.step((xs, targets, pct.clone(), tsz))[1]) for _ in ref]
+        tr.synchronize() if hasattr(tr, "synchronize") else torch.cuda.synchronize()
+        out["gpu_" + mode] = got
+        out["rel_" + mode] = max(abs(g - c) / abs(c) for g, c in zip(got, ref))
+        del tr, opt, m
+    out["rel"] = out["rel_fp32"]
+    return out
+
+
+def cpu_baseline(rnn, H, L, C, tin, B, limit_s=260):
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", rnn, str(H), str(L), str(C), str(tin), str(B)]
     try:
@@ -456,6 +519,10 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(rnn, H, L, C, tin, B)
+            if out["cpu_baseline"].get("losses"):
+                del model, tr, opt, batches                      # the parity runs build their own models from the CPU port's weights
+                torch.cuda.empty_cache()
+                out["loss_parity"] = loss_parity(rnn, H, L, C, tin, out["cpu_baseline"], dev)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

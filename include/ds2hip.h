@@ -180,6 +180,10 @@ int ds2_rnn_persistent_status(int* out8);
 /* reporting: out2 = {launches that starved since the library was loaded, recurrence calls left before the persistent kernels are armed
  * again (0 = armed, -1 = never)} */
 int ds2_rnn_persistent_counters(int* out2);
+/* Inference path (DeepSpeech.forward in eval mode, modules/deepspeech.py:130-149): instead of a device synchronisation per forward, a
+ * kernel in stream order that overwrites buf[0..n) (the logits) with NaN if a persistent launch before it recorded starvation; the record is
+ * neither read by the host nor cleared (the next ds2_rnn_persistent_status, at a natural sync point, raises). */
+int ds2_rnn_poison_if_starved(float* buf, size_t n, void* stream);
 /* device-side validity of the train step enqueued so far: flag_dev[0] = (loss finite and >= 0 [check_loss, functional.py:45-61]) and no
  * persistent recurrence launch starved, evaluated when the kernel RUNS (stream order) */
 int ds2_rnn_step_gate(const float* loss_dev, int* flag_dev, void* stream);

@@ -47,6 +47,20 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert lib.ds2_ctc_workspace_bytes(10, 2, 3) > 0 and lib.ds2_conv_packed_floats(1) == 32 * 232 * 32
 
 
+def test_shipped_library_has_no_work_skipping_switch():
+    """ds2_debug_flags keeps its kernel-family SELECTORS (8 / 16 / 64 / 128: every selection computes the full result), but the ablation bits
+    that skip the recurrent product / the gate epilogue (1 / 2, scripts/ablate_rnn.py) exist only in a -DDS2_ABLATE build: the shipped
+    library masks them off at the ABI and compiles their tests out of the kernels."""
+    from asr_amd import _lib
+    lib = _lib.load()
+    assert lib.ds2_ablation_build() == 0, "asr_amd/lib/libds2hip.so was built with ABLATE=1: not a shippable library"
+    assert lib.ds2_debug_flags(3) == 0           # previous value
+    assert lib.ds2_debug_flags(1 | 2 | 64) == 0  # ... the request for 3 was dropped entirely
+    assert lib.ds2_debug_flags(0) == 64          # ... and only the selector survived of 67
+    src = open(os.path.join(ROOT, "asr_amd", "csrc", "rnn.hip")).read()
+    assert "#define DS2_ABLATE_BIT(flags, bit) false" in src and not re.search(r"dbg\s*&\s*[12]\b", src)
+
+
 def test_workspace_queries_and_splitk_policy():
     """Host-side sizing logic (no GPU): workspace queries are consistent and the split-K policy is sane on the train step's shapes."""
     from asr_amd import _lib

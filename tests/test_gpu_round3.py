@@ -1,0 +1,241 @@
+"""-m gpu, round 3: the RCCL path of the data-parallel reducer with one rank (the driver's box has one GPU), the k-step bf16-vs-fp32 loss
+curve at the metric configuration's size, and the bookkeeping around a starved persistent launch (BatchNorm statistics restored, epoch loss
+taken back, inference returns NaN instead of synchronising)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+RCCL_WORKER = r'''
+import os, sys, json, hashlib
+import numpy as np, torch, torch.distributed as dist
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests")); sys.path.insert(0, os.path.join(root, "tests", "golden"))
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))        # RCCL, one rank
+import bench
+from test_gpu_model import make_model
+from asr_amd import CTCLoss, FusedAdamW, engine, ops
+from asr_amd.trainers import DeepSpeechTrainer
+mode = os.environ["DS2_DP_MODE"]
+B, tin, C = 64, 201, 29
+torch.manual_seed(0)
+model = make_model(dict(rnn="gru", hidden=1024, layers=2, classes=C))                          # c3's layer shape (256 persistent workgroups)
+model.precision = "bf16"
+opt = FusedAdamW(model, lr=1.5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5)
+dev = torch.device("cuda", 0)
+tr = DeepSpeechTrainer(model, CTCLoss(reduction="sum"), 1, None, opt, None, None, dev, dev, False, None)
+x, targets, pct, tsz = bench.synthetic_batch(B, tin, C, 1)
+x = x.cuda()
+# what runs where: collectives (wrapped) record the stream they were issued on and an event pair; the conv-stack backward an event pair
+log = {"collectives": [], "order": []}
+orig_ar = dist.all_reduce
+def ar(t, *a, **k):
+    s = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(s)
+    w = orig_ar(t, *a, **k)
+    e1.record(s)
+    log["collectives"].append((int(t.numel()), s.cuda_stream, e0, e1))
+    log["order"].append("allreduce:%d" % t.numel())
+    return w
+dist.all_reduce = ar
+conv_ev = []
+orig_c2, orig_c1 = ops.conv2_wgrad_bf16, ops.conv1_wgrad_bf16
+def c2(*a, **k):
+    e = torch.cuda.Event(enable_timing=True); e.record(); conv_ev.append(e); log["order"].append("conv2_wgrad")
+    return orig_c2(*a, **k)
+def c1(*a, **k):
+    r = orig_c1(*a, **k)
+    e = torch.cuda.Event(enable_timing=True); e.record(); conv_ev.append(e); log["order"].append("conv1_wgrad")
+    return r
+ops.conv2_wgrad_bf16, ops.conv1_wgrad_bf16 = c2, c1
+losses, paths = [], []
+for it in range(3):
+    log["collectives"].clear(); log["order"].clear(); conv_ev.clear()
+    valid, lv = tr.step((x, targets, pct.clone(), tsz))
+    paths.append(ops.rnn_last_path())
+    losses.append(lv)
+    assert valid
+tr.synchronize()
+red = tr._get_reducer()
+assert red.world == 1 and red.force and red.mode == mode
+main = torch.cuda.current_stream().cuda_stream
+big = max(log["collectives"], key=lambda c: c[0])
+flat, _ = model.flat_parameters()
+out = {"mode": mode, "losses": losses, "weights_sha": hashlib.sha256(flat.detach().cpu().numpy().tobytes()).hexdigest(),
+       "weights_sample": flat.detach().cpu().numpy()[::9973].tolist(),
+       "starved": DeepSpeechTrainer.starved_steps, "last_path": paths[-1], "order": list(log["order"]),
+       "n_collectives": len(log["collectives"]), "big_elems": big[0], "big_on_comm_stream": big[1] != main,
+       "gate_reduced": any(c[0] == 1 for c in log["collectives"]),
+       # time from the start of the conv-stack backward to the end of the big collective, and to the end of the conv-stack backward (ms)
+       "conv_start_to_big_start": conv_ev[0].elapsed_time(big[2]), "conv_start_to_conv_end": conv_ev[0].elapsed_time(conv_ev[-1])}
+print("RCCL_JSON " + json.dumps(out))
+dist.destroy_process_group()
+'''
+
+
+def _run_rccl(mode, tmp_path, port):
+    script = str(tmp_path / f"rccl_{mode}.py")
+    open(script, "w").write(RCCL_WORKER)
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DS2_FORCE_ALLREDUCE="1", DS2_DP_MODE=mode,
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, script, ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RCCL_JSON ")][-1]
+    return json.loads(line[len("RCCL_JSON "):])
+
+
+def test_rccl_single_rank_all_schedules(tmp_path):
+    """The `nccl` (= RCCL) branch of asr_amd/parallel.py, run by the driver's 1-GPU box: one rank, DS2_FORCE_ALLREDUCE=1, trainer.step at c3's
+    layer width (2 x 1024 BiGRU, B = 64: 256-workgroup persistent recurrences) under the three schedules.
+      * conv (default) and serial keep both persistent recurrences: identical losses and bit-identical weights after three steps;
+        overlap switches the persistent BACKWARD recurrence off (other kernel family: same loss at step 0, weights within tolerance);
+      * no launch starved; the validity flag goes through the MIN all-reduce with one rank too;
+      * conv: the fc + RNN buckets travel as ONE collective, issued on the communication stream when the last recurrent layer is done —
+        in front of the conv-stack backward in issue order, so that it runs beside it — and the compute stream joins only at the end."""
+    res = {m: _run_rccl(m, tmp_path, 29611 + i) for i, m in enumerate(("conv", "serial", "overlap"))}
+    for m, r in res.items():
+        assert r["starved"] == 0 and r["gate_reduced"], (m, r)
+        assert all(np.isfinite(r["losses"])), (m, r["losses"])
+    assert res["conv"]["losses"] == res["serial"]["losses"] and res["conv"]["weights_sha"] == res["serial"]["weights_sha"]
+    assert res["conv"]["last_path"] & 3 == 3 and res["serial"]["last_path"] & 3 == 3          # both recurrences persistent
+    assert res["overlap"]["last_path"] & 2 == 0                                               # backward on the step kernels
+    assert res["overlap"]["losses"][0] == res["conv"]["losses"][0]
+    wa, wb = np.asarray(res["overlap"]["weights_sample"]), np.asarray(res["conv"]["weights_sample"])
+    assert np.allclose(wa, wb, rtol=0, atol=3 * 3 * 1.5e-4 + 1e-6)           # three AdamW steps move a weight by at most ~3 lr each way
+    c = res["conv"]
+    assert c["big_on_comm_stream"] and c["n_collectives"] == 3               # fc+rnns bucket, conv bucket, validity flag
+    order = c["order"]
+    assert order.index("allreduce:%d" % c["big_elems"]) < order.index("conv2_wgrad") < order.index("conv1_wgrad"), order
+    # the big collective starts no later than the conv-stack backward ends (it was released before it in issue order)
+    assert c["conv_start_to_big_start"] <= c["conv_start_to_conv_end"], c
+    s = res["serial"]
+    assert not s["big_on_comm_stream"] and s["n_collectives"] == 2 + 2 + 1   # fc, rnns.1, rnns.0, conv, flag — all on the compute stream
+
+
+def test_kstep_loss_curve_bf16_vs_fp32_at_the_metric_config():
+    """SURVEY §8(d) "after k identical steps": ten fused train steps from identical weights on the identical batch at the metric
+    configuration's own size (5 x 1024 BiGRU, B = 64, 10 s), once in the fp32 parity mode and once in the bf16 mode the headline number is
+    measured in.  The bound that holds, and why: at step 0 (same weights) the losses agree to 3e-6; over the first four steps the gap stays
+    within north_star's 1e-3; afterwards the two TRAJECTORIES separate slowly — this is training from random initialisation on one batch,
+    the loss falls by 20-30 % per step (1307 -> 115 in ten steps) and AdamW's first updates move every weight by ~lr whatever the gradient's
+    size, so the few small-gradient elements whose sign differs in bf16 become O(lr) weight differences.  Asserted: gap <= 1e-3 for steps
+    0-3, <= 6e-3 for steps 4-9 (observed <= 3.2e-3), and never more than 5 % of that step's own loss decrease (observed <= 2.6 %).  The curve
+    goes to gpurun_out/ (committed as profiles/r03_kstep_loss_curve_c3.txt)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from test_gpu_model import make_model
+    from asr_amd import CTCLoss, FusedAdamW
+    from asr_amd.trainers import DeepSpeechTrainer
+    rnn, H, L, C, B, tin = bench.WORKLOADS["c3"]
+    x, targets, pct, tsz = bench.synthetic_batch(B, tin, C, 1)
+    x = x.cuda()
+    dev = torch.device("cuda:0")
+    curves = {}
+    for prec in ("fp32", "bf16"):
+        torch.manual_seed(0)
+        model = make_model(dict(rnn=rnn, hidden=H, layers=L, classes=C))
+        model.precision = prec
+        opt = FusedAdamW(model, lr=1.5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5)
+        tr = DeepSpeechTrainer(model, CTCLoss(reduction="sum"), 1, None, opt, None, None, dev, dev, False, None)
+        curves[prec] = [float(tr.step((x, targets, pct.clone(), tsz))[1]) for _ in range(10)]
+        tr.synchronize()
+        del tr, opt, model
+        torch.cuda.empty_cache()
+    rel = [abs(a - b) / abs(b) for a, b in zip(curves["bf16"], curves["fp32"])]
+    lines = ["step  loss_fp32      loss_bf16      |d|/loss"] + [f"{k:4d}  {b:12.6f}  {a:12.6f}  {r:.3e}" for k, (a, b, r) in
+                                                                enumerate(zip(curves["bf16"], curves["fp32"], rel))]
+    text = "\n".join([f"10 fused train steps, {L}x{H} bi-{rnn}, B={B}, T_in={tin}, AdamW lr 1.5e-4, identical init and batch"] + lines)
+    print(text)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    open(os.path.join(ROOT, "gpurun_out", "kstep_loss_curve_c3.txt"), "w").write(text + "\n")
+    assert curves["fp32"][-1] < curves["fp32"][0]                                # it trains
+    assert max(rel[:4]) <= 1e-3 and max(rel) <= 6e-3, rel
+    for k in range(1, 10):
+        assert abs(curves["bf16"][k] - curves["fp32"][k]) <= 0.05 * abs(curves["fp32"][k] - curves["fp32"][k - 1]), (k, curves)
+
+
+STARVE_STEP_WORKER = r'''
+import os, sys, json
+import numpy as np, torch
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests")); sys.path.insert(0, os.path.join(root, "tests", "golden"))
+import bench
+from test_gpu_model import make_model
+from asr_amd import CTCLoss, FusedAdamW, ops, _lib
+from asr_amd.trainers import DeepSpeechTrainer
+B, tin, C = 16, 101, 29
+torch.manual_seed(0)
+model = make_model(dict(rnn="gru", hidden=256, layers=2, classes=C))
+model.precision = "bf16"
+opt = FusedAdamW(model, lr=1.5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5)
+dev = torch.device("cuda", 0)
+tr = DeepSpeechTrainer(model, CTCLoss(reduction="sum"), 1, None, opt, None, None, dev, dev, False, None)
+x, targets, pct, tsz = bench.synthetic_batch(B, tin, C, 1)
+x = x.cuda()
+model._ensure_flat(dev)
+tr._get_reducer()                                         # (creates the reducer: it arms both persistent kernels)
+ops.rnn_persistent_enable(False, True)                    # forward on the step kernels (a valid loss), backward persistent: that one starves
+flat, _ = model.flat_parameters()
+w0 = flat.detach().clone()
+st0, ct0 = model._flat.stats.detach().clone(), model._flat.counters.detach().clone()
+# DS2_RNN_SPIN_LIMIT=0: the persistent launches of step 0 give up at their first failed poll -> the device gate rejects the step
+v0, l0 = tr.step((x, targets, pct.clone(), tsz))
+v1, l1 = tr.step((x, targets, pct.clone(), tsz))          # discovers the starvation of step 0 (settle), is itself not trusted
+tr.synchronize()
+taken_back = tr._take_back_rejected()
+res = {"v0": bool(v0), "v1": bool(v1), "weights_unchanged": bool(torch.equal(flat, w0)), "stats_restored": bool(torch.equal(model._flat.stats, st0)),
+       "counters_restored": bool(torch.equal(model._flat.counters, ct0)), "taken_back": taken_back, "l0": l0, "starved_steps": DeepSpeechTrainer.starved_steps,
+       "opt_steps": int(opt.state["step"])}
+# the library now runs the one-launch-per-step kernels for DS2_RNN_REARM_CALLS calls: a normal step goes through and updates everything
+v2, l2 = tr.step((x, targets, pct.clone(), tsz))
+tr.synchronize()
+res.update({"v2": bool(v2), "weights_moved": bool(not torch.equal(flat, w0)), "stats_moved": bool(not torch.equal(model._flat.stats, st0)),
+            "counters_after": model._flat.counters.tolist(), "rejected_after": tr._take_back_rejected()})
+# inference while the persistent kernels are armed again and starve: NaN logits without a host sync, then the check raises
+ops.rnn_persistent_enable(True, True)
+model.eval()
+lib = _lib.load()
+while ops.rnn_persistent_counters()[1] > 0:                 # burn the cooldown on the step kernels
+    with torch.no_grad():
+        out, _ = model.forward(x, (pct * x.size(3)).int())
+    res["eval_finite_on_step_kernels"] = bool(torch.isfinite(out).all())
+with torch.no_grad():
+    out, _ = model.forward(x, (pct * x.size(3)).int())      # persistent again, starves (spin limit 0)
+res["eval_path_persistent"] = bool(ops.rnn_last_path() & 1)
+res["eval_nan"] = bool(torch.isnan(out).all())
+try:
+    ops.rnn_persistent_check()
+    res["eval_check_raised"] = False
+except _lib.DS2LibraryError:
+    res["eval_check_raised"] = True
+print("STARVE_JSON " + json.dumps(res))
+'''
+
+
+def test_starved_step_bookkeeping_and_inference_poison(tmp_path):
+    """a train step whose persistent recurrence starved (forced: DS2_RNN_SPIN_LIMIT=0) is rejected by the device gate one step
+    late.  The weights stay untouched, the BatchNorm running statistics and counters written by the two un-trusted forwards are put back,
+    the loss that step() had already reported as valid is handed back to train()'s bookkeeping; after the cooldown on the step kernels a
+    normal step updates everything.  Inference never synchronises the device per forward: a starved launch turns the logits into NaN in
+    stream order and the next check raises."""
+    script = str(tmp_path / "starve_step.py")
+    open(script, "w").write(STARVE_STEP_WORKER)
+    env = dict(os.environ, DS2_RNN_SPIN_LIMIT="0", DS2_RNN_REARM_CALLS="8")
+    r = subprocess.run([sys.executable, script, ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("STARVE_JSON ")][-1][len("STARVE_JSON "):])
+    assert res["v0"] and not res["v1"], res                     # step 0 looked valid when it returned; step 1 was not trusted
+    assert res["weights_unchanged"] and res["stats_restored"] and res["counters_restored"], res
+    assert res["starved_steps"] >= 1 and abs(res["taken_back"] - res["l0"]) < 1e-6 * abs(res["l0"]) and res["opt_steps"] == 0, res
+    assert res["v2"] and res["weights_moved"] and res["stats_moved"] and res["rejected_after"] == 0.0, res
+    assert set(res["counters_after"]) == {1}, res               # exactly one accepted training forward
+    assert res.get("eval_finite_on_step_kernels", True) and res["eval_path_persistent"] and res["eval_nan"] and res["eval_check_raised"], res
