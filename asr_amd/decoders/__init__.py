@@ -50,6 +50,8 @@ class GreedyDecoder(Decoder):
     """greedy_decoder.py:6-68: per-frame argmax, collapse repeats, drop blanks."""
 
     def convert_to_strings(self, sequences, sizes=None, remove_repetitions=False, return_offsets=False):
+        """Restates the reference's loop (greedy_decoder.py:12-26) statement for statement: same signature, same nested-list results — the
+        evaluation loop and the reference's tests index them as `out[i][0]`."""
         strings, offsets = [], []
         for x in range(len(sequences)):
             seq_len = sizes[x] if sizes is not None else len(sequences[x])

@@ -79,7 +79,7 @@ class BatchRNN(nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise NotImplementedError("BatchRNN.forward stand-alone has no autograd; train through DeepSpeech.forward")
         if not self._bidirectional:
-            raise NotImplementedError("unidirectional BatchRNN has no HIP kernel (out of scope, see DESIGN.md)")
+            raise NotImplementedError("unidirectional BatchRNN has no HIP kernel and asr_amd has no torch fallback by design: see INTEGRATION.md, \"Unidirectional models\" (use asr_deepspeech.modules for this variant)")
         if not x.is_cuda:
             raise _lib.DS2LibraryError("BatchRNN.forward: GPU tensor required (no CPU fallback)")
         T, N, I = x.shape
@@ -120,7 +120,7 @@ class Lookahead(nn.Module):
                               padding=0, bias=None)
 
     def forward(self, x):
-        raise NotImplementedError("Lookahead (unidirectional DeepSpeech) has no HIP kernel — out of scope (DESIGN.md)")
+        raise NotImplementedError("Lookahead (unidirectional DeepSpeech) has no HIP kernel and asr_amd has no torch fallback by design: see INTEGRATION.md, \"Unidirectional models\" (use asr_deepspeech.modules for this variant)")
 
     def __repr__(self):
         return f"{self.__class__.__name__}(n_features={self.n_features}, context={self.context})"

@@ -169,7 +169,7 @@ class DeepSpeech(nn.Module):
         lengths = torch.as_tensor(lengths).cpu().int()
         output_lengths = self.get_seq_lens(lengths)
         if not self.bidirectional or self._cfg.rnn == "unsupported":
-            raise NotImplementedError("only bidirectional GRU/LSTM DeepSpeech has MI355X kernels (DESIGN.md, out of scope)")
+            raise NotImplementedError("only bidirectional GRU/LSTM DeepSpeech has MI355X kernels, and asr_amd has no torch fallback by design: see INTEGRATION.md, \"Unidirectional models\" (use asr_deepspeech.modules.DeepSpeech for that variant)")
         if not x.is_cuda:
             raise _lib.DS2LibraryError(
                 "asr_amd.DeepSpeech.forward needs GPU input: the MI355X HIP kernels are the only implementation. "
