@@ -611,34 +611,33 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
     const int wsub = wave >> 2, ju = j0 + (wsub % NS) * 16 + (lane >> 2) * EPL;   // first unit of this lane's group
     pub_off = dirbase + ((((long long)(bt * MB + wsub / NS) * nch + ju / KC) * 64) + ((ju % KC) / EPL) * 16 + (wave & 3) * 4 + (lane & 3)) * 16;
   }
-  auto gx_row = [&](int t) { return a.gx + (((long long)t * B + b) * 2 + dir) * G * H + j; };
+  // element offsets of this thread's pair at the step being processed, stepped by a wave-uniform stride per time step (one 64-bit add each
+  // instead of a fresh index computation with its multiply chain: the loop's VALU instructions are on the step's critical path)
+  const int t0 = dir == 0 ? 0 : T - 1;
+  const long long dH = (dir == 0 ? 1LL : -1LL) * B * 2 * H, dG = dH * G;
+  long long eH = (((long long)t0 * B + b) * 2 + dir) * H + j, eG = (((long long)t0 * B + b) * 2 + dir) * G * H + j;
   float pgx[G], pgx_next[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) { pgx[g] = 0.f; pgx_next[g] = 0.f; }
   if (pact) {
-    const float* p0 = gx_row(dir == 0 ? 0 : T - 1);
 #pragma unroll
-    for (int g = 0; g < G; ++g) pgx[g] = ldnt(p0 + g * H);
+    for (int g = 0; g < G; ++g) pgx[g] = ldnt(a.gx + eG + g * H);
   }
 
-  // saved-for-backward outputs of one time step (written one step late, see the loop)
-  int so_t = 0;
-  float so_g[4] = {0.f, 0.f, 0.f, 0.f}, so_aux = 0.f, so_h = 0.f;
-  bool so_live = false;
-  auto store_outputs = [&](int t, const float (&og)[4], float oaux, float oh, bool live) {
+  // saved-for-backward outputs of one time step
+  auto store_outputs = [&](long long fH, long long fG, const float (&og)[4], float oaux, float oh, bool live) {
     if (!pact) return;
-    const long long rowH = (((long long)t * B + b) * 2 + dir) * H + j;
     if (a.gates_bf) {
-      __builtin_nontemporal_store(bf16x4_{(__bf16)og[0], (__bf16)og[1], (__bf16)og[2], (__bf16)og[3]}, reinterpret_cast<bf16x4_*>(a.gates_bf) + rowH);
-      if (G == 4) a.aux[rowH] = oaux;
+      __builtin_nontemporal_store(bf16x4_{(__bf16)og[0], (__bf16)og[1], (__bf16)og[2], (__bf16)og[3]}, reinterpret_cast<bf16x4_*>(a.gates_bf) + fH);
+      if (G == 4) a.aux[fH] = oaux;
     } else {
-      float* gx = const_cast<float*>(gx_row(t));
+      float* gx = a.gx + fG;
       stnt(&gx[0], og[0]); stnt(&gx[H], og[1]); stnt(&gx[2 * H], og[2]);
-      if (G == 4) { stnt(&gx[3 * H], og[3]); a.aux[rowH] = oaux; }
-      else stnt(a.aux + rowH, live ? oaux : 0.f);
+      if (G == 4) { stnt(&gx[3 * H], og[3]); a.aux[fH] = oaux; }
+      else stnt(a.aux + fH, live ? oaux : 0.f);
     }
-    a.hbuf[rowH] = oh;
-    if (a.h_bf) __builtin_nontemporal_store((__bf16)oh, a.h_bf + rowH);
+    a.hbuf[fH] = oh;
+    if (a.h_bf) __builtin_nontemporal_store((__bf16)oh, a.h_bf + fH);
   };
 
   // this wave's chunks of the packed exchange buffer (byte offsets from the buffer's direction base) and the all-pending mask
@@ -718,17 +717,13 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
 #pragma unroll
       for (int g = 0; g < G; ++g) pgx[g] = pgx_next[g];  // x-projections of THIS step: loaded one step ago, landed
     }
-    // ---- HBM traffic of the step, issued HERE: the vector-memory counter retires in order, so whatever is outstanding when the next poll
-    // pass is issued delays it by its full latency.  Right behind the gather these loads and stores have the whole MFMA / reduce / gate-math
-    // phase to retire in (issued behind the publish, as the first version did, every step paid an HBM round trip in front of its gather):
-    //   * the saved-for-backward outputs of the PREVIOUS step (kept in registers for one step),
-    //   * the x-projections of the NEXT step.
+    // ---- the x-projections of the NEXT step are requested HERE: the vector-memory counter retires in order, so whatever is outstanding when the
+    // next poll pass is issued delays it by its full latency; right behind the gather these loads have the whole step to land.  (The step's own
+    // results go out at its end, behind the publish: nothing of the next step depends on them.)
     const bool more = s + 1 < T;
-    if (s > 0) store_outputs(so_t, so_g, so_aux, so_h, so_live);
     if (more && pact) {
-      const float* pn = gx_row(dir == 0 ? s + 1 : T - 2 - s);
 #pragma unroll
-      for (int g = 0; g < G; ++g) pgx_next[g] = ldnt(pn + g * H);
+      for (int g = 0; g < G; ++g) pgx_next[g] = ldnt(a.gx + eG + dG + g * H);
     }
 #pragma unroll
     for (int i = 0; i < MB; ++i)
@@ -784,12 +779,10 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
       store16_x(xbuf + (long long)((s + 2) & 3) * bufbytes + pub_off, u32x4_{PSENT, PSENT, PSENT, PSENT}, l2_local);
     }
     PTRACE(5);                                          // publish issued
-    // the step's saved-for-backward outputs wait in registers for the next step's early HBM section
-    so_t = t; so_aux = out_aux; so_h = hnew; so_live = live;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) so_g[g] = out_g[g];
+    // ---- the step's saved-for-backward outputs: last, in the shadow of the exchange
+    store_outputs(eH, eG, out_g, out_aux, hnew, live);
+    eH += dH; eG += dG;
   }
-  store_outputs(so_t, so_g, so_aux, so_h, so_live);      // the last step's outputs
   PTRACE_DUMP(0);
 }
 

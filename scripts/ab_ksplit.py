@@ -63,23 +63,35 @@ def check(kind, H, B, T, oracle=True):
 def timeit(name, G, H, B, T=501):
     gx, whh, bhh, lens, dy = setup(G, H, B, T, ragged=False)
     wpf, wpb = ops.rnn_pack(G, whh, bf16=True)
-    fw = ops.rnn_fwd(G, gx, wpf, bhh, lens, T, B, H, bf16=True, packed_gates=True)
+    fbest = 1e9
+    for _ in range(4):
+        h_bf = torch.empty(T * B, 2 * H, dtype=torch.bfloat16, device=dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        g2 = gx.clone()
+        torch.cuda.synchronize(); e0.record()
+        fw = ops.rnn_fwd(G, g2, wpf, bhh, lens, T, B, H, bf16=True, packed_gates=True, h_bf16=h_bf)
+        e1.record(); torch.cuda.synchronize()
+        fbest = min(fbest, e0.elapsed_time(e1) * 1e3 / T)
+    fpath = lib.ds2_rnn_last_path() & 1
     out = []
     for flags in (0, 128):
         best = 1e9
         for _ in range(4):
             lib.ds2_debug_flags(flags)
             side = torch.empty(T * B, 2 * G * H, dtype=torch.bfloat16, device=dev)
+            dhn = torch.empty(T * B, 2 * H, dtype=torch.bfloat16, device=dev) if G == 3 else None
+            bp = torch.empty(B, 2, 4, H, device=dev)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize(); e0.record()
-            ops.rnn_bwd(G, dy, None, fw[1], fw[0], wpb, lens, T, B, H, bf16=True, dgx_bf16=side, gates_bf16=fw[2])
+            ops.rnn_bwd(G, dy, None, fw[1], fw[0], wpb, lens, T, B, H, bf16=True, dgx_bf16=side, gates_bf16=fw[2], dhn_bf16=dhn, bias_part=bp)
             e1.record(); torch.cuda.synchronize()
             path = lib.ds2_rnn_last_path()
             lib.ds2_debug_flags(0)
             best = min(best, e0.elapsed_time(e1) * 1e3 / T)
         ops.rnn_persistent_check()
         out.append(f"{'k-split' if flags == 0 else 'all-gather'} (path {path}) {best:5.2f}")
-    print(f"{name}: bwd us/step  " + "  |  ".join(out), flush=True)
+    print(f"{name}: fwd (persistent {fpath}) {fbest:5.2f} us/step   bwd us/step  " + "  |  ".join(out), flush=True)
+
 
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
