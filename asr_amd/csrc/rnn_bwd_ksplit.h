@@ -275,42 +275,83 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char
     for (int g = 0; g < G; ++g) af[g] = *reinterpret_cast<const bf16x8*>(&As[s & 1][g][lane & 15][(lane >> 4) * 8]);
     u32x4_ outv = u32x4_{0u, 0u, 0u, 0u};
     if (lds_out && wave < 4) outv = *reinterpret_cast<const u32x4_*>(&As[s & 1][wave][srow][(lane & 3) * 8]);
-    // transposed product: acc[nt][r] of lane (q, c) = partial dh of batch row c, output unit 16 nt + 4q + r.  Two groups of tile pairs, so
-    // that the first group's pieces can be converted and stored while the matrix pipe still works on the second
+    // transposed product: acc[nt][r] of lane (q, c) = partial dh of batch row c, output unit 16 nt + 4q + r.
+    // PUBLISH: piece = [units 4q..4q+3 | 16+4q..16+4q+3] of batch row c as bf16 (round to nearest even); bit 0 of each 8-byte half — the last
+    // mantissa bit of its first value — is REPLACED by the tag and stays part of the value the consumer adds.
+    // Schedule: the two waves of a SIMD share its matrix pipe, and left to itself the older wave issues all of its G * NT MFMAs first — the
+    // younger one then converts and stores its whole result behind 2 x G * NT MFMAs (0.85 us against 0.37 in the timeline probe).  So the
+    // product goes tile pair by tile pair, software-pipelined by one: MFMAs of pair p + 1, THEN convert + store pair p (which stalls this
+    // wave on pair p's results and hands the pipe to the other wave); sched_barriers keep the compiler from regrouping it.
     f32x4 acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    constexpr int NT1 = 2 * ((NL + 1) / 2);
+    const char* xout = gbase + (long long)(s & 1) * slotbytes + pub_wave_off;
+    const unsigned tagw = ((unsigned)s >> 1) & 1u;
+    auto mfma_pair = [&](int pr) {
 #pragma unroll
-    for (int g = 0; g < G; ++g)
+      for (int g = 0; g < G; ++g) {
+        acc[2 * pr] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wreg[g][2 * pr]), af[g], acc[2 * pr], 0, 0, 0);
+        acc[2 * pr + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wreg[g][2 * pr + 1]), af[g], acc[2 * pr + 1], 0, 0, 0);
+      }
+    };
+    auto publish_pair = [&](int pr) {
+      const f32x4 lo = acc[2 * pr], hi = acc[2 * pr + 1];
+      const bf16x2_ p0 = __builtin_convertvector((f32x2_{lo[0], lo[1]}), bf16x2_), p1 = __builtin_convertvector((f32x2_{lo[2], lo[3]}), bf16x2_);
+      const bf16x2_ p2 = __builtin_convertvector((f32x2_{hi[0], hi[1]}), bf16x2_), p3 = __builtin_convertvector((f32x2_{hi[2], hi[3]}), bf16x2_);
+      const u32x4_ v = {(__builtin_bit_cast(unsigned, p0) & ~1u) | tagw, __builtin_bit_cast(unsigned, p1),
+                        (__builtin_bit_cast(unsigned, p2) & ~1u) | tagw, __builtin_bit_cast(unsigned, p3)};
+      if (l2_local) store16_base<true>(xout + (long long)pr * pub_step, pub_lane_off, v);
+      else store16_base<false>(xout + (long long)pr * pub_step, pub_lane_off, v);
+    };
+#ifndef DS2_KS_PIPE
+#define DS2_KS_PIPE 1
+#endif
+#if DS2_KS_PIPE == 1
+    mfma_pair(0);
 #pragma unroll
-      for (int nt = 0; nt < NT1; ++nt)
-        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wreg[g][nt]), af[g], acc[nt], 0, 0, 0);
-#pragma unroll
-    for (int g = 0; g < G; ++g)
-#pragma unroll
-      for (int nt = NT1; nt < NT; ++nt)
-        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wreg[g][nt]), af[g], acc[nt], 0, 0, 0);
-    PTRACE(4);
-    // ---- publish.  piece = [units 4q..4q+3 | 16+4q..16+4q+3] of batch row c as bf16 (round to nearest even); bit 0 of each 8-byte half —
-    // the last mantissa bit of its first value — is REPLACED by the tag and stays part of the value the consumer adds
-    {
-      const char* xout = gbase + (long long)(s & 1) * slotbytes + pub_wave_off;
-      const unsigned tagw = ((unsigned)s >> 1) & 1u;
-      auto publish = [&](auto local) {
-#pragma unroll
-        for (int pr = 0; pr < NL; ++pr) {
-          const f32x4 lo = acc[2 * pr], hi = acc[2 * pr + 1];
-          const bf16x2_ p0 = __builtin_convertvector((f32x2_{lo[0], lo[1]}), bf16x2_), p1 = __builtin_convertvector((f32x2_{lo[2], lo[3]}), bf16x2_);
-          const bf16x2_ p2 = __builtin_convertvector((f32x2_{hi[0], hi[1]}), bf16x2_), p3 = __builtin_convertvector((f32x2_{hi[2], hi[3]}), bf16x2_);
-          store16_base<decltype(local)::value>(xout + (long long)pr * pub_step, pub_lane_off,
-                                               u32x4_{(__builtin_bit_cast(unsigned, p0) & ~1u) | tagw, __builtin_bit_cast(unsigned, p1),
-                                                      (__builtin_bit_cast(unsigned, p2) & ~1u) | tagw, __builtin_bit_cast(unsigned, p3)});
-        }
-      };
-      if (l2_local) publish(std::true_type{});
-      else publish(std::false_type{});
+    for (int pr = 0; pr < NL; ++pr) {
+      if (pr + 1 < NL) mfma_pair(pr + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      publish_pair(pr);
+      __builtin_amdgcn_sched_barrier(0);
     }
+#elif DS2_KS_PIPE == 2          // tuning variants (scripts/ab_ks_pipe.sh): pair by pair without look-ahead
+#pragma unroll
+    for (int pr = 0; pr < NL; ++pr) {
+      mfma_pair(pr);
+      __builtin_amdgcn_sched_barrier(0);
+      publish_pair(pr);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#elif DS2_KS_PIPE == 3          // two pairs per group, pipelined by one group
+    mfma_pair(0);
+    if (NL > 1) mfma_pair(1);
+#pragma unroll
+    for (int pr = 0; pr < NL; pr += 2) {
+      if (pr + 2 < NL) mfma_pair(pr + 2);
+      if (pr + 3 < NL) mfma_pair(pr + 3);
+      __builtin_amdgcn_sched_barrier(0);
+      publish_pair(pr);
+      if (pr + 1 < NL) publish_pair(pr + 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#elif DS2_KS_PIPE == 4          // look-ahead of two pairs
+    mfma_pair(0);
+    if (NL > 1) mfma_pair(1);
+#pragma unroll
+    for (int pr = 0; pr < NL; ++pr) {
+      if (pr + 2 < NL) mfma_pair(pr + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      publish_pair(pr);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#else                           // everything first, then the conversions and stores (the compiler's own order)
+#pragma unroll
+    for (int pr = 0; pr < NL; ++pr) mfma_pair(pr);
+#pragma unroll
+    for (int pr = 0; pr < NL; ++pr) publish_pair(pr);
+#endif
+    PTRACE(4);
     PTRACE(5);
     // ---- this step's results go out LAST: their stores retire in the shadow of the exchange (nothing of the next step depends on them)
     if (s_on) __builtin_nontemporal_store(outv, reinterpret_cast<u32x4_*>(s_dst + sE));
