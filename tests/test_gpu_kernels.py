@@ -618,6 +618,42 @@ def test_ksplit_backward_vs_oracle(dev, kind, H, B, T):
     assert err["ksplit"] < 6e-3 and err["ksplit"] < 1.1 * err["allgather_or_step"]
 
 
+@pytest.mark.parametrize("kind,H,B,T,reps", [("gru", 1024, 64, 200, 120), ("lstm", 1280, 32, 120, 60), ("gru", 768, 32, 150, 60)])
+def test_ksplit_backward_soak_reruns_bit_identical(dev, kind, H, B, T, reps):
+    """The K-split exchange has no reset traffic: a slot's previous content is told from the step's by ONE tag bit per 8-byte half, two slots
+    alternate, and a line is reused after two steps.  A protocol hole (a consumer accepting a half-written or stale line) would show as a
+    result that differs from run to run.  `reps` launches of T steps each on the same inputs — 8 exchange groups x 32 x 32 lines x T x reps
+    hand-offs at the c3 shape, the placement-independent `sc1` flavour at the c4 shape (40 workgroups per group over two XCDs) — must all be
+    bit-identical to the first, with ragged lengths, and none may starve."""
+    from asr_amd import ops
+    G = 3 if kind == "gru" else 4
+    torch.manual_seed(5)
+    gx = torch.randn(T * B, 2 * G * H, device=dev) * 0.5
+    whh = (torch.rand(2, G * H, H, device=dev) * 2 - 1) / H ** 0.5
+    bhh = torch.randn(2, G * H, device=dev) * 0.1
+    lens = torch.sort(torch.randint(T // 3, T + 1, (B,), dtype=torch.int32, device=dev), descending=True).values.contiguous()
+    lens[0] = T
+    dy = torch.randn(T * B, H, device=dev)
+    wpf, wpb = ops.rnn_pack(G, whh, bf16=True)
+    hb, aux, rec = ops.rnn_fwd(G, gx, wpf, bhh, lens, T, B, H, bf16=True, packed_gates=True)
+
+    def run():
+        side = torch.empty(T * B, 2 * G * H, dtype=torch.bfloat16, device=dev)
+        dhn = torch.empty(T * B, 2 * H, dtype=torch.bfloat16, device=dev) if G == 3 else None
+        bp = torch.empty(B, 2, 4, H, device=dev)
+        ops.rnn_bwd(G, dy, None, aux.clone(), hb, wpb, lens, T, B, H, bf16=True, dgx_bf16=side, gates_bf16=rec, dhn_bf16=dhn, bias_part=bp)
+        return side, dhn, bp
+    ref = run()
+    assert ops.rnn_last_path() & 4, "this shape must take the K-split kernel"
+    assert bool(torch.isfinite(ref[0].float()).all())
+    for _ in range(reps):
+        got = run()
+        assert torch.equal(got[0].view(torch.int16), ref[0].view(torch.int16)) and torch.equal(got[2], ref[2])
+        if G == 3:
+            assert torch.equal(got[1].view(torch.int16), ref[1].view(torch.int16))
+    ops.rnn_persistent_check()
+
+
 STARVE_WORKER = r"""
 import os, sys, torch
 sys.path.insert(0, os.environ["REPO"])
