@@ -179,8 +179,10 @@ def cpu_baseline_worker(rnn, H, L, C, tin, B):
             break                                              # larger teams only get slower from here
     nthr = min(probe, key=probe.get)
     torch.set_num_threads(nthr)
-    # largest batch (<= 8) for which warm-up + two timed steps are predicted to stay inside ~100 s (at most linear in B on this path)
-    b_s = max(1, min(B, 8, int(pb * 100.0 / 3.0 / max(probe[nthr], 1e-9))))
+    # largest batch (<= 4) for which warm-up + two timed steps are predicted to stay inside ~100 s
+    # (the packed path is SUPER-linear in B — its per-time-step slice gradients allocate packed-sequence-sized buffers: 6 s per step at B = 3,
+    #  52 s at B = 8 on the same host — so the batch is capped at 4: three steps then stay well inside the parent's limit on a slower box too)
+    b_s = max(1, min(B, 4, int(pb * 100.0 / 3.0 / max(probe[nthr], 1e-9))))
     params = P.leaf_params(sd)
     opt = P.make_optimizer(params)
     x, targets, pct, tsz = synthetic_batch(b_s, tin, C, 1)
@@ -244,7 +246,7 @@ def loss_parity(rnn, H, L, C, tin, cpu, dev):
     return out
 
 
-def cpu_baseline(rnn, H, L, C, tin, B, limit_s=260):
+def cpu_baseline(rnn, H, L, C, tin, B, limit_s=300):
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", rnn, str(H), str(L), str(C), str(tin), str(B)]
     try:
