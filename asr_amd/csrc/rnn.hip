@@ -6,7 +6,10 @@
 //   * STEP kernels: one launch per time step and BOTH directions per launch (dir 0 walks t = s, dir 1 walks t = T-1-s); the kernel
 //     boundary is the all-to-all seam, the W_hh slices a block re-reads every step stay in its XCD's L2.  fp32 mode, and the fallback.
 //   * PERSISTENT kernels (bf16 mode, further down): one launch per layer, W_hh slice in registers, h_t exchanged between the resident
-//     workgroups by tagged-payload polling, one workgroup barrier per time step.  5.8 -> 3.5 us (forward) / 6.9 -> 3.9 us (backward) per step.
+//     workgroups by tagged-payload polling, one workgroup barrier per time step.  5.8 -> 2.1 us (forward) / 6.9 -> 3.1 us (backward) per step.
+//   * K-SPLIT persistent backward (rnn_bwd_ksplit.h, the bf16 default where H % 256 == 0): the product dGh W_hh split along K, bf16 partial
+//     sums of dh exchanged instead of dGh (a third of the gather, no reset traffic): 2.4-2.5 us per step at c3.  Equal to the other two
+//     families within a stated tolerance (one more bf16 rounding per partial sum), not to the bit.
 //
 // Step kernel = [h_{t-1} (BT x H) @ W_hh^T slice] on the f32 matrix cores (v_mfma_f32_16x16x4_f32)
 // fused with the gate non-linearities, the per-sample length mask and the state write-back.
