@@ -100,7 +100,38 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char
     if (has_prev) o.prev = (G == 3) ? a.hbuf[fH + dH] : a.aux[fH + dH];     // h / c of the previous frame in forward order = the NEXT step's row
     return o;
   };
-  Ops cur = fetch(eH, eG, eY, T > 1), nxt = cur;
+  // The gate-derivative math is LINEAR in dh (GRU) / in dh and dc (LSTM): everything that does not depend on the carry — the products of the
+  // saved gates, 1 - n^2, tanh(c) ... — is folded into five or six coefficients per pair as soon as a step's operands have landed, i.e. at the
+  // END of the step before, in the shadow of the exchange; behind the gather only dh = dy + carry (+ dcar) and one multiply per output remain
+  // on the step's dependent chain.  (Same formulas as gru_bwd_point / lstm_bwd_point, re-associated: agreement with the other kernel
+  // families stays inside the K-split tolerance.)  Rows beyond B / frames beyond the sample's length: all coefficients zero.
+  struct Coef { float k0, k1, k2, k3, kc, kcar, dy; };
+  auto coefficients = [&](Ops o, int step) {
+    Coef c{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int tt = dir == 0 ? T - 1 - step : step;
+    if (!(pact && tt < plen)) return c;
+    if (gates_bf) { o.g0 = (float)o.rec[0]; o.g1 = (float)o.rec[1]; o.g2 = (float)o.rec[2]; o.g3 = (float)o.rec[3]; }
+    c.dy = o.dy;
+    if constexpr (G == 3) {                                // r = g0, z = g1, n = g2, hn = g3
+      const float cn = (1.f - o.g1) * (1.f - o.g2 * o.g2);
+      c.kc = cn;                                           // d(pre-activation of n) = dh * cn
+      c.k0 = cn * o.g3 * o.g0 * (1.f - o.g0);              // dGh_r
+      c.k1 = (o.prev - o.g2) * o.g1 * (1.f - o.g1);        // dGh_z
+      c.k2 = cn * o.g0;                                    // d(hn)
+      c.kcar = o.g1;                                       // dh * z -> the next step's dcar
+    } else {                                               // i = g0, f = g1, g = g2, o = g3, c = ax, c_prev = prev
+      const float tc = tanhf_(o.ax);
+      c.kc = o.g3 * (1.f - tc * tc);                       // dc = dcar + dh * kc
+      c.k0 = o.g2 * o.g0 * (1.f - o.g0);
+      c.k1 = o.prev * o.g1 * (1.f - o.g1);
+      c.k2 = o.g0 * (1.f - o.g2 * o.g2);
+      c.k3 = tc * o.g3 * (1.f - o.g3);                     // dGh_o = dh * k3
+      c.kcar = o.g1;                                       // dc * f -> the next step's dcar
+    }
+    return c;
+  };
+  Ops nxt = fetch(eH, eG, eY, T > 1);
+  Coef cf = coefficients(nxt, 0);
 
   // Results.  bf16 training path (dgx_bf given): the bf16 values are in the LDS planes anyway — after the step's barrier, wave p < 4 sends
   // plane p out with ONE 16-byte store per lane (lane = row (lane >> 2), 8 units (lane & 3)): GRU planes 0, 1, 3 -> dGx columns r, z, n and
@@ -227,33 +258,25 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char
     }
     vm_drained();                                          // (the gather has waited for everything; tell the compiler)
     PTRACE(1);
-    if (s > 0) cur = nxt;                                  // operands of THIS step: fetched one step ago, landed
     // the NEXT step's gate-math operands: issued here, right behind the gather, so that they have a whole step to land (the next poll's
-    // wait retires them too: vmcnt is in order)
+    // wait retires them too: vmcnt is in order); their coefficients are formed at the end of this step
     const bool more = s + 1 < T;
     if (more) nxt = fetch(eH + dH, eG + dG, eY + dY, s + 2 < T);
-    if (gates_bf) { cur.g0 = (float)cur.rec[0]; cur.g1 = (float)cur.rec[1]; cur.g2 = (float)cur.rec[2]; cur.g3 = (float)cur.rec[3]; }
 
     float dgh[G], dgx[G], dax = 0.f;
-#pragma unroll
-    for (int g = 0; g < G; ++g) { dgh[g] = 0.f; dgx[g] = 0.f; }
-    if (pact && t < plen) {
-      if constexpr (G == 3) {
-        const float dh = cur.dy + carry + dcar;
-        float dpn;
-        gru_bwd_point(dh, cur.g0, cur.g1, cur.g2, cur.g3, cur.prev, dgh, dpn, dcar);
-        dgx[0] = dgh[0]; dgx[1] = dgh[1]; dgx[2] = dpn;
-        dax = dgh[2];
-      } else {
-        const float dh = cur.dy + carry;
-        float car;
-        lstm_bwd_point(dh, dcar, cur.g0, cur.g1, cur.g2, cur.g3, cur.ax, cur.prev, dgh, car);
-        dcar = car;
-#pragma unroll
-        for (int g = 0; g < G; ++g) dgx[g] = dgh[g];
-      }
+    if constexpr (G == 3) {
+      const float dh = cf.dy + carry + dcar;
+      dgh[0] = dh * cf.k0; dgh[1] = dh * cf.k1; dgh[2] = dh * cf.k2;
+      dgx[0] = dgh[0]; dgx[1] = dgh[1]; dgx[2] = dh * cf.kc;
+      dax = dgh[2];
+      dcar = dh * cf.kcar;
     } else {
-      dcar = 0.f;
+      const float dh = cf.dy + carry;
+      const float dc = __builtin_fmaf(dh, cf.kc, dcar);
+      dgh[0] = dc * cf.k0; dgh[1] = dc * cf.k1; dgh[2] = dc * cf.k2; dgh[G - 1] = dh * cf.k3;
+#pragma unroll
+      for (int g = 0; g < G; ++g) dgx[g] = dgh[g];
+      dcar = dc * cf.kcar;
     }
 #pragma unroll
     for (int g = 0; g < G; ++g) bs[g] += dgx[g];
@@ -357,6 +380,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char
     if (s_on) __builtin_nontemporal_store(outv, reinterpret_cast<u32x4_*>(s_dst + sE));
     store_lane(eH, eG, dgx, dax, !lds_out);
     eH += dH; eG += dG; eY += dY; sE += sD;
+    cf = coefficients(nxt, s + 1);                         // (the operands were requested a step ago; this wait is in the exchange's shadow)
     PTRACE(6);
   }
   if (a.bsum && pact) {
