@@ -209,7 +209,11 @@ size_t ds2_rnn_bwd_workspace_bytes(int gates, int B, int H, int bf16);
 int ds2_rnn_bwd(int gates, const float* dy, int lddy, float* gx, float* aux, const float* hbuf, const void* wp_bwd, const int* lens_dev,
                 int T, int B, int H, int bf16, void* dgx_bf16, const void* gates_bf16, void* ws, size_t ws_bytes, void* stream);
 
-/* ds2_rnn_bwd plus two optional outputs of a PERSISTENT launch (check ds2_rnn_last_path() & 2 after the call; untouched otherwise):
+/* ds2_rnn_last_path() bits after a backward call: 2 = ran as ONE persistent launch; 4 = that launch was the K-split kernel (bf16, H a multiple
+ * of 256: asr_amd/csrc/rnn_bwd_ksplit.h — bf16 partial sums of dh are exchanged instead of dGh; results equal those of the other kernel
+ * families within 4e-3 relative L2 and sit at the same distance from an fp64 recurrence, run-to-run bit-identical).  A K-split launch that
+ * is given dhn_bf16 writes ONLY that bf16 copy of d(W_hn h + b_hn), not the fp32 one into aux.
+ * ds2_rnn_bwd plus two optional outputs of a PERSISTENT launch (check ds2_rnn_last_path() & 2 after the call; untouched otherwise):
  * dhn_bf16 (GRU): (T,B,2,H) bf16 copy of d(W_hn h + b_hn); bias_part: (B,2,4,H) fp32 per-batch-row sums over time of
  * [d r, d z, d n, d(hn)] (GRU) / [d i, d f, d g, d o] (LSTM) - their column sums over B are the bias gradients, so no pass over dGx. */
 int ds2_rnn_bwd_ex(int gates, const float* dy, int lddy, float* gx, float* aux, const float* hbuf, const void* wp_bwd, const int* lens_dev,
