@@ -9,6 +9,8 @@ config's own size.
   * bf16 gradients at c3 size: every parameter gradient of the bf16 path against the fp32 path's (same weights, same batch),
     per-tensor relative L2 and cosine, with the Hardtanh-kink flips counted — the bound quoted in DESIGN.md §5.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -298,3 +300,42 @@ def test_weight_gradients_tn_form_vs_transposing_cast_path(rnn, hidden, layers, 
                 assert float((an - bn).norm() / bn.norm().clamp_min(1e-30)) <= 1e-5, n
         else:
             assert torch.equal(a, b), (n, float((a - b).abs().max()))
+
+
+# ---------------------------------------------------------------------------------------------------------------- full depth
+@pytest.mark.parametrize("rnn,hidden,layers,classes,t_ins", [("gru", 1024, 5, 29, [501, 433, 371, 290]), ("lstm", 1280, 7, 29, [301, 250, 188])])
+def test_full_depth_step_vs_packed_cpu_oracle(rnn, hidden, layers, classes, t_ins):
+    """The metric configuration's own depth AND width (5 x 1024 BiGRU; likewise c4's 7 x 1280 BiLSTM) against the CPU oracle in ONE comparison:
+    a ragged batch of 5 s utterances (T = 251 recurrent steps) through all layers, fp32 mode — logits, loss and EVERY parameter gradient
+    within north_star's 1e-3 of `oracle/ds2_packed.py`, the restatement in the reference's own packed-sequence formulation
+    (pack_padded_sequence -> aten gru / lstm -> pad_packed_sequence, blocks.py:87-89; pinned against the reference's goldens), which is fast
+    enough on the host cores for this size.  The bf16 mode of the same step is held to its stated tolerances beside it."""
+    from oracle import ds2_packed as P
+    from asr_amd import CTCLoss
+    cfg = dict(rnn=rnn, hidden=hidden, layers=layers, classes=classes, t_ins=t_ins)
+    sd, x, targets, pct, tsz = model_inputs(cfg, well_conditioned=False)
+    B = x.size(0)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    params = P.leaf_params(sd)
+    out_ref, _, loss_ref = P.fit(params, x, targets, pct.clone(), tsz)
+    loss_ref.backward()
+    gref = {k: v.grad.detach().numpy().astype(np.float64) for k, v in params.items() if v.requires_grad}
+    gmax = max(float(np.linalg.norm(g)) for g in gref.values())
+    lens = O.lengths_from_percentages(pct, x.size(3))
+    for precision, tl, tg, tc in (("fp32", TOL, TOL, TOL), ("bf16", 2e-2, 6e-2, 1.5e-1)):
+        model = make_model(cfg, sd)
+        model.precision = precision
+        out, out_lens = model.forward(x.cuda(), lens)
+        loss = CTCLoss(reduction="sum")(out.transpose(0, 1), targets, out_lens, tsz) / B
+        loss.backward()
+        # logits are compared on the valid frames (beyond a sample's length both sides hold BatchNorm-of-zero garbage that CTC ignores)
+        e_logits = max(rel_l2(out[b, :int(out_lens[b])].detach().cpu().numpy(), out_ref[b, :int(out_lens[b])].detach().numpy()) for b in range(B))
+        e_loss = abs(float(loss.detach()) - float(loss_ref.detach())) / float(loss_ref.detach())
+        worst = ("", 0.0)
+        for k, p in model.named_parameters():
+            err = np.linalg.norm(p.grad.cpu().numpy().astype(np.float64) - gref[k]) / max(np.linalg.norm(gref[k]), 1e-4 * gmax, 1e-12)
+            assert err <= (tc if k.startswith("conv.") else tg), (precision, k, err)
+            worst = max(worst, (k, err), key=lambda kv: kv[1])
+        print(f"{layers}x{hidden} {rnn} {precision}: logits {e_logits:.2e} loss {e_loss:.2e} worst gradient {worst[0]} {worst[1]:.2e}")
+        assert e_logits < tl and e_loss < tl, (precision, e_logits, e_loss)
+        del model
