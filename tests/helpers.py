@@ -66,3 +66,28 @@ def noise_only_grads(cfg):
     every utterance of the batch has the full length (BASELINE configs[0]: four 2 s utterances)."""
     t = cfg["t_ins"]
     return {"conv.seq_module.0.bias", "conv.seq_module.3.bias"} if len(set(t)) == 1 else set()
+
+
+def hardtanh_flip_fraction(model, x, pct):
+    """Fraction f of the live Hardtanh(0, 20) elements of the two conv stages whose branch differs between the fp32 and the bf16 forward of
+    `model` on batch `x` (a flipped element switches its whole upstream gradient on or off: uncorrelated gradient noise ~sqrt(f) on the
+    conv-stack parameters).  Two training-mode forwards: the BatchNorm running statistics move; model.precision is left as found."""
+    import torch
+    from asr_amd import engine
+    from oracle import ds2_oracle as O
+    dev = torch.device("cuda:0")
+    model._ensure_flat(dev)
+    lens_dev = model.get_seq_lens(O.lengths_from_percentages(pct, x.size(3))).to(dev)
+    keep, acts = model.precision, {}
+    for prec in ("fp32", "bf16"):
+        model.precision = prec
+        with torch.no_grad():
+            W = model._flat.tensors(model)
+            _, ctx = engine.forward(W, model._cfg, x.to(dev), lens_dev, training=True, save=True, debug_acts=True)   # batch statistics, as in the train step
+            acts[prec] = (ctx.a1.clone(), ctx.layers[0].xin.clone())
+    model.precision = keep
+    flips = live = 0
+    for p, q in zip(acts["fp32"], acts["bf16"]):
+        flips += int((((p <= 0) != (q <= 0)) | ((p >= 20) != (q >= 20))).sum())
+        live += int(((p > 0) & (p < 20)).sum())
+    return flips / max(live, 1)
