@@ -88,6 +88,7 @@ SIGNATURES = {
     "ds2_rnn_fwd": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, sz, vp]),
     "ds2_rnn_bwd_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "ds2_rnn_bwd_ex": (i32, [i32, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, sz, vp]),
+    "ds2_rnn_bwd_bn": (i32, [i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, sz, vp]),
     "ds2_rnn_bias_grads": (i32, [i32, vp, i32, i32, vp, vp, vp]),
     "ds2_rnn_bwd": (i32, [i32, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
     "ds2_ctc_workspace_bytes": (sz, [i32, i32, i32]),

@@ -61,3 +61,6 @@ __device__ __forceinline__ float tanhf_(float x) {
 // ---- cross-file internals (not part of the C ABI) ------------------------------------------------------------
 // norm.hip: out0[c] = sum_k part[k][c][0], out1[c] = sum_k part[k][c][1] over `chunks` fp32 partial rows, combined in fp64
 int ds2i_col_finalize_sums(const float* part, int chunks, int H, float* out0, float* out1, hipStream_t s);
+// norm.hip: the elementwise half of BatchNorm1d backward, dX = gamma rstd (dY - s0/M - xhat s1/M), from already reduced column sums s0 / s1
+int ds2i_bn1d_bwd_apply(const float* dY, int lddy, const float* X, int ldx, float* dX, int lddx, int M, int H, const float* mean, const float* var,
+                        const float* gamma, const float* s0, const float* s1, float eps, hipStream_t s);

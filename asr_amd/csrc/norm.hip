@@ -641,21 +641,27 @@ extern "C" int ds2_bn1d_apply_bf16(const float* X, int ldx, void* Y, int ldy, in
   return 0;
 }
 
-// BatchNorm1d backward (training mode): dX, dgamma, dbeta from dY and the forward input X.
-extern "C" int ds2_bn1d_bwd_f32(const float* dY, int lddy, const float* X, int ldx, float* dX, int lddx, int M, int H,
-                                const float* mean, const float* var, const float* gamma, float eps, float* dgamma, float* dbeta,
-                                void* ws, size_t ws_bytes, void* stream) {
-  DS2_REQUIRE(dY && X && dX && mean && var && gamma && dgamma && dbeta, "ds2_bn1d_bwd_f32: null pointer");
-  int rc = col_reduce_launch(2, X, ldx, dY, lddy, nullptr, 0, M, H, mean, var, eps, 1, dbeta, dgamma, nullptr, nullptr, 0.f, ws,
-                             ws_bytes, (hipStream_t)stream);
-  if (rc) return rc;
+int ds2i_bn1d_bwd_apply(const float* dY, int lddy, const float* X, int ldx, float* dX, int lddx, int M, int H, const float* mean, const float* var,
+                        const float* gamma, const float* s0, const float* s1, float eps, hipStream_t stream) {
   const int vec = (ldx % 4 == 0) && (lddy % 4 == 0) && (lddx % 4 == 0) && ((uintptr_t)X % 16 == 0) &&
                   ((uintptr_t)dY % 16 == 0) && ((uintptr_t)dX % 16 == 0);
   dim3 grid(ceil_div(ceil_div(H, 4), 256), ceil_div(M, BN_ROWS_PER_BLOCK));
-  hipLaunchKernelGGL(bn1d_bwd_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, dY, lddy, X, ldx, dX, lddx, M, H, mean,
-                     var, gamma, (const float*)dbeta, (const float*)dgamma, eps, 1.0f / (float)M, vec);
+  hipLaunchKernelGGL(bn1d_bwd_apply_kernel, grid, dim3(256), 0, stream, dY, lddy, X, ldx, dX, lddx, M, H, mean, var, gamma, s0, s1, eps,
+                     1.0f / (float)M, vec);
   DS2_LAUNCH_CHECK("bn1d_bwd_apply_kernel");
   return 0;
+}
+
+// BatchNorm1d backward (training mode): dX, dgamma, dbeta from dY and the forward input X.  dX == NULL: only the column sums (dgamma,
+// dbeta) — the caller hands dY, X and the sums to ds2_rnn_bwd_bn, whose K-split recurrence kernel applies the elementwise half on the fly.
+extern "C" int ds2_bn1d_bwd_f32(const float* dY, int lddy, const float* X, int ldx, float* dX, int lddx, int M, int H,
+                                const float* mean, const float* var, const float* gamma, float eps, float* dgamma, float* dbeta,
+                                void* ws, size_t ws_bytes, void* stream) {
+  DS2_REQUIRE(dY && X && mean && var && gamma && dgamma && dbeta, "ds2_bn1d_bwd_f32: null pointer");
+  int rc = col_reduce_launch(2, X, ldx, dY, lddy, nullptr, 0, M, H, mean, var, eps, 1, dbeta, dgamma, nullptr, nullptr, 0.f, ws,
+                             ws_bytes, (hipStream_t)stream);
+  if (rc || !dX) return rc;
+  return ds2i_bn1d_bwd_apply(dY, lddy, X, ldx, dX, lddx, M, H, mean, var, gamma, dbeta, dgamma, eps, (hipStream_t)stream);
 }
 
 extern "C" size_t ds2_chanreduce_workspace_bytes(int C) { return (size_t)2048 * 2 * sizeof(float) * (size_t)(C > 1 ? C : 1); }

@@ -79,6 +79,12 @@ struct RnnArgs {
   __bf16* h_bf;       // fwd: (T,B,2,H) bf16 copy of hbuf
   __bf16* dhn_bf;     // bwd, GRU: (T,B,2,H) bf16 copy of d(hn) (aux)
   float* bsum;        // bwd: (B,2,4,H) per-batch-row sums over time of [d r, d z, d n, d(hn)] (GRU) / [d i, d f, d g, d o] (LSTM): bias gradients
+  // bwd, K-split kernel only, optional (bn_x != NULL): `dy` is the gradient wrt the OUTPUT of the BatchNorm1d that follows this layer and the
+  // kernel applies that BatchNorm's elementwise backward itself (ds2_rnn_bwd_bn): dy_used = k1 dy - k2 - k3 (x - mean)
+  const float* bn_x;  // (T*B, H) pitch ldbnx: the BatchNorm's input = this layer's y
+  const float *bn_mean, *bn_var, *bn_gamma, *bn_s0, *bn_s1;   // (H) batch statistics, weight, column sums of dy and of dy * xhat
+  float bn_eps;
+  int ldbnx;
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -1696,11 +1702,57 @@ extern "C" int ds2_rnn_bwd_ex(int gates, const float* dy, int lddy, float* gx, f
                 : (gates == 3 ? try_launch_persistent_bwd<3, false>(a, st) : try_launch_persistent_bwd<4, false>(a, st));
       g_last_bwd_kind = rc == 1 ? 1 : 0;
     }
-    g_last_path = (g_last_path & ~6) | (rc == 1 ? 2 : 0) | (g_last_bwd_kind == 2 ? 4 : 0);
+    g_last_path = (g_last_path & ~(6 | 16)) | (rc == 1 ? 2 : 0) | (g_last_bwd_kind == 2 ? 4 : 0);
     if (rc != 0 && rc != 2) return rc < 0 ? rc : 0;
   }
   DS2_HIP(hipMemsetAsync(ws, 0, ds2_rnn_bwd_workspace_bytes(gates, B, H, bf16), (hipStream_t)stream));   // step kernels: zero carry + padding
   return bf16 ? dispatch<true>(gates, true, a, (hipStream_t)stream) : dispatch<false>(gates, true, a, (hipStream_t)stream);
+}
+
+// ds2_rnn_bwd_ex for a layer whose output feeds a BatchNorm1d (every recurrent layer of the model: SequenceWise(BatchNorm1d) of the next
+// layer, blocks.py:75,85-86, or of the fc block, deepspeech.py:104).  dyn = gradient wrt that BatchNorm's OUTPUT (pitch lddyn), bn_x = its
+// input = this layer's y (pitch ldx), bn_mean / bn_var / bn_gamma its batch statistics and weight, bn_s0 / bn_s1 the column sums of dyn
+// and of dyn * xhat (= dbeta / dgamma, from ds2_bn1d_bwd_f32 with dX = NULL).  Where the K-split persistent kernel takes the call, the
+// elementwise half of the BatchNorm backward is applied on the fly to the one value a (row, unit) pair needs per step (bit 16 of
+// ds2_rnn_last_path()) — no pass over (T*B, H); otherwise it is materialised into dy_scratch (T*B, H) first and the call proceeds as
+// ds2_rnn_bwd_ex(dy = dy_scratch).
+extern "C" int ds2_rnn_bwd_bn(int gates, const float* dyn, int lddyn, const float* bn_x, int ldx, const float* bn_mean, const float* bn_var,
+                              const float* bn_gamma, const float* bn_s0, const float* bn_s1, float bn_eps, float* dy_scratch, float* gx,
+                              float* aux, const float* hbuf, const void* wp_bwd, const int* lens_dev, int T, int B, int H, int bf16,
+                              void* dgx_bf16, const void* gates_bf16, void* dhn_bf16, float* bias_part, void* ws, size_t ws_bytes,
+                              void* stream) {
+  DS2_REQUIRE(gates == 3 || gates == 4, "ds2_rnn_bwd_bn: gates must be 3 (GRU) or 4 (LSTM)");
+  DS2_REQUIRE(dyn && bn_x && bn_mean && bn_var && bn_gamma && bn_s0 && bn_s1 && dy_scratch && aux && hbuf && wp_bwd && lens_dev,
+              "ds2_rnn_bwd_bn: null pointer");
+  DS2_REQUIRE(gx || (gates_bf16 && dgx_bf16), "ds2_rnn_bwd_bn: gx may only be NULL with both gates_bf16 and dgx_bf16 given");
+  DS2_REQUIRE(T > 0 && B > 0 && H > 0 && (H % 4) == 0, "ds2_rnn_bwd_bn: need H %% 4 == 0 (H=%d)", H);
+  DS2_REQUIRE(ws && ws_bytes >= ds2_rnn_bwd_workspace_bytes(gates, B, H, bf16), "ds2_rnn_bwd_bn: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  if (bf16) {
+    RnnArgs a{};
+    a.gx = gx; a.aux = aux; a.hbuf = const_cast<float*>(hbuf); a.wp = (const float*)wp_bwd; a.dy = dyn; a.lddy = lddyn;
+    a.dcar = (float*)ws; a.pk = (float*)ws + (size_t)4 * B * H;
+    a.dgx_bf = (__bf16*)dgx_bf16; a.gates_bf = (__bf16*)const_cast<void*>(gates_bf16);
+    a.dhn_bf = (__bf16*)dhn_bf16; a.bsum = bias_part;
+    a.lens = lens_dev; a.T = T; a.B = B; a.H = H;
+    a.bn_x = bn_x; a.ldbnx = ldx; a.bn_mean = bn_mean; a.bn_var = bn_var; a.bn_gamma = bn_gamma; a.bn_s0 = bn_s0; a.bn_s1 = bn_s1; a.bn_eps = bn_eps;
+    a.dbg = g_ds2_debug_flags;
+    // (only when the persistent backward is armed: a cool-down call is counted once, by the un-fused call below)
+    const int rc = (g_persist_cooldown == 0 && g_persist_bwd) ? (gates == 3 ? try_launch_ksplit_bwd<3>(a, st) : try_launch_ksplit_bwd<4>(a, st)) : 0;
+    if (rc < 0) return rc;
+    if (rc == 1) {
+      g_last_bwd_kind = 2;
+      g_last_path = (g_last_path & ~(2 | 4 | 16)) | 2 | 4 | 16;
+      return 0;
+    }
+  }
+  // not taken by the K-split kernel: materialise dy, then the ordinary path
+  int rc = ds2i_bn1d_bwd_apply(dyn, lddyn, bn_x, ldx, dy_scratch, H, T * B, H, bn_mean, bn_var, bn_gamma, bn_s0, bn_s1, bn_eps, st);
+  if (rc) return rc;
+  rc = ds2_rnn_bwd_ex(gates, dy_scratch, H, gx, aux, hbuf, wp_bwd, lens_dev, T, B, H, bf16, dgx_bf16, gates_bf16, dhn_bf16, bias_part, ws, ws_bytes,
+                      stream);
+  g_last_path &= ~16;
+  return rc;
 }
 
 extern "C" int ds2_rnn_bwd(int gates, const float* dy, int lddy, float* gx, float* aux, const float* hbuf, const void* wp_bwd,

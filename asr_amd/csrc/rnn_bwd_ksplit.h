@@ -82,10 +82,21 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char
   const int t0 = dir == 0 ? T - 1 : 0;
   const long long dH = (dir == 0 ? -1LL : 1LL) * B * 2 * H, dG = dH * G, dY = (dir == 0 ? -1LL : 1LL) * B * lddy;
   long long eH = (((long long)t0 * B + b) * 2 + dir) * H + j, eG = (((long long)t0 * B + b) * 2 + dir) * G * H + j, eY = ((long long)t0 * B + b) * lddy + j;
-  struct Ops { bf16x4_ rec; float g0, g1, g2, g3, ax, dy, prev; };       // see rnn_bwd_persistent_kernel: fetched one step ahead, kept raw
+  // BatchNorm1d backward of the layer above, applied on the fly (ds2_rnn_bwd_bn): dy_used = bn1 dy + bnx x + bn0 with this unit's constants
+  //   k1 = gamma rstd, k2 = k1 s0 / M, k3 = k1 rstd s1 / M  ->  bn1 = k1, bnx = -k3, bn0 = k3 mean - k2     (norm.hip: bn1d_bwd_apply_kernel)
+  const bool bn = a.bn_x != nullptr;
+  const long long dX = (dir == 0 ? -1LL : 1LL) * B * a.ldbnx;
+  long long eX = ((long long)t0 * B + b) * a.ldbnx + j;
+  float bn1 = 1.f, bnx = 0.f, bn0 = 0.f;
+  if (bn) {
+    const float rs = rsqrtf(a.bn_var[j] + a.bn_eps), k1 = a.bn_gamma[j] * rs, invm = 1.f / (float)((long long)T * B);
+    const float k2 = k1 * a.bn_s0[j] * invm, k3 = k1 * rs * a.bn_s1[j] * invm;
+    bn1 = k1; bnx = -k3; bn0 = __builtin_fmaf(k3, a.bn_mean[j], -k2);
+  }
+  struct Ops { bf16x4_ rec; float g0, g1, g2, g3, ax, dy, prev, bx; };   // see rnn_bwd_persistent_kernel: fetched one step ahead, kept raw
   // operands of the step whose offsets are (fH, fG, fY); has_prev: that step has a predecessor in FORWARD order (= the step processed after it)
-  auto fetch = [&](long long fH, long long fG, long long fY, bool has_prev) {
-    Ops o{bf16x4_{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f}, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto fetch = [&](long long fH, long long fG, long long fY, long long fX, bool has_prev) {
+    Ops o{bf16x4_{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f}, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (!pact) return o;
     if (gates_bf) {
       o.rec = __builtin_nontemporal_load(reinterpret_cast<const bf16x4_*>(gates_bf) + fH);
@@ -97,6 +108,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char
       else o.g3 = ldnt(a.aux + fH);
     }
     o.dy = ldnt(a.dy + fY);
+    if (bn) o.bx = ldnt(a.bn_x + fX);
     if (has_prev) o.prev = (G == 3) ? a.hbuf[fH + dH] : a.aux[fH + dH];     // h / c of the previous frame in forward order = the NEXT step's row
     return o;
   };
@@ -111,7 +123,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char
     const int tt = dir == 0 ? T - 1 - step : step;
     if (!(pact && tt < plen)) return c;
     if (gates_bf) { o.g0 = (float)o.rec[0]; o.g1 = (float)o.rec[1]; o.g2 = (float)o.rec[2]; o.g3 = (float)o.rec[3]; }
-    c.dy = o.dy;
+    c.dy = bn ? __builtin_fmaf(bn1, o.dy, __builtin_fmaf(bnx, o.bx, bn0)) : o.dy;
     if constexpr (G == 3) {                                // r = g0, z = g1, n = g2, hn = g3
       const float cn = (1.f - o.g1) * (1.f - o.g2 * o.g2);
       c.kc = cn;                                           // d(pre-activation of n) = dh * cn
@@ -130,7 +142,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char
     }
     return c;
   };
-  Ops nxt = fetch(eH, eG, eY, T > 1);
+  Ops nxt = fetch(eH, eG, eY, eX, T > 1);
   Coef cf = coefficients(nxt, 0);
 
   // Results.  bf16 training path (dgx_bf given): the bf16 values are in the LDS planes anyway — after the step's barrier, wave p < 4 sends
@@ -261,7 +273,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char
     // the NEXT step's gate-math operands: issued here, right behind the gather, so that they have a whole step to land (the next poll's
     // wait retires them too: vmcnt is in order); their coefficients are formed at the end of this step
     const bool more = s + 1 < T;
-    if (more) nxt = fetch(eH + dH, eG + dG, eY + dY, s + 2 < T);
+    if (more) nxt = fetch(eH + dH, eG + dG, eY + dY, eX + dX, s + 2 < T);
 
     float dgh[G], dgx[G], dax = 0.f;
     if constexpr (G == 3) {
@@ -379,7 +391,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char
     // ---- this step's results go out LAST: their stores retire in the shadow of the exchange (nothing of the next step depends on them)
     if (s_on) __builtin_nontemporal_store(outv, reinterpret_cast<u32x4_*>(s_dst + sE));
     store_lane(eH, eG, dgx, dax, !lds_out);
-    eH += dH; eG += dG; eY += dY; sE += sD;
+    eH += dH; eG += dG; eY += dY; eX += dX; sE += sD;
     cf = coefficients(nxt, s + 1);                         // (the operands were requested a step ago; this wait is in the exchange's shadow)
     PTRACE(6);
   }

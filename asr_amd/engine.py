@@ -40,6 +40,9 @@ OVERLAP_WGRAD = OVERLAP_MODE == "1"
 WGRAD_TN = _os.environ.get("DS2_WGRAD_TN", "1") != "0"
 # bf16 mode: BatchNorm2d batch statistics from the conv forward epilogues; needs the rows-per-block conv2 kernel (DS2_CONV2_ROWS != 1)
 CONV_STATS = _os.environ.get("DS2_CONV_STATS", "1") != "0" and _os.environ.get("DS2_CONV2_ROWS", "") != "1"
+# bf16 training: the elementwise half of every BatchNorm1d backward is applied inside the K-split backward recurrence of the layer below
+# (ops.rnn_bwd_bn: one more 4-byte load per pair and step instead of a pass over (T*B, H)); 0: a separate bn1d_bwd_apply pass as before
+FUSE_BN_BWD = _os.environ.get("DS2_FUSE_BN_BWD", "1") != "0"
 _BWD_PERSISTENT = {}      # (gates, H, B) -> did the last backward recurrence of this shape run as a persistent launch?
 _SIDE = {}
 
@@ -49,6 +52,27 @@ def _side_stream(device):
     if key not in _SIDE:
         _SIDE[key] = torch.cuda.Stream(device=device)
     return _SIDE[key]
+
+
+@dataclass
+class BnGrad:
+    """Gradient wrt a BatchNorm1d OUTPUT together with what its elementwise backward needs: consumed by ops.rnn_bwd_bn of the layer below."""
+    dyn: Tensor          # (M, H) gradient wrt the BatchNorm output
+    x: Tensor            # (M, H) the BatchNorm input (= the layer below's y)
+    mean: Tensor
+    var: Tensor
+    gamma: Tensor
+    sums: Tensor         # (2, H): column sums of dyn and of dyn * xhat
+
+
+def _bn_backward(dxn: Tensor, x: Tensor, mean, var, gamma, dgamma, dbeta, fuse: bool):
+    """BatchNorm1d backward in front of a recurrent layer's backward: the materialised gradient, or (fuse) the column sums only + a BnGrad."""
+    if not fuse:
+        return ops.bn1d_bwd(dxn, x, mean, var, gamma, dgamma, dbeta)
+    sums = ops.bn1d_bwd_sums(dxn, x, mean, var, gamma)
+    dbeta.copy_(sums[0])
+    dgamma.copy_(sums[1])
+    return BnGrad(dxn, x, mean, var, gamma, sums)
 
 
 @dataclass
@@ -244,7 +268,8 @@ def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy: Tensor, done):
     M = T * B
     lens_dev = ctx.lens_dev
     main = torch.cuda.current_stream()
-    side = _side_stream(dy.device)
+    dev = ctx.lens_dev.device
+    side = _side_stream(dev)
     pending = None
 
     def weight_gradients(p):
@@ -303,7 +328,7 @@ def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy: Tensor, done):
             dbhh.copy_(Gr[f"rnns.{l}.bih_cat"].view(2, G * H))
             auxT = None
             if G == 3:
-                dbn = torch.empty(2 * H, dtype=torch.float32, device=dy.device)
+                dbn = torch.empty(2 * H, dtype=torch.float32, device=dev)
                 auxT = ops.cast_transpose_bf16(aux, colsum=dbn)                                   # + d(b_hn) = column sums of d(hn)
                 dbhh[:, 2 * H:] = dbn.view(2, H)
             hT = ops.cast_transpose_bf16(hbuf)                                                    # (2H, M)
@@ -326,12 +351,16 @@ def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy: Tensor, done):
             start.record(main)
             pending = operand_passes(*queued, start)
             queued = None
-        dgx_bf = torch.empty(lc.gshape if lc.rec is not None else lc.gx.shape, dtype=torch.bfloat16, device=dy.device)
+        dgx_bf = torch.empty(lc.gshape if lc.rec is not None else lc.gx.shape, dtype=torch.bfloat16, device=dev)
         want_tn = lc.h_bf is not None
-        dhn_bf = torch.empty(M, 2 * H, dtype=torch.bfloat16, device=dy.device) if (want_tn and G == 3) else None
-        bias_part = torch.empty(B, 2, 4, H, dtype=torch.float32, device=dy.device) if want_tn else None
-        ops.rnn_bwd(G, dy, lc.gx, lc.aux, lc.hbuf, lc.wpb, lens_dev, T, B, H, bf16=True, dgx_bf16=dgx_bf, gates_bf16=lc.rec, dhn_bf16=dhn_bf,
-                    bias_part=bias_part)
+        dhn_bf = torch.empty(M, 2 * H, dtype=torch.bfloat16, device=dev) if (want_tn and G == 3) else None
+        bias_part = torch.empty(B, 2, 4, H, dtype=torch.float32, device=dev) if want_tn else None
+        if isinstance(dy, BnGrad):
+            ops.rnn_bwd_bn(G, dy.dyn, dy.x, dy.mean, dy.var, dy.gamma, dy.sums, lc.gx, lc.aux, lc.hbuf, lc.wpb, lens_dev, T, B, H, bf16=True,
+                           dgx_bf16=dgx_bf, gates_bf16=lc.rec, dhn_bf16=dhn_bf, bias_part=bias_part)
+        else:
+            ops.rnn_bwd(G, dy, lc.gx, lc.aux, lc.hbuf, lc.wpb, lens_dev, T, B, H, bf16=True, dgx_bf16=dgx_bf, gates_bf16=lc.rec, dhn_bf16=dhn_bf,
+                        bias_part=bias_part)
         _BWD_PERSISTENT[shape_key] = bool(lib.ds2_rnn_last_path() & 2)
         tn = want_tn and _BWD_PERSISTENT[shape_key]              # (only a persistent launch writes d(hn) in bf16 and the bias sums)
         lc.rec = None
@@ -346,7 +375,7 @@ def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy: Tensor, done):
         dxn = ops.gemm_bf16_nt(dgx_bf, ops.cast_transpose_bf16(W[f"rnns.{l}.wih_cat"]))
         if l > 0:
             bp = f"rnns.{l}.batch_norm.module."
-            dy = ops.bn1d_bwd(dxn, lc.xin, lc.mean, lc.var, W[bp + "weight"], Gr[bp + "weight"], Gr[bp + "bias"])
+            dy = _bn_backward(dxn, lc.xin, lc.mean, lc.var, W[bp + "weight"], Gr[bp + "weight"], Gr[bp + "bias"], FUSE_BN_BWD)
         else:
             dy = dxn
         del dxn
@@ -384,11 +413,12 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
     ops.gemm(dl, ctx.fc_xn, transA=True, out=Gr[fp + "1.weight"])                                 # (C, H)
     dxn = ops.gemm(dl, W[fp + "1.weight"])                                                        # (M, H)
     mean, var = ctx.fc_stats
-    dy = ops.bn1d_bwd(dxn, ctx.y_last, mean, var, W[fp + "0.weight"], Gr[fp + "0.weight"], Gr[fp + "0.bias"])
+    deferred = OVERLAP_MODE == "2" and cfg.precision == "bf16" and B % 8 == 0 and T > 1
+    dy = _bn_backward(dxn, ctx.y_last, mean, var, W[fp + "0.weight"], Gr[fp + "0.weight"], Gr[fp + "0.bias"], FUSE_BN_BWD and deferred)
     del dxn
     done("fc")
     # ---- recurrent stack ------------------------------------------------------------------------
-    if OVERLAP_MODE == "2" and cfg.precision == "bf16" and B % 8 == 0 and T > 1:
+    if deferred:
         dy = _backward_rnn_deferred(W, Gr, cfg, ctx, dy, done)
         first_layer = -1          # the loop below has nothing left to do
     else:

@@ -359,7 +359,7 @@ def main():
     # The dominant kernels (the two recurrences) are timed live INSIDE the timed region: a HIP event pair on the launch stream around every
     # ops.rnn_fwd / ops.rnn_bwd call of the K steps (recording an event does not synchronise anything), read back after the final sync.
     rnn_calls = {"fwd": [], "bwd": []}
-    orig_rnn = (ops.rnn_fwd, ops.rnn_bwd)
+    orig_rnn = (ops.rnn_fwd, ops.rnn_bwd, ops.rnn_bwd_bn)
 
     def with_events(fn, key, t_arg, bit):
         def wrapped(*a, **k):
@@ -372,6 +372,7 @@ def main():
         return wrapped
 
     ops.rnn_fwd, ops.rnn_bwd = with_events(orig_rnn[0], "fwd", 5, 1), with_events(orig_rnn[1], "bwd", 7, 2)
+    ops.rnn_bwd_bn = with_events(orig_rnn[2], "bwd", 12, 2)      # the same recurrence with the BatchNorm1d backward of the layer above applied inside
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -382,7 +383,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    ops.rnn_fwd, ops.rnn_bwd = orig_rnn
+    ops.rnn_fwd, ops.rnn_bwd, ops.rnn_bwd_bn = orig_rnn
     tr.synchronize()                                  # settle the last step's device-side verdict (starved-step counter)
     if use_dist:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -551,7 +552,7 @@ def breakdown(model, tr, x, targets, pct, tsz):
     tg, off, tl, max_u = _prep_targets(targets, tsz, dev)
     W = model._flat.tensors(model)
     Gr = model._flat.tensors(model, grads=True)
-    orig_rnn_fwd, orig_rnn_bwd, orig_gemm = ops.rnn_fwd, ops.rnn_bwd, ops.gemm_raw
+    orig_rnn_fwd, orig_rnn_bwd, orig_gemm, orig_rnn_bwd_bn = ops.rnn_fwd, ops.rnn_bwd, ops.gemm_raw, ops.rnn_bwd_bn
     acc = {"rnn_fwd": 0.0, "rnn_bwd": 0.0, "gemm": 0.0}
 
     def timed(fn, key):
@@ -565,6 +566,7 @@ def breakdown(model, tr, x, targets, pct, tsz):
         return w
     pend = []
     ops.rnn_fwd, ops.rnn_bwd, ops.gemm_raw = timed(orig_rnn_fwd, "rnn_fwd"), timed(orig_rnn_bwd, "rnn_bwd"), timed(orig_gemm, "gemm")
+    ops.rnn_bwd_bn = timed(orig_rnn_bwd_bn, "rnn_bwd")
     try:
         with torch.no_grad():
             torch.cuda.synchronize()
@@ -579,7 +581,7 @@ def breakdown(model, tr, x, targets, pct, tsz):
             mark("adamw")
             torch.cuda.synchronize()
     finally:
-        ops.rnn_fwd, ops.rnn_bwd, ops.gemm_raw = orig_rnn_fwd, orig_rnn_bwd, orig_gemm
+        ops.rnn_fwd, ops.rnn_bwd, ops.gemm_raw, ops.rnn_bwd_bn = orig_rnn_fwd, orig_rnn_bwd, orig_gemm, orig_rnn_bwd_bn
     for key, s, e in pend:
         acc[key] += s.elapsed_time(e)
     msg = ["breakdown (ms):"]

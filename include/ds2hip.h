@@ -88,6 +88,7 @@ int ds2_bn1d_apply_f32(const float* X, int ldx, float* Y, int ldy, int M, int H,
 /* same, Y written as bf16 (M, ldy), ldy % 8 == 0, pad columns zero: feeds the bf16 input-projection GEMM without a cast pass */
 int ds2_bn1d_apply_bf16(const float* X, int ldx, void* Y, int ldy, int M, int H, const float* mean, const float* var, const float* gamma,
                         const float* beta, float eps, void* stream);
+/* (dX may be NULL: only the column sums dgamma / dbeta are produced — see ds2_rnn_bwd_bn) */
 int ds2_bn1d_bwd_f32(const float* dY, int lddy, const float* X, int ldx, float* dX, int lddx, int M, int H, const float* mean,
                      const float* var, const float* gamma, float eps, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
                      void* stream);
@@ -219,6 +220,17 @@ int ds2_rnn_bwd(int gates, const float* dy, int lddy, float* gx, float* aux, con
 int ds2_rnn_bwd_ex(int gates, const float* dy, int lddy, float* gx, float* aux, const float* hbuf, const void* wp_bwd, const int* lens_dev,
                    int T, int B, int H, int bf16, void* dgx_bf16, const void* gates_bf16, void* dhn_bf16, float* bias_part, void* ws,
                    size_t ws_bytes, void* stream);
+
+/* ds2_rnn_bwd_ex for a layer whose output y feeds a BatchNorm1d (SequenceWise(BatchNorm1d) of the next layer, modules/blocks.py:75,85-86, or
+ * of the fc block, modules/deepspeech.py:104): dyn = gradient wrt that BatchNorm's OUTPUT, bn_x = its input (= y, pitch ldx), bn_mean /
+ * bn_var / bn_gamma its batch statistics and weight, bn_s0 / bn_s1 the column sums of dyn and dyn * xhat (dbeta / dgamma of
+ * ds2_bn1d_bwd_f32 called with dX = NULL).  Where the K-split persistent kernel takes the call it applies the elementwise half of the
+ * BatchNorm backward on the fly (ds2_rnn_last_path() & 16) and dy_scratch is not touched; otherwise dy is materialised into dy_scratch
+ * (T*B, H) and the call proceeds as ds2_rnn_bwd_ex.  Replaces autograd's native_batch_norm_backward + the recurrence backward. */
+int ds2_rnn_bwd_bn(int gates, const float* dyn, int lddyn, const float* bn_x, int ldx, const float* bn_mean, const float* bn_var,
+                   const float* bn_gamma, const float* bn_s0, const float* bn_s1, float bn_eps, float* dy_scratch, float* gx, float* aux,
+                   const float* hbuf, const void* wp_bwd, const int* lens_dev, int T, int B, int H, int bf16, void* dgx_bf16,
+                   const void* gates_bf16, void* dhn_bf16, float* bias_part, void* ws, size_t ws_bytes, void* stream);
 
 /* bias gradients of one recurrent layer from ds2_rnn_bwd_ex's bias_part (B,2,4,H): db_ih (2,G*H) [bias_ih_l0 | bias_ih_l0_reverse] and
  * db_hh (2,G*H); GRU: db_ih = [d r, d z, d n], db_hh = [d r, d z, d(hn)]; LSTM: both = [d i, d f, d g, d o]. */

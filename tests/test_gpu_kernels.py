@@ -618,6 +618,63 @@ def test_ksplit_backward_vs_oracle(dev, kind, H, B, T):
     assert err["ksplit"] < 6e-3 and err["ksplit"] < 1.1 * err["allgather_or_step"]
 
 
+@pytest.mark.parametrize("kind,H,B,T", [("gru", 1024, 64, 12), ("lstm", 1280, 32, 7), ("gru", 256, 20, 16)])
+def test_ksplit_backward_with_fused_batchnorm_backward(dev, kind, H, B, T):
+    """ds2_rnn_bwd_bn: the elementwise half of the BatchNorm1d backward that precedes a layer's recurrence backward (blocks.py:80-86:
+    SequenceWise(BatchNorm1d) in front of the next layer's RNN) applied inside the K-split kernel, from the column sums, instead of by a pass
+    over (T*B, H).  Same fp32 expression per element up to one re-association (k1*dyn - k3*x + (k3*mean - k2) vs k1*dyn - k2 - k3*(x - mean)):
+    dGx must agree with the two-pass form to bf16 rounding; with the step kernels forced (flag 64) the entry materialises the gradient with
+    the SAME kernel as ds2_bn1d_bwd_f32 and must agree to the bit."""
+    from asr_amd import ops, _lib
+    lib = _lib.load()
+    G = 3 if kind == "gru" else 4
+    torch.manual_seed(11)
+    M = T * B
+    gx = torch.randn(M, 2 * G * H, device=dev) * 0.5
+    whh = (torch.rand(2, G * H, H, device=dev) * 2 - 1) / H ** 0.5
+    bhh = torch.randn(2, G * H, device=dev) * 0.1
+    lens = torch.sort(torch.randint(max(1, T // 3), T + 1, (B,), dtype=torch.int32, device=dev), descending=True).values.contiguous()
+    lens[0] = T
+    wpf, wpb = ops.rnn_pack(G, whh, bf16=True)
+    hb, aux, rec = ops.rnn_fwd(G, gx, wpf, bhh, lens, T, B, H, bf16=True, packed_gates=True)
+    # the BatchNorm above this layer: input x = this layer's output (summed directions), statistics over all M rows as the forward pass takes them
+    x = torch.randn(M, H, device=dev) * 0.7 + 0.2
+    gamma = torch.rand(H, device=dev) + 0.5
+    mean, var = x.mean(0), x.var(0, unbiased=False)
+    dyn = torch.randn(M, H, device=dev)
+
+    def outs():
+        return (torch.empty(M, 2 * G * H, dtype=torch.bfloat16, device=dev), torch.empty(M, 2 * H, dtype=torch.bfloat16, device=dev) if G == 3 else None,
+                torch.empty(B, 2, 4, H, device=dev))
+    dgam, dbet = torch.empty(H, device=dev), torch.empty(H, device=dev)
+    dy = ops.bn1d_bwd(dyn, x, mean, var, gamma, dgam, dbet)
+    sums = ops.bn1d_bwd_sums(dyn, x, mean, var, gamma)
+    assert torch.equal(sums[0], dbet) and torch.equal(sums[1], dgam), "the sums-only call must give exactly the gradients of beta and gamma"
+    for flags in (0, 64):
+        lib.ds2_debug_flags(flags)
+        a = outs()
+        ops.rnn_bwd(G, dy, None, aux.clone(), hb, wpb, lens, T, B, H, bf16=True, dgx_bf16=a[0], gates_bf16=rec, dhn_bf16=a[1], bias_part=a[2])
+        pa = ops.rnn_last_path()
+        b = outs()
+        ops.rnn_bwd_bn(G, dyn, x, mean, var, gamma, sums, None, aux.clone(), hb, wpb, lens, T, B, H, bf16=True, dgx_bf16=b[0], gates_bf16=rec,
+                       dhn_bf16=b[1], bias_part=b[2])
+        pb = ops.rnn_last_path()
+        lib.ds2_debug_flags(0)
+        if flags == 0 and H % 256 == 0 and H <= 1280 and (H // 32) * ((B + 15) // 16) * 2 <= 256:
+            assert pa & 4 and pb & 4 and pb & 16 and not pa & 16, (pa, pb)
+            e = rel_l2(b[0].float().cpu(), a[0].float().cpu())
+            print(f"{kind} H={H}: fused vs two-pass dGx rel-l2 {e:.2e}")
+            assert e < 3e-3                       # bf16 outputs of fp32 values that differ by a re-association: a fraction of one bf16 ulp (2^-8) on a few elements
+            assert rel_l2(b[2].cpu(), a[2].cpu()) < 1e-4
+        else:
+            assert not pb & 16
+            assert pa == pb, (pa, pb)
+            assert torch.equal(a[0].view(torch.int16), b[0].view(torch.int16))
+            if pa & 2:                            # d(hn) copies and bias partial sums are outputs of the persistent kernels only
+                assert torch.equal(a[2], b[2]) and (G == 4 or torch.equal(a[1].view(torch.int16), b[1].view(torch.int16)))
+    ops.rnn_persistent_check()
+
+
 @pytest.mark.parametrize("kind,H,B,T,reps", [("gru", 1024, 64, 200, 120), ("lstm", 1280, 32, 120, 60), ("gru", 768, 32, 150, 60)])
 def test_ksplit_backward_soak_reruns_bit_identical(dev, kind, H, B, T, reps):
     """The K-split exchange has no reset traffic: a slot's previous content is told from the step's by ONE tag bit per 8-byte half, two slots
