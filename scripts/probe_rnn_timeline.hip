@@ -5,6 +5,9 @@
 // and prints the mean span of each phase plus the entry-to-entry period of consecutive launches.
 #include "../asr_amd/csrc/rnn.hip"
 #include <cstdio>
+// (rnn.hip's ds2_rnn_bwd_bn falls back to this norm.hip entry; the probe links rnn.hip alone and never calls it)
+int ds2i_bn1d_bwd_apply(const float*, int, const float*, int, float*, int, int, int, const float*, const float*, const float*, const float*, const float*,
+                        float, hipStream_t) { return -1; }
 #include <vector>
 #include <cstdlib>
 
