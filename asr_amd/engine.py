@@ -62,16 +62,20 @@ class BnGrad:
     mean: Tensor
     var: Tensor
     gamma: Tensor
-    sums: Tensor         # (2, H): column sums of dyn and of dyn * xhat
+    sums: tuple          # two (H,) vectors: column sums of dyn and of dyn * xhat
 
 
-def _bn_backward(dxn: Tensor, x: Tensor, mean, var, gamma, dgamma, dbeta, fuse: bool):
-    """BatchNorm1d backward in front of a recurrent layer's backward: the materialised gradient, or (fuse) the column sums only + a BnGrad."""
+def _bn_backward(dxn: Tensor, x: Tensor, mean, var, gamma, dgamma, dbeta, fuse: bool, private_sums: bool):
+    """BatchNorm1d backward in front of a recurrent layer's backward: the materialised gradient, or (fuse) the column sums only + a BnGrad.
+    private_sums: the gradient buffers may be all-reduced (asynchronously, in place) before the recurrence below has read the sums."""
     if not fuse:
         return ops.bn1d_bwd(dxn, x, mean, var, gamma, dgamma, dbeta)
-    sums = ops.bn1d_bwd_sums(dxn, x, mean, var, gamma)
-    dbeta.copy_(sums[0])
-    dgamma.copy_(sums[1])
+    if private_sums:
+        sums = ops.bn1d_bwd_sums(dxn, x, mean, var, gamma)
+        dbeta.copy_(sums[0])
+        dgamma.copy_(sums[1])
+    else:
+        sums = ops.bn1d_bwd_sums(dxn, x, mean, var, gamma, out=(dbeta, dgamma))
     return BnGrad(dxn, x, mean, var, gamma, sums)
 
 
@@ -255,7 +259,7 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
     return logits.view(T, B, cfg.classes), ctx
 
 
-def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy: Tensor, done):
+def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy, done, private: bool):
     """Backward of the recurrent stack in the bf16 training mode (packed gate records, bf16 dGx), DS2_OVERLAP=2 schedule: per layer
         compute stream:  recurrence(l) | weight-gradient GEMMs of layer l+1 | dXn(l) = dGx W_ih | BatchNorm1d backward(l)
         side stream:     [from the start of recurrence(l)] transposing casts of dGx(l+1) (+ db_ih), d(hn)(l+1) (+ db_hn), h(l+1), Xn(l+1)
@@ -375,7 +379,7 @@ def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy: Tensor, done):
         dxn = ops.gemm_bf16_nt(dgx_bf, ops.cast_transpose_bf16(W[f"rnns.{l}.wih_cat"]))
         if l > 0:
             bp = f"rnns.{l}.batch_norm.module."
-            dy = _bn_backward(dxn, lc.xin, lc.mean, lc.var, W[bp + "weight"], Gr[bp + "weight"], Gr[bp + "bias"], FUSE_BN_BWD)
+            dy = _bn_backward(dxn, lc.xin, lc.mean, lc.var, W[bp + "weight"], Gr[bp + "weight"], Gr[bp + "bias"], FUSE_BN_BWD, private)
         else:
             dy = dxn
         del dxn
@@ -414,12 +418,13 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
     dxn = ops.gemm(dl, W[fp + "1.weight"])                                                        # (M, H)
     mean, var = ctx.fc_stats
     deferred = OVERLAP_MODE == "2" and cfg.precision == "bf16" and B % 8 == 0 and T > 1
-    dy = _bn_backward(dxn, ctx.y_last, mean, var, W[fp + "0.weight"], Gr[fp + "0.weight"], Gr[fp + "0.bias"], FUSE_BN_BWD and deferred)
+    dy = _bn_backward(dxn, ctx.y_last, mean, var, W[fp + "0.weight"], Gr[fp + "0.weight"], Gr[fp + "0.bias"], FUSE_BN_BWD and deferred,
+                      on_bucket is not None)
     del dxn
     done("fc")
     # ---- recurrent stack ------------------------------------------------------------------------
     if deferred:
-        dy = _backward_rnn_deferred(W, Gr, cfg, ctx, dy, done)
+        dy = _backward_rnn_deferred(W, Gr, cfg, ctx, dy, done, on_bucket is not None)
         first_layer = -1          # the loop below has nothing left to do
     else:
         first_layer = L - 1

@@ -7,7 +7,7 @@ Nothing in this module has a CPU path: tensors must live on the GPU.
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional
+from typing import Optional, Tuple
 
 import torch
 
@@ -741,34 +741,40 @@ def rnn_bwd(gates: int, dy: Tensor, gx: Optional[Tensor], aux: Tensor, hbuf: Ten
                                   ws.data_ptr(), wsb, _stream()), "ds2_rnn_bwd")
 
 
-def bn1d_bwd_sums(dY: Tensor, X: Tensor, mean: Tensor, var: Tensor, gamma: Tensor) -> Tensor:
-    """Column sums of BatchNorm1d backward only: returns (2, H) fp32 = [sum dY ; sum dY * xhat] (= [dbeta ; dgamma]).  The elementwise half is
-    left to rnn_bwd_bn."""
+def bn1d_bwd_sums(dY: Tensor, X: Tensor, mean: Tensor, var: Tensor, gamma: Tensor, out: Optional[Tuple[Tensor, Tensor]] = None) -> Tuple[Tensor, Tensor]:
+    """Column sums of BatchNorm1d backward only: (sum dY, sum dY * xhat) = (dbeta, dgamma), two (H,) fp32 vectors — written into `out` when
+    given (e.g. the gradient buffers themselves).  The elementwise half is left to rnn_bwd_bn."""
     _chk_f32(dY, X, mean, var, gamma)
     lib = _lib.load()
     M, H = X.shape
-    sums = torch.empty(2, H, dtype=torch.float32, device=X.device)
+    if out is None:
+        both = torch.empty(2, H, dtype=torch.float32, device=X.device)
+        out = (both[0], both[1])
+    s0, s1 = out
+    _chk_f32(s0, s1)
+    assert s0.is_contiguous() and s1.is_contiguous() and s0.numel() == H == s1.numel()
     wsb = lib.ds2_colreduce_workspace_bytes(M, H)
     ws = _ws(wsb, X.device)
     _lib.check(lib.ds2_bn1d_bwd_f32(dY.data_ptr(), _row_pitch(dY), X.data_ptr(), _row_pitch(X), None, 0, M, H, mean.data_ptr(), var.data_ptr(),
-                                    gamma.data_ptr(), BN_EPS, sums[1].data_ptr(), sums[0].data_ptr(), ws.data_ptr(), wsb, _stream()), "ds2_bn1d_bwd_f32")
-    return sums
+                                    gamma.data_ptr(), BN_EPS, s1.data_ptr(), s0.data_ptr(), ws.data_ptr(), wsb, _stream()), "ds2_bn1d_bwd_f32")
+    return s0, s1
 
 
 def rnn_bwd_bn(gates: int, dyn: Tensor, bn_x: Tensor, mean: Tensor, var: Tensor, gamma: Tensor, sums: Tensor, gx: Optional[Tensor], aux: Tensor,
                hbuf: Tensor, wp_bwd: Tensor, lens_dev: Tensor, T: int, B: int, H: int, bf16: bool = False, dgx_bf16: Optional[Tensor] = None,
                gates_bf16: Optional[Tensor] = None, dhn_bf16: Optional[Tensor] = None, bias_part: Optional[Tensor] = None):
     """rnn_bwd for a layer whose output feeds a BatchNorm1d: `dyn` is the gradient wrt the BatchNorm's OUTPUT, `bn_x` its input, `sums` the
-    (2, H) result of bn1d_bwd_sums.  The K-split kernel applies the elementwise BatchNorm backward on the fly (rnn_last_path() & 16);
+    (s0, s1) result of bn1d_bwd_sums.  The K-split kernel applies the elementwise BatchNorm backward on the fly (rnn_last_path() & 16);
     any other kernel family gets it materialised first."""
-    _chk_f32(dyn, bn_x, mean, var, gamma, sums, gx, aux, hbuf, bias_part)
-    assert sums.is_contiguous() and sums.shape == (2, H) and bn_x.shape == (T * B, H) and dyn.shape == (T * B, H)
+    s0, s1 = sums
+    _chk_f32(dyn, bn_x, mean, var, gamma, s0, s1, gx, aux, hbuf, bias_part)
+    assert s0.is_contiguous() and s1.is_contiguous() and s0.numel() == H == s1.numel() and bn_x.shape == (T * B, H) and dyn.shape == (T * B, H)
     lib = _lib.load()
     wsb = lib.ds2_rnn_bwd_workspace_bytes(gates, B, H, int(bf16))
     ws = _ws(wsb, dyn.device)
     scratch = torch.empty(T * B, H, dtype=torch.float32, device=dyn.device)      # (untouched by a fused launch: the caching allocator's cost only)
     _lib.check(lib.ds2_rnn_bwd_bn(gates, dyn.data_ptr(), _row_pitch(dyn), bn_x.data_ptr(), _row_pitch(bn_x), mean.data_ptr(), var.data_ptr(),
-                                  gamma.data_ptr(), sums[0].data_ptr(), sums[1].data_ptr(), BN_EPS, scratch.data_ptr(), _ptr(gx), aux.data_ptr(),
+                                  gamma.data_ptr(), s0.data_ptr(), s1.data_ptr(), BN_EPS, scratch.data_ptr(), _ptr(gx), aux.data_ptr(),
                                   hbuf.data_ptr(), wp_bwd.data_ptr(), lens_dev.data_ptr(), T, B, H, int(bf16), _ptr(dgx_bf16), _ptr(gates_bf16),
                                   _ptr(dhn_bf16), _ptr(bias_part), ws.data_ptr(), wsb, _stream()), "ds2_rnn_bwd_bn")
 

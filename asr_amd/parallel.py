@@ -47,6 +47,11 @@ class BucketedAllReducer:
         rnn_names = [n for n in self.buckets if n.startswith("rnns.")]
         self._release_on = min(rnn_names, key=lambda n: int(n.split(".")[1])) if rnn_names else None
 
+    @property
+    def active(self) -> bool:
+        """False on a single rank (unless forced): on_bucket / finish do nothing, the gradient buffers are never touched by a collective."""
+        return self.world > 1 or bool(self.force)
+
     def on_bucket(self, name: str):
         """Called by engine.backward when bucket `name`'s gradient kernels are enqueued."""
         if self.world == 1 and not self.force:

@@ -202,7 +202,7 @@ class DeepSpeechTrainer:
                 pin["loss_done"].record(pin["stream"])
             loss.record_stream(pin["stream"])
             red = self._get_reducer()
-            engine.backward(W, Gr, model._cfg, ctx, dlogits, on_bucket=red.on_bucket)
+            engine.backward(W, Gr, model._cfg, ctx, dlogits, on_bucket=red.on_bucket if red.active else None)
             red.finish()
             pin["loss_done"].synchronize()                                   # the step's single host wait: CTC done (backward is running)
             loss_value = float(pin["loss"][0])
@@ -323,7 +323,7 @@ class DeepSpeechTrainer:
             nll, dlogits = ops.ctc_loss(logits, tg, off, lens_dev, tl, max_u, 1.0 / B, want_grad=True)
             loss = nll.sum() / B
             red = self._get_reducer()
-            engine.backward(W, Gr, model._cfg, ctx, dlogits, on_bucket=red.on_bucket)
+            engine.backward(W, Gr, model._cfg, ctx, dlogits, on_bucket=red.on_bucket if red.active else None)
             red.finish()
             loss_value = loss.item()
             starved = self._persistent_starved()                             # the device is idle here

@@ -650,6 +650,8 @@ def test_ksplit_backward_with_fused_batchnorm_backward(dev, kind, H, B, T):
     dy = ops.bn1d_bwd(dyn, x, mean, var, gamma, dgam, dbet)
     sums = ops.bn1d_bwd_sums(dyn, x, mean, var, gamma)
     assert torch.equal(sums[0], dbet) and torch.equal(sums[1], dgam), "the sums-only call must give exactly the gradients of beta and gamma"
+    into = (torch.empty(H, device=dev), torch.empty(H, device=dev))           # ... and write them where it is told to (the gradient buffers)
+    assert ops.bn1d_bwd_sums(dyn, x, mean, var, gamma, out=into)[0] is into[0] and torch.equal(into[0], dbet) and torch.equal(into[1], dgam)
     for flags in (0, 64):
         lib.ds2_debug_flags(flags)
         a = outs()
