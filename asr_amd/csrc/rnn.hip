@@ -680,6 +680,9 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
       while (pend) {
         // only the chunks that are still missing are read again: a blanket re-read of the whole operand by every waiting wave competes
         // with the very stores it is waiting for
+#ifdef DS2_RNN_TRACE
+        pt_acc[7] += 1;                                   // (trace build: poll passes, summed over the steps)
+#endif
         poll_pass<NCW * MB>(av, goff, xin, pend);
 #pragma unroll
         for (int k = 0; k < NCW; ++k)
@@ -722,6 +725,17 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
     }
     vm_drained();                                       // (the gather has waited for everything; tell the compiler)
     PTRACE(1);                                          // gather done
+#if defined(DS2_RNN_TRACE) && defined(DS2_DIAG_SECONDPASS)
+    if (s > 0) {                                        // diagnostic: one more full pass over data that is certainly there -> slot 6
+      u32x4_ dv[NCW * MB];
+#pragma unroll
+      for (int k = 0; k < NCW * MB; ++k) dv[k] = u32x4_{0u, 0u, 0u, 0u};
+      poll_pass<NCW * MB>(dv, goff, xbuf + (long long)((s - 1) & 3) * bufbytes + dirbase, pend0);
+#pragma unroll
+      for (int k = 0; k < NCW * MB; ++k) asm volatile("" ::"v"(dv[k]));
+      PTRACE(6);
+    }
+#endif
     if (s > 0) {
 #pragma unroll
       for (int g = 0; g < G; ++g) pgx[g] = pgx_next[g];  // x-projections of THIS step: loaded one step ago, landed

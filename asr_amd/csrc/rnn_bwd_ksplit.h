@@ -203,6 +203,9 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char
       int spins = 0;
       unsigned pend = pend0;
       while (pend) {
+#ifdef DS2_RNN_TRACE
+        pt_acc[7] += 1;                                     // (trace build: poll passes, summed over the steps)
+#endif
         poll_pass<NL>(av, goff, xin, pend);
 #pragma unroll
         for (int i = 0; i < NL; ++i)

@@ -1,16 +1,13 @@
 #!/bin/bash
-# same-box A/B of two builds of the library (asr_amd/lib/libds2hip.so vs libds2hip_b.so) on the recurrent micro-benchmark and c3
+# same-box A/B of two builds of the library (asr_amd/lib/libds2hip.so vs libds2hip_b.so): the c3 bench's step time and its in-region recurrence
+# times; TESTS=1 also runs the recurrence parity tests on the B build
 cd "$(dirname "$0")/.."
 for rep in 1 2; do
 for lib in libds2hip.so libds2hip_b.so; do
   echo "== $lib (rep $rep)"
-  DS2_LIB_PATH=$PWD/asr_amd/lib/$lib ABLATE_SKIP=1 timeout 200 python - <<'PY' 2>&1 | grep -v amdgpu.ids
-import os, sys
-sys.path.insert(0, "scripts")
-from ablate_rnn import run
-for (name, G, H, B) in [("c3", 3, 1024, 64), ("c4", 4, 1280, 32)]:
-    f = min(run(G, H, B, 501, False, 0, True) for _ in range(3)); b = min(run(G, H, B, 501, True, 0, True) for _ in range(3))
-    print(f"{name} bf16 fwd {f:6.2f} bwd {b:6.2f} us/step", flush=True)
-PY
-  DS2_LIB_PATH=$PWD/asr_amd/lib/$lib timeout 300 python bench.py --workload c3 --steps 8 --warmup 3 --no-cpu-baseline 2>&1 | grep -o '"ms_per_step": [0-9.]*'
+  DS2_LIB_PATH=$PWD/asr_amd/lib/$lib timeout 300 python bench.py --workload ${WL:-c3} --steps 8 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); r=d['roofline']; f,b=(r,r['second_kernel']) if 'fwd' in r['kernel'] else (r['second_kernel'],r)
+print('ms_per_step', round(d['ms_per_step'],2), 'fwd us/step', round(f['us_per_time_step'],3), 'bwd us/step', round(b['us_per_time_step'],3), 'starved', d.get('persistent_starved_steps'))"
 done; done
+if [ -n "$TESTS" ]; then DS2_LIB_PATH=$PWD/asr_amd/lib/libds2hip_b.so timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q -p no:cacheprovider -x -k "rnn_fwd_bwd or persistent or ksplit" 2>&1 | grep -v amdgpu.ids | tail -3; fi

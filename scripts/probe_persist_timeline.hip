@@ -70,6 +70,9 @@ int main(int argc, char** argv) {
       for (int w = 0; w < NW; ++w) printf(" %5.2f", (double)tr[(kind * NW + w) * 8 + k] / T * tick);
       printf("  us (waves 0..7)\n");
     }
+    printf("  %-32s", "poll passes per step");
+    for (int w = 0; w < NW; ++w) printf(" %5.2f", (double)tr[(kind * NW + w) * 8 + 7] / (T - 1));
+    printf("  (waves 0..7)\n");
   }
   return 0;
 }
