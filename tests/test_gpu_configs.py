@@ -303,13 +303,17 @@ def test_weight_gradients_tn_form_vs_transposing_cast_path(rnn, hidden, layers, 
 
 
 # ---------------------------------------------------------------------------------------------------------------- full depth
-@pytest.mark.parametrize("rnn,hidden,layers,classes,t_ins", [("gru", 1024, 5, 29, [501, 433, 371, 290]), ("lstm", 1280, 7, 29, [301, 250, 188])])
+@pytest.mark.parametrize("rnn,hidden,layers,classes,t_ins", [("gru", 1024, 5, 29, [501, 433, 371, 290]), ("lstm", 1280, 7, 29, [301, 250, 188]),
+                                                             ("gru", 768, 5, 29, [401, 350, 290, 211]),
+                                                             ("gru", 1024, 5, 80, [301, 280, 255, 230, 200, 171, 140, 101])])
 def test_full_depth_step_vs_packed_cpu_oracle(rnn, hidden, layers, classes, t_ins):
-    """The metric configuration's own depth AND width (5 x 1024 BiGRU; likewise c4's 7 x 1280 BiLSTM) against the CPU oracle in ONE comparison:
-    a ragged batch of 5 s utterances (T = 251 recurrent steps) through all layers, fp32 mode — logits, loss and EVERY parameter gradient
+    """The metric configuration's own depth AND width (5 x 1024 BiGRU; likewise c4's 7 x 1280 BiLSTM, c2's 5 x 768 and c5's 80 labels) against
+    the CPU oracle in ONE comparison: a ragged batch of utterances through all layers, fp32 mode — logits, loss and EVERY parameter gradient
     within north_star's 1e-3 of `oracle/ds2_packed.py`, the restatement in the reference's own packed-sequence formulation
     (pack_padded_sequence -> aten gru / lstm -> pad_packed_sequence, blocks.py:87-89; pinned against the reference's goldens), which is fast
-    enough on the host cores for this size.  The bf16 mode of the same step is held to its stated tolerances beside it."""
+    enough on the host cores for this size.  The bf16 mode of the same step is held to its stated tolerances beside it; the batch of 8 (the
+    c5 case) takes the bf16 mode through the train step's own schedule: packed gate records, persistent forward and K-split backward
+    recurrences with the BatchNorm1d backward applied inside, TN-form weight gradients."""
     from oracle import ds2_packed as P
     from asr_amd import CTCLoss
     cfg = dict(rnn=rnn, hidden=hidden, layers=layers, classes=classes, t_ins=t_ins)
@@ -328,6 +332,9 @@ def test_full_depth_step_vs_packed_cpu_oracle(rnn, hidden, layers, classes, t_in
         out, out_lens = model.forward(x.cuda(), lens)
         loss = CTCLoss(reduction="sum")(out.transpose(0, 1), targets, out_lens, tsz) / B
         loss.backward()
+        if precision == "bf16" and B % 8 == 0 and hidden % 256 == 0:
+            from asr_amd import ops
+            assert ops.rnn_last_path() & 22 == 22, "the train step's own schedule: persistent K-split backward with the BatchNorm backward inside"
         # logits are compared on the valid frames (beyond a sample's length both sides hold BatchNorm-of-zero garbage that CTC ignores)
         e_logits = max(rel_l2(out[b, :int(out_lens[b])].detach().cpu().numpy(), out_ref[b, :int(out_lens[b])].detach().numpy()) for b in range(B))
         e_loss = abs(float(loss.detach()) - float(loss_ref.detach())) / float(loss_ref.detach())
