@@ -175,9 +175,17 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst_wave_base
 // PP (ping-pong, 2 x 4 waves only): the two wave groups (rows 0-127 / 128-255 of the tile = one wave per SIMD each) run the k-steps
 // half a step out of phase, held there by two raw barriers per k-step: while one group issues its 8 MFMAs the other reads its next
 // fragments and issues DMA, so the matrix pipe of every SIMD always has a wave in its MFMA cluster.
-template <int WM, int WN, bool PP = false>
+// PERS (2 x 4 waves, no split-K, K a multiple of 128): PERSISTENT form for short reductions.  With K = 1024 a tile is 16 k-tiles = 29 us of
+// main loop, and a workgroup that computes ONE tile pays ~12 us around it (dispatch, pointer set-up, the first operand DMA's round trip,
+// the write-out of 256 KB): 29 % of the forward projection.  Here the grid is one workgroup per CU and each walks tiles orig, orig + grid,
+// ...: the k-tile stream simply continues across the tile boundary — the DMA of the NEXT tile's first two k-tiles goes out in the last two
+// k-steps of the current one, its first fragments are read behind the last MFMAs as always, and the epilogue (wave-private LDS patch outside
+// the operand buffers, bias fetched at the tile's start) runs while that DMA lands.  Same products, same order: bit-identical results.
+constexpr int G_PATCH = 8 * 16 * 40 * 4;          // PERS epilogue: 8 wave-private patches of 16 rows x 40 floats behind the operand buffers
+template <int WM, int WN, bool PP = false, bool PERS = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(BArgs g, int ntx, int nty) {
   static_assert(!PP || (WM == 2 && WN == 4), "ping-pong schedule is written for 2 x 4 waves");
+  static_assert(!PERS || (WM == 2 && WN == 4 && !PP), "persistent form: 2 x 4 waves, software-pipelined loop");
   constexpr int NWV = WM * WN;
   constexpr int NI = 8 / WM, NJ = 8 / WN;   // 32 x 32 MFMA tiles per wave along M / N
   constexpr int NP = 32 / NWV;              // 8-row pieces per wave per operand tile
@@ -189,10 +197,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(BArgs g
   // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs, so give each XCD one contiguous run of the
   // (row-tile major) tile list: the tiles sharing an A row-tile then hit the same 4 MB L2.  (bijective for any count)
   const int nt = ntx * nty;
-  const int orig = blockIdx.x;
-  const int xcd = orig & 7, q8 = nt >> 3, r8 = nt & 7;
-  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-  const int m0 = (tile / ntx) * 256, n0 = (tile % ntx) * 256;
+  int orig = blockIdx.x;
+  auto tile_origin = [&](int o, int& tm0, int& tn0) {
+    const int xcd = o & 7, q8 = nt >> 3, r8 = nt & 7;
+    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (o >> 3);
+    tm0 = (tile / ntx) * 256; tn0 = (tile % ntx) * 256;
+  };
+  int m0, n0;
+  tile_origin(orig, m0, n0);
   const int kbeg = zs * g.kchunk;
   const int kend = min(g.K, kbeg + g.kchunk);
   const int nkt = (kend - kbeg + BK - 1) / BK;
@@ -300,17 +312,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(BArgs g
     // rows beyond M / N are CLAMPED to the last valid row instead of zero-filled: they only feed C rows / columns that are never stored
     const char* qA[NP];
     const char* qB[NP];
+    auto retarget = [&](int tm0, int tn0) {
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      const int r = (wave + NWV * i) * 8 + prow;
-      qA[i] = reinterpret_cast<const char*>(A + (long long)min(m0 + r, g.M - 1) * g.lda + segk[i] + kbeg);
-      qB[i] = reinterpret_cast<const char*>(B + (long long)min(n0 + r, g.N - 1) * g.ldb + segk[i] + kbeg);
-    }
+      for (int i = 0; i < NP; ++i) {
+        const int r = (wave + NWV * i) * 8 + prow;
+        qA[i] = reinterpret_cast<const char*>(A + (long long)min(tm0 + r, g.M - 1) * g.lda + segk[i] + kbeg);
+        qB[i] = reinterpret_cast<const char*>(B + (long long)min(tn0 + r, g.N - 1) * g.ldb + segk[i] + kbeg);
+      }
+    };
+    retarget(m0, n0);
+    bool more_tiles = false;                            // PERS: another tile follows this one (its first k-tiles are staged from inside this one)
     const int nfull = (g.nt_store & 2) ? 1 : (kend - kbeg) / BK;       // tiles that lie completely inside [kbeg, kend)  (bit 1: timing experiment)
     // piece i (8 rows of A + 8 rows of B per wave) of tile kt -> buffer buf.  Tiles are staged in order, so the pointers just advance.
     auto stage_piece = [&](int buf, int kt, int i) {
       char* dA = ldsg + buf * 2 * G_TILE + (wave + NWV * i) * 1024;
-      if (kt < nfull) {
+      if (PERS || kt < nfull) {                       // (PERS: K is a multiple of the k-tile; `kt` may run into the next tile)
         glds16(qA[i], dA);
         glds16(qB[i], dA + G_TILE);
         qA[i] += BK * 2;
@@ -374,7 +390,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(BArgs g
                                                                      __builtin_bit_cast(bf16x8, fb[cur][m_ % NJ]), acc[m_ / NJ][m_ % NJ], 0, 0, 0); \
       __builtin_amdgcn_sched_barrier(0);                                                                                              \
       G_RD1(nxt, off_n, kk_n, m_);                                                                                                    \
-      if ((DMA) && m_ < NP && kt + 2 < nkt) stage_piece(kt & 1, kt + 2, m_);                                                          \
+      if ((DMA) && m_ < NP && (kt + 2 < nkt || more_tiles)) stage_piece(kt & 1, kt + 2, m_);                                          \
       __builtin_amdgcn_sched_barrier(0);                                                                                              \
     }                                                                                                                                 \
   } while (0)
@@ -389,20 +405,82 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(BArgs g
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = 0; r < NR; ++r) G_RD1(0, 0u, 0, r);
-    for (int kt = 0; kt < nkt; ++kt) {
-      const unsigned boff = (kt & 1) * 2 * G_TILE, noff = ((kt + 1) & 1) * 2 * G_TILE;
-      __builtin_amdgcn_sched_barrier(0);
-      G_STEP(0, 1, boff, 1, false);
-      G_STEP(1, 0, boff, 2, false);
-      G_STEP(0, 1, boff, 3, false);
-      // own DMA of tile kt+1 has landed and own reads of buffer kt&1 are complete; past the barrier that holds for every wave:
-      // tile kt+1 may be read, buffer kt&1 may be refilled (the last k-step's MFMAs still run from registers)
-      G_RETIRE_ALL("s_waitcnt vmcnt(0)");
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      G_STEP(1, 0, noff, 0, true);                     // (after the last tile: harmless reads of stale LDS, retired below)
+    for (;;) {                                         // PERS: one iteration per tile of this workgroup; else exactly one
+      int m0n = 0, n0n = 0;
+      f32x4 pbv[NJ];                                   // PERS: the tile's bias values, fetched here so that the epilogue waits for nothing
+      if constexpr (PERS) {
+        more_tiles = orig + (int)gridDim.x < nt;
+        if (more_tiles) tile_origin(orig + (int)gridDim.x, m0n, n0n);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int col = n0 + wn * (NJ * 32) + j * 32 + (lane & 7) * 4;
+          pbv[j] = (g.bias && col < g.N) ? *reinterpret_cast<const f32x4*>(g.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      }
+      for (int kt = 0; kt < nkt; ++kt) {
+        const unsigned boff = (kt & 1) * 2 * G_TILE, noff = ((kt + 1) & 1) * 2 * G_TILE;
+        __builtin_amdgcn_sched_barrier(0);
+        G_STEP(0, 1, boff, 1, false);
+        G_STEP(1, 0, boff, 2, false);
+        G_STEP(0, 1, boff, 3, false);
+        // own DMA of tile kt+1 has landed and own reads of buffer kt&1 are complete; past the barrier that holds for every wave:
+        // tile kt+1 may be read, buffer kt&1 may be refilled (the last k-step's MFMAs still run from registers)
+        G_RETIRE_ALL("s_waitcnt vmcnt(0)");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PERS) {
+          if (more_tiles && kt == nkt - 2) retarget(m0n, n0n);   // from here on the DMA stages the next tile's k-tiles 0 and 1
+        }
+        G_STEP(1, 0, noff, 0, true);                   // (after the last tile: harmless reads of stale LDS, retired below)
+      }
+      if constexpr (!PERS) break;
+      if constexpr (PERS) {
+        // ---- epilogue of this tile (the next tile's operands are landing meanwhile; its k-step-0 fragments are already on their way into
+        // fragment set 0): every 32 x 32 accumulator tile through the wave-private patch in two halves of 16 rows, out as 16-byte stores
+        constexpr int EP = 40;
+        float* patch = reinterpret_cast<float*>(ldsg + G_LDS) + wave * (16 * EP);
+        const int prow8 = lane >> 3, pc4 = (lane & 7) * 4;
+        float* C = g.C;
+        const long long ldc = g.ldc;
+        const bool stream_out = (g.nt_store & 1) != 0;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const int col = n0 + wn * (NJ * 32) + j * 32 + pc4;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+              for (int r = 0; r < 8; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * half) * EP + l31] = acc[i][j][hh * 8 + r];
+              __builtin_amdgcn_wave_barrier();
+#pragma unroll
+              for (int it = 0; it < 2; ++it) {
+                const int rl = it * 8 + prow8;
+                const int row = m0 + wm * (NI * 32) + i * 32 + hh * 16 + rl;
+                f32x4 v = *reinterpret_cast<const f32x4*>(&patch[rl * EP + pc4]);
+                if (row < g.M && col < g.N) {
+                  v += pbv[j];
+                  f32x4* pc = reinterpret_cast<f32x4*>(C + (long long)row * ldc + col);
+                  if (stream_out) __builtin_nontemporal_store(v, pc);
+                  else *pc = v;
+                }
+              }
+              __builtin_amdgcn_wave_barrier();
+            }
+          }
+        }
+        if (!more_tiles) break;
+        orig += (int)gridDim.x; m0 = m0n; n0 = n0n;
+      }
     }
     G_RETIRE_ALL("s_waitcnt");
+    if constexpr (PERS) return;
 #undef G_RD1
 #undef G_ISA
 #undef G_IDX
@@ -925,7 +1003,32 @@ extern "C" int ds2_gemm_bf16_nt(int M, int N, int K, const void* A, int lda, lon
       }
       hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<2, 4, true>), dim3(ntx * nty, 1, batch * splitk), dim3(512), G_LDS, s, g, ntx, nty);
     } else if (w16) hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<4, 4>), dim3(ntx * nty, 1, batch * splitk), dim3(1024), G_LDS, s, g, ntx, nty);
-    else hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<2, 4>), dim3(ntx * nty, 1, batch * splitk), dim3(512), G_LDS, s, g, ntx, nty);
+    else {
+      // persistent form (one workgroup per CU walking several tiles; see the kernel): short reductions with more tiles than CUs, plain write-out
+      static const char* pe = getenv("DS2_GEMM_PERS");     // "0": one workgroup per tile for every shape (A/B switch)
+      static int cus = 0;
+      if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                  ? prop.multiProcessorCount : 1;
+      }
+      const int nkt = K / BK;
+      const bool wide = (N % 4) == 0 && (ldc % 4) == 0 && ((uintptr_t)C % 16) == 0 && (!bias || ((uintptr_t)bias % 16) == 0);
+      const bool pers = !(pe && pe[0] == '0') && batch == 1 && splitk == 1 && !accumulate && (K % BK) == 0 && nkt >= 2 && (nkt % 2) == 0 &&
+                        nkt <= 128 && wide && !(g.nt_store & ~1) && ntx * nty > cus;
+      if (pers) {
+        static bool pattr = false;
+        if (!pattr) {
+          DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_nt_glds_kernel<2, 4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      G_LDS + G_PATCH));
+          pattr = true;
+        }
+        hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<2, 4, false, true>), dim3(cus, 1, 1), dim3(512), G_LDS + G_PATCH, s, g, ntx, nty);
+      } else {
+        hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<2, 4>), dim3(ntx * nty, 1, batch * splitk), dim3(512), G_LDS, s, g, ntx, nty);
+      }
+    }
     DS2_LAUNCH_CHECK("gemm_bf16_nt_glds_kernel");
   } else {
     dim3 grid(ceil_div(N, BN), ceil_div(M, BM), batch * splitk);

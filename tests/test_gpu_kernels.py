@@ -115,6 +115,26 @@ def test_gemm_bf16_large_tiles(dev, M, N, K, splitk):
         assert torch.equal(out, out2) and rel_l2(out.cpu(), ref.cpu()) < 3e-6
 
 
+@pytest.mark.parametrize("M,N,K,use_bias", [(4600, 3972, 1024, True), (4360, 4100, 128, False), (4100, 4360, 6144, False), (32064, 6144, 1024, True)])
+def test_gemm_bf16_persistent_tiles_bit_identical(dev, M, N, K, use_bias):
+    """The persistent form of the 256 x 256 NT kernel (one workgroup per CU walking several tiles, the next tile's operands staged from
+    inside the current one; taken for short reductions with more tiles than CUs — the forward input projection of every recurrent layer,
+    blocks.py:76-78 / 88) against the one-workgroup-per-tile form of the same kernel: an accumulating call into zeros never takes the
+    persistent form, and x + 0 is x — the two results must agree bit for bit, ragged edges included; fp64 check at the smaller sizes."""
+    from asr_amd import ops
+    A, B, bias = T_(50, M, K), T_(51, N, K), T_(52, N)
+    Ab, Bb = ops.cast_bf16(g(A, dev)), ops.cast_bf16(g(B, dev))
+    bd = g(bias, dev) if use_bias else None
+    out = ops.gemm_bf16_nt(Ab, Bb, bias=bd, splitk=1)
+    ref = torch.zeros(M, N, device=dev)
+    ops.gemm_bf16_nt(Ab, Bb, bias=bd, out=ref, accumulate=True, splitk=1)
+    assert torch.equal(out, ref), float((out - ref).abs().max())
+    assert torch.equal(out, ops.gemm_bf16_nt(Ab, Bb, bias=bd, splitk=1))
+    if M * N < 3e7:
+        r64 = Ab.double() @ Bb.double().t() + (bd.double() if use_bias else 0.0)
+        assert rel_l2(out.cpu(), r64.cpu()) < 3e-6
+
+
 @pytest.mark.parametrize("form", ["nt", "tn"])
 @pytest.mark.parametrize("M,N,K,splitk,batch_bias", [(2048, 2048, 2056, 2, True), (4096, 1024, 8192, 4, False), (2056, 2048, 1400, 2, True)])
 def test_gemm_bf16_splitk_is_the_ordered_sum_of_slice_products(dev, form, M, N, K, splitk, batch_bias):
