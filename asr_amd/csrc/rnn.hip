@@ -730,7 +730,18 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
       u32x4_ dv[NCW * MB];
 #pragma unroll
       for (int k = 0; k < NCW * MB; ++k) dv[k] = u32x4_{0u, 0u, 0u, 0u};
+#if DS2_DIAG_SECONDPASS == 2                           // ... with PLAIN loads (through the L1, which the sc1 polls have not filled)
+      if constexpr (NCW * MB == 4) {
+        const char* dbase = xbuf + (long long)((s - 1) & 3) * bufbytes + dirbase;
+        asm volatile("global_load_dwordx4 %0, %4, %8\n\tglobal_load_dwordx4 %1, %5, %8\n\tglobal_load_dwordx4 %2, %6, %8\n\t"
+                     "global_load_dwordx4 %3, %7, %8\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(dv[0]), "=&v"(dv[1]), "=&v"(dv[2]), "=&v"(dv[3])
+                     : "v"(goff[0]), "v"(goff[1]), "v"(goff[2]), "v"(goff[3]), "s"(dbase)
+                     : "memory");
+      }
+#else
       poll_pass<NCW * MB>(dv, goff, xbuf + (long long)((s - 1) & 3) * bufbytes + dirbase, pend0);
+#endif
 #pragma unroll
       for (int k = 0; k < NCW * MB; ++k) asm volatile("" ::"v"(dv[k]));
       PTRACE(6);
