@@ -115,7 +115,8 @@ def test_gemm_bf16_large_tiles(dev, M, N, K, splitk):
         assert torch.equal(out, out2) and rel_l2(out.cpu(), ref.cpu()) < 3e-6
 
 
-@pytest.mark.parametrize("M,N,K,use_bias", [(4600, 3972, 1024, True), (4360, 4100, 128, False), (4100, 4360, 6144, False), (32064, 6144, 1024, True)])
+@pytest.mark.parametrize("M,N,K,use_bias", [(4600, 3972, 1024, True), (4360, 4100, 128, False), (4100, 4360, 6144, False), (3072, 3800, 1312, True),
+                                            (4600, 3972, 1312, False), (32064, 6144, 1024, True)])
 def test_gemm_bf16_persistent_tiles_bit_identical(dev, M, N, K, use_bias):
     """The persistent form of the 256 x 256 NT kernel (one workgroup per CU walking several tiles, the next tile's operands staged from
     inside the current one; taken for short reductions with more tiles than CUs — the forward input projection of every recurrent layer,
