@@ -93,6 +93,8 @@ SIGNATURES = {
     "ds2_rnn_bwd": (i32, [i32, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
     "ds2_ctc_workspace_bytes": (sz, [i32, i32, i32]),
     "ds2_ctc_loss_f32": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, i32, f32, vp, sz, vp]),
+    "ds2_ctc_batch_mean_f32": (i32, [vp, i32, vp, vp]),
+    "ds2_add_i64": (i32, [vp, i32, i64, vp]),
     "ds2_softmax_rows_f32": (i32, [vp, i32, vp, i32, i32, i32, vp]),
     "ds2_greedy_decode_workspace_bytes": (sz, [i32, i32]),
     "ds2_greedy_decode_f32": (i32, [vp, i64, i64, i32, i32, i32, vp, i32, vp, vp, vp, vp, sz, vp]),

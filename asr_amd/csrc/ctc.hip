@@ -277,6 +277,25 @@ extern "C" int ds2_softmax_rows_f32(const float* x, int ldx, float* y, int ldy, 
   return 0;
 }
 
+namespace {
+// loss = sum_b nll[b] / B in a fixed order (lane-strided partial sums, then a shuffle tree): one wave
+__global__ __launch_bounds__(64) void batch_mean_kernel(const float* __restrict__ nll, int B, float* __restrict__ out) {
+  float s = 0.f;
+  for (int b = threadIdx.x; b < B; b += 64) s += nll[b];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (threadIdx.x == 0) out[0] = s / (float)B;
+}
+}  // namespace
+
+// out[0] = (sum of the per-utterance losses) / B: `loss = criterion(...) / inputs.size(0)` (trainers/deepspeech_trainer.py:110-112) on the device
+extern "C" int ds2_ctc_batch_mean_f32(const float* nll_dev, int B, float* out_dev, void* stream) {
+  DS2_REQUIRE(nll_dev && out_dev && B > 0, "ds2_ctc_batch_mean_f32: bad args");
+  hipLaunchKernelGGL(batch_mean_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, nll_dev, B, out_dev);
+  DS2_LAUNCH_CHECK("batch_mean_kernel");
+  return 0;
+}
+
 extern "C" size_t ds2_ctc_workspace_bytes(int T, int B, int max_target_len) {
   const size_t Smax = 2 * (size_t)max_target_len + 1;
   return align_up((size_t)T * B * sizeof(float), 256) + 2 * (size_t)B * T * Smax * sizeof(float);

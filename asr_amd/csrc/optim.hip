@@ -74,6 +74,22 @@ extern "C" int ds2_adamw_f32(float* p, const float* g, float* m, float* v, long 
   return ds2_adamw_gated_f32(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, nullptr, stream);
 }
 
+namespace {
+__global__ void add_i64_kernel(long long* __restrict__ x, int n, long long v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] += v;
+}
+}  // namespace
+
+// x[0..n) += v for a small int64 vector: every BatchNorm's num_batches_tracked in one launch (they are views of one buffer: asr_amd/params.py)
+extern "C" int ds2_add_i64(long long* x, int n, long long v, void* stream) {
+  DS2_REQUIRE(x && n >= 0, "ds2_add_i64: bad args");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(add_i64_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, x, n, v);
+  DS2_LAUNCH_CHECK("add_i64_kernel");
+  return 0;
+}
+
 extern "C" int ds2_scale_f32(float* x, long long n, float s, void* stream) {
   DS2_REQUIRE(x && n >= 0, "ds2_scale_f32: bad args");
   if (n == 0) return 0;

@@ -252,7 +252,7 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
         ctx.y_last, ctx.fc_xn, ctx.fc_stats = xin, xn, (mean, var)
     if training:
         if "_bn_counters" in W:
-            W["_bn_counters"] += 1                     # all num_batches_tracked (views of one buffer: asr_amd/params.py) in one launch
+            ops.add_i64(W["_bn_counters"], 1)          # all num_batches_tracked (views of one buffer: asr_amd/params.py) in one launch
         else:
             for name in ([cp + "1", cp + "4", fp + "0"] + [f"rnns.{l}.batch_norm.module" for l in range(1, L)]):
                 W[name + ".num_batches_tracked"] += 1

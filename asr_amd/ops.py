@@ -808,6 +808,21 @@ def ctc_loss(logits: Tensor, targets_dev: Tensor, tgt_off_dev: Tensor, in_lens_d
     return nll, grad
 
 
+def ctc_batch_mean(nll: Tensor) -> Tensor:
+    """(1,) fp32 = nll.sum() / B, on the device in a fixed order (trainers/deepspeech_trainer.py:110-112)."""
+    _chk_f32(nll)
+    assert nll.dim() == 1 and nll.is_contiguous()
+    out = torch.empty(1, dtype=torch.float32, device=nll.device)
+    _lib.check(_lib.load().ds2_ctc_batch_mean_f32(nll.data_ptr(), nll.numel(), out.data_ptr(), _stream()), "ds2_ctc_batch_mean_f32")
+    return out
+
+
+def add_i64(x: Tensor, v: int = 1):
+    """x += v for a small contiguous int64 vector (the BatchNorm num_batches_tracked counters)."""
+    assert x.dtype == torch.int64 and x.is_contiguous() and x.is_cuda
+    _lib.check(_lib.load().ds2_add_i64(x.data_ptr(), x.numel(), int(v), _stream()), "ds2_add_i64")
+
+
 def softmax_rows(x: Tensor) -> Tensor:
     """softmax over the last dim of a (rows, C) row-major view."""
     _chk_f32(x)

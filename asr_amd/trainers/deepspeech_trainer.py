@@ -191,7 +191,7 @@ class DeepSpeechTrainer:
             self._snapshot_bn_stats(self._step_index)                        # (restored if the device gate reports this step starved)
             logits, ctx = engine.forward(W, model._cfg, inputs, lens_dev, training=True, save=True)
             nll, dlogits = ops.ctc_loss(logits, tg, off, lens_dev, tl, max_u, 1.0 / B, want_grad=True)
-            loss = (nll.sum() / B).reshape(1)
+            loss = ops.ctc_batch_mean(nll)                                   # (1,): sum of the per-utterance losses / B
             # the loss value travels to pinned host memory on a copy stream that waits for the CTC kernels only
             pin = self._pinned()
             have_loss = torch.cuda.Event()
@@ -321,7 +321,7 @@ class DeepSpeechTrainer:
             Gr = model._flat.tensors(model, grads=True)
             logits, ctx = engine.forward(W, model._cfg, inputs, lens_dev, training=True, save=True)
             nll, dlogits = ops.ctc_loss(logits, tg, off, lens_dev, tl, max_u, 1.0 / B, want_grad=True)
-            loss = nll.sum() / B
+            loss = ops.ctc_batch_mean(nll)[0]
             red = self._get_reducer()
             engine.backward(W, Gr, model._cfg, ctx, dlogits, on_bucket=red.on_bucket if red.active else None)
             red.finish()

@@ -244,6 +244,10 @@ int ds2_ctc_loss_f32(const float* logits, int ld, int T, int B, int C, const int
                      const int* in_lens_dev, const int* tgt_lens_dev, int max_target_len, float* nll_dev, float* grad, int ldg,
                      float grad_scale, void* ws, size_t ws_bytes, void* stream);
 
+/* out[0] = sum_b nll[b] / B on the device, fixed summation order: `loss = criterion(...) / inputs.size(0)`,
+ * trainers/deepspeech_trainer.py:110-112 */
+int ds2_ctc_batch_mean_f32(const float* nll_dev, int B, float* out_dev, void* stream);
+
 /* softmax over the last dim (eval-mode InferenceBatchSoftmax, modules/blocks.py:59-64) */
 int ds2_softmax_rows_f32(const float* x, int ldx, float* y, int ldy, int rows, int C, void* stream);
 
@@ -293,6 +297,8 @@ int ds2_adamw_f32(float* p, const float* g, float* m, float* v, long long n, flo
 int ds2_adamw_gated_f32(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
                         float weight_decay, int step, float grad_scale, const int* apply_flag, void* stream);
 int ds2_scale_f32(float* x, long long n, float s, void* stream);
+/* x[0..n) += v (int64): every BatchNorm's num_batches_tracked (torch.nn.BatchNorm*d.forward in training mode) in one launch */
+int ds2_add_i64(long long* x, int n, long long v, void* stream);
 
 #ifdef __cplusplus
 }

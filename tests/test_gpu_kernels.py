@@ -879,6 +879,23 @@ def test_ctc_vs_numpy_oracle_large(dev):
     assert float(grad[il[1]:, 1].abs().max()) == 0.0                             # frames beyond the length get zero grad
 
 
+def test_step_scalars_on_device(dev):
+    """The two scalar updates of a train step that are not tensor math: loss = sum of the per-utterance CTC losses / B
+    (trainers/deepspeech_trainer.py:110-112) and num_batches_tracked += 1 of every BatchNorm (torch.nn.BatchNorm*d in training mode) —
+    device kernels in stream order, so that the step issues no framework compute kernel."""
+    from asr_amd import ops
+    for B in (1, 3, 64, 257):
+        nll = g(T_(60 + B, B).abs() * 300.0, dev)
+        got = ops.ctc_batch_mean(nll)
+        ref = nll.double().sum() / B
+        assert got.shape == (1,) and abs(float(got[0]) - float(ref)) <= 2e-7 * abs(float(ref))
+    assert bool(torch.isinf(ops.ctc_batch_mean(torch.tensor([1.0, float("inf")], device=dev)))[0])     # an infeasible utterance stays visible
+    cnt = torch.arange(7, dtype=torch.int64, device=dev) * (1 << 40)
+    ops.add_i64(cnt, 1)
+    ops.add_i64(cnt, 1)
+    assert torch.equal(cnt.cpu(), torch.arange(7, dtype=torch.int64) * (1 << 40) + 2)
+
+
 def test_softmax_and_adamw(dev):
     from asr_amd import ops
     x = T_(50, 77, 29) * 3
