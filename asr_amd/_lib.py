@@ -30,6 +30,7 @@ SIGNATURES = {
     "ds2_rnn_step_gate": (i32, [vp, vp, vp]),
     "ds2_rnn_persistent_enable": (i32, [i32, i32]),
     "ds2_rnn_last_path": (i32, []),
+    "ds2_rnn_bwd_ksplit_footprint": (i32, [i32, i32, C.POINTER(i32)]),
     "ds2_gemm_f32_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "ds2_gemm_f32": (i32, [i32, i32, i32, i32, i32, vp, i32, i64, vp, i32, i64, vp, i32, i64, vp, i32, i32, i32, vp, sz, vp]),
     "ds2_gemm_bf16_workspace_bytes": (sz, [i32, i32, i32, i32]),
@@ -40,6 +41,7 @@ SIGNATURES = {
     "ds2_chanstats_from_partials_workspace_bytes": (sz, []),
     "ds2_chanstats_from_partials": (i32, [vp, i32, i32, f64, vp, vp, vp, vp, f32, vp, sz, vp]),
     "ds2_gemm_bf16_tn": (i32, [i32, i32, i32, vp, i32, i64, vp, i32, i64, vp, i32, i64, i32, i32, i32, vp, sz, vp]),
+    "ds2_gemm_bf16_tn_group": (i32, [i32, vp, i32, vp]),
     "ds2_gemm_bf16_nt": (i32, [i32, i32, i32, vp, i32, i64, vp, i32, i64, vp, i32, i64, vp, i32, i32, i32, vp, sz, vp]),
     "ds2_cast_bf16": (i32, [vp, i32, vp, i32, i32, i32, vp]),
     "ds2_cast_transpose_bf16": (i32, [vp, i32, vp, i32, i32, i32, vp]),
@@ -111,6 +113,11 @@ SIGNATURES = {
     "ds2_adamw_gated_f32": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp, vp]),
     "ds2_scale_f32": (i32, [vp, i64, f32, vp]),
 }
+
+
+class TnProblem(C.Structure):
+    """`ds2_tn_problem` of include/ds2hip.h (one product of ds2_gemm_bf16_tn_group)."""
+    _fields_ = [("A", vp), ("B", vp), ("C", vp), ("M", i32), ("N", i32), ("K", i32), ("lda", i32), ("ldb", i32), ("ldc", i32)]
 
 
 class DS2LibraryError(RuntimeError):

@@ -941,6 +941,8 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const __bf16* __res
   }
 }
 
+#include "gemm_tn_group.h"
+
 }  // namespace
 
 extern "C" size_t ds2_gemm_bf16_workspace_bytes(int M, int N, int batch, int splitk) {
@@ -1078,6 +1080,47 @@ extern "C" int ds2_gemm_bf16_tn(int M, int N, int K, const void* A, int lda, lon
                        (const float*)nullptr, M, N, ldc, strideC, splitk, accumulate);
     DS2_LAUNCH_CHECK("splitk_reduce_bf_kernel");
   }
+  return 0;
+}
+
+// Several TN products C_p[M_p,N_p] = A_p[K_p,M_p]^T B_p[K_p,N_p] in ONE launch of the co-resident kernel (gemm_tn_group.h): a flat list of
+// 128 x 128 tiles, one workgroup per CU (at most `max_workgroups`, rounded down to a multiple of 8) walking it.  No split-K, no workspace.
+extern "C" int ds2_gemm_bf16_tn_group(int nprob, const ds2_tn_problem* probs, int max_workgroups, void* stream) {
+  DS2_REQUIRE(nprob >= 1 && nprob <= TN_MAX_PROBLEMS && probs, "ds2_gemm_bf16_tn_group: 1..%d problems", TN_MAX_PROBLEMS);
+  TnGroup g;
+  int tiles = 0;
+  for (int i = 0; i < nprob; ++i) {
+    const ds2_tn_problem& q = probs[i];
+    DS2_REQUIRE(q.A && q.B && q.C && q.M >= 8 && q.N >= 8 && q.K > 0, "ds2_gemm_bf16_tn_group: problem %d: bad dims M=%d N=%d K=%d", i, q.M, q.N, q.K);
+    DS2_REQUIRE((q.M % 8) == 0 && (q.N % 8) == 0 && (q.lda % 8) == 0 && (q.ldb % 8) == 0 && q.lda >= q.M && q.ldb >= q.N && q.ldc >= q.N,
+                "ds2_gemm_bf16_tn_group: problem %d: M, N, lda, ldb must be multiples of 8 (M=%d N=%d lda=%d ldb=%d)", i, q.M, q.N, q.lda, q.ldb);
+    DS2_REQUIRE(((uintptr_t)q.A % 16) == 0 && ((uintptr_t)q.B % 16) == 0, "ds2_gemm_bf16_tn_group: problem %d: operands must be 16-byte aligned", i);
+    TnProb& p = g.p[i];
+    p.A = (const __bf16*)q.A; p.B = (const __bf16*)q.B; p.C = q.C;
+    p.M = q.M; p.N = q.N; p.K = q.K; p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc;
+    p.ntx = ceil_div(q.N, 128);
+    p.first_tile = tiles;
+    tiles += p.ntx * ceil_div(q.M, 128);
+  }
+  for (int i = nprob; i < TN_MAX_PROBLEMS; ++i) g.p[i] = g.p[0];
+  g.nprob = nprob; g.ntiles = tiles;
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+              ? prop.multiProcessorCount : 8;
+  }
+  int grid = max_workgroups > 0 ? (max_workgroups < cus ? max_workgroups : cus) : cus;
+  if (grid > tiles) grid = tiles;
+  grid = grid < 8 ? 8 : grid / 8 * 8;                  // the tile walk deals whole runs to the 8 XCDs
+  static bool attr_set = false;
+  if (!attr_set) {
+    DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_tn_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, L_LDS_REQ));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_bf16_tn_group_kernel, dim3(grid), dim3(256), L_LDS_REQ, (hipStream_t)stream, g);
+  DS2_LAUNCH_CHECK("gemm_bf16_tn_group_kernel");
   return 0;
 }
 

@@ -1679,6 +1679,30 @@ extern "C" int ds2_rnn_poison_if_starved(float* buf, size_t n, void* stream) {
   return 0;
 }
 
+// What a workgroup of the K-split persistent backward recurrence occupies, from the binary that is loaded: out3 = {registers per lane
+// (hipFuncGetAttributes), static LDS bytes, threads}.  Returns 1 if this (gates, H) shape has a K-split instance, 0 if not.  The host
+// uses it to decide whether the co-resident weight-gradient kernel (ds2_gemm_bf16_tn_group: 4 waves x 128 registers) fits beside it.
+extern "C" int ds2_rnn_bwd_ksplit_footprint(int gates, int H, int* out3) {
+  DS2_REQUIRE(out3 && (gates == 3 || gates == 4), "ds2_rnn_bwd_ksplit_footprint: bad args");
+  out3[0] = out3[1] = out3[2] = 0;
+  if (!ksplit_shape_ok(H)) return 0;
+  const int nt = H / 128;
+  if (nt * gates * 4 > 176) return 0;
+  const void* fn = nullptr;
+#define DS2_KSF(G_, NT_)                                                           \
+  if (gates == G_ && nt == NT_) {                                                  \
+    if constexpr (NT_ * G_ * 4 <= 176) fn = (const void*)rnn_bwd_ksplit_kernel<G_, NT_>; \
+  }
+  DS2_KSF(3, 2) DS2_KSF(3, 4) DS2_KSF(3, 6) DS2_KSF(3, 8) DS2_KSF(3, 10)
+  DS2_KSF(4, 2) DS2_KSF(4, 4) DS2_KSF(4, 6) DS2_KSF(4, 8) DS2_KSF(4, 10)
+#undef DS2_KSF
+  if (!fn) return 0;
+  hipFuncAttributes at;
+  DS2_HIP(hipFuncGetAttributes(&at, fn));
+  out3[0] = at.numRegs; out3[1] = (int)at.sharedSizeBytes; out3[2] = NW * 64;
+  return 1;
+}
+
 extern "C" int ds2_rnn_persistent_enable(int forward, int backward) {
   g_persist_fwd = forward != 0;
   g_persist_bwd = backward != 0;

@@ -43,6 +43,17 @@ CONV_STATS = _os.environ.get("DS2_CONV_STATS", "1") != "0" and _os.environ.get("
 # bf16 training: the elementwise half of every BatchNorm1d backward is applied inside the K-split backward recurrence of the layer below
 # (ops.rnn_bwd_bn: one more 4-byte load per pair and step instead of a pass over (T*B, H)); 0: a separate bn1d_bwd_apply pass as before
 FUSE_BN_BWD = _os.environ.get("DS2_FUSE_BN_BWD", "1") != "0"
+# bf16 training, weight gradients of a recurrent layer whose recurrences ran as persistent launches (DS2_WGRAD_SIDE):
+#   "1" (default)  ONE launch of the co-resident grouped TN kernel (ops.gemm_bf16_tn_group: 4 waves x 128 registers, one workgroup per CU, no
+#                  split-K) on the side stream, released when the compute stream reaches the backward recurrence of the layer BELOW: the
+#                  K-split recurrence keeps 2 waves per SIMD and ~13 % of the matrix pipe busy for 1.2 ms and nothing else can run beside
+#                  it — this kernel is sized for exactly the registers / LDS it leaves, so the recurrence's residency holds by construction
+#                  (csrc/gemm_tn_group.h).  Layer 0's products run beside the conv-stack backward.  Shapes whose recurrence leaves no room
+#                  (LSTM H >= 1024: 2 x 224 registers) keep the schedule below.
+#   "main"         the same grouped kernel, on the compute stream right behind the layer's critical-path work (the one-stream schedule the
+#                  side-stream results are compared with bit for bit: tests/test_gpu_round4.py)
+#   "0"            round 3's kernels: three 256 x 256 TN launches with split-K slabs + reduce passes, compute stream
+WGRAD_SIDE = _os.environ.get("DS2_WGRAD_SIDE", "1")
 _BWD_PERSISTENT = {}      # (gates, H, B) -> did the last backward recurrence of this shape run as a persistent launch?
 _SIDE = {}
 
@@ -128,6 +139,7 @@ class Ctx:
     y_last: Optional[Tensor] = None
     fc_xn: Optional[Tensor] = None
     fc_stats: tuple = ()
+    side_used: bool = False          # backward put weight-gradient work on the side stream: the compute stream joins it at the end
 
 
 def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, training: bool, save: bool = True, debug_acts: bool = False):
@@ -259,7 +271,7 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
     return logits.view(T, B, cfg.classes), ctx
 
 
-def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy, done, private: bool):
+def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy, done, private: bool, serial_buckets: bool = False):
     """Backward of the recurrent stack in the bf16 training mode (packed gate records, bf16 dGx), DS2_OVERLAP=2 schedule: per layer
         compute stream:  recurrence(l) | weight-gradient GEMMs of layer l+1 | dXn(l) = dGx W_ih | BatchNorm1d backward(l)
         side stream:     [from the start of recurrence(l)] transposing casts of dGx(l+1) (+ db_ih), d(hn)(l+1) (+ db_hn), h(l+1), Xn(l+1)
@@ -313,6 +325,33 @@ def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy, done, private: bo
             dwih.copy_(ops.gemm_bf16_tn(dgx_bf, xn)[:, :I])
         done(f"rnns.{l}")
 
+    def weight_gradients_group(l, dgx_bf, dhn_bf, h_bf, xn, on_side, start):
+        """the products of weight_gradients_tn as ONE launch of the co-resident grouped kernel; on_side: on the side stream, not before
+        `start` (an event of the compute stream) — the bucket is reported from that stream, behind the launch"""
+        dwhh, dwih = Gr[f"rnns.{l}.whh_cat"], Gr[f"rnns.{l}.wih_cat"]
+        rows = 2 * H if G == 3 else 4 * H
+        probs = [(dgx_bf, xn[:, :dwih.shape[1]], dwih),
+                 (dgx_bf[B:M, 0:rows], h_bf[0:M - B, 0:H], dwhh[0, :rows]),
+                 (dgx_bf[0:M - B, G * H:G * H + rows], h_bf[B:M, H:2 * H], dwhh[1, :rows])]
+        if G == 3:
+            probs += [(dhn_bf[B:M, 0:H], h_bf[0:M - B, 0:H], dwhh[0, 2 * H:]), (dhn_bf[0:M - B, H:2 * H], h_bf[B:M, H:2 * H], dwhh[1, 2 * H:])]
+        if not on_side:
+            ops.gemm_bf16_tn_group(probs)
+            done(f"rnns.{l}")
+            return
+        with torch.cuda.stream(side):
+            side.wait_event(start)
+            ops.gemm_bf16_tn_group(probs)
+            if not serial_buckets:
+                done(f"rnns.{l}")                                # (a reducer records its "gradients final" event on the current = side stream)
+        if serial_buckets:                                       # the "serial" data-parallel schedule orders every collective INTO the compute stream
+            main.wait_stream(side)
+            done(f"rnns.{l}")
+        for t in (dgx_bf, dhn_bf, h_bf, xn):
+            if t is not None:
+                t.record_stream(side)
+        ctx.side_used = True
+
     # the side stream only pays beside a PERSISTENT recurrence (its resident workgroups leave registers and LDS for light kernels); beside
     # one-launch-per-step kernels (shapes whose W_hh^T slice does not fit: LSTM H = 1280) co-running passes delay every launch
     # (c4: 94.6 -> 99.5 ms per step), so there the passes stay on the compute stream.  What the library did for this shape is known from
@@ -346,8 +385,16 @@ def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy, done, private: bo
 
     queued = None                                                # layer whose operand passes wait for the next recurrence launch
     queued_tn = None
+    queued_side = None                                           # layer whose grouped weight-gradient launch waits for the next recurrence
+    group_ok = WGRAD_SIDE != "0" and W[f"rnns.0.wih_cat"].shape[1] % 8 == 0
+    side_ok = group_ok and WGRAD_SIDE != "main" and ops.wgrad_fits_beside_bwd_recurrence(G, H)
     for l in range(L - 1, -1, -1):
         lc = ctx.layers[l]
+        if queued_side is not None:
+            start = torch.cuda.Event()                           # everything of the layer above that is on the compute stream is behind this
+            start.record(main)
+            weight_gradients_group(*queued_side, True, start)
+            queued_side = None
         if queued is not None:
             # the compute stream is about to start this layer's recurrence: the operand passes of the layer above start WITH it (started
             # earlier they would only take CUs from the GEMMs in between, which fill the register file and leave them no room)
@@ -383,10 +430,21 @@ def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy, done, private: bo
         else:
             dy = dxn
         del dxn
-        if tn:
+        if tn and group_ok:
+            ops.rnn_bias_grads(G, bias_part, Gr[f"rnns.{l}.bih_cat"], Gr[f"rnns.{l}.bhh_cat"])
+            if side_ok:
+                queued_side = queued_tn[:5]                      # released with the next layer's recurrence launch (layer 0: below)
+            else:
+                weight_gradients_group(*queued_tn[:5], False, None)
+            queued_tn = None
+        elif tn:
             weight_gradients_tn(*queued_tn)                      # nothing to prepare: straight behind the critical-path work of the layer
             queued_tn = None
         lc.gx = lc.aux = lc.hbuf = lc.xn = lc.wpb = lc.h_bf = None
+    if queued_side is not None:
+        start = torch.cuda.Event()                               # layer 0: beside the conv-stack backward
+        start.record(main)
+        weight_gradients_group(*queued_side, True, start)
     if queued is not None:
         start = torch.cuda.Event()                               # layer 0: nothing latency-bound follows; run its passes now
         start.record(main)
@@ -424,7 +482,9 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
     done("fc")
     # ---- recurrent stack ------------------------------------------------------------------------
     if deferred:
-        dy = _backward_rnn_deferred(W, Gr, cfg, ctx, dy, done, on_bucket is not None)
+        # a reducer that orders its collectives into the compute stream ("serial") must be called from that stream
+        serial = getattr(getattr(on_bucket, "__self__", None), "mode", None) == "serial"
+        dy = _backward_rnn_deferred(W, Gr, cfg, ctx, dy, done, on_bucket is not None, serial)
         first_layer = -1          # the loop below has nothing left to do
     else:
         first_layer = L - 1
@@ -552,4 +612,6 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
     done("conv")
     if side is not main:
         main.wait_stream(side)              # all weight gradients are final for whoever runs next on the main stream
+    if getattr(ctx, "side_used", False):
+        main.wait_stream(_side_stream(dlogits.device))
     keep.clear()

@@ -262,6 +262,22 @@ def gemm_bf16_tn_pair(A0: Tensor, A1: Tensor, B0: Tensor, B1: Tensor, out: Tenso
     return out
 
 
+def gemm_bf16_tn_group(problems, max_workgroups: int = 0):
+    """Several TN products in ONE launch of the co-resident kernel (csrc/gemm_tn_group.h): `problems` = [(A (K, M), B (K, N), out (M, N))],
+    A / B bf16 row-major views sharing their K rows, out fp32 (row pitch arbitrary, columns contiguous).  out = A^T @ B, every tile a full
+    reduction over K (no split-K, no workspace)."""
+    lib = _lib.load()
+    arr = (_lib.TnProblem * len(problems))()
+    for q, (A, B, out) in zip(arr, problems):
+        assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and out.dtype == torch.float32 and A.is_cuda and B.is_cuda and out.is_cuda
+        assert A.dim() == 2 and B.dim() == 2 and out.dim() == 2 and A.stride(1) == 1 and B.stride(1) == 1 and out.stride(1) == 1
+        K, M = A.shape
+        assert B.size(0) == K and tuple(out.shape) == (M, B.size(1)), (A.shape, B.shape, out.shape)
+        q.A, q.B, q.C = A.data_ptr(), B.data_ptr(), out.data_ptr()
+        q.M, q.N, q.K, q.lda, q.ldb, q.ldc = M, B.size(1), K, _row_pitch(A), _row_pitch(B), _row_pitch(out)
+    _lib.check(lib.ds2_gemm_bf16_tn_group(len(problems), C.cast(arr, C.c_void_p), int(max_workgroups), _stream()), "ds2_gemm_bf16_tn_group")
+
+
 # ------------------------------------------------------------------------------------------------
 # BatchNorm1d family on (M, H)
 # ------------------------------------------------------------------------------------------------
@@ -708,6 +724,22 @@ def rnn_fwd(gates: int, gx: Tensor, wp_fwd: Tensor, bhh: Tensor, lens_dev: Tenso
                                   lens_dev.data_ptr(), T, B, H, int(bf16), _ptr(rec), _ptr(h_bf16), ws.data_ptr(), wsb, _stream()),
                "ds2_rnn_fwd")
     return (hbuf, aux, rec) if packed_gates else (hbuf, aux)
+
+
+_CORESIDENT = {}
+
+
+def wgrad_fits_beside_bwd_recurrence(gates: int, H: int) -> bool:
+    """Does a workgroup of the co-resident weight-gradient kernel (gemm_bf16_tn_group: one wave of <= 128 registers per SIMD, 84 KB of LDS)
+    fit on a CU that already holds a workgroup of the K-split backward recurrence of this shape (two waves per SIMD)?  Decided from the
+    register count of the LOADED kernel (512 registers per SIMD lane, allocated in blocks of 8; 160 KB of LDS per CU)."""
+    key = (gates, H)
+    if key not in _CORESIDENT:
+        out = (C.c_int * 3)()
+        has = _lib.load().ds2_rnn_bwd_ksplit_footprint(gates, H, out)
+        regs = (out[0] + 7) // 8 * 8
+        _CORESIDENT[key] = bool(has == 1 and out[2] == 512 and 2 * regs + 128 <= 512 and out[1] + 84 * 1024 <= 160 * 1024)
+    return _CORESIDENT[key]
 
 
 def rnn_last_path() -> int:

@@ -59,6 +59,15 @@ int ds2_gemm_bf16_nt(int M, int N, int K, const void* A, int lda, long long stri
 int ds2_gemm_bf16_tn(int M, int N, int K, const void* A, int lda, long long strideA, const void* B, int ldb, long long strideB, float* C,
                      int ldc, long long strideC, int accumulate, int batch, int splitk, void* workspace, size_t workspace_bytes,
                      void* stream);
+/* Grouped TN products in ONE launch of a kernel sized to run BESIDE a persistent backward recurrence (4 waves of <= 128 registers, at most
+ * one workgroup per CU): all weight-gradient products of one recurrent layer — dW_hh of both directions, a GRU's n-gate rows, dW_ih
+ * (asr_deepspeech/modules/blocks.py:76-78,88 under autograd) — as one flat list of 128 x 128 tiles walked by one workgroup per CU; every
+ * tile is a full reduction over K_p (no split-K, no workspace).  Same operand rules as ds2_gemm_bf16_tn; up to 8 problems. */
+typedef struct ds2_tn_problem {
+  const void* A; const void* B; float* C;
+  int M, N, K, lda, ldb, ldc;
+} ds2_tn_problem;
+int ds2_gemm_bf16_tn_group(int nprob, const ds2_tn_problem* problems, int max_workgroups, void* stream);
 int ds2_cast_bf16(const float* src, int ld_src, void* dst, int ld_dst, int R, int Cc, void* stream);
 int ds2_cast_transpose_bf16(const float* src, int ld_src, void* dst, int ld_dst, int R, int Cc, void* stream);
 /* both copies from ONE read of src: dst_r (R, ld_r) = bf16(src) (NULL: skipped), dst_t (C, ld_t) = bf16(src)^T, pads zero
@@ -191,6 +200,11 @@ int ds2_rnn_step_gate(const float* loss_dev, int* flag_dev, void* stream);
 /* Which recurrences may run as one persistent launch (default both).  Switch the backward one off when other kernels (collectives on a
  * communication stream) run on the device during backward: a persistent launch needs all of its workgroups resident at once. */
 int ds2_rnn_persistent_enable(int forward, int backward);
+/* Footprint of one workgroup of the K-split persistent backward recurrence for this (gates, H), read from the loaded binary: out3 =
+ * {registers per lane, static LDS bytes, threads}; returns 1 if the shape has such a kernel, 0 if not.  The host side decides with it
+ * whether ds2_gemm_bf16_tn_group (4 waves x 128 registers, 84 KB of LDS) fits on a CU BESIDE the recurrence of the layer below
+ * (asr_deepspeech/modules/blocks.py:87-89 backward; the weight gradients of blocks.py:76-78 are off its critical path). */
+int ds2_rnn_bwd_ksplit_footprint(int gates, int H, int* out3);
 /* reporting: bit 0 / bit 1 set if the last ds2_rnn_fwd / ds2_rnn_bwd call ran as a persistent launch (bench.py labels its roofline with it) */
 int ds2_rnn_last_path(void);
 size_t ds2_rnn_fwd_workspace_bytes(int B, int H, int bf16);

@@ -1,0 +1,148 @@
+"""-m gpu, round 4: the co-resident grouped weight-gradient kernel (csrc/gemm_tn_group.h) and the side-stream schedule that runs it beside
+the backward recurrence of the layer below (asr_amd/engine.py, DS2_WGRAD_SIDE)."""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _ref_tn(A, B):
+    """fp64 reference of A^T B on the bf16-rounded operands (CPU)."""
+    return (A.double().cpu().t() @ B.double().cpu()).float()
+
+
+@pytest.mark.parametrize("K,M,N,lda,ldb", [
+    (64, 128, 128, None, None),          # one tile, one k-tile
+    (130, 8, 8, None, None),             # smaller than a tile in every direction, K tail of 2 rows
+    (200, 264, 328, None, None),         # ragged edges in M and N, K tail
+    (1000, 520, 1312, None, None),       # layer 0's I = 1312 (not a multiple of 128)
+    (4096, 512, 256, 600, 304),          # pitched operands (column slices of wider buffers)
+    (5031, 768, 1024, 1024, 2048),       # odd K, pitched
+])
+def test_tn_group_single_problem_vs_fp64(K, M, N, lda, ldb):
+    from asr_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(K + M + N)
+    A = torch.randn(K, lda or M, device="cuda", generator=g).bfloat16()[:, :M]
+    B = torch.randn(K, ldb or N, device="cuda", generator=g).bfloat16()[:, :N]
+    out = torch.full((M, N), float("nan"), device="cuda")
+    ops.gemm_bf16_tn_group([(A, B, out)])
+    ref = _ref_tn(A, B)
+    err = (out.cpu() - ref).abs().max().item()
+    assert err <= 2e-5 * K ** 0.5 * 4 + 1e-4, (err, ref.abs().max().item())       # fp32 accumulation of exact bf16 products
+    # against the 256 x 256 split-K kernel (other summation order, same operands)
+    other = ops.gemm_bf16_tn(A, B) if (M % 8 == 0 and N % 8 == 0) else None
+    if other is not None:
+        assert (out - other).abs().max().item() <= 2e-5 * K ** 0.5 * 4 + 1e-4
+
+
+def test_tn_group_layer_problem_list_matches_separate_launches_and_is_deterministic():
+    """The five products of one GRU layer's weight gradients (dW_ih; dW_hh r,z rows and n rows of both directions: row-shifted, column-sliced
+    views of three buffers, two different K) in ONE launch: every output equals the fp64 reference and the single-problem launch bit for
+    bit (a tile's result does not depend on which workgroup computes it or on what else is in the list), repeated launches are identical,
+    and nothing outside the outputs is written."""
+    from asr_amd import ops
+    T, Bt, H, G, I = 23, 16, 256, 3, 328
+    Mr = T * Bt
+    g = torch.Generator(device="cuda").manual_seed(7)
+    dgx = torch.randn(Mr, 2 * G * H, device="cuda", generator=g).bfloat16()
+    dhn = torch.randn(Mr, 2 * H, device="cuda", generator=g).bfloat16()
+    h = torch.randn(Mr, 2 * H, device="cuda", generator=g).bfloat16()
+    xn = torch.randn(Mr, I, device="cuda", generator=g).bfloat16()
+    guard = 64
+    flat = torch.full((2 * G * H * I + 2 * G * H * H + 2 * guard,), 7.0, device="cuda")
+    dwih = flat[guard:guard + 2 * G * H * I].view(2 * G * H, I)
+    dwhh = flat[guard + 2 * G * H * I:guard + 2 * G * H * I + 2 * G * H * H].view(2, G * H, H)
+    rows = 2 * H
+
+    def problems(dwih, dwhh):
+        return [(dgx, xn, dwih),
+                (dgx[Bt:, 0:rows], h[:Mr - Bt, 0:H], dwhh[0, :rows]), (dgx[:Mr - Bt, G * H:G * H + rows], h[Bt:, H:2 * H], dwhh[1, :rows]),
+                (dhn[Bt:, 0:H], h[:Mr - Bt, 0:H], dwhh[0, rows:]), (dhn[:Mr - Bt, H:2 * H], h[Bt:, H:2 * H], dwhh[1, rows:])]
+
+    ops.gemm_bf16_tn_group(problems(dwih, dwhh))
+    torch.cuda.synchronize()
+    assert float(flat[:guard].min()) == 7.0 and float(flat[-guard:].max()) == 7.0
+    first = flat.clone()
+    for A, Bm, out in problems(dwih, dwhh):
+        ref = _ref_tn(A, Bm)
+        assert (out.cpu() - ref).abs().max().item() <= 2e-3, (A.shape, Bm.shape)
+        single = torch.empty(out.shape, device="cuda")
+        ops.gemm_bf16_tn_group([(A, Bm, single)])
+        assert torch.equal(single, out)
+    for wg in (0, 8, 24, 64):                                   # any grid walks the same tiles: bit-identical
+        flat.fill_(3.0)
+        ops.gemm_bf16_tn_group(problems(dwih, dwhh), max_workgroups=wg)
+        assert torch.equal(flat[guard:-guard], first[guard:-guard]), wg
+
+
+def _one_backward(mode, cfg, B, tin, seed=0, steps=1):
+    """sha256 of every gradient after one forward + backward of a bf16 model on a fixed batch under engine.WGRAD_SIDE = mode"""
+    sys.path.insert(0, ROOT)
+    import bench
+    from test_gpu_model import make_model
+    from asr_amd import engine, ops
+    from asr_amd.trainers.deepspeech_trainer import _prep_targets_host
+    old = engine.WGRAD_SIDE
+    engine.WGRAD_SIDE = mode
+    try:
+        torch.manual_seed(seed)
+        model = make_model(cfg)
+        model.precision = "bf16"
+        x, targets, pct, tsz = bench.synthetic_batch(B, tin, cfg["classes"], 1)
+        x = x.cuda()
+        model._ensure_flat(x.device)
+        out = None
+        for _ in range(steps):
+            with torch.no_grad():
+                W = model._flat.tensors(model)
+                Gr = model._flat.tensors(model, grads=True)
+                out_sizes = model.get_seq_lens((pct * tin).int())
+                t_h, off_h, tl_h, max_u = _prep_targets_host(targets, tsz)
+                lens_dev, tg, off, tl = out_sizes.to(torch.int32).cuda(), t_h.cuda(), off_h.cuda(), tl_h.cuda()
+                logits, ctx = engine.forward(W, model._cfg, x, lens_dev, training=True, save=True)
+                nll, dlogits = ops.ctc_loss(logits, tg, off, lens_dev, tl, max_u, 1.0 / B, want_grad=True)
+                engine.backward(W, Gr, model._cfg, ctx, dlogits)
+                torch.cuda.synchronize()
+                path = ops.rnn_last_path()
+                _, grad = model.flat_parameters()
+                out = (hashlib.sha256(grad.detach().cpu().numpy().tobytes()).hexdigest(), grad.detach().clone(), path, float(nll.sum()))
+        ops.rnn_persistent_check()
+        return out
+    finally:
+        engine.WGRAD_SIDE = old
+
+
+def test_side_stream_weight_gradients_bit_identical_to_one_stream_schedule():
+    """c3's layer shape (3 x 1024 BiGRU, B = 64: 256-workgroup persistent recurrences, the K-split backward kernel): the gradients of the
+    side-stream schedule (grouped weight-gradient launches running BESIDE the backward recurrence of the layer below) equal, bit for bit, the
+    one-stream schedule of the same kernels — twice, so that a race would have two chances; both are within the K-split / split-K summation
+    tolerance of round 3's kernels; no persistent launch starved."""
+    from asr_amd import ops
+    cfg = dict(rnn="gru", hidden=1024, layers=3, classes=29)
+    if not ops.wgrad_fits_beside_bwd_recurrence(3, 1024):
+        pytest.skip("the loaded K-split kernel leaves no room for the co-resident kernel")
+    main = _one_backward("main", cfg, 64, 301)
+    side = _one_backward("1", cfg, 64, 301)
+    side2 = _one_backward("1", cfg, 64, 301)
+    old = _one_backward("0", cfg, 64, 301)
+    assert main[2] & 6 == 6 and side[2] & 6 == 6, (main[2], side[2])           # persistent K-split backward in both
+    assert main[0] == side[0] == side2[0], "side-stream gradients differ from the one-stream schedule"
+    assert main[3] == side[3] == old[3]
+    d = (main[1] - old[1]).norm().item() / old[1].norm().item()
+    assert d < 1e-4, d                                                          # same operands, other fp32 summation order
+
+
+def test_side_stream_schedule_lstm_and_narrow_shapes_fall_back_cleanly():
+    """Shapes whose backward recurrence leaves no room (LSTM H = 1024: 2 x 224 registers) or that have no K-split kernel keep a one-stream
+    schedule; the result is the same in every mode."""
+    from asr_amd import ops
+    for cfg, B, tin in ((dict(rnn="lstm", hidden=1024, layers=2, classes=29), 32, 161), (dict(rnn="gru", hidden=256, layers=2, classes=29), 16, 121)):
+        a = _one_backward("1", cfg, B, tin)
+        b = _one_backward("main", cfg, B, tin)
+        assert a[0] == b[0], cfg
