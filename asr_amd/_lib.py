@@ -27,6 +27,7 @@ SIGNATURES = {
     "ds2_rnn_persistent_status": (i32, [vp]),
     "ds2_rnn_persistent_counters": (i32, [vp]),
     "ds2_rnn_poison_if_starved": (i32, [vp, sz, vp]),
+    "ds2_rnn_poison_seen": (i32, []),
     "ds2_rnn_step_gate": (i32, [vp, vp, vp]),
     "ds2_rnn_persistent_enable": (i32, [i32, i32]),
     "ds2_rnn_last_path": (i32, []),

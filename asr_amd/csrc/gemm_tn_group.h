@@ -18,10 +18,14 @@
 // slot s ^ ((r & 3) << 2).
 constexpr int L_TILE = 64 * 256;                  // bytes of one operand tile (64 k-rows x 128 bf16)
 constexpr int L_BUF = 2 * L_TILE;                 // [A | B]
-constexpr int L_LDS = 2 * L_BUF;                  // double buffer: 64 KiB
-constexpr int L_PATCH = 4 * 32 * 40 * 4;          // epilogue: 4 wave-private patches of 32 rows x 40 floats, behind the operand buffers
-constexpr int L_LDS_REQ = 84 * 1024;              // requested (> 80 KiB: at most one of these workgroups per CU)
-static_assert(L_LDS + L_PATCH <= L_LDS_REQ, "patch must fit in the request");
+// FOUR stages: with one wave per SIMD a k-tile is 16 MFMAs = 512 clocks (0.2 us) of work, far less than a trip to L2 / HBM, so the DMA of
+// k-tile kt + 3 is issued while kt is consumed (two to three tiles = 64-96 KB per CU in flight); the double buffer of the first version
+// waited a full memory latency per k-tile (1.5 ms per c3 layer against 0.86 ms for round 3's kernels, profiles/r04_wgrad_side_ab.txt).
+constexpr int L_STAGES = 4;
+constexpr int L_LDS = L_STAGES * L_BUF;           // 128 KiB
+constexpr int L_PATCH = 4 * 32 * 40 * 4;          // epilogue: 4 wave-private patches of 32 rows x 40 floats, IN the (then idle) stage buffers
+constexpr int L_LDS_REQ = L_LDS;                  // > 80 KiB: at most one of these workgroups per CU; + the recurrence's 10 KB <= 160 KB
+static_assert(L_PATCH <= L_LDS, "patch must fit in the stage buffers");
 constexpr int TN_MAX_PROBLEMS = 8;
 
 struct TnProb {
@@ -71,7 +75,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   // staging: piece p = wave + 4 i holds k-rows 4p .. 4p + 3 (1 KiB); lane -> k-row (lane >> 4), physical slot (lane & 15)
   const int rsub = lane >> 4;                                     // = (k-row & 3) for every piece
   const int gslot = (lane & 15) ^ (rsub << 2);                    // logical 16-byte segment this lane fetches
-  float* patch = reinterpret_cast<float*>(ldsg + L_LDS) + wave * (32 * 40);
+  float* patch = reinterpret_cast<float*>(ldsg) + wave * (32 * 40);
 
   for (int tile = run0 + ((int)blockIdx.x >> 3); tile < run1; tile += stride) {
     // the tile's problem: selected field by field with wave-uniform compares (a dynamically indexed kernel-argument struct would be
@@ -158,29 +162,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                                                      __builtin_bit_cast(bf16x8, fb[cur][m_ % NJ]), acc[m_ / NJ][m_ % NJ], 0, 0, 0); \
       __builtin_amdgcn_sched_barrier(0);                                                                                              \
       L_RD1(nxt, off_n, kk_n, m_);                                                                                                    \
-      if ((DMA) && kt + 2 < nkt) stage_piece(kt & 1, m_);                                                                               \
+      if ((DMA) && kt + (L_STAGES - 1) < nkt) stage_piece((kt + (L_STAGES - 1)) & (L_STAGES - 1), m_);                                                                     \
       __builtin_amdgcn_sched_barrier(0);                                                                                              \
     }                                                                                                                                 \
   } while (0)
+    // prologue: k-tiles 0 .. L_STAGES - 2 go out; tile 0 has landed when at most the DMA of the tiles behind it is outstanding
     stage_tile(0);
-    if (nkt > 1) {
-      stage_tile(1);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    if (nkt > 1) stage_tile(1);
+    if (nkt > 2) stage_tile(2);
+    if (nkt > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NP) : "memory");
+    else if (nkt > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = 0; r < NR; ++r) L_RD1(0, 0u, 0, r);
     for (int kt = 0; kt < nkt; ++kt) {
-      const unsigned boff = (kt & 1) * L_BUF, noff = ((kt + 1) & 1) * L_BUF;
+      const unsigned boff = (kt & (L_STAGES - 1)) * L_BUF, noff = ((kt + 1) & (L_STAGES - 1)) * L_BUF;
       __builtin_amdgcn_sched_barrier(0);
       L_STEP(0, 1, boff, 1, false);
       L_STEP(1, 0, boff, 2, false);
       L_STEP(0, 1, boff, 3, false);
-      // own DMA of tile kt+1 has landed, own reads of buffer kt&1 are complete; past the barrier that holds for every wave
-      L_RETIRE_ALL("s_waitcnt vmcnt(0)");
+      // own DMA of tile kt + 1 has landed (behind it only tile kt + 2's eight instructions may be outstanding; tile kt + 3 goes out below)
+      // and own reads of buffer kt are complete; past the barrier that holds for every wave: tile kt + 1 may be read, and the buffer of
+      // tile kt - 1 (every wave left it an iteration ago) may be refilled with tile kt + 3
+      if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      L_RETIRE_ALL("s_waitcnt");
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       L_STEP(1, 0, noff, 0, true);                     // (after the last k-tile: harmless reads of stale LDS, retired below)
@@ -194,6 +202,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #undef L_STEP
 
     // ---- epilogue: every 32 x 32 accumulator tile through the wave-private patch, out as 16-byte stores (8 rows x 128 B per instruction)
+    __syncthreads();                                   // the patches lie in the stage buffers: every wave has left the k-loop
     {
       constexpr int EP = 40;
       float* C = PC;

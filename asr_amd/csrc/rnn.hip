@@ -1539,6 +1539,13 @@ extern "C" int ds2_rnn_pack_whh(int gates, const float* whh, void* wp_fwd, void*
   return 0;
 }
 
+namespace {
+// host-visible "a poison kernel fired" word (pinned, mapped): lets a caller that never synchronises notice, with a plain host read, that
+// it has been handed NaN logits since the last ds2_rnn_persistent_status — and settle (raise, start the cooldown) before its next launch
+int* g_poison_host = nullptr;          // host address
+int* g_poison_dev = nullptr;           // the same word as the device sees it
+}  // namespace
+
 // status of the persistent forward kernel since the last call: 8 ints {starved, block x, y, z, step, wave, ok-mask lo, hi}; out8[0] != 0
 // if a wave ever gave up polling for its operand (results of that launch are then invalid).  Synchronises the device, clears the record.
 extern "C" int ds2_rnn_persistent_status(int* out8) {
@@ -1555,6 +1562,7 @@ extern "C" int ds2_rnn_persistent_status(int* out8) {
     int zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     DS2_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_persist_dbg), zero, sizeof(zero)));
   }
+  if (g_poison_host) *(volatile int*)g_poison_host = 0;      // (the device is idle: no poison kernel is in flight)
   return 0;
 }
 
@@ -1660,8 +1668,16 @@ extern "C" int ds2_rnn_step_gate(const float* loss_dev, int* flag_dev, void* str
 }
 
 namespace {
-__global__ void poison_if_starved_kernel(float* __restrict__ buf, long long n) {
+int poison_flag_init() {
+  if (g_poison_host) return 0;
+  DS2_HIP(hipHostMalloc((void**)&g_poison_host, 64, hipHostMallocMapped));
+  *g_poison_host = 0;
+  DS2_HIP(hipHostGetDevicePointer((void**)&g_poison_dev, g_poison_host, 0));
+  return 0;
+}
+__global__ void poison_if_starved_kernel(float* __restrict__ buf, long long n, int* __restrict__ seen) {
   if (g_persist_dbg[0] == 0) return;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { *seen = 1; __threadfence_system(); }
   const float qnan = __builtin_nanf("");
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) buf[i] = qnan;
 }
@@ -1673,11 +1689,16 @@ __global__ void poison_if_starved_kernel(float* __restrict__ buf, long long n) {
 extern "C" int ds2_rnn_poison_if_starved(float* buf, size_t n, void* stream) {
   DS2_REQUIRE(buf || n == 0, "ds2_rnn_poison_if_starved: null pointer");
   if (n == 0) return 0;
+  if (poison_flag_init()) return -1;
   const int blocks = (int)std::min<size_t>((n + 255) / 256, 1024);
-  hipLaunchKernelGGL(poison_if_starved_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, buf, (long long)n);
+  hipLaunchKernelGGL(poison_if_starved_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, buf, (long long)n, g_poison_dev);
   DS2_LAUNCH_CHECK("poison_if_starved_kernel");
   return 0;
 }
+
+// 1 if a ds2_rnn_poison_if_starved kernel has overwritten a buffer since the last ds2_rnn_persistent_status (a host memory read: no
+// synchronisation, no device call); the caller should then call ds2_rnn_persistent_status, which reports, clears and starts the cooldown.
+extern "C" int ds2_rnn_poison_seen(void) { return g_poison_host ? *(volatile int*)g_poison_host : 0; }
 
 // What a workgroup of the K-split persistent backward recurrence occupies, from the binary that is loaded: out3 = {registers per lane
 // (hipFuncGetAttributes), static LDS bytes, threads}.  Returns 1 if this (gates, H) shape has a K-split instance, 0 if not.  The host

@@ -44,16 +44,17 @@ CONV_STATS = _os.environ.get("DS2_CONV_STATS", "1") != "0" and _os.environ.get("
 # (ops.rnn_bwd_bn: one more 4-byte load per pair and step instead of a pass over (T*B, H)); 0: a separate bn1d_bwd_apply pass as before
 FUSE_BN_BWD = _os.environ.get("DS2_FUSE_BN_BWD", "1") != "0"
 # bf16 training, weight gradients of a recurrent layer whose recurrences ran as persistent launches (DS2_WGRAD_SIDE):
-#   "1" (default)  ONE launch of the co-resident grouped TN kernel (ops.gemm_bf16_tn_group: 4 waves x 128 registers, one workgroup per CU, no
-#                  split-K) on the side stream, released when the compute stream reaches the backward recurrence of the layer BELOW: the
-#                  K-split recurrence keeps 2 waves per SIMD and ~13 % of the matrix pipe busy for 1.2 ms and nothing else can run beside
-#                  it — this kernel is sized for exactly the registers / LDS it leaves, so the recurrence's residency holds by construction
-#                  (csrc/gemm_tn_group.h).  Layer 0's products run beside the conv-stack backward.  Shapes whose recurrence leaves no room
-#                  (LSTM H >= 1024: 2 x 224 registers) keep the schedule below.
-#   "main"         the same grouped kernel, on the compute stream right behind the layer's critical-path work (the one-stream schedule the
-#                  side-stream results are compared with bit for bit: tests/test_gpu_round4.py)
-#   "0"            round 3's kernels: three 256 x 256 TN launches with split-K slabs + reduce passes, compute stream
-WGRAD_SIDE = _os.environ.get("DS2_WGRAD_SIDE", "1")
+#   "0" (default)  round 3's kernels: three 256 x 256 TN launches with split-K slabs + reduce passes, compute stream
+#   "1"            ONE launch of the co-resident grouped TN kernel (ops.gemm_bf16_tn_group: 4 waves x 128 registers, one workgroup per CU, no
+#                  split-K) on the side stream, released when the compute stream reaches the backward recurrence of the layer BELOW.  The
+#                  kernel is sized for exactly the registers / LDS the K-split recurrence leaves on a CU, so the recurrence's residency
+#                  holds by construction (csrc/gemm_tn_group.h; 0 starved steps, gradients bit-identical to "main").  Layer 0's products run
+#                  beside the conv-stack backward.  MEASURED AND NOT KEPT AS THE DEFAULT (profiles/r04_wgrad_side_ab.txt): the recurrence's
+#                  per-step gather queues behind the co-resident kernel's operand DMA in the CU's own memory path and the recurrence loses
+#                  1.65-2.0 us per time step (0.83-1.0 ms per layer) — more than the 0.86 ms of work it hides: 27.3 vs 25.9 ms per step.
+#   "main"         the same grouped kernel on the compute stream right behind the layer's critical-path work (the one-stream schedule the
+#                  side-stream results are compared with bit for bit: tests/test_gpu_round4.py); +0.5 ms per step against "0"
+WGRAD_SIDE = _os.environ.get("DS2_WGRAD_SIDE", "0")
 _BWD_PERSISTENT = {}      # (gates, H, B) -> did the last backward recurrence of this shape run as a persistent launch?
 _SIDE = {}
 

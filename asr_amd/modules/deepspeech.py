@@ -182,6 +182,11 @@ class DeepSpeech(nn.Module):
             params = [p for _, p in self.named_parameters()]
             logits = _DS2Function.apply(self, x, lens_dev, *params)
         else:
+            if not self.training and ops.rnn_poison_seen():
+                # an EARLIER inference forward of this process was handed NaN logits (below) and nobody has settled the starvation since:
+                # settle it now — raises DS2LibraryError naming the launch, clears the record and moves the next recurrence calls onto the
+                # step kernels, so a caller that only ever calls forward() sees the failure once and then keeps working
+                ops.rnn_persistent_check()
             W = self._flat.tensors(self)
             logits, _ = engine.forward(W, self._cfg, x, lens_dev, training=self.training, save=False)
             if not self.training:
@@ -189,7 +194,9 @@ class DeepSpeech(nn.Module):
                 # must never return them, and must not pay a device synchronisation per forward either (streaming / batched inference
                 # would lose all host-device overlap), nor consume the starvation record of a trainer's un-settled step: a kernel in
                 # stream order turns the logits into NaN if a launch before it starved (fp32 shapes take the persistent kernels too),
-                # and the record stays for the next check at a natural sync point (evaluate() below, the trainer's step / synchronize).
+                # and the record stays for the next check at a natural sync point (evaluate() below, the trainer's step / synchronize,
+                # the decoders' device-to-host copy) — or, for callers that only ever call forward(), the NEXT forward: the poison kernel
+                # raises a pinned host flag that the test above reads without synchronising.
                 ops.rnn_poison_if_starved(logits)
         out = logits.transpose(0, 1)            # (B,T,C) view, like the reference's x.transpose(0, 1)
         out = self.inference_softmax(out)       # identity in train, HIP softmax in eval

@@ -697,6 +697,13 @@ def rnn_poison_if_starved(buf: Tensor) -> None:
     _lib.check(_lib.load().ds2_rnn_poison_if_starved(buf.data_ptr(), buf.numel(), _stream()), "ds2_rnn_poison_if_starved")
 
 
+def rnn_poison_seen() -> bool:
+    """True once a rnn_poison_if_starved kernel has actually overwritten a buffer since the last rnn_persistent_check(): a host memory read
+    (no synchronisation).  A caller that sees it should run rnn_persistent_check(), which raises, clears the record and moves the next
+    recurrence calls onto the step kernels."""
+    return bool(_lib.load().ds2_rnn_poison_seen())
+
+
 def rnn_persistent_counters():
     """(launches that starved since the library was loaded, recurrence calls left on the step kernels before re-arming)."""
     out = (C.c_int * 2)()
@@ -730,7 +737,7 @@ _CORESIDENT = {}
 
 
 def wgrad_fits_beside_bwd_recurrence(gates: int, H: int) -> bool:
-    """Does a workgroup of the co-resident weight-gradient kernel (gemm_bf16_tn_group: one wave of <= 128 registers per SIMD, 84 KB of LDS)
+    """Does a workgroup of the co-resident weight-gradient kernel (gemm_bf16_tn_group: one wave of <= 128 registers per SIMD, 128 KB of LDS)
     fit on a CU that already holds a workgroup of the K-split backward recurrence of this shape (two waves per SIMD)?  Decided from the
     register count of the LOADED kernel (512 registers per SIMD lane, allocated in blocks of 8; 160 KB of LDS per CU)."""
     key = (gates, H)
@@ -738,7 +745,7 @@ def wgrad_fits_beside_bwd_recurrence(gates: int, H: int) -> bool:
         out = (C.c_int * 3)()
         has = _lib.load().ds2_rnn_bwd_ksplit_footprint(gates, H, out)
         regs = (out[0] + 7) // 8 * 8
-        _CORESIDENT[key] = bool(has == 1 and out[2] == 512 and 2 * regs + 128 <= 512 and out[1] + 84 * 1024 <= 160 * 1024)
+        _CORESIDENT[key] = bool(has == 1 and out[2] == 512 and 2 * regs + 128 <= 512 and out[1] + 128 * 1024 <= 160 * 1024)
     return _CORESIDENT[key]
 
 

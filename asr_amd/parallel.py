@@ -43,6 +43,9 @@ class BucketedAllReducer:
         self._pending = []
         self.launched: List[str] = []
         self._held: List[str] = []
+        # measurement (bench.py sets it to a list): per collective {name, elements, start / end events on the stream it was issued on}, and per
+        # step an event on the compute stream where the conv-stack backward starts (= the big bucket's release) and ends (the conv bucket)
+        self.timing: Optional[list] = None
         # "conv" schedule: the bucket whose completion releases the held ones = the first recurrent layer (last in backward order)
         rnn_names = [n for n in self.buckets if n.startswith("rnns.")]
         self._release_on = min(rnn_names, key=lambda n: int(n.split(".")[1])) if rnn_names else None
@@ -70,19 +73,53 @@ class BucketedAllReducer:
             a, b = self.buckets[name]
             self.launched.append(name)
         view = self.flat_grad[a:b]
+        rec = None
+        if self.timing is not None and view.is_cuda:
+            rec = {"name": self.launched[-1], "elements": b - a, "mark": torch.cuda.Event(enable_timing=True),
+                   "start": torch.cuda.Event(enable_timing=True), "end": torch.cuda.Event(enable_timing=True)}
+            rec["mark"].record(torch.cuda.current_stream())          # where the caller's stream stands when the bucket is released
+            self.timing.append(rec)
         if self.use_stream:
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ready)
+                if rec:
+                    rec["start"].record(self.comm_stream)
                 work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                if rec:
+                    work.wait()                                      # (stream-level for RCCL; gloo stages through the host and blocks it)
+                    rec["end"].record(self.comm_stream)
             self._pending.append(work)
         else:
+            if rec:
+                rec["start"].record(torch.cuda.current_stream())
             work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             if view.is_cuda:
                 work.wait()          # stream-level: the compute stream waits for the collective, the host does not
+                if rec:
+                    rec["end"].record(torch.cuda.current_stream())
             else:
                 self._pending.append(work)
+
+    def timing_summary(self) -> dict:
+        """Per-step averages (ms) from the event records collected while `timing` was a list: the largest collective's duration on its
+        stream, the span of the conv-stack backward on the compute stream (from the release of the fc + RNN bucket to the conv bucket), and
+        how long the big collective outlasted the conv-stack backward (0: completely hidden).  Call after a device synchronisation."""
+        recs = self.timing or []
+        if not recs:
+            return {"collectives_per_step": 0}
+        big_elems = max(r["elements"] for r in recs)
+        bigs = [r for r in recs if r["elements"] == big_elems]
+        convs = [r for r in recs if r["name"] == "conv"]
+        out = {"collectives_per_step": len(recs) / max(len(bigs), 1), "big_collective_bytes": big_elems * 4,
+               "big_collective_ms": sum(r["start"].elapsed_time(r["end"]) for r in bigs) / len(bigs)}
+        if self.mode == "conv" and len(convs) == len(bigs):
+            span = [b["mark"].elapsed_time(c["mark"]) for b, c in zip(bigs, convs)]
+            tail = [max(0.0, b["mark"].elapsed_time(b["end"]) - sp) for b, sp in zip(bigs, span)]
+            out["conv_backward_ms"] = sum(span) / len(span)
+            out["big_collective_outlasts_conv_backward_ms"] = sum(tail) / len(tail)
+        return out
 
     def finish(self):
         """Block the compute stream until every bucket is reduced.  Gradients hold the SUM over ranks;

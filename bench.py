@@ -266,7 +266,7 @@ def spawn_ranks(n):
     import socket
     import subprocess
     have = torch.cuda.device_count()
-    if have < n:
+    if have < n and "--ranks-on-one-gpu" not in sys.argv:
         sys.exit(f"bench.py: --gpus {n} requested but this node exposes {have} GPU(s); refusing to run (a scaling point must use {n} devices)")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -291,6 +291,9 @@ def main():
     ap.add_argument("--dtype", default="", choices=["", "f32", "bf16"], help="default: the config dtype (bf16 for c3 and c5, f32 otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print a per-section time breakdown to stderr")
+    ap.add_argument("--ranks-on-one-gpu", action="store_true",
+                    help="TEST MODE for the N > 1 code path on a 1-GPU box: every rank uses cuda:0 and the process group is gloo (RCCL cannot put "
+                         "two ranks on one device) unless DS2_DIST_BACKEND says otherwise.  The line is labelled; it is not a scaling point.")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -299,14 +302,18 @@ def main():
     if world != max(args.gpus, 1):
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; they must agree")
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.ranks_on_one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = args.gpus > 1 or world > 1 or "RANK" in os.environ     # launched by torch.distributed.run
+    backend = os.environ.get("DS2_DIST_BACKEND", "gloo" if args.ranks_on_one_gpu else "nccl")      # "nccl" IS RCCL on ROCm
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from asr_amd import CTCLoss, DeepSpeech, FusedAdamW, ops
     from asr_amd.trainers import DeepSpeechTrainer
@@ -373,6 +380,9 @@ def main():
 
     ops.rnn_fwd, ops.rnn_bwd = with_events(orig_rnn[0], "fwd", 5, 1), with_events(orig_rnn[1], "bwd", 7, 2)
     ops.rnn_bwd_bn = with_events(orig_rnn[2], "bwd", 12, 2)      # the same recurrence with the BatchNorm1d backward of the layer above applied inside
+    red = tr._get_reducer() if use_dist else None
+    if red is not None:
+        red.timing = []                               # event records of every collective of the timed steps (asr_amd/parallel.py)
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -385,10 +395,22 @@ def main():
     dt = time.perf_counter() - t0
     ops.rnn_fwd, ops.rnn_bwd, ops.rnn_bwd_bn = orig_rnn
     tr.synchronize()                                  # settle the last step's device-side verdict (starved-step counter)
+    dist_info = None
     if use_dist:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        # every rank's own wall clock of the K steps (between the same two barriers), then the MAX is what the line reports
+        mine = torch.tensor([dt], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [float(t.item()) / args.steps * 1e3 for t in every]
+        tt = mine.clone()
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        assert abs(dt / args.steps * 1e3 - max(per_rank)) < 1e-6
+        dist_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "schedule": red.mode,
+                     "rank_ms_per_step": {"min": min(per_rank), "max": max(per_rank)}, **red.timing_summary()}
+        if args.ranks_on_one_gpu:
+            dist_info["ranks_on_one_gpu"] = "TEST MODE: all ranks share cuda:0 - exercises the N > 1 code path, NOT a scaling measurement"
+        red.timing = None
     ms = dt / args.steps * 1e3
     utts = world * B * args.steps / dt
 
@@ -525,6 +547,7 @@ def main():
             # train steps of this run (warm-up included) in which a persistent recurrence launch starved and the step was skipped
             "persistent_starved_steps": DeepSpeechTrainer.starved_steps - starved_before,
             "valid_last_step": bool(valid),
+            **({"dist": dist_info} if dist_info else {}),
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(rnn, H, L, C, tin, B)

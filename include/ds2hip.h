@@ -194,6 +194,10 @@ int ds2_rnn_persistent_counters(int* out2);
  * kernel in stream order that overwrites buf[0..n) (the logits) with NaN if a persistent launch before it recorded starvation; the record is
  * neither read by the host nor cleared (the next ds2_rnn_persistent_status, at a natural sync point, raises). */
 int ds2_rnn_poison_if_starved(float* buf, size_t n, void* stream);
+/* 1 if a ds2_rnn_poison_if_starved kernel has fired since the last ds2_rnn_persistent_status: a read of a pinned host word the kernel
+ * sets, no synchronisation and no device call.  Lets inference callers that only ever call forward (deepspeech.py:130-149 in eval mode)
+ * notice a starved launch and settle it (status call: report, clear, cooldown onto the step kernels) before their next forward. */
+int ds2_rnn_poison_seen(void);
 /* device-side validity of the train step enqueued so far: flag_dev[0] = (loss finite and >= 0 [check_loss, functional.py:45-61]) and no
  * persistent recurrence launch starved, evaluated when the kernel RUNS (stream order) */
 int ds2_rnn_step_gate(const float* loss_dev, int* flag_dev, void* stream);

@@ -146,3 +146,89 @@ def test_side_stream_schedule_lstm_and_narrow_shapes_fall_back_cleanly():
         a = _one_backward("1", cfg, B, tin)
         b = _one_backward("main", cfg, B, tin)
         assert a[0] == b[0], cfg
+
+
+def test_bench_two_ranks_end_to_end_on_one_gpu():
+    """The N > 1 branch of bench.py, executed before multi-GPU hardware sees it: `python bench.py --gpus 2 --ranks-on-one-gpu` self-spawns two
+    ranks under torch.distributed.run (both on cuda:0, gloo instead of RCCL), they run barrier -> K steps -> barrier, the MAX over ranks of
+    the wall clock is reported, and EXACTLY ONE JSON line comes out (rank 0) with n_gpus 2, global_batch 2 x B, parallelism dp2 and the
+    `dist` diagnostics (world size, backend, per-rank ms per step, the big collective's event-timed duration and how much of it outlasted the
+    conv-stack backward)."""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c1", "--steps", "3", "--warmup", "1",
+                        "--ranks-on-one-gpu", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 2 * 4 and out["config"]["parallelism"] == "dp2"
+    d = out["dist"]
+    assert d["world_size"] == 2 and d["backend"] == "gloo" and d["schedule"] == "conv" and "ranks_on_one_gpu" in d
+    assert 0 < d["rank_ms_per_step"]["min"] <= d["rank_ms_per_step"]["max"]
+    assert abs(d["rank_ms_per_step"]["max"] - out["ms_per_step"]) < 1e-6 * max(1.0, out["ms_per_step"])        # the line reports the MAX
+    assert abs(out["value"] - 2 * 4 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]                  # whole-job utterances / s
+    assert d["collectives_per_step"] == 2 and d["big_collective_bytes"] > 0 and d["big_collective_ms"] > 0    # fc + rnns bucket, conv bucket
+    assert d["conv_backward_ms"] > 0 and d["big_collective_outlasts_conv_backward_ms"] >= 0
+    assert np.isfinite(out["loss"]) and out["valid_last_step"] and out["persistent_starved_steps"] == 0
+
+
+FORWARD_ONLY_WORKER = r'''
+import os, sys, json
+import torch
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests")); sys.path.insert(0, os.path.join(root, "tests", "golden"))
+import bench
+from test_gpu_model import make_model
+from asr_amd import ops, _lib
+torch.manual_seed(0)
+model = make_model(dict(rnn="gru", hidden=256, layers=2, classes=29))
+model.precision = "bf16"
+model.eval()
+x, targets, pct, tsz = bench.synthetic_batch(16, 101, 29, 1)
+x = x.cuda()
+lens = (pct * x.size(3)).int()
+res = {"seen_before": ops.rnn_poison_seen()}
+with torch.no_grad():
+    out, _ = model.forward(x, lens)                         # persistent launch, starves at its first failed poll (DS2_RNN_SPIN_LIMIT=0)
+res["persistent"] = bool(ops.rnn_last_path() & 1)
+res["nan"] = bool(torch.isnan(out).all())                   # (this read synchronises: the poison kernel has run)
+res["seen_after_poison"] = ops.rnn_poison_seen()
+try:
+    with torch.no_grad():
+        model.forward(x, lens)                              # a caller that only ever calls forward(): the NEXT call settles and raises
+    res["second_forward_raised"] = False
+except _lib.DS2LibraryError as e:
+    res["second_forward_raised"] = True
+    res["message_names_step_kernels"] = "one-launch-per-step" in str(e)
+res["seen_after_settle"] = ops.rnn_poison_seen()
+res["cooldown"] = ops.rnn_persistent_counters()[1]
+with torch.no_grad():
+    out3, _ = model.forward(x, lens)                        # cooldown: step kernels, valid results, no exception
+res["third_finite"] = bool(torch.isfinite(out3).all())
+res["third_on_step_kernels"] = not bool(ops.rnn_last_path() & 1)
+res["seen_end"] = ops.rnn_poison_seen()
+print("FWD_JSON " + json.dumps(res))
+'''
+
+
+def test_forward_only_inference_notices_and_heals_a_starved_launch(tmp_path):
+    """ADVICE round 3 (medium): a caller that uses `model(x)` directly in eval mode and never calls evaluate() / the trainer / ops.rnn_persistent_check.
+    A starved persistent launch (forced) poisons that forward's logits in stream order (no synchronisation); the poison kernel also raises a
+    pinned host flag, so the NEXT forward notices with a plain host read, settles the record (DS2LibraryError naming the launch, cooldown
+    onto the step kernels) and every forward after that returns valid results again — instead of NaN for the rest of the process."""
+    import json
+    import subprocess
+    script = str(tmp_path / "fwd_only.py")
+    open(script, "w").write(FORWARD_ONLY_WORKER)
+    env = dict(os.environ, DS2_RNN_SPIN_LIMIT="0", DS2_RNN_REARM_CALLS="8")
+    r = subprocess.run([sys.executable, script, ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("FWD_JSON ")][-1][len("FWD_JSON "):])
+    assert not res["seen_before"] and res["persistent"] and res["nan"] and res["seen_after_poison"], res
+    assert res["second_forward_raised"] and res["message_names_step_kernels"] and not res["seen_after_settle"] and res["cooldown"] > 0, res
+    assert res["third_finite"] and res["third_on_step_kernels"] and not res["seen_end"], res
