@@ -10,7 +10,7 @@ namespace {
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
                                                     float wd, float bc1, float bc2_sqrt, float gscale, const int* __restrict__ apply) {
-  if (apply && *apply == 0) return;                     // device-side gate: the step was found invalid after this launch was enqueued
+  if (apply && *apply <= 0) return;                     // device-side gate (1 = apply; 0 / -1: the step was found invalid after this launch was enqueued)
   const long long n4 = n / 4;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, long 
 }  // namespace
 
 // step is 1-based.  grad_scale multiplies g on the fly (e.g. 1/world_size after an all-reduce SUM).
-// apply_flag: NULL, or a device int the kernel reads when it RUNS: 0 = leave everything untouched.  It lets the host enqueue the update
+// apply_flag: NULL, or a device int the kernel reads when it RUNS: <= 0 = leave everything untouched.  It lets the host enqueue the update
 // before it knows whether the step is valid (finite loss on every rank, no starved recurrence launch: ds2_rnn_step_gate), i.e. without
 // a host synchronisation between backward and the optimizer.
 extern "C" int ds2_adamw_gated_f32(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,

@@ -1653,12 +1653,14 @@ extern "C" int ds2_rnn_last_path(void) { return g_last_path; }
 namespace {
 __global__ void step_gate_kernel(const float* __restrict__ loss, int* __restrict__ flag) {
   const float l = *loss;
-  *flag = (l == l && l != __builtin_inff() && l != -__builtin_inff() && l >= 0.f && g_persist_dbg[0] == 0) ? 1 : 0;
+  // 1 = apply the update; 0 = this rank's loss is not valid; -1 = a persistent recurrence launch of this rank starved.  The MIN over the
+  // ranks then tells EVERY rank which of the two happened somewhere (the trainer restores BatchNorm statistics on all ranks after a -1).
+  *flag = g_persist_dbg[0] != 0 ? -1 : ((l == l && l != __builtin_inff() && l != -__builtin_inff() && l >= 0.f) ? 1 : 0);
 }
 }  // namespace
 
 // flag[0] = 1 if the train step enqueued so far on `stream` is valid when this kernel RUNS: the loss (device scalar) is finite and
-// non-negative (functional.py:45-61) and no persistent recurrence launch has recorded starvation; else 0.  Consumed on the device by
+// non-negative (functional.py:45-61) and no persistent recurrence launch has recorded starvation; 0 for an invalid loss, -1 for starvation.  Consumed on the device by
 // ds2_adamw_gated_f32 (and, under data parallelism, all-reduced with MIN first), read back by the host whenever convenient.
 extern "C" int ds2_rnn_step_gate(const float* loss_dev, int* flag_dev, void* stream) {
   DS2_REQUIRE(loss_dev && flag_dev, "ds2_rnn_step_gate: null pointer");
@@ -1792,7 +1794,7 @@ extern "C" int ds2_rnn_bwd_bn(int gates, const float* dyn, int lddyn, const floa
                               void* dgx_bf16, const void* gates_bf16, void* dhn_bf16, float* bias_part, void* ws, size_t ws_bytes,
                               void* stream) {
   DS2_REQUIRE(gates == 3 || gates == 4, "ds2_rnn_bwd_bn: gates must be 3 (GRU) or 4 (LSTM)");
-  DS2_REQUIRE(dyn && bn_x && bn_mean && bn_var && bn_gamma && bn_s0 && bn_s1 && dy_scratch && aux && hbuf && wp_bwd && lens_dev,
+  DS2_REQUIRE(dyn && bn_x && bn_mean && bn_var && bn_gamma && bn_s0 && bn_s1 && aux && hbuf && wp_bwd && lens_dev,
               "ds2_rnn_bwd_bn: null pointer");
   DS2_REQUIRE(gx || (gates_bf16 && dgx_bf16), "ds2_rnn_bwd_bn: gx may only be NULL with both gates_bf16 and dgx_bf16 given");
   DS2_REQUIRE(T > 0 && B > 0 && H > 0 && (H % 4) == 0, "ds2_rnn_bwd_bn: need H %% 4 == 0 (H=%d)", H);
@@ -1816,7 +1818,9 @@ extern "C" int ds2_rnn_bwd_bn(int gates, const float* dyn, int lddyn, const floa
       return 0;
     }
   }
-  // not taken by the K-split kernel: materialise dy, then the ordinary path
+  // not taken by the K-split kernel: materialise dy, then the ordinary path.  dy_scratch == NULL: nothing has been launched or counted
+  // yet — return 1 so that the caller allocates the (T*B, H) buffer only when it is really needed, and calls again
+  if (!dy_scratch) return 1;
   int rc = ds2i_bn1d_bwd_apply(dyn, lddyn, bn_x, ldx, dy_scratch, H, T * B, H, bn_mean, bn_var, bn_gamma, bn_s0, bn_s1, bn_eps, st);
   if (rc) return rc;
   rc = ds2_rnn_bwd_ex(gates, dy_scratch, H, gx, aux, hbuf, wp_bwd, lens_dev, T, B, H, bf16, dgx_bf16, gates_bf16, dhn_bf16, bias_part, ws, ws_bytes,

@@ -257,7 +257,9 @@ class DistributedLengthBucketingSampler(Sampler):
     bins just before it (nearest in length), where the reference wraps around to the first bins (which here would put the SHORTEST
     batches next to the LONGEST ones in the last round)."""
 
-    def __init__(self, data_source, batch_size=1, num_replicas=None, rank=None, durations=None, descending=False, partial="fill"):
+    _fill_logged = False
+
+    def __init__(self, data_source, batch_size=1, num_replicas=None, rank=None, durations=None, descending=False, partial="keep"):
         super().__init__()
         if num_replicas is None:
             num_replicas = torch.distributed.get_world_size()
@@ -267,9 +269,15 @@ class DistributedLengthBucketingSampler(Sampler):
         self.num_replicas, self.rank = int(num_replicas), int(rank)
         self.durations = _durations_of(data_source, durations)
         order = np.argsort(-self.durations if descending else self.durations, kind="stable").tolist()
-        # every rank of a round must run the SAME batch size: gradients are averaged unweighted, and a rank whose B is not a multiple of 8
-        # leaves the packed bf16 fast path and straggles in the all-reduce — so the short last bin is topped up by default
+        # partial="keep" (default, the reference sampler's behaviour: the short last bin stays short, epochs are composed exactly as with
+        # data/samplers/distributed_bucketing_sampler.py).  partial="fill" tops the short bin up with the ids just before it, so that every
+        # rank of every round runs the SAME batch size — gradients are averaged unweighted, and a rank whose B is not a multiple of 8 leaves
+        # the packed bf16 fast path and straggles in the all-reduce; it duplicates samples within an epoch (logged once), so it is opt-in.
         bins = _full_bins(order, self.batch_size, partial)
+        if partial == "fill" and len(order) % self.batch_size and not DistributedLengthBucketingSampler._fill_logged:
+            DistributedLengthBucketingSampler._fill_logged = True
+            print(f"[asr_amd] DistributedLengthBucketingSampler(partial='fill'): the last bin is topped up with "
+                  f"{self.batch_size - len(order) % self.batch_size} duplicate sample(s) per epoch", flush=True)
         self.num_samples = int(math.ceil(len(bins) / self.num_replicas))
         self.total_size = self.num_samples * self.num_replicas
         pad = self.total_size - len(bins)

@@ -28,21 +28,50 @@ class SequenceWise(nn.Module):
 
 
 class MaskConv(nn.Module):
-    """blocks.py:30-56: apply each sub-module, then zero every frame t >= lengths[b].  Inside
-    DeepSpeech the mask is fused into the conv / BN epilogues; stand-alone it is a vectorised
-    `masked_fill` (no per-sample host sync, unlike the reference's `.item()` loop at :52)."""
+    """blocks.py:30-56: apply each sub-module, then zero every frame t >= lengths[b].  Inside DeepSpeech the mask is fused into the conv /
+    BatchNorm epilogues of the kernel schedule (asr_amd/engine.py).  Stand-alone `forward` (forward-only, like BatchRNN's) runs the SAME HIP
+    kernels for the one stack they are written for — DeepSpeech's Conv2d(1,32,(41,11),s(2,2),p(20,5)) / BatchNorm2d / Hardtanh(0,20) /
+    Conv2d(32,32,(21,11),s(2,1),p(10,5)) / BatchNorm2d / Hardtanh(0,20) (deepspeech.py:60-67) — and raises for anything else: there is no
+    torch (MIOpen) fallback behind this class either."""
 
     def __init__(self, seq_module):
         super().__init__()
         self.seq_module = seq_module
 
+    def _is_ds2_stack(self):
+        m = list(self.seq_module)
+        if len(m) != 6 or not (isinstance(m[0], nn.Conv2d) and isinstance(m[1], nn.BatchNorm2d) and isinstance(m[2], nn.Hardtanh)
+                               and isinstance(m[3], nn.Conv2d) and isinstance(m[4], nn.BatchNorm2d) and isinstance(m[5], nn.Hardtanh)):
+            return False
+        c1, c2 = m[0], m[3]
+        return ((c1.in_channels, c1.out_channels, tuple(c1.kernel_size), tuple(c1.stride), tuple(c1.padding)) == (1, 32, (41, 11), (2, 2), (20, 5))
+                and (c2.in_channels, c2.out_channels, tuple(c2.kernel_size), tuple(c2.stride), tuple(c2.padding)) == (32, 32, (21, 11), (2, 1), (10, 5))
+                and all((h.min_val, h.max_val) == (0, 20) for h in (m[2], m[5])) and c1.bias is not None and c2.bias is not None)
+
     def forward(self, x, lengths):
-        lens = torch.as_tensor(lengths).to(x.device)
-        for module in self.seq_module:
-            x = module(x)
-            t = torch.arange(x.size(3), device=x.device).view(1, 1, 1, -1)
-            x = x.masked_fill(t >= lens.view(-1, 1, 1, 1), 0)
-        return x, lengths
+        """x (B,1,F,T_in) fp32 on the GPU, lengths (B,) = frames to keep in the OUTPUT (blocks.py:42-56) -> ((B,32,D2,T), lengths)."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("MaskConv.forward stand-alone has no autograd; train through DeepSpeech.forward")
+        if not x.is_cuda:
+            raise _lib.DS2LibraryError("MaskConv.forward: GPU tensor required (no CPU fallback)")
+        if not self._is_ds2_stack():
+            raise NotImplementedError("MaskConv.forward stand-alone runs the HIP kernels of DeepSpeech's own conv stack only (Conv2d(1,32,(41,11)) / "
+                                      "BatchNorm2d / Hardtanh(0,20) / Conv2d(32,32,(21,11)) / BatchNorm2d / Hardtanh(0,20)); asr_amd has no torch "
+                                      "fallback by design (see INTEGRATION.md)")
+        m = list(self.seq_module)
+        lens_dev = torch.as_tensor(lengths).to(torch.int32).to(x.device)
+        x = x.contiguous().float()
+        wpk1, wpk2, _ = ops.conv_pack(m[0].weight.detach(), m[3].weight.detach())
+
+        def stats(y, bn):
+            if self.training:
+                return ops.bn2d_stats(y, bn.running_mean, bn.running_var)
+            return bn.running_mean, bn.running_var
+        y1 = ops.conv1_fwd(x, wpk1, m[0].bias.detach(), lens_dev)
+        a1 = ops.bn2d_act_fwd(y1, lens_dev, *stats(y1, m[1]), m[1].weight.detach(), m[1].bias.detach())
+        y2 = ops.conv2_fwd(a1, wpk2, m[3].bias.detach(), lens_dev)
+        a2 = ops.bn2d_act_fwd(y2, lens_dev, *stats(y2, m[4]), m[4].weight.detach(), m[4].bias.detach())
+        return a2, lengths
 
 
 class InferenceBatchSoftmax(nn.Module):

@@ -811,11 +811,15 @@ def rnn_bwd_bn(gates: int, dyn: Tensor, bn_x: Tensor, mean: Tensor, var: Tensor,
     lib = _lib.load()
     wsb = lib.ds2_rnn_bwd_workspace_bytes(gates, B, H, int(bf16))
     ws = _ws(wsb, dyn.device)
-    scratch = torch.empty(T * B, H, dtype=torch.float32, device=dyn.device)      # (untouched by a fused launch: the caching allocator's cost only)
-    _lib.check(lib.ds2_rnn_bwd_bn(gates, dyn.data_ptr(), _row_pitch(dyn), bn_x.data_ptr(), _row_pitch(bn_x), mean.data_ptr(), var.data_ptr(),
-                                  gamma.data_ptr(), s0.data_ptr(), s1.data_ptr(), BN_EPS, scratch.data_ptr(), _ptr(gx), aux.data_ptr(),
+    def call(scratch):
+        return lib.ds2_rnn_bwd_bn(gates, dyn.data_ptr(), _row_pitch(dyn), bn_x.data_ptr(), _row_pitch(bn_x), mean.data_ptr(), var.data_ptr(),
+                                  gamma.data_ptr(), s0.data_ptr(), s1.data_ptr(), BN_EPS, _ptr(scratch), _ptr(gx), aux.data_ptr(),
                                   hbuf.data_ptr(), wp_bwd.data_ptr(), lens_dev.data_ptr(), T, B, H, int(bf16), _ptr(dgx_bf16), _ptr(gates_bf16),
-                                  _ptr(dhn_bf16), _ptr(bias_part), ws.data_ptr(), wsb, _stream()), "ds2_rnn_bwd_bn")
+                                  _ptr(dhn_bf16), _ptr(bias_part), ws.data_ptr(), wsb, _stream())
+    rc = call(None)                  # the fused K-split launch needs no scratch: the (T*B, H) fp32 buffer is allocated only on the fallback (rc 1)
+    if rc == 1:
+        rc = call(torch.empty(T * B, H, dtype=torch.float32, device=dyn.device))
+    _lib.check(rc, "ds2_rnn_bwd_bn")
 
 
 def rnn_bias_grads(gates: int, bias_part: Tensor, dbih: Tensor, dbhh: Tensor):

@@ -206,7 +206,7 @@ class DeepSpeechTrainer:
             red.finish()
             pin["loss_done"].synchronize()                                   # the step's single host wait: CTC done (backward is running)
             loss_value = float(pin["loss"][0])
-            prev_starved = self._settle()                                    # the PREVIOUS step's device verdict is long available
+            prev_starved = self._settle()                                    # the PREVIOUS step's (rank-reduced) verdict is long available
             valid_loss, _ = check_loss(None, loss_value)
             gate = ops.step_gate(loss)                                       # device verdict of THIS step, behind backward in stream order
             if prev_starved:
@@ -257,22 +257,27 @@ class DeepSpeechTrainer:
             return False
         self._unsettled = None
         self._pin["gate_done"].synchronize()
-        applied = int(self._pin["gate"][0]) != 0
-        starved = False
+        verdict = int(self._pin["gate"][0])                                  # MIN over ranks of {1 apply, 0 invalid loss, -1 starved launch}
+        applied = verdict > 0
+        starved_any = verdict < 0
         if not applied:
             self._optimizer.undo_step_count()
+            own = self._persistent_starved() if starved_any else False       # this rank's own record (counted, printed, cleared, cooldown)
             if pending:                                                      # not explained by this rank's own loss
-                starved = self._persistent_starved()                         # counted and printed there; the library re-arms later
-                if not starved:
+                if starved_any and not own:
+                    print("[asr_amd] step skipped on every rank: a persistent recurrence launch starved on another rank", flush=True)
+                elif not starved_any:
                     print("[asr_amd] step skipped on every rank: another rank's loss was not valid", flush=True)
                 # the step's loss was reported as valid (and train() has added it to the epoch loss) before this verdict existed:
                 # hand it back so that the bookkeeping matches the updates that were really applied
                 self._rejected_losses.append(self._unsettled_loss)
-            if starved:
+            if starved_any:
                 # The starved step's forward (and, because starvation is discovered one step late, the forward of the step that is running
-                # now) wrote BatchNorm running statistics from invalid activations: put back the statistics of BEFORE the starved step.
+                # now) wrote BatchNorm running statistics from invalid activations on the starving rank.  EVERY rank puts back the statistics
+                # of BEFORE the starved step — the verdict is the reduced one, so all ranks roll back the same two forwards and their
+                # running statistics / counters keep describing the same number of accepted updates, whichever rank checkpoints.
                 self._restore_bn_stats(self._unsettled_index)
-        return starved
+        return starved_any
 
     def _take_back_rejected(self) -> float:
         """Sum of the loss values of steps that step() reported as valid but the device gate rejected afterwards (and forget them)."""
@@ -319,6 +324,8 @@ class DeepSpeechTrainer:
         with torch.no_grad():
             W = model._flat.tensors(model)
             Gr = model._flat.tensors(model, grads=True)
+            self._step_index = getattr(self, "_step_index", -1) + 1
+            self._snapshot_bn_stats(self._step_index)
             logits, ctx = engine.forward(W, model._cfg, inputs, lens_dev, training=True, save=True)
             nll, dlogits = ops.ctc_loss(logits, tg, off, lens_dev, tl, max_u, 1.0 / B, want_grad=True)
             loss = ops.ctc_batch_mean(nll)[0]
@@ -327,6 +334,9 @@ class DeepSpeechTrainer:
             red.finish()
             loss_value = loss.item()
             starved = self._persistent_starved()                             # the device is idle here
+            if not red.all_valid(not starved, inputs.device):                # starved on ANY rank: every rank drops this forward's BatchNorm update
+                self._restore_bn_stats(self._step_index)
+                starved = True
             valid_loss, _ = check_loss(loss, loss_value)
             valid_loss = valid_loss and not starved                          # a starved step is skipped like a non-finite loss (on every rank)
             valid_loss = red.all_valid(valid_loss, inputs.device)

@@ -41,14 +41,36 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0    # same guide: dense bf16 MFMA (the 5 PF market
 HBM_PEAK_GBS = 8000.0
 
 
+def kernel_source_sha256():
+    """sha256 over the sources the recurrence kernels are built from (same function as scripts/pmc_summarize.py)"""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("rnn.hip", "rnn_bwd_ksplit.h", "permlane.h", "common.h", "Makefile"):
+        h.update(open(os.path.join(ROOT, "asr_amd", "csrc", name), "rb").read())
+    return h.hexdigest()
+
+
+PMC_SUMMARY = "r04_pmc_persistent.json"
+
+
 def load_pmc_summary():
-    """profiles/r03_pmc_persistent.json (written by scripts/pmc_summarize.py from the rocprofv3 PMC passes) or None."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_persistent.json")
+    """(summary, why_not): profiles/r04_pmc_persistent.json (written by scripts/pmc_summarize.py from the rocprofv3 PMC passes) — but only if
+    it was collected for THIS build of the recurrence kernels: the summary carries the sha256 of the kernel sources it was measured on, and
+    a summary for other sources is refused (`roofline.traffic` is then null with the reason) instead of silently going stale."""
+    path = os.path.join(ROOT, "profiles", PMC_SUMMARY)
     try:
         with open(path) as f:
-            return json.load(f)
+            pmc = json.load(f)
     except (OSError, ValueError):
-        return None
+        return None, f"profiles/{PMC_SUMMARY} not present"
+    try:
+        now = kernel_source_sha256()
+    except OSError as e:
+        return None, f"kernel sources not readable ({e})"
+    if pmc.get("kernel_source_sha256") != now:
+        return None, (f"profiles/{PMC_SUMMARY} was collected for other kernel sources (sha256 {str(pmc.get('kernel_source_sha256'))[:12]}..., this tree "
+                      f"{now[:12]}...): re-run scripts/gpu_pmc_persistent.sh")
+    return pmc, None
 
 
 def train_flops_per_utt(rnn, H, L, C, T):
@@ -151,8 +173,8 @@ def cpu_baseline_worker(rnn, H, L, C, tin, B):
     and utterance length at the largest batch that fits the time budget.
     Protocol: the thread count is probed AT THE TIMED SHAPE (one full-length utterance, T_in = tin), then ONE warm-up step and TWO timed
     steps of the same batch with the optimizer state carried through; the three loss values are returned so that the parent can run the HIP
-    path from the same weights on the same batch and report the matched-loss evidence (`loss_parity`).  The padded + masked oracle
-    (oracle/ds2_oracle.py, explicit time loops) is timed beside it on B = 1."""
+    path from the same weights on the same batch and report the matched-loss evidence (`loss_parity`).  Beside it (`fair_cpu_unpacked`):
+    the same three steps with the recurrent layers un-packed — the faster, fairer CPU figure BASELINE.md §3.2 asks for."""
     from oracle import ds2_oracle as O
     from oracle import ds2_packed as P
     cores = os.cpu_count() or 1
@@ -192,26 +214,34 @@ def cpu_baseline_worker(rnn, H, L, C, tin, B):
         losses.append(P.train_step(params, opt, (x, targets, pct.clone(), tsz)))
         times.append(time.time() - t0)
     dt = (times[1] + times[2]) / 2.0
-    # padded + masked restatement (B = 1; T_in = 201 scaled linearly when the full length would not fit)
-    def padded(t_in):
-        xx, tt, pp, ss = synthetic_batch(1, t_in, C, 1)
-        t0 = time.time()
-        O.fit_and_grads(sd, xx, tt, pp, ss)
-        return time.time() - t0
-    padded(41)
-    t_small = padded(201)
-    est = t_small * tin / 201.0
-    left = 215.0 - (time.time() - t_start)
-    pd_t, pd_s = (padded(tin), tin) if est < min(25.0, left) else (est, 201)
+    # the FAIR CPU figure: the same model, batch, optimizer and thread count with the recurrent layers as the fused aten
+    # gru / lstm on the PADDED tensor — no pack_padded_sequence, hence no per-time-step packed slices in autograd; exactly equivalent here
+    # because every utterance of the synthetic batch has the full length (oracle/ds2_packed.py forward(packed=False) asserts it; equality
+    # of the two forms' loss is checked below).  1 warm-up + 2 timed steps from the SAME initial weights as the packed run.
+    fair = None
+    if time.time() - t_start < 170.0:
+        params_u = P.leaf_params(sd)
+        opt_u = P.make_optimizer(params_u)
+        lu, tu = [], []
+        for k in range(3):
+            t0 = time.time()
+            lu.append(P.train_step(params_u, opt_u, (x, targets, pct.clone(), tsz), packed=False))
+            tu.append(time.time() - t0)
+            if time.time() - t_start > 230.0:
+                break
+        if len(tu) == 3:
+            fair = {"value": b_s / ((tu[1] + tu[2]) / 2.0), "unit": "utterances/sec", "cores": nthr, "batch": b_s, "losses": lu,
+                    "step_seconds": [round(t, 2) for t in tu],
+                    "loss_vs_packed_form": max(abs(a - b) / abs(b) for a, b in zip(lu, losses)),
+                    "sample": f"same model / batch (B={b_s}, T_in={tin}) / AdamW / {nthr} threads with the recurrent layers un-packed (fused aten "
+                              f"{rnn} on the padded tensor; equivalent: no utterance is padded): 1 warm-up + 2 timed steps"}
     out = {"value": b_s / dt, "unit": "utterances/sec", "cores": nthr, "kind": "port", "host_cores": cores, "host": _host_description(),
            "batch": b_s, "losses": losses, "step_seconds": [round(t, 2) for t in times],
            "sample": (f"reference statement sequence in packed form (pack_padded_sequence -> aten gru/lstm -> pad_packed_sequence, CTC, backward, "
                       f"torch AdamW) at B={b_s} of the config's {B}, same {L}x{H} {rnn} model, T_in={tin}: 1 warm-up step + 2 timed steps "
                       f"({times[1]:.1f} s, {times[2]:.1f} s; warm-up {times[0]:.1f} s), optimizer state carried through; threads probed at the timed "
                       f"shape (B={pb}, T_in={tin}) {({k: round(v, 2) for k, v in probe.items()})} s -> {nthr} of {cores}"),
-           "padded_port": {"value": 1.0 / pd_t, "unit": "utterances/sec", "cores": nthr,
-                           "sample": "padded+masked oracle (explicit time loops) fit+backward, no optimizer, B=1, T_in=" + str(pd_s)
-                                     + ("" if pd_s == tin else f" scaled linearly to T_in={tin}")}}
+           "fair_cpu_unpacked": fair if fair is not None else {"value": None, "sample": "skipped: the packed-form leg used up the time box"}}
     print("CPU_BASELINE_JSON " + json.dumps(out), flush=True)
 
 
@@ -259,6 +289,144 @@ def cpu_baseline(rnn, H, L, C, tin, B, limit_s=300):
         return {"value": None, "unit": "utterances/sec", "cores": 0, "kind": "port", "sample": f"worker exceeded {limit_s}s"}
 
 
+def _make_trainer(workload, dtype, dev, world=1, rank=0):
+    """(trainer, batches resident in HBM, (rnn, H, L, C, B, tin)) for a named workload, built exactly as main() builds the timed one."""
+    from asr_amd import CTCLoss, DeepSpeech, FusedAdamW
+    from asr_amd.trainers import DeepSpeechTrainer
+    rnn, H, L, C, B, tin = WORKLOADS[workload]
+    torch.manual_seed(0)
+    with tempfile.TemporaryDirectory() as tmp:
+        model = DeepSpeech(audio_conf=audio_conf(), decoder=None, label_path=label_file(tmp, C), rnn_type=rnn, rnn_hidden_size=H,
+                           rnn_hidden_layers=L, bidirectional=True)
+    model.to(dev).train()
+    model.precision = "bf16" if dtype == "bf16" else "fp32"
+    opt = FusedAdamW(model, lr=1.5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5)
+    tr = DeepSpeechTrainer(model, CTCLoss(reduction="sum"), 1, None, opt, None, None, dev, dev, False, None)
+    if workload in ("c4", "c5"):
+        from asr_amd.data import DistributedLengthBucketingSampler
+        lo = 1201 if workload == "c4" else 301
+        n_items = 8 * world * B
+        frames = torch.randint(lo, tin + 1, (n_items,), generator=torch.Generator().manual_seed(1))
+        frames[0] = tin
+        smp = DistributedLengthBucketingSampler(list(range(n_items)), B, world, rank, durations=frames.tolist(), partial="fill")
+        smp.shuffle(0)
+        batches = [synthetic_batch_from_lengths(frames[torch.tensor(ids)], C, 10 + 97 * k + rank) for k, ids in enumerate(smp)]
+    else:
+        batches = [synthetic_batch(B, tin, C, 1 + rank)]
+    return tr, [(bx.to(dev), bt, bp, bs) for bx, bt, bp, bs in batches], (rnn, H, L, C, B, tin)
+
+
+def quick_workload(workload, dtype, dev, steps, warmup):
+    """One of the OTHER BASELINE configurations, timed the same way as the headline one (full fused train steps on batches resident in HBM,
+    synchronise / K steps / synchronise) but short: the driver-written record then carries every single-GPU config, not only the metric's.
+    Returns ms per step, utterances / s, the step's fraction of the fp32 (or bf16) matrix roof and the live-timed recurrence kernels."""
+    from asr_amd import ops
+    from asr_amd.trainers import DeepSpeechTrainer
+    tr, batches, (rnn, H, L, C, B, tin) = _make_trainer(workload, dtype, dev)
+    starved0 = DeepSpeechTrainer.starved_steps
+    n = [0]
+
+    def one():
+        bx, bt, bp, bs = batches[n[0] % len(batches)]
+        n[0] += 1
+        return tr.step((bx, bt, bp.clone(), bs))
+    for _ in range(max(warmup, len(batches) if len(batches) > 1 else 0)):
+        one()
+    calls = {"fwd": [], "bwd": []}
+    orig = (ops.rnn_fwd, ops.rnn_bwd, ops.rnn_bwd_bn)
+
+    def ev(fn, key, t_arg, bit):
+        def w(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **k)
+            e1.record()
+            calls[key].append((e0, e1, int(a[t_arg]), bool(ops.rnn_last_path() & bit)))
+            return r
+        return w
+    ops.rnn_fwd, ops.rnn_bwd, ops.rnn_bwd_bn = ev(orig[0], "fwd", 5, 1), ev(orig[1], "bwd", 7, 2), ev(orig[2], "bwd", 12, 2)
+    first = n[0]
+    try:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            valid, lv = one()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        ops.rnn_fwd, ops.rnn_bwd, ops.rnn_bwd_bn = orig
+    tr.synchronize()
+    ms = dt / steps * 1e3
+    used = [batches[k % len(batches)] for k in range(first, first + steps)]
+    flops = sum(sum(train_flops_per_utt(rnn, H, L, C, (int(round(float(p) * int(b[0].size(3)))) + 1) // 2) for p in b[2]) for b in used) / len(used)
+    peak = BF16_MFMA_PEAK_TFLOPS if dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS
+    G = 3 if rnn == "gru" else 4
+    kern = {}
+    for key in ("fwd", "bwd"):
+        c = calls[key]
+        us = sum(a.elapsed_time(b) for a, b, _, _ in c) * 1e3
+        tsteps = sum(t for _, _, t, _ in c)
+        pers = all(p for _, _, _, p in c)
+        kern[key] = {"kernel": f"rnn_{key}_{'persistent' if pers else 'step'}_kernel", "us_per_time_step": us / tsteps,
+                     "achieved_tflops": 2.0 * 2 * B * H * G * H * tsteps / (us * 1e-6) / 1e12, "ms_per_step": us / 1e3 / steps}
+        kern[key]["frac"] = kern[key]["achieved_tflops"] / peak
+    dom = max(kern.values(), key=lambda k: k["ms_per_step"])
+    out = {"workload": f"{workload}: DS2 {L}x{H} bi-{rnn.upper()} {dtype}, T_in {tin}, batch {B}" + (", length-bucketed bins" if len(batches) > 1 else ""),
+           "steps": steps, "ms_per_step": ms, "utterances_per_sec": B * steps / dt, "loss": lv, "valid_last_step": bool(valid),
+           "step_tflops": flops / (ms * 1e-3) / 1e12, "step_frac_of_matrix_peak": flops / (ms * 1e-3) / 1e12 / peak, "matrix_peak_tflops": peak,
+           "roofline": {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved_tflops"], "peak": peak, "unit": "TFLOP/s", "frac": dom["frac"],
+                        "us_per_time_step": dom["us_per_time_step"], "ms_per_step_in_this_kernel": dom["ms_per_step"]},
+           "persistent_starved_steps": DeepSpeechTrainer.starved_steps - starved0}
+    del tr, batches
+    torch.cuda.empty_cache()
+    return out
+
+
+def dp_path_one_rank(dev, steps=5, warmup=3):
+    """The data-parallel code path of the metric configuration with ONE rank: an RCCL process group of size 1 created in this process, the
+    bucketed reducer forced on (DS2_FORCE_ALLREDUCE=1, schedule "conv": one big all-reduce on the communication stream beside the conv-stack
+    backward, the MIN-reduced validity flag) — what that path costs by itself, before there are peers to wait for."""
+    import socket
+    if dist.is_initialized():
+        return {"error": "a process group already exists"}
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    old = {k: os.environ.get(k) for k in ("MASTER_ADDR", "MASTER_PORT", "DS2_FORCE_ALLREDUCE", "DS2_DP_MODE")}
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DS2_FORCE_ALLREDUCE="1", DS2_DP_MODE="conv")
+    try:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        tr, batches, (rnn, H, L, C, B, tin) = _make_trainer("c3", "bf16", dev)
+        bx, bt, bp, bs = batches[0]
+        for _ in range(warmup):
+            tr.step((bx, bt, bp.clone(), bs))
+        red = tr._get_reducer()
+        red.timing = []
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tr.step((bx, bt, bp.clone(), bs))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        tr.synchronize()
+        out = {"ms_per_step": dt / steps * 1e3, "schedule": red.mode, "backend": dist.get_backend(), "world_size": dist.get_world_size(),
+               **red.timing_summary()}
+        del tr, batches
+        torch.cuda.empty_cache()
+        return out
+    except Exception as e:                                   # a box without a usable RCCL must not cost the headline line
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: re-run this command line as N ranks (one per GPU, RCCL) under
     torch.distributed.run and pass rank 0's JSON line through.  Fails loudly when the node has fewer than N GPUs — it never
@@ -291,6 +459,8 @@ def main():
     ap.add_argument("--dtype", default="", choices=["", "f32", "bf16"], help="default: the config dtype (bf16 for c3 and c5, f32 otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print a per-section time breakdown to stderr")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="skip the short runs of the other single-GPU BASELINE configurations (c2 f32, c4 f32) and of the 1-rank data-parallel path")
     ap.add_argument("--ranks-on-one-gpu", action="store_true",
                     help="TEST MODE for the N > 1 code path on a 1-GPU box: every rank uses cuda:0 and the process group is gloo (RCCL cannot put "
                          "two ranks on one device) unless DS2_DIST_BACKEND says otherwise.  The line is labelled; it is not a scaling point.")
@@ -341,7 +511,7 @@ def main():
         n_items = 8 * world * B
         frames = torch.randint(lo, tin + 1, (n_items,), generator=torch.Generator().manual_seed(1))
         frames[0] = tin
-        smp = DistributedLengthBucketingSampler(list(range(n_items)), B, world, rank, durations=frames.tolist())
+        smp = DistributedLengthBucketingSampler(list(range(n_items)), B, world, rank, durations=frames.tolist(), partial="fill")
         smp.shuffle(0)
         batches = [synthetic_batch_from_lengths(frames[torch.tensor(ids)], C, 10 + 97 * k + rank) for k, ids in enumerate(smp)]
         sampler_note = (f"DistributedLengthBucketingSampler over {n_items} synthetic lengths U{{{lo}..{tin}}} frames, {len(batches)} bins per rank cycled; "
@@ -477,14 +647,22 @@ def main():
     achieved = flops_per_launch / (us_per_launch * 1e-6) / 1e12
     peak = BF16_MFMA_PEAK_TFLOPS if bf else FP32_MFMA_PEAK_TFLOPS
     # HBM-side bytes per launch from the committed rocprofv3 PMC summary (separate FETCH_SIZE / WRITE_SIZE passes, FETCH x2 gfx950
-    # correction: scripts/gpu_pmc_persistent.sh -> profiles/r03_pmc_persistent.json), collected for exactly this layer shape and mode
+    # correction: scripts/gpu_pmc_persistent.sh -> profiles/r04_pmc_persistent.json), collected for exactly this layer shape and mode
     # (GRU H=1024 B=64, bf16 operands, packed gate records); null for any other shape or when the file is absent.
-    pmc = load_pmc_summary()
+    pmc, pmc_why_not = load_pmc_summary()
     same_shape = args.workload in ("c3", "c5") and bf and B == 64 and G == 3 and H == 1024
+    if pmc is not None and not same_shape:
+        pmc_why_not = "the PMC summary was collected for the c3 layer shape (GRU H=1024 B=64 bf16)"
+    # the template instance the library launches for this shape (rnn.hip / rnn_bwd_ksplit.h): a summary for another instance is refused too
+    expect = {"rnn_bwd_ksplit_kernel": f"rnn_bwd_ksplit_kernel<{G}, {H // 128}>"}
 
     def pmc_traffic(kernel, steps):
+        nonlocal pmc_why_not
         k = (pmc or {}).get("kernels", {}).get(kernel)
         if not (same_shape and k):
+            return None
+        if kernel in expect and k.get("kernel") != expect[kernel]:
+            pmc_why_not = f"the PMC summary holds {k.get('kernel')}, this run launched {expect[kernel]}"
             return None
         return k["hbm_bytes_per_time_step"] * steps if ("persistent" in kernel or "ksplit" in kernel) else k["hbm_bytes_per_launch"]
     traffic = pmc_traffic("rnn_fwd_persistent_kernel" if persistent else "rnn_fwd_step_kernel", T)
@@ -521,6 +699,8 @@ def main():
                     "us_per_time_step": bwd_layer_us / T, "launches_per_step": bl * L}
     if bwd_layer_us > layer_us:
         roofline, roofline_bwd = roofline_bwd, roofline
+    if roofline["traffic"] is None and pmc_why_not:
+        roofline["traffic_unavailable"] = pmc_why_not
     roofline["second_kernel"] = roofline_bwd
     roofline["timing"] = (f"HIP event pairs around the {len(rnn_calls['fwd'])} + {len(rnn_calls['bwd'])} recurrence calls of the timed region"
                           if timed_in_region else "stand-alone probe after the timed region")
@@ -549,10 +729,24 @@ def main():
             "valid_last_step": bool(valid),
             **({"dist": dist_info} if dist_info else {}),
         }
+        if world == 1 and not args.no_other_workloads and args.workload == "c3" and not args.dtype and not args.batch:
+            # the other single-GPU configurations of BASELINE.json in the driver-written record (short, after the timed region)
+            del model, tr, opt, batches, x
+            torch.cuda.empty_cache()
+            t_other = time.time()
+            other = {}
+            for name, wl, dt_, st in (("c2_f32", "c2", "f32", 6), ("c4_f32", "c4", "f32", 8)):
+                try:
+                    other[name] = quick_workload(wl, dt_, dev, st, 2) if time.time() - t_other < 30 else {"skipped": "time box"}
+                except Exception as e:
+                    other[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            out["other_workloads"] = other
+            out["dp_path_1rank"] = dp_path_one_rank(dev) if time.time() - t_other < 45 else {"skipped": "time box"}
+            model = tr = opt = batches = None
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(rnn, H, L, C, tin, B)
             if out["cpu_baseline"].get("losses"):
-                del model, tr, opt, batches                      # the parity runs build their own models from the CPU port's weights
+                model = tr = opt = batches = None                # the parity runs build their own models from the CPU port's weights
                 torch.cuda.empty_cache()
                 out["loss_parity"] = loss_parity(rnn, H, L, C, tin, out["cpu_baseline"], dev)
         print(json.dumps(out), flush=True)

@@ -198,8 +198,9 @@ int ds2_rnn_poison_if_starved(float* buf, size_t n, void* stream);
  * sets, no synchronisation and no device call.  Lets inference callers that only ever call forward (deepspeech.py:130-149 in eval mode)
  * notice a starved launch and settle it (status call: report, clear, cooldown onto the step kernels) before their next forward. */
 int ds2_rnn_poison_seen(void);
-/* device-side validity of the train step enqueued so far: flag_dev[0] = (loss finite and >= 0 [check_loss, functional.py:45-61]) and no
- * persistent recurrence launch starved, evaluated when the kernel RUNS (stream order) */
+/* device-side validity of the train step enqueued so far, evaluated when the kernel RUNS (stream order): flag_dev[0] = -1 if a persistent
+ * recurrence launch starved, else 1 if the loss is finite and >= 0 [check_loss, functional.py:45-61], else 0.  Under data parallelism the
+ * MIN over ranks is taken; the gated optimizer applies the update only for 1. */
 int ds2_rnn_step_gate(const float* loss_dev, int* flag_dev, void* stream);
 /* Which recurrences may run as one persistent launch (default both).  Switch the backward one off when other kernels (collectives on a
  * communication stream) run on the device during backward: a persistent launch needs all of its workgroups resident at once. */
@@ -244,7 +245,9 @@ int ds2_rnn_bwd_ex(int gates, const float* dy, int lddy, float* gx, float* aux, 
  * bn_var / bn_gamma its batch statistics and weight, bn_s0 / bn_s1 the column sums of dyn and dyn * xhat (dbeta / dgamma of
  * ds2_bn1d_bwd_f32 called with dX = NULL).  Where the K-split persistent kernel takes the call it applies the elementwise half of the
  * BatchNorm backward on the fly (ds2_rnn_last_path() & 16) and dy_scratch is not touched; otherwise dy is materialised into dy_scratch
- * (T*B, H) and the call proceeds as ds2_rnn_bwd_ex.  Replaces autograd's native_batch_norm_backward + the recurrence backward. */
+ * (T*B, H) and the call proceeds as ds2_rnn_bwd_ex.  dy_scratch may be NULL: the call then returns 1 — nothing launched, nothing counted —
+ * when the buffer is needed after all, and the caller repeats it with one (the fused launch never allocates or touches (T*B, H) fp32).
+ * Replaces autograd's native_batch_norm_backward + the recurrence backward. */
 int ds2_rnn_bwd_bn(int gates, const float* dyn, int lddyn, const float* bn_x, int ldx, const float* bn_mean, const float* bn_var,
                    const float* bn_gamma, const float* bn_s0, const float* bn_s1, float bn_eps, float* dy_scratch, float* gx, float* aux,
                    const float* hbuf, const void* wp_bwd, const int* lens_dev, int T, int B, int H, int bf16, void* dgx_bf16,

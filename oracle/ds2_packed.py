@@ -45,9 +45,12 @@ def _bn(x, sd, key, training):
                         training=training, momentum=O.BN_MOMENTUM, eps=O.BN_EPS)
 
 
-def forward(sd: Dict[str, Tensor], x: Tensor, lengths: Tensor, training: bool = True):
+def forward(sd: Dict[str, Tensor], x: Tensor, lengths: Tensor, training: bool = True, packed: bool = True):
     """x (B,1,F,T_in), lengths (B,) input frames, sorted descending (pack_padded_sequence enforces it, blocks.py:87).
-    Returns (logits (B,T,C), output_lengths int32)."""
+    Returns (logits (B,T,C), output_lengths int32).
+    packed=False: the recurrent layers run the same fused aten gru / lstm on the PADDED (T,B,I) tensor, without pack / unpack — exactly
+    equivalent when every utterance of the batch has the full length (nothing is padded), which is asserted; this is
+    the 'fair CPU' form of the bench's baseline leg (no per-time-step packed-sequence slices in autograd)."""
     out_lens = O.seq_lens_after_conv(lengths.cpu().int())
     cp = "conv.seq_module."
     # ---- MaskConv over Conv, BN, Hardtanh, Conv, BN, Hardtanh (deepspeech.py:60-67)
@@ -65,18 +68,26 @@ def forward(sd: Dict[str, Tensor], x: Tensor, lengths: Tensor, training: bool = 
         if l > 0:                                                                 # SequenceWise(BatchNorm1d) over (T*B, H)
             tt, bb = h.size(0), h.size(1)
             h = _bn(h.view(tt * bb, -1), sd, p + "batch_norm.module", training).view(tt, bb, -1)
-        packed = pack_padded_sequence(h, out_lens)                                # blocks.py:87
         flat: List[Tensor] = []
         for suffix in ("", "_reverse"):
             flat += [sd[p + "rnn.weight_ih_l0" + suffix], sd[p + "rnn.weight_hh_l0" + suffix], sd[p + "rnn.bias_ih_l0" + suffix],
                      sd[p + "rnn.bias_hh_l0" + suffix]]
         hid = flat[1].size(1)
-        h0 = torch.zeros(2, int(packed.batch_sizes[0]), hid, dtype=h.dtype)
-        if kind == "gru":
-            y, _ = torch._VF.gru(packed.data, packed.batch_sizes, h0, flat, True, 1, 0.0, training, True)
+        if packed:
+            pk = pack_padded_sequence(h, out_lens)                                # blocks.py:87
+            h0 = torch.zeros(2, int(pk.batch_sizes[0]), hid, dtype=h.dtype)
+            if kind == "gru":
+                y, _ = torch._VF.gru(pk.data, pk.batch_sizes, h0, flat, True, 1, 0.0, training, True)
+            else:
+                y, _, _ = torch._VF.lstm(pk.data, pk.batch_sizes, (h0, h0.clone()), flat, True, 1, 0.0, training, True)
+            y, _ = pad_packed_sequence(torch.nn.utils.rnn.PackedSequence(y, pk.batch_sizes, None, None))   # blocks.py:89
         else:
-            y, _, _ = torch._VF.lstm(packed.data, packed.batch_sizes, (h0, h0.clone()), flat, True, 1, 0.0, training, True)
-        y, _ = pad_packed_sequence(torch.nn.utils.rnn.PackedSequence(y, packed.batch_sizes, None, None))   # blocks.py:89
+            assert int(out_lens.min()) == h.size(0), "the un-packed form is only equivalent for batches without padding"
+            h0 = torch.zeros(2, h.size(1), hid, dtype=h.dtype)
+            if kind == "gru":
+                y, _ = torch._VF.gru(h, h0, flat, True, 1, 0.0, training, True, False)
+            else:
+                y, _, _ = torch._VF.lstm(h, (h0, h0.clone()), flat, True, 1, 0.0, training, True, False)
         h = y.view(y.size(0), y.size(1), 2, -1).sum(2)                            # blocks.py:91-92: fwd + bwd, not concat
     tt, bb = h.size(0), h.size(1)
     z = _bn(h.view(tt * bb, -1), sd, "fc.0.module.0", training)                   # deepspeech.py:103-109
@@ -98,10 +109,10 @@ def leaf_params(sd: Dict[str, Tensor], dtype=torch.float32) -> Dict[str, Tensor]
     return out
 
 
-def fit(params: Dict[str, Tensor], inputs: Tensor, targets: Tensor, input_percentages: Tensor, target_sizes: Tensor):
+def fit(params: Dict[str, Tensor], inputs: Tensor, targets: Tensor, input_percentages: Tensor, target_sizes: Tensor, packed: bool = True):
     """deepspeech_trainer.py:102-117 on the packed-form model: returns (logits (B,T,C), out_lens, loss tensor with graph)."""
     input_sizes = O.lengths_from_percentages(input_percentages, inputs.size(3))
-    out, out_lens = forward(params, inputs, input_sizes, training=True)
+    out, out_lens = forward(params, inputs, input_sizes, training=True, packed=packed)
     lp = out.transpose(0, 1).float().log_softmax(2)
     loss = F.ctc_loss(lp, targets, out_lens, target_sizes, blank=0, reduction="sum", zero_infinity=False) / inputs.size(0)
     return out, out_lens, loss
@@ -112,10 +123,10 @@ def make_optimizer(params: Dict[str, Tensor]):
     return torch.optim.AdamW([v for v in params.values() if v.requires_grad], lr=1.5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5)
 
 
-def train_step(params, optimizer, batch):
+def train_step(params, optimizer, batch, packed: bool = True):
     """One reference train step (deepspeech_trainer.py:86-97): fit -> zero_grad -> backward -> step.  Returns the loss value."""
     inputs, targets, pct, tsz = batch
-    _, _, loss = fit(params, inputs, targets, pct, tsz)
+    _, _, loss = fit(params, inputs, targets, pct, tsz, packed=packed)
     value = float(loss.detach())
     if O.check_loss_value(value):
         optimizer.zero_grad()

@@ -2,7 +2,8 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from asr_amd import ops
-G, H, B, T = 3, 1024, 64, 101
+G, H, B = 3, 1024, 64
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 501
 bf = (sys.argv[1] if len(sys.argv) > 1 else "bf16") == "bf16"
 dev = torch.device("cuda:0")
 gx = torch.randn(T * B, 2 * G * H, device=dev) * 0.5
@@ -19,6 +20,12 @@ if bf:
     side = torch.empty(T * B, 2 * G * H, dtype=torch.bfloat16, device=dev)
     dhn = torch.empty(T * B, 2 * H, dtype=torch.bfloat16, device=dev)
     bias_part = torch.empty(B, 2, 4, H, device=dev)
-    ops.rnn_bwd(G, dy, None, aux, hb, wpb, lens, T, B, H, bf16=True, dgx_bf16=side, gates_bf16=rec, dhn_bf16=dhn, bias_part=bias_part)
+    # as the train step calls it: the BatchNorm1d backward of the layer above applied inside the kernel (ds2_rnn_bwd_bn)
+    bn_x = torch.randn(T * B, H, device=dev)
+    mean, var, gamma = bn_x.mean(0), bn_x.var(0, unbiased=False), torch.ones(H, device=dev)
+    sums = ops.bn1d_bwd_sums(dy, bn_x, mean, var, gamma)
+    ops.rnn_bwd_bn(G, dy, bn_x, mean, var, gamma, sums, None, aux, hb, wpb, lens, T, B, H, bf16=True, dgx_bf16=side, gates_bf16=rec,
+                   dhn_bf16=dhn, bias_part=bias_part)
+    assert ops.rnn_last_path() & 16, "the fused K-split launch did not take the call"
 torch.cuda.synchronize()
 print("done", T, "launches")

@@ -4,7 +4,18 @@ JSON file: per persistent recurrence kernel, HBM-side bytes per launch and per t
 
     python scripts/pmc_summarize.py <dir with pmc_FETCH_SIZE_counter_collection.csv, pmc_WRITE_SIZE_...> <T> <out.json> [shape note]
 """
-import csv, json, os, re, sys
+import csv, hashlib, json, os, re, sys
+
+
+def kernel_source_sha256():
+    """sha256 over the sources the recurrence kernels are built from (the same function is in bench.py, which refuses a summary whose
+    hash differs from the tree it runs in: the counters then belong to another build of the kernels)"""
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "asr_amd", "csrc")
+    h = hashlib.sha256()
+    for name in ("rnn.hip", "rnn_bwd_ksplit.h", "permlane.h", "common.h", "Makefile"):
+        h.update(open(os.path.join(root, name), "rb").read())
+    return h.hexdigest()
+
 
 d, T, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 note = sys.argv[4] if len(sys.argv) > 4 else ""
@@ -21,7 +32,8 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             e = res.setdefault(key, {"kernel": short, "launches": {}, "grid": int(row["Grid_Size"]), "vgpr": int(row["VGPR_Count"])})
             e["launches"].setdefault(ctr, []).append(float(row["Counter_Value"]))
 summary = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over scripts/pmc_rnn.py", "time_steps_per_launch": T, "shape": note,
-           "corrections": "FETCH_SIZE x2 (gfx950: 128-B requests tallied at 64 B); counters in KB -> bytes x1024", "kernels": {}}
+           "corrections": "FETCH_SIZE x2 (gfx950: 128-B requests tallied at 64 B); counters in KB -> bytes x1024",
+           "kernel_source_sha256": kernel_source_sha256(), "kernels": {}}
 for key, e in res.items():
     f = e["launches"].get("FETCH_SIZE", [])
     w = e["launches"].get("WRITE_SIZE", [])

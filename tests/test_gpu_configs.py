@@ -23,8 +23,12 @@ from test_gpu_model import TOL, make_model
 pytestmark = pytest.mark.gpu
 
 
-def _step_vs_oracle(cfg, precision, tol_logits, tol_loss, tol_grad, tol_conv):
+def _step_vs_oracle(cfg, precision, tol_logits, tol_loss, tol_grad, tol_conv=None):
+    """tol_conv None (the bf16 cases): the conv-stack gradients are held to the COUNTED bound max(3 sqrt(f), 4e-2), f = the fraction of live
+    Hardtanh elements whose branch differs between the fp32 and the bf16 forward of this very model and batch (helpers.hardtanh_flip_fraction:
+    a flipped element switches its whole upstream gradient on or off) — not to a flat 15-20 %."""
     from asr_amd import CTCLoss
+    from helpers import hardtanh_flip_fraction
     sd, x, targets, pct, tsz = model_inputs(cfg)
     B = x.size(0)
     ref = O.fit_and_grads(sd, x, targets, pct, tsz, dtype=torch.float64)
@@ -40,13 +44,18 @@ def _step_vs_oracle(cfg, precision, tol_logits, tol_loss, tol_grad, tol_conv):
         assert e_logits > 1e-5, "the bf16 path did not run"
     assert abs(float(loss.detach()) - ref["loss"]) / ref["loss"] < tol_loss
     worst = {}
+    grads = {k: p.grad.cpu().numpy().astype(np.float64) for k, p in model.named_parameters()}
+    flips = None
+    if tol_conv is None:
+        flips = hardtanh_flip_fraction(model, x, pct)          # (two more training-mode forwards: after the gradients were taken)
+        tol_conv = max(3.0 * flips ** 0.5, 4e-2)
     # a gradient that is analytically zero (conv bias in front of BatchNorm when nothing is masked) is held to the scale of the others
     gmax = max(float(np.linalg.norm(g.numpy())) for g in ref["grads"].values())
-    for k, p in model.named_parameters():
+    for k in grads:
         gref = ref["grads"][k].numpy()
-        err = np.linalg.norm(p.grad.cpu().numpy().astype(np.float64) - gref) / max(np.linalg.norm(gref), 1e-4 * gmax, 1e-12)
+        err = np.linalg.norm(grads[k] - gref) / max(np.linalg.norm(gref), 1e-4 * gmax, 1e-12)
         worst[k] = err
-        assert err <= (tol_conv if k.startswith("conv.") else tol_grad), (k, err)
+        assert err <= (tol_conv if k.startswith("conv.") else tol_grad), (k, err, tol_conv, flips)
     return worst
 
 
@@ -58,7 +67,7 @@ def test_c1_tiny_full_config_vs_oracle(precision):
     if precision == "fp32":
         _step_vs_oracle(cfg, "fp32", TOL, TOL, TOL, TOL)
     else:
-        _step_vs_oracle(cfg, "bf16", 2e-2, 2e-2, 6e-2, 1.5e-1)
+        _step_vs_oracle(cfg, "bf16", 2e-2, 2e-2, 6e-2)
 
 
 def test_c1_tiny_fused_steps_follow_the_oracle_loss_curve():
@@ -93,7 +102,7 @@ def test_c4_width_lstm1280_vs_oracle(precision):
     if precision == "fp32":
         _step_vs_oracle(cfg, "fp32", TOL, TOL, TOL, TOL)
     else:
-        _step_vs_oracle(cfg, "bf16", 2e-2, 2e-2, 8e-2, 2e-1)
+        _step_vs_oracle(cfg, "bf16", 2e-2, 2e-2, 8e-2)
 
 
 def _full_size_properties(cfg, B, t_ins, classes, precision, steps=3, check_fp32_loss=True):
@@ -165,7 +174,7 @@ def test_c5_width_gru1024_80_classes_vs_oracle(precision):
     if precision == "fp32":
         _step_vs_oracle(cfg, "fp32", TOL, TOL, TOL, TOL)
     else:
-        _step_vs_oracle(cfg, "bf16", 2e-2, 2e-2, 8e-2, 2e-1)
+        _step_vs_oracle(cfg, "bf16", 2e-2, 2e-2, 8e-2)
 
 
 def test_c5_full_size_properties_bf16():
@@ -315,7 +324,6 @@ def test_full_depth_step_vs_packed_cpu_oracle(rnn, hidden, layers, classes, t_in
     c5 case) takes the bf16 mode through the train step's own schedule: packed gate records, persistent forward and K-split backward
     recurrences with the BatchNorm1d backward applied inside, TN-form weight gradients."""
     from oracle import ds2_packed as P
-    from asr_amd import CTCLoss
     cfg = dict(rnn=rnn, hidden=hidden, layers=layers, classes=classes, t_ins=t_ins)
     sd, x, targets, pct, tsz = model_inputs(cfg, well_conditioned=False)
     B = x.size(0)
@@ -324,25 +332,56 @@ def test_full_depth_step_vs_packed_cpu_oracle(rnn, hidden, layers, classes, t_in
     out_ref, _, loss_ref = P.fit(params, x, targets, pct.clone(), tsz)
     loss_ref.backward()
     gref = {k: v.grad.detach().numpy().astype(np.float64) for k, v in params.items() if v.requires_grad}
+    _hip_modes_vs_cpu_reference(cfg, sd, x, targets, pct, tsz, out_ref, loss_ref, gref, (("fp32", TOL, TOL), ("bf16", 2e-2, 6e-2)))
+
+
+def _hip_modes_vs_cpu_reference(cfg, sd, x, targets, pct, tsz, out_ref, loss_ref, gref, modes):
+    """logits / loss / every parameter gradient of the HIP path in each (precision, logit-and-loss tolerance, gradient tolerance) of `modes`
+    against the CPU reference results; the conv-stack gradients of the bf16 mode are held to the counted bound max(3 sqrt(f), 4e-2)."""
+    from asr_amd import CTCLoss, ops
+    from helpers import hardtanh_flip_fraction
+    B = x.size(0)
     gmax = max(float(np.linalg.norm(g)) for g in gref.values())
     lens = O.lengths_from_percentages(pct, x.size(3))
-    for precision, tl, tg, tc in (("fp32", TOL, TOL, TOL), ("bf16", 2e-2, 6e-2, 1.5e-1)):
+    for precision, tl, tg in modes:
         model = make_model(cfg, sd)
         model.precision = precision
         out, out_lens = model.forward(x.cuda(), lens)
         loss = CTCLoss(reduction="sum")(out.transpose(0, 1), targets, out_lens, tsz) / B
         loss.backward()
-        if precision == "bf16" and B % 8 == 0 and hidden % 256 == 0:
-            from asr_amd import ops
+        if precision == "bf16" and B % 8 == 0 and cfg["hidden"] % 256 == 0:
             assert ops.rnn_last_path() & 22 == 22, "the train step's own schedule: persistent K-split backward with the BatchNorm backward inside"
         # logits are compared on the valid frames (beyond a sample's length both sides hold BatchNorm-of-zero garbage that CTC ignores)
         e_logits = max(rel_l2(out[b, :int(out_lens[b])].detach().cpu().numpy(), out_ref[b, :int(out_lens[b])].detach().numpy()) for b in range(B))
         e_loss = abs(float(loss.detach()) - float(loss_ref.detach())) / float(loss_ref.detach())
+        grads = {k: p.grad.cpu().numpy().astype(np.float64) for k, p in model.named_parameters()}
+        tc, flips = tg, None
+        if precision == "bf16":
+            flips = hardtanh_flip_fraction(model, x, pct)
+            tc = max(3.0 * flips ** 0.5, 4e-2)
         worst = ("", 0.0)
-        for k, p in model.named_parameters():
-            err = np.linalg.norm(p.grad.cpu().numpy().astype(np.float64) - gref[k]) / max(np.linalg.norm(gref[k]), 1e-4 * gmax, 1e-12)
-            assert err <= (tc if k.startswith("conv.") else tg), (precision, k, err)
+        for k, g in grads.items():
+            err = np.linalg.norm(g - gref[k]) / max(np.linalg.norm(gref[k]), 1e-4 * gmax, 1e-12)
+            assert err <= (tc if k.startswith("conv.") else tg), (precision, k, err, tc, flips)
             worst = max(worst, (k, err), key=lambda kv: kv[1])
-        print(f"{layers}x{hidden} {rnn} {precision}: logits {e_logits:.2e} loss {e_loss:.2e} worst gradient {worst[0]} {worst[1]:.2e}")
+        print(f"{cfg['layers']}x{cfg['hidden']} {cfg['rnn']} B={B} T_in={x.size(3)} {precision}: logits {e_logits:.2e} loss {e_loss:.2e} worst gradient "
+              f"{worst[0]} {worst[1]:.2e}" + (f" (conv bound {tc:.2e}, flips {flips:.2e})" if flips is not None else ""))
         assert e_logits < tl and e_loss < tl, (precision, e_logits, e_loss)
         del model
+
+
+def test_bf16_train_step_schedule_vs_cpu_oracle_b16_t501():
+    """The headline mode against the CPU oracle at a batch and length where the train step's own schedule is fully engaged: 5 x 1024 BiGRU,
+    B = 16 (two 16-row batch tiles of every persistent recurrence would be B = 32; this is one tile per direction and slice), T_in = 501 (251
+    recurrent steps), bf16 operands through packed gate records, persistent forward, K-split backward with the fused BatchNorm backward and
+    TN-form weight gradients — logits, loss and every gradient against `oracle/ds2_packed.py` (equal-length batch: its un-packed form, which
+    is exactly the packed one when nothing is padded and takes seconds instead of minutes on the host), fp32 beside it at 1e-3."""
+    from oracle import ds2_packed as P
+    cfg = dict(rnn="gru", hidden=1024, layers=5, classes=29, t_ins=[501] * 16)
+    sd, x, targets, pct, tsz = model_inputs(cfg, well_conditioned=False)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    params = P.leaf_params(sd)
+    out_ref, _, loss_ref = P.fit(params, x, targets, pct.clone(), tsz, packed=False)
+    loss_ref.backward()
+    gref = {k: v.grad.detach().numpy().astype(np.float64) for k, v in params.items() if v.requires_grad}
+    _hip_modes_vs_cpu_reference(cfg, sd, x, targets, pct, tsz, out_ref, loss_ref, gref, (("fp32", TOL, TOL), ("bf16", 2e-2, 6e-2)))

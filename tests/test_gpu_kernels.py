@@ -633,10 +633,23 @@ def test_ksplit_backward_vs_oracle(dev, kind, H, B, T):
         path = ops.rnn_last_path()
         lib.ds2_debug_flags(0)
         assert bool(path & 4) == (name == "ksplit"), f"{name}: path {path}"
-        err[name] = rel_l2(side.float().cpu(), ref)
+        got = side.float().cpu()
+        err[name] = rel_l2(got, ref)
+        # per unit class: the exchange tag replaces the last mantissa bit of the partial sums of the hidden units u = 0 mod 4
+        # (rnn_bwd_ksplit.h: bit 0 of every 8-byte half of a piece) — up to one bf16 ulp of extra, same-signed error per producer on those
+        # units' dh and on no others.  Their error against the fp64 recurrence is measured separately from the other three quarters'.
+        tagged = ((torch.arange(2 * G * H) % H) % 4 == 0)
+        err[name + "_tagged_units"] = rel_l2(got[:, tagged], ref[:, tagged])
+        err[name + "_other_units"] = rel_l2(got[:, ~tagged], ref[:, ~tagged])
     ops.rnn_persistent_check()
-    print(f"{kind} H={H} B={B} T={T}: dGx vs fp64 oracle: K-split {err['ksplit']:.3e}, other kernel family {err['allgather_or_step']:.3e}")
+    print(f"{kind} H={H} B={B} T={T}: dGx vs fp64 oracle: K-split {err['ksplit']:.3e} (units 0 mod 4: {err['ksplit_tagged_units']:.3e}, others "
+          f"{err['ksplit_other_units']:.3e}), other kernel family {err['allgather_or_step']:.3e} (units 0 mod 4: "
+          f"{err['allgather_or_step_tagged_units']:.3e}, others {err['allgather_or_step_other_units']:.3e})")
     assert err["ksplit"] < 6e-3 and err["ksplit"] < 1.1 * err["allgather_or_step"]
+    # the tag's bias stays inside the bf16-operand error: the tagged quarter of the units is no worse than the rest by more than what the
+    # un-tagged kernel family shows between the same two groups (which is data, not tag) plus 15 %
+    base = err["allgather_or_step_tagged_units"] / err["allgather_or_step_other_units"]
+    assert err["ksplit_tagged_units"] <= (base + 0.15) * err["ksplit_other_units"], err
 
 
 @pytest.mark.parametrize("kind,H,B,T", [("gru", 1024, 64, 12), ("lstm", 1280, 32, 7), ("gru", 256, 20, 16)])
