@@ -45,6 +45,7 @@ SIGNATURES = {
     "ds2_gemm_bf16_tn_group": (i32, [i32, vp, i32, vp]),
     "ds2_gemm_bf16_nt": (i32, [i32, i32, i32, vp, i32, i64, vp, i32, i64, vp, i32, i64, vp, i32, i32, i32, vp, sz, vp]),
     "ds2_cast_bf16": (i32, [vp, i32, vp, i32, i32, i32, vp]),
+    "ds2_split_bf16": (i32, [vp, i32, vp, i32, i32, i32, i32, vp]),
     "ds2_cast_transpose_bf16": (i32, [vp, i32, vp, i32, i32, i32, vp]),
     "ds2_cast_bf16_both_workspace_bytes": (sz, [i32, i32]),
     "ds2_cast_bf16_both": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, vp, vp, sz, vp]),

@@ -941,6 +941,42 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const __bf16* __res
   }
 }
 
+// fp32 (R x C, pitch lds_) -> SPLIT bf16 operand for the fp32 mode's three-term products: x = hi + lo + O(2^-18 x) with hi = bf16(x),
+// lo = bf16(x - hi), and  a.b ~= a_hi b_hi + a_hi b_lo + a_lo b_hi  (the dropped lo.lo term is 2^-18 of the product): three bf16 MFMA
+// products with fp32 accumulation instead of one fp32-input MFMA product at a sixteenth of the rate.  The three terms are ONE GEMM over a
+// reduction index three times as long: the A operand is written as [hi | hi | lo] per row and the B operand as [hi | lo | hi]
+// (order 0 / 1), each block Cp = pad8(C) columns wide with zero padding; order 2 = [hi | lo] (operands of TN products, whose terms are
+// accumulated launch by launch on row-pitched views of the blocks).
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ src, int lds_, __bf16* __restrict__ dst, int ldd, int R, int Cc,
+                                                         int Cp, int order, int vec) {
+  const int cq = Cp / 4;
+  const long long total = (long long)R * cq;
+  const int b_hi2 = order == 0 ? Cp : (order == 1 ? 2 * Cp : -1);       // second copy of hi (none for order 2)
+  const int b_lo = order == 0 ? 2 * Cp : Cp;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int r = i / cq, c0 = (i % cq) * 4;
+    const float* sp = src + (long long)r * lds_ + c0;
+    float v[4];
+    if (c0 + 4 <= Cc && vec) {
+      const f32x4 q = *reinterpret_cast<const f32x4*>(sp);
+      v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = (c0 + j < Cc) ? sp[j] : 0.f;
+    }
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      hi[j] = (__bf16)v[j];
+      lo[j] = (__bf16)(v[j] - (float)hi[j]);
+    }
+    __bf16* d = dst + (long long)r * ldd + c0;
+    *reinterpret_cast<bf16x4*>(d) = hi;
+    if (b_hi2 >= 0) *reinterpret_cast<bf16x4*>(d + b_hi2) = hi;
+    *reinterpret_cast<bf16x4*>(d + b_lo) = lo;
+  }
+}
+
 #include "gemm_tn_group.h"
 
 }  // namespace
@@ -1133,6 +1169,22 @@ extern "C" int ds2_cast_bf16(const float* src, int ld_src, void* dst, int ld_dst
   const int vec = ((ld_src % 4) == 0) && (((uintptr_t)src % 16) == 0);
   hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, ld_src, (__bf16*)dst, ld_dst, R, Cc, vec);
   DS2_LAUNCH_CHECK("cast_bf16_kernel");
+  return 0;
+}
+
+// dst (R, ld_dst) bf16 = the split form of src (R, C) fp32 (pitch ld_src) for the fp32 mode's three-term bf16 products (split_bf16_kernel):
+// order 0 [hi | hi | lo], 1 [hi | lo | hi] (3 blocks), 2 [hi | lo] (2 blocks); every block pad8(C) columns, pad zero-filled.
+// ld_dst >= blocks * pad8(C), ld_dst % 8 == 0.
+extern "C" int ds2_split_bf16(const float* src, int ld_src, void* dst, int ld_dst, int R, int Cc, int order, void* stream) {
+  DS2_REQUIRE(src && dst && R > 0 && Cc > 0 && order >= 0 && order <= 2, "ds2_split_bf16: bad args");
+  const int Cp = (Cc + 7) / 8 * 8, nb = order == 2 ? 2 : 3;
+  DS2_REQUIRE(ld_dst >= nb * Cp && (ld_dst % 8) == 0 && ((uintptr_t)dst % 16) == 0, "ds2_split_bf16: ld_dst must be >= %d and a multiple of 8", nb * Cp);
+  const long long total = (long long)R * (Cp / 4);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 16384) blocks = 16384;
+  const int vec = ((ld_src % 4) == 0) && (((uintptr_t)src % 16) == 0);
+  hipLaunchKernelGGL(split_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, ld_src, (__bf16*)dst, ld_dst, R, Cc, Cp, order, vec);
+  DS2_LAUNCH_CHECK("split_bf16_kernel");
   return 0;
 }
 

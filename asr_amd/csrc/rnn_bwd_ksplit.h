@@ -46,9 +46,8 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char
   __shared__ __attribute__((aligned(16))) __bf16 As[2][4][16][AST];
   const PRole role = persist_role(a, census, spin_limit, 2);
   if (!role.active) return;
-  // every instruction of this kernel is on the layer's critical path; whatever shares the CU (the co-resident weight-gradient kernel of
-  // the layer above: gemm_tn_group.h) is not — win every issue arbitration against it
-  __builtin_amdgcn_s_setprio(3);
+  // (s_setprio 3 here — win every issue arbitration against a co-resident weight-gradient kernel, gemm_tn_group.h — changed nothing
+  // in the co-residency experiment: what the recurrence loses there is queueing in the CU's memory path, profiles/r04_wgrad_side_ab.txt)
   const int dir = role.dir, bt = role.bt, slice = role.slice;          // slice = my 32 units = my producer index
   const bool l2_local = role.local != 0;
   const int T = a.T, B = a.B, H = a.H, lddy = a.lddy;

@@ -55,6 +55,18 @@ FUSE_BN_BWD = _os.environ.get("DS2_FUSE_BN_BWD", "1") != "0"
 #   "main"         the same grouped kernel on the compute stream right behind the layer's critical-path work (the one-stream schedule the
 #                  side-stream results are compared with bit for bit: tests/test_gpu_round4.py); +0.5 ms per step against "0"
 WGRAD_SIDE = _os.environ.get("DS2_WGRAD_SIDE", "0")
+# fp32 mode, the dense input-to-hidden products (forward projection, dXn, dW_ih, dW_hh) of layers large enough for the 256 x 256 kernels
+# (DS2_F32_GEMM): "split" (default) = every fp32 operand split into two bf16 terms (hi = bf16(x), lo = bf16(x - hi)) and the product taken
+# as hi.hi + hi.lo + lo.hi on the bf16 matrix cores with fp32 accumulation — ~1e-5 of the fp32 product (the 2^-18 lo.lo term is dropped),
+# two orders inside north_star's 1e-3, at 3 bf16 MFMA products instead of one at a sixteenth of the rate (ops.split_bf16);
+# "f32" = the fp32-input MFMA kernels (csrc/gemm.hip) for every shape, as rounds 1-3.  Recurrences, BatchNorm, CTC, conv stack: fp32 as before.
+F32_GEMM = _os.environ.get("DS2_F32_GEMM", "split")
+
+
+def _f32_split_ok(M: int, N: int, K: int) -> bool:
+    return F32_GEMM == "split" and M >= 512 and N >= 256 and K >= 256 and K % 8 == 0 and N % 8 == 0
+
+
 _BWD_PERSISTENT = {}      # (gates, H, B) -> did the last backward recurrence of this shape run as a persistent launch?
 _SIDE = {}
 
@@ -117,6 +129,7 @@ class LayerCtx:
     wpb: Optional[Tensor] = None     # W_hh^T in fragment order for the backward recurrence
     rec: Optional[Tensor] = None     # bf16 training: packed saved-gate records (M, 2H, 4) instead of gates in gx
     h_bf: Optional[Tensor] = None    # bf16 training, persistent forward recurrence: (M, 2H) bf16 copy of hbuf (operand of the TN-form dW_hh)
+    xs: Optional[Tensor] = None      # fp32 mode, split-bf16 GEMMs: (M, 3 I) [hi | hi | lo] split copy of xn (xn itself is then not kept)
     gshape: tuple = ()               # (M, 2GH) when gx itself was released
 
 
@@ -229,6 +242,12 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
             xn = xn0 if cfg.precision == "bf16" else xin
         if cfg.precision == "bf16":
             gx = ops.gemm_bf16_nt(xn, ops.cast_bf16(W[f"rnns.{l}.wih_cat"]), bias=W[f"rnns.{l}.bih_cat"])
+        elif _f32_split_ok(M, 2 * G * H, xn.shape[1]):
+            # three-term split-bf16 product as ONE NT GEMM over a reduction index 3 I long: [hi | hi | lo] x [hi | lo | hi]^T
+            lc.xs = ops.split_bf16(xn, 0)
+            gx = ops.gemm_bf16_nt(lc.xs, ops.split_bf16(W[f"rnns.{l}.wih_cat"], 1), bias=W[f"rnns.{l}.bih_cat"])
+            if save:
+                xn = None                                        # backward takes dW_ih from the split copy (6 bytes per element instead of 4 + 6)
         else:
             gx = ops.gemm(xn, W[f"rnns.{l}.wih_cat"], transB=True, bias=W[f"rnns.{l}.bih_cat"])  # (M, 2GH)
         bf = cfg.precision == "bf16"
@@ -491,8 +510,8 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
         first_layer = L - 1
     for l in range(first_layer, -1, -1):
         lc = ctx.layers[l]
-        I = lc.xn.shape[1]
         bf = cfg.precision == "bf16"
+        split = (not bf) and lc.xs is not None                   # fp32 mode, three-term split-bf16 products (forward decided: _f32_split_ok)
         # bf16 mode: the step kernels write dGx in bf16 (row-major) into a side buffer that the GEMMs consume directly (needs
         # B % 8 == 0 for the 16-byte aligned time-shifted operand views below; other batch sizes keep fp32 dGx + a cast pass)
         bfd = bf and B % 8 == 0
@@ -511,6 +530,12 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
             dgx_r, dgxT, dbih_sum = ops.cast_bf16_both(dgx, colsum=True)
             dxn = ops.gemm_bf16_nt(dgx_r, ops.cast_transpose_bf16(W[f"rnns.{l}.wih_cat"]))
             del dgx_r
+        elif split:
+            # dXn = dGx W_ih as [hi | hi | lo](dGx) x [hi | lo | hi](W_ih^T)^T; the split copy of dGx also feeds both weight-gradient products
+            dgs = ops.split_bf16(dgx, 0)                                                          # (M, 3 * 2GH)
+            wT = ops.transpose_batched(W[f"rnns.{l}.wih_cat"].unsqueeze(0))[0]                    # (I, 2GH)
+            dxn = ops.gemm_bf16_nt(dgs, ops.split_bf16(wT, 1))
+            del wT
         else:
             dxn = ops.gemm(dgx, W[f"rnns.{l}.wih_cat"])                                           # (M, I)
         # ---- off the critical path: bias and weight gradients ------------------------------------------------------
@@ -543,6 +568,22 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
                 if G == 3:
                     ops.gemm_bf16_nt_pair(auxT[0:H, ka[0]], auxT[H:2 * H, ka[1]], hT[0:H, kb[0]], hT[H:2 * H, kb[1]], dwhh[:, 2 * H:])
                 keep.append((dgxT, hT, auxT))
+            elif T > 1 and split:
+                # three accumulating TN launches per product: hi.hi, hi.lo, lo.hi on row-pitched views of the split copies
+                C2 = 2 * G * H
+                hs = ops.split_bf16(lc.hbuf, 2)                                                   # (M, 4H) = [hi | lo]
+                terms = ((dgs[:, :C2], hs[:, :2 * H]), (dgs[:, :C2], hs[:, 2 * H:]), (dgs[:, 2 * C2:], hs[:, :2 * H]))
+                rows = 2 * H if G == 3 else 4 * H
+                ra, rb = (slice(B, M), slice(0, M - B)), (slice(0, M - B), slice(B, M))
+                for k, (a, b) in enumerate(terms):
+                    ops.gemm_bf16_tn_pair(a[ra[0], 0:rows], a[ra[1], G * H:G * H + rows], b[rb[0], 0:H], b[rb[1], H:2 * H], dwhh[:, :rows],
+                                          accumulate=k > 0)
+                if G == 3:                                                                        # n-gate rows use d(hn) (aux) instead of dGx_n
+                    axs = ops.split_bf16(lc.aux, 2)                                               # (M, 4H)
+                    for k, (a, b) in enumerate(((axs[:, :2 * H], hs[:, :2 * H]), (axs[:, :2 * H], hs[:, 2 * H:]), (axs[:, 2 * H:], hs[:, :2 * H]))):
+                        ops.gemm_bf16_tn_pair(a[ra[0], 0:H], a[ra[1], H:2 * H], b[rb[0], 0:H], b[rb[1], H:2 * H], dwhh[:, 2 * H:], accumulate=k > 0)
+                    keep.append((axs,))
+                keep.append((hs,))
             elif T > 1:
                 K = (T - 1) * B
                 ldg, ldh = 2 * G * H, 2 * H
@@ -565,9 +606,15 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
                 xnT = ops.transpose_bf16(lc.xn[:, :W[f"rnns.{l}.wih_cat"].shape[1]])              # lc.xn is bf16 (M, pad8(I)) in this mode
                 ops.gemm_bf16_nt(dgxT, xnT, out=Gr[f"rnns.{l}.wih_cat"])
                 keep.append((dgxT, xnT))
+            elif split:
+                C2, I = 2 * G * H, W[f"rnns.{l}.wih_cat"].shape[1]
+                Ip = lc.xs.shape[1] // 3
+                for k, (a, b) in enumerate(((dgs[:, :C2], lc.xs[:, :I]), (dgs[:, :C2], lc.xs[:, 2 * Ip:2 * Ip + I]), (dgs[:, 2 * C2:], lc.xs[:, :I]))):
+                    ops.gemm_bf16_tn(a, b, out=Gr[f"rnns.{l}.wih_cat"], accumulate=k > 0)
+                keep.append((dgs, lc.xs))
             else:
                 ops.gemm(dgx, lc.xn, transA=True, out=Gr[f"rnns.{l}.wih_cat"])
-        lc.gx = lc.aux = lc.hbuf = lc.xn = lc.wpb = None
+        lc.gx = lc.aux = lc.hbuf = lc.xn = lc.wpb = lc.xs = None
         if l > 0:
             bp = f"rnns.{l}.batch_norm.module."
             dy = ops.bn1d_bwd(dxn, lc.xin, lc.mean, lc.var, W[bp + "weight"], Gr[bp + "weight"], Gr[bp + "bias"])

@@ -240,7 +240,7 @@ def gemm_bf16_tn(A: Tensor, B: Tensor, out: Optional[Tensor] = None, accumulate:
     return out
 
 
-def gemm_bf16_tn_pair(A0: Tensor, A1: Tensor, B0: Tensor, B1: Tensor, out: Tensor):
+def gemm_bf16_tn_pair(A0: Tensor, A1: Tensor, B0: Tensor, B1: Tensor, out: Tensor, accumulate: bool = False):
     """Two equal-shape TN products in ONE launch: out[d] (M, N) = A_d (K, M)^T @ B_d (K, N).  A0/A1 (and B0/B1) are views of one bf16
     buffer with equal pitches (the two directions of dW_hh: column blocks of dGx / h at row offsets of +-B)."""
     for t in (A0, A1, B0, B1):
@@ -258,7 +258,19 @@ def gemm_bf16_tn_pair(A0: Tensor, A1: Tensor, B0: Tensor, B1: Tensor, out: Tenso
         wsb = lib.ds2_gemm_bf16_workspace_bytes(M, N, 2, splitk)
         ws = _ws(wsb, A0.device)
     _lib.check(lib.ds2_gemm_bf16_tn(M, N, K, A0.data_ptr(), A0.stride(0), dA // 2, B0.data_ptr(), B0.stride(0), dB // 2, out.data_ptr(),
-                                    out.stride(1), out.stride(0), 0, 2, splitk, _ptr(ws), wsb, _stream()), "ds2_gemm_bf16_tn")
+                                    out.stride(1), out.stride(0), int(accumulate), 2, splitk, _ptr(ws), wsb, _stream()), "ds2_gemm_bf16_tn")
+    return out
+
+
+def split_bf16(X: Tensor, order: int) -> Tensor:
+    """fp32 (R, C) row-major view -> its split bf16 operand (R, n * pad8(C)): x = hi + lo, hi = bf16(x), lo = bf16(x - hi); order 0 = [hi | hi | lo]
+    (A operand of the fp32 mode's three-term product), 1 = [hi | lo | hi] (B operand), 2 = [hi | lo] (TN products).  See ds2_split_bf16."""
+    _chk_f32(X)
+    assert X.dim() == 2 and X.stride(1) == 1 and order in (0, 1, 2)
+    R, Cc = X.shape
+    Cp = (Cc + 7) // 8 * 8
+    out = torch.empty(R, (2 if order == 2 else 3) * Cp, dtype=torch.bfloat16, device=X.device)
+    _lib.check(_lib.load().ds2_split_bf16(X.data_ptr(), _row_pitch(X), out.data_ptr(), out.stride(0), R, Cc, order, _stream()), "ds2_split_bf16")
     return out
 
 

@@ -382,8 +382,23 @@ def quick_workload(workload, dtype, dev, steps, warmup):
     return out
 
 
-def dp_path_one_rank(dev, steps=5, warmup=3):
-    """The data-parallel code path of the metric configuration with ONE rank: an RCCL process group of size 1 created in this process, the
+def dp_path_one_rank(limit_s=120):
+    """dp_path_one_rank_worker in a child process: RCCL prints its banner through C stdio when the process exits, i.e. BEHIND this process's
+    JSON line if it ran here — and the line must stay the last thing on stdout."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--dp-one-rank-worker"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=limit_s, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+        for line in r.stdout.splitlines():
+            if line.startswith("DP1_JSON "):
+                return json.loads(line[len("DP1_JSON "):])
+        return {"error": "worker failed: " + (r.stderr or r.stdout)[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"error": f"worker exceeded {limit_s}s"}
+
+
+def dp_path_one_rank_worker(dev, steps=5, warmup=3):
+    """The data-parallel code path of the metric configuration with ONE rank: an RCCL process group of size 1, the
     bucketed reducer forced on (DS2_FORCE_ALLREDUCE=1, schedule "conv": one big all-reduce on the communication stream beside the conv-stack
     backward, the MIN-reduced validity flag) — what that path costs by itself, before there are peers to wait for."""
     import socket
@@ -445,6 +460,10 @@ def spawn_ranks(n):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--dp-one-rank-worker":
+        torch.cuda.set_device(0)
+        print("DP1_JSON " + json.dumps(dp_path_one_rank_worker(torch.device("cuda", 0))), flush=True)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-baseline-worker":
         rnn, H, L, C, tin, B = sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7])
         return cpu_baseline_worker(rnn, H, L, C, tin, B)
@@ -741,7 +760,7 @@ def main():
                 except Exception as e:
                     other[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
             out["other_workloads"] = other
-            out["dp_path_1rank"] = dp_path_one_rank(dev) if time.time() - t_other < 45 else {"skipped": "time box"}
+            out["dp_path_1rank"] = dp_path_one_rank() if time.time() - t_other < 45 else {"skipped": "time box"}
             model = tr = opt = batches = None
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(rnn, H, L, C, tin, B)

@@ -69,6 +69,13 @@ typedef struct ds2_tn_problem {
 } ds2_tn_problem;
 int ds2_gemm_bf16_tn_group(int nprob, const ds2_tn_problem* problems, int max_workgroups, void* stream);
 int ds2_cast_bf16(const float* src, int ld_src, void* dst, int ld_dst, int R, int Cc, void* stream);
+/* fp32 mode (precision="fp32", BASELINE configs[1],[3]), large GEMMs: every fp32 operand is SPLIT into two bf16 terms, x = hi + lo with
+ * hi = bf16(x), lo = bf16(x - hi) (x is represented to 2^-18 relative), and a product is taken as a_hi b_hi + a_hi b_lo + a_lo b_hi on the bf16
+ * matrix cores with fp32 accumulation (the dropped lo.lo term is 2^-18 of the product; the result is within ~1e-5 of the fp32 product,
+ * two orders inside north_star's 1e-3) — torch.nn.functional.linear / autograd's mm (blocks.py:76-78,88) at ~5x the fp32-MFMA roof.
+ * dst (R, ld_dst) bf16 = blocks of pad8(C) columns each: order 0 [hi | hi | lo] (A operand), 1 [hi | lo | hi] (B operand: one NT product
+ * over a reduction index 3 pad8(C) long IS the three-term product), 2 [hi | lo] (TN products take row-pitched views of the blocks). */
+int ds2_split_bf16(const float* src, int ld_src, void* dst, int ld_dst, int R, int Cc, int order, void* stream);
 int ds2_cast_transpose_bf16(const float* src, int ld_src, void* dst, int ld_dst, int R, int Cc, void* stream);
 /* both copies from ONE read of src: dst_r (R, ld_r) = bf16(src) (NULL: skipped), dst_t (C, ld_t) = bf16(src)^T, pads zero
  * (ld_r % 8 == 0, C <= ld_r < C + 8; ld_t % 8 == 0, ld_t >= R); colsum (C) optional: column sums of src from the same read

@@ -339,9 +339,10 @@ def _hip_modes_vs_cpu_reference(cfg, sd, x, targets, pct, tsz, out_ref, loss_ref
     """logits / loss / every parameter gradient of the HIP path in each (precision, logit-and-loss tolerance, gradient tolerance) of `modes`
     against the CPU reference results; the conv-stack gradients of the bf16 mode are held to the counted bound max(3 sqrt(f), 4e-2)."""
     from asr_amd import CTCLoss, ops
-    from helpers import hardtanh_flip_fraction
+    from helpers import hardtanh_flip_fraction, noise_only_grads
     B = x.size(0)
     gmax = max(float(np.linalg.norm(g)) for g in gref.values())
+    noise = noise_only_grads(cfg)                              # analytically zero gradients (conv biases of an un-padded batch): round-off on both sides
     lens = O.lengths_from_percentages(pct, x.size(3))
     for precision, tl, tg in modes:
         model = make_model(cfg, sd)
@@ -361,6 +362,9 @@ def _hip_modes_vs_cpu_reference(cfg, sd, x, targets, pct, tsz, out_ref, loss_ref
             tc = max(3.0 * flips ** 0.5, 4e-2)
         worst = ("", 0.0)
         for k, g in grads.items():
+            if k in noise:
+                assert np.linalg.norm(g) <= 1e-3 * gmax, (precision, k)
+                continue
             err = np.linalg.norm(g - gref[k]) / max(np.linalg.norm(gref[k]), 1e-4 * gmax, 1e-12)
             assert err <= (tc if k.startswith("conv.") else tg), (precision, k, err, tc, flips)
             worst = max(worst, (k, err), key=lambda kv: kv[1])

@@ -232,3 +232,40 @@ def test_forward_only_inference_notices_and_heals_a_starved_launch(tmp_path):
     assert not res["seen_before"] and res["persistent"] and res["nan"] and res["seen_after_poison"], res
     assert res["second_forward_raised"] and res["message_names_step_kernels"] and not res["seen_after_settle"] and res["cooldown"] > 0, res
     assert res["third_finite"] and res["third_on_step_kernels"] and not res["seen_end"], res
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 768, 1312), (2048, 4608, 768), (520, 264, 328)])
+def test_split_bf16_three_term_products_vs_fp64(M, N, K):
+    """The fp32 mode's large GEMMs (DS2_F32_GEMM=split): operands split as x = hi + lo (two bf16 terms), product = hi.hi + hi.lo + lo.hi with fp32
+    accumulation.  Against the fp64 product of the fp32 operands the relative L2 error stays ~1e-5 (the dropped lo.lo term and the two
+    representation errors are 2^-18 each) — two orders inside the 1e-3 the fp32 mode is held to — for the NT form (one GEMM over 3K) and for
+    the TN form (three accumulating launches on row-pitched views); the plain bf16 product of the same operands is ~3e-3."""
+    from asr_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A = torch.randn(M, K, device="cuda", generator=g) * torch.rand(M, 1, device="cuda", generator=g) * 3.0
+    Bm = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
+    ref = (A.double() @ Bm.double().t()).cpu()
+    # the split itself: hi + lo reproduces x to 2^-17 relative
+    s2 = ops.split_bf16(A, 2)
+    Kp = (K + 7) // 8 * 8
+    assert s2.shape == (M, 2 * Kp)
+    rec = s2[:, :K].float() + s2[:, Kp:Kp + K].float()
+    assert float(((rec - A).abs() / A.abs().clamp_min(1e-30)).max()) < 2.0 ** -16
+    out = ops.gemm_bf16_nt(ops.split_bf16(A, 0), ops.split_bf16(Bm, 1))
+    e_split = float((out.double().cpu() - ref).norm() / ref.norm())
+    e_f32 = float((ops.gemm(A, Bm, transB=True).double().cpu() - ref).norm() / ref.norm())
+    e_bf16 = float((ops.gemm_bf16_nt(ops.cast_bf16(A), ops.cast_bf16(Bm)).double().cpu() - ref).norm() / ref.norm())
+    print(f"NT M={M} N={N} K={K}: split-bf16 {e_split:.2e}  fp32 kernel {e_f32:.2e}  plain bf16 {e_bf16:.2e}")
+    assert e_split < 2e-5 and e_bf16 > 20 * e_split
+    # TN form: C[N2, K] = X^T Y with X (M, N2), Y (M, K) sharing the M rows (the weight-gradient products), K and N2 multiples of 8 here
+    if K % 8 == 0 and N % 8 == 0:
+        X = torch.randn(M, N, device="cuda", generator=g)
+        refT = (X.double().t() @ A.double()).cpu()
+        xs, ys = ops.split_bf16(X, 0), ops.split_bf16(A, 2)
+        Np = N
+        outT = torch.empty(N, K, device="cuda")
+        for k, (a, b) in enumerate(((xs[:, :N], ys[:, :K]), (xs[:, :N], ys[:, Kp:Kp + K]), (xs[:, 2 * Np:], ys[:, :K]))):
+            ops.gemm_bf16_tn(a, b, out=outT, accumulate=k > 0)
+        e_tn = float((outT.double().cpu() - refT).norm() / refT.norm())
+        print(f"TN: split-bf16 {e_tn:.2e}")
+        assert e_tn < 2e-5
