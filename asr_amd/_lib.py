@@ -43,6 +43,8 @@ SIGNATURES = {
     "ds2_chanstats_from_partials": (i32, [vp, i32, i32, f64, vp, vp, vp, vp, f32, vp, sz, vp]),
     "ds2_gemm_bf16_tn": (i32, [i32, i32, i32, vp, i32, i64, vp, i32, i64, vp, i32, i64, i32, i32, i32, vp, sz, vp]),
     "ds2_gemm_bf16_tn_group": (i32, [i32, vp, i32, vp]),
+    "ds2_gemm_bf16_tn_splitk_group_workspace_bytes": (sz, [i32, vp, i32]),
+    "ds2_gemm_bf16_tn_splitk_group": (i32, [i32, vp, i32, vp, sz, vp]),
     "ds2_gemm_bf16_nt": (i32, [i32, i32, i32, vp, i32, i64, vp, i32, i64, vp, i32, i64, vp, i32, i32, i32, vp, sz, vp]),
     "ds2_cast_bf16": (i32, [vp, i32, vp, i32, i32, i32, vp]),
     "ds2_split_bf16": (i32, [vp, i32, vp, i32, i32, i32, i32, vp]),

@@ -28,6 +28,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TN_MAX_PROBLEMS = 8;             // products per grouped TN launch (gemm_bf16_tn_glds_kernel<true>, gemm_tn_group.h)
 constexpr int PITCH = 144;                       // bytes per LDS tile row (128 + 16 pad)
 constexpr int TILE_BYTES = BM * PITCH;           // 18432
 
@@ -592,20 +593,63 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(BArgs g
 //     block, lane i ends up with rows 0..3 of column i: two such reads give the 8 k of one MFMA operand;
 //   * the four rows of a read sit 512 B apart (same banks): the 16-byte slot s of row r is stored at slot s ^ ((r & 3) << 2) (applied to
 //     the DMA source address and to the read address), which spreads a 32-lane read group over all 64 banks exactly once.
-__global__ __launch_bounds__(512) void gemm_bf16_tn_glds_kernel(BArgs g, int ntx, int nty) {
+// GROUPED (TnSGroup): ONE launch for several products of different shapes sharing the split factor — the weight-gradient products of one
+// recurrent layer (dW_ih, the r,z rows and the n rows of dW_hh of both directions): blockIdx.x is a flat work-item index, item ->
+// (problem, K slice, tile); every item is one tile over one K slice of ~K / splitk rows, so with 192 tiles x 4 slices = 768 equal items the
+// chip runs exactly three full rounds where three separate launches each had their own ramp and tail, and the partial slabs are 4 per tile.
+struct TnSProb {
+  const __bf16* A; const __bf16* B; float* C; float* partial;       // partial: this problem's slabs [splitk][M][N] (unused when splitk == 1)
+  int M, N, K, lda, ldb, ldc, ntx, ntiles, kchunk, first_item;
+};
+struct TnSGroup {
+  TnSProb p[TN_MAX_PROBLEMS];
+  int nprob, splitk, nitems;
+};
+
+template <bool GROUPED>
+__global__ __launch_bounds__(512) void gemm_bf16_tn_glds_kernel(BArgs g, int ntx, int nty, TnSGroup grp) {
   constexpr int WN = 4, NWV = 8, NI = 4, NJ = 2, NP = 4;
   extern __shared__ __attribute__((aligned(1024))) char ldsg[];
-  const int z = blockIdx.z;
-  const int zb = z / g.splitk, zs = z % g.splitk;
-  const __bf16* A = g.A + (long long)zb * g.sA;
-  const __bf16* B = g.B + (long long)zb * g.sB;
-  const int nt = ntx * nty;
-  const int orig = blockIdx.x;
+  const __bf16* A;
+  const __bf16* B;
+  int pM, pN, pK, plda, pldb, zb, zs, orig, nt, kchunk;
+  float* Cfinal; float* Cslab; long long ldcf;
+  bool partial;
+  if constexpr (GROUPED) {
+    // the item's problem: field by field with wave-uniform compares (a dynamically indexed kernel-argument struct would go to scratch)
+    const int item = blockIdx.x;
+    A = grp.p[0].A; B = grp.p[0].B; Cfinal = grp.p[0].C; Cslab = grp.p[0].partial;
+    pM = grp.p[0].M; pN = grp.p[0].N; pK = grp.p[0].K; plda = grp.p[0].lda; pldb = grp.p[0].ldb; ldcf = grp.p[0].ldc; ntx = grp.p[0].ntx;
+    nt = grp.p[0].ntiles; kchunk = grp.p[0].kchunk;
+    int first = 0;
+#pragma unroll
+    for (int k = 1; k < TN_MAX_PROBLEMS; ++k)
+      if (k < grp.nprob && item >= grp.p[k].first_item) {
+        A = grp.p[k].A; B = grp.p[k].B; Cfinal = grp.p[k].C; Cslab = grp.p[k].partial;
+        pM = grp.p[k].M; pN = grp.p[k].N; pK = grp.p[k].K; plda = grp.p[k].lda; pldb = grp.p[k].ldb; ldcf = grp.p[k].ldc; ntx = grp.p[k].ntx;
+        nt = grp.p[k].ntiles; kchunk = grp.p[k].kchunk; first = grp.p[k].first_item;
+      }
+    const int local = item - first;
+    zb = 0; zs = local / nt; orig = local % nt;
+    partial = grp.splitk > 1;
+    Cslab += (long long)zs * pM * pN;
+  } else {
+    const int z = blockIdx.z;
+    zb = z / g.splitk; zs = z % g.splitk;
+    A = g.A + (long long)zb * g.sA;
+    B = g.B + (long long)zb * g.sB;
+    pM = g.M; pN = g.N; pK = g.K; plda = g.lda; pldb = g.ldb; kchunk = g.kchunk;
+    nt = ntx * nty;
+    orig = blockIdx.x;
+    partial = g.splitk > 1;
+    Cfinal = g.C + (long long)zb * g.sC; ldcf = g.ldc;
+    Cslab = g.partial + ((long long)zb * g.splitk + zs) * (long long)g.M * g.N;
+  }
   const int xcd = orig & 7, q8 = nt >> 3, r8 = nt & 7;
   const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
   const int m0 = (tile / ntx) * 256, n0 = (tile % ntx) * 256;
-  const int kbeg = zs * g.kchunk;
-  const int kend = min(g.K, kbeg + g.kchunk);
+  const int kbeg = zs * kchunk;
+  const int kend = min(pK, kbeg + kchunk);
   const int nkt = (kend - kbeg + BK - 1) / BK;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -623,10 +667,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_tn_glds_kernel(BArgs g, int ntx
     const int r = (wave + NWV * i) * 2 + (lane >> 5);
     const int gs = (lane & 31) ^ ((r & 3) << 2);
     rowk[i] = r;
-    qA[i] = reinterpret_cast<const char*>(A + (long long)(kbeg + r) * g.lda + min(m0 + gs * 8, g.M - 8));
-    qB[i] = reinterpret_cast<const char*>(B + (long long)(kbeg + r) * g.ldb + min(n0 + gs * 8, g.N - 8));
+    qA[i] = reinterpret_cast<const char*>(A + (long long)(kbeg + r) * plda + min(m0 + gs * 8, pM - 8));
+    qB[i] = reinterpret_cast<const char*>(B + (long long)(kbeg + r) * pldb + min(n0 + gs * 8, pN - 8));
   }
-  const long long stepA = (long long)g.lda * (BK * 2), stepB = (long long)g.ldb * (BK * 2);
+  const long long stepA = (long long)plda * (BK * 2), stepB = (long long)pldb * (BK * 2);
   const int nfull = (kend - kbeg) / BK;
   auto stage_piece = [&](int buf, int kt, int i) {
     char* dA = ldsg + buf * 2 * G_TILE + (wave + NWV * i) * 1024;
@@ -745,18 +789,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_tn_glds_kernel(BArgs g, int ntx
 #undef T_RETIRE_ALL
 #undef T_STEP
 
-  float* C;
-  long long ldc;
-  const bool partial = g.splitk > 1;
-  if (partial) {
-    C = g.partial + ((long long)zb * g.splitk + zs) * (long long)g.M * g.N;
-    ldc = g.N;
-  } else {
-    C = g.C + (long long)zb * g.sC;
-    ldc = g.ldc;
-  }
+  float* C = partial ? Cslab : Cfinal;
+  const long long ldc = partial ? (long long)pN : ldcf;
+  const bool accumulate = !partial && !GROUPED && g.accumulate;
   // wide epilogue (see the NT kernel): 32 x 32 accumulator tiles through a wave-private LDS patch, 16-byte stores
-  if ((ldc % 4) == 0 && ((uintptr_t)C % 16) == 0 && !(g.nt_store & 128)) {
+  if ((ldc % 4) == 0 && ((uintptr_t)C % 16) == 0 && !(!GROUPED && (g.nt_store & 128))) {
     constexpr int EP = 40;
     __syncthreads();
     float* patch = reinterpret_cast<float*>(ldsg) + wave * (32 * EP);
@@ -774,9 +811,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_tn_glds_kernel(BArgs g, int ntx
           const int rl = it * 8 + prow;
           const int row = m0 + wm * (NI * 32) + i * 32 + rl;
           f32x4 v = *reinterpret_cast<const f32x4*>(&patch[rl * EP + pc4]);
-          if (row < g.M && col < g.N) {                 // (N % 8 == 0: a 4-column run never straddles the edge)
+          if (row < pM && col < pN) {                   // (N % 8 == 0: a 4-column run never straddles the edge)
             f32x4* pc = reinterpret_cast<f32x4*>(C + (long long)row * ldc + col);
-            if (!partial && g.accumulate) v += *pc;
+            if (accumulate) v += *pc;
             *pc = v;
           }
         }
@@ -790,14 +827,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_tn_glds_kernel(BArgs g, int ntx
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int col = n0 + wn * (NJ * 32) + j * 32 + l31;
-      if (col >= g.N) continue;
+      if (col >= pN) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * (NI * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (row < g.M) {
+        if (row < pM) {
           float v = acc[i][j][r];
           float* p = C + (long long)row * ldc + col;
-          if (!partial && g.accumulate) v += *p;
+          if (accumulate) v += *p;
           *p = v;
         }
       }
@@ -818,6 +855,28 @@ __global__ void splitk_reduce_bf_kernel(const float* __restrict__ part, float* _
   float* c = C + zb * sC + (long long)row * ldc + col;
   if (accumulate) s += *c;
   *c = s;
+}
+
+// the split-K slabs of every problem of a grouped launch -> C (one launch; fixed summation order: bit-identical from run to run)
+__global__ __launch_bounds__(256) void splitk_reduce_group_kernel(TnSGroup grp, long long total) {
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    long long local = idx;
+    int k = 0;
+#pragma unroll
+    for (int q = 0; q < TN_MAX_PROBLEMS - 1; ++q) {
+      const long long mn = (long long)grp.p[q].M * grp.p[q].N / 4;
+      if (k == q && q + 1 < grp.nprob && local >= mn) { local -= mn; k = q + 1; }
+    }
+    const float* part = grp.p[0].partial; float* C = grp.p[0].C; int M = grp.p[0].M, N = grp.p[0].N, ldc = grp.p[0].ldc;
+#pragma unroll
+    for (int q = 1; q < TN_MAX_PROBLEMS; ++q)
+      if (q == k) { part = grp.p[q].partial; C = grp.p[q].C; M = grp.p[q].M; N = grp.p[q].N; ldc = grp.p[q].ldc; }
+    const long long e = local * 4;                      // N % 8 == 0: a float4 never straddles a row
+    const int row = (int)(e / N), col = (int)(e % N);
+    f32x4 sum = *reinterpret_cast<const f32x4*>(part + e);
+    for (int sidx = 1; sidx < grp.splitk; ++sidx) sum += *reinterpret_cast<const f32x4*>(part + (long long)sidx * M * N + e);
+    *reinterpret_cast<f32x4*>(C + (long long)row * ldc + col) = sum;
+  }
 }
 
 // dst[r][c] = bf16(src[r][c]), c < C ; dst[r][c] = 0 for C <= c < ldd      (ldd % 8 == 0)
@@ -1105,16 +1164,74 @@ extern "C" int ds2_gemm_bf16_tn(int M, int N, int K, const void* A, int lda, lon
   hipStream_t s = (hipStream_t)stream;
   static bool attr_set = false;
   if (!attr_set) {
-    DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_tn_glds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
+    DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_tn_glds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
     attr_set = true;
   }
   const int ntx = ceil_div(N, 256), nty = ceil_div(M, 256);
-  hipLaunchKernelGGL(gemm_bf16_tn_glds_kernel, dim3(ntx * nty, 1, batch * splitk), dim3(512), G_LDS, s, g, ntx, nty);
+  hipLaunchKernelGGL(gemm_bf16_tn_glds_kernel<false>, dim3(ntx * nty, 1, batch * splitk), dim3(512), G_LDS, s, g, ntx, nty, TnSGroup{});
   DS2_LAUNCH_CHECK("gemm_bf16_tn_glds_kernel");
   if (splitk > 1) {
     hipLaunchKernelGGL(splitk_reduce_bf_kernel, dim3(ceil_div(M * N, 256), batch), dim3(256), 0, s, (const float*)workspace, C,
                        (const float*)nullptr, M, N, ldc, strideC, splitk, accumulate);
     DS2_LAUNCH_CHECK("splitk_reduce_bf_kernel");
+  }
+  return 0;
+}
+
+// Several TN products in ONE launch of the 256 x 256 kernel with a common split-K factor (gemm_bf16_tn_glds_kernel<true>) + ONE reduce launch.
+extern "C" size_t ds2_gemm_bf16_tn_splitk_group_workspace_bytes(int nprob, const ds2_tn_problem* probs, int splitk) {
+  if (splitk <= 1 || !probs) return 0;
+  size_t n = 0;
+  for (int i = 0; i < nprob; ++i) n += (size_t)splitk * probs[i].M * probs[i].N * sizeof(float);
+  return n;
+}
+
+extern "C" int ds2_gemm_bf16_tn_splitk_group(int nprob, const ds2_tn_problem* probs, int splitk, void* workspace, size_t workspace_bytes,
+                                             void* stream) {
+  DS2_REQUIRE(nprob >= 1 && nprob <= TN_MAX_PROBLEMS && probs, "ds2_gemm_bf16_tn_splitk_group: 1..%d problems", TN_MAX_PROBLEMS);
+  if (splitk < 1) splitk = 1;
+  int kmin = probs[0].K;
+  for (int i = 1; i < nprob; ++i) kmin = probs[i].K < kmin ? probs[i].K : kmin;
+  while (splitk > 1 && ceil_div(kmin, ceil_div(ceil_div(kmin, splitk), BK) * BK) < splitk) --splitk;   // every slice of every problem must hold rows
+  TnSGroup g;
+  int items = 0;
+  size_t off = 0;
+  long long elems = 0;
+  for (int i = 0; i < nprob; ++i) {
+    const ds2_tn_problem& q = probs[i];
+    DS2_REQUIRE(q.A && q.B && q.C && q.M >= 8 && q.N >= 8 && q.K > 0, "ds2_gemm_bf16_tn_splitk_group: problem %d: bad dims M=%d N=%d K=%d", i, q.M, q.N, q.K);
+    DS2_REQUIRE((q.M % 8) == 0 && (q.N % 8) == 0 && (q.lda % 8) == 0 && (q.ldb % 8) == 0 && (q.ldc % 4) == 0 && ((uintptr_t)q.C % 16) == 0,
+                "ds2_gemm_bf16_tn_splitk_group: problem %d: M, N, lda, ldb must be multiples of 8, ldc of 4, C 16-byte aligned", i);
+    DS2_REQUIRE(((uintptr_t)q.A % 16) == 0 && ((uintptr_t)q.B % 16) == 0, "ds2_gemm_bf16_tn_splitk_group: problem %d: operands must be 16-byte aligned", i);
+    TnSProb& p = g.p[i];
+    p.A = (const __bf16*)q.A; p.B = (const __bf16*)q.B; p.C = q.C;
+    p.partial = (float*)((char*)workspace + off);
+    p.M = q.M; p.N = q.N; p.K = q.K; p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc;
+    p.ntx = ceil_div(q.N, 256);
+    p.ntiles = p.ntx * ceil_div(q.M, 256);
+    p.kchunk = ceil_div(ceil_div(q.K, splitk), BK) * BK;
+    DS2_REQUIRE(ceil_div(q.K, p.kchunk) == splitk, "ds2_gemm_bf16_tn_splitk_group: problem %d: K=%d does not split %d ways", i, q.K, splitk);
+    p.first_item = items;
+    items += p.ntiles * splitk;
+    off += (size_t)splitk * q.M * q.N * sizeof(float);
+    elems += (long long)q.M * q.N / 4;
+  }
+  for (int i = nprob; i < TN_MAX_PROBLEMS; ++i) g.p[i] = g.p[0];
+  g.nprob = nprob; g.splitk = splitk; g.nitems = items;
+  if (splitk > 1) DS2_REQUIRE(workspace && workspace_bytes >= off, "ds2_gemm_bf16_tn_splitk_group: workspace too small");
+  static bool attr_set = false;
+  if (!attr_set) {
+    DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_tn_glds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
+    attr_set = true;
+  }
+  BArgs unused{};
+  hipLaunchKernelGGL(gemm_bf16_tn_glds_kernel<true>, dim3(items), dim3(512), G_LDS, (hipStream_t)stream, unused, 0, 0, g);
+  DS2_LAUNCH_CHECK("gemm_bf16_tn_glds_kernel<grouped>");
+  if (splitk > 1) {
+    int blocks = (int)((elems + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, elems);
+    DS2_LAUNCH_CHECK("splitk_reduce_group_kernel");
   }
   return 0;
 }

@@ -26,7 +26,6 @@ constexpr int L_LDS = L_STAGES * L_BUF;           // 128 KiB
 constexpr int L_PATCH = 4 * 32 * 40 * 4;          // epilogue: 4 wave-private patches of 32 rows x 40 floats, IN the (then idle) stage buffers
 constexpr int L_LDS_REQ = L_LDS;                  // > 80 KiB: at most one of these workgroups per CU; + the recurrence's 10 KB <= 160 KB
 static_assert(L_PATCH <= L_LDS, "patch must fit in the stage buffers");
-constexpr int TN_MAX_PROBLEMS = 8;
 
 struct TnProb {
   const __bf16* A; const __bf16* B; float* C;

@@ -44,7 +44,9 @@ CONV_STATS = _os.environ.get("DS2_CONV_STATS", "1") != "0" and _os.environ.get("
 # (ops.rnn_bwd_bn: one more 4-byte load per pair and step instead of a pass over (T*B, H)); 0: a separate bn1d_bwd_apply pass as before
 FUSE_BN_BWD = _os.environ.get("DS2_FUSE_BN_BWD", "1") != "0"
 # bf16 training, weight gradients of a recurrent layer whose recurrences ran as persistent launches (DS2_WGRAD_SIDE):
-#   "0" (default)  round 3's kernels: three 256 x 256 TN launches with split-K slabs + reduce passes, compute stream
+#   "sk" (default) ONE launch of the 256 x 256 TN kernel over all products of the layer with a common split-K factor + ONE reduce launch
+#                  (ops.gemm_bf16_tn_splitk_group: 192 tiles x 4 K slices = 768 equal work items = three full rounds of the chip), compute stream
+#   "0"            round 3's schedule: three TN launches, each with its own split-K factor, slabs and reduce pass, compute stream
 #   "1"            ONE launch of the co-resident grouped TN kernel (ops.gemm_bf16_tn_group: 4 waves x 128 registers, one workgroup per CU, no
 #                  split-K) on the side stream, released when the compute stream reaches the backward recurrence of the layer BELOW.  The
 #                  kernel is sized for exactly the registers / LDS the K-split recurrence leaves on a CU, so the recurrence's residency
@@ -54,7 +56,7 @@ FUSE_BN_BWD = _os.environ.get("DS2_FUSE_BN_BWD", "1") != "0"
 #                  1.65-2.0 us per time step (0.83-1.0 ms per layer) — more than the 0.86 ms of work it hides: 27.3 vs 25.9 ms per step.
 #   "main"         the same grouped kernel on the compute stream right behind the layer's critical-path work (the one-stream schedule the
 #                  side-stream results are compared with bit for bit: tests/test_gpu_round4.py); +0.5 ms per step against "0"
-WGRAD_SIDE = _os.environ.get("DS2_WGRAD_SIDE", "0")
+WGRAD_SIDE = _os.environ.get("DS2_WGRAD_SIDE", "sk")
 # fp32 mode, the dense input-to-hidden products (forward projection, dXn, dW_ih, dW_hh) of layers large enough for the 256 x 256 kernels
 # (DS2_F32_GEMM): "split" (default) = every fp32 operand split into two bf16 terms (hi = bf16(x), lo = bf16(x - hi)) and the product taken
 # as hi.hi + hi.lo + lo.hi on the bf16 matrix cores with fp32 accumulation — ~1e-5 of the fp32 product (the 2^-18 lo.lo term is dropped),
@@ -355,6 +357,10 @@ def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy, done, private: bo
                  (dgx_bf[0:M - B, G * H:G * H + rows], h_bf[B:M, H:2 * H], dwhh[1, :rows])]
         if G == 3:
             probs += [(dhn_bf[B:M, 0:H], h_bf[0:M - B, 0:H], dwhh[0, 2 * H:]), (dhn_bf[0:M - B, H:2 * H], h_bf[B:M, H:2 * H], dwhh[1, 2 * H:])]
+        if WGRAD_SIDE == "sk":
+            ops.gemm_bf16_tn_splitk_group(probs)
+            done(f"rnns.{l}")
+            return
         if not on_side:
             ops.gemm_bf16_tn_group(probs)
             done(f"rnns.{l}")
@@ -407,7 +413,7 @@ def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy, done, private: bo
     queued_tn = None
     queued_side = None                                           # layer whose grouped weight-gradient launch waits for the next recurrence
     group_ok = WGRAD_SIDE != "0" and W[f"rnns.0.wih_cat"].shape[1] % 8 == 0
-    side_ok = group_ok and WGRAD_SIDE != "main" and ops.wgrad_fits_beside_bwd_recurrence(G, H)
+    side_ok = group_ok and WGRAD_SIDE == "1" and ops.wgrad_fits_beside_bwd_recurrence(G, H)
     for l in range(L - 1, -1, -1):
         lc = ctx.layers[l]
         if queued_side is not None:

@@ -274,6 +274,45 @@ def split_bf16(X: Tensor, order: int) -> Tensor:
     return out
 
 
+def _tn_problem_array(problems):
+    arr = (_lib.TnProblem * len(problems))()
+    for q, (A, B, out) in zip(arr, problems):
+        assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and out.dtype == torch.float32 and A.is_cuda and B.is_cuda and out.is_cuda
+        assert A.dim() == 2 and B.dim() == 2 and out.dim() == 2 and A.stride(1) == 1 and B.stride(1) == 1 and out.stride(1) == 1
+        K, M = A.shape
+        assert B.size(0) == K and tuple(out.shape) == (M, B.size(1)), (A.shape, B.shape, out.shape)
+        q.A, q.B, q.C = A.data_ptr(), B.data_ptr(), out.data_ptr()
+        q.M, q.N, q.K, q.lda, q.ldb, q.ldc = M, B.size(1), K, _row_pitch(A), _row_pitch(B), _row_pitch(out)
+    return arr
+
+
+def gemm_bf16_tn_splitk_group(problems, splitk: int = 0):
+    """Several TN products `[(A (K, M), B (K, N), out (M, N))]` in ONE launch of the 256 x 256 kernel with a common split-K factor and one reduce
+    launch (ds2_gemm_bf16_tn_splitk_group).  splitk 0: chosen so that tiles x splitk fills whole rounds of the chip (the cost model of
+    _pick_splitk over the tiles of all products together)."""
+    lib = _lib.load()
+    arr = _tn_problem_array(problems)
+    if splitk <= 0:
+        tiles = sum(((q.M + 255) // 256) * ((q.N + 255) // 256) for q in arr)
+        kmin = min(q.K for q in arr)
+        mn = sum(q.M * q.N for q in arr)
+        best, best_cost = 1, None
+        for s_ in (1, 2, 3, 4, 5, 6, 8, 12, 16):
+            if s_ > 1 and kmin // s_ < 1024:
+                break
+            rounds = -(-tiles * s_ // 256)
+            util = tiles * s_ / (rounds * 256.0)
+            cost = 2.0 * mn * kmin / (1.1e15 * util) + (0.0 if s_ == 1 else (s_ + 1) * mn * 4 / 3e12)
+            if best_cost is None or cost < best_cost * 0.97:
+                best, best_cost = s_, cost
+        splitk = best
+    ap = C.cast(arr, C.c_void_p)
+    wsb = lib.ds2_gemm_bf16_tn_splitk_group_workspace_bytes(len(problems), ap, splitk)
+    ws = _ws(wsb, problems[0][0].device) if wsb else None
+    _lib.check(lib.ds2_gemm_bf16_tn_splitk_group(len(problems), ap, splitk, _ptr(ws), wsb, _stream()), "ds2_gemm_bf16_tn_splitk_group")
+    return splitk
+
+
 def gemm_bf16_tn_group(problems, max_workgroups: int = 0):
     """Several TN products in ONE launch of the co-resident kernel (csrc/gemm_tn_group.h): `problems` = [(A (K, M), B (K, N), out (M, N))],
     A / B bf16 row-major views sharing their K rows, out fp32 (row pitch arbitrary, columns contiguous).  out = A^T @ B, every tile a full

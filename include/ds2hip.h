@@ -68,6 +68,11 @@ typedef struct ds2_tn_problem {
   int M, N, K, lda, ldb, ldc;
 } ds2_tn_problem;
 int ds2_gemm_bf16_tn_group(int nprob, const ds2_tn_problem* problems, int max_workgroups, void* stream);
+/* The same problem list through the 256 x 256 TN kernel with ONE split-K factor for all of them: one GEMM launch whose work items are
+ * (problem, K slice, tile) — a layer's 192 weight-gradient tiles x 4 slices are 768 equal items = three full rounds of the chip, where
+ * three separate launches each had their own ramp and tail and up to 8 slabs per tile — and one reduce launch.  workspace: the slabs. */
+size_t ds2_gemm_bf16_tn_splitk_group_workspace_bytes(int nprob, const ds2_tn_problem* problems, int splitk);
+int ds2_gemm_bf16_tn_splitk_group(int nprob, const ds2_tn_problem* problems, int splitk, void* workspace, size_t workspace_bytes, void* stream);
 int ds2_cast_bf16(const float* src, int ld_src, void* dst, int ld_dst, int R, int Cc, void* stream);
 /* fp32 mode (precision="fp32", BASELINE configs[1],[3]), large GEMMs: every fp32 operand is SPLIT into two bf16 terms, x = hi + lo with
  * hi = bf16(x), lo = bf16(x - hi) (x is represented to 2^-18 relative), and a product is taken as a_hi b_hi + a_hi b_lo + a_lo b_hi on the bf16

@@ -43,9 +43,19 @@ def _regs(tok: str):
 
 
 def check_tn_loop(asm: str):
-    m = re.search(r"^(_ZN\S*gemm_bf16_tn_glds_kernel\w*):[^\n]*\n(.*?)s_endpgm", asm, re.S | re.M)
-    assert m, "TN kernel not found"
-    lines = [l.strip() for l in m.group(2).splitlines()]
+    """every kernel that gathers fragments with ds_read_b64_tr_b16 (both instances of the 256 x 256 TN kernel and the co-resident grouped one)"""
+    found = list(re.finditer(r"^(_ZN\S*gemm_bf16_tn_(?:glds|group)_kernel\w*):[^\n]*\n(.*?)s_endpgm", asm, re.S | re.M))
+    assert len(found) >= 3, "TN kernels not found"
+    reads = violations = 0
+    for m in found:
+        r, v = _check_tn_body(m.group(1), m.group(2))
+        reads += r
+        violations += v
+    return reads, violations
+
+
+def _check_tn_body(name: str, body: str):
+    lines = [l.strip() for l in body.splitlines()]
     lines = [l for l in lines if l and not l.startswith((";", "//")) and not (l.startswith(".") and not l.endswith(":"))]
     pending = []          # destination register sets of LDS reads not yet covered by a wait, oldest first
     reads = violations = 0
@@ -77,7 +87,7 @@ def check_tn_loop(asm: str):
                 used |= _regs(t)
             if used & busy:
                 violations += 1
-                print("  touches in-flight fragment registers:", l)
+                print(f"  {name}: touches in-flight fragment registers:", l)
     return reads, violations
 
 

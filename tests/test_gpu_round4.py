@@ -138,6 +138,32 @@ def test_side_stream_weight_gradients_bit_identical_to_one_stream_schedule():
     assert d < 1e-4, d                                                          # same operands, other fp32 summation order
 
 
+def test_grouped_splitk_weight_gradients_match_separate_launches():
+    """DS2_WGRAD_SIDE=sk (the default): the five products of a layer in ONE launch of the 256 x 256 TN kernel with a common split-K factor +
+    one reduce launch.  Against round 3's three launches: same operands, same MFMA kernel, another split of K -> other fp32 summation order
+    (<= 1e-5 relative on every tensor, loss identical); reruns bit-identical; the stand-alone call equals ds2_gemm_bf16_tn with the same
+    split factor to the bit (same slices, same order of the slab sum)."""
+    from asr_amd import ops
+    cfg = dict(rnn="gru", hidden=1024, layers=3, classes=29)
+    sk = _one_backward("sk", cfg, 64, 301)
+    sk2 = _one_backward("sk", cfg, 64, 301)
+    old = _one_backward("0", cfg, 64, 301)
+    assert sk[0] == sk2[0] and sk[3] == old[3]
+    assert (sk[1] - old[1]).norm().item() / old[1].norm().item() < 1e-5
+    # LSTM (three products) and a shape with a K tail
+    for c, B, tin in ((dict(rnn="lstm", hidden=1280, layers=2, classes=29), 32, 161), (dict(rnn="gru", hidden=768, layers=2, classes=29), 24, 203)):
+        a, b = _one_backward("sk", c, B, tin), _one_backward("0", c, B, tin)
+        assert (a[1] - b[1]).norm().item() / b[1].norm().item() < 1e-5, c
+    g = torch.Generator(device="cuda").manual_seed(3)
+    K, M, N = 5000, 768, 512
+    A = torch.randn(K, M, device="cuda", generator=g).bfloat16()
+    Bm = torch.randn(K, N, device="cuda", generator=g).bfloat16()
+    one, ref = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+    used = ops.gemm_bf16_tn_splitk_group([(A, Bm, one)], splitk=3)
+    ops.gemm_bf16_tn(A, Bm, out=ref, splitk=used)
+    assert torch.equal(one, ref)
+
+
 def test_side_stream_schedule_lstm_and_narrow_shapes_fall_back_cleanly():
     """Shapes whose backward recurrence leaves no room (LSTM H = 1024: 2 x 224 registers) or that have no K-split kernel keep a one-stream
     schedule; the result is the same in every mode."""
