@@ -5,7 +5,7 @@ WL=${1:-c2}; TAG=${2:-r01}
 mkdir -p gpurun_out/prof_$TAG
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$TAG -o $TAG -- python $GRAFT_REPO_ROOT/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline $BENCHARGS > $GRAFT_REPO_ROOT/gpurun_out/prof_$TAG/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$TAG -o $TAG -- python $GRAFT_REPO_ROOT/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline --no-other-workloads $BENCHARGS > $GRAFT_REPO_ROOT/gpurun_out/prof_$TAG/bench.log 2>&1
 echo "rocprof rc=$?"
 cd $GRAFT_REPO_ROOT
 find gpurun_out/prof_$TAG -name "*stats*" | head
