@@ -1714,7 +1714,7 @@ extern "C" int ds2_rnn_bwd_ksplit_footprint(int gates, int H, int* out3) {
   const void* fn = nullptr;
 #define DS2_KSF(G_, NT_)                                                           \
   if (gates == G_ && nt == NT_) {                                                  \
-    if constexpr (NT_ * G_ * 4 <= 176) fn = (const void*)rnn_bwd_ksplit_kernel<G_, NT_>; \
+    if constexpr (NT_ * G_ * 4 <= 176) fn = G_ == 3 ? (const void*)rnn_bwd_ksplit_kernel<3, NT_, true> : (const void*)rnn_bwd_ksplit_kernel<G_, NT_, false>; \
   }
   DS2_KSF(3, 2) DS2_KSF(3, 4) DS2_KSF(3, 6) DS2_KSF(3, 8) DS2_KSF(3, 10)
   DS2_KSF(4, 2) DS2_KSF(4, 4) DS2_KSF(4, 6) DS2_KSF(4, 8) DS2_KSF(4, 10)

@@ -37,8 +37,11 @@
 // remains: the 16 x G*32 bf16 tile of dGh goes through LDS so that every wave can take it as its MFMA operand (and leave through it).
 typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
 typedef float f32x2_ __attribute__((ext_vector_type(2)));
-template <int G, int NT>
+// TR: the GRU TRAINING instance (packed bf16 gate records in, bf16 dGx out — what engine.py's bf16 train step passes): the generic operand
+// fetch is compiled out, see ASM_FETCH below.
+template <int G, int NT, bool TR = false>
 __global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char* xbuf, unsigned* census, int spin_limit) {
+  static_assert(!TR || G == 3, "the training instance exists for the GRU");
   static_assert(NW == 8 && NT >= 2 && (NT % 2) == 0, "8 waves: wave w owns output columns [w*H/8, (w+1)*H/8) = NT 16-column tiles");
   constexpr int NL = NT / 2;                                  // 1 KB wave loads per gather = producers / 8 = tile pairs per wave
   constexpr int AST = 40;                                     // bf16 per staged row (80 B pitch: conflict-free ds_read_b128)
@@ -96,6 +99,38 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char
     bn1 = k1; bnx = -k3; bn0 = __builtin_fmaf(k3, a.bn_mean[j], -k2);
   }
   struct Ops { bf16x4_ rec; float g0, g1, g2, g3, ax, dy, prev, bx; };   // see rnn_bwd_persistent_kernel: fetched one step ahead, kept raw
+  // GRU training path (packed gate records + bf16 dGx, the shapes the bench runs): the four operand loads of a step are issued by INLINE ASM
+  // and retired by a COUNTED wait (`fetch_wait`).  The vector-memory counter retires in order and counts stores too; left to the compiler,
+  // the wait in front of the coefficient math at the end of a step was `vmcnt(0)` — i.e. it waited for the step's four publish stores and
+  // its result store (issued just before, write-through: ~0.5 us) although the loads it needs were issued a whole step earlier.  With the
+  // loads invisible to the compiler's counter bookkeeping, the wait names exactly what may still be outstanding: the NL publish stores.
+  // Every lane issues every load (inactive lanes / a missing BatchNorm / the last step read a valid dummy address and their value is
+  // discarded after the wait), so no result register is merged or copied between its load and its wait.
+  constexpr bool ASM_FETCH = TR;
+  constexpr bool asm_fetch = TR;                               // (the launcher picks TR exactly when gates_bf and dgx_bf are given)
+  struct Raw { f32x2_ rec; float dy, bx, prev; };
+  // (a separate template instance, not a run-time branch: with the compiler-managed `fetch` below on another path of the same code, its
+  // pending loads put the compiler's own vmcnt(0) right back behind the counted wait)
+  auto fetch_asm = [&](long long fH, long long fY, long long fX, bool has_prev) {
+    Raw r;
+    const bool on = pact && asm_fetch;
+    const void* prec = on ? (const void*)(gates_bf + 4 * fH) : (const void*)a.dy;
+    const float* pdy = on ? a.dy + fY : a.dy;
+    const float* pbx = (on && bn) ? a.bn_x + fX : a.dy;
+    const float* ppv = (on && has_prev) ? a.hbuf + fH + dH : a.hbuf;
+    asm volatile("global_load_dwordx2 %0, %4, off nt\n\tglobal_load_dword %1, %5, off nt\n\tglobal_load_dword %2, %6, off nt\n\t"
+                 "global_load_dword %3, %7, off"
+                 : "=&v"(r.rec), "=&v"(r.dy), "=&v"(r.bx), "=&v"(r.prev)
+                 : "v"(prec), "v"(pdy), "v"(pbx), "v"(ppv)
+                 : "memory");
+    return r;
+  };
+  // the loads of `r` have landed once at most YOUNGER vector-memory operations are outstanding (the counter retires in order and at least
+  // that many were issued behind them); the record is used in place — same registers from the load to the last use
+#define DS2_KS_FETCH_WAIT(r, YOUNGER) asm volatile("s_waitcnt vmcnt(%4)" : "+v"((r).rec), "+v"((r).dy), "+v"((r).bx), "+v"((r).prev) : "n"(YOUNGER) : "memory")
+  auto raw_ops = [&](const Raw& r, bool has_prev) {
+    return Ops{__builtin_bit_cast(bf16x4_, r.rec), 0.f, 0.f, 0.f, 0.f, 0.f, r.dy, has_prev ? r.prev : 0.f, r.bx};
+  };
   // operands of the step whose offsets are (fH, fG, fY); has_prev: that step has a predecessor in FORWARD order (= the step processed after it)
   auto fetch = [&](long long fH, long long fG, long long fY, long long fX, bool has_prev) {
     Ops o{bf16x4_{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f}, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -124,7 +159,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char
     Coef c{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int tt = dir == 0 ? T - 1 - step : step;
     if (!(pact && tt < plen)) return c;
-    if (gates_bf) { o.g0 = (float)o.rec[0]; o.g1 = (float)o.rec[1]; o.g2 = (float)o.rec[2]; o.g3 = (float)o.rec[3]; }
+    if (TR || gates_bf) { o.g0 = (float)o.rec[0]; o.g1 = (float)o.rec[1]; o.g2 = (float)o.rec[2]; o.g3 = (float)o.rec[3]; }
     c.dy = bn ? __builtin_fmaf(bn1, o.dy, __builtin_fmaf(bnx, o.bx, bn0)) : o.dy;
     if constexpr (G == 3) {                                // r = g0, z = g1, n = g2, hn = g3
       const float cn = (1.f - o.g1) * (1.f - o.g2 * o.g2);
@@ -144,14 +179,23 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char
     }
     return c;
   };
-  Ops nxt = fetch(eH, eG, eY, eX, T > 1);
-  Coef cf = coefficients(nxt, 0);
+  Ops nxt{};
+  bool nraw_prev = false;
+  Coef cf;
+  if constexpr (ASM_FETCH) {
+    Raw r0 = fetch_asm(eH, eY, eX, T > 1);
+    DS2_KS_FETCH_WAIT(r0, 0);
+    cf = coefficients(raw_ops(r0, T > 1), 0);
+  } else {
+    nxt = fetch(eH, eG, eY, eX, T > 1);
+    cf = coefficients(nxt, 0);
+  }
 
   // Results.  bf16 training path (dgx_bf given): the bf16 values are in the LDS planes anyway — after the step's barrier, wave p < 4 sends
   // plane p out with ONE 16-byte store per lane (lane = row (lane >> 2), 8 units (lane & 3)): GRU planes 0, 1, 3 -> dGx columns r, z, n and
   // plane 2 -> the bf16 copy of d(hn); LSTM plane g -> dGx column g.  The fp32 d(hn) (aux) is written lane by lane only when nobody asked
   // for the bf16 copy.  Plain fp32 buffers (tests) and the last step: lane by lane.
-  const bool lds_out = a.dgx_bf != nullptr;
+  const bool lds_out = TR || a.dgx_bf != nullptr;
   const bool aux_f32 = G == 3 && !(lds_out && a.dhn_bf);
   auto store_lane = [&](long long fH, long long fG, const float (&dgx)[G], float dax, bool all) {
     if (!pact) return;
@@ -278,7 +322,13 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char
     // the NEXT step's gate-math operands: issued here, right behind the gather, so that they have a whole step to land (the next poll's
     // wait retires them too: vmcnt is in order); their coefficients are formed at the end of this step
     const bool more = s + 1 < T;
-    if (more) nxt = fetch(eH + dH, eG + dG, eY + dY, eX + dX, s + 2 < T);
+    Raw nraw;
+    if constexpr (ASM_FETCH) {
+      nraw_prev = s + 2 < T;
+      nraw = fetch_asm(more ? eH + dH : eH, more ? eY + dY : eY, more ? eX + dX : eX, nraw_prev);
+    } else {
+      if (more) nxt = fetch(eH + dH, eG + dG, eY + dY, eX + dX, s + 2 < T);
+    }
 
     float dgh[G], dgx[G], dax = 0.f;
     if constexpr (G == 3) {
@@ -397,7 +447,14 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char
     if (s_on) __builtin_nontemporal_store(outv, reinterpret_cast<u32x4_*>(s_dst + sE));
     store_lane(eH, eG, dgx, dax, !lds_out);
     eH += dH; eG += dG; eY += dY; eX += dX; sE += sD;
-    cf = coefficients(nxt, s + 1);                         // (the operands were requested a step ago; this wait is in the exchange's shadow)
+    // the operands were requested right behind this step's gather; behind them only this step's NL publish stores (and, on four waves,
+    // one result store, which then has to retire too) are outstanding
+    if constexpr (ASM_FETCH) {
+      DS2_KS_FETCH_WAIT(nraw, NL);
+      cf = coefficients(raw_ops(nraw, nraw_prev), s + 1);                             // (this wait is in the exchange's shadow)
+    } else {
+      cf = coefficients(nxt, s + 1);
+    }
     PTRACE(6);
   }
   if (a.bsum && pact) {
@@ -406,6 +463,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char
     for (int g = 0; g < 4; ++g) o[g * H] = bs[g];
   }
   PTRACE_DUMP(1);
+#undef DS2_KS_FETCH_WAIT
 }
 
 // bytes of the two exchange slots: [2 slots][2 dirs x batch tiles][gs consumers][8 waves][gs producers][128 B]
@@ -437,10 +495,15 @@ int try_launch_ksplit_bwd(RnnArgs a, hipStream_t st) {
   switch (nt) {
 #define DS2_KS(NT_)                                                                                                       \
   case NT_:                                                                                                               \
-    if constexpr (NT_ * G * 4 <= 176)                                                                                     \
-      hipLaunchKernelGGL((rnn_bwd_ksplit_kernel<G, NT_>), grid, block, 0, st, a, xbuf, census, spin_limit);               \
-    else                                                                                                                  \
+    if constexpr (NT_ * G * 4 <= 176) {                                                                                   \
+      if (G == 3 && a.gates_bf && a.dgx_bf) {                                                                             \
+        if constexpr (G == 3) hipLaunchKernelGGL((rnn_bwd_ksplit_kernel<3, NT_, true>), grid, block, 0, st, a, xbuf, census, spin_limit); \
+      } else {                                                                                                            \
+        hipLaunchKernelGGL((rnn_bwd_ksplit_kernel<G, NT_, false>), grid, block, 0, st, a, xbuf, census, spin_limit);      \
+      }                                                                                                                   \
+    } else {                                                                                                              \
       return 0;                                                                                                           \
+    }                                                                                                                     \
     break;
     DS2_KS(2) DS2_KS(4) DS2_KS(6) DS2_KS(8) DS2_KS(10)
 #undef DS2_KS

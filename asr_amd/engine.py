@@ -175,8 +175,9 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
         return (W[name + ".running_mean"], W[name + ".running_var"]) if training else (None, None)
 
     # ---- conv stack -----------------------------------------------------------------------------
-    wpk1, wpk2, wpk2d = ops.conv_pack(W[cp + "0.weight"], W[cp + "3.weight"])
-    ctx.packs = (wpk2d,)
+    if cfg.precision != "bf16":                                  # (the bf16 mode has its own operand packs: conv1_pack_bf16 / conv2_pack_bf16)
+        wpk1, wpk2, wpk2d = ops.conv_pack(W[cp + "0.weight"], W[cp + "3.weight"])
+        ctx.packs = (wpk2d,)
     if cfg.precision == "bf16":
         # conv1 on the bf16 matrix cores: operand images gathered once from the spectrogram (the time-contiguous one is kept
         # for the weight gradient)
@@ -202,7 +203,7 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
         a1, a1p, a1n = ops.bn2d_act_fwd_fused(y1, lens_dev, m1, v1, W[cp + "1.weight"], W[cp + "1.bias"], want_f32=debug_acts, want_pad=save,
                                               want_nhwc=True)
         cwf, cwd0, cwd1 = ops.conv2_pack_bf16(W[cp + "3.weight"])
-        ctx.packs = (wpk2d, cwd0, cwd1)
+        ctx.packs = (None, cwd0, cwd1)
         y2 = ops.conv2_fwd_bf16(a1n, cwf, W[cp + "3.bias"], lens_dev, stats=training and CONV_STATS)
         st_part2 = None
         if training and CONV_STATS:

@@ -91,6 +91,41 @@ def _check_tn_body(name: str, body: str):
     return reads, violations
 
 
+def check_ksplit_fetch(asm: str):
+    """GRU training instances of the K-split backward recurrence (rnn_bwd_ksplit_kernel<3, NT, true>): the operand loads of a step are issued
+    by inline asm and retired by a counted inline-asm wait (csrc/rnn_bwd_ksplit.h, ASM_FETCH); the compiler does not know that the result
+    registers are in flight in between, so NO instruction between a load block and the wait that retires it may name one of them — a copy
+    there would move data that has not landed.  Walks every such instance in layout order."""
+    inst = viol = 0
+    for m in re.finditer(r"^(_ZN\S*rnn_bwd_ksplit_kernelILi3ELi\d+ELb1E\w*):[^\n]*\n(.*?)s_endpgm", asm, re.S | re.M):
+        inst += 1
+        lines = [l.strip() for l in m.group(2).splitlines()]
+        pending = None
+        blocks = 0
+        for i, l in enumerate(lines):
+            if l.startswith("global_load_dwordx2") and " nt" in l and i > 0 and "#ASMSTART" in lines[i - 1]:
+                regs = set()
+                for k in range(4):
+                    regs |= _regs(re.split(r"[ ,]+", lines[i + k].partition(" ")[2].strip())[0])
+                pending, start = regs, i + 4
+                blocks += 1
+                continue
+            if pending is not None and i >= start:
+                if re.fullmatch(r"s_waitcnt vmcnt\(\d+\)", l) and "#ASMSTART" in lines[i - 1]:
+                    pending = None
+                    continue
+                if l.startswith((";", ".")) or l.endswith(":"):
+                    continue
+                used = set()
+                for t in re.split(r"[ ,]+", l.partition(" ")[2]):
+                    used |= _regs(t.strip())
+                if used & pending:
+                    viol += 1
+                    print(f"  {m.group(1)}: line {i} names an in-flight operand register: {l}")
+        assert blocks == 2 and pending is None, (m.group(1), blocks)
+    return inst, viol
+
+
 def main() -> int:
     asm = compile_asm()
     bad = 0
@@ -110,6 +145,9 @@ def main() -> int:
     for n, v in spilled.items():
         print(f"  {n}: vgpr spills {v}   <-- SPILLS")
     bad += len(spilled)
+    ki, kv = check_ksplit_fetch(rnn)
+    print(f"K-split training instances: {ki} walked, {kv} instruction(s) naming in-flight operand registers")
+    bad += kv + (ki == 0)
     reads, viol = check_tn_loop(asm)
     print(f"TN kernel: {reads} tr-reads walked, {viol} instruction(s) touching in-flight fragment registers")
     bad += viol

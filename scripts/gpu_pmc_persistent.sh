@@ -7,7 +7,7 @@ R=$PWD
 mkdir -p gpurun_out/pmc_r04
 cd /tmp
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $R/gpurun_out/pmc_r04 -o pmc_$ctr -- PYTHONPATH=$R python $R/scripts/pmc_rnn.py bf16 ${PMC_T:-501} > $R/gpurun_out/pmc_r04/log_$ctr.txt 2>&1
+  rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $R/gpurun_out/pmc_r04 -o pmc_$ctr -- python $R/scripts/pmc_rnn.py bf16 ${PMC_T:-501} > $R/gpurun_out/pmc_r04/log_$ctr.txt 2>&1
   echo "$ctr rc=$?"
 done
 cd $R
