@@ -673,7 +673,7 @@ def main():
     if pmc is not None and not same_shape:
         pmc_why_not = "the PMC summary was collected for the c3 layer shape (GRU H=1024 B=64 bf16)"
     # the template instance the library launches for this shape (rnn.hip / rnn_bwd_ksplit.h): a summary for another instance is refused too
-    expect = {"rnn_bwd_ksplit_kernel": f"rnn_bwd_ksplit_kernel<{G}, {H // 128}>"}
+    expect = {"rnn_bwd_ksplit_kernel": f"rnn_bwd_ksplit_kernel<{G}, {H // 128}, {'true' if G == 3 else 'false'}>"}
 
     def pmc_traffic(kernel, steps):
         nonlocal pmc_why_not
