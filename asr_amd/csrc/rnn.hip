@@ -1347,7 +1347,7 @@ int try_launch_persistent_fwd(RnnArgs a, hipStream_t st) {
   // 4 VGPRs) and the alternative would be a 32-row tile; else the step kernels' 16|32 rows x 16 units (with 16-row tiles the gather
   // is the same size either way and twice as many, half as big workgroups measured slightly faster).
   int mb = 1, ns = 2;
-  const bool ns2_ok = (nsl % 2) == 0 && ncw * (2 * G + 1) * 4 <= 176 && (long long)(nsl / 2) * ceil_div(a.B, 16) * 2 <= cu_count();
+  const bool ns2_ok = (nsl % 2) == 0 && ncw * (2 * G + 1) * 4 <= 180 && (long long)(nsl / 2) * ceil_div(a.B, 16) * 2 <= cu_count();
   // ... and 16 x 32 also where 16 x 16 would be chosen but only the wider slice lets an exchange group fit one XCD (L2-local exchange;
   // bf16 only: in fp32 the doubled MFMA instruction count per workgroup costs more than the exchange saves, c2 5.4 -> 6.1 us per step)
   const bool ns2_for_local = BF && ns2_ok && !xcd_local_fits(nsl, ceil_div(a.B, 16 * pick_mb(a.B, a.H)) * 2) && xcd_local_fits(nsl / 2, ceil_div(a.B, 16) * 2);
@@ -1373,7 +1373,7 @@ int try_launch_persistent_fwd(RnnArgs a, hipStream_t st) {
   const int spin_limit = sl ? atoi(sl) : (1 << 20);              // ~1 s of polling: a missing workgroup is reported instead of hanging the queue
 #define DS2_PLAUNCH(MB_, NS_, NCW_)                                                                                                   \
   do {                                                                                                                                \
-    if constexpr (NCW_ * (NS_ * G + MB_) * 4 <= 176)                                                                                  \
+    if constexpr (NCW_ * (NS_ * G + MB_) * 4 <= 180)                                                                                  \
       hipLaunchKernelGGL((rnn_fwd_persistent_kernel<G, MB_, NS_, NCW_, BF>), grid, block, 0, st, a, xbuf, census, spin_limit);                 \
     else                                                                                                                              \
       return 0;                                                                                                                       \
