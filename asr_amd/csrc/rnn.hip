@@ -562,13 +562,20 @@ __device__ __forceinline__ PRole persist_role(const RnnArgs& a, unsigned* census
   return r;
 }
 
-template <int G, int MB, int NS, int NCW, bool BF>
+// SP (fp32 mode, DS2_F32_RNN=split): the recurrent product h W_hh^T at fp32 accuracy on the bf16 matrix cores.  Both operands travel as TWO
+// bf16 planes, x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (2^-18 relative): W_hh as hi / lo fragment sets in registers, h_t as a hi and a
+// lo plane of every exchange buffer (4 bytes per element, as the fp32 exchange), and a chunk's product is hi.hi + lo.hi + hi.lo — three
+// 16x16x32 bf16 MFMAs (48 cycles) where the fp32 path issues eight 16x16x4 fp32 MFMAs (256 cycles) for the same 32 k.  Everything else
+// (state, gate math, outputs, protocol) is the BF = true data path; results are within ~1e-6 of the fp32 kernels', not bit-identical to them.
+template <int G, int MB, int NS, int NCW, bool BF, bool SP = false>
 __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, char* xbuf, unsigned* census, int spin_limit) {
   static_assert(MB * NS * 256 <= NW * 64, "one (row, unit) pair per thread");
+  static_assert(!SP || BF, "the split form runs on the bf16 data path");
+  constexpr int NPL = SP ? 2 : 1;                                             // operand planes: [hi | lo]
   __shared__ __attribute__((aligned(16))) f32x4 red[2][NW][MB * NS * G][64];       // double-buffered: ONE workgroup barrier per time step
   constexpr int KC = kchunk<BF>(), EPL = KC / 4;                              // units per chunk (32 | 16) and per 16-byte lane vector (8 | 4)
   using elem_t = typename std::conditional<BF, __bf16, float>::type;
-  __shared__ __attribute__((aligned(16))) elem_t stage[NW][64];               // wave-private: a wave's 64 (row, unit) pairs = 64 / EPL complete 16-byte chunks
+  __shared__ __attribute__((aligned(16))) elem_t stage[NPL][NW][64];          // wave-private: a wave's 64 (row, unit) pairs = 64 / EPL complete 16-byte chunks
   // 1-D grid; (direction, batch tile, slice) from the XCD census or from the workgroup id: persist_role
   const PRole role = persist_role(a, census, spin_limit, 1);
   if (!role.active) return;
@@ -579,20 +586,24 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
   const int j0 = slice * (16 * NS), b0 = bt * (16 * MB);      // slice = NS consecutive 16-unit slices
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const long long bufbytes = (long long)2 * a.nbt16 * nch * 1024;            // one packed h buffer: [dir][tile][chunk][64 lanes][16 B]
+  const long long planebytes = (long long)2 * a.nbt16 * nch * 1024;          // one packed h plane: [dir][tile][chunk][64 lanes][16 B]
+  const long long bufbytes = NPL * planebytes;                               // one exchange buffer (SP: hi plane, lo plane)
   const long long dirbase = (long long)dir * a.nbt16 * nch * 1024;
 
-  // ---- W_hh slice -> registers (once)
-  f32x4 wreg[NCW][NS * G];
+  // ---- W_hh slice -> registers (once; SP: the hi and the lo fragment set, one packed operand behind the other)
+  f32x4 wreg[NPL][NCW][NS * G];
   bool cval[NCW];
+  const long long wplane = (long long)2 * nsl * G * nch * 256;               // floats of one packed forward operand
 #pragma unroll
   for (int k = 0; k < NCW; ++k) {
     const int c = wave + NW * k;
     cval[k] = c < nch;
 #pragma unroll
-    for (int g = 0; g < NS * G; ++g)                    // (slice * NS + n, gate g') are consecutive 1 KiB-chunk rows of the packed W_hh
-      wreg[k][g] = cval[k] ? *reinterpret_cast<const f32x4*>(a.wp + (((((long long)dir * nsl + slice * NS) * G + g) * nch + c) * 256) + lane * 4)
-                           : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+      for (int g = 0; g < NS * G; ++g)                  // (slice * NS + n, gate g') are consecutive 1 KiB-chunk rows of the packed W_hh
+        wreg[pl][k][g] = cval[k] ? *reinterpret_cast<const f32x4*>(a.wp + pl * wplane + (((((long long)dir * nsl + slice * NS) * G + g) * nch + c) * 256) + lane * 4)
+                                 : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   // lanes of a chunk whose 8 hidden units lie beyond H are never written by anybody: ignored by the poll, zero in the product
   bool lval[NCW];
@@ -650,14 +661,17 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
   };
 
   // this wave's chunks of the packed exchange buffer (byte offsets from the buffer's direction base) and the all-pending mask
-  unsigned goff[NCW * MB], pend0 = 0;
+  static_assert(NPL * NCW * MB <= 32, "pending mask is 32 bits");
+  unsigned goff[NPL * NCW * MB], pend0 = 0;
 #pragma unroll
-  for (int k = 0; k < NCW; ++k)
+  for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
-    for (int i = 0; i < MB; ++i) {
-      goff[k * MB + i] = (unsigned)(((((long long)(bt * MB + i) * nch + (wave + NW * k)) * 64) + lane) * 16);
-      if (cval[k]) pend0 |= 1u << (k * MB + i);
-    }
+    for (int k = 0; k < NCW; ++k)
+#pragma unroll
+      for (int i = 0; i < MB; ++i) {
+        goff[(pl * NCW + k) * MB + i] = (unsigned)(pl * planebytes + ((((long long)(bt * MB + i) * nch + (wave + NW * k)) * 64) + lane) * 16);
+        if (cval[k]) pend0 |= 1u << ((pl * NCW + k) * MB + i);
+      }
 
   PTRACE_DECL;
   vm_drained();                                         // prologue loads (W_hh slice, biases, lengths, first x-projections) have landed
@@ -672,9 +686,9 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
     if (s > 0) {
       // ---- gather h_{s-1}: poll this wave's chunks until none carries the sentinel (one asm statement per pass: poll_pass)
       const char* xin = xbuf + (long long)((s - 1) & 3) * bufbytes + dirbase;
-      u32x4_ av[NCW * MB];
+      u32x4_ av[NPL * NCW * MB];
 #pragma unroll
-      for (int k = 0; k < NCW * MB; ++k) av[k] = u32x4_{0u, 0u, 0u, 0u};
+      for (int k = 0; k < NPL * NCW * MB; ++k) av[k] = u32x4_{0u, 0u, 0u, 0u};
       int spins = 0;
       unsigned pend = pend0;                              // wave-uniform: chunks of this wave that have not been seen complete yet
       while (pend) {
@@ -683,16 +697,18 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
 #ifdef DS2_RNN_TRACE
         pt_acc[7] += 1;                                   // (trace build: poll passes, summed over the steps)
 #endif
-        poll_pass<NCW * MB>(av, goff, xin, pend);
+        poll_pass<NPL * NCW * MB>(av, goff, xin, pend);
 #pragma unroll
-        for (int k = 0; k < NCW; ++k)
+        for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
-          for (int i = 0; i < MB; ++i)
-            if (pend & (1u << (k * MB + i))) {
-              const u32x4_ c = av[k * MB + i];
-              const bool ok = !lval[k] || (c.x != PSENT && c.y != PSENT && c.z != PSENT && c.w != PSENT);
-              if (__ballot(ok) == ~0ull) pend &= ~(1u << (k * MB + i));
-            }
+          for (int k = 0; k < NCW; ++k)
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+              if (pend & (1u << ((pl * NCW + k) * MB + i))) {
+                const u32x4_ c = av[(pl * NCW + k) * MB + i];
+                const bool ok = !lval[k] || (c.x != PSENT && c.y != PSENT && c.z != PSENT && c.w != PSENT);
+                if (__ballot(ok) == ~0ull) pend &= ~(1u << ((pl * NCW + k) * MB + i));
+              }
         pend = __builtin_amdgcn_readfirstlane(pend);
         if (pend && ++spins > spin_limit) {
           // record who starved and on what (first failure only); the host raises at the step's sync point (no __builtin_trap: hipcc sinks
@@ -710,16 +726,24 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
           const u32x4_ v = lval[k] ? av[k * MB + i] : u32x4_{0u, 0u, 0u, 0u};
-          if constexpr (BF) {
+          if constexpr (SP) {
+            const u32x4_ vl = lval[k] ? av[(NCW + k) * MB + i] : u32x4_{0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int g = 0; g < NS * G; ++g) {              // smallest terms first: lo.hi, hi.lo, then hi.hi
+              acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vl), __builtin_bit_cast(bf16x8, wreg[0][k][g]), acc[i][g], 0, 0, 0);
+              acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v), __builtin_bit_cast(bf16x8, wreg[NPL - 1][k][g]), acc[i][g], 0, 0, 0);
+              acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v), __builtin_bit_cast(bf16x8, wreg[0][k][g]), acc[i][g], 0, 0, 0);
+            }
+          } else if constexpr (BF) {
 #pragma unroll
             for (int g = 0; g < NS * G; ++g)
-              acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v), __builtin_bit_cast(bf16x8, wreg[k][g]), acc[i][g], 0, 0, 0);
+              acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v), __builtin_bit_cast(bf16x8, wreg[0][k][g]), acc[i][g], 0, 0, 0);
           } else {
             const f32x4 vf = __builtin_bit_cast(f32x4, v);
 #pragma unroll
             for (int e = 0; e < 4; ++e)                   // same element order as the step kernel (mfma_packed): bit-identical sums
 #pragma unroll
-              for (int g = 0; g < NS * G; ++g) acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[e], wreg[k][g][e], acc[i][g], 0, 0, 0);
+              for (int g = 0; g < NS * G; ++g) acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[e], wreg[0][k][g][e], acc[i][g], 0, 0, 0);
           }
         }
     }
@@ -807,10 +831,15 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
     // h_{s+1}" needs my reset of buffer (s+1) & 3 — issued at step s-1 — to be visible before this publish: this step's gather has waited
     // for vmcnt(0) in between (at s = 0 the buffers still hold the launcher's fill).  The reset of buffer (s+2) & 3 is safe here: this wave
     // is past the step's barrier, so every workgroup of the group has published h_{s-1}, i.e. has finished gathering h_{s-2}.
-    stage[wave][lane] = (elem_t)hnew;                   // rows beyond B / units beyond H publish zeros: consumers wait for every chunk
+    stage[0][wave][lane] = (elem_t)hnew;                // rows beyond B / units beyond H publish zeros: consumers wait for every chunk
+    if constexpr (SP) stage[NPL - 1][wave][lane] = (elem_t)(hnew - (float)(elem_t)hnew);
     if (pub_lane) {
-      store16_x(xbuf + (long long)(s & 3) * bufbytes + pub_off, *reinterpret_cast<const u32x4_*>(&stage[wave][(lane & 3) * 16 + (lane >> 2) * EPL]), l2_local);
-      store16_x(xbuf + (long long)((s + 2) & 3) * bufbytes + pub_off, u32x4_{PSENT, PSENT, PSENT, PSENT}, l2_local);
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        store16_x(xbuf + (long long)(s & 3) * bufbytes + pl * planebytes + pub_off,
+                  *reinterpret_cast<const u32x4_*>(&stage[pl][wave][(lane & 3) * 16 + (lane >> 2) * EPL]), l2_local);
+        store16_x(xbuf + (long long)((s + 2) & 3) * bufbytes + pl * planebytes + pub_off, u32x4_{PSENT, PSENT, PSENT, PSENT}, l2_local);
+      }
     }
     PTRACE(5);                                          // publish issued
     // ---- the step's saved-for-backward outputs: last, in the shadow of the exchange
@@ -1277,6 +1306,32 @@ __global__ __launch_bounds__(256) void rnn_pack_kernel(const float* __restrict__
   }
 }
 
+// forward operand of the split persistent kernel: the bf16 fragment order of rnn_pack_kernel<true>, once for hi = bf16(w) and once for
+// lo = bf16(w - hi)
+__global__ __launch_bounds__(256) void rnn_pack_split_fwd_kernel(const float* __restrict__ whh, void* __restrict__ wp_hi, void* __restrict__ wp_lo, int G, int H) {
+  constexpr int KC = 32;
+  const int nsl = (H + 15) >> 4, nch = (H + KC - 1) / KC;
+  const long long nf = (long long)2 * nsl * G * nch * 64;
+  for (long long ii = (long long)blockIdx.x * blockDim.x + threadIdx.x; ii < nf; ii += (long long)gridDim.x * blockDim.x) {
+    const int lane = (int)(ii & 63);
+    long long r = ii >> 6;
+    const int c = r % nch; r /= nch;
+    const int g = r % G; r /= G;
+    const int slice = r % nsl, dir = r / nsl;
+    const int j = slice * 16 + (lane & 15), k0 = c * KC + (lane >> 4) * 8;
+    const float* src = whh + ((long long)dir * G * H + g * H + j) * H + k0;
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float v = (j < H && k0 + e < H) ? src[e] : 0.f;
+      hi[e] = (__bf16)v;
+      lo[e] = (__bf16)(v - (float)hi[e]);
+    }
+    reinterpret_cast<bf16x8*>(wp_hi)[ii] = hi;
+    reinterpret_cast<bf16x8*>(wp_lo)[ii] = lo;
+  }
+}
+
 inline int pick_mb(int B, int H) {
   const int nsl = ceil_div(H, 16);
   if (B <= 16) return 1;
@@ -1330,8 +1385,10 @@ constexpr size_t CENSUS_BYTES = 64;                       // 8 per-XCD slot coun
 
 // Forward recurrence in one persistent launch (bf16 operands).  Returns 1 if launched, 0 if the shape / device does not qualify
 // (the caller then runs the step kernels), < 0 on error.
-template <int G, bool BF>
+template <int G, bool BF, bool SP = false>
 int try_launch_persistent_fwd(RnnArgs a, hipStream_t st) {
+  constexpr int NPL = SP ? 2 : 1;
+  constexpr int RLIM = SP ? 200 : 180;                            // lane-vector budget (x 4 registers) of W_hh fragments + gathered operand
   static const char* env = getenv("DS2_RNN_PERSISTENT");          // "0" = always the step kernels (A/B runs, debugging)
   if (env && env[0] == '0') return 0;
   if (a.dbg & ~128) return 0;                                     // any selector but 128 (= no K-split backward) selects the step kernels
@@ -1347,14 +1404,14 @@ int try_launch_persistent_fwd(RnnArgs a, hipStream_t st) {
   // 4 VGPRs) and the alternative would be a 32-row tile; else the step kernels' 16|32 rows x 16 units (with 16-row tiles the gather
   // is the same size either way and twice as many, half as big workgroups measured slightly faster).
   int mb = 1, ns = 2;
-  const bool ns2_ok = (nsl % 2) == 0 && ncw * (2 * G + 1) * 4 <= 180 && (long long)(nsl / 2) * ceil_div(a.B, 16) * 2 <= cu_count();
+  const bool ns2_ok = (nsl % 2) == 0 && ncw * NPL * (2 * G + 1) * 4 <= RLIM && (long long)(nsl / 2) * ceil_div(a.B, 16) * 2 <= cu_count();
   // ... and 16 x 32 also where 16 x 16 would be chosen but only the wider slice lets an exchange group fit one XCD (L2-local exchange;
   // bf16 only: in fp32 the doubled MFMA instruction count per workgroup costs more than the exchange saves, c2 5.4 -> 6.1 us per step)
   const bool ns2_for_local = BF && ns2_ok && !xcd_local_fits(nsl, ceil_div(a.B, 16 * pick_mb(a.B, a.H)) * 2) && xcd_local_fits(nsl / 2, ceil_div(a.B, 16) * 2);
   if (!ns2_ok || (pick_mb(a.B, a.H) != 2 && !ns2_for_local)) {
     ns = 1;
     mb = pick_mb(a.B, a.H);
-    if (ncw * (G + mb) * 4 > 176) return 0;
+    if (ncw * NPL * (G + mb) * 4 > (SP ? RLIM : 176)) return 0;
   }
   const int nbt = ceil_div(a.B, 16 * mb);
   // every workgroup must be resident at once: one per CU (up to 160 KB of registers + up to 129 KB of LDS each)
@@ -1364,7 +1421,7 @@ int try_launch_persistent_fwd(RnnArgs a, hipStream_t st) {
   a.p_nbt = nbt; a.p_gs = nsl / ns; a.p_cux = CUS_PER_XCD;
   a.p_census = xcd_local_fits(a.p_gs, 2 * nbt) ? 1 : 0;
   char* xbuf = reinterpret_cast<char*>(a.pk);
-  const size_t xbytes = 4 * fwd_xbuf_bytes(a.B, a.H, BF ? 1 : 0);
+  const size_t xbytes = 4 * NPL * fwd_xbuf_bytes(a.B, a.H, BF ? 1 : 0);
   DS2_HIP(hipMemsetAsync(xbuf, 0xff, xbytes + CENSUS_BYTES, st));      // every 16-byte chunk = the "not yet published" sentinel; census words = -1
   unsigned* census = reinterpret_cast<unsigned*>(xbuf + xbytes);
   // 1-D grid.  Census mode: one workgroup per CU of the whole chip, roles by real XCD id (surplus workgroups exit); else exactly the workgroups needed
@@ -1373,8 +1430,8 @@ int try_launch_persistent_fwd(RnnArgs a, hipStream_t st) {
   const int spin_limit = sl ? atoi(sl) : (1 << 20);              // ~1 s of polling: a missing workgroup is reported instead of hanging the queue
 #define DS2_PLAUNCH(MB_, NS_, NCW_)                                                                                                   \
   do {                                                                                                                                \
-    if constexpr (NCW_ * (NS_ * G + MB_) * 4 <= 180)                                                                                  \
-      hipLaunchKernelGGL((rnn_fwd_persistent_kernel<G, MB_, NS_, NCW_, BF>), grid, block, 0, st, a, xbuf, census, spin_limit);                 \
+    if constexpr (NCW_ * NPL * (NS_ * G + MB_) * 4 <= RLIM)                                                                           \
+      hipLaunchKernelGGL((rnn_fwd_persistent_kernel<G, MB_, NS_, NCW_, BF, SP>), grid, block, 0, st, a, xbuf, census, spin_limit);             \
     else                                                                                                                              \
       return 0;                                                                                                                       \
   } while (0)
@@ -1522,8 +1579,10 @@ int dispatch(int gates, bool bwd, const RnnArgs& a, hipStream_t st) {
 }  // namespace
 
 // packed-weight sizes in BYTES: which = 0 forward operand, 1 backward operand; bf16 = 0 | 1
+// bf16 = 2 (fp32 mode with the split forward recurrence): forward operand = [fp32 fragments | bf16 hi fragments | bf16 lo fragments], backward = fp32
 extern "C" size_t ds2_rnn_packed_bytes(int gates, int H, int which, int bf16) {
   const size_t nsl = (size_t)ceil_div(H, 16);
+  if (bf16 == 2) return ds2_rnn_packed_bytes(gates, H, which, 0) + (which == 0 ? 2 * ds2_rnn_packed_bytes(gates, H, 0, 1) : 0);
   const int kc = bf16 ? 32 : 16;
   return (which == 0 ? 2 * nsl * gates * ceil_div(H, kc) : 2 * nsl * ceil_div(gates * H, kc)) * 1024;
 }
@@ -1533,9 +1592,15 @@ extern "C" size_t ds2_rnn_packed_bytes(int gates, int H, int which, int bf16) {
 extern "C" int ds2_rnn_pack_whh(int gates, const float* whh, void* wp_fwd, void* wp_bwd, int H, int bf16, void* stream) {
   DS2_REQUIRE(gates == 3 || gates == 4, "ds2_rnn_pack_whh: gates must be 3 or 4");
   DS2_REQUIRE(whh && wp_fwd && wp_bwd && H > 0 && (H % 4) == 0, "ds2_rnn_pack_whh: bad args");
-  if (bf16) hipLaunchKernelGGL(rnn_pack_kernel<true>, dim3(2048), dim3(256), 0, (hipStream_t)stream, whh, wp_fwd, wp_bwd, gates, H);
+  if (bf16 == 1) hipLaunchKernelGGL(rnn_pack_kernel<true>, dim3(2048), dim3(256), 0, (hipStream_t)stream, whh, wp_fwd, wp_bwd, gates, H);
   else hipLaunchKernelGGL(rnn_pack_kernel<false>, dim3(2048), dim3(256), 0, (hipStream_t)stream, whh, wp_fwd, wp_bwd, gates, H);
   DS2_LAUNCH_CHECK("rnn_pack_kernel");
+  if (bf16 == 2) {                                               // + the split forward operand behind the fp32 one
+    char* hi = (char*)wp_fwd + ds2_rnn_packed_bytes(gates, H, 0, 0);
+    hipLaunchKernelGGL(rnn_pack_split_fwd_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, whh, (void*)hi,
+                       (void*)(hi + ds2_rnn_packed_bytes(gates, H, 0, 1)), gates, H);
+    DS2_LAUNCH_CHECK("rnn_pack_split_fwd_kernel");
+  }
   return 0;
 }
 
@@ -1566,9 +1631,11 @@ extern "C" int ds2_rnn_persistent_status(int* out8) {
   return 0;
 }
 
+// bf16: 0 fp32, 1 bf16 operands, 2 fp32 mode with the split (hi + lo bf16) persistent forward kernel and the fp32 kernels as fallback
 extern "C" size_t ds2_rnn_fwd_workspace_bytes(int B, int H, int bf16) {
-  const size_t step = pk_floats(B, H, H, bf16) * sizeof(float);                 // two ping-pong buffers of the step kernels
-  const size_t pers = 4 * fwd_xbuf_bytes(B, H, bf16) + 64;                       // four round-robin buffers of the persistent kernel + its census words
+  const size_t step = pk_floats(B, H, H, bf16 == 1) * sizeof(float);            // two ping-pong buffers of the step kernels
+  size_t pers = 4 * fwd_xbuf_bytes(B, H, bf16 == 1) + 64;                        // four round-robin buffers of the persistent kernel + its census words
+  if (bf16 == 2) { const size_t sp = 8 * fwd_xbuf_bytes(B, H, 1) + 64; pers = sp > pers ? sp : pers; }
   return step > pers ? step : pers;
 }
 
@@ -1591,14 +1658,29 @@ extern "C" int ds2_rnn_fwd_ex(int gates, float* gx, const void* wp_fwd, const fl
   {
     a.dbg = g_ds2_debug_flags;
     hipStream_t st = (hipStream_t)stream;
-    const int rc = bf16 ? (gates == 3 ? try_launch_persistent_fwd<3, true>(a, st) : try_launch_persistent_fwd<4, true>(a, st))
-                        : (gates == 3 ? try_launch_persistent_fwd<3, false>(a, st) : try_launch_persistent_fwd<4, false>(a, st));
+    int rc = 0;
+    if (bf16 == 2) {
+      // fp32 mode, split forward recurrence: operands behind the fp32 fragments of wp_fwd (ds2_rnn_packed_bytes(.., 0, 2)); where its shape
+      // does not qualify (or during a cooldown, which the fp32 attempt below counts) the fp32 kernels take the call with the fp32 fragments
+      static const char* env = getenv("DS2_F32_RNN");              // "f32": never the split kernel (A/B runs)
+      if (g_persist_cooldown == 0 && g_persist_fwd && !(env && env[0] == 'f') && !a.gates_bf) {
+        RnnArgs b = a;
+        b.wp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(wp_fwd) + ds2_rnn_packed_bytes(gates, H, 0, 0));
+        rc = gates == 3 ? try_launch_persistent_fwd<3, true, true>(b, st) : try_launch_persistent_fwd<4, true, true>(b, st);
+        if (rc == 1) g_last_path |= 32;                             // bit 5: the split kernel took the call
+      }
+      if (rc == 0) { g_last_path &= ~32; rc = gates == 3 ? try_launch_persistent_fwd<3, false>(a, st) : try_launch_persistent_fwd<4, false>(a, st); }
+    } else {
+      g_last_path &= ~32;
+      rc = bf16 ? (gates == 3 ? try_launch_persistent_fwd<3, true>(a, st) : try_launch_persistent_fwd<4, true>(a, st))
+                : (gates == 3 ? try_launch_persistent_fwd<3, false>(a, st) : try_launch_persistent_fwd<4, false>(a, st));
+    }
     g_last_path = (g_last_path & ~1) | (rc == 1 ? 1 : 0);
     if (rc != 0) return rc < 0 ? rc : 0;
   }
   // step kernels: zero padding rows / columns of the ping-pong buffers (the persistent path has filled its own with the sentinel)
   DS2_HIP(hipMemsetAsync(ws, 0, ds2_rnn_fwd_workspace_bytes(B, H, bf16), (hipStream_t)stream));
-  return bf16 ? dispatch<true>(gates, false, a, (hipStream_t)stream) : dispatch<false>(gates, false, a, (hipStream_t)stream);
+  return bf16 == 1 ? dispatch<true>(gates, false, a, (hipStream_t)stream) : dispatch<false>(gates, false, a, (hipStream_t)stream);
 }
 
 extern "C" int ds2_rnn_fwd(int gates, float* gx, const void* wp_fwd, const float* bhh, float* hbuf, float* aux, const int* lens_dev, int T,

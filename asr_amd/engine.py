@@ -65,6 +65,13 @@ WGRAD_SIDE = _os.environ.get("DS2_WGRAD_SIDE", "sk")
 F32_GEMM = _os.environ.get("DS2_F32_GEMM", "split")
 
 
+# fp32 mode, forward recurrence (DS2_F32_RNN): "split" (default) = the persistent kernel with h_t and W_hh as two bf16 planes each (hi + lo) and
+# three bf16 MFMAs per product where the shape fits (GRU up to H = 1024, LSTM up to H = 768: csrc/rnn.hip, SP) — fp32-grade results (~1e-6 of the
+# fp32 kernels) at a fifth of the fp32-MFMA time; "f32" = the fp32-MFMA kernels.  The library falls back to them by itself where the split
+# kernel does not fit, and during a cooldown.
+F32_RNN = _os.environ.get("DS2_F32_RNN", "split")
+
+
 def _f32_split_ok(M: int, N: int, K: int) -> bool:
     return F32_GEMM == "split" and M >= 512 and N >= 256 and K >= 256 and K % 8 == 0 and N % 8 == 0
 
@@ -254,7 +261,8 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
         else:
             gx = ops.gemm(xn, W[f"rnns.{l}.wih_cat"], transB=True, bias=W[f"rnns.{l}.bih_cat"])  # (M, 2GH)
         bf = cfg.precision == "bf16"
-        wpf, wpb = ops.rnn_pack(G, W[f"rnns.{l}.whh_cat"], bf16=bf)
+        rmode = 1 if bf else (2 if (F32_RNN == "split" and H % 32 == 0) else 0)
+        wpf, wpb = ops.rnn_pack(G, W[f"rnns.{l}.whh_cat"], bf16=rmode)
         # bf16 training (B % 8 == 0, the condition of the bf16 dGx path in backward): the saved gates are ONE packed bf16 record per
         # hidden unit; the fp32 x-projection buffer is then dead after the recurrence
         pack = bf and save and B % 8 == 0
@@ -268,7 +276,7 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
             if h_bf is not None and (ops.rnn_last_path() & 1):
                 lc.h_bf = h_bf                                   # (only a persistent launch writes it)
         else:
-            hbuf, aux = ops.rnn_fwd(G, gx, wpf, W[f"rnns.{l}.bhh_cat"], lens_dev, T, B, H, bf16=bf)
+            hbuf, aux = ops.rnn_fwd(G, gx, wpf, W[f"rnns.{l}.bhh_cat"], lens_dev, T, B, H, bf16=rmode)
         lc.wpb = wpb
         nxt = f"rnns.{l + 1}.batch_norm.module" if l + 1 < L else "fc.0.module.0"
         y, mean, var = ops.add_colstats(hbuf[:, :H], hbuf[:, H:], *run(nxt))

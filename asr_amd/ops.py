@@ -707,8 +707,9 @@ def conv2_wgrad_bf16(a1p: Tensor, dy2p: Tensor, lens_dev: Tensor, dW2: Tensor, T
 # ------------------------------------------------------------------------------------------------
 # recurrence
 # ------------------------------------------------------------------------------------------------
-def rnn_pack(gates: int, whh: Tensor, bf16: bool = False):
-    """W_hh (2, G*H, H) fp32 -> (wp_fwd, wp_bwd) in MFMA-fragment order (fp32 or bf16 fragments; see csrc/rnn.hip)."""
+def rnn_pack(gates: int, whh: Tensor, bf16=False):
+    """W_hh (2, G*H, H) fp32 -> (wp_fwd, wp_bwd) in MFMA-fragment order (fp32 or bf16 fragments; see csrc/rnn.hip).  bf16 = 2: the fp32
+    mode with the SPLIT forward recurrence (rnn_fwd(bf16=2)): wp_fwd = [fp32 fragments | bf16 hi fragments | bf16 lo fragments], wp_bwd fp32."""
     _chk_f32(whh)
     assert whh.is_contiguous() and whh.dim() == 3
     lib = _lib.load()
@@ -762,9 +763,11 @@ def rnn_persistent_counters():
     return int(out[0]), int(out[1])
 
 
-def rnn_fwd(gates: int, gx: Tensor, wp_fwd: Tensor, bhh: Tensor, lens_dev: Tensor, T: int, B: int, H: int, bf16: bool = False,
+def rnn_fwd(gates: int, gx: Tensor, wp_fwd: Tensor, bhh: Tensor, lens_dev: Tensor, T: int, B: int, H: int, bf16=False,
             packed_gates: bool = False, h_bf16: Optional[Tensor] = None):
     """gx (T*B, 2*G*H) in/out; returns (hbuf (T*B, 2H), aux (T*B, 2H)[, gates_bf (T*B, 2H, 4) bf16]).
+    bf16: False / 0 fp32, True / 1 bf16 operands, 2 = fp32 mode with the split persistent kernel (h and W_hh as hi + lo bf16 planes, three MFMAs
+    per product: fp32-grade results at the bf16 matrix rate; wp_fwd from rnn_pack(bf16=2); rnn_last_path() & 32 when it took the call).
     packed_gates: the saved-for-backward gates go to one 8-byte bf16 record per hidden unit (gx keeps the x-projections; GRU aux
     is not written) — pass the returned buffer to rnn_bwd.
     h_bf16: optional (T*B, 2H) bf16 buffer that receives a bf16 copy of hbuf — by a persistent launch only (rnn_last_path() & 1)."""

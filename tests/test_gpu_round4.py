@@ -295,3 +295,89 @@ def test_split_bf16_three_term_products_vs_fp64(M, N, K):
         e_tn = float((outT.double().cpu() - refT).norm() / refT.norm())
         print(f"TN: split-bf16 {e_tn:.2e}")
         assert e_tn < 2e-5
+
+
+def test_grouped_tn_kernels_fuzz():
+    """Random problem lists through both grouped TN kernels (the 256 x 256 split-K one and the co-resident 128 x 128 one): 1-6 products per launch,
+    M / N / K anywhere (multiples of 8 for M and N; K with tails), operands as column slices of wider buffers with row offsets (the shapes
+    the weight gradients hand over), outputs as slices of a guarded flat buffer.  Every product against the fp32 torch product of the same
+    bf16 operands; nothing outside the outputs is written; a second launch is bit-identical."""
+    from asr_amd import ops
+    rng = np.random.default_rng(4)
+    g = torch.Generator(device="cuda").manual_seed(4)
+    for trial in range(12):
+        nprob = int(rng.integers(1, 7))
+        probs, refs = [], []
+        total = sum(1 for _ in range(0))
+        sizes = []
+        for _ in range(nprob):
+            M, N = 8 * int(rng.integers(1, 90)), 8 * int(rng.integers(1, 90))
+            K = int(rng.integers(1, 1400)) if trial % 3 else 64 * int(rng.integers(1, 20))
+            sizes.append((M, N, K))
+        flat = torch.full((sum(M * N for M, N, _ in sizes) + 2 * 64,), 5.0, device="cuda")
+        off = 64
+        for M, N, K in sizes:
+            pa, pb = M + 8 * int(rng.integers(0, 4)), N + 8 * int(rng.integers(0, 4))
+            r0 = int(rng.integers(0, 3)) * 8
+            A = torch.randn(K + r0, pa, device="cuda", generator=g).bfloat16()[r0:, pa - M:]
+            Bm = torch.randn(K + r0, pb, device="cuda", generator=g).bfloat16()[r0:, :N]
+            out = flat[off:off + M * N].view(M, N)
+            off += M * N
+            probs.append((A, Bm, out))
+            refs.append(A.float().t() @ Bm.float())
+        kmin = min(k for _, _, k in sizes)
+        for name, run in (("splitk_group", lambda: ops.gemm_bf16_tn_splitk_group(probs, splitk=int(rng.integers(1, 4)) if kmin >= 256 else 1)),
+                          ("coresident_group", lambda: ops.gemm_bf16_tn_group(probs, max_workgroups=int(rng.choice([0, 8, 40]))))):
+            flat[64:-64].fill_(float("nan"))
+            run()
+            torch.cuda.synchronize()
+            assert float(flat[:64].min()) == 5.0 == float(flat[-64:].max()), (name, trial)
+            for (A, Bm, out), ref, (M, N, K) in zip(probs, refs, sizes):
+                err = float((out - ref).abs().max())
+                assert err <= 3e-5 * K ** 0.5 * 8 + 1e-4, (name, trial, (M, N, K), err)
+        first = flat.clone()
+        ops.gemm_bf16_tn_group(probs)
+        assert torch.equal(flat, first), trial
+
+
+@pytest.mark.parametrize("kind,H,B,T", [("gru", 768, 32, 9), ("gru", 1024, 64, 7), ("lstm", 512, 32, 8), ("gru", 256, 16, 12), ("lstm", 1280, 32, 4)])
+def test_split_forward_recurrence_vs_fp64_and_fp32_kernels(kind, H, B, T):
+    """fp32 mode, DS2_F32_RNN=split: the persistent forward recurrence with h_t and W_hh as hi + lo bf16 planes (three bf16 MFMAs per product)
+    against the fp64 recurrence (oracle.gru_direction / lstm_direction, blocks.py:87-89) and against the fp32-MFMA kernels on ragged lengths:
+    h, the saved gates and aux within 2e-5 of fp64 (the fp32 kernels: ~1e-6; the plain bf16 kernel: 3e-3), zeros beyond every length,
+    reruns bit-identical.  LSTM H = 1280 does not fit the split kernel (registers): the library takes the fp32 kernels by itself."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import det
+    from oracle import ds2_oracle as O
+    from asr_amd import ops
+    G = 3 if kind == "gru" else 4
+    lens = sorted([int(v) for v in det.randint((B,), 51, max(1, T // 3), T + 1)], reverse=True)
+    lens[0] = T
+    lens_t = torch.tensor(lens, dtype=torch.int32)
+    k = 1.0 / H ** 0.5
+    gx = torch.from_numpy(det.uniform((T, B, 2, G * H), 52, -1.5, 1.5)).double()
+    whh = torch.from_numpy(det.uniform((2, G * H, H), 53, -k, k)).double()
+    bhh = torch.from_numpy(det.uniform((2, G * H), 54, -k, k)).double()
+    step = O.gru_direction if kind == "gru" else O.lstm_direction
+    ref = torch.stack([step(gx[:, :, 0], whh[0], bhh[0], lens_t, False), step(gx[:, :, 1], whh[1], bhh[1], lens_t, True)], 2)   # (T,B,2,H)
+    dev = torch.device("cuda:0")
+    ld = lens_t.to(dev)
+    outs = {}
+    for mode in (2, 0, 1):
+        wpf, _ = ops.rnn_pack(G, whh.float().to(dev), bf16=mode)
+        gxd = gx.float().reshape(T * B, 2 * G * H).to(dev).clone()
+        hb, aux = ops.rnn_fwd(G, gxd, wpf, bhh.float().to(dev), ld, T, B, H, bf16=mode)
+        outs[mode] = (hb.view(T, B, 2, H).double().cpu(), gxd.cpu(), ops.rnn_last_path())
+        if mode == 2:
+            gx2 = gx.float().reshape(T * B, 2 * G * H).to(dev).clone()
+            hb2, _ = ops.rnn_fwd(G, gx2, wpf, bhh.float().to(dev), ld, T, B, H, bf16=2)
+            assert torch.equal(hb2, hb) and torch.equal(gx2, gxd), "reruns differ"
+    ops.rnn_persistent_check()
+    fits = not (kind == "lstm" and H == 1280)
+    assert bool(outs[2][2] & 32) == fits, outs[2][2]
+    err = {m: float((outs[m][0] - ref).norm() / ref.norm()) for m in outs}
+    print(f"{kind} H={H} B={B} T={T}: h vs fp64: split {err[2]:.2e}  fp32 kernels {err[0]:.2e}  bf16 kernels {err[1]:.2e}  (split kernel took the call: {fits})")
+    assert err[2] < 2e-5 and err[0] < 2e-5 and err[1] > 10 * err[2]
+    assert float((outs[2][1] - outs[0][1]).abs().max()) < 5e-5                      # saved gates against the fp32 kernels'
+    tmask = torch.arange(T).view(T, 1) >= lens_t.view(1, B)
+    assert float(outs[2][0][tmask].abs().max()) == 0.0
