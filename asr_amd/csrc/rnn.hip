@@ -1029,13 +1029,16 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(const float* pk, 
 // W_hh^T slice (32 units x G*H bf16 = 192 KB) lives in registers (96 per lane), there is no launch boundary, and the carry
 // (dh*z / dc*f) never leaves its thread.  Exchange protocol, buffers, starvation handling: see rnn_fwd_persistent_kernel.
 // ------------------------------------------------------------------------------------------
-template <int G, int MB, int NS, int NCW, bool BF>
+// SP: the split form of the fp32 mode (see rnn_fwd_persistent_kernel): dGh_t and W_hh^T as hi + lo bf16 planes, three bf16 MFMAs per product.
+template <int G, int MB, int NS, int NCW, bool BF, bool SP = false>
 __global__ __launch_bounds__(NW * 64) void rnn_bwd_persistent_kernel(RnnArgs a, char* xbuf, unsigned* census, int spin_limit) {
   static_assert(MB * NS * 256 <= NW * 64, "one (row, unit) pair per thread");
+  static_assert(!SP || BF, "the split form runs on the bf16 data path");
+  constexpr int NPL = SP ? 2 : 1;                                             // operand planes: [hi | lo]
   __shared__ __attribute__((aligned(16))) f32x4 red[2][NW][MB * NS][64];      // double-buffered: one workgroup barrier per time step
   constexpr int KC = kchunk<BF>(), EPL = KC / 4, NPUB = 64 / EPL;             // units per chunk / per 16-byte lane vector; chunks per wave and gate
   using elem_t = typename std::conditional<BF, __bf16, float>::type;
-  __shared__ __attribute__((aligned(16))) elem_t stage[NW][G][64];             // wave-private: NPUB complete 16-byte chunks per gate
+  __shared__ __attribute__((aligned(16))) elem_t stage[NPL][NW][G][64];        // wave-private: NPUB complete 16-byte chunks per gate
   const PRole role = persist_role(a, census, spin_limit, 2);                  // 1-D grid; roles from the XCD census or the workgroup id
   if (!role.active) return;
   const int dir = role.dir, bt = role.bt, slice = role.slice;
@@ -1045,20 +1048,24 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_persistent_kernel(RnnArgs a, 
   const int j0 = slice * (16 * NS), b0 = bt * (16 * MB);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const long long bufbytes = (long long)2 * a.nbt16 * nchb * 1024;
+  const long long planebytes = (long long)2 * a.nbt16 * nchb * 1024;
+  const long long bufbytes = NPL * planebytes;
   const long long dirbase = (long long)dir * a.nbt16 * nchb * 1024;
 
-  f32x4 wreg[NCW][NS];
+  f32x4 wreg[NPL][NCW][NS];
   bool cval[NCW], lval[NCW];
+  const long long wplane = (long long)2 * nsl * nchb * 256;                   // floats of one packed backward operand
 #pragma unroll
   for (int k = 0; k < NCW; ++k) {
     const int c = wave + NW * k;
     cval[k] = c < nchb;
     lval[k] = cval[k] && (c * KC + (lane >> 4) * EPL) < G * H;
 #pragma unroll
-    for (int n = 0; n < NS; ++n)
-      wreg[k][n] = cval[k] ? *reinterpret_cast<const f32x4*>(a.wp + ((((long long)dir * nsl + slice * NS + n) * nchb + c) * 256) + lane * 4)
-                           : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+      for (int n = 0; n < NS; ++n)
+        wreg[pl][k][n] = cval[k] ? *reinterpret_cast<const f32x4*>(a.wp + pl * wplane + ((((long long)dir * nsl + slice * NS + n) * nchb + c) * 256) + lane * 4)
+                                 : f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
   const int q = threadIdx.x;
@@ -1133,14 +1140,17 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_persistent_kernel(RnnArgs a, 
   };
   float bs[4] = {0.f, 0.f, 0.f, 0.f};                       // this thread's (batch row, unit) sums over time: the bias gradients' partials
 
-  unsigned goff[NCW * MB], pend0 = 0;                       // this wave's chunks of the packed exchange buffer, and the all-pending mask
+  static_assert(NPL * NCW * MB <= 32, "pending mask is 32 bits");
+  unsigned goff[NPL * NCW * MB], pend0 = 0;                 // this wave's chunks of the packed exchange buffer, and the all-pending mask
 #pragma unroll
-  for (int k = 0; k < NCW; ++k)
+  for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
-    for (int i = 0; i < MB; ++i) {
-      goff[k * MB + i] = (unsigned)(((((long long)(bt * MB + i) * nchb + (wave + NW * k)) * 64) + lane) * 16);
-      if (cval[k]) pend0 |= 1u << (k * MB + i);
-    }
+    for (int k = 0; k < NCW; ++k)
+#pragma unroll
+      for (int i = 0; i < MB; ++i) {
+        goff[(pl * NCW + k) * MB + i] = (unsigned)(pl * planebytes + ((((long long)(bt * MB + i) * nchb + (wave + NW * k)) * 64) + lane) * 16);
+        if (cval[k]) pend0 |= 1u << ((pl * NCW + k) * MB + i);
+      }
 
   PTRACE_DECL;
   vm_drained();                                         // prologue loads have landed
@@ -1154,23 +1164,25 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_persistent_kernel(RnnArgs a, 
       for (int n = 0; n < NS; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (s > 0) {
       const char* xin = xbuf + (long long)((s - 1) & 3) * bufbytes + dirbase;
-      u32x4_ av[NCW * MB];
+      u32x4_ av[NPL * NCW * MB];
 #pragma unroll
-      for (int k = 0; k < NCW * MB; ++k) av[k] = u32x4_{0u, 0u, 0u, 0u};
+      for (int k = 0; k < NPL * NCW * MB; ++k) av[k] = u32x4_{0u, 0u, 0u, 0u};
       int spins = 0;
       unsigned pend = pend0;                              // wave-uniform: chunks of this wave that have not been seen complete yet
       while (pend) {
         // only the chunks that are still missing are read again (one asm statement per pass: poll_pass)
-        poll_pass<NCW * MB>(av, goff, xin, pend);
+        poll_pass<NPL * NCW * MB>(av, goff, xin, pend);
 #pragma unroll
-        for (int k = 0; k < NCW; ++k)
+        for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
-          for (int i = 0; i < MB; ++i)
-            if (pend & (1u << (k * MB + i))) {
-              const u32x4_ c = av[k * MB + i];
-              const bool ok = !lval[k] || (c.x != PSENT && c.y != PSENT && c.z != PSENT && c.w != PSENT);
-              if (__ballot(ok) == ~0ull) pend &= ~(1u << (k * MB + i));
-            }
+          for (int k = 0; k < NCW; ++k)
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+              if (pend & (1u << ((pl * NCW + k) * MB + i))) {
+                const u32x4_ c = av[(pl * NCW + k) * MB + i];
+                const bool ok = !lval[k] || (c.x != PSENT && c.y != PSENT && c.z != PSENT && c.w != PSENT);
+                if (__ballot(ok) == ~0ull) pend &= ~(1u << ((pl * NCW + k) * MB + i));
+              }
         pend = __builtin_amdgcn_readfirstlane(pend);
         if (pend && ++spins > spin_limit) {
           // record who starved and on what (first failure only); the host raises at the step's sync point
@@ -1187,16 +1199,24 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_persistent_kernel(RnnArgs a, 
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
           const u32x4_ v = lval[k] ? av[k * MB + i] : u32x4_{0u, 0u, 0u, 0u};
-          if constexpr (BF) {
+          if constexpr (SP) {
+            const u32x4_ vl = lval[k] ? av[(NCW + k) * MB + i] : u32x4_{0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int n = 0; n < NS; ++n) {                  // smallest terms first: lo.hi, hi.lo, then hi.hi
+              acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vl), __builtin_bit_cast(bf16x8, wreg[0][k][n]), acc[i][n], 0, 0, 0);
+              acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v), __builtin_bit_cast(bf16x8, wreg[NPL - 1][k][n]), acc[i][n], 0, 0, 0);
+              acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v), __builtin_bit_cast(bf16x8, wreg[0][k][n]), acc[i][n], 0, 0, 0);
+            }
+          } else if constexpr (BF) {
 #pragma unroll
             for (int n = 0; n < NS; ++n)
-              acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v), __builtin_bit_cast(bf16x8, wreg[k][n]), acc[i][n], 0, 0, 0);
+              acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v), __builtin_bit_cast(bf16x8, wreg[0][k][n]), acc[i][n], 0, 0, 0);
           } else {
             const f32x4 vf = __builtin_bit_cast(f32x4, v);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-              for (int n = 0; n < NS; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[e], wreg[k][n][e], acc[i][n], 0, 0, 0);
+              for (int n = 0; n < NS; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[e], wreg[0][k][n][e], acc[i][n], 0, 0, 0);
           }
         }
     }
@@ -1245,10 +1265,17 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_persistent_kernel(RnnArgs a, 
     // ---- publish dGh_s (see the forward kernel): wave-local assembly, publish, reset two steps ahead (the previous reset was acknowledged
     // inside this step's gather)
 #pragma unroll
-    for (int g = 0; g < G; ++g) stage[wave][g][lane] = (elem_t)dgh[g];
+    for (int g = 0; g < G; ++g) {
+      stage[0][wave][g][lane] = (elem_t)dgh[g];
+      if constexpr (SP) stage[NPL - 1][wave][g][lane] = (elem_t)(dgh[g] - (float)(elem_t)dgh[g]);
+    }
     if (pub_lane) {
-      store16_x(xbuf + (long long)(s & 3) * bufbytes + pub_off, *reinterpret_cast<const u32x4_*>(&stage[wave][pg][(pp & 3) * 16 + (pp >> 2) * EPL]), l2_local);
-      store16_x(xbuf + (long long)((s + 2) & 3) * bufbytes + pub_off, u32x4_{PSENT, PSENT, PSENT, PSENT}, l2_local);
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        store16_x(xbuf + (long long)(s & 3) * bufbytes + pl * planebytes + pub_off,
+                  *reinterpret_cast<const u32x4_*>(&stage[pl][wave][pg][(pp & 3) * 16 + (pp >> 2) * EPL]), l2_local);
+        store16_x(xbuf + (long long)((s + 2) & 3) * bufbytes + pl * planebytes + pub_off, u32x4_{PSENT, PSENT, PSENT, PSENT}, l2_local);
+      }
     }
     PTRACE(5);
     so_t = t; so_dax = dax;
@@ -1324,6 +1351,30 @@ __global__ __launch_bounds__(256) void rnn_pack_split_fwd_kernel(const float* __
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float v = (j < H && k0 + e < H) ? src[e] : 0.f;
+      hi[e] = (__bf16)v;
+      lo[e] = (__bf16)(v - (float)hi[e]);
+    }
+    reinterpret_cast<bf16x8*>(wp_hi)[ii] = hi;
+    reinterpret_cast<bf16x8*>(wp_lo)[ii] = lo;
+  }
+}
+
+// backward operand of the split persistent kernel: the bf16 fragment order of rnn_pack_kernel<true>'s backward half, hi and lo
+__global__ __launch_bounds__(256) void rnn_pack_split_bwd_kernel(const float* __restrict__ whh, void* __restrict__ wp_hi, void* __restrict__ wp_lo, int G, int H) {
+  constexpr int KC = 32;
+  const int nsl = (H + 15) >> 4, nchb = (G * H + KC - 1) / KC;
+  const long long nb = (long long)2 * nsl * nchb * 64;
+  for (long long ii = (long long)blockIdx.x * blockDim.x + threadIdx.x; ii < nb; ii += (long long)gridDim.x * blockDim.x) {
+    const int lane = (int)(ii & 63);
+    long long r = ii >> 6;
+    const int c = r % nchb; r /= nchb;
+    const int slice = r % nsl, dir = r / nsl;
+    const int j = slice * 16 + (lane & 15), k0 = c * KC + (lane >> 4) * 8;
+    const float* src = whh + ((long long)dir * G * H + k0) * H + j;
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float v = (j < H && k0 + e < G * H) ? src[(long long)e * H] : 0.f;
       hi[e] = (__bf16)v;
       lo[e] = (__bf16)(v - (float)hi[e]);
     }
@@ -1457,8 +1508,9 @@ int try_launch_persistent_fwd(RnnArgs a, hipStream_t st) {
 size_t bwd_xbuf_bytes(int gates, int B, int H, int bf16) { return (size_t)2 * (ceil_div(B, 32) * 2) * ceil_div(gates * H, bf16 ? 32 : 16) * 1024; }
 
 // Backward recurrence in one persistent launch (bf16 training path).  1 = launched, 0 = not eligible, < 0 = error.
-template <int G, bool BF>
+template <int G, bool BF, bool SP = false>
 int try_launch_persistent_bwd(RnnArgs a, hipStream_t st) {
+  constexpr int NPL = SP ? 2 : 1;
   static const char* env = getenv("DS2_RNN_PERSISTENT");
   if ((env && env[0] == '0') || (a.dbg & ~128)) return 0;
   // buffers: either the bf16 training path's (packed gate records in, bf16 dGx out) or the plain ones (gates in gx, dGx in place)
@@ -1471,19 +1523,19 @@ int try_launch_persistent_bwd(RnnArgs a, hipStream_t st) {
   const int ncw = ceil_div(ceil_div(nchb, NW), q) * q;
   int ns = (mb == 2 && (nsl % 2) == 0) ? 2 : 1;                       // same tile choice as the step kernels ...
   // ... and 16 rows x 32 units also where that is what lets an exchange group fit one XCD (L2-local exchange)
-  if (BF && ns == 1 && mb == 1 && (nsl % 2) == 0 && ncw * (2 + 1) * 4 <= 192 && !xcd_local_fits(nsl, ceil_div(a.B, 16) * 2) &&
+  if (BF && ns == 1 && mb == 1 && (nsl % 2) == 0 && ncw * NPL * (2 + 1) * 4 <= (SP ? 160 : 192) && !xcd_local_fits(nsl, ceil_div(a.B, 16) * 2) &&
       xcd_local_fits(nsl / 2, ceil_div(a.B, 16) * 2))
     ns = 2;
   if (ns == 2) mb = 1;
   const int nbt = ceil_div(a.B, 16 * mb);
-  if (ncw > (BF ? 12 : 18) || ncw * (ns + mb) * 4 > 192) return 0;    // W_hh^T fragments + operand lane vectors must fit the registers
+  if (ncw > (BF ? 12 : 18) || ncw * NPL * (ns + mb) * 4 > (SP ? 160 : 192) || NPL * ncw * mb > 32) return 0;   // W_hh^T fragments + operand lane vectors must fit the registers
   if ((long long)(nsl / ns) * nbt * 2 > cu_count()) return 0;
   a.nsl = nsl;
   a.nbt16 = ceil_div(a.B, 32) * 2;
   a.p_nbt = nbt; a.p_gs = nsl / ns; a.p_cux = CUS_PER_XCD;
   a.p_census = xcd_local_fits(a.p_gs, 2 * nbt) ? 1 : 0;
   char* xbuf = reinterpret_cast<char*>(a.pk);
-  const size_t xbytes = 4 * bwd_xbuf_bytes(G, a.B, a.H, BF ? 1 : 0);
+  const size_t xbytes = 4 * NPL * bwd_xbuf_bytes(G, a.B, a.H, BF ? 1 : 0);
   DS2_HIP(hipMemsetAsync(xbuf, 0xff, xbytes + CENSUS_BYTES, st));
   unsigned* census = reinterpret_cast<unsigned*>(xbuf + xbytes);
   dim3 grid(a.p_census ? cu_count() : a.p_gs * nbt * 2), block(NW * 64);   // see the forward launcher
@@ -1491,8 +1543,8 @@ int try_launch_persistent_bwd(RnnArgs a, hipStream_t st) {
   const int spin_limit = sl ? atoi(sl) : (1 << 20);
 #define DS2_PB(MB_, NS_, NCW_)                                                                                                      \
   do {                                                                                                                              \
-    if constexpr (NCW_ * (NS_ + MB_) * 4 <= 192)                                                                                    \
-      hipLaunchKernelGGL((rnn_bwd_persistent_kernel<G, MB_, NS_, NCW_, BF>), grid, block, 0, st, a, xbuf, census, spin_limit);               \
+    if constexpr (NCW_ * NPL * (NS_ + MB_) * 4 <= (SP ? 160 : 192) && NPL * NCW_ * MB_ <= 32)                                                   \
+      hipLaunchKernelGGL((rnn_bwd_persistent_kernel<G, MB_, NS_, NCW_, BF, SP>), grid, block, 0, st, a, xbuf, census, spin_limit);           \
     else                                                                                                                            \
       return 0;                                                                                                                     \
   } while (0)
@@ -1579,10 +1631,10 @@ int dispatch(int gates, bool bwd, const RnnArgs& a, hipStream_t st) {
 }  // namespace
 
 // packed-weight sizes in BYTES: which = 0 forward operand, 1 backward operand; bf16 = 0 | 1
-// bf16 = 2 (fp32 mode with the split forward recurrence): forward operand = [fp32 fragments | bf16 hi fragments | bf16 lo fragments], backward = fp32
+// bf16 = 2 (fp32 mode with the split recurrences): each operand = [fp32 fragments | bf16 hi fragments | bf16 lo fragments]
 extern "C" size_t ds2_rnn_packed_bytes(int gates, int H, int which, int bf16) {
   const size_t nsl = (size_t)ceil_div(H, 16);
-  if (bf16 == 2) return ds2_rnn_packed_bytes(gates, H, which, 0) + (which == 0 ? 2 * ds2_rnn_packed_bytes(gates, H, 0, 1) : 0);
+  if (bf16 == 2) return ds2_rnn_packed_bytes(gates, H, which, 0) + 2 * ds2_rnn_packed_bytes(gates, H, which, 1);
   const int kc = bf16 ? 32 : 16;
   return (which == 0 ? 2 * nsl * gates * ceil_div(H, kc) : 2 * nsl * ceil_div(gates * H, kc)) * 1024;
 }
@@ -1600,6 +1652,10 @@ extern "C" int ds2_rnn_pack_whh(int gates, const float* whh, void* wp_fwd, void*
     hipLaunchKernelGGL(rnn_pack_split_fwd_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, whh, (void*)hi,
                        (void*)(hi + ds2_rnn_packed_bytes(gates, H, 0, 1)), gates, H);
     DS2_LAUNCH_CHECK("rnn_pack_split_fwd_kernel");
+    char* bh = (char*)wp_bwd + ds2_rnn_packed_bytes(gates, H, 1, 0);
+    hipLaunchKernelGGL(rnn_pack_split_bwd_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, whh, (void*)bh,
+                       (void*)(bh + ds2_rnn_packed_bytes(gates, H, 1, 1)), gates, H);
+    DS2_LAUNCH_CHECK("rnn_pack_split_bwd_kernel");
   }
   return 0;
 }
@@ -1720,9 +1776,10 @@ extern "C" int ds2_rnn_bias_grads(int gates, const float* bias_part, int B, int 
 }
 
 extern "C" size_t ds2_rnn_bwd_workspace_bytes(int gates, int B, int H, int bf16) {
-  const size_t step = pk_floats(B, H, gates * H, bf16) * sizeof(float);          // two ping-pong buffers of the step kernels
-  size_t pers = 4 * bwd_xbuf_bytes(gates, B, H, bf16) + 64;                       // four round-robin buffers of the persistent kernel + its census words
-  if (bf16 && ksplit_shape_ok(H)) pers = std::max(pers, ksplit_xbuf_bytes(B, H) + 64);   // two slots of the K-split kernel + census
+  const size_t step = pk_floats(B, H, gates * H, bf16 == 1) * sizeof(float);     // two ping-pong buffers of the step kernels
+  size_t pers = 4 * bwd_xbuf_bytes(gates, B, H, bf16 == 1) + 64;                  // four round-robin buffers of the persistent kernel + its census words
+  if (bf16 == 2) pers = std::max(pers, 8 * bwd_xbuf_bytes(gates, B, H, 1) + 64);  // the split form: hi and lo plane per buffer
+  if (bf16 == 1 && ksplit_shape_ok(H)) pers = std::max(pers, ksplit_xbuf_bytes(B, H) + 64);   // two slots of the K-split kernel + census
   return (size_t)4 * B * H * sizeof(float) + (step > pers ? step : pers);
 }
 
@@ -1849,18 +1906,30 @@ extern "C" int ds2_rnn_bwd_ex(int gates, const float* dy, int lddy, float* gx, f
     a.dbg = g_ds2_debug_flags;
     hipStream_t st = (hipStream_t)stream;
     // bf16: the K-split kernel where the shape qualifies (2 = it does, but a starved launch's cooldown is running: step kernels)
-    int rc = bf16 ? (gates == 3 ? try_launch_ksplit_bwd<3>(a, st) : try_launch_ksplit_bwd<4>(a, st)) : 0;
+    int rc = bf16 == 1 ? (gates == 3 ? try_launch_ksplit_bwd<3>(a, st) : try_launch_ksplit_bwd<4>(a, st)) : 0;
     g_last_bwd_kind = rc == 1 ? 2 : 0;
+    bool split = false;
+    if (rc == 0 && bf16 == 2) {
+      // fp32 mode, split backward recurrence (operands behind the fp32 fragments of wp_bwd); else / during a cooldown the fp32 kernels
+      static const char* env = getenv("DS2_F32_RNN");
+      if (g_persist_cooldown == 0 && g_persist_bwd && !(env && env[0] == 'f') && !a.gates_bf && !a.dgx_bf) {
+        RnnArgs b = a;
+        b.wp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(wp_bwd) + ds2_rnn_packed_bytes(gates, H, 1, 0));
+        rc = gates == 3 ? try_launch_persistent_bwd<3, true, true>(b, st) : try_launch_persistent_bwd<4, true, true>(b, st);
+        split = rc == 1;
+        if (split) g_last_bwd_kind = 1;
+      }
+    }
     if (rc == 0) {
-      rc = bf16 ? (gates == 3 ? try_launch_persistent_bwd<3, true>(a, st) : try_launch_persistent_bwd<4, true>(a, st))
-                : (gates == 3 ? try_launch_persistent_bwd<3, false>(a, st) : try_launch_persistent_bwd<4, false>(a, st));
+      rc = bf16 == 1 ? (gates == 3 ? try_launch_persistent_bwd<3, true>(a, st) : try_launch_persistent_bwd<4, true>(a, st))
+                     : (gates == 3 ? try_launch_persistent_bwd<3, false>(a, st) : try_launch_persistent_bwd<4, false>(a, st));
       g_last_bwd_kind = rc == 1 ? 1 : 0;
     }
-    g_last_path = (g_last_path & ~(6 | 16)) | (rc == 1 ? 2 : 0) | (g_last_bwd_kind == 2 ? 4 : 0);
+    g_last_path = (g_last_path & ~(6 | 16 | 64)) | (rc == 1 ? 2 : 0) | (g_last_bwd_kind == 2 ? 4 : 0) | (split ? 64 : 0);   // bit 6: the split kernel
     if (rc != 0 && rc != 2) return rc < 0 ? rc : 0;
   }
   DS2_HIP(hipMemsetAsync(ws, 0, ds2_rnn_bwd_workspace_bytes(gates, B, H, bf16), (hipStream_t)stream));   // step kernels: zero carry + padding
-  return bf16 ? dispatch<true>(gates, true, a, (hipStream_t)stream) : dispatch<false>(gates, true, a, (hipStream_t)stream);
+  return bf16 == 1 ? dispatch<true>(gates, true, a, (hipStream_t)stream) : dispatch<false>(gates, true, a, (hipStream_t)stream);
 }
 
 // ds2_rnn_bwd_ex for a layer whose output feeds a BatchNorm1d (every recurrent layer of the model: SequenceWise(BatchNorm1d) of the next
@@ -1882,7 +1951,7 @@ extern "C" int ds2_rnn_bwd_bn(int gates, const float* dyn, int lddyn, const floa
   DS2_REQUIRE(T > 0 && B > 0 && H > 0 && (H % 4) == 0, "ds2_rnn_bwd_bn: need H %% 4 == 0 (H=%d)", H);
   DS2_REQUIRE(ws && ws_bytes >= ds2_rnn_bwd_workspace_bytes(gates, B, H, bf16), "ds2_rnn_bwd_bn: workspace too small");
   hipStream_t st = (hipStream_t)stream;
-  if (bf16) {
+  if (bf16 == 1) {
     RnnArgs a{};
     a.gx = gx; a.aux = aux; a.hbuf = const_cast<float*>(hbuf); a.wp = (const float*)wp_bwd; a.dy = dyn; a.lddy = lddyn;
     a.dcar = (float*)ws; a.pk = (float*)ws + (size_t)4 * B * H;

@@ -65,8 +65,9 @@ WGRAD_SIDE = _os.environ.get("DS2_WGRAD_SIDE", "sk")
 F32_GEMM = _os.environ.get("DS2_F32_GEMM", "split")
 
 
-# fp32 mode, forward recurrence (DS2_F32_RNN): "split" (default) = the persistent kernel with h_t and W_hh as two bf16 planes each (hi + lo) and
-# three bf16 MFMAs per product where the shape fits (GRU up to H = 1024, LSTM up to H = 768: csrc/rnn.hip, SP) — fp32-grade results (~1e-6 of the
+# fp32 mode, recurrences (DS2_F32_RNN): "split" (default) = the persistent kernels with the moving operand (h_t / dGh_t) and W_hh as two bf16
+# planes each (hi + lo) and three bf16 MFMAs per product where the shape fits (forward: GRU up to H = 1024, LSTM up to H = 768; backward:
+# GRU / LSTM up to H = 768: csrc/rnn.hip, SP) — fp32-grade results (~1e-6 of the
 # fp32 kernels) at a fifth of the fp32-MFMA time; "f32" = the fp32-MFMA kernels.  The library falls back to them by itself where the split
 # kernel does not fit, and during a cooldown.
 F32_RNN = _os.environ.get("DS2_F32_RNN", "split")
@@ -532,7 +533,8 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
         bfd = bf and B % 8 == 0
         gshape = lc.gshape if lc.rec is not None else lc.gx.shape
         dgx_bf = torch.empty(gshape, dtype=torch.bfloat16, device=dy.device) if bfd else None
-        ops.rnn_bwd(G, dy, lc.gx, lc.aux, lc.hbuf, lc.wpb, lens_dev, T, B, H, bf16=bf, dgx_bf16=dgx_bf, gates_bf16=lc.rec)
+        rmode = 1 if bf else (2 if (F32_RNN == "split" and H % 32 == 0) else 0)          # (the mode lc.wpb was packed for in forward)
+        ops.rnn_bwd(G, dy, lc.gx, lc.aux, lc.hbuf, lc.wpb, lens_dev, T, B, H, bf16=rmode, dgx_bf16=dgx_bf, gates_bf16=lc.rec)
         lc.rec = None
         dgx = dgx_bf if bfd else lc.gx                                                            # dGx (M, 2GH)
         # ---- critical path: dXn = dGx W_ih (feeds the next layer's backward) ---------------------------------------

@@ -381,3 +381,47 @@ def test_split_forward_recurrence_vs_fp64_and_fp32_kernels(kind, H, B, T):
     assert float((outs[2][1] - outs[0][1]).abs().max()) < 5e-5                      # saved gates against the fp32 kernels'
     tmask = torch.arange(T).view(T, 1) >= lens_t.view(1, B)
     assert float(outs[2][0][tmask].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("kind,H,B,T", [("gru", 768, 32, 9), ("lstm", 512, 32, 8), ("gru", 256, 16, 12), ("gru", 1024, 64, 6)])
+def test_split_backward_recurrence_vs_fp64_and_fp32_kernels(kind, H, B, T):
+    """fp32 mode, DS2_F32_RNN=split, backward: the persistent (all-gather) backward recurrence with dGh_t and W_hh^T as hi + lo bf16 planes
+    against autograd through the fp64 recurrence (oracle.gru_direction / lstm_direction) on ragged lengths: dGx within 2e-5 (fp32 kernels
+    ~1e-6, bf16 kernels 3e-3); GRU H = 1024 does not fit (registers): the fp32 kernels take the call; reruns bit-identical."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import det
+    from oracle import ds2_oracle as O
+    from asr_amd import ops
+    G = 3 if kind == "gru" else 4
+    lens = sorted([int(v) for v in det.randint((B,), 61, max(1, T // 3), T + 1)], reverse=True)
+    lens[0] = T
+    lens_t = torch.tensor(lens, dtype=torch.int32)
+    k = 1.0 / H ** 0.5
+    gx = torch.from_numpy(det.uniform((T, B, 2, G * H), 62, -1.5, 1.5)).double().requires_grad_(True)
+    whh = torch.from_numpy(det.uniform((2, G * H, H), 63, -k, k)).double()
+    bhh = torch.from_numpy(det.uniform((2, G * H), 64, -k, k)).double()
+    step = O.gru_direction if kind == "gru" else O.lstm_direction
+    y = step(gx[:, :, 0], whh[0], bhh[0], lens_t, False) + step(gx[:, :, 1], whh[1], bhh[1], lens_t, True)
+    dy = torch.from_numpy(det.uniform((T, B, H), 65, -1.0, 1.0)).double()
+    (y * dy).sum().backward()
+    ref = gx.grad.reshape(T * B, 2 * G * H)
+    dev = torch.device("cuda:0")
+    ld, dyd = lens_t.to(dev), dy.float().reshape(T * B, H).to(dev)
+    err, paths, first = {}, {}, None
+    for mode in (2, 2, 0):
+        wpf, wpb = ops.rnn_pack(G, whh.float().to(dev), bf16=mode)
+        gxd = gx.detach().float().reshape(T * B, 2 * G * H).to(dev).clone()
+        hb, aux = ops.rnn_fwd(G, gxd, wpf, bhh.float().to(dev), ld, T, B, H, bf16=mode)
+        ops.rnn_bwd(G, dyd, gxd, aux, hb, wpb, ld, T, B, H, bf16=mode)
+        paths[mode] = ops.rnn_last_path()
+        got = gxd.double().cpu()
+        if mode == 2 and first is None:
+            first = gxd.clone()
+        elif mode == 2:
+            assert torch.equal(first, gxd), "reruns differ"
+        err[mode] = float((got - ref).norm() / ref.norm())
+    ops.rnn_persistent_check()
+    fits = not (kind == "gru" and H == 1024)
+    assert bool(paths[2] & 64) == fits, paths
+    print(f"{kind} H={H} B={B} T={T}: dGx vs fp64: split {err[2]:.2e}  fp32 kernels {err[0]:.2e}  (split backward kernel took the call: {fits})")
+    assert err[2] < 2e-5 and err[0] < 2e-5
