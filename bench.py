@@ -36,6 +36,9 @@ WORKLOADS = {
     "c4": ("lstm", 1280, 7, 29, 32, 1501),
     "c5": ("gru", 1024, 5, 80, 64, 2001),       # ragged 3-20 s (T_b ~ U{301..2001}), length-sorted, ~80 kana classes
 }
+F32_NOTE = ("fp32 storage, state, accumulation, BatchNorm, CTC, optimizer; the large input-to-hidden GEMMs and the persistent recurrences (where "
+            "the shape fits) take each fp32 operand as TWO bf16 terms (hi + lo) and form a product as hi.hi + hi.lo + lo.hi on the bf16 matrix cores "
+            "with fp32 accumulation: 4e-6 / 1e-6 of the fp64 result (DS2_F32_GEMM=f32 DS2_F32_RNN=f32: the fp32-input MFMA kernels)")
 FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, dense f32-input matrix rate
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # same guide: dense bf16 MFMA (the 5 PF marketing figure is 2:1 sparse)
 HBM_PEAK_GBS = 8000.0
@@ -372,6 +375,7 @@ def quick_workload(workload, dtype, dev, steps, warmup):
         kern[key]["frac"] = kern[key]["achieved_tflops"] / peak
     dom = max(kern.values(), key=lambda k: k["ms_per_step"])
     out = {"workload": f"{workload}: DS2 {L}x{H} bi-{rnn.upper()} {dtype}, T_in {tin}, batch {B}" + (", length-bucketed bins" if len(batches) > 1 else ""),
+           **({"dtype_note": F32_NOTE} if dtype == "f32" else {}),
            "steps": steps, "ms_per_step": ms, "utterances_per_sec": B * steps / dt, "loss": lv, "valid_last_step": bool(valid),
            "step_tflops": flops / (ms * 1e-3) / 1e12, "step_frac_of_matrix_peak": flops / (ms * 1e-3) / 1e12 / peak, "matrix_peak_tflops": peak,
            "roofline": {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved_tflops"], "peak": peak, "unit": "TFLOP/s", "frac": dom["frac"],
@@ -735,6 +739,7 @@ def main():
                       else f"utterances/sec DS2 {L}x{H} bi-{rnn} CTC train step",
             "value": utts, "unit": "utterances/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
+            **({"dtype_note": F32_NOTE} if dtype == "f32" else {}),
             "data": "synthetic N(0,1) 161-bin spectrograms, random-init weights, random labels U=T_in/20",
             "config": {"workload": f"{args.workload}: DS2 {L}x{H} bi-{rnn.upper()} {dtype}, {tin} input frames ({tin // 100} s), "
                                    f"batch {B}/GPU, {C} classes", "global_batch": B * world, "parallelism": f"dp{world}",
