@@ -291,6 +291,10 @@ def test_weight_gradients_tn_form_vs_transposing_cast_path(rnn, hidden, layers, 
         return real(*a, **k)
 
     monkeypatch.setattr(ops, "gemm_bf16_tn_pair", counted)
+    # (the per-product TN launches of round 3, DS2_WGRAD_SIDE=0: they split K exactly as the NT launches of the cast path do, which is what
+    # makes the comparison bit-exact; the default grouped launch uses one common split factor — its results are compared with these
+    # launches in tests/test_gpu_round4.py::test_grouped_splitk_weight_gradients_match_separate_launches)
+    monkeypatch.setattr(engine, "WGRAD_SIDE", "0")
     monkeypatch.setattr(engine, "WGRAD_TN", True)
     g_tn, l_tn, _ = _grads_of(model, "bf16", x, targets, pct, tsz, sd0)
     assert calls["tn"] >= layers, "the TN-form path did not run (recurrences not persistent?)"
