@@ -28,7 +28,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TN_MAX_PROBLEMS = 8;             // products per grouped TN launch (gemm_bf16_tn_glds_kernel<true>, gemm_tn_group.h)
+constexpr int TN_MAX_PROBLEMS = 16;            // products per grouped TN launch (gemm_bf16_tn_glds_kernel<true>, gemm_tn_group.h)
 constexpr int PITCH = 144;                       // bytes per LDS tile row (128 + 16 pad)
 constexpr int TILE_BYTES = BM * PITCH;           // 18432
 
@@ -597,9 +597,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(BArgs g
 // recurrent layer (dW_ih, the r,z rows and the n rows of dW_hh of both directions): blockIdx.x is a flat work-item index, item ->
 // (problem, K slice, tile); every item is one tile over one K slice of ~K / splitk rows, so with 192 tiles x 4 slices = 768 equal items the
 // chip runs exactly three full rounds where three separate launches each had their own ramp and tail, and the partial slabs are 4 per tile.
+// TERMS: consecutive problems that name the same C are terms of ONE product (the fp32 mode's hi.hi + hi.lo + lo.hi on row-pitched views of
+// split operands): each term is an entry of its own, all of them write slabs of the product's slab array (slab0 = term * splitk) and the
+// entry of the first term carries the reduce over all nslab = terms * splitk slabs.
 struct TnSProb {
-  const __bf16* A; const __bf16* B; float* C; float* partial;       // partial: this problem's slabs [splitk][M][N] (unused when splitk == 1)
+  const __bf16* A; const __bf16* B; float* C; float* partial;       // partial: the product's slabs [nslab][M][N] (unused when it has one slab)
   int M, N, K, lda, ldb, ldc, ntx, ntiles, kchunk, first_item;
+  int slab0, nslab, to_slab;                                        // this entry's first slab; slabs to reduce (first term only, else 0); write a slab?
 };
 struct TnSGroup {
   TnSProb p[TN_MAX_PROBLEMS];
@@ -621,18 +625,18 @@ __global__ __launch_bounds__(512) void gemm_bf16_tn_glds_kernel(BArgs g, int ntx
     A = grp.p[0].A; B = grp.p[0].B; Cfinal = grp.p[0].C; Cslab = grp.p[0].partial;
     pM = grp.p[0].M; pN = grp.p[0].N; pK = grp.p[0].K; plda = grp.p[0].lda; pldb = grp.p[0].ldb; ldcf = grp.p[0].ldc; ntx = grp.p[0].ntx;
     nt = grp.p[0].ntiles; kchunk = grp.p[0].kchunk;
-    int first = 0;
+    int first = 0, slab0 = grp.p[0].slab0, to_slab = grp.p[0].to_slab;
 #pragma unroll
     for (int k = 1; k < TN_MAX_PROBLEMS; ++k)
       if (k < grp.nprob && item >= grp.p[k].first_item) {
         A = grp.p[k].A; B = grp.p[k].B; Cfinal = grp.p[k].C; Cslab = grp.p[k].partial;
         pM = grp.p[k].M; pN = grp.p[k].N; pK = grp.p[k].K; plda = grp.p[k].lda; pldb = grp.p[k].ldb; ldcf = grp.p[k].ldc; ntx = grp.p[k].ntx;
-        nt = grp.p[k].ntiles; kchunk = grp.p[k].kchunk; first = grp.p[k].first_item;
+        nt = grp.p[k].ntiles; kchunk = grp.p[k].kchunk; first = grp.p[k].first_item; slab0 = grp.p[k].slab0; to_slab = grp.p[k].to_slab;
       }
     const int local = item - first;
     zb = 0; zs = local / nt; orig = local % nt;
-    partial = grp.splitk > 1;
-    Cslab += (long long)zs * pM * pN;
+    partial = to_slab != 0;
+    Cslab += (long long)(slab0 + zs) * pM * pN;
   } else {
     const int z = blockIdx.z;
     zb = z / g.splitk; zs = z % g.splitk;
@@ -857,24 +861,26 @@ __global__ void splitk_reduce_bf_kernel(const float* __restrict__ part, float* _
   *c = s;
 }
 
-// the split-K slabs of every problem of a grouped launch -> C (one launch; fixed summation order: bit-identical from run to run)
+// the slabs of every product of a grouped launch -> C (one launch; fixed summation order: bit-identical from run to run).  Entries with
+// nslab == 0 (further terms of a product, or a product written directly) own no elements here.
 __global__ __launch_bounds__(256) void splitk_reduce_group_kernel(TnSGroup grp, long long total) {
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     long long local = idx;
-    int k = 0;
+    const float* part = nullptr; float* C = nullptr; int M = 0, N = 1, ldc = 0, nslab = 0;
+    bool found = false;
 #pragma unroll
-    for (int q = 0; q < TN_MAX_PROBLEMS - 1; ++q) {
-      const long long mn = (long long)grp.p[q].M * grp.p[q].N / 4;
-      if (k == q && q + 1 < grp.nprob && local >= mn) { local -= mn; k = q + 1; }
+    for (int q = 0; q < TN_MAX_PROBLEMS; ++q) {
+      const long long mn = (q < grp.nprob && grp.p[q].nslab > 0) ? (long long)grp.p[q].M * grp.p[q].N / 4 : 0;
+      if (!found && local < mn) {
+        part = grp.p[q].partial; C = grp.p[q].C; M = grp.p[q].M; N = grp.p[q].N; ldc = grp.p[q].ldc; nslab = grp.p[q].nslab;
+        found = true;
+      }
+      if (!found) local -= mn;
     }
-    const float* part = grp.p[0].partial; float* C = grp.p[0].C; int M = grp.p[0].M, N = grp.p[0].N, ldc = grp.p[0].ldc;
-#pragma unroll
-    for (int q = 1; q < TN_MAX_PROBLEMS; ++q)
-      if (q == k) { part = grp.p[q].partial; C = grp.p[q].C; M = grp.p[q].M; N = grp.p[q].N; ldc = grp.p[q].ldc; }
     const long long e = local * 4;                      // N % 8 == 0: a float4 never straddles a row
     const int row = (int)(e / N), col = (int)(e % N);
     f32x4 sum = *reinterpret_cast<const f32x4*>(part + e);
-    for (int sidx = 1; sidx < grp.splitk; ++sidx) sum += *reinterpret_cast<const f32x4*>(part + (long long)sidx * M * N + e);
+    for (int sidx = 1; sidx < nslab; ++sidx) sum += *reinterpret_cast<const f32x4*>(part + (long long)sidx * M * N + e);
     *reinterpret_cast<f32x4*>(C + (long long)row * ldc + col) = sum;
   }
 }
@@ -1180,9 +1186,10 @@ extern "C" int ds2_gemm_bf16_tn(int M, int N, int K, const void* A, int lda, lon
 
 // Several TN products in ONE launch of the 256 x 256 kernel with a common split-K factor (gemm_bf16_tn_glds_kernel<true>) + ONE reduce launch.
 extern "C" size_t ds2_gemm_bf16_tn_splitk_group_workspace_bytes(int nprob, const ds2_tn_problem* probs, int splitk) {
-  if (splitk <= 1 || !probs) return 0;
+  if (!probs) return 0;
+  if (splitk < 1) splitk = 1;
   size_t n = 0;
-  for (int i = 0; i < nprob; ++i) n += (size_t)splitk * probs[i].M * probs[i].N * sizeof(float);
+  for (int i = 0; i < nprob; ++i) n += (size_t)splitk * probs[i].M * probs[i].N * sizeof(float);   // (an upper bound: one-slab products use none)
   return n;
 }
 
@@ -1197,15 +1204,22 @@ extern "C" int ds2_gemm_bf16_tn_splitk_group(int nprob, const ds2_tn_problem* pr
   int items = 0;
   size_t off = 0;
   long long elems = 0;
+  bool any_slab = false;
   for (int i = 0; i < nprob; ++i) {
     const ds2_tn_problem& q = probs[i];
     DS2_REQUIRE(q.A && q.B && q.C && q.M >= 8 && q.N >= 8 && q.K > 0, "ds2_gemm_bf16_tn_splitk_group: problem %d: bad dims M=%d N=%d K=%d", i, q.M, q.N, q.K);
     DS2_REQUIRE((q.M % 8) == 0 && (q.N % 8) == 0 && (q.lda % 8) == 0 && (q.ldb % 8) == 0 && (q.ldc % 4) == 0 && ((uintptr_t)q.C % 16) == 0,
                 "ds2_gemm_bf16_tn_splitk_group: problem %d: M, N, lda, ldb must be multiples of 8, ldc of 4, C 16-byte aligned", i);
     DS2_REQUIRE(((uintptr_t)q.A % 16) == 0 && ((uintptr_t)q.B % 16) == 0, "ds2_gemm_bf16_tn_splitk_group: problem %d: operands must be 16-byte aligned", i);
+    // consecutive problems with the same C = terms of one product
+    int term = 0;
+    while (i - term - 1 >= 0 && probs[i - term - 1].C == q.C) ++term;
+    int terms = term + 1;
+    while (i + (terms - term) < nprob && probs[i + (terms - term)].C == q.C) ++terms;
+    if (term > 0)
+      DS2_REQUIRE(probs[i - term].M == q.M && probs[i - term].N == q.N && probs[i - term].ldc == q.ldc, "ds2_gemm_bf16_tn_splitk_group: problem %d: terms of one product must agree in M, N, ldc", i);
     TnSProb& p = g.p[i];
     p.A = (const __bf16*)q.A; p.B = (const __bf16*)q.B; p.C = q.C;
-    p.partial = (float*)((char*)workspace + off);
     p.M = q.M; p.N = q.N; p.K = q.K; p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc;
     p.ntx = ceil_div(q.N, 256);
     p.ntiles = p.ntx * ceil_div(q.M, 256);
@@ -1213,12 +1227,20 @@ extern "C" int ds2_gemm_bf16_tn_splitk_group(int nprob, const ds2_tn_problem* pr
     DS2_REQUIRE(ceil_div(q.K, p.kchunk) == splitk, "ds2_gemm_bf16_tn_splitk_group: problem %d: K=%d does not split %d ways", i, q.K, splitk);
     p.first_item = items;
     items += p.ntiles * splitk;
-    off += (size_t)splitk * q.M * q.N * sizeof(float);
-    elems += (long long)q.M * q.N / 4;
+    const int nslab = terms * splitk;
+    p.to_slab = nslab > 1;
+    p.slab0 = term * splitk;
+    p.nslab = (term == 0 && nslab > 1) ? nslab : 0;
+    if (term == 0) {
+      p.partial = (float*)((char*)workspace + off);
+      if (nslab > 1) { off += (size_t)nslab * q.M * q.N * sizeof(float); elems += (long long)q.M * q.N / 4; any_slab = true; }
+    } else {
+      p.partial = g.p[i - term].partial;
+    }
   }
-  for (int i = nprob; i < TN_MAX_PROBLEMS; ++i) g.p[i] = g.p[0];
+  for (int i = nprob; i < TN_MAX_PROBLEMS; ++i) { g.p[i] = g.p[0]; g.p[i].nslab = 0; }
   g.nprob = nprob; g.splitk = splitk; g.nitems = items;
-  if (splitk > 1) DS2_REQUIRE(workspace && workspace_bytes >= off, "ds2_gemm_bf16_tn_splitk_group: workspace too small");
+  if (any_slab) DS2_REQUIRE(workspace && workspace_bytes >= off, "ds2_gemm_bf16_tn_splitk_group: workspace too small");
   static bool attr_set = false;
   if (!attr_set) {
     DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_tn_glds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
@@ -1227,7 +1249,7 @@ extern "C" int ds2_gemm_bf16_tn_splitk_group(int nprob, const ds2_tn_problem* pr
   BArgs unused{};
   hipLaunchKernelGGL(gemm_bf16_tn_glds_kernel<true>, dim3(items), dim3(512), G_LDS, (hipStream_t)stream, unused, 0, 0, g);
   DS2_LAUNCH_CHECK("gemm_bf16_tn_glds_kernel<grouped>");
-  if (splitk > 1) {
+  if (any_slab) {
     int blocks = (int)((elems + 255) / 256);
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, elems);
@@ -1239,7 +1261,7 @@ extern "C" int ds2_gemm_bf16_tn_splitk_group(int nprob, const ds2_tn_problem* pr
 // Several TN products C_p[M_p,N_p] = A_p[K_p,M_p]^T B_p[K_p,N_p] in ONE launch of the co-resident kernel (gemm_tn_group.h): a flat list of
 // 128 x 128 tiles, one workgroup per CU (at most `max_workgroups`, rounded down to a multiple of 8) walking it.  No split-K, no workspace.
 extern "C" int ds2_gemm_bf16_tn_group(int nprob, const ds2_tn_problem* probs, int max_workgroups, void* stream) {
-  DS2_REQUIRE(nprob >= 1 && nprob <= TN_MAX_PROBLEMS && probs, "ds2_gemm_bf16_tn_group: 1..%d problems", TN_MAX_PROBLEMS);
+  DS2_REQUIRE(nprob >= 1 && nprob <= TNG_MAX_PROBLEMS && probs, "ds2_gemm_bf16_tn_group: 1..%d problems", TNG_MAX_PROBLEMS);
   TnGroup g;
   int tiles = 0;
   for (int i = 0; i < nprob; ++i) {
@@ -1255,7 +1277,7 @@ extern "C" int ds2_gemm_bf16_tn_group(int nprob, const ds2_tn_problem* probs, in
     p.first_tile = tiles;
     tiles += p.ntx * ceil_div(q.M, 128);
   }
-  for (int i = nprob; i < TN_MAX_PROBLEMS; ++i) g.p[i] = g.p[0];
+  for (int i = nprob; i < TNG_MAX_PROBLEMS; ++i) g.p[i] = g.p[0];
   g.nprob = nprob; g.ntiles = tiles;
   static int cus = 0;
   if (!cus) {

@@ -27,13 +27,15 @@ constexpr int L_PATCH = 4 * 32 * 40 * 4;          // epilogue: 4 wave-private pa
 constexpr int L_LDS_REQ = L_LDS;                  // > 80 KiB: at most one of these workgroups per CU; + the recurrence's 10 KB <= 160 KB
 static_assert(L_PATCH <= L_LDS, "patch must fit in the stage buffers");
 
+constexpr int TNG_MAX_PROBLEMS = 8;              // products per launch of THIS kernel (its 106 SGPRs hold the selected problem's fields)
+
 struct TnProb {
   const __bf16* A; const __bf16* B; float* C;
   int M, N, K, lda, ldb, ldc;
   int ntx, first_tile;                            // column tiles; index of this problem's first tile in the flat list
 };
 struct TnGroup {
-  TnProb p[TN_MAX_PROBLEMS];
+  TnProb p[TNG_MAX_PROBLEMS];
   int nprob, ntiles;
 };
 
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const __bf16* PA = g.p[0].A; const __bf16* PB = g.p[0].B; float* PC = g.p[0].C;
     int M = g.p[0].M, N = g.p[0].N, K = g.p[0].K, lda = g.p[0].lda, ldb = g.p[0].ldb, ldc_ = g.p[0].ldc, ntx = g.p[0].ntx, first = 0;
 #pragma unroll
-    for (int k = 1; k < TN_MAX_PROBLEMS; ++k)
+    for (int k = 1; k < TNG_MAX_PROBLEMS; ++k)
       if (k < g.nprob && tile >= g.p[k].first_tile) {
         PA = g.p[k].A; PB = g.p[k].B; PC = g.p[k].C;
         M = g.p[k].M; N = g.p[k].N; K = g.p[k].K; lda = g.p[k].lda; ldb = g.p[k].ldb; ldc_ = g.p[k].ldc; ntx = g.p[k].ntx;

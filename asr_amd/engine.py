@@ -586,21 +586,37 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
                     ops.gemm_bf16_nt_pair(auxT[0:H, ka[0]], auxT[H:2 * H, ka[1]], hT[0:H, kb[0]], hT[H:2 * H, kb[1]], dwhh[:, 2 * H:])
                 keep.append((dgxT, hT, auxT))
             elif T > 1 and split:
-                # three accumulating TN launches per product: hi.hi, hi.lo, lo.hi on row-pitched views of the split copies
-                C2 = 2 * G * H
+                # every product = three terms (hi.hi, hi.lo, lo.hi) on row-pitched views of the split copies; ALL terms of ALL products of the
+                # layer (dW_hh of both directions, a GRU's n rows, dW_ih) in ONE grouped split-K launch + one reduce (terms of a product
+                # name the same output and are summed: ds2_gemm_bf16_tn_splitk_group)
+                C2, Iw = 2 * G * H, W[f"rnns.{l}.wih_cat"].shape[1]
+                Ip = lc.xs.shape[1] // 3
                 hs = ops.split_bf16(lc.hbuf, 2)                                                   # (M, 4H) = [hi | lo]
-                terms = ((dgs[:, :C2], hs[:, :2 * H]), (dgs[:, :C2], hs[:, 2 * H:]), (dgs[:, 2 * C2:], hs[:, :2 * H]))
+                d_hi, d_lo, h_hi, h_lo = dgs[:, :C2], dgs[:, 2 * C2:], hs[:, :2 * H], hs[:, 2 * H:]
                 rows = 2 * H if G == 3 else 4 * H
                 ra, rb = (slice(B, M), slice(0, M - B)), (slice(0, M - B), slice(B, M))
-                for k, (a, b) in enumerate(terms):
-                    ops.gemm_bf16_tn_pair(a[ra[0], 0:rows], a[ra[1], G * H:G * H + rows], b[rb[0], 0:H], b[rb[1], H:2 * H], dwhh[:, :rows],
-                                          accumulate=k > 0)
+                probs = []
+                for d in (0, 1):
+                    for a, b in ((d_hi, h_hi), (d_hi, h_lo), (d_lo, h_hi)):
+                        probs.append((a[ra[d], d * G * H:d * G * H + rows], b[rb[d], d * H:(d + 1) * H], dwhh[d, :rows]))
                 if G == 3:                                                                        # n-gate rows use d(hn) (aux) instead of dGx_n
                     axs = ops.split_bf16(lc.aux, 2)                                               # (M, 4H)
-                    for k, (a, b) in enumerate(((axs[:, :2 * H], hs[:, :2 * H]), (axs[:, :2 * H], hs[:, 2 * H:]), (axs[:, 2 * H:], hs[:, :2 * H]))):
-                        ops.gemm_bf16_tn_pair(a[ra[0], 0:H], a[ra[1], H:2 * H], b[rb[0], 0:H], b[rb[1], H:2 * H], dwhh[:, 2 * H:], accumulate=k > 0)
+                    a_hi, a_lo = axs[:, :2 * H], axs[:, 2 * H:]
+                    for d in (0, 1):
+                        for a, b in ((a_hi, h_hi), (a_hi, h_lo), (a_lo, h_hi)):
+                            probs.append((a[ra[d], d * H:(d + 1) * H], b[rb[d], d * H:(d + 1) * H], dwhh[d, 2 * H:]))
                     keep.append((axs,))
-                keep.append((hs,))
+                x_hi, x_lo = lc.xs[:, :Iw], lc.xs[:, 2 * Ip:2 * Ip + Iw]
+                for a, b in ((d_hi, x_hi), (d_hi, x_lo), (d_lo, x_hi)):
+                    probs.append((a, b, Gr[f"rnns.{l}.wih_cat"]))
+                if len(probs) <= 16 and Iw % 8 == 0:
+                    ops.gemm_bf16_tn_splitk_group(probs)
+                else:                                                                             # (never at the reference's shapes) term by term
+                    seen = set()
+                    for a, b, o in probs:
+                        ops.gemm_bf16_tn(a, b, out=o, accumulate=o.data_ptr() in seen)
+                        seen.add(o.data_ptr())
+                keep.append((hs, dgs, lc.xs))
             elif T > 1:
                 K = (T - 1) * B
                 ldg, ldh = 2 * G * H, 2 * H
@@ -623,6 +639,8 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
                 xnT = ops.transpose_bf16(lc.xn[:, :W[f"rnns.{l}.wih_cat"].shape[1]])              # lc.xn is bf16 (M, pad8(I)) in this mode
                 ops.gemm_bf16_nt(dgxT, xnT, out=Gr[f"rnns.{l}.wih_cat"])
                 keep.append((dgxT, xnT))
+            elif split and T > 1:
+                pass                                                                              # (dW_ih went out with the grouped launch above)
             elif split:
                 C2, I = 2 * G * H, W[f"rnns.{l}.wih_cat"].shape[1]
                 Ip = lc.xs.shape[1] // 3

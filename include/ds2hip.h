@@ -70,7 +70,9 @@ typedef struct ds2_tn_problem {
 int ds2_gemm_bf16_tn_group(int nprob, const ds2_tn_problem* problems, int max_workgroups, void* stream);
 /* The same problem list through the 256 x 256 TN kernel with ONE split-K factor for all of them: one GEMM launch whose work items are
  * (problem, K slice, tile) — a layer's 192 weight-gradient tiles x 4 slices are 768 equal items = three full rounds of the chip, where
- * three separate launches each had their own ramp and tail and up to 8 slabs per tile — and one reduce launch.  workspace: the slabs. */
+ * three separate launches each had their own ramp and tail and up to 8 slabs per tile — and one reduce launch.  workspace: the slabs.
+ * Consecutive problems that name the SAME C are TERMS of one product and are summed (the fp32 mode's hi.hi + hi.lo + lo.hi on views of
+ * split operands, ds2_split_bf16): up to 16 entries per launch. */
 size_t ds2_gemm_bf16_tn_splitk_group_workspace_bytes(int nprob, const ds2_tn_problem* problems, int splitk);
 int ds2_gemm_bf16_tn_splitk_group(int nprob, const ds2_tn_problem* problems, int splitk, void* workspace, size_t workspace_bytes, void* stream);
 int ds2_cast_bf16(const float* src, int ld_src, void* dst, int ld_dst, int R, int Cc, void* stream);

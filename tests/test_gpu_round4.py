@@ -425,3 +425,32 @@ def test_split_backward_recurrence_vs_fp64_and_fp32_kernels(kind, H, B, T):
     assert bool(paths[2] & 64) == fits, paths
     print(f"{kind} H={H} B={B} T={T}: dGx vs fp64: split {err[2]:.2e}  fp32 kernels {err[0]:.2e}  (split backward kernel took the call: {fits})")
     assert err[2] < 2e-5 and err[0] < 2e-5
+
+
+def test_grouped_splitk_terms_of_one_product_are_summed():
+    """Consecutive problems of ds2_gemm_bf16_tn_splitk_group that name the SAME output are terms of one product (the fp32 mode's
+    hi.hi + hi.lo + lo.hi): the launch writes their sum, for any split factor, next to ordinary single-term products, bit-identically
+    from run to run; a three-term split product reproduces the fp64 product of the fp32 operands to ~5e-6."""
+    from asr_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(9)
+    K, M, N = 3000, 520, 264
+    X = torch.randn(K, M, device="cuda", generator=g)
+    Y = torch.randn(K, N, device="cuda", generator=g)
+    xs, ys = ops.split_bf16(X, 2), ops.split_bf16(Y, 2)                      # [hi | lo], pad8(M) = 520, pad8(N) = 264
+    x_hi, x_lo, y_hi, y_lo = xs[:, :M], xs[:, M:], ys[:, :N], ys[:, N:]
+    A2 = torch.randn(K - 64, 256, device="cuda", generator=g).bfloat16()
+    B2 = torch.randn(K - 64, 512, device="cuda", generator=g).bfloat16()
+    ref = (X.double().t() @ Y.double()).cpu()
+    ref2 = A2.float().t() @ B2.float()
+    prev = None
+    for sk in (1, 2, 3):
+        out, out2 = torch.full((M, N), float("nan"), device="cuda"), torch.full((256, 512), float("nan"), device="cuda")
+        used = ops.gemm_bf16_tn_splitk_group([(x_hi, y_hi, out), (x_hi, y_lo, out), (x_lo, y_hi, out), (A2, B2, out2)], splitk=sk)
+        assert used == sk
+        e = float((out.double().cpu() - ref).norm() / ref.norm())
+        assert e < 2e-5, (sk, e)
+        assert float((out2 - ref2).abs().max()) < 3e-2
+        again = torch.empty_like(out)
+        ops.gemm_bf16_tn_splitk_group([(x_hi, y_hi, again), (x_hi, y_lo, again), (x_lo, y_hi, again)], splitk=sk)
+        assert torch.equal(again, out), sk
+        prev = out
