@@ -1779,6 +1779,7 @@ extern "C" size_t ds2_rnn_bwd_workspace_bytes(int gates, int B, int H, int bf16)
   const size_t step = pk_floats(B, H, gates * H, bf16 == 1) * sizeof(float);     // two ping-pong buffers of the step kernels
   size_t pers = 4 * bwd_xbuf_bytes(gates, B, H, bf16 == 1) + 64;                  // four round-robin buffers of the persistent kernel + its census words
   if (bf16 == 2) pers = std::max(pers, 8 * bwd_xbuf_bytes(gates, B, H, 1) + 64);  // the split form: hi and lo plane per buffer
+  if (bf16 == 2 && ksplit_shape_ok(H)) pers = std::max(pers, 2 * ksplit_xbuf_bytes(B, H) + 64);   // ... of the K-split kernel: two planes of two slots
   if (bf16 == 1 && ksplit_shape_ok(H)) pers = std::max(pers, ksplit_xbuf_bytes(B, H) + 64);   // two slots of the K-split kernel + census
   return (size_t)4 * B * H * sizeof(float) + (step > pers ? step : pers);
 }
@@ -1915,9 +1916,15 @@ extern "C" int ds2_rnn_bwd_ex(int gates, const float* dy, int lddy, float* gx, f
       if (g_persist_cooldown == 0 && g_persist_bwd && !(env && env[0] == 'f') && !a.gates_bf && !a.dgx_bf) {
         RnnArgs b = a;
         b.wp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(wp_bwd) + ds2_rnn_packed_bytes(gates, H, 1, 0));
-        rc = gates == 3 ? try_launch_persistent_bwd<3, true, true>(b, st) : try_launch_persistent_bwd<4, true, true>(b, st);
-        split = rc == 1;
-        if (split) g_last_bwd_kind = 1;
+        static const char* envk = getenv("DS2_RNN_KSPLIT");
+        const int rk = (envk && envk[0] == '0') ? 0 : (gates == 3 ? try_launch_ksplit_bwd<3, true>(b, st) : try_launch_ksplit_bwd<4, true>(b, st));
+        if (rk < 0) return rk;
+        if (rk == 1) { rc = 1; split = true; g_last_bwd_kind = 2; }
+        else {
+          rc = gates == 3 ? try_launch_persistent_bwd<3, true, true>(b, st) : try_launch_persistent_bwd<4, true, true>(b, st);
+          split = rc == 1;
+          if (split) g_last_bwd_kind = 1;
+        }
       }
     }
     if (rc == 0) {

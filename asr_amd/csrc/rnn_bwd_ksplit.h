@@ -39,14 +39,21 @@ typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
 typedef float f32x2_ __attribute__((ext_vector_type(2)));
 // TR: the GRU TRAINING instance (packed bf16 gate records in, bf16 dGx out — what engine.py's bf16 train step passes): the generic operand
 // fetch is compiled out, see ASM_FETCH below.
-template <int G, int NT, bool TR = false>
+// SP: the SPLIT form of the fp32 mode (DS2_F32_RNN=split; plain fp32 buffers in and out): W_hh as hi and lo bf16 fragment sets, the dGh tile
+// as a hi and a lo LDS plane, the product as lo.hi + hi.lo + hi.hi, and every partial sum published as TWO tagged bf16 pieces in two planes of
+// the exchange slots: hi' = the tagged bf16 of the fp32 partial (as in the bf16 form) and lo = bf16(partial - hi') — the lo piece absorbs
+// both the bf16 rounding AND the tag bit of the hi piece, so a consumer's hi' + lo is the fp32 partial to 2^-17 and the tag costs nothing.
+// The gather reads both planes (2 NL loads per lane, one poll statement), everything behind it is the same reduce-scatter.
+template <int G, int NT, bool TR = false, bool SP = false>
 __global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char* xbuf, unsigned* census, int spin_limit) {
   static_assert(!TR || G == 3, "the training instance exists for the GRU");
+  static_assert(!(TR && SP), "the split form takes the plain fp32 buffers");
+  constexpr int NPL = SP ? 2 : 1;
   static_assert(NW == 8 && NT >= 2 && (NT % 2) == 0, "8 waves: wave w owns output columns [w*H/8, (w+1)*H/8) = NT 16-column tiles");
   constexpr int NL = NT / 2;                                  // 1 KB wave loads per gather = producers / 8 = tile pairs per wave
   constexpr int AST = 40;                                     // bf16 per staged row (80 B pitch: conflict-free ds_read_b128)
   // planes 0..G-1: dGh gate by gate (the MFMA operand); GRU plane 3: d(pre-activation of n) = the n column of dGx.  Double-buffered: ONE barrier per step
-  __shared__ __attribute__((aligned(16))) __bf16 As[2][4][16][AST];
+  __shared__ __attribute__((aligned(16))) __bf16 As[NPL][2][4][16][AST];
   const PRole role = persist_role(a, census, spin_limit, 2);
   if (!role.active) return;
   // (s_setprio 3 here — win every issue arbitration against a co-resident weight-gradient kernel, gemm_tn_group.h — changed nothing
@@ -60,16 +67,20 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char
   const int nsl = H >> 4, nchb = (G * H) >> 5;
   const long long groupbytes = (long long)gs * gs * 1024;               // [consumer][wave][producer][128 B]
   const long long slotbytes = (long long)2 * a.p_nbt * groupbytes;
+  const long long planebytes = 2 * slotbytes;                           // SP: the lo plane of both slots lies behind the hi plane's
   char* gbase = xbuf + (long long)(dir * a.p_nbt + bt) * groupbytes;
 
   // ---- my K slice of W_hh (rows g*H + 32*slice .. +31, gate by gate) x this wave's NT column tiles -> registers (once).  The packed
   // backward operand of the other kernels holds exactly these fragments: [dir][16-column slice][32-row chunk][lane] (rnn_pack_kernel).
-  f32x4 wreg[G][NT];
+  f32x4 wreg[NPL][G][NT];
+  const long long wplane = (long long)2 * nsl * nchb * 256;             // floats of one packed backward operand (SP: hi, then lo)
 #pragma unroll
-  for (int g = 0; g < G; ++g)
+  for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-      wreg[g][nt] = *reinterpret_cast<const f32x4*>(a.wp + ((((long long)dir * nsl + (wave * NT + nt)) * nchb + (g * (H >> 5) + slice)) * 256) + lane * 4);
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        wreg[pl][g][nt] = *reinterpret_cast<const f32x4*>(a.wp + pl * wplane + ((((long long)dir * nsl + (wave * NT + nt)) * nchb + (g * (H >> 5) + slice)) * 256) + lane * 4);
 
   // ---- this lane's (batch row, hidden unit) pair: where the reduce-scatter below leaves its complete sum.  Lane = (b5, b4, b3, h, q):
   // piece (h, q) of the line; of the 8 sums of a piece [dword d = 2 b5 + b4][half b3] it keeps unit (d >> 1) * 16 + 4q + (d & 1) * 2 + b3
@@ -226,10 +237,12 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char
   // gather: this wave's lines of all producers are contiguous.  publish: lane (q = lane >> 4, c = lane & 15) holds, per tile pair, units
   // [4q..4q+3 | 16+4q..] of batch row c: piece (c & 1, q) of the line of consumer wave c >> 1 — a wave-uniform base per store + one
   // per-lane 32-bit offset
-  unsigned goff[NL];
+  unsigned goff[NPL * NL];
 #pragma unroll
-  for (int i = 0; i < NL; ++i) goff[i] = (unsigned)((((slice * 8 + wave) * gs) * 128) + i * 1024 + lane * 16);
-  const unsigned pend0 = (1u << NL) - 1u;
+  for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+    for (int i = 0; i < NL; ++i) goff[pl * NL + i] = (unsigned)(pl * planebytes + (((slice * 8 + wave) * gs) * 128) + i * 1024 + lane * 16);
+  const unsigned pend0 = (1u << (NPL * NL)) - 1u;
   const unsigned pub_lane_off = (unsigned)(((((lane & 15) >> 1) * gs + slice) * 128) + ((lane & 1) * 4 + (lane >> 4)) * 16);
   const long long pub_wave_off = (long long)(wave * NL) * 8 * gs * 128;
   const long long pub_step = (long long)8 * gs * 128;                    // next consumer workgroup (tile pair)
@@ -243,18 +256,18 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char
     if (s > 0) {
       const char* xin = gbase + (long long)((s - 1) & 1) * slotbytes;
       const unsigned tagw = ((unsigned)(s - 1) >> 1) & 1u;
-      u32x4_ av[NL];
+      u32x4_ av[NPL * NL];
 #pragma unroll
-      for (int i = 0; i < NL; ++i) av[i] = u32x4_{0u, 0u, 0u, 0u};
+      for (int i = 0; i < NPL * NL; ++i) av[i] = u32x4_{0u, 0u, 0u, 0u};
       int spins = 0;
       unsigned pend = pend0;
       while (pend) {
 #ifdef DS2_RNN_TRACE
         pt_acc[7] += 1;                                     // (trace build: poll passes, summed over the steps)
 #endif
-        poll_pass<NL>(av, goff, xin, pend);
+        poll_pass<NPL * NL>(av, goff, xin, pend);
 #pragma unroll
-        for (int i = 0; i < NL; ++i)
+        for (int i = 0; i < NPL * NL; ++i)
           if (pend & (1u << i)) {
             const bool ok = (((av[i].x ^ tagw) | (av[i].z ^ tagw)) & 1u) == 0u;      // both halves of this lane's piece carry the step's tag
             if (__ballot(ok) == ~0ull) pend &= ~(1u << i);
@@ -273,7 +286,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char
       // producers of a load.  (Dwords 0 / 2 carry the tag in the last mantissa bit of their low half: it is part of the value.)
       f32x2_ S2[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
-      for (int i = 0; i < NL; ++i) {
+      for (int i = 0; i < NPL * NL; ++i) {
         const u32x4_ c = av[i];
         S2[0] += f32x2_{__builtin_bit_cast(float, c.x << 16), __builtin_bit_cast(float, c.x & 0xffff0000u)};
         S2[1] += f32x2_{__builtin_bit_cast(float, c.y << 16), __builtin_bit_cast(float, c.y & 0xffff0000u)};
@@ -356,15 +369,21 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char
 
     // ---- my K slice of dGh_s (+ the n column of dGx) -> LDS: every wave's MFMA operand, and the way the bf16 results leave
 #pragma unroll
-    for (int g = 0; g < G; ++g) As[s & 1][g][row][unit] = (__bf16)dgh[g];
-    if (G == 3) As[s & 1][3][row][unit] = (__bf16)dgx[2];
+    for (int g = 0; g < G; ++g) {
+      const __bf16 hi = (__bf16)dgh[g];
+      As[0][s & 1][g][row][unit] = hi;
+      if constexpr (SP) As[NPL - 1][s & 1][g][row][unit] = (__bf16)(dgh[g] - (float)hi);
+    }
+    if (G == 3 && !SP) As[0][s & 1][3][row][unit] = (__bf16)dgx[2];
     __syncthreads();
     PTRACE(3);
-    bf16x8 af[G];
+    bf16x8 af[NPL][G];
 #pragma unroll
-    for (int g = 0; g < G; ++g) af[g] = *reinterpret_cast<const bf16x8*>(&As[s & 1][g][lane & 15][(lane >> 4) * 8]);
+    for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+      for (int g = 0; g < G; ++g) af[pl][g] = *reinterpret_cast<const bf16x8*>(&As[pl][s & 1][g][lane & 15][(lane >> 4) * 8]);
     u32x4_ outv = u32x4_{0u, 0u, 0u, 0u};
-    if (lds_out && wave < 4) outv = *reinterpret_cast<const u32x4_*>(&As[s & 1][wave][srow][(lane & 3) * 8]);
+    if (lds_out && wave < 4) outv = *reinterpret_cast<const u32x4_*>(&As[0][s & 1][wave][srow][(lane & 3) * 8]);
     // transposed product: acc[nt][r] of lane (q, c) = partial dh of batch row c, output unit 16 nt + 4q + r.
     // PUBLISH: piece = [units 4q..4q+3 | 16+4q..16+4q+3] of batch row c as bf16 (round to nearest even); bit 0 of each 8-byte half — the last
     // mantissa bit of its first value — is REPLACED by the tag and stays part of the value the consumer adds.
@@ -380,8 +399,15 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char
     auto mfma_pair = [&](int pr) {
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-        acc[2 * pr] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wreg[g][2 * pr]), af[g], acc[2 * pr], 0, 0, 0);
-        acc[2 * pr + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wreg[g][2 * pr + 1]), af[g], acc[2 * pr + 1], 0, 0, 0);
+        if constexpr (SP) {                                  // smallest terms first: W_hi.d_lo, W_lo.d_hi
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            acc[2 * pr + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wreg[0][g][2 * pr + q]), af[NPL - 1][g], acc[2 * pr + q], 0, 0, 0);
+            acc[2 * pr + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wreg[NPL - 1][g][2 * pr + q]), af[0][g], acc[2 * pr + q], 0, 0, 0);
+          }
+        }
+        acc[2 * pr] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wreg[0][g][2 * pr]), af[0][g], acc[2 * pr], 0, 0, 0);
+        acc[2 * pr + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wreg[0][g][2 * pr + 1]), af[0][g], acc[2 * pr + 1], 0, 0, 0);
       }
     };
     auto publish_pair = [&](int pr) {
@@ -392,6 +418,17 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char
                         (__builtin_bit_cast(unsigned, p2) & ~1u) | tagw, __builtin_bit_cast(unsigned, p3)};
       if (l2_local) store16_base<true>(xout + (long long)pr * pub_step, pub_lane_off, v);
       else store16_base<false>(xout + (long long)pr * pub_step, pub_lane_off, v);
+      if constexpr (SP) {
+        // the lo piece: what the TAGGED hi piece leaves of the fp32 partial (so the tag bit of the hi piece is compensated exactly), itself
+        // tagged in the last bit of two of its values (2^-17 of the partial)
+        auto lo2 = [](float x0, float x1, unsigned hw) {
+          const f32x2_ r = {x0 - __builtin_bit_cast(float, hw << 16), x1 - __builtin_bit_cast(float, hw & 0xffff0000u)};
+          return __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_));
+        };
+        const u32x4_ w = {(lo2(lo[0], lo[1], v.x) & ~1u) | tagw, lo2(lo[2], lo[3], v.y), (lo2(hi[0], hi[1], v.z) & ~1u) | tagw, lo2(hi[2], hi[3], v.w)};
+        if (l2_local) store16_base<true>(xout + planebytes + (long long)pr * pub_step, pub_lane_off, w);
+        else store16_base<false>(xout + planebytes + (long long)pr * pub_step, pub_lane_off, w);
+      }
     };
 #ifndef DS2_KS_PIPE
 #define DS2_KS_PIPE 1
@@ -472,21 +509,23 @@ bool ksplit_shape_ok(int H) { return H >= 256 && (H % 256) == 0 && H <= 1280; }
 
 // 1 = launched, 0 = not eligible (the caller tries the all-gather persistent kernel, then the step kernels), 2 = eligible but cooling
 // down after a starved launch (step kernels), < 0 = error
-template <int G>
+template <int G, bool SP = false>
 int try_launch_ksplit_bwd(RnnArgs a, hipStream_t st) {
+  constexpr int NPL = SP ? 2 : 1;
   static const char* env = getenv("DS2_RNN_PERSISTENT");
   static const char* envk = getenv("DS2_RNN_KSPLIT");               // "0": keep the all-gather backward kernel (A/B runs)
   if ((env && env[0] == '0') || (envk && envk[0] == '0') || a.dbg) return 0;   // any selector: not this kernel
   if (!((a.gates_bf && a.dgx_bf) || (!a.gates_bf && !a.dgx_bf && a.gx))) return 0;
+  if (SP && (a.gates_bf || a.dgx_bf)) return 0;                      // the split form: plain fp32 buffers
   if (!ksplit_shape_ok(a.H) || a.T < 2) return 0;
   const int gs = a.H / 32, nt = a.H / 128, nbt = ceil_div(a.B, 16);
-  if (nt * G * 4 > 176) return 0;                                    // W_hh fragments must leave room for the rest (256 registers per lane)
+  if (nt * G * 4 * NPL > (SP ? 150 : 176)) return 0;                 // W_hh fragments must leave room for the rest (256 registers per lane)
   if ((long long)gs * nbt * 2 > cu_count()) return 0;
   if (!persist_allowed(true)) return 2;                              // eligible, but a starved launch's cooldown is running
   a.p_nbt = nbt; a.p_gs = gs; a.p_cux = CUS_PER_XCD;
   a.p_census = xcd_local_fits(gs, 2 * nbt) ? 1 : 0;
   char* xbuf = reinterpret_cast<char*>(a.pk);
-  const size_t xbytes = ksplit_xbuf_bytes(a.B, a.H);
+  const size_t xbytes = NPL * ksplit_xbuf_bytes(a.B, a.H);
   DS2_HIP(hipMemsetAsync(xbuf, 0xff, xbytes + CENSUS_BYTES, st));     // both slots: tag 1 = "not the data of steps 0 / 1"; census words = -1
   unsigned* census = reinterpret_cast<unsigned*>(xbuf + xbytes);
   dim3 grid(a.p_census ? cu_count() : gs * nbt * 2), block(NW * 64);
@@ -495,7 +534,9 @@ int try_launch_ksplit_bwd(RnnArgs a, hipStream_t st) {
   switch (nt) {
 #define DS2_KS(NT_)                                                                                                       \
   case NT_:                                                                                                               \
-    if constexpr (NT_ * G * 4 <= 176) {                                                                                   \
+    if constexpr (SP && NT_ * G * 4 * 2 <= 150) {                                                                         \
+      hipLaunchKernelGGL((rnn_bwd_ksplit_kernel<G, NT_, false, true>), grid, block, 0, st, a, xbuf, census, spin_limit);  \
+    } else if constexpr (!SP && NT_ * G * 4 <= 176) {                                                                     \
       if (G == 3 && a.gates_bf && a.dgx_bf) {                                                                             \
         if constexpr (G == 3) hipLaunchKernelGGL((rnn_bwd_ksplit_kernel<3, NT_, true>), grid, block, 0, st, a, xbuf, census, spin_limit); \
       } else {                                                                                                            \

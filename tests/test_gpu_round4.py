@@ -423,7 +423,9 @@ def test_split_backward_recurrence_vs_fp64_and_fp32_kernels(kind, H, B, T):
     ops.rnn_persistent_check()
     fits = not (kind == "gru" and H == 1024)
     assert bool(paths[2] & 64) == fits, paths
-    print(f"{kind} H={H} B={B} T={T}: dGx vs fp64: split {err[2]:.2e}  fp32 kernels {err[0]:.2e}  (split backward kernel took the call: {fits})")
+    ksplit = bool(paths[2] & 4)                                   # the K-split split kernel where H is a multiple of 256 and the registers allow
+    assert ksplit == (fits and H % 256 == 0), paths
+    print(f"{kind} H={H} B={B} T={T}: dGx vs fp64: split {err[2]:.2e}  fp32 kernels {err[0]:.2e}  (split backward kernel took the call: {fits}, K-split form: {ksplit})")
     assert err[2] < 2e-5 and err[0] < 2e-5
 
 
