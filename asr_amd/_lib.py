@@ -116,6 +116,8 @@ SIGNATURES = {
     "ds2_adamw_f32": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp]),
     "ds2_adamw_gated_f32": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp, vp]),
     "ds2_scale_f32": (i32, [vp, i64, f32, vp]),
+    "ds2_bf16_residual_f32": (i32, [vp, vp, i64, vp]),
+    "ds2_sum3_f32": (i32, [vp, vp, vp, vp, i64, vp]),
 }
 
 

@@ -46,6 +46,38 @@ __global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, long 
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) x[i] *= s;
 }
 
+// fp32 mode's split products for the conv stack (engine.F32_CONV): r = x - float(bf16(x)), the part of x a bf16 operand drops; feeding r
+// through the bf16 mode's own cast / pack kernels yields the "lo" operand of the three-term product
+__global__ __launch_bounds__(256) void bf16_residual_kernel(const float* __restrict__ x, float* __restrict__ r, long long n4, long long n) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    float4 o;
+    o.x = v.x - (float)(__bf16)v.x; o.y = v.y - (float)(__bf16)v.y; o.z = v.z - (float)(__bf16)v.z; o.w = v.w - (float)(__bf16)v.w;
+    reinterpret_cast<float4*>(r)[i] = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n - n4 * 4)) {
+    const long long i = n4 * 4 + threadIdx.x;
+    r[i] = x[i] - (float)(__bf16)x[i];
+  }
+}
+
+// out = a + b + c (out may be a): the three partial results of a split product
+__global__ __launch_bounds__(256) void sum3_kernel(const float* a, const float* __restrict__ b, const float* __restrict__ c, float* out,
+                                                   long long n4, long long n) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 u = reinterpret_cast<const float4*>(a)[i], v = reinterpret_cast<const float4*>(b)[i], w = reinterpret_cast<const float4*>(c)[i];
+    float4 o;
+    o.x = u.x + v.x + w.x; o.y = u.y + v.y + w.y; o.z = u.z + v.z + w.z; o.w = u.w + v.w + w.w;
+    reinterpret_cast<float4*>(out)[i] = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n - n4 * 4)) {
+    const long long i = n4 * 4 + threadIdx.x;
+    out[i] = a[i] + b[i] + c[i];
+  }
+}
+
 }  // namespace
 
 // step is 1-based.  grad_scale multiplies g on the fly (e.g. 1/world_size after an all-reduce SUM).
@@ -97,5 +129,25 @@ extern "C" int ds2_scale_f32(float* x, long long n, float s, void* stream) {
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(scale_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, s);
   DS2_LAUNCH_CHECK("scale_kernel");
+  return 0;
+}
+
+extern "C" int ds2_bf16_residual_f32(const float* x, float* r, long long n, void* stream) {
+  DS2_REQUIRE(x && r && n >= 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)r % 16) == 0, "ds2_bf16_residual_f32: bad args");
+  if (n == 0) return 0;
+  long long blocks = (n / 4 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks);
+  hipLaunchKernelGGL(bf16_residual_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, r, n / 4, n);
+  DS2_LAUNCH_CHECK("bf16_residual_kernel");
+  return 0;
+}
+
+extern "C" int ds2_sum3_f32(const float* a, const float* b, const float* c, float* out, long long n, void* stream) {
+  DS2_REQUIRE(a && b && c && out && n >= 0 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)out) % 16) == 0, "ds2_sum3_f32: bad args");
+  if (n == 0) return 0;
+  long long blocks = (n / 4 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks);
+  hipLaunchKernelGGL(sum3_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b, c, out, n / 4, n);
+  DS2_LAUNCH_CHECK("sum3_kernel");
   return 0;
 }

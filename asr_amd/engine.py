@@ -73,6 +73,16 @@ F32_GEMM = _os.environ.get("DS2_F32_GEMM", "split")
 F32_RNN = _os.environ.get("DS2_F32_RNN", "split")
 
 
+# fp32 mode, conv2's BACKWARD (DS2_F32_CONV): "split" (default) = the bf16 mode's conv2 input-gradient and weight-gradient kernels run three
+# times each on split operands — a = hi + lo with hi = bf16(a), lo = bf16(a - hi) (ops.bf16_residual + the bf16 mode's own cast / pack
+# kernels), product = hi.hi + lo.hi + hi.lo, the three fp32 results summed by ops.sum3_ (<= 2e-5 of fp64) — instead of the fp32-input MFMA
+# kernels (csrc/conv.hip), which run at a sixteenth of the bf16 rate; "f32" = those kernels, as rounds 1-3.  The conv FORWARD stays on the
+# fp32 kernels on purpose: measured, a 1e-6 perturbation of y2 flips a ~1e-6 fraction of the Hardtanh(0, 20) branches behind it, and a
+# flipped element switches its whole gradient on or off, so the conv-stack gradients move by ~sqrt(1e-6) = 2e-3 — outside north_star's 1e-3
+# (4.bias, which depends on the forward alone, showed exactly that; profiles/r04_f32_conv_ab.txt).  conv1 stays fp32 as well.
+F32_CONV = _os.environ.get("DS2_F32_CONV", "split")
+
+
 def _f32_split_ok(M: int, N: int, K: int) -> bool:
     return F32_GEMM == "split" and M >= 512 and N >= 256 and K >= 256 and K % 8 == 0 and N % 8 == 0
 
@@ -680,6 +690,35 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
         del da1
         ops.conv1_wgrad_bf16(ctx.x16t, dy1, lens_dev, Gr[cp + "0.weight"], ctx.x.shape[3])
         ctx.x16t = None
+    elif F32_CONV == "split":
+        dy2, dy2p, dy2n = ops.bn2d_act_bwd_fused(ctx.y2, da2, lens_dev, m2, v2, W[cp + "4.weight"], W[cp + "4.bias"], Gr[cp + "4.weight"],
+                                                 Gr[cp + "4.bias"], Gr[cp + "3.bias"], want_f32=True, want_pad=True, want_nhwc=True)
+        del da2
+        r2 = ops.bf16_residual(dy2)
+        del dy2
+        dy2p_lo, dy2n_lo = ops.padcast_bf16(r2), ops.nhwc_bf16(r2)
+        r2 = ops.bf16_residual(ctx.a1)
+        a1p = (ops.padcast_bf16(ctx.a1), ops.padcast_bf16(r2))
+        del r2
+        ph = ops.conv2_pack_bf16(W[cp + "3.weight"])
+        pl = ops.conv2_pack_bf16(ops.bf16_residual(W[cp + "3.weight"]))
+        # dW2 = a_hi (x) dy_hi + a_lo (x) dy_hi + a_hi (x) dy_lo;  da1 = dy_hi * w_hi + dy_lo * w_hi + dy_hi * w_lo
+        g2 = Gr[cp + "3.weight"]
+        gb, gc = torch.empty_like(g2), torch.empty_like(g2)
+        ops.conv2_wgrad_bf16(a1p[0], dy2p, lens_dev, g2, T)
+        ops.conv2_wgrad_bf16(a1p[1], dy2p, lens_dev, gb, T)
+        ops.conv2_wgrad_bf16(a1p[0], dy2p_lo, lens_dev, gc, T)
+        ops.sum3_(g2, gb, gc)
+        del a1p
+        wd0, wd1, wl0, wl1 = ph[1], ph[2], pl[1], pl[2]
+        da1 = ops.conv2_dgrad_bf16(dy2n, wd0, wd1, D1)
+        ops.sum3_(da1, ops.conv2_dgrad_bf16(dy2n_lo, wd0, wd1, D1), ops.conv2_dgrad_bf16(dy2n, wl0, wl1, D1))
+        del dy2p, dy2n, dy2p_lo, dy2n_lo
+        m1, v1 = ctx.st1
+        dy1 = ops.bn2d_act_bwd(ctx.y1, da1, lens_dev, m1, v1, W[cp + "1.weight"], W[cp + "1.bias"], Gr[cp + "1.weight"], Gr[cp + "1.bias"])
+        del da1
+        Gr[cp + "0.bias"].copy_(ops.chan_sum(dy1))
+        ops.conv1_wgrad(ctx.x, dy1, lens_dev, Gr[cp + "0.weight"])
     else:
         dy2 = ops.bn2d_act_bwd(ctx.y2, da2, lens_dev, m2, v2, W[cp + "4.weight"], W[cp + "4.bias"], Gr[cp + "4.weight"], Gr[cp + "4.bias"])
         del da2

@@ -664,6 +664,23 @@ def nhwc_bf16(x: Tensor) -> Tensor:
     return out
 
 
+def bf16_residual(x: Tensor) -> Tensor:
+    """x - float(bf16(x)): what a bf16 operand of x drops (the "lo" term of the fp32 mode's split products on the conv stack)."""
+    _chk_f32(x)
+    assert x.is_contiguous()
+    r = torch.empty_like(x)
+    _lib.check(_lib.load().ds2_bf16_residual_f32(x.data_ptr(), r.data_ptr(), x.numel(), _stream()), "ds2_bf16_residual_f32")
+    return r
+
+
+def sum3_(a: Tensor, b: Tensor, c: Tensor) -> Tensor:
+    """a += b + c in place (the three partial results of a split product)."""
+    _chk_f32(a, b, c)
+    assert a.is_contiguous() and b.is_contiguous() and c.is_contiguous() and a.shape == b.shape == c.shape
+    _lib.check(_lib.load().ds2_sum3_f32(a.data_ptr(), b.data_ptr(), c.data_ptr(), a.data_ptr(), a.numel(), _stream()), "ds2_sum3_f32")
+    return a
+
+
 def conv2_fwd_bf16(a1_nhwc: Tensor, wf: Tensor, bias: Tensor, lens_dev: Tensor, stats: bool = False):
     B, D1, T, _ = a1_nhwc.shape
     D2 = (D1 + 20 - 21) // 2 + 1

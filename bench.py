@@ -36,9 +36,10 @@ WORKLOADS = {
     "c4": ("lstm", 1280, 7, 29, 32, 1501),
     "c5": ("gru", 1024, 5, 80, 64, 2001),       # ragged 3-20 s (T_b ~ U{301..2001}), length-sorted, ~80 kana classes
 }
-F32_NOTE = ("fp32 storage, state, accumulation, BatchNorm, CTC, optimizer; the large input-to-hidden GEMMs and the persistent recurrences (where "
-            "the shape fits) take each fp32 operand as TWO bf16 terms (hi + lo) and form a product as hi.hi + hi.lo + lo.hi on the bf16 matrix cores "
-            "with fp32 accumulation: 4e-6 / 1e-6 of the fp64 result (DS2_F32_GEMM=f32 DS2_F32_RNN=f32: the fp32-input MFMA kernels)")
+F32_NOTE = ("fp32 storage, state, accumulation, BatchNorm, CTC, optimizer, conv forward; the large input-to-hidden GEMMs, the persistent "
+            "recurrences (where the shape fits) and conv2's backward take each fp32 operand as TWO bf16 terms (hi + lo) and form a product as "
+            "hi.hi + hi.lo + lo.hi on the bf16 matrix cores with fp32 accumulation: 4e-6 / 1e-6 / 2e-5 of the fp64 result "
+            "(DS2_F32_GEMM=f32 DS2_F32_RNN=f32 DS2_F32_CONV=f32: the fp32-input MFMA kernels)")
 FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, dense f32-input matrix rate
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # same guide: dense bf16 MFMA (the 5 PF marketing figure is 2:1 sparse)
 HBM_PEAK_GBS = 8000.0

@@ -335,6 +335,10 @@ int ds2_adamw_f32(float* p, const float* g, float* m, float* v, long long n, flo
 int ds2_adamw_gated_f32(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
                         float weight_decay, int step, float grad_scale, const int* apply_flag, void* stream);
 int ds2_scale_f32(float* x, long long n, float s, void* stream);
+/* fp32 mode, conv2 on the bf16 matrix cores (three-term split products; engine.F32_CONV): r = x - float(bf16(x)) — the bf16 mode's cast / pack
+ * entries applied to r give the "lo" operand — and out = a + b + c for the three partial results (out may alias a). */
+int ds2_bf16_residual_f32(const float* x, float* r, long long n, void* stream);
+int ds2_sum3_f32(const float* a, const float* b, const float* c, float* out, long long n, void* stream);
 /* x[0..n) += v (int64): every BatchNorm's num_batches_tracked (torch.nn.BatchNorm*d.forward in training mode) in one launch */
 int ds2_add_i64(long long* x, int n, long long v, void* stream);
 

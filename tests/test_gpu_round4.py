@@ -456,3 +456,112 @@ def test_grouped_splitk_terms_of_one_product_are_summed():
         ops.gemm_bf16_tn_splitk_group([(x_hi, y_hi, again), (x_hi, y_lo, again), (x_lo, y_hi, again)], splitk=sk)
         assert torch.equal(again, out), sk
         prev = out
+
+
+def _conv2_fp64(a, w, bias, lens):
+    """MaskConv's conv2 (modules/blocks.py:36-53 semantic): Conv2d(32,32,(21,11),stride (2,1),pad (10,5)) + mask beyond each length, fp64"""
+    y = torch.nn.functional.conv2d(a.double(), w.double(), bias.double(), stride=(2, 1), padding=(10, 5))
+    T = y.size(3)
+    keep = (torch.arange(T, device=y.device)[None, :] < lens[:, None].to(y.device)).view(-1, 1, 1, T)
+    return y * keep
+
+
+@pytest.mark.parametrize("B,D1,T", [(3, 81, 57), (2, 81, 200)])
+def test_fp32_mode_conv2_split_products_vs_fp64(B, D1, T):
+    """engine.F32_CONV = split: conv2 forward / input gradient / weight gradient as three bf16-operand launches each on (hi, lo) operands made by
+    ops.bf16_residual + the bf16 mode's cast / pack kernels, summed by ops.sum3_ — against fp64 on the same fp32 tensors: <= 2e-5 of the result's
+    norm (the fp32-MFMA kernels: ~1e-6; one bf16 product: ~3e-3), ragged lengths masked identically."""
+    from asr_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + T)
+    a = (torch.rand(B, 32, D1, T, device="cuda", generator=g) * 20).contiguous()
+    w = (torch.randn(32, 32, 21, 11, device="cuda", generator=g) * 0.02).contiguous()
+    bias = torch.randn(32, device="cuda", generator=g)
+    lens = torch.tensor([T, max(1, T // 2), max(1, T - 3)][:B], dtype=torch.int32, device="cuda")
+    keep = (torch.arange(T, device="cuda")[None, :] < lens[:, None]).view(B, 1, 1, T)
+    a = (a * keep).contiguous()
+    r = ops.bf16_residual(a)
+    assert torch.equal(r, a - a.bfloat16().float())
+    ph, pl = ops.conv2_pack_bf16(w), ops.conv2_pack_bf16(ops.bf16_residual(w))
+    an, al = ops.nhwc_bf16(a), ops.nhwc_bf16(r)
+    zb = torch.zeros_like(bias)
+    y = ops.conv2_fwd_bf16(an, ph[0], bias, lens)
+    one = y.clone()
+    ops.sum3_(y, ops.conv2_fwd_bf16(al, ph[0], zb, lens), ops.conv2_fwd_bf16(an, pl[0], zb, lens))
+    ref = _conv2_fp64(a, w, bias, lens)
+    rel = lambda u, v: ((u.double() - v).norm() / v.norm()).item()
+    assert rel(y, ref) < 2e-5, rel(y, ref)
+    assert rel(one, ref) > 10 * rel(y, ref)                 # the single bf16 product is what the split improves on
+    f32 = ops.conv2_fwd(a, ops.conv_pack(torch.zeros(32, 1, 41, 11, device="cuda"), w)[1], bias, lens)
+    assert rel(f32, ref) < 2e-5
+    # backward: dy masked like the BatchNorm backward leaves it
+    dy = (torch.randn_like(ref.float()) * keep).contiguous()
+    rd = ops.bf16_residual(dy)
+    a64, w64 = a.double().requires_grad_(True), w.double().requires_grad_(True)
+    (_conv2_fp64(a64, w64, bias, lens) * dy.double()).sum().backward()
+    dn, dl = ops.nhwc_bf16(dy), ops.nhwc_bf16(rd)
+    da = ops.conv2_dgrad_bf16(dn, ph[1], ph[2], D1)
+    ops.sum3_(da, ops.conv2_dgrad_bf16(dl, ph[1], ph[2], D1), ops.conv2_dgrad_bf16(dn, pl[1], pl[2], D1))
+    assert rel(da, a64.grad) < 2e-5, rel(da, a64.grad)
+    ap, apl, dp, dpl = ops.padcast_bf16(a), ops.padcast_bf16(r), ops.padcast_bf16(dy), ops.padcast_bf16(rd)
+    gw, gb, gc = (torch.empty_like(w) for _ in range(3))
+    ops.conv2_wgrad_bf16(ap, dp, lens, gw, T)
+    ops.conv2_wgrad_bf16(apl, dp, lens, gb, T)
+    ops.conv2_wgrad_bf16(ap, dpl, lens, gc, T)
+    ops.sum3_(gw, gb, gc)
+    assert rel(gw, w64.grad) < 2e-5, rel(gw, w64.grad)
+
+
+def test_fp32_mode_split_conv_step_matches_fp32_mfma_conv_step():
+    """whole fp32-mode step, conv2's backward through the split products (default) vs through the fp32-input MFMA kernels (DS2_F32_CONV=f32):
+    the forward is the same code (logits, loss and every gradient behind the conv stack bit-identical), the conv-stack gradients within 1e-4
+    of the other mode's norm; reruns bit-identical.  (The forward stays fp32 on purpose — see engine.F32_CONV: a split forward moved these
+    gradients by 2e-3 through flipped Hardtanh branches.)"""
+    sys.path.insert(0, ROOT)
+    import bench
+    from test_gpu_model import make_model
+    from asr_amd import engine, ops
+    from asr_amd.trainers.deepspeech_trainer import _prep_targets_host
+    cfg = dict(rnn="gru", hidden=256, layers=2, classes=29)
+    B, tin = 6, 241
+
+    def run(mode):
+        old = engine.F32_CONV
+        engine.F32_CONV = mode
+        try:
+            torch.manual_seed(11)
+            model = make_model(cfg)
+            model.precision = "fp32"
+            x, targets, pct, tsz = bench.synthetic_batch(B, tin, cfg["classes"], 1)
+            x = x.cuda()
+            model._ensure_flat(x.device)
+            with torch.no_grad():
+                W = model._flat.tensors(model)
+                Gr = model._flat.tensors(model, grads=True)
+                out_sizes = model.get_seq_lens((pct * tin).int())
+                t_h, off_h, tl_h, max_u = _prep_targets_host(targets, tsz)
+                lens_dev, tg, off, tl = out_sizes.to(torch.int32).cuda(), t_h.cuda(), off_h.cuda(), tl_h.cuda()
+                logits, ctx = engine.forward(W, model._cfg, x, lens_dev, training=True, save=True)
+                nll, dlogits = ops.ctc_loss(logits, tg, off, lens_dev, tl, max_u, 1.0 / B, want_grad=True)
+                engine.backward(W, Gr, model._cfg, ctx, dlogits)
+                torch.cuda.synchronize()
+                return logits.clone(), float(nll.sum()), {k: v.clone() for k, v in Gr.items()}
+        finally:
+            engine.F32_CONV = old
+
+    ls, ns, gs = run("split")
+    ls2, ns2, gs2 = run("split")
+    lf, nf, gf = run("f32")
+    assert torch.equal(ls, ls2) and all(torch.equal(gs[k], gs2[k]) for k in gs)
+    assert ns == nf and torch.equal(ls, lf)
+    ds = {}
+    for k in gf:
+        if gf[k].dtype != torch.float32:
+            continue
+        if not k.startswith("conv."):
+            assert torch.equal(gs[k], gf[k]), k
+        elif gf[k].norm().item() > 0 and k not in ("conv.seq_module.0.bias", "conv.seq_module.3.bias"):
+            ds[k] = ((gs[k] - gf[k]).norm() / gf[k].norm()).item()       # (full-length batch: the conv biases' gradients are analytically zero)
+    print("\nsplit-conv-backward vs fp32-MFMA-conv step, relative gradient differences:", {k: float("%.2g" % v) for k, v in ds.items()})
+    assert len(ds) >= 4
+    for k, d in ds.items():
+        assert d < 1e-4, (k, d)
