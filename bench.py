@@ -42,6 +42,11 @@ F32_NOTE = ("fp32 storage, state, accumulation, BatchNorm, CTC, optimizer, conv 
             "(DS2_F32_GEMM=f32 DS2_F32_RNN=f32 DS2_F32_CONV=f32: the fp32-input MFMA kernels)")
 FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, dense f32-input matrix rate
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # same guide: dense bf16 MFMA (the 5 PF marketing figure is 2:1 sparse)
+# fp32 mode, split kernels: an fp32-grade product is THREE bf16 MFMA products (hi.hi + hi.lo + lo.hi), so the roof of such a kernel, in
+# algorithmic (one-product) FLOPs, is a third of the bf16 matrix rate - NOT the 157 TF/s of the fp32-input MFMA it no longer uses
+SPLIT_BF16_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 3.0
+SPLIT_PEAK_NOTE = ("fp32-grade product formed as three bf16 MFMA products (hi.hi + hi.lo + lo.hi): peak = dense bf16 MFMA rate / 3, achieved = "
+                   "algorithmic (one-product) FLOPs")
 HBM_PEAK_GBS = 8000.0
 
 
@@ -55,6 +60,12 @@ def kernel_source_sha256():
 
 
 PMC_SUMMARY = "r04_pmc_persistent.json"
+
+
+def expected_ksplit_instance(G, H):
+    """the template instance of the K-split backward recurrence the library launches for a bf16 training layer (rnn_bwd_ksplit.h:
+    <G, NT = H / 128, TR = GRU training instance, SP = fp32 split form>), as rocprofv3 prints it"""
+    return f"rnn_bwd_ksplit_kernel<{G}, {H // 128}, {'true' if G == 3 else 'false'}, false>"
 
 
 def load_pmc_summary():
@@ -345,7 +356,8 @@ def quick_workload(workload, dtype, dev, steps, warmup):
             e0.record()
             r = fn(*a, **k)
             e1.record()
-            calls[key].append((e0, e1, int(a[t_arg]), bool(ops.rnn_last_path() & bit)))
+            lp = ops.rnn_last_path()
+            calls[key].append((e0, e1, int(a[t_arg]), bool(lp & bit), bool(lp & 4), bool(lp & (32 if key == "fwd" else 64))))
             return r
         return w
     ops.rnn_fwd, ops.rnn_bwd, ops.rnn_bwd_bn = ev(orig[0], "fwd", 5, 1), ev(orig[1], "bwd", 7, 2), ev(orig[2], "bwd", 12, 2)
@@ -368,18 +380,23 @@ def quick_workload(workload, dtype, dev, steps, warmup):
     kern = {}
     for key in ("fwd", "bwd"):
         c = calls[key]
-        us = sum(a.elapsed_time(b) for a, b, _, _ in c) * 1e3
-        tsteps = sum(t for _, _, t, _ in c)
-        pers = all(p for _, _, _, p in c)
-        kern[key] = {"kernel": f"rnn_{key}_{'persistent' if pers else 'step'}_kernel", "us_per_time_step": us / tsteps,
-                     "achieved_tflops": 2.0 * 2 * B * H * G * H * tsteps / (us * 1e-6) / 1e12, "ms_per_step": us / 1e3 / steps}
-        kern[key]["frac"] = kern[key]["achieved_tflops"] / peak
+        us = sum(q[0].elapsed_time(q[1]) for q in c) * 1e3
+        tsteps = sum(q[2] for q in c)
+        pers, ks, sp = all(q[3] for q in c), all(q[4] for q in c), dtype != "bf16" and all(q[5] for q in c)
+        kern[key] = {"kernel": "rnn_bwd_ksplit_kernel" if (key == "bwd" and pers and ks) else f"rnn_{key}_{'persistent' if pers else 'step'}_kernel",
+                     "us_per_time_step": us / tsteps, "achieved_tflops": 2.0 * 2 * B * H * G * H * tsteps / (us * 1e-6) / 1e12,
+                     "ms_per_step": us / 1e3 / steps, "peak": SPLIT_BF16_PEAK_TFLOPS if sp else peak, "split": sp}
+        kern[key]["frac"] = kern[key]["achieved_tflops"] / kern[key]["peak"]
     dom = max(kern.values(), key=lambda k: k["ms_per_step"])
+    from asr_amd import engine as _eng
+    step_peak = SPLIT_BF16_PEAK_TFLOPS if (dtype != "bf16" and _eng.F32_GEMM == "split") else peak      # the GEMMs' roof in this mode
     out = {"workload": f"{workload}: DS2 {L}x{H} bi-{rnn.upper()} {dtype}, T_in {tin}, batch {B}" + (", length-bucketed bins" if len(batches) > 1 else ""),
            **({"dtype_note": F32_NOTE} if dtype == "f32" else {}),
            "steps": steps, "ms_per_step": ms, "utterances_per_sec": B * steps / dt, "loss": lv, "valid_last_step": bool(valid),
-           "step_tflops": flops / (ms * 1e-3) / 1e12, "step_frac_of_matrix_peak": flops / (ms * 1e-3) / 1e12 / peak, "matrix_peak_tflops": peak,
-           "roofline": {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved_tflops"], "peak": peak, "unit": "TFLOP/s", "frac": dom["frac"],
+           "step_tflops": flops / (ms * 1e-3) / 1e12, "step_frac_of_matrix_peak": flops / (ms * 1e-3) / 1e12 / step_peak, "matrix_peak_tflops": step_peak,
+           **({"matrix_peak_note": SPLIT_PEAK_NOTE, "step_vs_fp32_mfma_peak": flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS} if step_peak != peak else {}),
+           "roofline": {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved_tflops"], "peak": dom["peak"], "unit": "TFLOP/s",
+                        "frac": dom["frac"], **({"peak_note": SPLIT_PEAK_NOTE} if dom["split"] else {}),
                         "us_per_time_step": dom["us_per_time_step"], "ms_per_step_in_this_kernel": dom["ms_per_step"]},
            "persistent_starved_steps": DeepSpeechTrainer.starved_steps - starved0}
     del tr, batches
@@ -568,7 +585,7 @@ def main():
             e0.record()
             r = fn(*a, **k)
             e1.record()
-            rnn_calls[key].append((e0, e1, int(a[t_arg]), bool(ops.rnn_last_path() & bit), bool(ops.rnn_last_path() & 4), bool(ops.rnn_last_path() & 16)))
+            rnn_calls[key].append((e0, e1, int(a[t_arg]), bool(ops.rnn_last_path() & bit), bool(ops.rnn_last_path() & 4), bool(ops.rnn_last_path() & 16), bool(ops.rnn_last_path() & (32 if key == "fwd" else 64))))
             return r
         return wrapped
 
@@ -633,6 +650,7 @@ def main():
         T = T_f
         path_bits = (1 if p_f else 0) | (2 if p_b else 0) | (4 if (p_b and ks_b) else 0)
         bn_fused = all(c[5] for c in rnn_calls["bwd"])       # BatchNorm1d backward applied inside the K-split kernel (ds2_rnn_bwd_bn)
+        path_bits |= (32 if all(c[6] for c in rnn_calls["fwd"]) else 0) | (64 if all(c[6] for c in rnn_calls["bwd"]) else 0)   # fp32 mode: split kernels
     else:
         # fallback (no recurrence call was seen in the timed region): one layer's recurrences stand-alone, same shape and mode
         gx = torch.randn(M, 2 * G * H, device=dev) * 0.5
@@ -678,7 +696,7 @@ def main():
     if pmc is not None and not same_shape:
         pmc_why_not = "the PMC summary was collected for the c3 layer shape (GRU H=1024 B=64 bf16)"
     # the template instance the library launches for this shape (rnn.hip / rnn_bwd_ksplit.h): a summary for another instance is refused too
-    expect = {"rnn_bwd_ksplit_kernel": f"rnn_bwd_ksplit_kernel<{G}, {H // 128}, {'true' if G == 3 else 'false'}>"}
+    expect = {"rnn_bwd_ksplit_kernel": expected_ksplit_instance(G, H)}
 
     def pmc_traffic(kernel, steps):
         nonlocal pmc_why_not
@@ -692,8 +710,11 @@ def main():
     traffic = pmc_traffic("rnn_fwd_persistent_kernel" if persistent else "rnn_fwd_step_kernel", T)
     # x-projections 3 x 4 + gate record 8 + h 4 + packed h 2 (+ the bf16 copy of h 2) bytes per hidden unit and direction (packed mode)
     alg_bytes_step = (3 * 4 + 8 + 4 + 2 + (2 if tn else 0) if pack else 8 * 4 + (2 if bf else 4)) * B * 2 * H
+    split_f, split_b = (not bf) and bool(path_bits & 32), (not bf) and bool(path_bits & 64)
+    peak_f, peak_b = (SPLIT_BF16_PEAK_TFLOPS if split_f else peak), (SPLIT_BF16_PEAK_TFLOPS if split_b else peak)
     roofline = {"kernel": "rnn_fwd_persistent_kernel" if persistent else "rnn_fwd_step_kernel", "bound": "mfma", "achieved": achieved,
-                "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                "peak": peak_f, "unit": "TFLOP/s", "frac": achieved / peak_f, "traffic": traffic,
+                **({"peak_note": SPLIT_PEAK_NOTE} if split_f else {}),
                 "algorithmic_hbm_bytes_per_launch": alg_bytes_step * (T if persistent else 1),
                 "us_per_launch": us_per_launch, "us_per_time_step": layer_us / T, "launches_per_step": (1 if persistent else T) * L}
     # the backward recurrence (same FLOPs per time step): on a single GPU it is persistent too wherever its W_hh^T slice fits the
@@ -712,7 +733,8 @@ def main():
     # fp32, + 2 for the bf16 copy in the TN-form mode — the K-split kernel writes ONLY the bf16 copy then
     dhn_bytes = 0 if G != 3 else ((2 if ksplit else 6) if tn else 4)
     roofline_bwd = {"kernel": bwd_name, "bound": "mfma", "achieved": b_ach,
-                    "peak": peak, "unit": "TFLOP/s", "frac": b_ach / peak, "traffic": bwd_traffic,
+                    "peak": peak_b, "unit": "TFLOP/s", "frac": b_ach / peak_b, "traffic": bwd_traffic,
+                    **({"peak_note": SPLIT_PEAK_NOTE} if split_b else {}),
                     "algorithmic_hbm_bytes_per_launch": ((8 + 4 + 2 * G + dhn_bytes) * 2 + 4 + (4 if (ksplit and bn_fused) else 0) if pack
                                                          else (4 * G + 4 + 4 + 4 * G + 4) * 2 + 4) * B * H * bl_steps,
                     **({"traffic_note": "the L2 of this part writes every stored byte through to the fabric (MI355X_MICROARCH.md, store table): "
@@ -747,6 +769,8 @@ def main():
                        **({"sampler": sampler_note} if sampler_note else {})},
             "loss": lv, "step_tflops": step_flops * world / (ms * 1e-3) / 1e12,
             "step_frac_of_fp32_mfma_peak": step_flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+            **({"step_frac_of_split_bf16_peak": step_flops / (ms * 1e-3) / 1e12 / SPLIT_BF16_PEAK_TFLOPS, "split_bf16_peak_note": SPLIT_PEAK_NOTE}
+               if (dtype == "f32" and _engine.F32_GEMM == "split") else {}),
             "step_frac_of_bf16_mfma_peak": step_flops / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
             "roofline": roofline,
             # train steps of this run (warm-up included) in which a persistent recurrence launch starved and the step was skipped

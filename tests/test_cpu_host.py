@@ -454,3 +454,15 @@ def test_gemm_isa_no_spills_and_no_copy_of_inflight_fragments():
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_isa.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0 instruction(s) touching in-flight" in r.stdout
+
+
+def test_committed_pmc_summary_belongs_to_this_tree_and_names_the_launched_instance():
+    """bench.py only quotes `roofline.traffic` from a PMC summary whose recorded kernel-source hash equals the tree's and whose kernel is the
+    template instance the metric config launches: the committed summary must satisfy both, or every bench line of this tree reports
+    traffic null (it did once: a fourth template parameter changed the printed instance name)."""
+    import bench
+    pmc, why_not = bench.load_pmc_summary()
+    assert pmc is not None and why_not is None, why_not
+    assert pmc["kernels"]["rnn_bwd_ksplit_kernel"]["kernel"] == bench.expected_ksplit_instance(3, 1024)
+    assert pmc["kernels"]["rnn_bwd_ksplit_kernel"]["hbm_bytes_per_time_step"] > 0
+    assert pmc["kernels"]["rnn_fwd_persistent_kernel"]["hbm_bytes_per_time_step"] > 0
