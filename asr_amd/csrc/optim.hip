@@ -62,19 +62,20 @@ __global__ __launch_bounds__(256) void bf16_residual_kernel(const float* __restr
   }
 }
 
-// out = a + b + c (out may be a): the three partial results of a split product
+// out = a + b + c (out may be a; c may be NULL: out = a + b): the partial results of a split product
 __global__ __launch_bounds__(256) void sum3_kernel(const float* a, const float* __restrict__ b, const float* __restrict__ c, float* out,
                                                    long long n4, long long n) {
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    const float4 u = reinterpret_cast<const float4*>(a)[i], v = reinterpret_cast<const float4*>(b)[i], w = reinterpret_cast<const float4*>(c)[i];
+    const float4 u = reinterpret_cast<const float4*>(a)[i], v = reinterpret_cast<const float4*>(b)[i];
+    const float4 w = c ? reinterpret_cast<const float4*>(c)[i] : float4{0.f, 0.f, 0.f, 0.f};
     float4 o;
     o.x = u.x + v.x + w.x; o.y = u.y + v.y + w.y; o.z = u.z + v.z + w.z; o.w = u.w + v.w + w.w;
     reinterpret_cast<float4*>(out)[i] = o;
   }
   if (blockIdx.x == 0 && threadIdx.x < (int)(n - n4 * 4)) {
     const long long i = n4 * 4 + threadIdx.x;
-    out[i] = a[i] + b[i] + c[i];
+    out[i] = a[i] + b[i] + (c ? c[i] : 0.f);
   }
 }
 
@@ -143,7 +144,7 @@ extern "C" int ds2_bf16_residual_f32(const float* x, float* r, long long n, void
 }
 
 extern "C" int ds2_sum3_f32(const float* a, const float* b, const float* c, float* out, long long n, void* stream) {
-  DS2_REQUIRE(a && b && c && out && n >= 0 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)out) % 16) == 0, "ds2_sum3_f32: bad args");
+  DS2_REQUIRE(a && b && out && n >= 0 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)out) % 16) == 0, "ds2_sum3_f32: bad args");
   if (n == 0) return 0;
   long long blocks = (n / 4 + 255) / 256;
   blocks = blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks);

@@ -81,6 +81,14 @@ F32_RNN = _os.environ.get("DS2_F32_RNN", "split")
 # flipped element switches its whole gradient on or off, so the conv-stack gradients move by ~sqrt(1e-6) = 2e-3 — outside north_star's 1e-3
 # (4.bias, which depends on the forward alone, showed exactly that; profiles/r04_f32_conv_ab.txt).  conv1 stays fp32 as well.
 F32_CONV = _os.environ.get("DS2_F32_CONV", "split")
+# fp32 mode, conv2's FORWARD (DS2_F32_CONV_FWD): "f32" (default) = the fp32-input MFMA kernel; "split6" = three bf16 pieces per operand
+# (a = h + m + l, each the bf16 of what the pieces before it leave: 24 significant bits) and the six products h.h, h.m, m.h, m.m, h.l, l.h on
+# the bf16 conv kernel.  Measured: 4.8e-7 of fp64 (the fp32-input kernel: 1.5e-6; three terms: 4.6e-6), c2 f32 33.80 -> 33.16 ms — and NOT the
+# default: whichever fp32-grade forward runs, its rounding flips a few Hardtanh branches against the fp64 oracle and the conv-stack gradients
+# move by the square root of that fraction; with this form one oracle case lands at 1.14e-3 against north_star's 1e-3
+# (test_step_vs_oracle_larger[gru-128-2-33-90], conv.seq_module.0.weight; the fp32-input kernel passes all of them), and 0.6 ms on a
+# secondary configuration does not buy a parity case (profiles/r04_f32_conv_ab.txt).
+F32_CONV_FWD = _os.environ.get("DS2_F32_CONV_FWD", "f32")
 
 
 def _f32_split_ok(M: int, N: int, K: int) -> bool:
@@ -227,6 +235,26 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
         if training and CONV_STATS:
             y2, st_part2 = y2
         del a1n
+    elif F32_CONV_FWD == "split6":
+        a1, a1p = ops.bn2d_act_fwd(y1, lens_dev, m1, v1, W[cp + "1.weight"], W[cp + "1.bias"]), None      # (the same a1 as the fp32-kernel path, bit for bit)
+        ah = ops.nhwc_bf16(a1)
+        r = ops.bf16_residual(a1)
+        am = ops.nhwc_bf16(r)
+        al = ops.nhwc_bf16(ops.bf16_residual(r))
+        del r
+        w2 = W[cp + "3.weight"]
+        wr = ops.bf16_residual(w2)
+        wh, wm, wl = ops.conv2_pack_bf16(w2)[0], ops.conv2_pack_bf16(wr)[0], ops.conv2_pack_bf16(ops.bf16_residual(wr))[0]
+        zb = torch.zeros_like(W[cp + "3.bias"])
+        # smallest terms first: (m.m + h.l + l.h), then + h.m + m.h, then h.h (+ bias)
+        y2 = ops.conv2_fwd_bf16(am, wm, zb, lens_dev)
+        ops.sum3_(y2, ops.conv2_fwd_bf16(ah, wl, zb, lens_dev), ops.conv2_fwd_bf16(al, wh, zb, lens_dev))
+        t2 = ops.conv2_fwd_bf16(ah, wm, zb, lens_dev)
+        ops.sum3_(y2, t2, ops.conv2_fwd_bf16(am, wh, zb, lens_dev))
+        del t2
+        y2 = ops.sum3_(ops.conv2_fwd_bf16(ah, wh, W[cp + "3.bias"], lens_dev), y2)
+        del ah, am, al
+        st_part2 = None
     else:
         a1, a1p = ops.bn2d_act_fwd(y1, lens_dev, m1, v1, W[cp + "1.weight"], W[cp + "1.bias"]), None
         y2 = ops.conv2_fwd(a1, wpk2, W[cp + "3.bias"], lens_dev)

@@ -673,11 +673,11 @@ def bf16_residual(x: Tensor) -> Tensor:
     return r
 
 
-def sum3_(a: Tensor, b: Tensor, c: Tensor) -> Tensor:
-    """a += b + c in place (the three partial results of a split product)."""
-    _chk_f32(a, b, c)
-    assert a.is_contiguous() and b.is_contiguous() and c.is_contiguous() and a.shape == b.shape == c.shape
-    _lib.check(_lib.load().ds2_sum3_f32(a.data_ptr(), b.data_ptr(), c.data_ptr(), a.data_ptr(), a.numel(), _stream()), "ds2_sum3_f32")
+def sum3_(a: Tensor, b: Tensor, c: Optional[Tensor] = None) -> Tensor:
+    """a += b (+ c) in place (the partial results of a split product)."""
+    _chk_f32(a, b) if c is None else _chk_f32(a, b, c)
+    assert a.is_contiguous() and b.is_contiguous() and a.shape == b.shape and (c is None or (c.is_contiguous() and c.shape == a.shape))
+    _lib.check(_lib.load().ds2_sum3_f32(a.data_ptr(), b.data_ptr(), _ptr(c), a.data_ptr(), a.numel(), _stream()), "ds2_sum3_f32")
     return a
 
 

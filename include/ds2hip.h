@@ -336,7 +336,7 @@ int ds2_adamw_gated_f32(float* p, const float* g, float* m, float* v, long long 
                         float weight_decay, int step, float grad_scale, const int* apply_flag, void* stream);
 int ds2_scale_f32(float* x, long long n, float s, void* stream);
 /* fp32 mode, conv2 on the bf16 matrix cores (three-term split products; engine.F32_CONV): r = x - float(bf16(x)) — the bf16 mode's cast / pack
- * entries applied to r give the "lo" operand — and out = a + b + c for the three partial results (out may alias a). */
+ * entries applied to r give the "lo" operand — and out = a + b + c for the partial results (out may alias a; c may be NULL: out = a + b). */
 int ds2_bf16_residual_f32(const float* x, float* r, long long n, void* stream);
 int ds2_sum3_f32(const float* a, const float* b, const float* c, float* out, long long n, void* stream);
 /* x[0..n) += v (int64): every BatchNorm's num_batches_tracked (torch.nn.BatchNorm*d.forward in training mode) in one launch */

@@ -498,6 +498,18 @@ def test_fp32_mode_conv2_split_products_vs_fp64(B, D1, T):
     assert rel(one, ref) > 10 * rel(y, ref)                 # the single bf16 product is what the split improves on
     f32 = ops.conv2_fwd(a, ops.conv_pack(torch.zeros(32, 1, 41, 11, device="cuda"), w)[1], bias, lens)
     assert rel(f32, ref) < 2e-5
+    # the FORWARD's form (engine.F32_CONV_FWD = split6): three pieces per operand, six products — fp32-grade, like the fp32-input MFMA kernel
+    r2 = ops.bf16_residual(r)
+    assert torch.equal(a, a.bfloat16().float() + (r.bfloat16().float() + r2))          # h + m + (what l rounds) is exactly a
+    wr = ops.bf16_residual(w)
+    am, al2 = ops.nhwc_bf16(r), ops.nhwc_bf16(r2)
+    wm, wl2 = ops.conv2_pack_bf16(wr)[0], ops.conv2_pack_bf16(ops.bf16_residual(wr))[0]
+    y6 = ops.conv2_fwd_bf16(am, wm, zb, lens)
+    ops.sum3_(y6, ops.conv2_fwd_bf16(an, wl2, zb, lens), ops.conv2_fwd_bf16(al2, ph[0], zb, lens))
+    ops.sum3_(y6, ops.conv2_fwd_bf16(an, wm, zb, lens), ops.conv2_fwd_bf16(am, ph[0], zb, lens))
+    y6 = ops.sum3_(ops.conv2_fwd_bf16(an, ph[0], bias, lens), y6)
+    print(f"\nconv2 forward vs fp64: six-term split {rel(y6, ref):.2e}, three-term {rel(y, ref):.2e}, fp32-input MFMA {rel(f32, ref):.2e}, one bf16 product {rel(one, ref):.2e}")
+    assert rel(y6, ref) < max(3 * rel(f32, ref), 3e-7), (rel(y6, ref), rel(f32, ref))
     # backward: dy masked like the BatchNorm backward leaves it
     dy = (torch.randn_like(ref.float()) * keep).contiguous()
     rd = ops.bf16_residual(dy)
