@@ -57,6 +57,10 @@ FUSE_BN_BWD = _os.environ.get("DS2_FUSE_BN_BWD", "1") != "0"
 #   "main"         the same grouped kernel on the compute stream right behind the layer's critical-path work (the one-stream schedule the
 #                  side-stream results are compared with bit for bit: tests/test_gpu_round4.py); +0.5 ms per step against "0"
 WGRAD_SIDE = _os.environ.get("DS2_WGRAD_SIDE", "sk")
+# "sk" only: run a layer's grouped launch on the side stream beside the NEXT layer's persistent backward recurrence when that recurrence leaves
+# at least DS2_WGRAD_IDLE_MIN_CUS compute units without a workgroup (B = 32 shapes: c2, c4); see _backward_rnn_deferred
+WGRAD_IDLE = _os.environ.get("DS2_WGRAD_IDLE", "1") != "0"
+WGRAD_IDLE_MIN_CUS = int(_os.environ.get("DS2_WGRAD_IDLE_MIN_CUS", "64"))
 # fp32 mode, the dense input-to-hidden products (forward projection, dXn, dW_ih, dW_hh) of layers large enough for the 256 x 256 kernels
 # (DS2_F32_GEMM): "split" (default) = every fp32 operand split into two bf16 terms (hi = bf16(x), lo = bf16(x - hi)) and the product taken
 # as hi.hi + hi.lo + lo.hi on the bf16 matrix cores with fp32 accumulation — ~1e-5 of the fp32 product (the 2^-18 lo.lo term is dropped),
@@ -97,6 +101,12 @@ def _f32_split_ok(M: int, N: int, K: int) -> bool:
 
 _BWD_PERSISTENT = {}      # (gates, H, B) -> did the last backward recurrence of this shape run as a persistent launch?
 _SIDE = {}
+
+
+def _idle_cus_beside_bwd_recurrence(device, B: int, H: int) -> int:
+    """compute units without a workgroup while a persistent backward recurrence runs: it is one workgroup per (direction, 16-row batch tile,
+    32-unit slice) (csrc/rnn_bwd_ksplit.h, rnn_bwd_persistent_kernel)"""
+    return torch.cuda.get_device_properties(device).multi_processor_count - 2 * ((B + 15) // 16) * ((H + 31) // 32)
 
 
 def _side_stream(device):
@@ -405,17 +415,14 @@ def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy, done, private: bo
                  (dgx_bf[0:M - B, G * H:G * H + rows], h_bf[B:M, H:2 * H], dwhh[1, :rows])]
         if G == 3:
             probs += [(dhn_bf[B:M, 0:H], h_bf[0:M - B, 0:H], dwhh[0, 2 * H:]), (dhn_bf[0:M - B, H:2 * H], h_bf[B:M, H:2 * H], dwhh[1, 2 * H:])]
-        if WGRAD_SIDE == "sk":
-            ops.gemm_bf16_tn_splitk_group(probs)
-            done(f"rnns.{l}")
-            return
+        launch = ops.gemm_bf16_tn_splitk_group if WGRAD_SIDE == "sk" else ops.gemm_bf16_tn_group
         if not on_side:
-            ops.gemm_bf16_tn_group(probs)
+            launch(probs)
             done(f"rnns.{l}")
             return
         with torch.cuda.stream(side):
             side.wait_event(start)
-            ops.gemm_bf16_tn_group(probs)
+            launch(probs)
             if not serial_buckets:
                 done(f"rnns.{l}")                                # (a reducer records its "gradients final" event on the current = side stream)
         if serial_buckets:                                       # the "serial" data-parallel schedule orders every collective INTO the compute stream
@@ -460,8 +467,19 @@ def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy, done, private: bo
     queued = None                                                # layer whose operand passes wait for the next recurrence launch
     queued_tn = None
     queued_side = None                                           # layer whose grouped weight-gradient launch waits for the next recurrence
+    queued_idle = None                                           # the same for the idle-CU schedule (DS2_WGRAD_IDLE)
     group_ok = WGRAD_SIDE != "0" and W[f"rnns.0.wih_cat"].shape[1] % 8 == 0
     side_ok = group_ok and WGRAD_SIDE == "1" and ops.wgrad_fits_beside_bwd_recurrence(G, H)
+    # "sk" + DS2_WGRAD_IDLE: a persistent backward recurrence is one workgroup per (direction, 16-row batch tile, 32-unit slice) — at B = 32
+    # that is 96 (H = 768) or 160 (H = 1280) of the 256 CUs.  The grouped split-K launch of the layer above then runs on the side stream BEHIND
+    # the recurrence launch: its 256 x 256 workgroups (2 x 256 registers per SIMD lane) cannot share a CU with a recurrence workgroup, so they
+    # take exactly the CUs the recurrence leaves idle — no CU's memory path is shared (what sank the co-resident kernel, DS2_WGRAD_SIDE=1)
+    # Measured (profiles/r04_wgrad_idle_ab.txt): c4 (LSTM 1280, 160 of 256 CUs in the recurrence) 55.6 -> 51.7 ms — the recurrence pays 3.93 ->
+    # 4.52 us per time step for 1.07 ms of hidden GEMM per layer; c2 (GRU 768, 96 CUs in the recurrence) 15.08 -> 15.07: with 160 CUs the GEMM
+    # is over in 0.4 ms and doubles the step time meanwhile — so only where the recurrence is the majority tenant (idle <= half the chip).
+    n_idle = _idle_cus_beside_bwd_recurrence(dev, B, H)
+    idle_ok = (group_ok and WGRAD_SIDE == "sk" and WGRAD_IDLE and T > 1
+               and WGRAD_IDLE_MIN_CUS <= n_idle <= torch.cuda.get_device_properties(dev).multi_processor_count // 2)
     for l in range(L - 1, -1, -1):
         lc = ctx.layers[l]
         if queued_side is not None:
@@ -476,6 +494,10 @@ def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy, done, private: bo
             start.record(main)
             pending = operand_passes(*queued, start)
             queued = None
+        start_idle = None
+        if queued_idle is not None:
+            start_idle = torch.cuda.Event()                      # the layer above's operands are final; the recurrence launch follows
+            start_idle.record(main)
         dgx_bf = torch.empty(lc.gshape if lc.rec is not None else lc.gx.shape, dtype=torch.bfloat16, device=dev)
         want_tn = lc.h_bf is not None
         dhn_bf = torch.empty(M, 2 * H, dtype=torch.bfloat16, device=dev) if (want_tn and G == 3) else None
@@ -487,6 +509,10 @@ def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy, done, private: bo
             ops.rnn_bwd(G, dy, lc.gx, lc.aux, lc.hbuf, lc.wpb, lens_dev, T, B, H, bf16=True, dgx_bf16=dgx_bf, gates_bf16=lc.rec, dhn_bf16=dhn_bf,
                         bias_part=bias_part)
         _BWD_PERSISTENT[shape_key] = bool(lib.ds2_rnn_last_path() & 2)
+        if queued_idle is not None:
+            # enqueued BEHIND the recurrence launch: the recurrence's workgroups are dispatched first, the GEMM's fill what is left
+            weight_gradients_group(*queued_idle, _BWD_PERSISTENT[shape_key], start_idle)
+            queued_idle = None
         tn = want_tn and _BWD_PERSISTENT[shape_key]              # (only a persistent launch writes d(hn) in bf16 and the bias sums)
         lc.rec = None
         if pending is not None:
@@ -508,6 +534,8 @@ def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy, done, private: bo
             ops.rnn_bias_grads(G, bias_part, Gr[f"rnns.{l}.bih_cat"], Gr[f"rnns.{l}.bhh_cat"])
             if side_ok:
                 queued_side = queued_tn[:5]                      # released with the next layer's recurrence launch (layer 0: below)
+            elif idle_ok and l > 0:
+                queued_idle = queued_tn[:5]                      # launched behind the next layer's recurrence launch, on the CUs it leaves idle
             else:
                 weight_gradients_group(*queued_tn[:5], False, None)
             queued_tn = None
@@ -538,7 +566,14 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
     # Weight gradients (dW_ih, dW_hh and their casts) are not on the critical path of backward: they run on a side
     # stream and fill the CUs the latency-bound recurrent step kernels of the NEXT layer leave idle.
     main = torch.cuda.current_stream()
-    side = _side_stream(dlogits.device) if OVERLAP_WGRAD else main
+    # fp32 mode (this function's own loop): the same side stream when the backward recurrences of this shape run as persistent launches that
+    # leave >= DS2_WGRAD_IDLE_MIN_CUS compute units without a workgroup (c2: 96 of 256 used) — the split-bf16 weight-gradient launch of a layer
+    # then runs beside the next layer's recurrence on those CUs: c2 f32 33.9 -> 32.6 ms (the recurrence pays 3.40 -> 3.75 us per time step,
+    # profiles/r04_wgrad_idle_ab.txt).  What the library did for the shape is known from the previous step (first step: one stream).
+    f32_key = (G, H, ctx.B, "f32")
+    idle_f32 = (cfg.precision != "bf16" and WGRAD_IDLE and _BWD_PERSISTENT.get(f32_key, False)
+                and _idle_cus_beside_bwd_recurrence(dlogits.device, ctx.B, H) >= WGRAD_IDLE_MIN_CUS)
+    side = _side_stream(dlogits.device) if (OVERLAP_WGRAD or idle_f32) else main
     keep = []      # tensors used on the side stream must outlive it (caching-allocator reuse is per stream)
     B, T, D1, D2 = ctx.B, ctx.T, ctx.D1, ctx.D2
     M = T * B
@@ -573,6 +608,8 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
         dgx_bf = torch.empty(gshape, dtype=torch.bfloat16, device=dy.device) if bfd else None
         rmode = 1 if bf else (2 if (F32_RNN == "split" and H % 32 == 0) else 0)          # (the mode lc.wpb was packed for in forward)
         ops.rnn_bwd(G, dy, lc.gx, lc.aux, lc.hbuf, lc.wpb, lens_dev, T, B, H, bf16=rmode, dgx_bf16=dgx_bf, gates_bf16=lc.rec)
+        if not bf:
+            _BWD_PERSISTENT[f32_key] = bool(ops.rnn_last_path() & 2)
         lc.rec = None
         dgx = dgx_bf if bfd else lc.gx                                                            # dGx (M, 2GH)
         # ---- critical path: dXn = dGx W_ih (feeds the next layer's backward) ---------------------------------------

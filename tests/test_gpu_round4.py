@@ -582,3 +582,57 @@ def test_fp32_mode_split_conv_step_matches_fp32_mfma_conv_step():
     assert len(ds) >= 4
     for k, d in ds.items():
         assert d < 1e-4, (k, d)
+
+
+def test_weight_gradients_beside_a_recurrence_that_leaves_cus_idle_are_bit_identical():
+    """DS2_WGRAD_IDLE: where a persistent backward recurrence leaves >= 64 CUs without a workgroup, the layer above's grouped split-K launch
+    runs on the side stream beside it (bf16: behind the recurrence launch, when the recurrence holds at least half the chip; fp32 mode: the
+    whole off-critical-path block, from the second step of a shape on).  Same kernels, same operands, same split factors: every gradient is
+    bit-identical to the one-stream schedule, twice (a race would have two chances), and no persistent launch starves."""
+    from asr_amd import engine, ops
+    sys.path.insert(0, ROOT)
+    import bench
+    from test_gpu_model import make_model
+    from asr_amd.trainers.deepspeech_trainer import _prep_targets_host
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+
+    def run(precision, cfg, B, tin, idle, steps):
+        old = engine.WGRAD_IDLE
+        engine.WGRAD_IDLE = idle
+        engine._BWD_PERSISTENT.clear()
+        try:
+            torch.manual_seed(3)
+            model = make_model(cfg)
+            model.precision = precision
+            x, targets, pct, tsz = bench.synthetic_batch(B, tin, cfg["classes"], 1)
+            x = x.cuda()
+            model._ensure_flat(x.device)
+            out = []
+            for _ in range(steps):
+                with torch.no_grad():
+                    W, Gr = model._flat.tensors(model), model._flat.tensors(model, grads=True)
+                    out_sizes = model.get_seq_lens((pct * tin).int())
+                    t_h, off_h, tl_h, max_u = _prep_targets_host(targets, tsz)
+                    lens_dev, tg, off, tl = out_sizes.to(torch.int32).cuda(), t_h.cuda(), off_h.cuda(), tl_h.cuda()
+                    logits, ctx = engine.forward(W, model._cfg, x, lens_dev, training=True, save=True)
+                    nll, dlogits = ops.ctc_loss(logits, tg, off, lens_dev, tl, max_u, 1.0 / B, want_grad=True)
+                    engine.backward(W, Gr, model._cfg, ctx, dlogits)
+                    torch.cuda.synchronize()
+                    out.append((model.flat_parameters()[1].clone(), ops.rnn_last_path(), bool(getattr(ctx, "side_used", False))))
+            ops.rnn_persistent_check()
+            return out
+        finally:
+            engine.WGRAD_IDLE = old
+
+    # bf16, 3 x 1024 GRU, B = 48: 2 x 3 x 32 = 192 workgroups in the recurrence, 64 CUs idle
+    cfg = dict(rnn="gru", hidden=1024, layers=3, classes=29)
+    if 64 <= engine._idle_cus_beside_bwd_recurrence(torch.device("cuda:0"), 48, 1024) <= cus // 2:
+        on, on2, off = run("bf16", cfg, 48, 241, True, 1), run("bf16", cfg, 48, 241, True, 1), run("bf16", cfg, 48, 241, False, 1)
+        assert on[0][1] & 6 == 6 and on[0][2] and not off[0][2], (on[0][1:], off[0][1:])       # K-split persistent backward; side stream used only when on
+        assert torch.equal(on[0][0], off[0][0]) and torch.equal(on2[0][0], off[0][0])
+    # fp32 mode, 2 x 768 GRU, B = 32 (c2's layer shape: 96 workgroups): the side stream from the second step on
+    cfg = dict(rnn="gru", hidden=768, layers=2, classes=29)
+    on, off = run("fp32", cfg, 32, 161, True, 3), run("fp32", cfg, 32, 161, False, 3)
+    assert on[1][1] & 2, on[1][1]                                                              # persistent (split) backward recurrence
+    for a, b in zip(on, off):
+        assert torch.equal(a[0], b[0])
