@@ -597,6 +597,8 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
         first_layer = -1          # the loop below has nothing left to do
     else:
         first_layer = L - 1
+    defer = idle_f32 and not OVERLAP_WGRAD
+    pending_off = None
     for l in range(first_layer, -1, -1):
         lc = ctx.layers[l]
         bf = cfg.precision == "bf16"
@@ -610,10 +612,16 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
         ops.rnn_bwd(G, dy, lc.gx, lc.aux, lc.hbuf, lc.wpb, lens_dev, T, B, H, bf16=rmode, dgx_bf16=dgx_bf, gates_bf16=lc.rec)
         if not bf:
             _BWD_PERSISTENT[f32_key] = bool(ops.rnn_last_path() & 2)
+        if pending_off is not None:
+            fn, ev, pl = pending_off
+            pending_off = None
+            fn(after=ev)
+            with torch.cuda.stream(side):
+                done(f"rnns.{pl}")
         lc.rec = None
         dgx = dgx_bf if bfd else lc.gx                                                            # dGx (M, 2GH)
         # ---- critical path: dXn = dGx W_ih (feeds the next layer's backward) ---------------------------------------
-        dgxT = None
+        dgxT = dgs = dbih_sum = None
         if bfd:
             dxn = ops.gemm_bf16_nt(dgx_bf, ops.cast_transpose_bf16(W[f"rnns.{l}.wih_cat"]))
             # dW = dGx^T [Xn | h] needs the transposed copy; the same read gives db_ih = column sums of dGx
@@ -631,106 +639,121 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
         else:
             dxn = ops.gemm(dgx, W[f"rnns.{l}.wih_cat"])                                           # (M, I)
         # ---- off the critical path: bias and weight gradients ------------------------------------------------------
-        side.wait_stream(main)
-        keep.append((dgx, lc.aux, lc.hbuf, lc.xn))
-        with torch.cuda.stream(side):
-            dbih = Gr[f"rnns.{l}.bih_cat"]
-            if not bfd:
-                dbih.copy_(dbih_sum if bf else ops.colsum(dgx))
-            dbhh = Gr[f"rnns.{l}.bhh_cat"]                                                        # (2, GH)
-            dbhh.copy_(dbih.view(2, G * H))
-            auxT = None
-            if G == 3 and T > 1 and bfd:
-                # d(b_hn) = column sums of d(hn): taken from the read that produces the transposed bf16 copy for dW_hh below
-                dbn = torch.empty(2 * H, dtype=torch.float32, device=dy.device)
-                auxT = ops.cast_transpose_bf16(lc.aux, colsum=dbn)
-                dbhh[:, 2 * H:] = dbn.view(2, H)
-            elif G == 3:
-                dbhh[:, 2 * H:] = ops.colsum(lc.aux).view(2, H)
-            # dW_hh[dir] = sum_t dGh[t]^T h_prev[t]  (h_prev = h[t-1] fwd / h[t+1] reverse)
-            dwhh = Gr[f"rnns.{l}.whh_cat"]                                                        # (2, GH, H)
-            if T > 1 and bfd:
-                # bf16 MFMA path: transposed bf16 copies (dgxT: (2GH, M)), the time shift is a column offset of B elements
-                hT = ops.cast_transpose_bf16(lc.hbuf)                                             # (2H, M)
-                rows = 2 * H if G == 3 else 4 * H
-                # both directions per launch: direction 0 pairs rows t of dGh with h[t-1], direction 1 rows t with h[t+1]
-                ka = (slice(B, M), slice(0, M - B))
-                kb = (slice(0, M - B), slice(B, M))
-                ops.gemm_bf16_nt_pair(dgxT[0:rows, ka[0]], dgxT[G * H:G * H + rows, ka[1]], hT[0:H, kb[0]], hT[H:2 * H, kb[1]], dwhh[:, :rows])
-                if G == 3:
-                    ops.gemm_bf16_nt_pair(auxT[0:H, ka[0]], auxT[H:2 * H, ka[1]], hT[0:H, kb[0]], hT[H:2 * H, kb[1]], dwhh[:, 2 * H:])
-                keep.append((dgxT, hT, auxT))
-            elif T > 1 and split:
-                # every product = three terms (hi.hi, hi.lo, lo.hi) on row-pitched views of the split copies; ALL terms of ALL products of the
-                # layer (dW_hh of both directions, a GRU's n rows, dW_ih) in ONE grouped split-K launch + one reduce (terms of a product
-                # name the same output and are summed: ds2_gemm_bf16_tn_splitk_group)
-                C2, Iw = 2 * G * H, W[f"rnns.{l}.wih_cat"].shape[1]
-                Ip = lc.xs.shape[1] // 3
-                hs = ops.split_bf16(lc.hbuf, 2)                                                   # (M, 4H) = [hi | lo]
-                d_hi, d_lo, h_hi, h_lo = dgs[:, :C2], dgs[:, 2 * C2:], hs[:, :2 * H], hs[:, 2 * H:]
-                rows = 2 * H if G == 3 else 4 * H
-                ra, rb = (slice(B, M), slice(0, M - B)), (slice(0, M - B), slice(B, M))
-                probs = []
-                for d in (0, 1):
-                    for a, b in ((d_hi, h_hi), (d_hi, h_lo), (d_lo, h_hi)):
-                        probs.append((a[ra[d], d * G * H:d * G * H + rows], b[rb[d], d * H:(d + 1) * H], dwhh[d, :rows]))
-                if G == 3:                                                                        # n-gate rows use d(hn) (aux) instead of dGx_n
-                    axs = ops.split_bf16(lc.aux, 2)                                               # (M, 4H)
-                    a_hi, a_lo = axs[:, :2 * H], axs[:, 2 * H:]
+        def off_path(l=l, lc=lc, dgx=dgx, dgs=dgs, dgxT=dgxT, dbih_sum=dbih_sum, bf=bf, bfd=bfd, split=split, after=None):
+            if after is not None:
+                side.wait_event(after)
+            else:
+                side.wait_stream(main)
+            keep.append((dgx, lc.aux, lc.hbuf, lc.xn))
+            with torch.cuda.stream(side):
+                dbih = Gr[f"rnns.{l}.bih_cat"]
+                if not bfd:
+                    dbih.copy_(dbih_sum if bf else ops.colsum(dgx))
+                dbhh = Gr[f"rnns.{l}.bhh_cat"]                                                        # (2, GH)
+                dbhh.copy_(dbih.view(2, G * H))
+                auxT = None
+                if G == 3 and T > 1 and bfd:
+                    # d(b_hn) = column sums of d(hn): taken from the read that produces the transposed bf16 copy for dW_hh below
+                    dbn = torch.empty(2 * H, dtype=torch.float32, device=dgx.device)
+                    auxT = ops.cast_transpose_bf16(lc.aux, colsum=dbn)
+                    dbhh[:, 2 * H:] = dbn.view(2, H)
+                elif G == 3:
+                    dbhh[:, 2 * H:] = ops.colsum(lc.aux).view(2, H)
+                # dW_hh[dir] = sum_t dGh[t]^T h_prev[t]  (h_prev = h[t-1] fwd / h[t+1] reverse)
+                dwhh = Gr[f"rnns.{l}.whh_cat"]                                                        # (2, GH, H)
+                if T > 1 and bfd:
+                    # bf16 MFMA path: transposed bf16 copies (dgxT: (2GH, M)), the time shift is a column offset of B elements
+                    hT = ops.cast_transpose_bf16(lc.hbuf)                                             # (2H, M)
+                    rows = 2 * H if G == 3 else 4 * H
+                    # both directions per launch: direction 0 pairs rows t of dGh with h[t-1], direction 1 rows t with h[t+1]
+                    ka = (slice(B, M), slice(0, M - B))
+                    kb = (slice(0, M - B), slice(B, M))
+                    ops.gemm_bf16_nt_pair(dgxT[0:rows, ka[0]], dgxT[G * H:G * H + rows, ka[1]], hT[0:H, kb[0]], hT[H:2 * H, kb[1]], dwhh[:, :rows])
+                    if G == 3:
+                        ops.gemm_bf16_nt_pair(auxT[0:H, ka[0]], auxT[H:2 * H, ka[1]], hT[0:H, kb[0]], hT[H:2 * H, kb[1]], dwhh[:, 2 * H:])
+                    keep.append((dgxT, hT, auxT))
+                elif T > 1 and split:
+                    # every product = three terms (hi.hi, hi.lo, lo.hi) on row-pitched views of the split copies; ALL terms of ALL products of the
+                    # layer (dW_hh of both directions, a GRU's n rows, dW_ih) in ONE grouped split-K launch + one reduce (terms of a product
+                    # name the same output and are summed: ds2_gemm_bf16_tn_splitk_group)
+                    C2, Iw = 2 * G * H, W[f"rnns.{l}.wih_cat"].shape[1]
+                    Ip = lc.xs.shape[1] // 3
+                    hs = ops.split_bf16(lc.hbuf, 2)                                                   # (M, 4H) = [hi | lo]
+                    d_hi, d_lo, h_hi, h_lo = dgs[:, :C2], dgs[:, 2 * C2:], hs[:, :2 * H], hs[:, 2 * H:]
+                    rows = 2 * H if G == 3 else 4 * H
+                    ra, rb = (slice(B, M), slice(0, M - B)), (slice(0, M - B), slice(B, M))
+                    probs = []
                     for d in (0, 1):
-                        for a, b in ((a_hi, h_hi), (a_hi, h_lo), (a_lo, h_hi)):
-                            probs.append((a[ra[d], d * H:(d + 1) * H], b[rb[d], d * H:(d + 1) * H], dwhh[d, 2 * H:]))
-                    keep.append((axs,))
-                x_hi, x_lo = lc.xs[:, :Iw], lc.xs[:, 2 * Ip:2 * Ip + Iw]
-                for a, b in ((d_hi, x_hi), (d_hi, x_lo), (d_lo, x_hi)):
-                    probs.append((a, b, Gr[f"rnns.{l}.wih_cat"]))
-                if len(probs) <= 16 and Iw % 8 == 0:
-                    ops.gemm_bf16_tn_splitk_group(probs)
-                else:                                                                             # (never at the reference's shapes) term by term
-                    seen = set()
-                    for a, b, o in probs:
-                        ops.gemm_bf16_tn(a, b, out=o, accumulate=o.data_ptr() in seen)
-                        seen.add(o.data_ptr())
-                keep.append((hs, dgs, lc.xs))
-            elif T > 1:
-                K = (T - 1) * B
-                ldg, ldh = 2 * G * H, 2 * H
-                a0 = dgx.data_ptr() + 4 * (B * ldg)                 # dir 0: rows t >= 1
-                b0 = lc.hbuf.data_ptr()                             #        h[t-1]
-                a1 = dgx.data_ptr() + 4 * (G * H)                   # dir 1: rows t <= T-2, column block of dir 1
-                b1 = lc.hbuf.data_ptr() + 4 * (H + B * ldh)         #        h[t+1]
-                sA, sB = (a1 - a0) // 4, (b1 - b0) // 4
-                rows = 2 * H if G == 3 else 4 * H
-                ops.gemm_raw(True, False, rows, H, K, a0, ldg, sA, b0, ldh, sB, dwhh.data_ptr(), H, G * H * H, dgx.device, batch=2)
-                if G == 3:  # n-gate rows use d(hn) (aux) instead of dGx_n
-                    x0 = lc.aux.data_ptr() + 4 * (B * ldh)
-                    x1 = lc.aux.data_ptr() + 4 * H
-                    ops.gemm_raw(True, False, H, H, K, x0, ldh, (x1 - x0) // 4, b0, ldh, sB, dwhh.data_ptr() + 4 * (2 * H * H), H,
-                                 G * H * H, dgx.device, batch=2)
-            else:
-                dwhh.zero_()
-            # dW_ih (2GH, I) = dGx^T Xn
-            if bf:
-                xnT = ops.transpose_bf16(lc.xn[:, :W[f"rnns.{l}.wih_cat"].shape[1]])              # lc.xn is bf16 (M, pad8(I)) in this mode
-                ops.gemm_bf16_nt(dgxT, xnT, out=Gr[f"rnns.{l}.wih_cat"])
-                keep.append((dgxT, xnT))
-            elif split and T > 1:
-                pass                                                                              # (dW_ih went out with the grouped launch above)
-            elif split:
-                C2, I = 2 * G * H, W[f"rnns.{l}.wih_cat"].shape[1]
-                Ip = lc.xs.shape[1] // 3
-                for k, (a, b) in enumerate(((dgs[:, :C2], lc.xs[:, :I]), (dgs[:, :C2], lc.xs[:, 2 * Ip:2 * Ip + I]), (dgs[:, 2 * C2:], lc.xs[:, :I]))):
-                    ops.gemm_bf16_tn(a, b, out=Gr[f"rnns.{l}.wih_cat"], accumulate=k > 0)
-                keep.append((dgs, lc.xs))
-            else:
-                ops.gemm(dgx, lc.xn, transA=True, out=Gr[f"rnns.{l}.wih_cat"])
-        lc.gx = lc.aux = lc.hbuf = lc.xn = lc.wpb = lc.xs = None
+                        for a, b in ((d_hi, h_hi), (d_hi, h_lo), (d_lo, h_hi)):
+                            probs.append((a[ra[d], d * G * H:d * G * H + rows], b[rb[d], d * H:(d + 1) * H], dwhh[d, :rows]))
+                    if G == 3:                                                                        # n-gate rows use d(hn) (aux) instead of dGx_n
+                        axs = ops.split_bf16(lc.aux, 2)                                               # (M, 4H)
+                        a_hi, a_lo = axs[:, :2 * H], axs[:, 2 * H:]
+                        for d in (0, 1):
+                            for a, b in ((a_hi, h_hi), (a_hi, h_lo), (a_lo, h_hi)):
+                                probs.append((a[ra[d], d * H:(d + 1) * H], b[rb[d], d * H:(d + 1) * H], dwhh[d, 2 * H:]))
+                        keep.append((axs,))
+                    x_hi, x_lo = lc.xs[:, :Iw], lc.xs[:, 2 * Ip:2 * Ip + Iw]
+                    for a, b in ((d_hi, x_hi), (d_hi, x_lo), (d_lo, x_hi)):
+                        probs.append((a, b, Gr[f"rnns.{l}.wih_cat"]))
+                    if len(probs) <= 16 and Iw % 8 == 0:
+                        ops.gemm_bf16_tn_splitk_group(probs)
+                    else:                                                                             # (never at the reference's shapes) term by term
+                        seen = set()
+                        for a, b, o in probs:
+                            ops.gemm_bf16_tn(a, b, out=o, accumulate=o.data_ptr() in seen)
+                            seen.add(o.data_ptr())
+                    keep.append((hs, dgs, lc.xs))
+                elif T > 1:
+                    K = (T - 1) * B
+                    ldg, ldh = 2 * G * H, 2 * H
+                    a0 = dgx.data_ptr() + 4 * (B * ldg)                 # dir 0: rows t >= 1
+                    b0 = lc.hbuf.data_ptr()                             #        h[t-1]
+                    a1 = dgx.data_ptr() + 4 * (G * H)                   # dir 1: rows t <= T-2, column block of dir 1
+                    b1 = lc.hbuf.data_ptr() + 4 * (H + B * ldh)         #        h[t+1]
+                    sA, sB = (a1 - a0) // 4, (b1 - b0) // 4
+                    rows = 2 * H if G == 3 else 4 * H
+                    ops.gemm_raw(True, False, rows, H, K, a0, ldg, sA, b0, ldh, sB, dwhh.data_ptr(), H, G * H * H, dgx.device, batch=2)
+                    if G == 3:  # n-gate rows use d(hn) (aux) instead of dGx_n
+                        x0 = lc.aux.data_ptr() + 4 * (B * ldh)
+                        x1 = lc.aux.data_ptr() + 4 * H
+                        ops.gemm_raw(True, False, H, H, K, x0, ldh, (x1 - x0) // 4, b0, ldh, sB, dwhh.data_ptr() + 4 * (2 * H * H), H,
+                                     G * H * H, dgx.device, batch=2)
+                else:
+                    dwhh.zero_()
+                # dW_ih (2GH, I) = dGx^T Xn
+                if bf:
+                    xnT = ops.transpose_bf16(lc.xn[:, :W[f"rnns.{l}.wih_cat"].shape[1]])              # lc.xn is bf16 (M, pad8(I)) in this mode
+                    ops.gemm_bf16_nt(dgxT, xnT, out=Gr[f"rnns.{l}.wih_cat"])
+                    keep.append((dgxT, xnT))
+                elif split and T > 1:
+                    pass                                                                              # (dW_ih went out with the grouped launch above)
+                elif split:
+                    C2, I = 2 * G * H, W[f"rnns.{l}.wih_cat"].shape[1]
+                    Ip = lc.xs.shape[1] // 3
+                    for k, (a, b) in enumerate(((dgs[:, :C2], lc.xs[:, :I]), (dgs[:, :C2], lc.xs[:, 2 * Ip:2 * Ip + I]), (dgs[:, 2 * C2:], lc.xs[:, :I]))):
+                        ops.gemm_bf16_tn(a, b, out=Gr[f"rnns.{l}.wih_cat"], accumulate=k > 0)
+                    keep.append((dgs, lc.xs))
+                else:
+                    ops.gemm(dgx, lc.xn, transA=True, out=Gr[f"rnns.{l}.wih_cat"])
+            lc.gx = lc.aux = lc.hbuf = lc.xn = lc.wpb = lc.xs = None
+        if not defer:
+            off_path()
         if l > 0:
             bp = f"rnns.{l}.batch_norm.module."
             dy = ops.bn1d_bwd(dxn, lc.xin, lc.mean, lc.var, W[bp + "weight"], Gr[bp + "weight"], Gr[bp + "bias"])
         else:
             dy = dxn
         del dxn
+        if defer and l > 0:
+            # launched behind the NEXT layer's recurrence launch (the loop's top): dispatched first, the GEMM's 256 x 256 workgroups would hold
+            # every CU for their first round and the recurrence would wait for them
+            ev = torch.cuda.Event()
+            ev.record(main)                 # the layer's operands and its BatchNorm gradients are final
+            pending_off = (off_path, ev, l)
+            continue
+        if defer:
+            off_path()
         if side is not main:
             side.wait_stream(main)          # the bucket also holds this layer's BN grads (main stream)
         with torch.cuda.stream(side):
