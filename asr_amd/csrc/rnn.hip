@@ -1579,6 +1579,7 @@ __device__ __forceinline__ void store16_base(const char* base, unsigned off, u32
 }
 
 #include "rnn_bwd_ksplit.h"
+#include "rnn_fwd_u10.h"
 
 template <int G, bool BF>
 int launch_steps(bool bwd, RnnArgs a, hipStream_t st) {
@@ -1634,7 +1635,10 @@ int dispatch(int gates, bool bwd, const RnnArgs& a, hipStream_t st) {
 // bf16 = 2 (fp32 mode with the split recurrences): each operand = [fp32 fragments | bf16 hi fragments | bf16 lo fragments]
 extern "C" size_t ds2_rnn_packed_bytes(int gates, int H, int which, int bf16) {
   const size_t nsl = (size_t)ceil_div(H, 16);
-  if (bf16 == 2) return ds2_rnn_packed_bytes(gates, H, which, 0) + 2 * ds2_rnn_packed_bytes(gates, H, which, 1);
+  // bf16 = 2 (fp32 mode, split recurrences): [fp32 | hi | lo] and, forward operand of shapes the 10-unit-slice kernel exists for, [u10 hi | u10 lo]
+  if (bf16 == 2)
+    return ds2_rnn_packed_bytes(gates, H, which, 0) + 2 * ds2_rnn_packed_bytes(gates, H, which, 1) +
+           ((which == 0 && u10_shape_ok(H)) ? 2 * u10_plane_bytes(gates, H) : 0);
   const int kc = bf16 ? 32 : 16;
   return (which == 0 ? 2 * nsl * gates * ceil_div(H, kc) : 2 * nsl * ceil_div(gates * H, kc)) * 1024;
 }
@@ -1652,6 +1656,11 @@ extern "C" int ds2_rnn_pack_whh(int gates, const float* whh, void* wp_fwd, void*
     hipLaunchKernelGGL(rnn_pack_split_fwd_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, whh, (void*)hi,
                        (void*)(hi + ds2_rnn_packed_bytes(gates, H, 0, 1)), gates, H);
     DS2_LAUNCH_CHECK("rnn_pack_split_fwd_kernel");
+    if (u10_shape_ok(H)) {                                       // + the 10-unit-slice operand (rnn_fwd_u10.h) behind those
+      char* uh = hi + 2 * ds2_rnn_packed_bytes(gates, H, 0, 1);
+      hipLaunchKernelGGL(rnn_pack_u10_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, whh, (void*)uh, (void*)(uh + u10_plane_bytes(gates, H)), gates, H);
+      DS2_LAUNCH_CHECK("rnn_pack_u10_kernel");
+    }
     char* bh = (char*)wp_bwd + ds2_rnn_packed_bytes(gates, H, 1, 0);
     hipLaunchKernelGGL(rnn_pack_split_bwd_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, whh, (void*)bh,
                        (void*)(bh + ds2_rnn_packed_bytes(gates, H, 1, 1)), gates, H);
@@ -1722,12 +1731,22 @@ extern "C" int ds2_rnn_fwd_ex(int gates, float* gx, const void* wp_fwd, const fl
       if (g_persist_cooldown == 0 && g_persist_fwd && !(env && env[0] == 'f') && !a.gates_bf) {
         RnnArgs b = a;
         b.wp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(wp_fwd) + ds2_rnn_packed_bytes(gates, H, 0, 0));
-        rc = gates == 3 ? try_launch_persistent_fwd<3, true, true>(b, st) : try_launch_persistent_fwd<4, true, true>(b, st);
-        if (rc == 1) g_last_path |= 32;                             // bit 5: the split kernel took the call
+        b.dbg &= ~256;
+        g_last_path &= ~256;
+        if (!(a.dbg & 256))                                         // (debug flag 256: prefer the 10-unit kernel where its shape qualifies)
+          rc = gates == 3 ? try_launch_persistent_fwd<3, true, true>(b, st) : try_launch_persistent_fwd<4, true, true>(b, st);
+        if (rc == 0 && u10_shape_ok(H)) {
+          // the 16-unit split kernel does not fit (LSTM H = 1280 at B = 32: BASELINE C4): ten-unit slices, rnn_fwd_u10.h
+          b.wp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(wp_fwd) + ds2_rnn_packed_bytes(gates, H, 0, 0) +
+                                                2 * ds2_rnn_packed_bytes(gates, H, 0, 1));
+          rc = gates == 3 ? try_launch_fwd_u10<3>(b, st) : try_launch_fwd_u10<4>(b, st);
+          if (rc == 1) g_last_path |= 256;                          // bit 8: the 10-unit kernel
+        }
+        if (rc == 1) g_last_path |= 32;                             // bit 5: a split kernel took the call
       }
-      if (rc == 0) { g_last_path &= ~32; rc = gates == 3 ? try_launch_persistent_fwd<3, false>(a, st) : try_launch_persistent_fwd<4, false>(a, st); }
+      if (rc == 0) { g_last_path &= ~32; a.dbg &= ~256; rc = gates == 3 ? try_launch_persistent_fwd<3, false>(a, st) : try_launch_persistent_fwd<4, false>(a, st); }
     } else {
-      g_last_path &= ~32;
+      g_last_path &= ~(32 | 256);
       rc = bf16 ? (gates == 3 ? try_launch_persistent_fwd<3, true>(a, st) : try_launch_persistent_fwd<4, true>(a, st))
                 : (gates == 3 ? try_launch_persistent_fwd<3, false>(a, st) : try_launch_persistent_fwd<4, false>(a, st));
     }

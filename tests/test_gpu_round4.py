@@ -350,7 +350,8 @@ def test_split_forward_recurrence_vs_fp64_and_fp32_kernels(kind, H, B, T):
     """fp32 mode, DS2_F32_RNN=split: the persistent forward recurrence with h_t and W_hh as hi + lo bf16 planes (three bf16 MFMAs per product)
     against the fp64 recurrence (oracle.gru_direction / lstm_direction, blocks.py:87-89) and against the fp32-MFMA kernels on ragged lengths:
     h, the saved gates and aux within 2e-5 of fp64 (the fp32 kernels: ~1e-6; the plain bf16 kernel: 3e-3), zeros beyond every length,
-    reruns bit-identical.  LSTM H = 1280 does not fit the split kernel (registers): the library takes the fp32 kernels by itself."""
+    reruns bit-identical.  LSTM H = 1280 at B = 32 does not fit the 16-unit split kernel (registers): the library takes the 10-unit-slice
+    split kernel (csrc/rnn_fwd_u10.h, rnn_last_path bit 8) by itself."""
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import det
     from oracle import ds2_oracle as O
@@ -378,8 +379,8 @@ def test_split_forward_recurrence_vs_fp64_and_fp32_kernels(kind, H, B, T):
             hb2, _ = ops.rnn_fwd(G, gx2, wpf, bhh.float().to(dev), ld, T, B, H, bf16=2)
             assert torch.equal(hb2, hb) and torch.equal(gx2, gxd), "reruns differ"
     ops.rnn_persistent_check()
-    fits = not (kind == "lstm" and H == 1280)
-    assert bool(outs[2][2] & 32) == fits, outs[2][2]
+    fits = True
+    assert outs[2][2] & 32 and bool(outs[2][2] & 256) == (kind == "lstm" and H == 1280), outs[2][2]
     err = {m: float((outs[m][0] - ref).norm() / ref.norm()) for m in outs}
     print(f"{kind} H={H} B={B} T={T}: h vs fp64: split {err[2]:.2e}  fp32 kernels {err[0]:.2e}  bf16 kernels {err[1]:.2e}  (split kernel took the call: {fits})")
     assert err[2] < 2e-5 and err[0] < 2e-5 and err[1] > 10 * err[2]
@@ -636,3 +637,54 @@ def test_weight_gradients_beside_a_recurrence_that_leaves_cus_idle_are_bit_ident
     assert on[1][1] & 2, on[1][1]                                                              # persistent (split) backward recurrence
     for a, b in zip(on, off):
         assert torch.equal(a[0], b[0])
+
+
+@pytest.mark.parametrize("kind,H,B,T", [("lstm", 160, 32, 9), ("gru", 320, 16, 7), ("lstm", 640, 20, 6), ("lstm", 1280, 32, 5), ("lstm", 1280, 13, 4),
+                                        ("gru", 960, 32, 5)])
+def test_u10_split_forward_recurrence_vs_fp64_and_fp32_kernels(kind, H, B, T):
+    """csrc/rnn_fwd_u10.h: the split forward recurrence with TEN-unit hidden slices (G x 10 gate columns in 16-column MFMA tiles, h published
+    dword by dword, operand gathered plane by plane) — what lets BASELINE C4's LSTM (H = 1280, B = 32) run as one launch per layer in the fp32
+    mode.  Forced here on smaller shapes too (debug flag 256): h, the saved gates and the cell state / hn within 2e-5 of the fp64 recurrence
+    (blocks.py:87-89) and 5e-5 of the fp32 kernels' values, zeros beyond every length, reruns bit-identical, no starved launch."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import det
+    from oracle import ds2_oracle as O
+    from asr_amd import ops, _lib
+    G = 3 if kind == "gru" else 4
+    lens = sorted([int(v) for v in det.randint((B,), 61, max(1, T // 3), T + 1)], reverse=True)
+    lens[0] = T
+    lens_t = torch.tensor(lens, dtype=torch.int32)
+    k = 1.0 / H ** 0.5
+    gx = torch.from_numpy(det.uniform((T, B, 2, G * H), 62, -1.5, 1.5)).double()
+    whh = torch.from_numpy(det.uniform((2, G * H, H), 63, -k, k)).double()
+    bhh = torch.from_numpy(det.uniform((2, G * H), 64, -k, k)).double()
+    step = O.gru_direction if kind == "gru" else O.lstm_direction
+    ref = torch.stack([step(gx[:, :, 0], whh[0], bhh[0], lens_t, False), step(gx[:, :, 1], whh[1], bhh[1], lens_t, True)], 2)   # (T,B,2,H)
+    dev = torch.device("cuda:0")
+    ld = lens_t.to(dev)
+    wpf, _ = ops.rnn_pack(G, whh.float().to(dev), bf16=2)
+
+    def run(flags):
+        old = _lib.load().ds2_debug_flags(flags)
+        try:
+            gxd = gx.float().reshape(T * B, 2 * G * H).to(dev).clone()
+            hb, aux = ops.rnn_fwd(G, gxd, wpf, bhh.float().to(dev), ld, T, B, H, bf16=2)
+            torch.cuda.synchronize()
+            return hb.view(T, B, 2, H).clone(), gxd, aux.clone(), ops.rnn_last_path()
+        finally:
+            _lib.load().ds2_debug_flags(old)
+
+    u, u2 = run(256), run(256)
+    assert u[3] & 256 and u[3] & 32 and u[3] & 1, u[3]                      # the 10-unit kernel took the call
+    assert all(torch.equal(a, b) for a, b in zip(u[:3], u2[:3])), "reruns differ"
+    wpf0, _ = ops.rnn_pack(G, whh.float().to(dev), bf16=0)
+    g0 = gx.float().reshape(T * B, 2 * G * H).to(dev).clone()
+    h0, a0 = ops.rnn_fwd(G, g0, wpf0, bhh.float().to(dev), ld, T, B, H, bf16=0)
+    ops.rnn_persistent_check()
+    e_u = float((u[0].double().cpu() - ref).norm() / ref.norm())
+    e_0 = float((h0.view(T, B, 2, H).double().cpu() - ref).norm() / ref.norm())
+    print(f"{kind} H={H} B={B} T={T}: h vs fp64: 10-unit split {e_u:.2e}  fp32 kernels {e_0:.2e}")
+    assert e_u < 2e-5 and e_0 < 2e-5
+    assert float((u[1] - g0).abs().max()) < 5e-5 and float((u[2] - a0).abs().max()) < 5e-5       # saved gates, cell state / hn
+    tmask = torch.arange(T).view(T, 1) >= lens_t.view(1, B)
+    assert float(u[0].cpu()[tmask].abs().max()) == 0.0
