@@ -357,7 +357,7 @@ def quick_workload(workload, dtype, dev, steps, warmup):
             r = fn(*a, **k)
             e1.record()
             lp = ops.rnn_last_path()
-            calls[key].append((e0, e1, int(a[t_arg]), bool(lp & bit), bool(lp & 4), bool(lp & (32 if key == "fwd" else 64))))
+            calls[key].append((e0, e1, int(a[t_arg]), bool(lp & bit), bool(lp & 4), bool(lp & (32 if key == "fwd" else 64)), bool(lp & 256)))
             return r
         return w
     ops.rnn_fwd, ops.rnn_bwd, ops.rnn_bwd_bn = ev(orig[0], "fwd", 5, 1), ev(orig[1], "bwd", 7, 2), ev(orig[2], "bwd", 12, 2)
@@ -383,7 +383,9 @@ def quick_workload(workload, dtype, dev, steps, warmup):
         us = sum(q[0].elapsed_time(q[1]) for q in c) * 1e3
         tsteps = sum(q[2] for q in c)
         pers, ks, sp = all(q[3] for q in c), all(q[4] for q in c), dtype != "bf16" and all(q[5] for q in c)
-        kern[key] = {"kernel": "rnn_bwd_ksplit_kernel" if (key == "bwd" and pers and ks) else f"rnn_{key}_{'persistent' if pers else 'step'}_kernel",
+        u10 = key == "fwd" and pers and all(q[6] for q in c)
+        kern[key] = {"kernel": "rnn_bwd_ksplit_kernel" if (key == "bwd" and pers and ks) else ("rnn_fwd_u10_kernel" if u10 else
+                               f"rnn_{key}_{'persistent' if pers else 'step'}_kernel"),
                      "us_per_time_step": us / tsteps, "achieved_tflops": 2.0 * 2 * B * H * G * H * tsteps / (us * 1e-6) / 1e12,
                      "ms_per_step": us / 1e3 / steps, "peak": SPLIT_BF16_PEAK_TFLOPS if sp else peak, "split": sp}
         kern[key]["frac"] = kern[key]["achieved_tflops"] / kern[key]["peak"]
@@ -585,7 +587,8 @@ def main():
             e0.record()
             r = fn(*a, **k)
             e1.record()
-            rnn_calls[key].append((e0, e1, int(a[t_arg]), bool(ops.rnn_last_path() & bit), bool(ops.rnn_last_path() & 4), bool(ops.rnn_last_path() & 16), bool(ops.rnn_last_path() & (32 if key == "fwd" else 64))))
+            rnn_calls[key].append((e0, e1, int(a[t_arg]), bool(ops.rnn_last_path() & bit), bool(ops.rnn_last_path() & 4), bool(ops.rnn_last_path() & 16), bool(ops.rnn_last_path() & (32 if key == "fwd" else 64)),
+                                   bool(ops.rnn_last_path() & 256)))
             return r
         return wrapped
 
@@ -651,6 +654,7 @@ def main():
         path_bits = (1 if p_f else 0) | (2 if p_b else 0) | (4 if (p_b and ks_b) else 0)
         bn_fused = all(c[5] for c in rnn_calls["bwd"])       # BatchNorm1d backward applied inside the K-split kernel (ds2_rnn_bwd_bn)
         path_bits |= (32 if all(c[6] for c in rnn_calls["fwd"]) else 0) | (64 if all(c[6] for c in rnn_calls["bwd"]) else 0)   # fp32 mode: split kernels
+        path_bits |= 256 if all(c[7] for c in rnn_calls["fwd"]) else 0                                                         # ... the 10-unit-slice one
     else:
         # fallback (no recurrence call was seen in the timed region): one layer's recurrences stand-alone, same shape and mode
         gx = torch.randn(M, 2 * G * H, device=dev) * 0.5
@@ -712,7 +716,8 @@ def main():
     alg_bytes_step = (3 * 4 + 8 + 4 + 2 + (2 if tn else 0) if pack else 8 * 4 + (2 if bf else 4)) * B * 2 * H
     split_f, split_b = (not bf) and bool(path_bits & 32), (not bf) and bool(path_bits & 64)
     peak_f, peak_b = (SPLIT_BF16_PEAK_TFLOPS if split_f else peak), (SPLIT_BF16_PEAK_TFLOPS if split_b else peak)
-    roofline = {"kernel": "rnn_fwd_persistent_kernel" if persistent else "rnn_fwd_step_kernel", "bound": "mfma", "achieved": achieved,
+    roofline = {"kernel": ("rnn_fwd_u10_kernel" if (path_bits & 256) else "rnn_fwd_persistent_kernel") if persistent else "rnn_fwd_step_kernel",
+                "bound": "mfma", "achieved": achieved,
                 "peak": peak_f, "unit": "TFLOP/s", "frac": achieved / peak_f, "traffic": traffic,
                 **({"peak_note": SPLIT_PEAK_NOTE} if split_f else {}),
                 "algorithmic_hbm_bytes_per_launch": alg_bytes_step * (T if persistent else 1),

@@ -193,7 +193,8 @@ size_t ds2_rnn_packed_bytes(int gates, int H, int which /*0: forward operand, 1:
  * (once per optimizer step).  bf16 = 2 (here, in ds2_rnn_packed_bytes, ds2_rnn_fwd_workspace_bytes and ds2_rnn_fwd*): the fp32 mode with the
  * SPLIT persistent forward recurrence — h_t and W_hh each as two bf16 planes, x = bf16(x) + bf16(x - bf16(x)), product = hi.hi + lo.hi + hi.lo on
  * the bf16 matrix cores with fp32 accumulation (fp32-grade: ~1e-6 of the fp32 kernels, far inside north_star's 1e-3): the forward operand
- * is then [fp32 fragments | hi fragments | lo fragments] and the fp32 kernels remain the fallback (shape does not fit, cooldown). */
+ * is then [fp32 fragments | hi fragments | lo fragments (| the ten-unit-slice hi / lo operand of csrc/rnn_fwd_u10.h when H % 160 == 0, H <= 1280)]
+ * and the fp32 kernels remain the fallback (shape does not fit, cooldown). */
 int ds2_rnn_pack_whh(int gates, const float* whh, void* wp_fwd, void* wp_bwd, int H, int bf16, void* stream);
 /* Status of the persistent recurrences (a layer's whole recurrence in ONE launch whose workgroups exchange h_t / dGh_t through memory;
  * it needs every workgroup resident at once).  out8 = {starved, slice | workgroup, tile | XCD, direction | kind, step, wave, pending
