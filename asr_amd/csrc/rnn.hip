@@ -199,6 +199,57 @@ __device__ __forceinline__ void mfma_packed(f32x4 (&acc)[MB][NB], int nch, int w
   }
 }
 
+// The split form of the fp32 mode (three-term products on the bf16 matrix cores, see rnn_fwd_persistent_kernel SP): both operands come as a hi
+// and a lo bf16 plane (pa_lo / pb_lo floats behind pa / pb), acc += a_lo.b_hi + a_hi.b_lo + a_hi.b_hi per chunk — same bytes per chunk as the
+// fp32 operands (2 x 16 B per lane), 3 x 16 MFMA cycles instead of 8 x 32.
+template <int MB, int NB, int PF, typename F>
+__device__ __forceinline__ void mfma_packed_split(f32x4 (&acc)[MB][NB], int nch, int wave, const float* __restrict__ pa, long long sa, long long pa_lo,
+                                                  const float* __restrict__ pb, long long sb, long long pb_lo, F&& after_prefetch) {
+  f32x4 fa[PF][2][MB], fb[PF][2][NB];
+  auto load = [&](f32x4(&a)[2][MB], f32x4(&b)[2][NB], int c) {
+    if (c < nch) {   // wave-uniform
+#pragma unroll
+      for (int i = 0; i < MB; ++i) {
+        a[0][i] = *reinterpret_cast<const f32x4*>(pa + i * sa + (long long)c * 256);
+        a[1][i] = *reinterpret_cast<const f32x4*>(pa + pa_lo + i * sa + (long long)c * 256);
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        b[0][j] = *reinterpret_cast<const f32x4*>(pb + j * sb + (long long)c * 256);
+        b[1][j] = *reinterpret_cast<const f32x4*>(pb + pb_lo + j * sb + (long long)c * 256);
+      }
+    }
+  };
+  int c = wave;
+#pragma unroll
+  for (int p = 0; p < PF; ++p) load(fa[p], fb[p], c + p * NW);
+  after_prefetch();
+  for (; c < nch; c += NW * PF) {
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+      f32x4 ta[2][MB], tb[2][NB];
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+        for (int i = 0; i < MB; ++i) ta[pl][i] = fa[p][pl][i];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) tb[pl][j] = fb[p][pl][j];
+      }
+      load(fa[p], fb[p], c + (p + PF) * NW);
+      if (c + p * NW < nch) {   // wave-uniform
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+          for (int j = 0; j < NB; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ta[1][i]), __builtin_bit_cast(bf16x8, tb[0][j]), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ta[0][i]), __builtin_bit_cast(bf16x8, tb[1][j]), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ta[0][i]), __builtin_bit_cast(bf16x8, tb[0][j]), acc[i][j], 0, 0, 0);
+          }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // forward step.  block = NW waves = MB 16-row batch tiles x NS 16-unit slices x all gates, K split over the waves.
 // grid = (slice group, batch tile, direction): the linear workgroup id is x + gridDim.x * (bt + nbt * dir), so the batch tiles (and
@@ -879,9 +930,13 @@ __device__ __forceinline__ void lstm_bwd_point(float dh, float dcar_in, float ig
 // ------------------------------------------------------------------------------------------
 // Preloaded arguments as in the forward kernel: operand bases + the three HBM-streamed epilogue inputs (saved gates, aux, dy).
 //   s_H = s | H << 16;  T_B = T | B << 16;  nbt16_dbg = tiles | flags << 16
-template <int G, int MB, int NS, bool BF>
+// SP (BF = true): the split form of the fp32 mode for shapes no persistent split kernel fits (C4: LSTM H = 1280; c3 / c5: GRU H = 1024) — dGh
+// travels as a hi and a lo bf16 plane of the ping-pong buffers (the second plane behind the first: together the size of the fp32 buffers),
+// W_hh^T as the hi / lo fragment sets of the split operand, products on the bf16 matrix cores (mfma_packed_split); plain fp32 buffers otherwise.
+template <int G, int MB, int NS, bool BF, bool SP = false>
 __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(const float* pk, const float* wp, float* gxbase, float* auxbase, const float* dy,
                                                                int s_H, int T_B, int nbt16_dbg, int lddy, RnnArgs a) {
+  static_assert(!SP || BF, "the split form runs on the bf16 data path");
   // bit 2 of the flags: gxbase is really the packed bf16 gate-record buffer (RnnArgs::gates_bf), preloaded in gx's place
   const __bf16* gates_bf = ((nbt16_dbg >> 16) & 4) ? reinterpret_cast<const __bf16*>(gxbase) : nullptr;
   __shared__ __attribute__((aligned(16))) f32x4 red[NW][MB * NS][64];
@@ -971,7 +1026,11 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(const float* pk, 
     const int nch_eff = (has_q && !DS2_ABLATE_BIT(dbg, 1)) ? nchb : 0;  // one code path, see the forward kernel
     const float* pa = pk_in + ((long long)(bt * MB) * nchb) * 256 + lane * 4;
     const float* pw = wp + (((long long)dir * nsl + slice * NS) * nchb) * 256 + lane * 4;
-    mfma_packed<BF, MB, NS, (MB * NS > 2 ? 4 : 6)>(acc, nch_eff, wave, pa, (long long)nchb * 256, pw, (long long)nchb * 256, issue_epilogue_loads);
+    if constexpr (SP)
+      mfma_packed_split<MB, NS, (MB * NS > 2 ? 3 : 4)>(acc, nch_eff, wave, pa, (long long)nchb * 256, (long long)4 * nbt16 * nchb * 256, pw,
+                                                       (long long)nchb * 256, (long long)2 * nsl * nchb * 256, issue_epilogue_loads);
+    else
+      mfma_packed<BF, MB, NS, (MB * NS > 2 ? 4 : 6)>(acc, nch_eff, wave, pa, (long long)nchb * 256, pw, (long long)nchb * 256, issue_epilogue_loads);
   }
   float* dcar_out = a.dcar + ((long long)((s & 1) * 2 + dir)) * B * H;
 #pragma unroll
@@ -1019,7 +1078,11 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(const float* pk, 
       }
     }
 #pragma unroll
-    for (int g = 0; g < G; ++g) packed_store<BF>(pk_out, packed_index<BF>(b, g * H + j, nchb), dgh[g]);
+    for (int g = 0; g < G; ++g) {
+      const long long pi = packed_index<BF>(b, g * H + j, nchb);
+      packed_store<BF>(pk_out, pi, dgh[g]);
+      if constexpr (SP) packed_store<true>(pk_out + (long long)4 * nbt16 * nchb * 256, pi, dgh[g] - (float)(__bf16)dgh[g]);
+    }
   }
 }
 
@@ -1581,7 +1644,7 @@ __device__ __forceinline__ void store16_base(const char* base, unsigned off, u32
 #include "rnn_bwd_ksplit.h"
 #include "rnn_fwd_u10.h"
 
-template <int G, bool BF>
+template <int G, bool BF, bool SP = false>
 int launch_steps(bool bwd, RnnArgs a, hipStream_t st) {
   a.dbg = g_ds2_debug_flags;
   int mb = pick_mb(a.B, a.H);
@@ -1609,9 +1672,9 @@ int launch_steps(bool bwd, RnnArgs a, hipStream_t st) {
       else if (mb == 2) hipLaunchKernelGGL((rnn_fwd_step_kernel<G, 2, 1, BF>), grid, block, 0, st, pk, wp, a.gx, prev, a.bhh, s_H, T_B, packed, a);
       else hipLaunchKernelGGL((rnn_fwd_step_kernel<G, 1, 1, BF>), grid, block, 0, st, pk, wp, a.gx, prev, a.bhh, s_H, T_B, packed, a);
     } else {
-      if (ns == 2) hipLaunchKernelGGL((rnn_bwd_step_kernel<G, 1, 2, BF>), grid, block, 0, st, pk, wp, gx_or_rec, a.aux, a.dy, s_H, T_B, packed, a.lddy, a);
-      else if (mb == 2) hipLaunchKernelGGL((rnn_bwd_step_kernel<G, 2, 1, BF>), grid, block, 0, st, pk, wp, gx_or_rec, a.aux, a.dy, s_H, T_B, packed, a.lddy, a);
-      else hipLaunchKernelGGL((rnn_bwd_step_kernel<G, 1, 1, BF>), grid, block, 0, st, pk, wp, gx_or_rec, a.aux, a.dy, s_H, T_B, packed, a.lddy, a);
+      if (ns == 2) hipLaunchKernelGGL((rnn_bwd_step_kernel<G, 1, 2, BF, SP>), grid, block, 0, st, pk, wp, gx_or_rec, a.aux, a.dy, s_H, T_B, packed, a.lddy, a);
+      else if (mb == 2) hipLaunchKernelGGL((rnn_bwd_step_kernel<G, 2, 1, BF, SP>), grid, block, 0, st, pk, wp, gx_or_rec, a.aux, a.dy, s_H, T_B, packed, a.lddy, a);
+      else hipLaunchKernelGGL((rnn_bwd_step_kernel<G, 1, 1, BF, SP>), grid, block, 0, st, pk, wp, gx_or_rec, a.aux, a.dy, s_H, T_B, packed, a.lddy, a);
     }
   }
   hipError_t e = hipGetLastError();
@@ -1955,6 +2018,15 @@ extern "C" int ds2_rnn_bwd_ex(int gates, const float* dy, int lddy, float* gx, f
     if (rc != 0 && rc != 2) return rc < 0 ? rc : 0;
   }
   DS2_HIP(hipMemsetAsync(ws, 0, ds2_rnn_bwd_workspace_bytes(gates, B, H, bf16), (hipStream_t)stream));   // step kernels: zero carry + padding
+  if (bf16 == 2 && (H % 32) == 0 && !a.gates_bf && !a.dgx_bf) {
+    // fp32 mode, no persistent kernel took the call (shape, cooldown): the step kernels in split form — unless DS2_F32_RNN=f32 / debug selectors
+    static const char* env = getenv("DS2_F32_RNN");
+    if (!(env && env[0] == 'f') && !(a.dbg & ~128)) {
+      a.wp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(wp_bwd) + ds2_rnn_packed_bytes(gates, H, 1, 0));
+      g_last_path |= 64;                                            // bit 6 without bit 1: split step kernels
+      return gates == 3 ? launch_steps<3, true, true>(true, a, (hipStream_t)stream) : launch_steps<4, true, true>(true, a, (hipStream_t)stream);
+    }
+  }
   return bf16 == 1 ? dispatch<true>(gates, true, a, (hipStream_t)stream) : dispatch<false>(gates, true, a, (hipStream_t)stream);
 }
 
