@@ -33,6 +33,7 @@ constexpr int PITCH = 144;                       // bytes per LDS tile row (128 
 constexpr int TILE_BYTES = BM * PITCH;           // 18432
 
 __device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};   // global address space zero page
+__device__ __attribute__((aligned(16))) float g_sink16[4];                          // where store lanes outside the matrix write (gemm_nt_ring.h)
 
 struct BArgs {
   const __bf16* A; const __bf16* B; float* C; const float* bias;
@@ -40,6 +41,7 @@ struct BArgs {
   long long sA, sB, sC;
   int splitk, kchunk, accumulate;
   int nt_store;        // final C written with non-temporal stores (streamed out once)
+  int super_rows;      // 256 x 256 NT kernels: row tiles per super-row of the XCD-aware tile walk (0: row-major)
   float* partial;
 };
 
@@ -199,10 +201,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(BArgs g
   // (row-tile major) tile list: the tiles sharing an A row-tile then hit the same 4 MB L2.  (bijective for any count)
   const int nt = ntx * nty;
   int orig = blockIdx.x;
+  // (g.super_rows > 0: the sequence runs through super-rows of that many row tiles column by column, so that the 32 tiles an XCD holds at one
+  // time form a compact block — see gemm_nt_ring.h)
   auto tile_origin = [&](int o, int& tm0, int& tn0) {
     const int xcd = o & 7, q8 = nt >> 3, r8 = nt & 7;
     const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (o >> 3);
-    tm0 = (tile / ntx) * 256; tn0 = (tile % ntx) * 256;
+    if (g.super_rows > 0) {
+      const int per = g.super_rows * ntx, sr = tile / per, rem = tile - sr * per;
+      const int rows = min(g.super_rows, nty - sr * g.super_rows);
+      const int tn = rem / rows;
+      tm0 = (sr * g.super_rows + rem - tn * rows) * 256; tn0 = tn * 256;
+    } else {
+      tm0 = (tile / ntx) * 256; tn0 = (tile % ntx) * 256;
+    }
   };
   int m0, n0;
   tile_origin(orig, m0, n0);
@@ -1042,6 +1053,7 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
   }
 }
 
+#include "gemm_nt_ring.h"
 #include "gemm_tn_group.h"
 
 }  // namespace
@@ -1078,6 +1090,8 @@ extern "C" int ds2_gemm_bf16_nt(int M, int N, int K, const void* A, int lda, lon
   g.nt_store |= dbg_bits;
   static const char* wide_env = getenv("DS2_GEMM_WIDE");  // "0": lane-per-column epilogue stores (A/B switch)
   if (wide_env && wide_env[0] == '0') g.nt_store |= 128;
+  static const int super_rows = getenv("DS2_GEMM_SR") ? atoi(getenv("DS2_GEMM_SR")) : 4;   // row tiles per super-row of the tile walk (0: row-major)
+  g.super_rows = batch == 1 ? super_rows : 0;
   hipStream_t s = (hipStream_t)stream;
   // 256 x 256 LDS-DMA kernel whenever its tiles cover at least half the chip; the 128 x 128 kernel for everything smaller
   const long long tiles256 = (long long)ceil_div(N, 256) * ceil_div(M, 256) * batch * splitk;
@@ -1120,7 +1134,31 @@ extern "C" int ds2_gemm_bf16_nt(int M, int N, int K, const void* A, int lda, lon
       const bool wide = (N % 4) == 0 && (ldc % 4) == 0 && ((uintptr_t)C % 16) == 0 && (!bias || ((uintptr_t)bias % 16) == 0);
       const bool pers = !(pe && pe[0] == '0') && batch == 1 && splitk == 1 && !accumulate && (K % BK) == 0 && nkt >= 2 && (nkt % 2) == 0 &&
                         nkt <= 128 && wide && !(g.nt_store & ~1) && ntx * nty > cus;
-      if (pers) {
+      // EXPERIMENTS of round 5 (gemm_nt_ring.h; profiles/r05_gemm_ring_ab.txt), bit-identical to the production kernel and not faster:
+      // DS2_GEMM_RING=1 the software-pipelined loop over a four-slice LDS ring with counted DMA waits, =q the ping-pong form on
+      // v_mfma_f32_16x16x32_bf16 with a register-direct epilogue.  Both are bound, like the production kernel, by what a CU can take in
+      // through its vector-memory path when part of the operand stream misses the L2 (the operand DMA alone, no MFMA: 350 us on the dX shape).
+      static const char* ring_env = getenv("DS2_GEMM_RING");
+      const bool ring = ring_env && (ring_env[0] == '1' || ring_env[0] == 'q') && !(pe && pe[0] == '0') && batch == 1 && splitk == 1 && !accumulate &&
+                        (K % 32) == 0 && K >= 128 && wide && !(g.nt_store & ~1) && ntx * nty > cus;
+      if (ring) {
+        static bool rattr = false;
+        if (!rattr) {
+          DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_nt_ring_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, R_RING + G_PATCH));
+          DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_nt_pp16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, R_RING));
+          rattr = true;
+        }
+        static const int rdbg = getenv("DS2_RING_DBG") ? atoi(getenv("DS2_RING_DBG")) : 0;   // timing ablations of the pp16 kernel (WRONG RESULTS)
+        if (ring_env[0] == 'q' && rdbg) {
+#define DS2_Q_DBG(n) if (rdbg == n) { DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_nt_pp16_kernel<false, n>, hipFuncAttributeMaxDynamicSharedMemorySize, R_RING)); \
+                       hipLaunchKernelGGL((gemm_bf16_nt_pp16_kernel<false, n>), dim3(cus, 1, 1), dim3(512), R_RING, s, g, ntx, nty); }
+          DS2_Q_DBG(1) DS2_Q_DBG(2) DS2_Q_DBG(3) DS2_Q_DBG(8) DS2_Q_DBG(18) DS2_Q_DBG(26)
+#undef DS2_Q_DBG
+        } else if (ring_env[0] == 'q')
+          hipLaunchKernelGGL((gemm_bf16_nt_pp16_kernel<false>), dim3(cus, 1, 1), dim3(512), R_RING, s, g, ntx, nty);
+        else
+          hipLaunchKernelGGL((gemm_bf16_nt_ring_kernel<false>), dim3(cus, 1, 1), dim3(512), R_RING + G_PATCH, s, g, ntx, nty);
+      } else if (pers) {
         static bool pattr = false;
         if (!pattr) {
           DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_nt_glds_kernel<2, 4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1165,7 +1203,7 @@ extern "C" int ds2_gemm_bf16_tn(int M, int N, int K, const void* A, int lda, lon
   g.A = (const __bf16*)A; g.B = (const __bf16*)B; g.C = C; g.bias = nullptr;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.sA = strideA; g.sB = strideB; g.sC = strideC;
-  g.splitk = splitk; g.kchunk = kchunk; g.accumulate = accumulate; g.partial = (float*)workspace; g.nt_store = 0;
+  g.splitk = splitk; g.kchunk = kchunk; g.accumulate = accumulate; g.partial = (float*)workspace; g.nt_store = 0; g.super_rows = 0;
   { static const char* wide_env = getenv("DS2_GEMM_WIDE"); if (wide_env && wide_env[0] == '0') g.nt_store |= 128; }
   hipStream_t s = (hipStream_t)stream;
   static bool attr_set = false;

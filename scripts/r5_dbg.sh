@@ -1,0 +1,5 @@
+#!/bin/bash
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+RING_VARIANTS="0 q" python scripts/r5_ring.py check | tail -8
+for rep in 1 2; do for v in "DS2_GEMM_RING=0 DS2_GEMM_SR=0" "DS2_GEMM_RING=0 DS2_GEMM_SR=4" "DS2_GEMM_RING=q DS2_GEMM_SR=4" "DS2_GEMM_RING=1 DS2_GEMM_SR=4"; do echo "== $v"; env $v timeout 200 python scripts/bench_gemm.py 2>&1 | grep -E "fwd|dXn"; done; done

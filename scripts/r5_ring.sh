@@ -1,0 +1,5 @@
+#!/bin/bash
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out; export TMPDIR=/tmp
+timeout 600 python scripts/r5_ring.py check > gpurun_out/r5_ring_check.log 2>&1; echo "check rc=$?"; tail -12 gpurun_out/r5_ring_check.log
+timeout 900 python scripts/r5_ring.py time > gpurun_out/r5_ring_time.log 2>&1; echo "time rc=$?"; tail -12 gpurun_out/r5_ring_time.log
