@@ -1101,16 +1101,12 @@ extern "C" int ds2_gemm_bf16_nt(int M, int N, int K, const void* A, int lda, lon
     static bool attr_set = false;
     if (!attr_set) {
       DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_nt_glds_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
-      DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_nt_glds_kernel<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
       attr_set = true;
     }
     const int ntx = ceil_div(N, 256), nty = ceil_div(M, 256);
-    // 8 waves (128 x 64 per wave) for every shape.  Short reductions are dominated by the C write-out; 16 waves (64 x 64 per wave, 4 per
-    // SIMD) used to overlap it better (+5-10 % on the K = 1024 forward projection), but with the wide (16-byte, LDS-staged) epilogue
-    // the 8-wave kernel is 13 % faster there on random operands (549 vs 630 us; whole c3 step, same box: 29.05 vs 29.27 ms) and the
-    // 16-wave variant has no registers left for it.
-    static const char* wv = getenv("DS2_GEMM_WAVES");      // "8" | "16" | "pp": tuning override
-    const bool w16 = wv && wv[0] == '1';
+    // 8 waves (128 x 64 per wave) for every shape (a 16-wave 64 x 64 variant lost to it in round 2 once the epilogue went through LDS and is no
+    // longer built).
+    static const char* wv = getenv("DS2_GEMM_WAVES");      // "pp": the ping-pong schedule of the one-tile kernel (tuning override)
     const bool pp = wv && wv[0] == 'p';
     if (pp) {
       static bool pp_attr = false;
@@ -1119,8 +1115,7 @@ extern "C" int ds2_gemm_bf16_nt(int M, int N, int K, const void* A, int lda, lon
         pp_attr = true;
       }
       hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<2, 4, true>), dim3(ntx * nty, 1, batch * splitk), dim3(512), G_LDS, s, g, ntx, nty);
-    } else if (w16) hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<4, 4>), dim3(ntx * nty, 1, batch * splitk), dim3(1024), G_LDS, s, g, ntx, nty);
-    else {
+    } else {
       // persistent form (one workgroup per CU walking several tiles; see the kernel): short reductions with more tiles than CUs, plain write-out
       static const char* pe = getenv("DS2_GEMM_PERS");     // "0": one workgroup per tile for every shape (A/B switch)
       static int cus = 0;

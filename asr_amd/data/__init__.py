@@ -120,62 +120,6 @@ class SpectrogramDataset(Dataset):
         return self.size
 
 
-class BucketingSampler(Sampler):
-    """Restates the reference class of the same name statement for statement (data/samplers/bucketing_sampler.py:5-25): consecutive manifest
-    rows form a bin (= batch); kept by name and behaviour because the reference's loaders and tests construct it."""
-
-    def __init__(self, data_source, batch_size=1):
-        super().__init__()
-        self.data_source = data_source
-        ids = list(range(len(data_source)))
-        self.bins = [ids[i:i + batch_size] for i in range(0, len(ids), batch_size)]
-
-    def __iter__(self):
-        for ids in self.bins:
-            np.random.shuffle(ids)
-            yield ids
-
-    def __len__(self):
-        return len(self.bins)
-
-    def shuffle(self, epoch=None):
-        np.random.shuffle(self.bins)
-
-
-class DistributedBucketingSampler(Sampler):
-    """Restates the reference class of the same name statement for statement (data/samplers/distributed_bucketing_sampler.py:8-44: same
-    attributes, wrap-pad, `bins[rank::num_replicas]`, seeded randperm shuffle).  It is dead code in the reference; here it is the SURVEY §8(e)
-    partition rule, kept by name: rank r takes bins[r::world], wrap-padded to a multiple of world."""
-
-    def __init__(self, data_source, batch_size=1, num_replicas=None, rank=None):
-        super().__init__()
-        if num_replicas is None or rank is None:
-            import torch.distributed as dist
-            num_replicas = dist.get_world_size() if num_replicas is None else num_replicas
-            rank = dist.get_rank() if rank is None else rank
-        self.data_source = data_source
-        self.ids = list(range(len(data_source)))
-        self.batch_size = batch_size
-        self.bins = [self.ids[i:i + batch_size] for i in range(0, len(self.ids), batch_size)]
-        self.num_replicas, self.rank = num_replicas, rank
-        self.num_samples = int(math.ceil(len(self.bins) * 1.0 / self.num_replicas))
-        self.total_size = self.num_samples * self.num_replicas
-
-    def __iter__(self):
-        bins = self.bins + self.bins[: (self.total_size - len(self.bins))]
-        assert len(bins) == self.total_size
-        return iter(bins[self.rank::self.num_replicas])
-
-    def __len__(self):
-        return self.num_samples
-
-    def shuffle(self, epoch):
-        g = torch.Generator()
-        g.manual_seed(epoch)
-        order = torch.randperm(len(self.bins), generator=g).tolist()
-        self.bins = [self.bins[i] for i in order]
-
-
 def _durations_of(data_source, durations=None):
     """Per-item lengths for bucketing: explicit sequence, else the manifest's `duration` column (etl/jsut_dataset.py:36-42,
     etl/librispeech_dataset.py:100-103 write it), else the text length as a proxy."""
@@ -192,6 +136,17 @@ def _durations_of(data_source, durations=None):
     if len(d) != len(data_source):
         raise ValueError(f"{len(d)} durations for {len(data_source)} items")
     return d
+
+
+def _item_order(self, data_source, durations, descending, order):
+    """Item ids in binning order: by duration (stable; ties by manifest index) or as the manifest lists them."""
+    if order == "manifest":
+        self.durations = None
+        return list(range(len(data_source)))
+    if order != "duration":
+        raise ValueError(f"order={order!r}: expected duration or manifest")
+    self.durations = _durations_of(data_source, durations)
+    return np.argsort(-self.durations if descending else self.durations, kind="stable").tolist()
 
 
 def _full_bins(order, batch_size, partial):
@@ -219,13 +174,11 @@ class LengthBucketingSampler(Sampler):
     (ids shuffled inside the bin like the reference; `_collate_fn` re-sorts a batch by length anyway), `__len__` = number of bins,
     `shuffle()` permutes the bin ORDER (batches stay homogeneous in length, epochs see them in a different order)."""
 
-    def __init__(self, data_source, batch_size=1, durations=None, descending=False, partial="keep"):
+    def __init__(self, data_source, batch_size=1, durations=None, descending=False, partial="keep", order="duration"):
         super().__init__()
         self.data_source = data_source
         self.batch_size = int(batch_size)
-        self.durations = _durations_of(data_source, durations)
-        order = np.argsort(-self.durations if descending else self.durations, kind="stable").tolist()
-        self.bins = _full_bins(order, self.batch_size, partial)
+        self.bins = _full_bins(_item_order(self, data_source, durations, descending, order), self.batch_size, partial)
 
     def __iter__(self):
         for ids in self.bins:
@@ -248,6 +201,15 @@ class LengthBucketingSampler(Sampler):
         return [float(self.durations[b].max() - self.durations[b].min()) for b in self.bins]
 
 
+class BucketingSampler(LengthBucketingSampler):
+    """The reference's sampler of this name (data/samplers/bucketing_sampler.py:5-25: bins of consecutive manifest rows, "assuming they are
+    in order of size") = the length-bucketing sampler with the manifest order taken as given.  Bins, in-bin shuffle and `shuffle()` are
+    held to the reference's own output in tests/golden/data_formats.json."""
+
+    def __init__(self, data_source, batch_size=1):
+        super().__init__(data_source, batch_size=batch_size, order="manifest")
+
+
 class DistributedLengthBucketingSampler(Sampler):
     """Length bucketing for one-process-per-GPU data parallelism: the partition rule is the reference's (rank r takes every
     `num_replicas`-th bin starting at r, distributed_bucketing_sampler.py:22-34), applied to LENGTH-SORTED bins, and the epoch shuffle
@@ -255,36 +217,56 @@ class DistributedLengthBucketingSampler(Sampler):
     hold batches that are neighbours in length, and the gradient all-reduce does not wait for a straggler with a much longer T
     ("for C5 sort by length first so concurrent ranks get similar T").  The tail is padded to a whole round with the
     bins just before it (nearest in length), where the reference wraps around to the first bins (which here would put the SHORTEST
-    batches next to the LONGEST ones in the last round)."""
+    batches next to the LONGEST ones in the last round).
+
+    `order="manifest"`, `pad="wrap"`, `shuffle_unit="bin"` select the reference's own behaviour instead (DistributedBucketingSampler below):
+    manifest order, wrap-around padding applied AFTER the shuffle, single bins permuted."""
 
     _fill_logged = False
 
-    def __init__(self, data_source, batch_size=1, num_replicas=None, rank=None, durations=None, descending=False, partial="keep"):
+    def __init__(self, data_source, batch_size=1, num_replicas=None, rank=None, durations=None, descending=False, partial="keep",
+                 order="duration", pad="nearest", shuffle_unit="round"):
         super().__init__()
         if num_replicas is None:
             num_replicas = torch.distributed.get_world_size()
         if rank is None:
             rank = torch.distributed.get_rank()
+        if pad not in ("nearest", "wrap") or shuffle_unit not in ("round", "bin"):
+            raise ValueError(f"pad={pad!r} / shuffle_unit={shuffle_unit!r}: expected nearest | wrap and round | bin")
         self.data_source, self.batch_size = data_source, int(batch_size)
         self.num_replicas, self.rank = int(num_replicas), int(rank)
-        self.durations = _durations_of(data_source, durations)
-        order = np.argsort(-self.durations if descending else self.durations, kind="stable").tolist()
+        self.pad, self.shuffle_unit = pad, shuffle_unit
+        self.ids = _item_order(self, data_source, durations, descending, order)
         # partial="keep" (default, the reference sampler's behaviour: the short last bin stays short, epochs are composed exactly as with
         # data/samplers/distributed_bucketing_sampler.py).  partial="fill" tops the short bin up with the ids just before it, so that every
         # rank of every round runs the SAME batch size — gradients are averaged unweighted, and a rank whose B is not a multiple of 8 leaves
         # the packed bf16 fast path and straggles in the all-reduce; it duplicates samples within an epoch (logged once), so it is opt-in.
-        bins = _full_bins(order, self.batch_size, partial)
-        if partial == "fill" and len(order) % self.batch_size and not DistributedLengthBucketingSampler._fill_logged:
+        self.bins = _full_bins(self.ids, self.batch_size, partial)
+        if partial == "fill" and len(self.ids) % self.batch_size and not DistributedLengthBucketingSampler._fill_logged:
             DistributedLengthBucketingSampler._fill_logged = True
             print(f"[asr_amd] DistributedLengthBucketingSampler(partial='fill'): the last bin is topped up with "
-                  f"{self.batch_size - len(order) % self.batch_size} duplicate sample(s) per epoch", flush=True)
-        self.num_samples = int(math.ceil(len(bins) / self.num_replicas))
+                  f"{self.batch_size - len(self.ids) % self.batch_size} duplicate sample(s) per epoch", flush=True)
+        self.num_samples = int(math.ceil(len(self.bins) / self.num_replicas))
         self.total_size = self.num_samples * self.num_replicas
-        pad = self.total_size - len(bins)
-        if pad:
-            src = bins[-(pad + 1):-1] if len(bins) > pad else (bins * (pad // max(len(bins), 1) + 1))[:pad]
-            bins = bins + [list(b) for b in src]
-        self.rounds = [bins[i:i + self.num_replicas] for i in range(0, self.total_size, self.num_replicas)]
+        self._round_order = None                                   # shuffle_unit="round": permutation of the rounds, set by shuffle()
+
+    def _padded(self):
+        """The bins of one epoch, padded to a whole number of rounds."""
+        pad = self.total_size - len(self.bins)
+        if self.pad == "wrap":                                     # the reference: the epoch's first bins again
+            bins = self.bins + self.bins[:pad]
+            assert len(bins) == self.total_size                    # (its own assertion: fails when there are fewer bins than padding)
+            return bins
+        if not pad:
+            return self.bins
+        src = self.bins[-(pad + 1):-1] if len(self.bins) > pad else (self.bins * (pad // max(len(self.bins), 1) + 1))[:pad]
+        return self.bins + [list(b) for b in src]
+
+    @property
+    def rounds(self):
+        bins = self._padded()
+        rounds = [bins[i:i + self.num_replicas] for i in range(0, self.total_size, self.num_replicas)]
+        return rounds if self._round_order is None else [rounds[i] for i in self._round_order]
 
     def __iter__(self):
         return iter([r[self.rank] for r in self.rounds])
@@ -295,7 +277,49 @@ class DistributedLengthBucketingSampler(Sampler):
     def shuffle(self, epoch):
         g = torch.Generator()
         g.manual_seed(int(epoch))
-        self.rounds = [self.rounds[i] for i in torch.randperm(len(self.rounds), generator=g).tolist()]
+        if self.shuffle_unit == "bin":
+            self.bins = [self.bins[i] for i in torch.randperm(len(self.bins), generator=g).tolist()]
+        else:
+            prev = self._round_order if self._round_order is not None else list(range(self.num_samples))
+            self._round_order = [prev[i] for i in torch.randperm(self.num_samples, generator=g).tolist()]
+
+
+class DistributedBucketingSampler(DistributedLengthBucketingSampler):
+    """The reference's sampler of this name (data/samplers/distributed_bucketing_sampler.py:8-44; dead code there, the SURVEY §8(e) partition
+    rule here): bins of consecutive manifest rows, rank r takes bins[r::world] of the bin list wrap-padded to a multiple of world, `shuffle(epoch)`
+    permutes the bins with a generator seeded by the epoch.  Same attributes (`ids`, `bins`, `num_replicas`, `rank`, `num_samples`,
+    `total_size`); per-rank bins for world 1 / 2 / 4 / 8 and the shuffles are held to the reference's own output (tests/golden/data_formats.json)."""
+
+    def __init__(self, data_source, batch_size=1, num_replicas=None, rank=None):
+        super().__init__(data_source, batch_size=batch_size, num_replicas=num_replicas, rank=rank, order="manifest", pad="wrap",
+                         shuffle_unit="bin")
+
+
+def write_manifest(records, path):
+    """Manifest CSV in the layout the reference's ETL writes (etl/jsut_dataset.py:36-42 + etl/__main__.py:55: DataFrame.to_csv(index=False)
+    with the columns audio_filepath, duration, fq, text, text_size).  `records`: iterable of (audio_filepath, duration, fq, text)."""
+    import pandas as pd
+    rows = [(str(f), float(d), int(fq), str(t), len(str(t))) for f, d, fq, t in records]
+    pd.DataFrame.from_records(rows, columns=["audio_filepath", "duration", "fq", "text", "text_size"]).to_csv(path, index=False)
+
+
+def export_labels(texts, path):
+    """labels.csv as the reference writes it (etl/jsut_dataset.py:56-60): one `label` column holding every character of the corpus; the
+    reference emits the set in hash order, this writes it sorted (index 0 = CTC blank is whatever row comes first, as there)."""
+    import pandas as pd
+    chars = set()
+    for t in texts:
+        chars |= set(t)
+    pd.DataFrame.from_records([(c,) for c in sorted(chars)], columns=["label"]).to_csv(path, index=False)
+
+
+def clean_jsut_text(line):
+    """`key:text` line of a JSUT transcript_utf8.txt -> (key, text) with spaces, newlines and the two Japanese punctuation marks removed
+    (etl/jsut_dataset.py:46-50)."""
+    k, v = line.split(":")
+    for ch in (" ", "\n", "\u3001", "\u3002"):
+        v = v.replace(ch, "")
+    return k, v
 
 
 class AudioDataLoader(DataLoader):

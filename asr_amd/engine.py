@@ -95,8 +95,11 @@ F32_CONV = _os.environ.get("DS2_F32_CONV", "split")
 F32_CONV_FWD = _os.environ.get("DS2_F32_CONV_FWD", "f32")
 
 
-def _f32_split_ok(M: int, N: int, K: int) -> bool:
-    return F32_GEMM == "split" and M >= 512 and N >= 256 and K >= 256 and K % 8 == 0 and N % 8 == 0
+def _f32_split_ok(M: int, N: int, K: int, H: int = 8) -> bool:
+    """fp32 mode: do this layer's input-to-hidden products run as three-term split-bf16 GEMMs?  H: the layer's hidden size — backward's dW_hh
+    problems have N = H and column offsets d * H, d * G * H, which the grouped TN launch wants 16-byte aligned (H % 8 == 0); hidden sizes
+    with H % 8 == 4 (accepted by the recurrence entry points) keep the fp32-MFMA GEMM path."""
+    return F32_GEMM == "split" and M >= 512 and N >= 256 and K >= 256 and K % 8 == 0 and N % 8 == 0 and H % 8 == 0
 
 
 _BWD_PERSISTENT = {}      # (gates, H, B) -> did the last backward recurrence of this shape run as a persistent launch?
@@ -301,7 +304,7 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
             xn = xn0 if cfg.precision == "bf16" else xin
         if cfg.precision == "bf16":
             gx = ops.gemm_bf16_nt(xn, ops.cast_bf16(W[f"rnns.{l}.wih_cat"]), bias=W[f"rnns.{l}.bih_cat"])
-        elif _f32_split_ok(M, 2 * G * H, xn.shape[1]):
+        elif _f32_split_ok(M, 2 * G * H, xn.shape[1], H):
             # three-term split-bf16 product as ONE NT GEMM over a reduction index 3 I long: [hi | hi | lo] x [hi | lo | hi]^T
             lc.xs = ops.split_bf16(xn, 0)
             gx = ops.gemm_bf16_nt(lc.xs, ops.split_bf16(W[f"rnns.{l}.wih_cat"], 1), bias=W[f"rnns.{l}.bih_cat"])
@@ -367,6 +370,15 @@ def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy, done, private: bo
     dev = ctx.lens_dev.device
     side = _side_stream(dev)
     pending = None
+    report = done
+
+    def done(name):
+        """A reducer may release MORE than the named bucket from the calling stream (the "conv" schedule holds fc and every recurrent layer
+        until rnns.0 and then records ONE "gradients final" event on the stream it is called from): weight gradients that earlier layers
+        left on the side stream must be ordered before that event — the calling stream joins the side stream first."""
+        if name == "rnns.0" and getattr(ctx, "side_used", False) and not serial_buckets:
+            torch.cuda.current_stream().wait_stream(side)
+        report(name)
 
     def weight_gradients(p):
         """layer p's dW_hh / dW_ih GEMMs on the compute stream, behind the event of its operand passes"""

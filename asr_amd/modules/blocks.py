@@ -50,14 +50,23 @@ class MaskConv(nn.Module):
 
     def forward(self, x, lengths):
         """x (B,1,F,T_in) fp32 on the GPU, lengths (B,) = frames to keep in the OUTPUT (blocks.py:42-56) -> ((B,32,D2,T), lengths)."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if not self._is_ds2_stack():
+            # any OTHER stack: the reference container's own semantics (blocks.py:42-56: run each module, zero everything beyond each
+            # utterance's length after it) in plain torch — a generic container, not the train-step path (DeepSpeech never builds one)
+            for module in self.seq_module:
+                x = module(x)
+                mask = torch.zeros(x.size(), dtype=torch.bool, device=x.device)
+                for i, length in enumerate(lengths):
+                    length = int(length)
+                    if mask[i].size(2) - length > 0:
+                        mask[i].narrow(2, length, mask[i].size(2) - length).fill_(True)
+                x = x.masked_fill(mask, 0)
+            return x, lengths
+        # DeepSpeech's own stack: the HIP kernels, never a torch / MIOpen fallback
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise NotImplementedError("MaskConv.forward stand-alone has no autograd; train through DeepSpeech.forward")
         if not x.is_cuda:
-            raise _lib.DS2LibraryError("MaskConv.forward: GPU tensor required (no CPU fallback)")
-        if not self._is_ds2_stack():
-            raise NotImplementedError("MaskConv.forward stand-alone runs the HIP kernels of DeepSpeech's own conv stack only (Conv2d(1,32,(41,11)) / "
-                                      "BatchNorm2d / Hardtanh(0,20) / Conv2d(32,32,(21,11)) / BatchNorm2d / Hardtanh(0,20)); asr_amd has no torch "
-                                      "fallback by design (see INTEGRATION.md)")
+            raise _lib.DS2LibraryError("MaskConv.forward: GPU tensor required (no CPU fallback for DeepSpeech's conv stack)")
         m = list(self.seq_module)
         lens_dev = torch.as_tensor(lengths).to(torch.int32).to(x.device)
         x = x.contiguous().float()

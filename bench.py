@@ -51,15 +51,25 @@ HBM_PEAK_GBS = 8000.0
 
 
 def kernel_source_sha256():
-    """sha256 over the sources the recurrence kernels are built from (same function as scripts/pmc_summarize.py)"""
-    import hashlib
+    """sha256 over the sources the recurrence kernels are built from: rnn.hip, the headers it includes (rnn_bwd_ksplit.h, rnn_fwd_u10.h,
+    permlane.h, common.h, ...) and the Makefile (same function as scripts/pmc_summarize.py)"""
+    CSRC = os.path.join(ROOT, "asr_amd", "csrc")
+    import hashlib, re
     h = hashlib.sha256()
-    for name in ("rnn.hip", "rnn_bwd_ksplit.h", "permlane.h", "common.h", "Makefile"):
-        h.update(open(os.path.join(ROOT, "asr_amd", "csrc", name), "rb").read())
+    seen, todo = [], ["rnn.hip"]
+    while todo:                                        # rnn.hip and every local header it (transitively) includes, in discovery order
+        name = todo.pop(0)
+        if name in seen:
+            continue
+        seen.append(name)
+        src = open(os.path.join(CSRC, name), "rb").read()
+        h.update(src)
+        todo += [m for m in re.findall(r'#include "([^"/]+)"', src.decode("utf-8", "replace")) if os.path.exists(os.path.join(CSRC, m))]
+    h.update(open(os.path.join(CSRC, "Makefile"), "rb").read())
     return h.hexdigest()
 
 
-PMC_SUMMARY = "r04_pmc_persistent.json"
+PMC_SUMMARY = "r05_pmc_persistent.json"
 
 
 def expected_ksplit_instance(G, H):

@@ -1,6 +1,6 @@
 """Build-time checks on the generated gfx950 code of asr_amd/csrc/gemm_bf16.hip (no GPU needed: hipcc -S).
 
-1. No hot GEMM kernel spills registers (the 16-wave NT variant is allowed its 3 prologue dwords), and no instance of the persistent
+1. No hot GEMM kernel spills registers, and no instance of the persistent
    recurrence kernels of asr_amd/csrc/rnn.hip does.
 2. TN kernel: the fragment reads (`ds_read_b64_tr_b16`, inline asm) and the `s_waitcnt lgkmcnt` that retires them are separate
    statements; between a read and the wait that covers it NO instruction may touch the destination registers - a register copy there
@@ -132,7 +132,7 @@ def main() -> int:
     for name, n in spill_table(asm).items():
         if "gemm_bf16" not in name:
             continue
-        allowed = 3 if "nt_glds_kernelILi4ELi4" in name else 0
+        allowed = 0
         flag = "" if n <= allowed else "   <-- SPILLS"
         print(f"{name}: vgpr spills {n}{flag}")
         bad += n > allowed

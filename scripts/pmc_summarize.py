@@ -8,12 +8,21 @@ import csv, hashlib, json, os, re, sys
 
 
 def kernel_source_sha256():
-    """sha256 over the sources the recurrence kernels are built from (the same function is in bench.py, which refuses a summary whose
-    hash differs from the tree it runs in: the counters then belong to another build of the kernels)"""
-    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "asr_amd", "csrc")
+    """sha256 over the sources the recurrence kernels are built from: rnn.hip, the headers it includes and the Makefile (the same function is
+    in bench.py, which refuses a summary whose hash differs from the tree it runs in: the counters then belong to another build of the kernels)"""
+    CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "asr_amd", "csrc")
+    import hashlib, re
     h = hashlib.sha256()
-    for name in ("rnn.hip", "rnn_bwd_ksplit.h", "permlane.h", "common.h", "Makefile"):
-        h.update(open(os.path.join(root, name), "rb").read())
+    seen, todo = [], ["rnn.hip"]
+    while todo:                                        # rnn.hip and every local header it (transitively) includes, in discovery order
+        name = todo.pop(0)
+        if name in seen:
+            continue
+        seen.append(name)
+        src = open(os.path.join(CSRC, name), "rb").read()
+        h.update(src)
+        todo += [m for m in re.findall(r'#include "([^"/]+)"', src.decode("utf-8", "replace")) if os.path.exists(os.path.join(CSRC, m))]
+    h.update(open(os.path.join(CSRC, "Makefile"), "rb").read())
     return h.hexdigest()
 
 

@@ -10,6 +10,9 @@ Outputs (committed, data only — expected outputs, never reference source):
     tests/golden/collate.npz        _collate_fn on a 3-sample batch
     tests/golden/state_manifest.json  state_dict keys/shapes of the reference model (A.1)
     tests/golden/decode.json        GreedyDecoder.decode (argmax, collapse repeats, drop blanks) known answers
+    tests/golden/data_formats.json  labels.csv / manifest.csv through the reference's SpectrogramDataset (labels_map, parse_transcript), the
+                                    reference's BucketingSampler / DistributedBucketingSampler bins and shuffles, the JSUT ETL's manifest and
+                                    labels layout (`--only-data-formats`)
     tests/golden/model_<name>.npz   whole model: logits, loss, grads (sub-sampled), BN running
                                     stats, 3 AdamW steps — reference statement sequence of
                                     DeepSpeechTrainer.fit + backward + AdamW.step
@@ -298,12 +301,134 @@ def gen_checkpoint(out, DeepSpeech, tmp):
     print("checkpoint fixture:", os.path.getsize(os.path.join(out, "ref_checkpoint_gru_16x2_c7.pth")), "bytes")
 
 
+def gen_data_formats(out, tmp):
+    """SURVEY §8(f) rank 4 pin: the data-side formats and partition rules, produced by the reference's OWN classes (imported unmodified
+    through _ref_shim; the only stand-ins are for file-system / audio I-O: gnutools.fs.listfiles / name and the ffmpeg-backed WAVConverter,
+    which get test doubles that list the files this function creates and return fixed durations).
+      * labels.csv -> SpectrogramDataset.labels_map (pandas skips the whitespace-only row: the space-row quirk) and parse_transcript outputs
+        (spectrogram_dataset.py:36, :70-73);
+      * BucketingSampler bins / iteration / shuffle under a seeded numpy RNG (bucketing_sampler.py:5-25);
+      * DistributedBucketingSampler per-rank bins for world 1, 2, 4, 8 and the epoch-seeded shuffle (distributed_bucketing_sampler.py:8-44);
+      * the JSUT ETL's manifest and labels layout: JSUTDataset.run -> filter_duration -> to_csv(index=False), export_labels
+        (etl/jsut_dataset.py:28-60, etl/__main__.py:46-56)."""
+    import pandas as pd
+    from _ref_shim import _install
+    _install()
+    from asr_deepspeech.data.dataset.spectrogram_dataset import SpectrogramDataset as RefDataset
+    from asr_deepspeech.data.samplers.bucketing_sampler import BucketingSampler as RefBS
+    from asr_deepspeech.data.samplers.distributed_bucketing_sampler import DistributedBucketingSampler as RefDBS
+    import asr_deepspeech.etl.jsut_dataset as ref_jsut
+
+    rec = {}
+    # ---- labels.csv with the space row in the middle, an apostrophe and kana; manifest with the reference's columns
+    labels = ["_", "a", "b", " ", "c", "'", "\u3042", "\u3044", "d"]
+    labels_csv = os.path.join(tmp, "labels_q.csv")
+    pd.DataFrame({"label": labels}).to_csv(labels_csv, index=False)
+    transcripts = ["ab c", "cab\n", "b?a", "_a_b", "d'\u3042\u3044c", "", " ", "xyz", "a\u3042 \u3044b"]
+    manifest_csv = os.path.join(tmp, "manifest_q.csv")
+    pd.DataFrame({"audio_filepath": [f"u{i}.npy" for i in range(len(transcripts))], "duration": [1.0 + 0.25 * i for i in range(len(transcripts))],
+                  "fq": [16000] * len(transcripts), "text": transcripts, "text_size": [len(t) for t in transcripts]}).to_csv(manifest_csv, index=False)
+    ds = RefDataset(audio_conf=audio_conf(), manifest_filepath=manifest_csv, labels=labels_csv, normalize=True)
+    rec["labels_csv_text"] = open(labels_csv, encoding="utf-8").read()
+    rec["manifest_csv_text"] = open(manifest_csv, encoding="utf-8").read()
+    rec["labels_map"] = {k: int(v) for k, v in ds.labels_map.items()}
+    rec["dataset_len"] = len(ds)
+    # the manifest's text column as the reference's DataFrame holds it (pandas reads "" and " " back as NaN): parse what it can
+    rec["manifest_text_isnull"] = [bool(x) for x in ds.df["text"].isnull().tolist()]
+    rec["parse_transcript"] = [[t, [int(x) for x in ds.parse_transcript(t)]] for t in transcripts]
+
+    # ---- BucketingSampler
+    class _N:                                                   # a data source is only asked for its length
+        def __init__(self, n): self.n = n
+        def __len__(self): return self.n
+    bs_cases = []
+    for n, b in ((23, 5), (16, 4), (7, 10), (1, 1)):
+        smp = RefBS(_N(n), batch_size=b)
+        bins0 = [list(map(int, x)) for x in smp.bins]
+        np.random.seed(1234)
+        it = [list(map(int, x)) for x in smp]                   # shuffles inside each bin, in place
+        np.random.seed(99)
+        smp.shuffle()
+        bs_cases.append({"n": n, "batch_size": b, "bins": bins0, "len": len(smp), "iter_seed1234": it,
+                         "bins_after_iter_then_shuffle_seed99": [list(map(int, x)) for x in smp.bins]})
+    rec["bucketing_sampler"] = bs_cases
+
+    # ---- DistributedBucketingSampler.  Its ctor calls Sampler.__init__(data_source): accepted (and ignored) by the torch the reference pins
+    # (uv.lock: 2.8.0), a TypeError on this image's 2.10 — the base ctor gets the old signature back while the fixture is made.
+    from torch.utils.data.sampler import Sampler as _Sampler
+    _saved_init = _Sampler.__init__
+    _Sampler.__init__ = lambda self, data_source=None: None
+    dbs_cases = []
+    for n, b in ((23, 3), (64, 8), (5, 2)):
+        for world in (1, 2, 4, 8):
+            per_rank, lens = [], []
+            try:
+                for rank in range(world):
+                    smp = RefDBS(_N(n), batch_size=b, num_replicas=world, rank=rank)
+                    per_rank.append([list(map(int, x)) for x in smp])
+                    lens.append(len(smp))
+            except AssertionError:                              # fewer bins than the wrap-around padding needs (its own assert, line 32)
+                dbs_cases.append({"n": n, "batch_size": b, "world": world, "raises": "AssertionError"})
+                continue
+            shuf = {}
+            for epoch in (0, 1, 7):
+                smp = RefDBS(_N(n), batch_size=b, num_replicas=world, rank=0)
+                smp.shuffle(epoch)
+                shuf[str(epoch)] = {"bins": [list(map(int, x)) for x in smp.bins],
+                                    "per_rank": [[list(map(int, x)) for x in _rank_iter(RefDBS, _N(n), b, world, r, epoch)] for r in range(world)]}
+            dbs_cases.append({"n": n, "batch_size": b, "world": world, "per_rank": per_rank, "len": lens, "shuffle": shuf})
+    rec["distributed_bucketing_sampler"] = dbs_cases
+    _Sampler.__init__ = _saved_init
+
+    # ---- JSUT ETL layout (test doubles for the file listing and the ffmpeg converter only)
+    landing = os.path.join(tmp, "landing"); os.makedirs(os.path.join(landing, "basic5000"), exist_ok=True)
+    lines = ["BASIC5000_0001:\u6c34\u3092 \u30de\u30ec\u30fc\u30b7\u30a2\u304b\u3089\u3001\u8cb7\u308f\u306a\u304f\u3066\u306f\u3002",
+             "BASIC5000_0002:\u6728\u66dc\u65e5\u3001\u505c\u6226\u4f1a\u8ac7\u306f\u3002",
+             "BASIC5000_0003:\u4e0a\u9662\u8b70\u54e1\u306f ab"]
+    tpath = os.path.join(landing, "basic5000", "transcript_utf8.txt")
+    open(tpath, "w", encoding="utf-8").write("\n".join(lines) + "\n")
+    durs = {"BASIC5000_0001": 3.19, "BASIC5000_0002": 0.9, "BASIC5000_0003": 4.5}
+    saved = (ref_jsut.listfiles, ref_jsut.name, ref_jsut.WAVConverter)
+
+    class _Conv:
+        def __init__(self, landing, bronze, fq): self.bronze = bronze
+        def run(self): return [(os.path.join(self.bronze, "basic5000", "wav", k + ".wav"), d) for k, d in durs.items()]
+    ref_jsut.listfiles = lambda root, pats=None: [tpath]
+    ref_jsut.name = lambda f: os.path.splitext(os.path.basename(f))[0]
+    ref_jsut.WAVConverter = _Conv
+    try:
+        etl = ref_jsut.JSUTDataset(16000).run(landing, "/bronze")
+        kept = etl.filter_duration(1, 5)
+        mpath, lpath = os.path.join(tmp, "etl_manifest.csv"), os.path.join(tmp, "etl_labels.csv")
+        kept.to_csv(mpath, index=False)                         # etl/__main__.py:55
+        etl.export_labels(lpath)
+        rec["etl"] = {"transcript_lines": lines, "durations": durs, "manifest_csv_text": open(mpath, encoding="utf-8").read(),
+                      "manifest_columns": list(kept.columns), "labels_csv_header": open(lpath, encoding="utf-8").read().splitlines()[0],
+                      "labels_set": sorted(pd.read_csv(lpath)["label"].tolist()),
+                      "clean_text": [[l, list(ref_jsut.JSUTDataset.clean_text(l.split(":")))] for l in lines]}
+    finally:
+        ref_jsut.listfiles, ref_jsut.name, ref_jsut.WAVConverter = saved
+    with open(os.path.join(out, "data_formats.json"), "w", encoding="utf-8") as f:
+        json.dump(rec, f, ensure_ascii=True, indent=0, sort_keys=True)
+    print("data_formats.json:", os.path.getsize(os.path.join(out, "data_formats.json")), "bytes")
+
+
+def _rank_iter(cls, src, b, world, rank, epoch):
+    smp = cls(src, batch_size=b, num_replicas=world, rank=rank)
+    smp.shuffle(epoch)
+    return list(smp)
+
+
 def main():
     DeepSpeech, blocks, functional = import_reference()
     torch.set_num_threads(4)
     out = HERE
     if "--only-decode" in sys.argv:
         gen_decode(out)
+        return
+    if "--only-data-formats" in sys.argv:
+        with tempfile.TemporaryDirectory() as tmp:
+            gen_data_formats(out, tmp)
         return
     if "--only-checkpoint" in sys.argv:
         with tempfile.TemporaryDirectory() as tmp:
@@ -321,6 +446,7 @@ def main():
         for name in MODELS:
             gen_model(out, name, DeepSpeech, tmp)
         gen_checkpoint(out, DeepSpeech, tmp)
+        gen_data_formats(out, tmp)
     for f in sorted(os.listdir(out)):
         if f.endswith((".npz", ".json")):
             print(f, os.path.getsize(os.path.join(out, f)))
