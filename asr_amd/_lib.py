@@ -22,15 +22,16 @@ SIGNATURES = {
     "ds2_version": (C.c_char_p, []),
     "ds2_last_error": (C.c_char_p, []),
     "ds2_device_info": (i32, [C.POINTER(i32), C.POINTER(i32), C.c_char_p, i32]),
-    "ds2_debug_flags": (i32, [i32]),
+    "ds2_debug_flags": (i32, [vp, i32]),
+    "ds2_rnn_ctx_init": (i32, [vp, vp, vp, vp]),
     "ds2_ablation_build": (i32, []),
-    "ds2_rnn_persistent_status": (i32, [vp]),
-    "ds2_rnn_persistent_counters": (i32, [vp]),
-    "ds2_rnn_poison_if_starved": (i32, [vp, sz, vp]),
-    "ds2_rnn_poison_seen": (i32, []),
-    "ds2_rnn_step_gate": (i32, [vp, vp, vp]),
-    "ds2_rnn_persistent_enable": (i32, [i32, i32]),
-    "ds2_rnn_last_path": (i32, []),
+    "ds2_rnn_persistent_status": (i32, [vp, vp]),
+    "ds2_rnn_persistent_counters": (i32, [vp, vp]),
+    "ds2_rnn_poison_if_starved": (i32, [vp, vp, sz, vp]),
+    "ds2_rnn_poison_seen": (i32, [vp]),
+    "ds2_rnn_step_gate": (i32, [vp, vp, vp, vp]),
+    "ds2_rnn_persistent_enable": (i32, [vp, i32, i32]),
+    "ds2_rnn_last_path": (i32, [vp]),
     "ds2_rnn_bwd_ksplit_footprint": (i32, [i32, i32, C.POINTER(i32)]),
     "ds2_gemm_f32_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "ds2_gemm_f32": (i32, [i32, i32, i32, i32, i32, vp, i32, i64, vp, i32, i64, vp, i32, i64, vp, i32, i32, i32, vp, sz, vp]),
@@ -90,13 +91,13 @@ SIGNATURES = {
     "ds2_rnn_packed_bytes": (sz, [i32, i32, i32, i32]),
     "ds2_rnn_pack_whh": (i32, [i32, vp, vp, vp, i32, i32, vp]),
     "ds2_rnn_fwd_workspace_bytes": (sz, [i32, i32, i32]),
-    "ds2_rnn_fwd_ex": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
-    "ds2_rnn_fwd": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, sz, vp]),
+    "ds2_rnn_fwd_ex": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
+    "ds2_rnn_fwd": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, sz, vp]),
     "ds2_rnn_bwd_workspace_bytes": (sz, [i32, i32, i32, i32]),
-    "ds2_rnn_bwd_ex": (i32, [i32, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, sz, vp]),
-    "ds2_rnn_bwd_bn": (i32, [i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, sz, vp]),
+    "ds2_rnn_bwd_ex": (i32, [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, sz, vp]),
+    "ds2_rnn_bwd_bn": (i32, [vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, sz, vp]),
     "ds2_rnn_bias_grads": (i32, [i32, vp, i32, i32, vp, vp, vp]),
-    "ds2_rnn_bwd": (i32, [i32, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
+    "ds2_rnn_bwd": (i32, [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
     "ds2_ctc_workspace_bytes": (sz, [i32, i32, i32]),
     "ds2_ctc_loss_f32": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, i32, f32, vp, sz, vp]),
     "ds2_ctc_batch_mean_f32": (i32, [vp, i32, vp, vp]),

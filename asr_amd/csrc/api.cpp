@@ -2,6 +2,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include "common.h"
+#include <string.h>
+#include <stdlib.h>
 
 static thread_local char g_ds2_err[1024] = "";
 
@@ -31,14 +33,26 @@ extern "C" int ds2_device_info(int* cu_count, int* wave_size, char* arch, int ar
 // wide step kernels, 64 = step kernels instead of the persistent ones, 128 = all-gather persistent backward instead of the K-split one.
 // Bits 1 / 2 (skip the h.W_hh product / the gate epilogue: scripts/ablate_rnn.py) SKIP WORK and exist only in a library built with
 // -DDS2_ABLATE (make ABLATE=1); the shipped library masks them off here and compiles the tests out of the kernels (rnn.hip).
-int g_ds2_debug_flags = 0;
-extern "C" int ds2_debug_flags(int flags) {
-  int old = g_ds2_debug_flags;
+extern "C" int ds2_debug_flags(ds2_rnn_ctx* ctx, int flags) {
+  if (!ctx) return ds2_set_error("ds2_debug_flags: null context");
+  int old = ctx->debug_flags;
 #ifndef DS2_ABLATE
   flags &= ~3;
 #endif
-  g_ds2_debug_flags = flags;
+  ctx->debug_flags = flags;
   return old;
+}
+// The recurrence's state lives with the caller (include/ds2hip.h): zero the struct, record where its device / pinned words are.
+extern "C" int ds2_rnn_ctx_init(ds2_rnn_ctx* ctx, int* status_dev, int* poison_host, int* poison_dev) {
+  if (!ctx || !status_dev) return ds2_set_error("ds2_rnn_ctx_init: ctx and status_dev are required");
+  if ((poison_host == nullptr) != (poison_dev == nullptr)) return ds2_set_error("ds2_rnn_ctx_init: poison_host and poison_dev go together");
+  memset(ctx, 0, sizeof(*ctx));
+  ctx->size = (int)sizeof(*ctx);
+  ctx->persist_fwd = ctx->persist_bwd = 1;
+  const char* env = getenv("DS2_RNN_REARM_CALLS");            // read here, once per context; never written
+  ctx->rearm_calls = env ? atoi(env) : 64;
+  ctx->status_dev = status_dev; ctx->poison_host = poison_host; ctx->poison_dev = poison_dev;
+  return 0;
 }
 extern "C" int ds2_ablation_build(void) {
 #ifdef DS2_ABLATE

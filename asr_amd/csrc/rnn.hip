@@ -33,7 +33,6 @@
 #include <type_traits>
 #include <algorithm>
 
-extern int g_ds2_debug_flags;
 
 namespace {
 
@@ -85,6 +84,10 @@ struct RnnArgs {
   const float *bn_mean, *bn_var, *bn_gamma, *bn_s0, *bn_s1;   // (H) batch statistics, weight, column sums of dy and of dy * xhat
   float bn_eps;
   int ldbnx;
+  // persistent kernels: the caller's starvation record (ds2_rnn_ctx.status_dev, 8 ints) — {set, block x, y, z, step, wave, ok-mask lo, hi} of the
+  // first wave that gave up polling; and (host side only, never dereferenced on the device) the context itself
+  int* status;
+  ds2_rnn_ctx* hctx;
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -453,7 +456,6 @@ typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
 //  own stores but cannot see inside inline asm, and back-to-back publishes then shipped partly overwritten payloads)
 __device__ __forceinline__ void store16_sc1(void* p, u32x4_ v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" ::"v"(p), "v"(v) : "memory"); }
 constexpr unsigned PSENT = 0xffffffffu;
-__device__ int g_persist_dbg[8];      // first starved wave of a persistent launch: {set, block x, y, z, step, wave, ok-mask lo, hi}
 
 // `s_waitcnt vmcnt(0)` in the form the compiler's own wait-insertion pass understands: after it, the scoreboard knows that every vector
 // load issued so far has landed.  Placed right behind the gather (whose asm statement has really waited, invisibly to the compiler) and in
@@ -594,9 +596,9 @@ __device__ __forceinline__ PRole persist_role(const RnnArgs& a, unsigned* census
         } else {
           by_id(g, sl);
         }
-      } else if (atomicCAS(&g_persist_dbg[0], 0, 3) == 0) {     // the grid never became resident: record it (the host raises), leave
-        g_persist_dbg[1] = wg; g_persist_dbg[2] = (int)xcc; g_persist_dbg[3] = kind; g_persist_dbg[4] = -1; g_persist_dbg[5] = 0;
-        g_persist_dbg[6] = (int)__hip_atomic_load(&census[8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1; g_persist_dbg[7] = 0;
+      } else if (atomicCAS(&a.status[0], 0, 3) == 0) {     // the grid never became resident: record it (the host raises), leave
+        a.status[1] = wg; a.status[2] = (int)xcc; a.status[3] = kind; a.status[4] = -1; a.status[5] = 0;
+        a.status[6] = (int)__hip_atomic_load(&census[8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1; a.status[7] = 0;
         __threadfence_system();
       }
       s_role[0] = g; s_role[1] = sl; s_role[2] = loc;
@@ -764,9 +766,9 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
         if (pend && ++spins > spin_limit) {
           // record who starved and on what (first failure only); the host raises at the step's sync point (no __builtin_trap: hipcc sinks
           // a trap to the kernel's common exit block, where it then fires on NORMAL completion too)
-          if (lane == 0 && atomicCAS(&g_persist_dbg[0], 0, 1) == 0) {
-            g_persist_dbg[1] = slice; g_persist_dbg[2] = bt; g_persist_dbg[3] = dir; g_persist_dbg[4] = s; g_persist_dbg[5] = wave;
-            g_persist_dbg[6] = (int)pend; g_persist_dbg[7] = l2_local;
+          if (lane == 0 && atomicCAS(&a.status[0], 0, 1) == 0) {
+            a.status[1] = slice; a.status[2] = bt; a.status[3] = dir; a.status[4] = s; a.status[5] = wave;
+            a.status[6] = (int)pend; a.status[7] = l2_local;
             __threadfence_system();
           }
           return;
@@ -1249,9 +1251,9 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_persistent_kernel(RnnArgs a, 
         pend = __builtin_amdgcn_readfirstlane(pend);
         if (pend && ++spins > spin_limit) {
           // record who starved and on what (first failure only); the host raises at the step's sync point
-          if (lane == 0 && atomicCAS(&g_persist_dbg[0], 0, 2) == 0) {
-            g_persist_dbg[1] = slice; g_persist_dbg[2] = bt; g_persist_dbg[3] = dir; g_persist_dbg[4] = s; g_persist_dbg[5] = wave;
-            g_persist_dbg[6] = (int)pend; g_persist_dbg[7] = l2_local;
+          if (lane == 0 && atomicCAS(&a.status[0], 0, 2) == 0) {
+            a.status[1] = slice; a.status[2] = bt; a.status[3] = dir; a.status[4] = s; a.status[5] = wave;
+            a.status[6] = (int)pend; a.status[7] = l2_local;
             __threadfence_system();
           }
           return;
@@ -1455,23 +1457,21 @@ inline int pick_mb(int B, int H) {
   return ((long long)nsl * ceil_div(B, 32) * 2 >= 200) ? 2 : 1;
 }
 
-// which persistent kernels may be used (ds2_rnn_persistent_enable): the backward one must be switched off by a caller that runs
-// collectives on another stream during backward, because a persistent launch needs every one of its workgroups resident at once
-int g_persist_fwd = 1, g_persist_bwd = 1;
-int g_last_path = 0;                    // bit 0 / bit 1: the last ds2_rnn_fwd / ds2_rnn_bwd call took a persistent kernel; bit 2: the K-split one
-int g_last_bwd_kind = 0;                // 0 step kernels, 1 all-gather persistent, 2 K-split persistent
-// After a starved launch (ds2_rnn_persistent_status) the next g_persist_cooldown recurrence calls take the one-launch-per-step kernels,
-// then the persistent kernels are armed again: a transient (another process or stream holding CUs for a moment) costs a few slow steps,
-// not the rest of the run.  DS2_RNN_REARM_CALLS sets the length (default 64 calls = 6 train steps of a 5-layer model; 0 = never re-arm).
-int g_persist_cooldown = 0;
-int g_persist_starved_total = 0;        // launches that starved since the library was loaded (reporting)
-bool persist_allowed(bool bwd) {
-  if (g_persist_cooldown != 0) {
-    if (g_persist_cooldown > 0) --g_persist_cooldown;
+// Which persistent kernels may be used, the cooldown after a starved launch, what the last call took: all of it lives in the CALLER's
+// ds2_rnn_ctx (include/ds2hip.h) — the library keeps no mutable global state.  After a starved launch (ds2_rnn_persistent_status) the next
+// ctx->rearm_calls recurrence calls through that context take the one-launch-per-step kernels, then the persistent kernels are armed again: a
+// transient (another process or stream holding CUs for a moment) costs a few slow steps, not the rest of the run.  The backward kernel must
+// be switched off (ds2_rnn_persistent_enable) by a caller that runs collectives on another stream during backward, because a persistent
+// launch needs every one of its workgroups resident at once.  No context: no persistent launch.
+bool persist_allowed(ds2_rnn_ctx* c, bool bwd) {
+  if (!c || !c->status_dev) return false;
+  if (c->cooldown != 0) {
+    if (c->cooldown > 0) --c->cooldown;
     return false;
   }
-  return bwd ? g_persist_bwd != 0 : g_persist_fwd != 0;
+  return bwd ? c->persist_bwd != 0 : c->persist_fwd != 0;
 }
+bool persist_idle(const ds2_rnn_ctx* c, bool bwd) { return c && c->status_dev && c->cooldown == 0 && (bwd ? c->persist_bwd : c->persist_fwd) != 0; }
 
 // bytes of ONE packed h buffer of the forward recurrence ([2 dirs][tiles][chunks][1 KiB]); the persistent kernel uses four
 size_t fwd_xbuf_bytes(int B, int H, int bf16) { return (size_t)2 * (ceil_div(B, 32) * 2) * ceil_div(H, bf16 ? 32 : 16) * 1024; }
@@ -1506,7 +1506,7 @@ int try_launch_persistent_fwd(RnnArgs a, hipStream_t st) {
   static const char* env = getenv("DS2_RNN_PERSISTENT");          // "0" = always the step kernels (A/B runs, debugging)
   if (env && env[0] == '0') return 0;
   if (a.dbg & ~128) return 0;                                     // any selector but 128 (= no K-split backward) selects the step kernels
-  if ((a.H % 16) != 0 || a.T < 2 || !persist_allowed(false)) return 0;
+  if ((a.H % 16) != 0 || a.T < 2 || !persist_allowed(a.hctx, false)) return 0;
   const int nsl = a.H / 16;
   const int nch = ceil_div(a.H, kchunk<BF>());
   int ncw = ceil_div(nch, NW);
@@ -1578,7 +1578,7 @@ int try_launch_persistent_bwd(RnnArgs a, hipStream_t st) {
   if ((env && env[0] == '0') || (a.dbg & ~128)) return 0;
   // buffers: either the bf16 training path's (packed gate records in, bf16 dGx out) or the plain ones (gates in gx, dGx in place)
   if (!((a.gates_bf && a.dgx_bf) || (!a.gates_bf && !a.dgx_bf && a.gx))) return 0;
-  if ((a.H % 16) != 0 || a.T < 2 || !persist_allowed(true)) return 0;
+  if ((a.H % 16) != 0 || a.T < 2 || !persist_allowed(a.hctx, true)) return 0;
   int mb = pick_mb(a.B, a.H);
   const int nsl = a.H / 16;
   const int nchb = ceil_div(G * a.H, kchunk<BF>());
@@ -1646,7 +1646,7 @@ __device__ __forceinline__ void store16_base(const char* base, unsigned off, u32
 
 template <int G, bool BF, bool SP = false>
 int launch_steps(bool bwd, RnnArgs a, hipStream_t st) {
-  a.dbg = g_ds2_debug_flags;
+  a.dbg = a.hctx ? a.hctx->debug_flags : 0;
   int mb = pick_mb(a.B, a.H);
   a.nsl = ceil_div(a.H, 16);
   // backward: the moving operand (dGh, G*H wide, FRESH from the previous launch = through the fabric) costs about twice as much
@@ -1732,30 +1732,21 @@ extern "C" int ds2_rnn_pack_whh(int gates, const float* whh, void* wp_fwd, void*
   return 0;
 }
 
-namespace {
-// host-visible "a poison kernel fired" word (pinned, mapped): lets a caller that never synchronises notice, with a plain host read, that
-// it has been handed NaN logits since the last ds2_rnn_persistent_status — and settle (raise, start the cooldown) before its next launch
-int* g_poison_host = nullptr;          // host address
-int* g_poison_dev = nullptr;           // the same word as the device sees it
-}  // namespace
-
 // status of the persistent forward kernel since the last call: 8 ints {starved, block x, y, z, step, wave, ok-mask lo, hi}; out8[0] != 0
 // if a wave ever gave up polling for its operand (results of that launch are then invalid).  Synchronises the device, clears the record.
-extern "C" int ds2_rnn_persistent_status(int* out8) {
+extern "C" int ds2_rnn_persistent_status(ds2_rnn_ctx* ctx, int* out8) {
+  DS2_REQUIRE(ctx && ctx->status_dev && out8, "ds2_rnn_persistent_status: null pointer");
   DS2_HIP(hipDeviceSynchronize());
-  DS2_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_persist_dbg), 8 * sizeof(int)));
+  DS2_HIP(hipMemcpy(out8, ctx->status_dev, 8 * sizeof(int), hipMemcpyDeviceToHost));
   if (out8[0]) {
     // a launch starved (not every workgroup could be resident, or something else held CUs): the step that starved is invalid and must be
-    // reported as failed; the next calls take the one-launch-per-step kernels so that the caller's retry / next steps work, then the
-    // persistent kernels are armed again (see g_persist_cooldown)
-    static const char* env = getenv("DS2_RNN_REARM_CALLS");
-    const int n = env ? atoi(env) : 64;
-    g_persist_cooldown = n > 0 ? n : -1;
-    ++g_persist_starved_total;
-    int zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    DS2_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_persist_dbg), zero, sizeof(zero)));
+    // reported as failed; the next calls through this context take the one-launch-per-step kernels so that the caller's retry / next steps
+    // work, then the persistent kernels are armed again (ctx->rearm_calls)
+    ctx->cooldown = ctx->rearm_calls > 0 ? ctx->rearm_calls : -1;
+    ++ctx->starved_total;
+    DS2_HIP(hipMemset(ctx->status_dev, 0, 8 * sizeof(int)));
   }
-  if (g_poison_host) *(volatile int*)g_poison_host = 0;      // (the device is idle: no poison kernel is in flight)
+  if (ctx->poison_host) *(volatile int*)ctx->poison_host = 0;      // (the device is idle: no poison kernel is in flight)
   return 0;
 }
 
@@ -1774,7 +1765,7 @@ extern "C" size_t ds2_rnn_fwd_workspace_bytes(int B, int H, int bf16) {
 //   hbuf   (T,B,2,H) out: h per direction (0 beyond each sample's length)
 //   aux    (T,B,2,H) out: GRU W_hn h + b_hn ; LSTM cell state
 //   h_bf16 optional (T,B,2,H) bf16: a bf16 copy of hbuf, written by a PERSISTENT launch only (ds2_rnn_last_path() & 1 after the call)
-extern "C" int ds2_rnn_fwd_ex(int gates, float* gx, const void* wp_fwd, const float* bhh, float* hbuf, float* aux, const int* lens_dev, int T,
+extern "C" int ds2_rnn_fwd_ex(ds2_rnn_ctx* ctx, int gates, float* gx, const void* wp_fwd, const float* bhh, float* hbuf, float* aux, const int* lens_dev, int T,
                               int B, int H, int bf16, void* gates_bf16, void* h_bf16, void* ws, size_t ws_bytes, void* stream) {
   DS2_REQUIRE(gates == 3 || gates == 4, "ds2_rnn_fwd: gates must be 3 (GRU) or 4 (LSTM)");
   DS2_REQUIRE(gx && wp_fwd && bhh && hbuf && aux && lens_dev, "ds2_rnn_fwd: null pointer");
@@ -1783,19 +1774,22 @@ extern "C" int ds2_rnn_fwd_ex(int gates, float* gx, const void* wp_fwd, const fl
   RnnArgs a{};
   a.gx = gx; a.aux = aux; a.hbuf = hbuf; a.wp = (const float*)wp_fwd; a.bhh = bhh; a.pk = (float*)ws; a.lens = lens_dev;
   a.T = T; a.B = B; a.H = H; a.gates_bf = (__bf16*)gates_bf16; a.h_bf = (__bf16*)h_bf16;
+  a.hctx = ctx; a.status = ctx ? ctx->status_dev : nullptr;
+  int scratch_path = 0;
+  int& last_path = ctx ? ctx->last_path : scratch_path;
   {
-    a.dbg = g_ds2_debug_flags;
+    a.dbg = ctx ? ctx->debug_flags : 0;
     hipStream_t st = (hipStream_t)stream;
     int rc = 0;
     if (bf16 == 2) {
       // fp32 mode, split forward recurrence: operands behind the fp32 fragments of wp_fwd (ds2_rnn_packed_bytes(.., 0, 2)); where its shape
       // does not qualify (or during a cooldown, which the fp32 attempt below counts) the fp32 kernels take the call with the fp32 fragments
       static const char* env = getenv("DS2_F32_RNN");              // "f32": never the split kernel (A/B runs)
-      if (g_persist_cooldown == 0 && g_persist_fwd && !(env && env[0] == 'f') && !a.gates_bf) {
+      if (persist_idle(ctx, false) && !(env && env[0] == 'f') && !a.gates_bf) {
         RnnArgs b = a;
         b.wp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(wp_fwd) + ds2_rnn_packed_bytes(gates, H, 0, 0));
         b.dbg &= ~256;
-        g_last_path &= ~256;
+        last_path &= ~256;
         if (!(a.dbg & 256))                                         // (debug flag 256: prefer the 10-unit kernel where its shape qualifies)
           rc = gates == 3 ? try_launch_persistent_fwd<3, true, true>(b, st) : try_launch_persistent_fwd<4, true, true>(b, st);
         if (rc == 0 && u10_shape_ok(H)) {
@@ -1803,17 +1797,17 @@ extern "C" int ds2_rnn_fwd_ex(int gates, float* gx, const void* wp_fwd, const fl
           b.wp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(wp_fwd) + ds2_rnn_packed_bytes(gates, H, 0, 0) +
                                                 2 * ds2_rnn_packed_bytes(gates, H, 0, 1));
           rc = gates == 3 ? try_launch_fwd_u10<3>(b, st) : try_launch_fwd_u10<4>(b, st);
-          if (rc == 1) g_last_path |= 256;                          // bit 8: the 10-unit kernel
+          if (rc == 1) last_path |= 256;                          // bit 8: the 10-unit kernel
         }
-        if (rc == 1) g_last_path |= 32;                             // bit 5: a split kernel took the call
+        if (rc == 1) last_path |= 32;                             // bit 5: a split kernel took the call
       }
-      if (rc == 0) { g_last_path &= ~32; a.dbg &= ~256; rc = gates == 3 ? try_launch_persistent_fwd<3, false>(a, st) : try_launch_persistent_fwd<4, false>(a, st); }
+      if (rc == 0) { last_path &= ~32; a.dbg &= ~256; rc = gates == 3 ? try_launch_persistent_fwd<3, false>(a, st) : try_launch_persistent_fwd<4, false>(a, st); }
     } else {
-      g_last_path &= ~(32 | 256);
+      last_path &= ~(32 | 256);
       rc = bf16 ? (gates == 3 ? try_launch_persistent_fwd<3, true>(a, st) : try_launch_persistent_fwd<4, true>(a, st))
                 : (gates == 3 ? try_launch_persistent_fwd<3, false>(a, st) : try_launch_persistent_fwd<4, false>(a, st));
     }
-    g_last_path = (g_last_path & ~1) | (rc == 1 ? 1 : 0);
+    last_path = (last_path & ~1) | (rc == 1 ? 1 : 0);
     if (rc != 0) return rc < 0 ? rc : 0;
   }
   // step kernels: zero padding rows / columns of the ping-pong buffers (the persistent path has filled its own with the sentinel)
@@ -1821,9 +1815,9 @@ extern "C" int ds2_rnn_fwd_ex(int gates, float* gx, const void* wp_fwd, const fl
   return bf16 == 1 ? dispatch<true>(gates, false, a, (hipStream_t)stream) : dispatch<false>(gates, false, a, (hipStream_t)stream);
 }
 
-extern "C" int ds2_rnn_fwd(int gates, float* gx, const void* wp_fwd, const float* bhh, float* hbuf, float* aux, const int* lens_dev, int T,
+extern "C" int ds2_rnn_fwd(ds2_rnn_ctx* ctx, int gates, float* gx, const void* wp_fwd, const float* bhh, float* hbuf, float* aux, const int* lens_dev, int T,
                            int B, int H, int bf16, void* gates_bf16, void* ws, size_t ws_bytes, void* stream) {
-  return ds2_rnn_fwd_ex(gates, gx, wp_fwd, bhh, hbuf, aux, lens_dev, T, B, H, bf16, gates_bf16, nullptr, ws, ws_bytes, stream);
+  return ds2_rnn_fwd_ex(ctx, gates, gx, wp_fwd, bhh, hbuf, aux, lens_dev, T, B, H, bf16, gates_bf16, nullptr, ws, ws_bytes, stream);
 }
 
 // bias gradients from the per-batch-row sums of the persistent backward kernel: part (B,2,4,H) -> db_ih (2,G*H), db_hh (2,G*H).
@@ -1870,38 +1864,31 @@ extern "C" size_t ds2_rnn_bwd_workspace_bytes(int gates, int B, int H, int bf16)
 // at once, so a caller that runs other kernels concurrently on the device during backward (collectives on a communication stream)
 // must switch the backward one off.  DS2_RNN_PERSISTENT=0 in the environment switches both off.
 // which kernel family the last recurrence calls used: bit 0 = ds2_rnn_fwd, bit 1 = ds2_rnn_bwd took the persistent kernel (reporting only)
-extern "C" int ds2_rnn_last_path(void) { return g_last_path; }
+extern "C" int ds2_rnn_last_path(const ds2_rnn_ctx* ctx) { return ctx ? ctx->last_path : 0; }
 
 namespace {
-__global__ void step_gate_kernel(const float* __restrict__ loss, int* __restrict__ flag) {
+__global__ void step_gate_kernel(const float* __restrict__ loss, int* __restrict__ flag, const int* __restrict__ status) {
   const float l = *loss;
   // 1 = apply the update; 0 = this rank's loss is not valid; -1 = a persistent recurrence launch of this rank starved.  The MIN over the
   // ranks then tells EVERY rank which of the two happened somewhere (the trainer restores BatchNorm statistics on all ranks after a -1).
-  *flag = g_persist_dbg[0] != 0 ? -1 : ((l == l && l != __builtin_inff() && l != -__builtin_inff() && l >= 0.f) ? 1 : 0);
+  *flag = (status && status[0] != 0) ? -1 : ((l == l && l != __builtin_inff() && l != -__builtin_inff() && l >= 0.f) ? 1 : 0);
 }
 }  // namespace
 
 // flag[0] = 1 if the train step enqueued so far on `stream` is valid when this kernel RUNS: the loss (device scalar) is finite and
 // non-negative (functional.py:45-61) and no persistent recurrence launch has recorded starvation; 0 for an invalid loss, -1 for starvation.  Consumed on the device by
 // ds2_adamw_gated_f32 (and, under data parallelism, all-reduced with MIN first), read back by the host whenever convenient.
-extern "C" int ds2_rnn_step_gate(const float* loss_dev, int* flag_dev, void* stream) {
+extern "C" int ds2_rnn_step_gate(const ds2_rnn_ctx* ctx, const float* loss_dev, int* flag_dev, void* stream) {
   DS2_REQUIRE(loss_dev && flag_dev, "ds2_rnn_step_gate: null pointer");
-  hipLaunchKernelGGL(step_gate_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, loss_dev, flag_dev);
+  hipLaunchKernelGGL(step_gate_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, loss_dev, flag_dev, ctx ? (const int*)ctx->status_dev : (const int*)nullptr);
   DS2_LAUNCH_CHECK("step_gate_kernel");
   return 0;
 }
 
 namespace {
-int poison_flag_init() {
-  if (g_poison_host) return 0;
-  DS2_HIP(hipHostMalloc((void**)&g_poison_host, 64, hipHostMallocMapped));
-  *g_poison_host = 0;
-  DS2_HIP(hipHostGetDevicePointer((void**)&g_poison_dev, g_poison_host, 0));
-  return 0;
-}
-__global__ void poison_if_starved_kernel(float* __restrict__ buf, long long n, int* __restrict__ seen) {
-  if (g_persist_dbg[0] == 0) return;
-  if (blockIdx.x == 0 && threadIdx.x == 0) { *seen = 1; __threadfence_system(); }
+__global__ void poison_if_starved_kernel(float* __restrict__ buf, long long n, const int* __restrict__ status, int* __restrict__ seen) {
+  if (status[0] == 0) return;
+  if (seen && blockIdx.x == 0 && threadIdx.x == 0) { *seen = 1; __threadfence_system(); }
   const float qnan = __builtin_nanf("");
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) buf[i] = qnan;
 }
@@ -1910,19 +1897,18 @@ __global__ void poison_if_starved_kernel(float* __restrict__ buf, long long n, i
 // Inference without a host synchronisation: if a persistent recurrence launch enqueued before this call on `stream` has recorded
 // starvation (its activations are invalid), overwrite buf[0..n) with NaN — in stream order, without reading or clearing the record.  The
 // caller's next ds2_rnn_persistent_status (at a point where it synchronises anyway) raises; until then nothing plausible-looking leaves.
-extern "C" int ds2_rnn_poison_if_starved(float* buf, size_t n, void* stream) {
-  DS2_REQUIRE(buf || n == 0, "ds2_rnn_poison_if_starved: null pointer");
+extern "C" int ds2_rnn_poison_if_starved(ds2_rnn_ctx* ctx, float* buf, size_t n, void* stream) {
+  DS2_REQUIRE(ctx && ctx->status_dev && (buf || n == 0), "ds2_rnn_poison_if_starved: null pointer");
   if (n == 0) return 0;
-  if (poison_flag_init()) return -1;
   const int blocks = (int)std::min<size_t>((n + 255) / 256, 1024);
-  hipLaunchKernelGGL(poison_if_starved_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, buf, (long long)n, g_poison_dev);
+  hipLaunchKernelGGL(poison_if_starved_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, buf, (long long)n, (const int*)ctx->status_dev, ctx->poison_dev);
   DS2_LAUNCH_CHECK("poison_if_starved_kernel");
   return 0;
 }
 
 // 1 if a ds2_rnn_poison_if_starved kernel has overwritten a buffer since the last ds2_rnn_persistent_status (a host memory read: no
 // synchronisation, no device call); the caller should then call ds2_rnn_persistent_status, which reports, clears and starts the cooldown.
-extern "C" int ds2_rnn_poison_seen(void) { return g_poison_host ? *(volatile int*)g_poison_host : 0; }
+extern "C" int ds2_rnn_poison_seen(const ds2_rnn_ctx* ctx) { return (ctx && ctx->poison_host) ? *(volatile int*)ctx->poison_host : 0; }
 
 // What a workgroup of the K-split persistent backward recurrence occupies, from the binary that is loaded: out3 = {registers per lane
 // (hipFuncGetAttributes), static LDS bytes, threads}.  Returns 1 if this (gates, H) shape has a K-split instance, 0 if not.  The host
@@ -1948,16 +1934,18 @@ extern "C" int ds2_rnn_bwd_ksplit_footprint(int gates, int H, int* out3) {
   return 1;
 }
 
-extern "C" int ds2_rnn_persistent_enable(int forward, int backward) {
-  g_persist_fwd = forward != 0;
-  g_persist_bwd = backward != 0;
+extern "C" int ds2_rnn_persistent_enable(ds2_rnn_ctx* ctx, int forward, int backward) {
+  DS2_REQUIRE(ctx, "ds2_rnn_persistent_enable: null context");
+  ctx->persist_fwd = forward != 0;
+  ctx->persist_bwd = backward != 0;
   return 0;
 }
 
-// {launches that starved since load, recurrence calls left on the step kernels before the persistent ones are armed again (-1: never)}
-extern "C" int ds2_rnn_persistent_counters(int* out2) {
-  out2[0] = g_persist_starved_total;
-  out2[1] = g_persist_cooldown;
+// {launches through this context that starved, recurrence calls left on the step kernels before the persistent ones are armed again (-1: never)}
+extern "C" int ds2_rnn_persistent_counters(const ds2_rnn_ctx* ctx, int* out2) {
+  DS2_REQUIRE(ctx && out2, "ds2_rnn_persistent_counters: null pointer");
+  out2[0] = ctx->starved_total;
+  out2[1] = ctx->cooldown;
   return 0;
 }
 
@@ -1970,7 +1958,7 @@ extern "C" int ds2_rnn_persistent_counters(int* out2) {
 //   dhn_bf16  optional (T,B,2,H) bf16 (GRU): a bf16 copy of the d(hn) written into aux          } written by a PERSISTENT launch only
 //   bias_part optional (B,2,4,H) fp32: per-batch-row sums over time of [d r, d z, d n, d(hn)] (GRU)  } (ds2_rnn_last_path() & 2 after the
 //             / [d i, d f, d g, d o] (LSTM); their column sums over B are db_ih / db_hh             } call); untouched otherwise
-extern "C" int ds2_rnn_bwd_ex(int gates, const float* dy, int lddy, float* gx, float* aux, const float* hbuf, const void* wp_bwd,
+extern "C" int ds2_rnn_bwd_ex(ds2_rnn_ctx* ctx, int gates, const float* dy, int lddy, float* gx, float* aux, const float* hbuf, const void* wp_bwd,
                               const int* lens_dev, int T, int B, int H, int bf16, void* dgx_bf16, const void* gates_bf16, void* dhn_bf16,
                               float* bias_part, void* ws, size_t ws_bytes, void* stream) {
   DS2_REQUIRE(gates == 3 || gates == 4, "ds2_rnn_bwd: gates must be 3 (GRU) or 4 (LSTM)");
@@ -1985,36 +1973,40 @@ extern "C" int ds2_rnn_bwd_ex(int gates, const float* dy, int lddy, float* gx, f
   a.gates_bf = (__bf16*)const_cast<void*>(gates_bf16);
   a.dhn_bf = (__bf16*)dhn_bf16; a.bsum = bias_part;
   a.lens = lens_dev; a.T = T; a.B = B; a.H = H;
+  a.hctx = ctx; a.status = ctx ? ctx->status_dev : nullptr;
+  int scratch_path = 0, scratch_kind = 0;
+  int& last_path = ctx ? ctx->last_path : scratch_path;
+  int& last_bwd_kind = ctx ? ctx->last_bwd_kind : scratch_kind;
   {
-    a.dbg = g_ds2_debug_flags;
+    a.dbg = ctx ? ctx->debug_flags : 0;
     hipStream_t st = (hipStream_t)stream;
     // bf16: the K-split kernel where the shape qualifies (2 = it does, but a starved launch's cooldown is running: step kernels)
     int rc = bf16 == 1 ? (gates == 3 ? try_launch_ksplit_bwd<3>(a, st) : try_launch_ksplit_bwd<4>(a, st)) : 0;
-    g_last_bwd_kind = rc == 1 ? 2 : 0;
+    last_bwd_kind = rc == 1 ? 2 : 0;
     bool split = false;
     if (rc == 0 && bf16 == 2) {
       // fp32 mode, split backward recurrence (operands behind the fp32 fragments of wp_bwd); else / during a cooldown the fp32 kernels
       static const char* env = getenv("DS2_F32_RNN");
-      if (g_persist_cooldown == 0 && g_persist_bwd && !(env && env[0] == 'f') && !a.gates_bf && !a.dgx_bf) {
+      if (persist_idle(ctx, true) && !(env && env[0] == 'f') && !a.gates_bf && !a.dgx_bf) {
         RnnArgs b = a;
         b.wp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(wp_bwd) + ds2_rnn_packed_bytes(gates, H, 1, 0));
         static const char* envk = getenv("DS2_RNN_KSPLIT");
         const int rk = (envk && envk[0] == '0') ? 0 : (gates == 3 ? try_launch_ksplit_bwd<3, true>(b, st) : try_launch_ksplit_bwd<4, true>(b, st));
         if (rk < 0) return rk;
-        if (rk == 1) { rc = 1; split = true; g_last_bwd_kind = 2; }
+        if (rk == 1) { rc = 1; split = true; last_bwd_kind = 2; }
         else {
           rc = gates == 3 ? try_launch_persistent_bwd<3, true, true>(b, st) : try_launch_persistent_bwd<4, true, true>(b, st);
           split = rc == 1;
-          if (split) g_last_bwd_kind = 1;
+          if (split) last_bwd_kind = 1;
         }
       }
     }
     if (rc == 0) {
       rc = bf16 == 1 ? (gates == 3 ? try_launch_persistent_bwd<3, true>(a, st) : try_launch_persistent_bwd<4, true>(a, st))
                      : (gates == 3 ? try_launch_persistent_bwd<3, false>(a, st) : try_launch_persistent_bwd<4, false>(a, st));
-      g_last_bwd_kind = rc == 1 ? 1 : 0;
+      last_bwd_kind = rc == 1 ? 1 : 0;
     }
-    g_last_path = (g_last_path & ~(6 | 16 | 64)) | (rc == 1 ? 2 : 0) | (g_last_bwd_kind == 2 ? 4 : 0) | (split ? 64 : 0);   // bit 6: the split kernel
+    last_path = (last_path & ~(6 | 16 | 64)) | (rc == 1 ? 2 : 0) | (last_bwd_kind == 2 ? 4 : 0) | (split ? 64 : 0);   // bit 6: the split kernel
     if (rc != 0 && rc != 2) return rc < 0 ? rc : 0;
   }
   DS2_HIP(hipMemsetAsync(ws, 0, ds2_rnn_bwd_workspace_bytes(gates, B, H, bf16), (hipStream_t)stream));   // step kernels: zero carry + padding
@@ -2023,7 +2015,7 @@ extern "C" int ds2_rnn_bwd_ex(int gates, const float* dy, int lddy, float* gx, f
     static const char* env = getenv("DS2_F32_RNN");
     if (!(env && env[0] == 'f') && !(a.dbg & ~128)) {
       a.wp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(wp_bwd) + ds2_rnn_packed_bytes(gates, H, 1, 0));
-      g_last_path |= 64;                                            // bit 6 without bit 1: split step kernels
+      last_path |= 64;                                            // bit 6 without bit 1: split step kernels
       return gates == 3 ? launch_steps<3, true, true>(true, a, (hipStream_t)stream) : launch_steps<4, true, true>(true, a, (hipStream_t)stream);
     }
   }
@@ -2037,7 +2029,7 @@ extern "C" int ds2_rnn_bwd_ex(int gates, const float* dy, int lddy, float* gx, f
 // elementwise half of the BatchNorm backward is applied on the fly to the one value a (row, unit) pair needs per step (bit 16 of
 // ds2_rnn_last_path()) — no pass over (T*B, H); otherwise it is materialised into dy_scratch (T*B, H) first and the call proceeds as
 // ds2_rnn_bwd_ex(dy = dy_scratch).
-extern "C" int ds2_rnn_bwd_bn(int gates, const float* dyn, int lddyn, const float* bn_x, int ldx, const float* bn_mean, const float* bn_var,
+extern "C" int ds2_rnn_bwd_bn(ds2_rnn_ctx* ctx, int gates, const float* dyn, int lddyn, const float* bn_x, int ldx, const float* bn_mean, const float* bn_var,
                               const float* bn_gamma, const float* bn_s0, const float* bn_s1, float bn_eps, float* dy_scratch, float* gx,
                               float* aux, const float* hbuf, const void* wp_bwd, const int* lens_dev, int T, int B, int H, int bf16,
                               void* dgx_bf16, const void* gates_bf16, void* dhn_bf16, float* bias_part, void* ws, size_t ws_bytes,
@@ -2057,13 +2049,14 @@ extern "C" int ds2_rnn_bwd_bn(int gates, const float* dyn, int lddyn, const floa
     a.dhn_bf = (__bf16*)dhn_bf16; a.bsum = bias_part;
     a.lens = lens_dev; a.T = T; a.B = B; a.H = H;
     a.bn_x = bn_x; a.ldbnx = ldx; a.bn_mean = bn_mean; a.bn_var = bn_var; a.bn_gamma = bn_gamma; a.bn_s0 = bn_s0; a.bn_s1 = bn_s1; a.bn_eps = bn_eps;
-    a.dbg = g_ds2_debug_flags;
+    a.hctx = ctx; a.status = ctx ? ctx->status_dev : nullptr;
+    a.dbg = ctx ? ctx->debug_flags : 0;
     // (only when the persistent backward is armed: a cool-down call is counted once, by the un-fused call below)
-    const int rc = (g_persist_cooldown == 0 && g_persist_bwd) ? (gates == 3 ? try_launch_ksplit_bwd<3>(a, st) : try_launch_ksplit_bwd<4>(a, st)) : 0;
+    const int rc = persist_idle(ctx, true) ? (gates == 3 ? try_launch_ksplit_bwd<3>(a, st) : try_launch_ksplit_bwd<4>(a, st)) : 0;
     if (rc < 0) return rc;
     if (rc == 1) {
-      g_last_bwd_kind = 2;
-      g_last_path = (g_last_path & ~(2 | 4 | 16)) | 2 | 4 | 16;
+      ctx->last_bwd_kind = 2;
+      ctx->last_path = (ctx->last_path & ~(2 | 4 | 16)) | 2 | 4 | 16;
       return 0;
     }
   }
@@ -2072,15 +2065,15 @@ extern "C" int ds2_rnn_bwd_bn(int gates, const float* dyn, int lddyn, const floa
   if (!dy_scratch) return 1;
   int rc = ds2i_bn1d_bwd_apply(dyn, lddyn, bn_x, ldx, dy_scratch, H, T * B, H, bn_mean, bn_var, bn_gamma, bn_s0, bn_s1, bn_eps, st);
   if (rc) return rc;
-  rc = ds2_rnn_bwd_ex(gates, dy_scratch, H, gx, aux, hbuf, wp_bwd, lens_dev, T, B, H, bf16, dgx_bf16, gates_bf16, dhn_bf16, bias_part, ws, ws_bytes,
+  rc = ds2_rnn_bwd_ex(ctx, gates, dy_scratch, H, gx, aux, hbuf, wp_bwd, lens_dev, T, B, H, bf16, dgx_bf16, gates_bf16, dhn_bf16, bias_part, ws, ws_bytes,
                       stream);
-  g_last_path &= ~16;
+  if (ctx) ctx->last_path &= ~16;
   return rc;
 }
 
-extern "C" int ds2_rnn_bwd(int gates, const float* dy, int lddy, float* gx, float* aux, const float* hbuf, const void* wp_bwd,
+extern "C" int ds2_rnn_bwd(ds2_rnn_ctx* ctx, int gates, const float* dy, int lddy, float* gx, float* aux, const float* hbuf, const void* wp_bwd,
                            const int* lens_dev, int T, int B, int H, int bf16, void* dgx_bf16, const void* gates_bf16, void* ws, size_t ws_bytes,
                            void* stream) {
-  return ds2_rnn_bwd_ex(gates, dy, lddy, gx, aux, hbuf, wp_bwd, lens_dev, T, B, H, bf16, dgx_bf16, gates_bf16, nullptr, nullptr, ws, ws_bytes,
+  return ds2_rnn_bwd_ex(ctx, gates, dy, lddy, gx, aux, hbuf, wp_bwd, lens_dev, T, B, H, bf16, dgx_bf16, gates_bf16, nullptr, nullptr, ws, ws_bytes,
                         stream);
 }

@@ -274,9 +274,9 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char
           }
         pend = __builtin_amdgcn_readfirstlane(pend);
         if (pend && ++spins > spin_limit) {
-          if (lane == 0 && atomicCAS(&g_persist_dbg[0], 0, 2) == 0) {
-            g_persist_dbg[1] = slice; g_persist_dbg[2] = bt; g_persist_dbg[3] = dir; g_persist_dbg[4] = s; g_persist_dbg[5] = wave;
-            g_persist_dbg[6] = (int)pend; g_persist_dbg[7] = l2_local;
+          if (lane == 0 && atomicCAS(&a.status[0], 0, 2) == 0) {
+            a.status[1] = slice; a.status[2] = bt; a.status[3] = dir; a.status[4] = s; a.status[5] = wave;
+            a.status[6] = (int)pend; a.status[7] = l2_local;
             __threadfence_system();
           }
           return;
@@ -521,7 +521,7 @@ int try_launch_ksplit_bwd(RnnArgs a, hipStream_t st) {
   const int gs = a.H / 32, nt = a.H / 128, nbt = ceil_div(a.B, 16);
   if (nt * G * 4 * NPL > (SP ? 150 : 176)) return 0;                 // W_hh fragments must leave room for the rest (256 registers per lane)
   if ((long long)gs * nbt * 2 > cu_count()) return 0;
-  if (!persist_allowed(true)) return 2;                              // eligible, but a starved launch's cooldown is running
+  if (!persist_allowed(a.hctx, true)) return 2;                             // eligible, but a starved launch's cooldown is running
   a.p_nbt = nbt; a.p_gs = gs; a.p_cux = CUS_PER_XCD;
   a.p_census = xcd_local_fits(gs, 2 * nbt) ? 1 : 0;
   char* xbuf = reinterpret_cast<char*>(a.pk);

@@ -159,9 +159,9 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_u10_kernel(RnnArgs a, char* x
             }
           pend = __builtin_amdgcn_readfirstlane(pend);
           if (pend && ++spins > spin_limit) {
-            if (lane == 0 && atomicCAS(&g_persist_dbg[0], 0, 1) == 0) {
-              g_persist_dbg[1] = slice; g_persist_dbg[2] = bt; g_persist_dbg[3] = dir; g_persist_dbg[4] = s; g_persist_dbg[5] = wave;
-              g_persist_dbg[6] = (int)pend; g_persist_dbg[7] = 0;
+            if (lane == 0 && atomicCAS(&a.status[0], 0, 1) == 0) {
+              a.status[1] = slice; a.status[2] = bt; a.status[3] = dir; a.status[4] = s; a.status[5] = wave;
+              a.status[6] = (int)pend; a.status[7] = 0;
               __threadfence_system();
             }
             return;

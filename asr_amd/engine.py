@@ -102,7 +102,7 @@ def _f32_split_ok(M: int, N: int, K: int, H: int = 8) -> bool:
     return F32_GEMM == "split" and M >= 512 and N >= 256 and K >= 256 and K % 8 == 0 and N % 8 == 0 and H % 8 == 0
 
 
-_BWD_PERSISTENT = {}      # (gates, H, B) -> did the last backward recurrence of this shape run as a persistent launch?
+_BWD_PERSISTENT = {}      # (recurrence context of the calling thread, gates, H, B) -> did the last backward recurrence of this shape run as a persistent launch?
 _SIDE = {}
 
 
@@ -113,7 +113,8 @@ def _idle_cus_beside_bwd_recurrence(device, B: int, H: int) -> int:
 
 
 def _side_stream(device):
-    key = (device.type, device.index)
+    import threading
+    key = (device.type, device.index, threading.get_ident())      # one side stream per driving thread: two threads never share one
     if key not in _SIDE:
         _SIDE[key] = torch.cuda.Stream(device=device)
     return _SIDE[key]
@@ -449,8 +450,7 @@ def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy, done, private: bo
     # one-launch-per-step kernels (shapes whose W_hh^T slice does not fit: LSTM H = 1280) co-running passes delay every launch
     # (c4: 94.6 -> 99.5 ms per step), so there the passes stay on the compute stream.  What the library did for this shape is known from
     # the previous call (ds2_rnn_last_path); the first call of a shape assumes persistent.
-    shape_key = (G, H, B)
-    lib = _lib.load()
+    shape_key = (ops.rnn_ctx_key(dev), G, H, B)
 
     def operand_passes(l, lc_t, dgx_bf, start):
         """side stream, not before `start`: transposing casts of layer l's dGx (+ db_ih), d(hn) (+ db_hn), h and Xn"""
@@ -520,7 +520,7 @@ def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy, done, private: bo
         else:
             ops.rnn_bwd(G, dy, lc.gx, lc.aux, lc.hbuf, lc.wpb, lens_dev, T, B, H, bf16=True, dgx_bf16=dgx_bf, gates_bf16=lc.rec, dhn_bf16=dhn_bf,
                         bias_part=bias_part)
-        _BWD_PERSISTENT[shape_key] = bool(lib.ds2_rnn_last_path() & 2)
+        _BWD_PERSISTENT[shape_key] = bool(ops.rnn_last_path() & 2)
         if queued_idle is not None:
             # enqueued BEHIND the recurrence launch: the recurrence's workgroups are dispatched first, the GEMM's fill what is left
             weight_gradients_group(*queued_idle, _BWD_PERSISTENT[shape_key], start_idle)
@@ -582,7 +582,7 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
     # leave >= DS2_WGRAD_IDLE_MIN_CUS compute units without a workgroup (c2: 96 of 256 used) — the split-bf16 weight-gradient launch of a layer
     # then runs beside the next layer's recurrence on those CUs: c2 f32 33.9 -> 32.6 ms (the recurrence pays 3.40 -> 3.75 us per time step,
     # profiles/r04_wgrad_idle_ab.txt).  What the library did for the shape is known from the previous step (first step: one stream).
-    f32_key = (G, H, ctx.B, "f32")
+    f32_key = (ops.rnn_ctx_key(dlogits.device), G, H, ctx.B, "f32")
     idle_f32 = (cfg.precision != "bf16" and WGRAD_IDLE and _BWD_PERSISTENT.get(f32_key, False)
                 and _idle_cus_beside_bwd_recurrence(dlogits.device, ctx.B, H) >= WGRAD_IDLE_MIN_CUS)
     side = _side_stream(dlogits.device) if (OVERLAP_WGRAD or idle_f32) else main

@@ -7,6 +7,7 @@ Nothing in this module has a CPU path: tensors must live on the GPU.
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import Optional, Tuple
 
 import torch
@@ -38,6 +39,64 @@ def _chk_f32(*ts):
 
 def _ws(nbytes: int, device) -> Tensor:
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+class RnnCtx(C.Structure):
+    """include/ds2hip.h `ds2_rnn_ctx`: everything the recurrence entry points remember between calls, owned by the CALLER (the library
+    keeps no mutable global state).  One per (thread, device): two Python threads driving two streams never see each other's kernel-path
+    bits, cooldown, enable switches or starvation record."""
+    _fields_ = [("size", C.c_int), ("persist_fwd", C.c_int), ("persist_bwd", C.c_int), ("cooldown", C.c_int), ("rearm_calls", C.c_int),
+                ("starved_total", C.c_int), ("last_path", C.c_int), ("last_bwd_kind", C.c_int), ("debug_flags", C.c_int),
+                ("reserved", C.c_int * 7), ("status_dev", C.c_void_p), ("poison_host", C.c_void_p), ("poison_dev", C.c_void_p)]
+
+
+_RNN_TLS = threading.local()
+
+
+def _pinned_word():
+    """(tensor, host address, device address) of one pinned, mapped int32 word — or (None, None, None) when the runtime will not map it."""
+    try:
+        t = torch.zeros(16, dtype=torch.int32).pin_memory()
+        hip = C.CDLL("libamdhip64.so")
+        dptr = C.c_void_p()
+        if hip.hipHostGetDevicePointer(C.byref(dptr), C.c_void_p(t.data_ptr()), 0) == 0 and dptr.value:
+            return t, t.data_ptr(), dptr.value
+    except (OSError, RuntimeError):
+        pass
+    return None, None, None
+
+
+def rnn_ctx(device=None) -> RnnCtx:
+    """The calling thread's recurrence context for `device` (default: the current CUDA device), created on first use: the struct itself, its
+    8-int device status record and its pinned poison word are allocated HERE, by the caller of the C ABI."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    table = getattr(_RNN_TLS, "ctx", None)
+    if table is None:
+        table = _RNN_TLS.ctx = {}
+    if key not in table:
+        ctx = RnnCtx()
+        status = torch.zeros(8, dtype=torch.int32, device=dev)
+        pin, phost, pdev = _pinned_word()
+        torch.cuda.synchronize(dev)                                   # the status record is zero before the first launch reads it
+        _lib.check(_lib.load().ds2_rnn_ctx_init(C.addressof(ctx), status.data_ptr(), phost, pdev), "ds2_rnn_ctx_init")
+        assert ctx.size == C.sizeof(RnnCtx), "ds2_rnn_ctx layout mismatch between include/ds2hip.h and asr_amd/ops.py"
+        table[key] = (ctx, status, pin)                               # (the tensors live as long as the context)
+    return table[key][0]
+
+
+def _ctxp(device=None) -> int:
+    return C.addressof(rnn_ctx(device))
+
+
+def rnn_ctx_key(device=None):
+    """hashable identity of the calling thread's context (host-side caches of "what did the last call of this shape do" are keyed with it)"""
+    return (threading.get_ident(), _ctxp(device))
+
+
+def debug_flags(flags: int, device=None) -> int:
+    """ds2_debug_flags on the calling thread's context: kernel-family selectors of the recurrence; returns the previous value."""
+    return _lib.load().ds2_debug_flags(_ctxp(device), int(flags))
 
 
 def _row_pitch(t: Tensor) -> int:
@@ -740,14 +799,14 @@ def rnn_pack(gates: int, whh: Tensor, bf16=False):
 def rnn_persistent_enable(forward: bool = True, backward: bool = True) -> None:
     """Which bf16 recurrences may run as one persistent launch.  A persistent launch needs all of its workgroups resident at once, so
     the backward one must be off while collectives run on a communication stream during backward (data-parallel training)."""
-    _lib.check(_lib.load().ds2_rnn_persistent_enable(int(bool(forward)), int(bool(backward))), "ds2_rnn_persistent_enable")
+    _lib.check(_lib.load().ds2_rnn_persistent_enable(_ctxp(), int(bool(forward)), int(bool(backward))), "ds2_rnn_persistent_enable")
 
 
 def rnn_persistent_check() -> None:
     """Raise if a persistent recurrence launch starved since the last call (a workgroup never saw its operand, or the launch never became
     resident: it needs every workgroup on the chip at once).  Call at a point where the device is idle anyway (the train step's loss sync)."""
     rec = (C.c_int * 8)()
-    _lib.check(_lib.load().ds2_rnn_persistent_status(C.cast(rec, C.c_void_p)), "ds2_rnn_persistent_status")
+    _lib.check(_lib.load().ds2_rnn_persistent_status(_ctxp(), C.cast(rec, C.c_void_p)), "ds2_rnn_persistent_status")
     if rec[0]:
         starved, left = rnn_persistent_counters()
         what = {1: "forward", 2: "backward", 3: "census (launch never resident)"}.get(rec[0], str(rec[0]))
@@ -763,20 +822,20 @@ def rnn_poison_if_starved(buf: Tensor) -> None:
     before this call has recorded starvation.  The record stays for the next rnn_persistent_check()."""
     _chk_f32(buf)
     assert buf.is_contiguous()
-    _lib.check(_lib.load().ds2_rnn_poison_if_starved(buf.data_ptr(), buf.numel(), _stream()), "ds2_rnn_poison_if_starved")
+    _lib.check(_lib.load().ds2_rnn_poison_if_starved(_ctxp(buf.device), buf.data_ptr(), buf.numel(), _stream()), "ds2_rnn_poison_if_starved")
 
 
 def rnn_poison_seen() -> bool:
     """True once a rnn_poison_if_starved kernel has actually overwritten a buffer since the last rnn_persistent_check(): a host memory read
     (no synchronisation).  A caller that sees it should run rnn_persistent_check(), which raises, clears the record and moves the next
     recurrence calls onto the step kernels."""
-    return bool(_lib.load().ds2_rnn_poison_seen())
+    return bool(_lib.load().ds2_rnn_poison_seen(_ctxp()))
 
 
 def rnn_persistent_counters():
-    """(launches that starved since the library was loaded, recurrence calls left on the step kernels before re-arming)."""
+    """(launches through the calling thread's context that starved, recurrence calls left on the step kernels before re-arming)."""
     out = (C.c_int * 2)()
-    _lib.check(_lib.load().ds2_rnn_persistent_counters(C.cast(out, C.c_void_p)), "ds2_rnn_persistent_counters")
+    _lib.check(_lib.load().ds2_rnn_persistent_counters(_ctxp(), C.cast(out, C.c_void_p)), "ds2_rnn_persistent_counters")
     return int(out[0]), int(out[1])
 
 
@@ -798,7 +857,7 @@ def rnn_fwd(gates: int, gx: Tensor, wp_fwd: Tensor, bhh: Tensor, lens_dev: Tenso
     rec = torch.empty(T * B, 2 * H, 4, dtype=torch.bfloat16, device=gx.device) if packed_gates else None
     wsb = lib.ds2_rnn_fwd_workspace_bytes(B, H, int(bf16))
     ws = _ws(wsb, gx.device)
-    _lib.check(lib.ds2_rnn_fwd_ex(gates, gx.data_ptr(), wp_fwd.data_ptr(), bhh.data_ptr(), hbuf.data_ptr(), aux.data_ptr(),
+    _lib.check(lib.ds2_rnn_fwd_ex(_ctxp(gx.device), gates, gx.data_ptr(), wp_fwd.data_ptr(), bhh.data_ptr(), hbuf.data_ptr(), aux.data_ptr(),
                                   lens_dev.data_ptr(), T, B, H, int(bf16), _ptr(rec), _ptr(h_bf16), ws.data_ptr(), wsb, _stream()),
                "ds2_rnn_fwd")
     return (hbuf, aux, rec) if packed_gates else (hbuf, aux)
@@ -823,7 +882,7 @@ def wgrad_fits_beside_bwd_recurrence(gates: int, H: int) -> bool:
 def rnn_last_path() -> int:
     """bit 0 / bit 1: the last rnn_fwd / rnn_bwd call ran as one persistent launch (and produced its optional outputs); bit 2: that
     backward launch was the K-split kernel (bf16 partial-dh exchange; results within a stated tolerance of the step kernels')"""
-    return _lib.load().ds2_rnn_last_path()
+    return _lib.load().ds2_rnn_last_path(_ctxp())
 
 
 def rnn_bwd(gates: int, dy: Tensor, gx: Optional[Tensor], aux: Tensor, hbuf: Tensor, wp_bwd: Tensor, lens_dev: Tensor, T: int, B: int, H: int,
@@ -846,7 +905,7 @@ def rnn_bwd(gates: int, dy: Tensor, gx: Optional[Tensor], aux: Tensor, hbuf: Ten
     lib = _lib.load()
     wsb = lib.ds2_rnn_bwd_workspace_bytes(gates, B, H, int(bf16))
     ws = _ws(wsb, dy.device)
-    _lib.check(lib.ds2_rnn_bwd_ex(gates, dy.data_ptr(), _row_pitch(dy), _ptr(gx), aux.data_ptr(), hbuf.data_ptr(), wp_bwd.data_ptr(),
+    _lib.check(lib.ds2_rnn_bwd_ex(_ctxp(dy.device), gates, dy.data_ptr(), _row_pitch(dy), _ptr(gx), aux.data_ptr(), hbuf.data_ptr(), wp_bwd.data_ptr(),
                                   lens_dev.data_ptr(), T, B, H, int(bf16), _ptr(dgx_bf16), _ptr(gates_bf16), _ptr(dhn_bf16), _ptr(bias_part),
                                   ws.data_ptr(), wsb, _stream()), "ds2_rnn_bwd")
 
@@ -883,7 +942,7 @@ def rnn_bwd_bn(gates: int, dyn: Tensor, bn_x: Tensor, mean: Tensor, var: Tensor,
     wsb = lib.ds2_rnn_bwd_workspace_bytes(gates, B, H, int(bf16))
     ws = _ws(wsb, dyn.device)
     def call(scratch):
-        return lib.ds2_rnn_bwd_bn(gates, dyn.data_ptr(), _row_pitch(dyn), bn_x.data_ptr(), _row_pitch(bn_x), mean.data_ptr(), var.data_ptr(),
+        return lib.ds2_rnn_bwd_bn(_ctxp(dyn.device), gates, dyn.data_ptr(), _row_pitch(dyn), bn_x.data_ptr(), _row_pitch(bn_x), mean.data_ptr(), var.data_ptr(),
                                   gamma.data_ptr(), s0.data_ptr(), s1.data_ptr(), BN_EPS, _ptr(scratch), _ptr(gx), aux.data_ptr(),
                                   hbuf.data_ptr(), wp_bwd.data_ptr(), lens_dev.data_ptr(), T, B, H, int(bf16), _ptr(dgx_bf16), _ptr(gates_bf16),
                                   _ptr(dhn_bf16), _ptr(bias_part), ws.data_ptr(), wsb, _stream())
@@ -1026,5 +1085,5 @@ def step_gate(loss: Tensor) -> Tensor:
     persistent recurrence launch has recorded starvation — the device-side form of check_loss + rnn_persistent_check."""
     _chk_f32(loss)
     flag = torch.empty(1, dtype=torch.int32, device=loss.device)
-    _lib.check(_lib.load().ds2_rnn_step_gate(loss.data_ptr(), flag.data_ptr(), _stream()), "ds2_rnn_step_gate")
+    _lib.check(_lib.load().ds2_rnn_step_gate(_ctxp(loss.device), loss.data_ptr(), flag.data_ptr(), _stream()), "ds2_rnn_step_gate")
     return flag

@@ -98,6 +98,27 @@ def load_pmc_summary():
     return pmc, None
 
 
+def _pci_bus_id(index):
+    """PCI bus id of a visible device, through the HIP runtime torch has already loaded."""
+    try:
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, int(index)) == 0:
+            return buf.value.decode()
+    except OSError:
+        pass
+    return f"unknown:{index}"
+
+
+def _rccl_version():
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+    except Exception as e:                      # noqa: BLE001 - diagnostics only
+        return f"unavailable ({type(e).__name__})"
+
+
 def train_flops_per_utt(rnn, H, L, C, T):
     """FLOPs(train) = 2*conv1 + 3*(conv2 + rnn + fc)."""
     G = 3 if rnn == "gru" else 4
@@ -537,6 +558,8 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        # an N-GPU line comes from N ranks: a process group of any other size never reaches the timed region
+        assert dist.get_world_size() == max(args.gpus, 1), f"--gpus {args.gpus} but the process group has {dist.get_world_size()} rank(s)"
 
     from asr_amd import CTCLoss, DeepSpeech, FusedAdamW, ops
     from asr_amd.trainers import DeepSpeechTrainer
@@ -630,7 +653,16 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
         assert abs(dt / args.steps * 1e3 - max(per_rank)) < 1e-6
+        # which device every rank really ran on (index + PCI bus id: what tells N ranks on one GPU from N GPUs) and what starved launches cost it
+        where = [None] * world
+        dist.all_gather_object(where, {"rank": rank, "device_index": dev.index, "pci_bus_id": _pci_bus_id(dev.index),
+                                       "name": torch.cuda.get_device_properties(dev).name,
+                                       "starved_steps": DeepSpeechTrainer.starved_steps - starved_before})
         dist_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "schedule": red.mode,
+                     "rccl_version": _rccl_version(), "device_count": torch.cuda.device_count(),
+                     "ranks": [{k: w[k] for k in ("rank", "device_index", "pci_bus_id", "name")} for w in where],
+                     "distinct_devices": len({w["pci_bus_id"] for w in where}),
+                     "persistent_starved_steps_all_ranks": int(sum(w["starved_steps"] for w in where)),
                      "rank_ms_per_step": {"min": min(per_rank), "max": max(per_rank)}, **red.timing_summary()}
         if args.ranks_on_one_gpu:
             dist_info["ranks_on_one_gpu"] = "TEST MODE: all ranks share cuda:0 - exercises the N > 1 code path, NOT a scaling measurement"

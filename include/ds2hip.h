@@ -11,6 +11,11 @@
  *     allocates, frees or retains memory: caller owns inputs, outputs, saved tensors, workspaces.
  *   - `stream` is a hipStream_t (as void*); all work is enqueued asynchronously on it.
  *   - return 0 on success, negative on error; `ds2_last_error()` returns a thread-local message.
+ *   - threading: the library keeps NO mutable global state besides that thread-local message.  Everything the recurrence entry points
+ *     remember between calls (which kernel family the last call took, the cooldown after a starved persistent launch, the enable
+ *     switches, the debug selectors, where the starvation record and the poison word live) is in a caller-owned `ds2_rnn_ctx`
+ *     (below); one context per thread / stream that launches recurrences, calls on different contexts are independent.  Environment
+ *     switches (DS2_*) are tuning / A-B overrides read once and never written.
  *   - all tensors fp32, row-major, contiguous unless a pitch (`ld*`) is given.
  *   - lengths (`lens_dev`) are int32 per-sample valid OUTPUT frame counts (after the conv stack,
  *     modules/deepspeech.py:275-288), sorted descending as the reference requires (blocks.py:87).
@@ -28,13 +33,36 @@ extern "C" {
 const char* ds2_version(void);
 const char* ds2_last_error(void);
 int ds2_device_info(int* cu_count, int* wave_size, char* arch, int arch_len);
+int ds2_ablation_build(void);
+
+/* ---- caller-owned state of the recurrence entry points (modules/blocks.py:84-93 is stateless in the reference: aten::gru / aten::lstm) ----
+ * The caller allocates the struct (any memory it owns), zeroes it and calls ds2_rnn_ctx_init with
+ *   status_dev   device memory, 8 ints, zero-initialised: the starvation record of persistent launches made through this context
+ *   poison_host / poison_dev   optional (both NULL, or both set): host and device address of ONE pinned, mapped int that
+ *                ds2_rnn_poison_if_starved raises — lets a caller that never synchronises notice a starved launch with a host read.
+ * The library never allocates any of it and holds no reference beyond the call it is passed to.  ctx == NULL is accepted by the launch
+ * entry points: the recurrence then runs on the one-launch-per-step kernels (no persistent launch: nothing to remember, nothing to record). */
+typedef struct ds2_rnn_ctx {
+  int size;                 /* sizeof(ds2_rnn_ctx) of the build that initialised it (ABI check) */
+  int persist_fwd, persist_bwd;   /* which recurrences may run as ONE persistent launch (ds2_rnn_persistent_enable) */
+  int cooldown;             /* recurrence calls left on the one-launch-per-step kernels after a starved launch (0 armed, < 0 never re-arm) */
+  int rearm_calls;          /* length of that cooldown (default 64 calls; 0 = never re-arm); DS2_RNN_REARM_CALLS at init */
+  int starved_total;        /* launches through this context that starved (reporting) */
+  int last_path;            /* out: bits describing what the last forward / backward call launched (ds2_rnn_last_path) */
+  int last_bwd_kind;        /* out: 0 step kernels, 1 all-gather persistent, 2 K-split persistent */
+  int debug_flags;          /* kernel-family selectors (ds2_debug_flags) */
+  int reserved[7];
+  int* status_dev;
+  int* poison_host;
+  int* poison_dev;
+} ds2_rnn_ctx;
+int ds2_rnn_ctx_init(ds2_rnn_ctx* ctx, int* status_dev, int* poison_host, int* poison_dev);
 /* Kernel-family selectors of the recurrence (every selection computes the full result; used by the parity tests and A/B scripts):
  * 8 / 16 alternative tile shapes of the wide step kernels, 64 one launch per time step instead of the persistent kernels, 128 the
  * all-gather persistent backward kernel instead of the K-split one.  Returns the previous value; 0 = production.  Bits 1 / 2 (skip the
  * recurrent product / the gate epilogue, scripts/ablate_rnn.py) are honoured only by a library built with -DDS2_ABLATE
  * (ds2_ablation_build() == 1); the shipped library masks them off. */
-int ds2_debug_flags(int flags);
-int ds2_ablation_build(void);
+int ds2_debug_flags(ds2_rnn_ctx* ctx, int flags);
 
 /* ---- dense GEMM on the f32 matrix cores -------------------------------------------------------
  * C[M,N] (+)= op(A) op(B) (+ bias[N]);  transA: A stored (K,M);  transB: B stored (N,K).
@@ -204,47 +232,47 @@ int ds2_rnn_pack_whh(int gates, const float* whh, void* wp_fwd, void* wp_bwd, in
  * (default 64) recurrence calls run on the one-launch-per-step kernels, then the persistent kernels are armed again.
  * DS2_RNN_PERSISTENT=0 selects the one-launch-per-step kernels from the start; DS2_RNN_XCD_LOCAL=0 keeps the placement-independent
  * (sc1) exchange instead of the exchange through the group's own L2 (asr_amd/csrc/rnn.hip: persist_role). */
-int ds2_rnn_persistent_status(int* out8);
-/* reporting: out2 = {launches that starved since the library was loaded, recurrence calls left before the persistent kernels are armed
+int ds2_rnn_persistent_status(ds2_rnn_ctx* ctx, int* out8);
+/* reporting: out2 = {launches through this context that starved, recurrence calls left before the persistent kernels are armed
  * again (0 = armed, -1 = never)} */
-int ds2_rnn_persistent_counters(int* out2);
+int ds2_rnn_persistent_counters(const ds2_rnn_ctx* ctx, int* out2);
 /* Inference path (DeepSpeech.forward in eval mode, modules/deepspeech.py:130-149): instead of a device synchronisation per forward, a
  * kernel in stream order that overwrites buf[0..n) (the logits) with NaN if a persistent launch before it recorded starvation; the record is
  * neither read by the host nor cleared (the next ds2_rnn_persistent_status, at a natural sync point, raises). */
-int ds2_rnn_poison_if_starved(float* buf, size_t n, void* stream);
+int ds2_rnn_poison_if_starved(ds2_rnn_ctx* ctx, float* buf, size_t n, void* stream);
 /* 1 if a ds2_rnn_poison_if_starved kernel has fired since the last ds2_rnn_persistent_status: a read of a pinned host word the kernel
  * sets, no synchronisation and no device call.  Lets inference callers that only ever call forward (deepspeech.py:130-149 in eval mode)
  * notice a starved launch and settle it (status call: report, clear, cooldown onto the step kernels) before their next forward. */
-int ds2_rnn_poison_seen(void);
+int ds2_rnn_poison_seen(const ds2_rnn_ctx* ctx);
 /* device-side validity of the train step enqueued so far, evaluated when the kernel RUNS (stream order): flag_dev[0] = -1 if a persistent
  * recurrence launch starved, else 1 if the loss is finite and >= 0 [check_loss, functional.py:45-61], else 0.  Under data parallelism the
  * MIN over ranks is taken; the gated optimizer applies the update only for 1. */
-int ds2_rnn_step_gate(const float* loss_dev, int* flag_dev, void* stream);
+int ds2_rnn_step_gate(const ds2_rnn_ctx* ctx, const float* loss_dev, int* flag_dev, void* stream);
 /* Which recurrences may run as one persistent launch (default both).  Switch the backward one off when other kernels (collectives on a
  * communication stream) run on the device during backward: a persistent launch needs all of its workgroups resident at once. */
-int ds2_rnn_persistent_enable(int forward, int backward);
+int ds2_rnn_persistent_enable(ds2_rnn_ctx* ctx, int forward, int backward);
 /* Footprint of one workgroup of the K-split persistent backward recurrence for this (gates, H), read from the loaded binary: out3 =
  * {registers per lane, static LDS bytes, threads}; returns 1 if the shape has such a kernel, 0 if not.  The host side decides with it
  * whether ds2_gemm_bf16_tn_group (4 waves x 128 registers, 84 KB of LDS) fits on a CU BESIDE the recurrence of the layer below
  * (asr_deepspeech/modules/blocks.py:87-89 backward; the weight gradients of blocks.py:76-78 are off its critical path). */
 int ds2_rnn_bwd_ksplit_footprint(int gates, int H, int* out3);
-/* reporting: bit 0 / bit 1 set if the last ds2_rnn_fwd / ds2_rnn_bwd call ran as a persistent launch (bench.py labels its roofline with it) */
-int ds2_rnn_last_path(void);
+/* reporting: bit 0 / bit 1 set if the last ds2_rnn_fwd / ds2_rnn_bwd call through this context ran as a persistent launch (bench.py labels its roofline with it) */
+int ds2_rnn_last_path(const ds2_rnn_ctx* ctx);
 size_t ds2_rnn_fwd_workspace_bytes(int B, int H, int bf16);
 /* gates_bf16: NULL, or a (T,B,2,H,4) bf16 buffer that receives the saved-for-backward record of every hidden unit as ONE 8-byte
  * store — GRU [r, z, n, W_hn h + b_hn], LSTM [i, f, g, o] — instead of four fp32 stores into gx / aux (gx is then left untouched
  * and, for GRU, aux is not written).  Pass the same buffer to ds2_rnn_bwd. */
-int ds2_rnn_fwd(int gates, float* gx, const void* wp_fwd, const float* bhh, float* hbuf, float* aux, const int* lens_dev, int T, int B,
+int ds2_rnn_fwd(ds2_rnn_ctx* ctx, int gates, float* gx, const void* wp_fwd, const float* bhh, float* hbuf, float* aux, const int* lens_dev, int T, int B,
                 int H, int bf16, void* gates_bf16, void* ws, size_t ws_bytes, void* stream);
 /* ds2_rnn_fwd plus h_bf16: NULL, or a (T,B,2,H) bf16 buffer that receives a bf16 copy of hbuf (the K-row-major operand of the TN-form
  * dW_hh GEMM).  Written by a PERSISTENT launch only: check ds2_rnn_last_path() & 1 after the call. */
-int ds2_rnn_fwd_ex(int gates, float* gx, const void* wp_fwd, const float* bhh, float* hbuf, float* aux, const int* lens_dev, int T, int B,
+int ds2_rnn_fwd_ex(ds2_rnn_ctx* ctx, int gates, float* gx, const void* wp_fwd, const float* bhh, float* hbuf, float* aux, const int* lens_dev, int T, int B,
                    int H, int bf16, void* gates_bf16, void* h_bf16, void* ws, size_t ws_bytes, void* stream);
 size_t ds2_rnn_bwd_workspace_bytes(int gates, int B, int H, int bf16);
 /* dgx_bf16: NULL, or a (T,B,2,G*H) bf16 buffer that receives the gradient wrt the x-projections instead of gx (which then keeps
  * the gates): the bf16-mode GEMMs consume it directly.  gates_bf16: NULL, or the packed records written by ds2_rnn_fwd — read
  * instead of gx (and, for GRU, instead of aux, which is then output only: d(W_hn h + b_hn)); gx may be NULL when both are given. */
-int ds2_rnn_bwd(int gates, const float* dy, int lddy, float* gx, float* aux, const float* hbuf, const void* wp_bwd, const int* lens_dev,
+int ds2_rnn_bwd(ds2_rnn_ctx* ctx, int gates, const float* dy, int lddy, float* gx, float* aux, const float* hbuf, const void* wp_bwd, const int* lens_dev,
                 int T, int B, int H, int bf16, void* dgx_bf16, const void* gates_bf16, void* ws, size_t ws_bytes, void* stream);
 
 /* ds2_rnn_last_path() bits after a backward call: 2 = ran as ONE persistent launch; 4 = that launch was the K-split kernel (bf16, H a multiple
@@ -254,7 +282,7 @@ int ds2_rnn_bwd(int gates, const float* dy, int lddy, float* gx, float* aux, con
  * ds2_rnn_bwd plus two optional outputs of a PERSISTENT launch (check ds2_rnn_last_path() & 2 after the call; untouched otherwise):
  * dhn_bf16 (GRU): (T,B,2,H) bf16 copy of d(W_hn h + b_hn); bias_part: (B,2,4,H) fp32 per-batch-row sums over time of
  * [d r, d z, d n, d(hn)] (GRU) / [d i, d f, d g, d o] (LSTM) - their column sums over B are the bias gradients, so no pass over dGx. */
-int ds2_rnn_bwd_ex(int gates, const float* dy, int lddy, float* gx, float* aux, const float* hbuf, const void* wp_bwd, const int* lens_dev,
+int ds2_rnn_bwd_ex(ds2_rnn_ctx* ctx, int gates, const float* dy, int lddy, float* gx, float* aux, const float* hbuf, const void* wp_bwd, const int* lens_dev,
                    int T, int B, int H, int bf16, void* dgx_bf16, const void* gates_bf16, void* dhn_bf16, float* bias_part, void* ws,
                    size_t ws_bytes, void* stream);
 
@@ -266,7 +294,7 @@ int ds2_rnn_bwd_ex(int gates, const float* dy, int lddy, float* gx, float* aux, 
  * (T*B, H) and the call proceeds as ds2_rnn_bwd_ex.  dy_scratch may be NULL: the call then returns 1 — nothing launched, nothing counted —
  * when the buffer is needed after all, and the caller repeats it with one (the fused launch never allocates or touches (T*B, H) fp32).
  * Replaces autograd's native_batch_norm_backward + the recurrence backward. */
-int ds2_rnn_bwd_bn(int gates, const float* dyn, int lddyn, const float* bn_x, int ldx, const float* bn_mean, const float* bn_var,
+int ds2_rnn_bwd_bn(ds2_rnn_ctx* ctx, int gates, const float* dyn, int lddyn, const float* bn_x, int ldx, const float* bn_mean, const float* bn_var,
                    const float* bn_gamma, const float* bn_s0, const float* bn_s1, float bn_eps, float* dy_scratch, float* gx, float* aux,
                    const float* hbuf, const void* wp_bwd, const int* lens_dev, int T, int B, int H, int bf16, void* dgx_bf16,
                    const void* gates_bf16, void* dhn_bf16, float* bias_part, void* ws, size_t ws_bytes, void* stream);

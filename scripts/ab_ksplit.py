@@ -24,15 +24,15 @@ def setup(G, H, B, T, seed=0, ragged=True):
 
 def bwd(G, H, B, T, fw, wpb, lens, dy, flags):
     hb, aux0, rec = fw
-    lib.ds2_debug_flags(flags)
+    ops.debug_flags(flags)
     side = torch.empty(T * B, 2 * G * H, dtype=torch.bfloat16, device=dev)
     aux = aux0.clone()
     dhn = torch.empty(T * B, 2 * H, dtype=torch.bfloat16, device=dev) if G == 3 else None
     bp = torch.zeros(B, 2, 4, H, device=dev)
     ops.rnn_bwd(G, dy, None, aux, hb, wpb, lens, T, B, H, bf16=True, dgx_bf16=side, gates_bf16=rec, dhn_bf16=dhn, bias_part=bp)
-    path = lib.ds2_rnn_last_path()
+    path = ops.rnn_last_path()
     torch.cuda.synchronize()
-    lib.ds2_debug_flags(0)
+    ops.debug_flags(0)
     ops.rnn_persistent_check()
     return side, (dhn if G == 3 else aux), bp, path
 
@@ -72,12 +72,12 @@ def timeit(name, G, H, B, T=501):
         fw = ops.rnn_fwd(G, g2, wpf, bhh, lens, T, B, H, bf16=True, packed_gates=True, h_bf16=h_bf)
         e1.record(); torch.cuda.synchronize()
         fbest = min(fbest, e0.elapsed_time(e1) * 1e3 / T)
-    fpath = lib.ds2_rnn_last_path() & 1
+    fpath = ops.rnn_last_path() & 1
     out = []
     for flags in (0, 128):
         best = 1e9
         for _ in range(4):
-            lib.ds2_debug_flags(flags)
+            ops.debug_flags(flags)
             side = torch.empty(T * B, 2 * G * H, dtype=torch.bfloat16, device=dev)
             dhn = torch.empty(T * B, 2 * H, dtype=torch.bfloat16, device=dev) if G == 3 else None
             bp = torch.empty(B, 2, 4, H, device=dev)
@@ -85,8 +85,8 @@ def timeit(name, G, H, B, T=501):
             torch.cuda.synchronize(); e0.record()
             ops.rnn_bwd(G, dy, None, fw[1], fw[0], wpb, lens, T, B, H, bf16=True, dgx_bf16=side, gates_bf16=fw[2], dhn_bf16=dhn, bias_part=bp)
             e1.record(); torch.cuda.synchronize()
-            path = lib.ds2_rnn_last_path()
-            lib.ds2_debug_flags(0)
+            path = ops.rnn_last_path()
+            ops.debug_flags(0)
             best = min(best, e0.elapsed_time(e1) * 1e3 / T)
         ops.rnn_persistent_check()
         out.append(f"{'k-split' if flags == 0 else 'all-gather'} (path {path}) {best:5.2f}")

@@ -6,7 +6,7 @@ from asr_amd import _lib, ops
 lib = _lib.load()
 dev = torch.device("cuda:0")
 def run(G, H, B, T, bwd, flags, bf=False):
-    lib.ds2_debug_flags(flags)
+    ops.debug_flags(flags)
     M = T * B
     gx = torch.randn(M, 2 * G * H, device=dev) * 0.5
     whh = (torch.rand(2, G * H, H, device=dev) * 2 - 1) / H ** 0.5
@@ -25,7 +25,7 @@ def run(G, H, B, T, bwd, flags, bf=False):
         torch.cuda.synchronize(); e0.record()
         ops.rnn_bwd(G, dy, gx, aux, hbuf, wpb, lens, T, B, H, bf16=bf)
         e1.record(); torch.cuda.synchronize()
-    lib.ds2_debug_flags(0)
+    ops.debug_flags(0)
     return e0.elapsed_time(e1) * 1e3 / T
 for (name, G, H, B) in ([] if os.environ.get("ABLATE_SKIP") else [("c2", 3, 768, 32), ("c3", 3, 1024, 64), ("c4-lstm", 4, 1280, 32)]):
     for bwd in (False, True):

@@ -31,10 +31,10 @@ for it in range(n):
     wpf, wpb = ops.rnn_pack(G, whh, bf16=bf)
     res = []
     for flags in (0, 0, 128, 64):              # 0: default (twice: rerun identity) ; 128: all-gather persistent backward ; 64: step kernels
-        lib.ds2_debug_flags(flags)
+        ops.debug_flags(flags)
         g = gx.clone()
         out = ops.rnn_fwd(G, g, wpf, bhh, lens, T, B, H, bf16=bf, packed_gates=packed)
-        path = lib.ds2_rnn_last_path() & 1
+        path = ops.rnn_last_path() & 1
         if packed:
             hb, aux, rec = out
             side = torch.empty(T * B, 2 * G * H, dtype=torch.bfloat16, device=dev)
@@ -46,10 +46,10 @@ for it in range(n):
             auxb = aux.clone()
             ops.rnn_bwd(G, dy, g, auxb, hb, wpb, lens, T, B, H, bf16=bf)
             outs = (hb, aux, g, auxb)
-        path |= lib.ds2_rnn_last_path() & 6
+        path |= ops.rnn_last_path() & 6
         torch.cuda.synchronize()
         res.append((path, [o.clone() for o in outs]))
-    lib.ds2_debug_flags(0)
+    ops.debug_flags(0)
     took += res[0][0] != 0
     eq = lambda ra, rb: all(torch.equal(a.view(torch.uint8) if a.dtype == torch.bfloat16 else a, b.view(torch.uint8) if b.dtype == torch.bfloat16 else b)
                             for a, b in zip(ra, rb))

@@ -4,7 +4,7 @@ os.environ.setdefault("DS2_RNN_SPIN_LIMIT", "20000")
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
-from asr_amd import CTCLoss, DeepSpeech, FusedAdamW, _lib
+from asr_amd import CTCLoss, DeepSpeech, FusedAdamW, _lib, ops
 from asr_amd.trainers import DeepSpeechTrainer
 lib = _lib.load()
 dev = torch.device("cuda:0")
@@ -21,5 +21,5 @@ x = x.to(dev)
 rec = (ctypes.c_int * 8)()
 for i in range(int(os.environ.get("NSTEPS", "30"))):
     valid, lv = tr.step((x, targets, pct.clone(), tsz))
-    lib.ds2_rnn_persistent_status(ctypes.cast(rec, ctypes.c_void_p))
+    lib.ds2_rnn_persistent_status(ops._ctxp(), ctypes.cast(rec, ctypes.c_void_p))
     print(f"step {i}: loss {lv} valid {valid} record {list(rec)}", flush=True)

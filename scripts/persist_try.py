@@ -14,10 +14,10 @@ bhh = torch.randn(2, G * H, device=dev) * 0.1
 lens = torch.randint(T // 4, T + 1, (B,), dtype=torch.int32, device=dev); lens[0] = T
 wpf, wpb = ops.rnn_pack(G, whh, bf16=True)
 def run(packed, flags):
-    lib.ds2_debug_flags(flags)          # any non-zero flag selects the step kernels (64 is unused by them)
+    ops.debug_flags(flags)          # any non-zero flag selects the step kernels (64 is unused by them)
     out = ops.rnn_fwd(G, gx.clone(), wpf, bhh, lens, T, B, H, bf16=True, packed_gates=packed)
     torch.cuda.synchronize()
-    lib.ds2_debug_flags(0)
+    ops.debug_flags(0)
     return out
 ref = run(False, 64)
 for packed in (False, True):
@@ -30,12 +30,12 @@ for packed in (False, True):
 hb, aux0, rec = run(True, 0)
 dy = torch.randn(T * B, H, device=dev)
 def runb(flags):
-    lib.ds2_debug_flags(flags)
+    ops.debug_flags(flags)
     side = torch.empty(T * B, 2 * G * H, dtype=torch.bfloat16, device=dev)
     aux = aux0.clone()
     ops.rnn_bwd(G, dy, None, aux, hb, wpb, lens, T, B, H, bf16=True, dgx_bf16=side, gates_bf16=rec)
     torch.cuda.synchronize()
-    lib.ds2_debug_flags(0)
+    ops.debug_flags(0)
     return side, aux
 sref, aref = runb(64)
 for it in range(3):

@@ -54,9 +54,13 @@ def test_shipped_library_has_no_work_skipping_switch():
     from asr_amd import _lib
     lib = _lib.load()
     assert lib.ds2_ablation_build() == 0, "asr_amd/lib/libds2hip.so was built with ABLATE=1: not a shippable library"
-    assert lib.ds2_debug_flags(3) == 0           # previous value
-    assert lib.ds2_debug_flags(1 | 2 | 64) == 0  # ... the request for 3 was dropped entirely
-    assert lib.ds2_debug_flags(0) == 64          # ... and only the selector survived of 67
+    from asr_amd import ops
+    ctx = ops.RnnCtx()                           # the selectors live in the caller's context (no device needed for this entry point)
+    at = ctypes.addressof(ctx)
+    assert lib.ds2_debug_flags(at, 3) == 0           # previous value
+    assert lib.ds2_debug_flags(at, 1 | 2 | 64) == 0  # ... the request for 3 was dropped entirely
+    assert lib.ds2_debug_flags(at, 0) == 64          # ... and only the selector survived of 67
+    assert ctx.debug_flags == 0
     src = open(os.path.join(ROOT, "asr_amd", "csrc", "rnn.hip")).read()
     assert "#define DS2_ABLATE_BIT(flags, bit) false" in src and not re.search(r"dbg\s*&\s*[12]\b", src)
 
@@ -553,3 +557,26 @@ def test_fp32_split_gemm_decision_needs_an_aligned_hidden_size():
         pytest.skip("DS2_F32_GEMM overridden")
     assert engine._f32_split_ok(648, 2 * 3 * 96, 1312, 96)
     assert not engine._f32_split_ok(648, 2 * 3 * 100, 1312, 100)          # dW_hh problems would have N = 100, column offsets 100, 300
+
+
+def test_library_exports_no_writable_global_state():
+    """SURVEY §8(b) "Threading": no mutable global state besides the thread-local error message.  The dynamic symbol table of the shipped
+    library holds functions, kernel descriptors and the HIP fat-binary bookkeeping — no data object of the library's own — and the
+    recurrence state that used to be process-global (kernel-path bits, cooldown, enable switches, debug selectors, poison word) is a
+    caller-owned ds2_rnn_ctx whose layout the header, the library and the ctypes mirror agree on."""
+    from asr_amd import _lib, ops
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    data = [l.split() for l in out.splitlines() if len(l.split()) == 3 and l.split()[1] in "BDbdCGgSs"]
+    own = [n for _, _, n in data if not (n.startswith("__hip_") or n.startswith("_Z") or n.startswith("__") or n in ("_edata", "_end", "_fini", "_init"))]
+    assert own == [], f"writable data symbols exported by libds2hip.so: {own}"
+    src = open(os.path.join(ROOT, "asr_amd", "csrc", "rnn.hip")).read() + open(os.path.join(ROOT, "asr_amd", "csrc", "api.cpp")).read()
+    assert not re.search(r"^\s*(static\s+)?(int|bool)\s*\*?\s*g_(last|persist|poison|ds2_debug)\w*\s*(=|;)", src, re.M)
+    hdr = open(os.path.join(ROOT, "include", "ds2hip.h")).read()
+    fields = re.search(r"typedef struct ds2_rnn_ctx \{(.*?)\} ds2_rnn_ctx;", hdr, re.S).group(1)
+    n_int = sum(int(m.group(2) or 1) for m in re.finditer(r"\bint\s+(\w+)(?:\[(\d+)\])?\s*[;,]", fields)) + fields.count("persist_fwd, persist_bwd") * 1
+    assert ctypes.sizeof(ops.RnnCtx) == 16 * 4 + 3 * 8 and [f[0] for f in ops.RnnCtx._fields_][-3:] == ["status_dev", "poison_host", "poison_dev"]
+    ctx = ops.RnnCtx()
+    dummy = (ctypes.c_int * 8)()
+    assert _lib.load().ds2_rnn_ctx_init(ctypes.addressof(ctx), ctypes.addressof(dummy), None, None) == 0
+    assert ctx.size == ctypes.sizeof(ops.RnnCtx) and (ctx.persist_fwd, ctx.persist_bwd, ctx.cooldown, ctx.last_path) == (1, 1, 0, 0)
+    assert ctx.rearm_calls == int(os.environ.get("DS2_RNN_REARM_CALLS", "64"))

@@ -467,12 +467,12 @@ def test_rnn_fwd_bwd(dev, kind, H, B, T, lens, bf):
         from asr_amd import _lib
         lib = _lib.load()
         gx_alt = g(gx.detach().float().reshape(T * B, 2 * G * H), dev).clone()
-        lib.ds2_debug_flags(16)
+        ops.debug_flags(16)
         hb_alt, aux_alt = ops.rnn_fwd(G, gx_alt, wpf, bhd, ld, T, B, H, bf16=bf)
-        lib.ds2_debug_flags(8)
+        ops.debug_flags(8)
         aux_b = aux.clone()
         ops.rnn_bwd(G, g(dy.float().reshape(T * B, H), dev), gx_alt, aux_b, hbuf, wpb, ld, T, B, H, bf16=bf)
-        lib.ds2_debug_flags(0)
+        ops.debug_flags(0)
         assert torch.equal(hb_alt, hbuf) and torch.equal(aux_alt, aux)
     ops.rnn_bwd(G, g(dy.float().reshape(T * B, H), dev), gxd, aux, hbuf, wpb, ld, T, B, H, bf16=bf)
     default_is_ksplit = bool(ops.rnn_last_path() & 4)                     # K-split persistent backward: within a stated tolerance of the step kernels
@@ -509,16 +509,16 @@ def test_rnn_fwd_bwd(dev, kind, H, B, T, lens, bf):
         from asr_amd import _lib
         lib = _lib.load()
         KS_TOL = 4e-3                      # observed 0.9e-3 .. 1.3e-3 (scripts/ab_ksplit.py); the bf16 operand rounding itself is 2.8e-3 vs fp64
-        lib.ds2_debug_flags(64)
+        ops.debug_flags(64)
         hb4, aux4, rec4 = ops.rnn_fwd(G, keep_x.clone(), wpf, bhd, ld, T, B, H, bf16=True, packed_gates=True)
         side4 = torch.empty_like(side3)
         aux_in4 = aux4.clone() if G == 4 else torch.full_like(aux4, float("nan"))
         ops.rnn_bwd(G, g(dy.float().reshape(T * B, H), dev), None, aux_in4, hb4, wpb, ld, T, B, H, bf16=True, dgx_bf16=side4, gates_bf16=rec4)
-        lib.ds2_debug_flags(128)
+        ops.debug_flags(128)
         side_ag = torch.empty_like(side3)
         aux_ag = aux4.clone() if G == 4 else torch.full_like(aux4, float("nan"))
         ops.rnn_bwd(G, g(dy.float().reshape(T * B, H), dev), None, aux_ag, hb4, wpb, ld, T, B, H, bf16=True, dgx_bf16=side_ag, gates_bf16=rec4)
-        lib.ds2_debug_flags(0)
+        ops.debug_flags(0)
         assert torch.equal(hb4, hb3) and torch.equal(rec4, rec)
         assert torch.equal(side_ag, side4) and torch.equal(aux_ag, aux_in4)       # all-gather persistent == step kernels, to the bit
         if ksplit:
@@ -627,11 +627,11 @@ def test_ksplit_backward_vs_oracle(dev, kind, H, B, T):
                                packed_gates=True)
     err = {}
     for name, flags in (("ksplit", 0), ("allgather_or_step", 128)):
-        lib.ds2_debug_flags(flags)
+        ops.debug_flags(flags)
         side = torch.empty(T * B, 2 * G * H, dtype=torch.bfloat16, device=dev)
         ops.rnn_bwd(G, dyd, None, aux.clone(), hb, wpb, ld, T, B, H, bf16=True, dgx_bf16=side, gates_bf16=rec)
         path = ops.rnn_last_path()
-        lib.ds2_debug_flags(0)
+        ops.debug_flags(0)
         assert bool(path & 4) == (name == "ksplit"), f"{name}: path {path}"
         got = side.float().cpu()
         err[name] = rel_l2(got, ref)
@@ -687,7 +687,7 @@ def test_ksplit_backward_with_fused_batchnorm_backward(dev, kind, H, B, T):
     into = (torch.empty(H, device=dev), torch.empty(H, device=dev))           # ... and write them where it is told to (the gradient buffers)
     assert ops.bn1d_bwd_sums(dyn, x, mean, var, gamma, out=into)[0] is into[0] and torch.equal(into[0], dbet) and torch.equal(into[1], dgam)
     for flags in (0, 64):
-        lib.ds2_debug_flags(flags)
+        ops.debug_flags(flags)
         a = outs()
         ops.rnn_bwd(G, dy, None, aux.clone(), hb, wpb, lens, T, B, H, bf16=True, dgx_bf16=a[0], gates_bf16=rec, dhn_bf16=a[1], bias_part=a[2])
         pa = ops.rnn_last_path()
@@ -695,7 +695,7 @@ def test_ksplit_backward_with_fused_batchnorm_backward(dev, kind, H, B, T):
         ops.rnn_bwd_bn(G, dyn, x, mean, var, gamma, sums, None, aux.clone(), hb, wpb, lens, T, B, H, bf16=True, dgx_bf16=b[0], gates_bf16=rec,
                        dhn_bf16=b[1], bias_part=b[2])
         pb = ops.rnn_last_path()
-        lib.ds2_debug_flags(0)
+        ops.debug_flags(0)
         if flags == 0 and H % 256 == 0 and H <= 1280 and (H // 32) * ((B + 15) // 16) * 2 <= 256:
             assert pa & 4 and pb & 4 and pb & 16 and not pa & 16, (pa, pb)
             e = rel_l2(b[0].float().cpu(), a[0].float().cpu())
@@ -768,17 +768,17 @@ except _lib.DS2LibraryError as e:
 lib = _lib.load()
 h2 = ops.rnn_fwd(G, gx.clone(), wpf, bhh, lens, T, B, H, bf16=True)[0]          # the library has fallen back to the step kernels ...
 ops.rnn_persistent_check()
-print("COOLDOWN", lib.ds2_rnn_last_path() & 1, ops.rnn_persistent_counters())      # ... for DS2_RNN_REARM_CALLS = 3 calls: (1 starved, 2 left)
-lib.ds2_debug_flags(64)
+print("COOLDOWN", ops.rnn_last_path() & 1, ops.rnn_persistent_counters())      # ... for DS2_RNN_REARM_CALLS = 3 calls: (1 starved, 2 left)
+ops.debug_flags(64)
 h3 = ops.rnn_fwd(G, gx.clone(), wpf, bhh, lens, T, B, H, bf16=True)[0]          # step kernels, explicitly (not a cooldown call: the flag decides first)
-lib.ds2_debug_flags(0)
+ops.debug_flags(0)
 print("FALLBACK-EQUAL", bool(torch.equal(h2, h3)))
 for _ in range(2):
     ops.rnn_fwd(G, gx.clone(), wpf, bhh, lens, T, B, H, bf16=True)
 ops.rnn_persistent_check()
 print("ARMED-AGAIN", ops.rnn_persistent_counters()[1] == 0)
 ops.rnn_fwd(G, gx.clone(), wpf, bhh, lens, T, B, H, bf16=True)                   # persistent again (and, with a poll limit of 0, starved again)
-took = lib.ds2_rnn_last_path() & 1
+took = ops.rnn_last_path() & 1
 try:
     ops.rnn_persistent_check()
     print("REARMED", False)
@@ -833,7 +833,7 @@ def test_persistent_recurrence_beside_a_busy_second_stream(dev):
     quiet = run()
     torch.cuda.synchronize()
     ops.rnn_persistent_check()
-    assert _lib.load().ds2_rnn_last_path() == 7, "the quiet run must take both persistent kernels (backward: the K-split one)"
+    assert ops.rnn_last_path() == 7, "the quiet run must take both persistent kernels (backward: the K-split one)"
     a = torch.randn(8192, 8192, device=dev)
     busy = torch.cuda.Stream(device=dev)
     starved = 0

@@ -199,6 +199,11 @@ def test_bench_two_ranks_end_to_end_on_one_gpu():
     assert abs(d["rank_ms_per_step"]["max"] - out["ms_per_step"]) < 1e-6 * max(1.0, out["ms_per_step"])        # the line reports the MAX
     assert abs(out["value"] - 2 * 4 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]                  # whole-job utterances / s
     assert d["collectives_per_step"] == 2 and d["big_collective_bytes"] > 0 and d["big_collective_ms"] > 0    # fc + rnns bucket, conv bucket
+    # first-SCALE-run readiness (round 5): the line says which devices the ranks really ran on and what starved launches cost them
+    assert d["device_count"] >= 1 and isinstance(d["rccl_version"], str) and len(d["ranks"]) == 2
+    assert [r["rank"] for r in d["ranks"]] == [0, 1] and all(r["device_index"] == 0 and r["pci_bus_id"] for r in d["ranks"])
+    assert d["distinct_devices"] == 1                                           # test mode: both ranks on cuda:0 — a real run reports N
+    assert d["persistent_starved_steps_all_ranks"] == 0
     assert d["conv_backward_ms"] > 0 and d["big_collective_outlasts_conv_backward_ms"] >= 0
     # two PROCESSES time-share the one GPU here, so a persistent recurrence launch of one rank can find its CUs held by the other rank's kernels
     # for longer than the spin limit: that is the starvation path doing its job (every rank skips the step, restores the BatchNorm statistics,
@@ -668,14 +673,14 @@ def test_u10_split_forward_recurrence_vs_fp64_and_fp32_kernels(kind, H, B, T):
     wpf, _ = ops.rnn_pack(G, whh.float().to(dev), bf16=2)
 
     def run(flags):
-        old = _lib.load().ds2_debug_flags(flags)
+        old = ops.debug_flags(flags)
         try:
             gxd = gx.float().reshape(T * B, 2 * G * H).to(dev).clone()
             hb, aux = ops.rnn_fwd(G, gxd, wpf, bhh.float().to(dev), ld, T, B, H, bf16=2)
             torch.cuda.synchronize()
             return hb.view(T, B, 2, H).clone(), gxd, aux.clone(), ops.rnn_last_path()
         finally:
-            _lib.load().ds2_debug_flags(old)
+            ops.debug_flags(old)
 
     u, u2 = run(256), run(256)
     assert u[3] & 256 and u[3] & 32 and u[3] & 1, u[3]                      # the 10-unit kernel took the call

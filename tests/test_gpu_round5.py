@@ -185,3 +185,64 @@ def test_fp32_step_with_hidden_size_not_a_multiple_of_8():
     assert abs(float(loss.detach()) - ref["loss"]) / ref["loss"] < 1e-3
     worst = max(rel_l2(p.grad.cpu().numpy(), ref["grads"][k].numpy()) for k, p in model.named_parameters())
     assert worst < 1e-3, worst
+
+
+def _three_steps(cfg, stream, barrier=None):
+    """three fused train steps of a c1-sized model on `stream`; returns (losses, flat weights, kernel-path bits, starved launches of this context)"""
+    from helpers import model_inputs
+    from asr_amd import CTCLoss, ops
+    from asr_amd.optim import FusedAdamW
+    from asr_amd.trainers import DeepSpeechTrainer
+    torch.cuda.set_device(0)
+    sd, x, targets, pct, tsz = model_inputs(cfg)
+    with torch.cuda.stream(stream):
+        model = make_model(cfg, sd)
+        model.precision = cfg.get("precision", "fp32")
+        tr = DeepSpeechTrainer(model, CTCLoss(reduction="sum"), 1, None, FusedAdamW(model, lr=1e-3), None, None, "cuda", "cuda", False, None)
+        losses, paths = [], []
+        for _ in range(3):
+            if barrier is not None:
+                barrier.wait(timeout=120)                       # both threads enqueue their step at the same moment
+            valid, loss = tr.step((x, targets, pct.clone(), tsz))
+            assert valid
+            losses.append(float(loss))
+            paths.append(ops.rnn_last_path())
+        tr.synchronize()
+        stream.synchronize()
+        flat, _ = model.flat_parameters()
+        return losses, flat.detach().cpu().clone(), paths, ops.rnn_persistent_counters()[0], ops.rnn_ctx_key()
+
+
+def test_two_threads_on_two_streams_are_independent_and_bit_identical_to_serial_runs():
+    """SURVEY §8(b) "Threading": the library keeps no mutable global state — what the recurrence entry points remember lives in a
+    caller-owned ds2_rnn_ctx, one per (thread, device) in this binding.  Two Python threads drive c1-sized GRU and LSTM train steps (BASELINE
+    configs[0]'s 2 x 256 width, bf16 and fp32) on two streams AT THE SAME TIME; each must end bit-identical to its own serial run, each sees
+    its own kernel-path bits (GRU bf16: K-split backward = bits 1|2|4; LSTM fp32: another family), and the two threads hold different contexts."""
+    t_ins = [201, 190, 171, 160]
+    gru = dict(rnn="gru", hidden=256, layers=2, classes=29, t_ins=t_ins, precision="bf16")
+    lstm = dict(rnn="lstm", hidden=256, layers=2, classes=29, t_ins=t_ins, precision="fp32")
+    serial = {k: _three_steps(c, torch.cuda.Stream()) for k, c in (("gru", gru), ("lstm", lstm))}
+    barrier = threading.Barrier(2)
+    res, err = {}, []
+
+    def work(name, cfg):
+        try:
+            res[name] = _three_steps(cfg, torch.cuda.Stream(), barrier)
+        except BaseException as e:               # noqa: BLE001 - reported by the main thread
+            err.append((name, repr(e)))
+            barrier.abort()
+    th = [threading.Thread(target=work, args=("gru", gru)), threading.Thread(target=work, args=("lstm", lstm))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+    assert not err, err
+    for name in ("gru", "lstm"):
+        sl, sw, sp, ss, sk = serial[name]
+        cl, cw, cp, cs, ck = res[name]
+        assert cl == sl, (name, cl, sl)                          # losses bit for bit
+        assert torch.equal(cw, sw), name                         # every weight after three AdamW steps
+        assert cp == sp, (name, cp, sp)                          # the same kernel families as in the serial run
+        assert cs == 0 and ss == 0
+    assert res["gru"][4] != res["lstm"][4] and res["gru"][4] != serial["gru"][4]   # three different contexts (main thread + two workers)
+    assert res["gru"][2] != res["lstm"][2]                       # each thread read ITS OWN path bits, not the other's
