@@ -88,6 +88,7 @@ SIGNATURES = {
     "ds2_padcast_bf16": (i32, [vp, vp, i64, i32, vp]),
     "ds2_conv2_wgrad_bf16_workspace_bytes": (sz, [i32, i32]),
     "ds2_conv2_wgrad_bf16": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, sz, vp]),
+    "ds2_conv2_wgrad_nhwc_bf16": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, sz, vp]),
     "ds2_rnn_packed_bytes": (sz, [i32, i32, i32, i32]),
     "ds2_rnn_pack_whh": (i32, [i32, vp, vp, vp, i32, i32, vp]),
     "ds2_rnn_fwd_workspace_bytes": (sz, [i32, i32, i32]),

@@ -607,6 +607,185 @@ __global__ __launch_bounds__(256) void padcast_kernel(const float* __restrict__ 
 
 }  // namespace
 
+
+// =============================================================================================================
+// conv2 weight gradient from the CHANNELS-LAST operands the rest of the bf16 conv stack already has (round 5).
+//   dW[co][ci][kd][kt] = sum_{b,o,t} dY[b,o,t][co] * A1[b, 2o+kd-10, t+kt-5][ci]       dY (B,D2,T,32), A1 (B,D1,T,32) bf16
+// With time as the ROW index of both LDS images ([t][32 channels], 64-byte rows) the tap shift is a row offset — always aligned — so the
+// eight pre-shifted dY copies of the kernel above (80 KB of ds_write_b128 per 64 output steps: as much LDS time as the MFMAs) are not
+// needed: rows go global -> LDS by DMA (global_load_lds, one 1 KiB instruction = 16 time steps, no VGPR staging, no write pass) and an
+// MFMA operand (32 channels x 16 steps, 8 consecutive steps per lane) is gathered by two ds_read_b64_tr_b16 — a 32-lane half of such a
+// read covers 4 consecutive rows = 256 contiguous bytes = every bank once, no swizzle.  K runs over the OUTPUT time of a 128-step segment
+// (no halo steps multiplied: 8 k-steps of 16, against 5 for 64 outputs above); the A1 rows are staged with 8 halo steps on either side.
+// block = (group of 3 kernel rows, chunk of (b,o) pairs) as above: 4 waves split the 11 time taps, 9 accumulators per wave live in registers
+// across the chunk; per k-step one dY fragment feeds all 9 MFMAs of the wave, each (kernel row, tap) has its own A1 fragment.
+// Segments are double-buffered: the DMA of segment i+1 is issued behind the barrier that ends segment i-1's reads.
+// Same partial layout as above (ordered reduction by conv2_wgrad_bf16_reduce_kernel: deterministic).
+// =============================================================================================================
+namespace {
+constexpr int NS = 128;                          // output time steps per segment
+constexpr int NA1 = NS + 16;                     // staged steps per A1 row: t in [t0 - 8, t0 + 136)
+constexpr int SEG_DY = NS * 64;                  // 8192
+constexpr int SEG_A1 = NA1 * 64;                 // 9216 per kernel row
+constexpr int SEG_BYTES = SEG_DY + KDG * SEG_A1; // 35840
+typedef __attribute__((address_space(3))) void lds_void_c;
+typedef const __attribute__((address_space(1))) void gbl_void_c;
+typedef float f32x2c __attribute__((ext_vector_type(2)));
+
+struct W2Args {
+  const __bf16* a1n;   // (B, D1, T, 32)
+  const __bf16* dyn;   // (B, D2, T, 32)
+  float* part;         // [chunks][7 groups][33 taps][32 co][32 ci]
+  const int* lens;
+  int B, D1, D2, T, pairs_per_chunk;
+};
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv2_wgrad_nhwc_kernel(W2Args a) {
+  extern __shared__ __attribute__((aligned(1024))) char seg[];      // [2][dY 128 x 64 B | A1 3 x 144 x 64 B]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int grp = blockIdx.x, chunk = blockIdx.y;
+  const int kd0 = grp * KDG;
+
+  f32x16 acc[TPW];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  const int npairs = a.B * a.D2;
+  const int pend = min(npairs, (chunk + 1) * a.pairs_per_chunk);
+  int p = chunk * a.pairs_per_chunk, t0 = 0;
+  auto settle = [&]() {                         // move (p, t0) to the next existing segment; false when the chunk is exhausted
+    while (p < pend) {
+      const int len = a.lens ? min(a.lens[p / a.D2], a.T) : a.T;
+      if (t0 < len) return true;
+      ++p;
+      t0 = 0;
+    }
+    return false;
+  };
+  // DMA of one segment: wave w moves dY pieces w, w + 4 (16 steps each) and A1 pieces w, w + 4, .. (< 27 = 3 rows x 9); a lane fetches the
+  // 16-byte quarter (lane & 3) of step (lane >> 2) of its piece; steps outside the tensor read the zero page
+  const int prow = lane >> 2, pq = (lane & 3) * 8;
+  auto stage = [&](int buf, int sp, int st0) {
+    const int b = sp / a.D2, o = sp % a.D2;
+    char* base = seg + buf * SEG_BYTES;
+    const __bf16* dyrow = a.dyn + ((long long)(b * a.D2 + o) * a.T) * 32;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int piece = wave + 4 * i;
+      const int t = st0 + piece * 16 + prow;
+      const void* src = t < a.T ? (const void*)(dyrow + (long long)t * 32 + pq) : (const void*)g_zero_cb;
+      __builtin_amdgcn_global_load_lds((gbl_void_c*)src, (lds_void_c*)(base + piece * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int idx = wave + 4 * i;
+      if (idx < KDG * 9) {
+        const int kdl = idx / 9, piece = idx % 9;
+        const int f = 2 * o + (kd0 + kdl) - 10;
+        const int t = st0 - 8 + piece * 16 + prow;
+        const bool ok = (kd0 + kdl) < 21 && f >= 0 && f < a.D1 && t >= 0 && t < a.T;
+        const void* src = ok ? (const void*)(a.a1n + ((long long)(b * a.D1 + f) * a.T + t) * 32 + pq) : (const void*)g_zero_cb;
+        __builtin_amdgcn_global_load_lds((gbl_void_c*)src, (lds_void_c*)(base + SEG_DY + kdl * SEG_A1 + piece * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  // fragment addresses (buffer 0, k-step 0, first of the two tr-reads): lane p of a 16-lane group addresses row (p >> 2), channels
+  // 4 (p & 3) .. + 3 of the group's 16 channels; the second read is 4 rows (256 B) on, a k-step 16 rows (1024 B)
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_c*)seg;
+  const int p16 = lane & 15, g16 = (lane >> 4) & 1;
+  const unsigned lanepart = (unsigned)((half * 8 + (p16 >> 2)) * 64 + (g16 * 16 + 4 * (p16 & 3)) * 2);
+  const unsigned dyaddr = lds0 + lanepart;
+  unsigned a1addr[3];                            // per tap of this wave: the staged A1 row image starts at t0 - 8, tap kt reads step t + kt - 5
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int kt = min(wave + 4 * q, KT - 1);
+    a1addr[q] = lds0 + SEG_DY + (unsigned)((kt - PT + 8) * 64) + lanepart;
+  }
+
+  bool have = settle();
+  int cur = 0;
+  int np = p, nt0 = t0;
+  if (have) stage(0, p, t0);
+  while (have) {
+    // next segment of the chunk (its DMA goes out behind the barrier below)
+    nt0 = t0 + NS; np = p;
+    { const int sp = p, st = t0; p = np; t0 = nt0; const bool more = settle(); np = p; nt0 = t0; p = sp; t0 = st; have = more; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // own pieces of the current segment have landed
+    __syncthreads();                                          // everybody's have; everybody is done reading the other buffer
+    if (have) stage(cur ^ 1, np, nt0);
+    const unsigned boff = (unsigned)(cur * SEG_BYTES);
+    // 8 k-steps x 3 tap groups, software-pipelined by one group: the reads of group (ks, q + 1) — for q = 2: the next k-step's dY fragment
+    // and its first group — are issued BEFORE the three MFMAs of group (ks, q), whose own fragments a counted lgkmcnt retires (LDS returns in
+    // order; at most 8 + 6 = 14 reads in flight, the counter holds 15).  Fragment registers: two dY slots, two group slots.
+    f32x4 fd[2], fg[2][KDG];
+#define W2_RD(dst, addr, off)                                                                                                         \
+    do {                                                                                                                              \
+      f32x2c lo_, hi_;                                                                                                                \
+      asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"                                        \
+                   : "=&v"(lo_), "=&v"(hi_)                                                                                           \
+                   : "v"(addr), "n"(off), "n"((off) + 256));                                                                          \
+      dst = __builtin_shufflevector(lo_, hi_, 0, 1, 2, 3);                                                                            \
+    } while (0)
+#define W2_GROUP_RD(slot, ks, q)                                                                                                      \
+    do {                                                                                                                              \
+      W2_RD(fg[slot][0], a1addr[q] + boff, (ks) * 1024);                                                                              \
+      W2_RD(fg[slot][1], a1addr[q] + boff, (ks) * 1024 + SEG_A1);                                                                     \
+      W2_RD(fg[slot][2], a1addr[q] + boff, (ks) * 1024 + 2 * SEG_A1);                                                                 \
+    } while (0)
+#define W2_GROUP_MMA(slot, dslot, q, NWAIT)                                                                                           \
+    do {                                                                                                                              \
+      asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fd[dslot]), "+v"(fg[slot][0]), "+v"(fg[slot][1]), "+v"(fg[slot][2]) : "n"(NWAIT) : "memory"); \
+      _Pragma("unroll") for (int kdl = 0; kdl < KDG; ++kdl)                                                                           \
+        acc[(q) * KDG + kdl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fd[dslot]), __builtin_bit_cast(bf16x8, fg[slot][kdl]), \
+                                                                      acc[(q) * KDG + kdl], 0, 0, 0);                                  \
+      __builtin_amdgcn_sched_barrier(0);                                                                                              \
+    } while (0)
+    W2_RD(fd[0], dyaddr + boff, 0);
+    W2_GROUP_RD(0, 0, 0);
+#pragma unroll
+    for (int ks = 0; ks < NS / 16; ++ks) {
+      const int s0 = (3 * ks) & 1, d = ks & 1;               // slot of group (ks, 0); groups alternate slots
+      W2_GROUP_RD(s0 ^ 1, ks, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      W2_GROUP_MMA(s0, d, 0, 6);
+      W2_GROUP_RD(s0, ks, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      W2_GROUP_MMA(s0 ^ 1, d, 1, 6);
+      if (ks + 1 < NS / 16) {
+        W2_RD(fd[d ^ 1], dyaddr + boff, (ks + 1) * 1024);
+        W2_GROUP_RD(s0 ^ 1, ks + 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        W2_GROUP_MMA(s0, d, 2, 8);
+      } else {
+        W2_GROUP_MMA(s0, d, 2, 0);
+      }
+    }
+#undef W2_RD
+#undef W2_GROUP_RD
+#undef W2_GROUP_MMA
+    p = np; t0 = nt0; cur ^= 1;
+  }
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int kt = wave + 4 * (i / KDG), kdl = i % KDG;
+    if (kt < KT) {
+      const int tap = kdl * KT + kt;
+      float* out = a.part + ((((long long)chunk * gridDim.x + grp) * TAPS + tap) * 32) * 32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
+        out[co * 32 + l31] = acc[i][r];
+      }
+    }
+  }
+}
+}  // namespace
+
 extern "C" int ds2_conv_padded_pitch(int T) { return (T + 16 + 7) / 8 * 8; }
 
 // (R, T) fp32 -> (R, Tp) bf16 with 8 leading zeros and zero tail, Tp = ds2_conv_padded_pitch(T)
@@ -643,6 +822,34 @@ extern "C" int ds2_conv2_wgrad_bf16(const void* a1p, const void* dy2p, const int
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(conv2_wgrad_bf16_kernel, dim3(7, chunks), dim3(256), 0, s, a);
   DS2_LAUNCH_CHECK("conv2_wgrad_bf16_kernel");
+  hipLaunchKernelGGL(conv2_wgrad_bf16_reduce_kernel, dim3(ceil_div(7 * TAPS * 32 * 32, 256)), dim3(256), 0, s, (const float*)ws, dW2, chunks, 7);
+  DS2_LAUNCH_CHECK("conv2_wgrad_bf16_reduce_kernel");
+  return 0;
+}
+
+// dW2 (32,32,21,11) fp32 from the channels-last bf16 operands a1 (B,D1,T,32) and dy2 (B,D2,T,32) [ds2_nhwc_bf16_f32 / the fused BatchNorm2d
+// kernels' nhwc outputs]: conv2_wgrad_nhwc_kernel.  Same workspace as ds2_conv2_wgrad_bf16.  Replaces Conv2d's weight gradient under
+// loss.backward() (asr_deepspeech/modules/deepspeech.py:64, trainers/deepspeech_trainer.py:87).
+extern "C" int ds2_conv2_wgrad_nhwc_bf16(const void* a1_nhwc, const void* dy2_nhwc, const int* lens_dev, float* dW2, int B, int D1, int T, void* ws,
+                                         size_t ws_bytes, void* stream) {
+  DS2_REQUIRE(a1_nhwc && dy2_nhwc && dW2 && ws, "ds2_conv2_wgrad_nhwc_bf16: null pointer");
+  DS2_REQUIRE(ws_bytes >= ds2_conv2_wgrad_bf16_workspace_bytes(B, D1), "ds2_conv2_wgrad_nhwc_bf16: workspace too small");
+  const int D2 = (D1 + 2 * 10 - 21) / 2 + 1;
+  const int pairs = B * D2;
+  int chunks = pairs < 73 ? pairs : 73;
+  const int ppc = ceil_div(pairs, chunks);
+  chunks = ceil_div(pairs, ppc);
+  W2Args a{};
+  a.a1n = (const __bf16*)a1_nhwc; a.dyn = (const __bf16*)dy2_nhwc; a.part = (float*)ws; a.lens = lens_dev;
+  a.B = B; a.D1 = D1; a.D2 = D2; a.T = T; a.pairs_per_chunk = ppc;
+  hipStream_t s = (hipStream_t)stream;
+  static bool attr = false;
+  if (!attr) {
+    DS2_HIP(hipFuncSetAttribute((const void*)conv2_wgrad_nhwc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SEG_BYTES));
+    attr = true;
+  }
+  hipLaunchKernelGGL(conv2_wgrad_nhwc_kernel, dim3(7, chunks), dim3(256), 2 * SEG_BYTES, s, a);
+  DS2_LAUNCH_CHECK("conv2_wgrad_nhwc_kernel");
   hipLaunchKernelGGL(conv2_wgrad_bf16_reduce_kernel, dim3(ceil_div(7 * TAPS * 32 * 32, 256)), dim3(256), 0, s, (const float*)ws, dW2, chunks, 7);
   DS2_LAUNCH_CHECK("conv2_wgrad_bf16_reduce_kernel");
   return 0;

@@ -93,6 +93,10 @@ F32_CONV = _os.environ.get("DS2_F32_CONV", "split")
 # (test_step_vs_oracle_larger[gru-128-2-33-90], conv.seq_module.0.weight; the fp32-input kernel passes all of them), and 0.6 ms on a
 # secondary configuration does not buy a parity case (profiles/r04_f32_conv_ab.txt).
 F32_CONV_FWD = _os.environ.get("DS2_F32_CONV_FWD", "f32")
+# bf16 mode, conv2's weight gradient (DS2_CONV2_WGRAD): "nhwc" (default, round 5) = from the channels-last operands conv2's forward / data
+# gradient already take (time-major LDS images filled by DMA; no padded copies of a1 / dY2 are written any more); "pad" = the round-2 kernel
+# on zero-padded (B,32,D,Tp) copies (eight pre-shifted dY copies in LDS).  A/B: profiles/r05_conv_ab.txt.
+CONV2_WGRAD = _os.environ.get("DS2_CONV2_WGRAD", "nhwc")
 
 
 def _f32_split_ok(M: int, N: int, K: int, H: int = 8) -> bool:
@@ -185,7 +189,7 @@ class Ctx:
     lens_dev: Optional[Tensor] = None
     y1: Optional[Tensor] = None
     a1: Optional[Tensor] = None      # fp32 Hardtanh(BN(conv1)) (fp32 mode; bf16 mode keeps only a1p)
-    a1p: Optional[Tensor] = None     # bf16 mode: its zero-padded bf16 copy, operand of conv2's weight gradient
+    a1p: Optional[Tensor] = None     # bf16 mode: the bf16 operand of conv2's weight gradient (channels-last copy; DS2_CONV2_WGRAD=pad: zero-padded rows)
     y2: Optional[Tensor] = None
     st1: tuple = ()
     st2: tuple = ()
@@ -240,14 +244,16 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
     if cfg.precision == "bf16":
         # one pass over y1 emits conv2's channels-last operand and (when backward follows) the zero-padded operand of conv2's weight
         # gradient; the fp32 activation itself has no consumer in this mode (debug_acts keeps it for the tests that inspect it)
-        a1, a1p, a1n = ops.bn2d_act_fwd_fused(y1, lens_dev, m1, v1, W[cp + "1.weight"], W[cp + "1.bias"], want_f32=debug_acts, want_pad=save,
-                                              want_nhwc=True)
+        a1, a1p, a1n = ops.bn2d_act_fwd_fused(y1, lens_dev, m1, v1, W[cp + "1.weight"], W[cp + "1.bias"], want_f32=debug_acts,
+                                              want_pad=save and CONV2_WGRAD != "nhwc", want_nhwc=True)
         cwf, cwd0, cwd1 = ops.conv2_pack_bf16(W[cp + "3.weight"])
         ctx.packs = (None, cwd0, cwd1)
         y2 = ops.conv2_fwd_bf16(a1n, cwf, W[cp + "3.bias"], lens_dev, stats=training and CONV_STATS)
         st_part2 = None
         if training and CONV_STATS:
             y2, st_part2 = y2
+        if save and CONV2_WGRAD == "nhwc":
+            a1p = a1n                                            # the channels-last copy IS the weight-gradient operand (kept for backward)
         del a1n
     elif F32_CONV_FWD == "split6":
         a1, a1p = ops.bn2d_act_fwd(y1, lens_dev, m1, v1, W[cp + "1.weight"], W[cp + "1.bias"]), None      # (the same a1 as the fp32-kernel path, bit for bit)
@@ -779,9 +785,12 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
         # dY2 leaves the BatchNorm backward directly as the two bf16 operands conv2's weight gradient / input gradient take, together
         # with conv2's bias gradient (its per-channel sums); conv1's stage keeps fp32 dY1 (cast on the fly by conv1's weight gradient)
         _, dy2p, dy2n = ops.bn2d_act_bwd_fused(ctx.y2, da2, lens_dev, m2, v2, W[cp + "4.weight"], W[cp + "4.bias"], Gr[cp + "4.weight"],
-                                               Gr[cp + "4.bias"], Gr[cp + "3.bias"], want_pad=True, want_nhwc=True)
+                                               Gr[cp + "4.bias"], Gr[cp + "3.bias"], want_pad=CONV2_WGRAD != "nhwc", want_nhwc=True)
         del da2
-        ops.conv2_wgrad_bf16(ctx.a1p, dy2p, lens_dev, Gr[cp + "3.weight"], T)
+        if CONV2_WGRAD == "nhwc":
+            ops.conv2_wgrad_nhwc_bf16(ctx.a1p, dy2n, lens_dev, Gr[cp + "3.weight"])
+        else:
+            ops.conv2_wgrad_bf16(ctx.a1p, dy2p, lens_dev, Gr[cp + "3.weight"], T)
         da1 = ops.conv2_dgrad_bf16(dy2n, ctx.packs[1], ctx.packs[2], D1)
         del dy2p, dy2n
         m1, v1 = ctx.st1

@@ -780,6 +780,18 @@ def conv2_wgrad_bf16(a1p: Tensor, dy2p: Tensor, lens_dev: Tensor, dW2: Tensor, T
                                         _stream()), "ds2_conv2_wgrad_bf16")
 
 
+def conv2_wgrad_nhwc_bf16(a1n: Tensor, dy2n: Tensor, lens_dev: Tensor, dW2: Tensor):
+    """dW2 (32,32,21,11) fp32 from the channels-last bf16 operands a1n (B,D1,T,32), dy2n (B,D2,T,32) (ops.nhwc_bf16 / the fused BatchNorm2d
+    kernels' nhwc outputs)."""
+    lib = _lib.load()
+    B, D1, T, _ = a1n.shape
+    assert a1n.dtype == torch.bfloat16 and dy2n.dtype == torch.bfloat16 and a1n.is_contiguous() and dy2n.is_contiguous() and dy2n.shape[2] == T
+    wsb = lib.ds2_conv2_wgrad_bf16_workspace_bytes(B, D1)
+    ws = _ws(wsb, a1n.device)
+    _lib.check(lib.ds2_conv2_wgrad_nhwc_bf16(a1n.data_ptr(), dy2n.data_ptr(), lens_dev.data_ptr(), dW2.data_ptr(), B, D1, T, ws.data_ptr(), wsb,
+                                             _stream()), "ds2_conv2_wgrad_nhwc_bf16")
+
+
 # ------------------------------------------------------------------------------------------------
 # recurrence
 # ------------------------------------------------------------------------------------------------

@@ -212,6 +212,11 @@ int ds2_padcast_bf16(const float* src, void* dst, long long R, int T, void* stre
 size_t ds2_conv2_wgrad_bf16_workspace_bytes(int B, int D1);
 int ds2_conv2_wgrad_bf16(const void* a1p, const void* dy2p, const int* lens_dev, float* dW2, int B, int D1, int T, void* ws, size_t ws_bytes,
                          void* stream);
+/* The same weight gradient from the CHANNELS-LAST bf16 operands the conv2 forward / data-gradient kernels already take (a1 (B,D1,T,32),
+ * dy2 (B,D2,T,32)): no padded copies, operands go global -> LDS by DMA and the kernel-tap shift is a row offset of the time-major LDS image
+ * (Conv2d weight gradient under loss.backward(), modules/deepspeech.py:64 / trainers/deepspeech_trainer.py:87).  Workspace: as above. */
+int ds2_conv2_wgrad_nhwc_bf16(const void* a1_nhwc, const void* dy2_nhwc, const int* lens_dev, float* dW2, int B, int D1, int T, void* ws,
+                              size_t ws_bytes, void* stream);
 
 /* ---- bidirectional GRU / LSTM recurrence -------------------------------------------------------
  * pack_padded_sequence -> aten::gru / aten::lstm -> pad_packed_sequence, modules/blocks.py:87-89, h0 = 0,

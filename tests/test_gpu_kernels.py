@@ -351,6 +351,13 @@ def test_conv2_bf16(dev, B, Tin, lens_in):
     assert float(a1p[..., :8].abs().sum()) == 0 and torch.equal(a1p[..., 8:8 + T].cpu(), a1.bfloat16())
     ops.conv2_wgrad_bf16(a1p, dyp, ld, dW2, T)
     assert rel_l2(dW2.cpu(), w2r.grad) < 1e-5
+    # the same gradient from the channels-last operands (round 5: time-major LDS images filled by DMA, tap shift = row offset)
+    dW2n = torch.full((32, 32, 21, 11), float("nan"), device=dev)
+    ops.conv2_wgrad_nhwc_bf16(a1n, ops.nhwc_bf16(g(dy2, dev)), ld, dW2n)
+    assert rel_l2(dW2n.cpu(), w2r.grad) < 1e-5
+    dW2m = torch.empty_like(dW2n)
+    ops.conv2_wgrad_nhwc_bf16(a1n, ops.nhwc_bf16(g(dy2, dev)), ld, dW2m)
+    assert torch.equal(dW2n, dW2m)                                               # run-to-run bit-identical (ordered reduction)
 
 
 @pytest.mark.parametrize("B,Tin,lens_in", [(2, 40, [40, 21]), (3, 300, [300, 257, 90]), (2, 131, [131, 1])])
