@@ -28,6 +28,14 @@ int ds2_set_error(const char* fmt, ...);
   } while (0)
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+// Environment switches.  OPERATIONAL ones (DS2_RNN_PERSISTENT, DS2_RNN_SPIN_LIMIT, DS2_RNN_REARM_CALLS, DS2_RNN_XCD_LOCAL, DS2_F32_RNN) are read
+// with getenv.  TUNING / A-B switches of experiments — most of which lost (DS2_GEMM_RING, DS2_GEMM_WAVES, DS2_GEMM_TILE, DS2_GEMM_DBG, ...) —
+// are honoured only when DS2_EXPERIMENTAL=1 is set as well, so that a stray variable cannot change what the product runs.
+#include <stdlib.h>
+static inline const char* ds2_exp_getenv(const char* name) {
+  const char* on = getenv("DS2_EXPERIMENTAL");
+  return (on && on[0] == '1') ? getenv(name) : nullptr;
+}
 static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 
 // wave64 reductions (all 64 lanes participate)

@@ -365,7 +365,7 @@ extern "C" int ds2_conv2_fwd_bf16_stats(const void* a1_nhwc, const void* wf, con
   a.B = B; a.Din = D1; a.T = T; a.Dtot = D2; a.KD = 21; a.SD = 2; a.PD = 10; a.OS = 1; a.OO = 0;
   // three output rows per block (5 input-row slots + the weight row = 77 KB of LDS, two blocks per CU): 655 -> 561 us at c3; two rows
   // 614, four rows (one block per CU) 767.  DS2_CONV2_ROWS=1: the one-row kernel (A/B switch)
-  static const char* rows_env = getenv("DS2_CONV2_ROWS");
+  static const char* rows_env = ds2_exp_getenv("DS2_CONV2_ROWS");
   DS2_REQUIRE(!stat_part || !(rows_env && rows_env[0] == '1'), "ds2_conv2_fwd_bf16_stats: the one-row kernel (DS2_CONV2_ROWS=1) has no statistics epilogue");
   // blocks of a fully masked tile return early: their slots must read as zeros
   if (stat_part) DS2_HIP(hipMemsetAsync(stat_part, 0, (size_t)ds2_conv2_fwd_bf16_stat_blocks(B, D1, T) * 64 * sizeof(float), (hipStream_t)stream));
@@ -391,7 +391,7 @@ extern "C" int ds2_conv2_dgrad_bf16(const void* dy2_nhwc, const void* wd0, const
     a.in = (const __bf16*)dy2_nhwc; a.wpk = (const __bf16*)(p == 0 ? wd0 : wd1); a.bias = nullptr; a.out = da1; a.lens = nullptr;
     a.B = B; a.Din = D2; a.T = T; a.Dtot = D1; a.KD = KDe; a.SD = 1; a.PD = KDe - 6; a.OS = 2; a.OO = p;
     // four output rows per block here (rows one apart: 4 input-row slots): 2 x 347 -> 2 x 290 us
-    static const char* rows_env = getenv("DS2_CONV2_ROWS");
+    static const char* rows_env = ds2_exp_getenv("DS2_CONV2_ROWS");
     if (rows_env && rows_env[0] == '1') hipLaunchKernelGGL(conv2_bf16_kernel, dim3(ceil_div(T, TT), n_o, B), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((conv2_bf16_rows_kernel<1, 4>), dim3(ceil_div(T, TT), ceil_div(n_o, 4), B), dim3(256), 0, (hipStream_t)stream, a, n_o, (float*)nullptr);
   }

@@ -1082,20 +1082,20 @@ extern "C" int ds2_gemm_bf16_nt(int M, int N, int K, const void* A, int lda, lon
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.sA = strideA; g.sB = strideB; g.sC = strideC;
   g.splitk = splitk; g.kchunk = kchunk; g.accumulate = accumulate; g.partial = (float*)workspace;
-  static const char* nt_env = getenv("DS2_GEMM_NT");       // tuning override, default on
+  static const char* nt_env = ds2_exp_getenv("DS2_GEMM_NT");       // tuning override, default on
   g.nt_store = nt_env ? (nt_env[0] != '0') : 1;
   // timing experiments only (WRONG RESULTS; scripts/ab_gemm_dbg.sh): 1 = no operand DMA after the first k-tile, 16 = 1/16 of the C
   // stores, 32 = C stores aimed at an L2-resident region
-  static const int dbg_bits = getenv("DS2_GEMM_DBG") ? atoi(getenv("DS2_GEMM_DBG")) << 1 : 0;
+  static const int dbg_bits = ds2_exp_getenv("DS2_GEMM_DBG") ? atoi(ds2_exp_getenv("DS2_GEMM_DBG")) << 1 : 0;
   g.nt_store |= dbg_bits;
-  static const char* wide_env = getenv("DS2_GEMM_WIDE");  // "0": lane-per-column epilogue stores (A/B switch)
+  static const char* wide_env = ds2_exp_getenv("DS2_GEMM_WIDE");  // "0": lane-per-column epilogue stores (A/B switch)
   if (wide_env && wide_env[0] == '0') g.nt_store |= 128;
-  static const int super_rows = getenv("DS2_GEMM_SR") ? atoi(getenv("DS2_GEMM_SR")) : 4;   // row tiles per super-row of the tile walk (0: row-major)
+  static const int super_rows = ds2_exp_getenv("DS2_GEMM_SR") ? atoi(ds2_exp_getenv("DS2_GEMM_SR")) : 4;   // row tiles per super-row of the tile walk (0: row-major)
   g.super_rows = batch == 1 ? super_rows : 0;
   hipStream_t s = (hipStream_t)stream;
   // 256 x 256 LDS-DMA kernel whenever its tiles cover at least half the chip; the 128 x 128 kernel for everything smaller
   const long long tiles256 = (long long)ceil_div(N, 256) * ceil_div(M, 256) * batch * splitk;
-  static const char* force = getenv("DS2_GEMM_TILE");      // "128" | "glds": tuning override (scripts/bench_gemm.py)
+  static const char* force = ds2_exp_getenv("DS2_GEMM_TILE");      // "128" | "glds": tuning override (scripts/bench_gemm.py)
   const bool use_glds = force ? (force[0] == 'g') : (M >= 256 && N >= 256 && tiles256 >= 128);
   if (use_glds) {
     static bool attr_set = false;
@@ -1106,7 +1106,7 @@ extern "C" int ds2_gemm_bf16_nt(int M, int N, int K, const void* A, int lda, lon
     const int ntx = ceil_div(N, 256), nty = ceil_div(M, 256);
     // 8 waves (128 x 64 per wave) for every shape (a 16-wave 64 x 64 variant lost to it in round 2 once the epilogue went through LDS and is no
     // longer built).
-    static const char* wv = getenv("DS2_GEMM_WAVES");      // "pp": the ping-pong schedule of the one-tile kernel (tuning override)
+    static const char* wv = ds2_exp_getenv("DS2_GEMM_WAVES");      // "pp": the ping-pong schedule of the one-tile kernel (tuning override)
     const bool pp = wv && wv[0] == 'p';
     if (pp) {
       static bool pp_attr = false;
@@ -1117,7 +1117,7 @@ extern "C" int ds2_gemm_bf16_nt(int M, int N, int K, const void* A, int lda, lon
       hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<2, 4, true>), dim3(ntx * nty, 1, batch * splitk), dim3(512), G_LDS, s, g, ntx, nty);
     } else {
       // persistent form (one workgroup per CU walking several tiles; see the kernel): short reductions with more tiles than CUs, plain write-out
-      static const char* pe = getenv("DS2_GEMM_PERS");     // "0": one workgroup per tile for every shape (A/B switch)
+      static const char* pe = ds2_exp_getenv("DS2_GEMM_PERS");     // "0": one workgroup per tile for every shape (A/B switch)
       static int cus = 0;
       if (!cus) {
         int dev = 0;
@@ -1133,7 +1133,7 @@ extern "C" int ds2_gemm_bf16_nt(int M, int N, int K, const void* A, int lda, lon
       // DS2_GEMM_RING=1 the software-pipelined loop over a four-slice LDS ring with counted DMA waits, =q the ping-pong form on
       // v_mfma_f32_16x16x32_bf16 with a register-direct epilogue.  Both are bound, like the production kernel, by what a CU can take in
       // through its vector-memory path when part of the operand stream misses the L2 (the operand DMA alone, no MFMA: 350 us on the dX shape).
-      static const char* ring_env = getenv("DS2_GEMM_RING");
+      static const char* ring_env = ds2_exp_getenv("DS2_GEMM_RING");
       const bool ring = ring_env && (ring_env[0] == '1' || ring_env[0] == 'q') && !(pe && pe[0] == '0') && batch == 1 && splitk == 1 && !accumulate &&
                         (K % 32) == 0 && K >= 128 && wide && !(g.nt_store & ~1) && ntx * nty > cus;
       if (ring) {
@@ -1143,7 +1143,7 @@ extern "C" int ds2_gemm_bf16_nt(int M, int N, int K, const void* A, int lda, lon
           DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_nt_pp16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, R_RING));
           rattr = true;
         }
-        static const int rdbg = getenv("DS2_RING_DBG") ? atoi(getenv("DS2_RING_DBG")) : 0;   // timing ablations of the pp16 kernel (WRONG RESULTS)
+        static const int rdbg = ds2_exp_getenv("DS2_RING_DBG") ? atoi(ds2_exp_getenv("DS2_RING_DBG")) : 0;   // timing ablations of the pp16 kernel (WRONG RESULTS)
         if (ring_env[0] == 'q' && rdbg) {
 #define DS2_Q_DBG(n) if (rdbg == n) { DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_nt_pp16_kernel<false, n>, hipFuncAttributeMaxDynamicSharedMemorySize, R_RING)); \
                        hipLaunchKernelGGL((gemm_bf16_nt_pp16_kernel<false, n>), dim3(cus, 1, 1), dim3(512), R_RING, s, g, ntx, nty); }
@@ -1199,7 +1199,7 @@ extern "C" int ds2_gemm_bf16_tn(int M, int N, int K, const void* A, int lda, lon
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.sA = strideA; g.sB = strideB; g.sC = strideC;
   g.splitk = splitk; g.kchunk = kchunk; g.accumulate = accumulate; g.partial = (float*)workspace; g.nt_store = 0; g.super_rows = 0;
-  { static const char* wide_env = getenv("DS2_GEMM_WIDE"); if (wide_env && wide_env[0] == '0') g.nt_store |= 128; }
+  { static const char* wide_env = ds2_exp_getenv("DS2_GEMM_WIDE"); if (wide_env && wide_env[0] == '0') g.nt_store |= 128; }
   hipStream_t s = (hipStream_t)stream;
   static bool attr_set = false;
   if (!attr_set) {

@@ -1990,7 +1990,7 @@ extern "C" int ds2_rnn_bwd_ex(ds2_rnn_ctx* ctx, int gates, const float* dy, int 
       if (persist_idle(ctx, true) && !(env && env[0] == 'f') && !a.gates_bf && !a.dgx_bf) {
         RnnArgs b = a;
         b.wp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(wp_bwd) + ds2_rnn_packed_bytes(gates, H, 1, 0));
-        static const char* envk = getenv("DS2_RNN_KSPLIT");
+        static const char* envk = ds2_exp_getenv("DS2_RNN_KSPLIT");
         const int rk = (envk && envk[0] == '0') ? 0 : (gates == 3 ? try_launch_ksplit_bwd<3, true>(b, st) : try_launch_ksplit_bwd<4, true>(b, st));
         if (rk < 0) return rk;
         if (rk == 1) { rc = 1; split = true; last_bwd_kind = 2; }

@@ -513,7 +513,7 @@ template <int G, bool SP = false>
 int try_launch_ksplit_bwd(RnnArgs a, hipStream_t st) {
   constexpr int NPL = SP ? 2 : 1;
   static const char* env = getenv("DS2_RNN_PERSISTENT");
-  static const char* envk = getenv("DS2_RNN_KSPLIT");               // "0": keep the all-gather backward kernel (A/B runs)
+  static const char* envk = ds2_exp_getenv("DS2_RNN_KSPLIT");               // "0": keep the all-gather backward kernel (A/B runs)
   if ((env && env[0] == '0') || (envk && envk[0] == '0') || a.dbg) return 0;   // any selector: not this kernel
   if (!((a.gates_bf && a.dgx_bf) || (!a.gates_bf && !a.dgx_bf && a.gx))) return 0;
   if (SP && (a.gates_bf || a.dgx_bf)) return 0;                      // the split form: plain fp32 buffers

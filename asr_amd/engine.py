@@ -31,18 +31,25 @@ import os as _os
 #   "1"            everything off the critical path (GEMMs included) on the side stream (round 1's form: +2.6 ms with the step kernels,
 #                  -0.6 ms with the persistent ones)
 #   "0"            one stream
-OVERLAP_MODE = _os.environ.get("DS2_OVERLAP", "2")
+def _tune(name: str, default: str) -> str:
+    """Tuning / A-B switches of the schedule (most of them experiments that lost and are kept runnable for the record): honoured only together
+    with DS2_EXPERIMENTAL=1, so that a stray variable cannot change what the product runs.  The precision selectors DS2_F32_GEMM / _RNN / _CONV
+    ("f32" = exact fp32 arithmetic instead of split-bf16 products) and the data-parallel schedule DS2_DP_MODE are user choices, not gated."""
+    return _os.environ.get(name, default) if _os.environ.get("DS2_EXPERIMENTAL") == "1" else default
+
+
+OVERLAP_MODE = _tune("DS2_OVERLAP", "2")
 OVERLAP_WGRAD = OVERLAP_MODE == "1"
 # Weight gradients of the recurrent layers in bf16 mode (DS2_WGRAD_TN, default 1): dW_ih / dW_hh as TN-form GEMMs straight from the row-major
 # bf16 buffers the recurrence kernels write (dGx, d(hn), h) and the forward pass kept (Xn), bias gradients from the per-row sums of the
 # backward recurrence — no cast / transpose pass at all.  Needs both recurrences of the layer to have run as persistent launches (they are
 # the ones that write the bf16 copies); a layer whose recurrences did not keeps the transposing-cast passes below.  0: always those passes.
-WGRAD_TN = _os.environ.get("DS2_WGRAD_TN", "1") != "0"
+WGRAD_TN = _tune("DS2_WGRAD_TN", "1") != "0"
 # bf16 mode: BatchNorm2d batch statistics from the conv forward epilogues; needs the rows-per-block conv2 kernel (DS2_CONV2_ROWS != 1)
-CONV_STATS = _os.environ.get("DS2_CONV_STATS", "1") != "0" and _os.environ.get("DS2_CONV2_ROWS", "") != "1"
+CONV_STATS = _tune("DS2_CONV_STATS", "1") != "0" and _tune("DS2_CONV2_ROWS", "") != "1"
 # bf16 training: the elementwise half of every BatchNorm1d backward is applied inside the K-split backward recurrence of the layer below
 # (ops.rnn_bwd_bn: one more 4-byte load per pair and step instead of a pass over (T*B, H)); 0: a separate bn1d_bwd_apply pass as before
-FUSE_BN_BWD = _os.environ.get("DS2_FUSE_BN_BWD", "1") != "0"
+FUSE_BN_BWD = _tune("DS2_FUSE_BN_BWD", "1") != "0"
 # bf16 training, weight gradients of a recurrent layer whose recurrences ran as persistent launches (DS2_WGRAD_SIDE):
 #   "sk" (default) ONE launch of the 256 x 256 TN kernel over all products of the layer with a common split-K factor + ONE reduce launch
 #                  (ops.gemm_bf16_tn_splitk_group: 192 tiles x 4 K slices = 768 equal work items = three full rounds of the chip), compute stream
@@ -56,11 +63,11 @@ FUSE_BN_BWD = _os.environ.get("DS2_FUSE_BN_BWD", "1") != "0"
 #                  1.65-2.0 us per time step (0.83-1.0 ms per layer) — more than the 0.86 ms of work it hides: 27.3 vs 25.9 ms per step.
 #   "main"         the same grouped kernel on the compute stream right behind the layer's critical-path work (the one-stream schedule the
 #                  side-stream results are compared with bit for bit: tests/test_gpu_round4.py); +0.5 ms per step against "0"
-WGRAD_SIDE = _os.environ.get("DS2_WGRAD_SIDE", "sk")
+WGRAD_SIDE = _tune("DS2_WGRAD_SIDE", "sk")
 # "sk" only: run a layer's grouped launch on the side stream beside the NEXT layer's persistent backward recurrence when that recurrence leaves
 # at least DS2_WGRAD_IDLE_MIN_CUS compute units without a workgroup (B = 32 shapes: c2, c4); see _backward_rnn_deferred
-WGRAD_IDLE = _os.environ.get("DS2_WGRAD_IDLE", "1") != "0"
-WGRAD_IDLE_MIN_CUS = int(_os.environ.get("DS2_WGRAD_IDLE_MIN_CUS", "64"))
+WGRAD_IDLE = _tune("DS2_WGRAD_IDLE", "1") != "0"
+WGRAD_IDLE_MIN_CUS = int(_tune("DS2_WGRAD_IDLE_MIN_CUS", "64"))
 # fp32 mode, the dense input-to-hidden products (forward projection, dXn, dW_ih, dW_hh) of layers large enough for the 256 x 256 kernels
 # (DS2_F32_GEMM): "split" (default) = every fp32 operand split into two bf16 terms (hi = bf16(x), lo = bf16(x - hi)) and the product taken
 # as hi.hi + hi.lo + lo.hi on the bf16 matrix cores with fp32 accumulation — ~1e-5 of the fp32 product (the 2^-18 lo.lo term is dropped),
@@ -92,11 +99,11 @@ F32_CONV = _os.environ.get("DS2_F32_CONV", "split")
 # move by the square root of that fraction; with this form one oracle case lands at 1.14e-3 against north_star's 1e-3
 # (test_step_vs_oracle_larger[gru-128-2-33-90], conv.seq_module.0.weight; the fp32-input kernel passes all of them), and 0.6 ms on a
 # secondary configuration does not buy a parity case (profiles/r04_f32_conv_ab.txt).
-F32_CONV_FWD = _os.environ.get("DS2_F32_CONV_FWD", "f32")
+F32_CONV_FWD = _tune("DS2_F32_CONV_FWD", "f32")
 # bf16 mode, conv2's weight gradient (DS2_CONV2_WGRAD): "nhwc" (default, round 5) = from the channels-last operands conv2's forward / data
 # gradient already take (time-major LDS images filled by DMA; no padded copies of a1 / dY2 are written any more); "pad" = the round-2 kernel
 # on zero-padded (B,32,D,Tp) copies (eight pre-shifted dY copies in LDS).  A/B: profiles/r05_conv_ab.txt.
-CONV2_WGRAD = _os.environ.get("DS2_CONV2_WGRAD", "nhwc")
+CONV2_WGRAD = _tune("DS2_CONV2_WGRAD", "nhwc")
 
 
 def _f32_split_ok(M: int, N: int, K: int, H: int = 8) -> bool:
@@ -494,10 +501,12 @@ def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy, done, private: bo
     # take exactly the CUs the recurrence leaves idle — no CU's memory path is shared (what sank the co-resident kernel, DS2_WGRAD_SIDE=1)
     # Measured (profiles/r04_wgrad_idle_ab.txt): c4 (LSTM 1280, 160 of 256 CUs in the recurrence) 55.6 -> 51.7 ms — the recurrence pays 3.93 ->
     # 4.52 us per time step for 1.07 ms of hidden GEMM per layer; c2 (GRU 768, 96 CUs in the recurrence) 15.08 -> 15.07: with 160 CUs the GEMM
-    # is over in 0.4 ms and doubles the step time meanwhile — so only where the recurrence is the majority tenant (idle <= half the chip).
+    # is over in 0.4 ms and doubles the step time meanwhile; at an even 128 / 128 split (GRU 1024 at B = 32: what a 32-row backward kernel
+    # would create at c3's B = 64) the recurrence pays MORE than is hidden — 5.61 -> 7.63 ms of recurrences for 4 x 0.45 ms of GEMM, the step
+    # 18.2 -> 19.2 ms (profiles/r05_idle_split_proxy.txt) — so only where the recurrence is the clear majority tenant (idle < half the chip).
     n_idle = _idle_cus_beside_bwd_recurrence(dev, B, H)
     idle_ok = (group_ok and WGRAD_SIDE == "sk" and WGRAD_IDLE and T > 1
-               and WGRAD_IDLE_MIN_CUS <= n_idle <= torch.cuda.get_device_properties(dev).multi_processor_count // 2)
+               and WGRAD_IDLE_MIN_CUS <= n_idle < torch.cuda.get_device_properties(dev).multi_processor_count // 2)
     for l in range(L - 1, -1, -1):
         lc = ctx.layers[l]
         if queued_side is not None:

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS2_EXPERIMENTAL=1   # the A/B switches below are honoured only with this (asr_amd/engine.py::_tune, csrc/common.h::ds2_exp_getenv)
 # the three data-parallel schedules with a single-rank RCCL all-reduce forced (exercises the collective + persistent-kernel interplay on one GPU)
 cd "$(dirname "$0")/.."
 export MASTER_ADDR=127.0.0.1 MASTER_PORT=29611 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 DS2_FORCE_ALLREDUCE=1

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS2_EXPERIMENTAL=1   # the A/B switches below are honoured only with this (asr_amd/engine.py::_tune, csrc/common.h::ds2_exp_getenv)
 # K-split backward: MFMA / publish schedule variants (DS2_KS_PIPE) through the timeline probe (builds rnn.hip itself)
 cd "$(dirname "$0")"
 mkdir -p build

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS2_EXPERIMENTAL=1   # the A/B switches below are honoured only with this (asr_amd/engine.py::_tune, csrc/common.h::ds2_exp_getenv)
 # K-split backward recurrence: correctness vs the other two kernel families + the oracle, per-step time, c3 bench A/B
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out; export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS2_EXPERIMENTAL=1   # the A/B switches below are honoured only with this (asr_amd/engine.py::_tune, csrc/common.h::ds2_exp_getenv)
 # same-box A/B of two builds of the library (asr_amd/lib/libds2hip.so vs libds2hip_b.so): the c3 bench's step time and its in-region recurrence
 # times; TESTS=1 also runs the recurrence parity tests on the B build
 cd "$(dirname "$0")/.."

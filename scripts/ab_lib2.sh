@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS2_EXPERIMENTAL=1   # the A/B switches below are honoured only with this (asr_amd/engine.py::_tune, csrc/common.h::ds2_exp_getenv)
 # same-box A/B of two builds of the library (asr_amd/lib/libds2hip.so vs $1, default libds2hip_prev.so): persistent-recurrence micro-benchmark
 # (bf16 training mode, c3 / c2 / c5-at-B=32 layer shapes) and the c3 bench
 cd "$(dirname "$0")/.."

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS2_EXPERIMENTAL=1   # the A/B switches below are honoured only with this (asr_amd/engine.py::_tune, csrc/common.h::ds2_exp_getenv)
 # same-box A/B: persistent recurrences (default) vs one launch per step (DS2_RNN_PERSISTENT=0), micro-benchmark (packed bf16 training mode) + c3 bench
 cd "$(dirname "$0")/.."
 for rep in 1 2; do for p in 1 0; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS2_EXPERIMENTAL=1   # the A/B switches below are honoured only with this (asr_amd/engine.py::_tune, csrc/common.h::ds2_exp_getenv)
 # same-box A/B: L2-local exchange by XCD census (default) vs the placement-independent sc1 protocol (DS2_RNN_XCD_LOCAL=0), persistent
 # recurrence micro-benchmark (packed bf16 training mode) + c3 bench
 cd "$(dirname "$0")/.."

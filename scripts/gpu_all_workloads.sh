@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS2_EXPERIMENTAL=1   # the A/B switches below are honoured only with this (asr_amd/engine.py::_tune, csrc/common.h::ds2_exp_getenv)
 # every bench workload in both precisions (the DESIGN.md §5 table) -> gpurun_out/all_workloads.log
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out

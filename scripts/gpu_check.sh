@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS2_EXPERIMENTAL=1   # the A/B switches below are honoured only with this (asr_amd/engine.py::_tune, csrc/common.h::ds2_exp_getenv)
 # Runs on the GPU box via gpurun: per-family kernel parity tests (separate processes so one fault
 # does not hide the others), whole-model tests, smoke and a short bench.  Logs -> gpurun_out/.
 cd "$(dirname "$0")/.."

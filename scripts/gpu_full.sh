@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS2_EXPERIMENTAL=1   # the A/B switches below are honoured only with this (asr_amd/engine.py::_tune, csrc/common.h::ds2_exp_getenv)
 # whole GPU suite + smoke + default bench (what the driver runs at round end)
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS2_EXPERIMENTAL=1   # the A/B switches below are honoured only with this (asr_amd/engine.py::_tune, csrc/common.h::ds2_exp_getenv)
 # SQ counters of the bf16 GEMM kernels on the train step's shapes (scripts/bench_gemm.py) -> gpurun_out/pmc_gemm/
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp

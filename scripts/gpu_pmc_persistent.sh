@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS2_EXPERIMENTAL=1   # the A/B switches below are honoured only with this (asr_amd/engine.py::_tune, csrc/common.h::ds2_exp_getenv)
 # HBM-side bytes of the persistent recurrence kernels (C3 layer shape, bf16 training mode): two separate rocprofv3 PMC passes
 # (--kernel-trace only beside --pmc), reduced to gpurun_out/pmc_r04/summary.json by scripts/pmc_summarize.py.  Copy to profiles/ to commit.
 cd "$(dirname "$0")/.."

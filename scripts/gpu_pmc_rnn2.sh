@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS2_EXPERIMENTAL=1   # the A/B switches below are honoured only with this (asr_amd/engine.py::_tune, csrc/common.h::ds2_exp_getenv)
 # memory-path counters of the recurrent forward step kernel (two passes) -> gpurun_out/pmc_rnn2/
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp

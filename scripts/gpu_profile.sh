@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS2_EXPERIMENTAL=1   # the A/B switches below are honoured only with this (asr_amd/engine.py::_tune, csrc/common.h::ds2_exp_getenv)
 # rocprofv3 kernel trace + stats of the bench command (summary copied to profiles/ by the caller)
 cd "$(dirname "$0")/.."
 WL=${1:-c2}; TAG=${2:-r01}

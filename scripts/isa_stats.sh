@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS2_EXPERIMENTAL=1   # the A/B switches below are honoured only with this (asr_amd/engine.py::_tune, csrc/common.h::ds2_exp_getenv)
 # usage: scripts/isa_stats.sh <file.hip> <kernel-name-regex>   -> registers / LDS / spills and instruction counts of matching kernels (no GPU needed)
 set -e
 cd "$(dirname "$0")/../asr_amd/csrc"

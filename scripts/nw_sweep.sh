@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS2_EXPERIMENTAL=1   # the A/B switches below are honoured only with this (asr_amd/engine.py::_tune, csrc/common.h::ds2_exp_getenv)
 # build rnn.hip with different waves-per-block and run the ablation (GPU box)
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS2_EXPERIMENTAL=1   # the A/B switches below are honoured only with this (asr_amd/engine.py::_tune, csrc/common.h::ds2_exp_getenv)
 # same-box A/B of two builds of the library: asr_amd/lib/libds2hip_old.so (built from an earlier commit) vs the current one (DS2_LIB_PATH)
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out

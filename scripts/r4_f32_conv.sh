@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS2_EXPERIMENTAL=1   # the A/B switches below are honoured only with this (asr_amd/engine.py::_tune, csrc/common.h::ds2_exp_getenv)
 # round 4: fp32 mode, conv2 through three-term split products on the bf16 conv kernels: tests, then fp32 A/B per workload (same box)
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out

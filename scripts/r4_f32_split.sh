@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS2_EXPERIMENTAL=1   # the A/B switches below are honoured only with this (asr_amd/engine.py::_tune, csrc/common.h::ds2_exp_getenv)
 # round 4: fp32 mode with three-term split-bf16 GEMMs: tests, then c2 / c4 fp32 A/B against the fp32-MFMA kernels (same box)
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS2_EXPERIMENTAL=1   # the A/B switches below are honoured only with this (asr_amd/engine.py::_tune, csrc/common.h::ds2_exp_getenv)
 # round 4: weight-gradient launches on the side stream beside a persistent backward recurrence that leaves CUs idle (DS2_WGRAD_IDLE), same box
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS2_EXPERIMENTAL=1   # the A/B switches below are honoured only with this (asr_amd/engine.py::_tune, csrc/common.h::ds2_exp_getenv)
 # round 4: grouped split-K weight-gradient launch (DS2_WGRAD_SIDE=sk) vs round 3's three launches (0): tests + same-box A/B
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS2_EXPERIMENTAL=1   # the A/B switches below are honoured only with this (asr_amd/engine.py::_tune, csrc/common.h::ds2_exp_getenv)
 # round 4: grouped co-resident weight-gradient kernel: tests, stand-alone bench, whole-step A/B of the three schedules
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS2_EXPERIMENTAL=1   # the A/B switches below are honoured only with this (asr_amd/engine.py::_tune, csrc/common.h::ds2_exp_getenv)
 # round 5 baseline: GEMM micro-benchmarks + c3 bench on one box
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS2_EXPERIMENTAL=1   # the A/B switches below are honoured only with this (asr_amd/engine.py::_tune, csrc/common.h::ds2_exp_getenv)
 # round 5: conv2 weight gradient from channels-last operands (DS2_CONV2_WGRAD=nhwc) vs the padded-copy kernel (=pad): kernel tests + same-box c3 A/B
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp

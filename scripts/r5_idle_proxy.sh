@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS2_EXPERIMENTAL=1   # the A/B switches below are honoured only with this (asr_amd/engine.py::_tune, csrc/common.h::ds2_exp_getenv)
 # round 5, VERDICT item 2 priced: the 128 / 128 CU split that a 32-row K-split backward kernel would create at c3, measured with the EXISTING
 # kernels at B = 32 (c3's layer shape, half the batch: the recurrence then holds 128 of the 256 CUs and the layer above's grouped
 # weight-gradient launch runs on the other 128) — what the recurrence pays per time step for the GEMM beside it, and what the step gains.

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS2_EXPERIMENTAL=1   # the A/B switches below are honoured only with this (asr_amd/engine.py::_tune, csrc/common.h::ds2_exp_getenv)
 # L2 counters of the NT GEMM (RING variant in $RING, default q) on fwd and dX shapes
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp

@@ -41,7 +41,7 @@ if len(sys.argv) > 2 and sys.argv[1] == "child":
     child(sys.argv[2]); sys.exit(0)
 mode = sys.argv[1] if len(sys.argv) > 1 else "check"
 def run(ring):
-    env = dict(os.environ, DS2_GEMM_RING=ring)
+    env = dict(os.environ, DS2_GEMM_RING=ring, DS2_EXPERIMENTAL="1")
     r = subprocess.run([sys.executable, __file__, "child", mode], env=env, capture_output=True, text=True)
     if r.returncode != 0: print(r.stdout[-2000:], r.stderr[-3000:]); sys.exit(1)
     return eval(r.stdout.strip().splitlines()[-1])

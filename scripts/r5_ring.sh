@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS2_EXPERIMENTAL=1   # the A/B switches below are honoured only with this (asr_amd/engine.py::_tune, csrc/common.h::ds2_exp_getenv)
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out; export TMPDIR=/tmp
 timeout 600 python scripts/r5_ring.py check > gpurun_out/r5_ring_check.log 2>&1; echo "check rc=$?"; tail -12 gpurun_out/r5_ring_check.log

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DS2_EXPERIMENTAL=1   # the A/B switches below are honoured only with this (asr_amd/engine.py::_tune, csrc/common.h::ds2_exp_getenv)
 # runs the L2 residency / fresh-data probe over its configurations (on the GPU box) -> gpurun_out/probe_l2_residency.txt
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
