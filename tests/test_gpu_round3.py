@@ -48,7 +48,7 @@ def ar(t, *a, **k):
     return w
 dist.all_reduce = ar
 conv_ev = []
-orig_c2, orig_c1 = ops.conv2_wgrad_bf16, ops.conv1_wgrad_bf16
+orig_c2, orig_c1 = ops.conv2_wgrad_nhwc_bf16, ops.conv1_wgrad_bf16
 def c2(*a, **k):
     e = torch.cuda.Event(enable_timing=True); e.record(); conv_ev.append(e); log["order"].append("conv2_wgrad")
     return orig_c2(*a, **k)
@@ -56,7 +56,7 @@ def c1(*a, **k):
     r = orig_c1(*a, **k)
     e = torch.cuda.Event(enable_timing=True); e.record(); conv_ev.append(e); log["order"].append("conv1_wgrad")
     return r
-ops.conv2_wgrad_bf16, ops.conv1_wgrad_bf16 = c2, c1
+ops.conv2_wgrad_nhwc_bf16, ops.conv1_wgrad_bf16 = c2, c1
 losses, paths = [], []
 for it in range(3):
     log["collectives"].clear(); log["order"].clear(); conv_ev.clear()
