@@ -258,7 +258,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_ring_kernel(BArgs g, int ntx
 // the accumulators leave as 16-byte stores straight from the registers — no LDS patch, the same 32 store instructions per wave.
 constexpr int Q_EPS = 32, Q_BIASL = 4;
 // DBG (timing experiments, WRONG RESULTS): bit 0 = no operand DMA behind the prologue, bit 1 = no fragment reads, bit 2 = no barriers
-template <bool OBF, int DBG = 0>
+// NSLOT: ring slots (4 = 128 KB, 5 = all 160 KB of the LDS: one more slice in flight)
+template <bool OBF, int DBG = 0, int NSLOT = 4>
 __global__ __launch_bounds__(512) void gemm_bf16_nt_pp16_kernel(BArgs g, int ntx, int nty) {
   constexpr int WN = 4, NWV = 8, NI = 8, NJ = 4;        // 16 x 16 accumulator tiles per wave along M / N (128 x 64)
   extern __shared__ __attribute__((aligned(1024))) char ldsg[];
@@ -374,12 +375,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_pp16_kernel(BArgs g, int ntx
 
   load_bias(n0);
 #pragma unroll
-  for (int s = 0; s < 3; ++s) {
+  for (int s = 0; s < NSLOT - 1; ++s) {
     dma_next_slice();
 #pragma unroll
     for (int i = 0; i < 4; ++i) dma_piece(s, i);
   }
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // bias and slice 0 have landed
+  if constexpr (NSLOT == 5) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // bias and slice 0 have landed
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();          // group B runs one barrier behind
   __builtin_amdgcn_sched_barrier(0);
@@ -393,21 +395,23 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_pp16_kernel(BArgs g, int ntx
       for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < nsl; ++s) {
       const unsigned soff = (unsigned)slot * R_SLICE;
-      const int wslot = (slot + 3) & 3;
+      const int wslot = slot == 0 ? NSLOT - 1 : slot - 1;       // the slot of slice s - 1 takes slice s + NSLOT - 1
       dma_next_slice();
       static_assert(8 + Q_EPS + Q_BIASL == 44, "the literal below");
 #define Q_VMWAIT                                                                   \
   do {                                                                             \
     if (epi_syncs > 0) {                                                           \
-      asm volatile("s_waitcnt vmcnt(44)" ::: "memory");                            \
+      if constexpr (NSLOT == 5) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");  \
+      else asm volatile("s_waitcnt vmcnt(44)" ::: "memory");                       \
       --epi_syncs;                                                                 \
     } else {                                                                       \
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                             \
+      if constexpr (NSLOT == 5) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  \
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                        \
     }                                                                              \
   } while (0)
       Q_PHASE(soff, wslot, Q_VMWAIT);
 #undef Q_VMWAIT
-      slot = (slot + 1) & 3;
+      slot = slot + 1 == NSLOT ? 0 : slot + 1;
     }
     // ---- epilogue: straight from the accumulators (lane: C row m0 + wm*128 + i*16 + (lane & 15), columns .. + j*16 + (lane >> 4)*4 .. + 3)
     {
@@ -431,7 +435,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_pp16_kernel(BArgs g, int ntx
     if (orig >= nt) break;
     tile_origin(orig, m0, n0);
     load_bias(n0);
-    epi_syncs = 2;
+    epi_syncs = NSLOT - 2;
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();          // group A catches the barrier group B is one behind on
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
