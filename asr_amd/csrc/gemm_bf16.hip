@@ -1147,7 +1147,7 @@ extern "C" int ds2_gemm_bf16_nt(int M, int N, int K, const void* A, int lda, lon
         if (ring_env[0] == 'q' && rdbg) {
 #define DS2_Q_DBG(n) if (rdbg == n) { DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_nt_pp16_kernel<false, n>, hipFuncAttributeMaxDynamicSharedMemorySize, R_RING)); \
                        hipLaunchKernelGGL((gemm_bf16_nt_pp16_kernel<false, n>), dim3(cus, 1, 1), dim3(512), R_RING, s, g, ntx, nty); }
-          DS2_Q_DBG(1) DS2_Q_DBG(2) DS2_Q_DBG(3) DS2_Q_DBG(8) DS2_Q_DBG(18) DS2_Q_DBG(26)
+          DS2_Q_DBG(1) DS2_Q_DBG(2) DS2_Q_DBG(3) DS2_Q_DBG(8) DS2_Q_DBG(18) DS2_Q_DBG(22) DS2_Q_DBG(26) DS2_Q_DBG(82) DS2_Q_DBG(146)
 #undef DS2_Q_DBG
         } else if (ring_env[0] == 'q' && ring_env[1] == '5') {       // five slots: the whole LDS
           static bool a5 = false;

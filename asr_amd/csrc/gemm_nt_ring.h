@@ -299,6 +299,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_pp16_kernel(BArgs g, int ntx
     }
   };
   auto dma_piece = [&](int slot, int i) {
+    if ((DBG & 64) && !(i & 1)) return;                  // (bit 6: no A pieces, bit 7: no B pieces)
+    if ((DBG & 128) && (i & 1)) return;
     glds16(q[i], ldsg + slot * R_SLICE + (i & 1) * 16384 + (wave + NWV * (i >> 1)) * 1024);
     if (!(DBG & 8)) q[i] += 64;                         // (bit 3: every DMA re-reads the same L2-resident 64 KB)
   };

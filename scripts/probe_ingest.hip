@@ -55,6 +55,102 @@ void runmix(const char* name, const char* src, float* out) {
          bytes_per_cu * 256 / best / 1e9 * (8 - MIXHOT) / 8);
 }
 
+
+// SHARED cold stream (the GEMM's situation): the 4 workgroups g, g + 8, g + 16, g + 24 of a group (same XCD under round-robin dispatch) stream
+// the SAME 16 MB in step — every line is fetched from HBM once and requested by all four while it is still in flight, so all four wait
+// for it.  SPLIT = false: every workgroup requests the pieces in the same order.  SPLIT = true: of every 4 consecutive pieces a workgroup
+// requests ITS OWN one FAR ahead (AHEAD iterations) and the other three at the normal distance — by then its siblings' far requests have
+// brought them into the L2: each workgroup waits for HBM on a quarter of the bytes only.
+template <bool SPLIT, int DEPTH, int AHEAD>
+__global__ __launch_bounds__(512) void kshare(const char* __restrict__ src, float* __restrict__ out, int iters) {
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int grp = (blockIdx.x & 7) + 8 * (blockIdx.x >> 5), me = (blockIdx.x >> 3) & 3;      // 64 groups of 4
+  const char* base = src + (long long)grp * (16LL << 20);
+  const long long loff = (long long)(lane >> 3) * 128 + (lane & 7) * 16;
+  const long long npieces = (16LL << 20) / 8192;                                   // 8 KB per (iteration step): 8 waves x 1 KB
+  long long p = 0;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      long long pp = p;
+      if (SPLIT) pp = ((int)(p & 3) == me) ? p + 4 * AHEAD : p;                     // own quarter of every 4 pieces: far ahead
+      if (pp >= npieces) pp -= npieces;
+      const char* g = base + (pp * 8 + wave) * 1024 + loff;
+      __builtin_amdgcn_global_load_lds((gbl_void*)g, (lds_void*)(lds + ((it & 1) * DEPTH + d) * 8192 + wave * 1024), 16, 0, 0);
+      if (++p >= npieces) p = 0;
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEPTH) : "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  f32x4 accv = *reinterpret_cast<f32x4*>(lds + threadIdx.x * 16);
+  out[blockIdx.x * 512 + threadIdx.x] = accv[0] + accv[1] + accv[2] + accv[3];
+}
+template <bool SPLIT, int DEPTH, int AHEAD>
+void runshare(const char* name, const char* src, float* out) {
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  const int iters = 4096 / DEPTH * 2;
+  (void)hipFuncSetAttribute((const void*)kshare<SPLIT, DEPTH, AHEAD>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DEPTH * 8192);
+  float best = 1e9;
+  for (int rep = 0; rep < 3; ++rep) {
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL((kshare<SPLIT, DEPTH, AHEAD>), dim3(256), dim3(512), 2 * DEPTH * 8192, 0, src, out, iters);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best) best = ms;
+  }
+  const double bytes_per_cu = (double)iters * DEPTH * 8 * 1024;
+  printf("%-76s %7.1f GB/s per CU  (HBM side: %5.2f TB/s)\n", name, bytes_per_cu / best / 1e6, bytes_per_cu * 64 / best / 1e9);
+}
+
+
+// the GEMM's A-operand pattern under sharing: 4 workgroups of a group stream the same (256 rows x K) panel, k-slice by k-slice; a wave
+// instruction takes ROWS rows x (1024 / ROWS) bytes, row pitch 12288 B (dX: K = 6144 bf16); consecutive k-slices continue along the rows.
+template <int ROWS>
+__global__ __launch_bounds__(512) void kpanel(const char* __restrict__ src, float* __restrict__ out, int iters) {
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  constexpr int SEG = 1024 / ROWS, LPR = SEG / 16;                       // bytes per row per instruction, lanes per row
+  constexpr int PITCH = 12288, PIECES = 256 / ROWS / 8;                  // wave-instructions per wave per k-slice
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int grp = (blockIdx.x & 7) + 8 * (blockIdx.x >> 5);
+  const char* base = src + (long long)grp * (16LL << 20);                // 5 panels of 256 x 12288 B in 16 MB
+  const long long loff = (long long)(lane / LPR) * PITCH + (lane % LPR) * 16;
+  int ks = 0, panel = 0;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      const int piece = d % PIECES;
+      const char* g = base + (long long)panel * 256 * PITCH + (long long)((wave * PIECES + piece) * ROWS) * PITCH + (long long)ks * SEG + loff;
+      __builtin_amdgcn_global_load_lds((gbl_void*)g, (lds_void*)(lds + ((it & 1) * 8 + d) * 8192 + wave * 1024), 16, 0, 0);
+      if (piece == PIECES - 1) { if (++ks >= PITCH / SEG) { ks = 0; if (++panel >= 5) panel = 0; } }
+    }
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  f32x4 accv = *reinterpret_cast<f32x4*>(lds + threadIdx.x * 16);
+  out[blockIdx.x * 512 + threadIdx.x] = accv[0] + accv[1] + accv[2] + accv[3];
+}
+template <int ROWS>
+void runpanel(const char* name, const char* src, float* out) {
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  const int iters = 1024;
+  (void)hipFuncSetAttribute((const void*)kpanel<ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 8192);
+  float best = 1e9;
+  for (int rep = 0; rep < 3; ++rep) {
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL((kpanel<ROWS>), dim3(256), dim3(512), 2 * 8 * 8192, 0, src, out, iters);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best) best = ms;
+  }
+  const double bytes_per_cu = (double)iters * 8 * 8 * 1024;
+  printf("%-76s %7.1f GB/s per CU  (HBM side: %5.2f TB/s)\n", name, bytes_per_cu / best / 1e6, bytes_per_cu * 64 / best / 1e9);
+}
+
 template <int MODE, int DEPTH>
 __global__ __launch_bounds__(512) void k(const char* __restrict__ src, float* __restrict__ out, long long span, int iters, long long pitch) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
@@ -142,6 +238,13 @@ int main() {
   runmix<7, 8>("glds mix 7/8 L2-resident + 1/8 HBM stream, 8-16 in flight", src, out);
   runmix<6, 8>("glds mix 6/8 L2-resident + 2/8 HBM stream, 8-16 in flight", src, out);
   runmix<4, 8>("glds mix 4/8 L2-resident + 4/8 HBM stream, 8-16 in flight", src, out);
-  runmix<6, 4>("glds mix 6/8 L2-resident + 2/8 HBM stream (depth 4: 3+1), 4-8 in flight", src, out);
+  runpanel<16>("shared 256-row panel, pitch 12 KB: 16 rows x 64 B per instruction (ring slices)", src, out);
+  runpanel<8>("shared 256-row panel, pitch 12 KB: 8 rows x 128 B per instruction (64-deep k-tiles)", src, out);
+  runpanel<4>("shared 256-row panel, pitch 12 KB: 4 rows x 256 B per instruction", src, out);
+  runpanel<2>("shared 256-row panel, pitch 12 KB: 2 rows x 512 B per instruction", src, out);
+  runshare<false, 8, 0>("4 workgroups share one HBM stream, same request order", src, out);
+  runshare<true, 8, 4>("4 workgroups share one HBM stream, own quarter 4 iterations (256 KB) ahead", src, out);
+  runshare<true, 8, 16>("4 workgroups share one HBM stream, own quarter 16 iterations (1 MB) ahead", src, out);
+  runshare<true, 8, 64>("4 workgroups share one HBM stream, own quarter 64 iterations (4 MB) ahead", src, out);
   return 0;
 }
