@@ -1054,6 +1054,7 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
 }
 
 #include "gemm_nt_ring.h"
+#include "gemm_nt_w4.h"
 #include "gemm_tn_group.h"
 
 }  // namespace
@@ -1136,7 +1137,29 @@ extern "C" int ds2_gemm_bf16_nt(int M, int N, int K, const void* A, int lda, lon
       static const char* ring_env = ds2_exp_getenv("DS2_GEMM_RING");
       const bool ring = ring_env && (ring_env[0] == '1' || ring_env[0] == 'q') && !(pe && pe[0] == '0') && batch == 1 && splitk == 1 && !accumulate &&
                         (K % 32) == 0 && K >= 128 && wide && !(g.nt_store & ~1) && ntx * nty > cus;
-      if (ring) {
+      // four waves x 128 x 128 (gemm_nt_w4.h)
+      const bool w4 = ring_env && ring_env[0] == 'w' && !(pe && pe[0] == '0') && batch == 1 && splitk == 1 && !accumulate && (K % 64) == 0 && K >= 128 &&
+                      wide && !(g.nt_store & ~1) && ntx * nty > cus && (long long)lda * 512 < (1ll << 31) && (long long)ldb * 512 < (1ll << 31);
+      if (w4) {
+        static bool wattr = false;
+        if (!wattr) { DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_nt_w4_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS)); wattr = true; }
+        static const int wdbg = ds2_exp_getenv("DS2_W4_DBG") ? atoi(ds2_exp_getenv("DS2_W4_DBG")) : 0;   // timing ablations (WRONG RESULTS)
+        if (wdbg) {
+#define DS2_W_DBG(n) if (wdbg == n) { DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_nt_w4_kernel<n>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS)); \
+                       hipLaunchKernelGGL((gemm_bf16_nt_w4_kernel<n>), dim3(cus, 1, 1), dim3(256), W4_LDS, s, g, ntx, nty); }
+          DS2_W_DBG(1) DS2_W_DBG(2) DS2_W_DBG(4) DS2_W_DBG(5) DS2_W_DBG(6) DS2_W_DBG(8) DS2_W_DBG(10)
+#undef DS2_W_DBG
+        } else {
+          // "w" / "wp" (L2 prefetch) + optional schedule digit: "w3", "wp4", ...
+          const bool wpf = ring_env[1] == 'p';
+          const char sc = ring_env[wpf ? 2 : 1];
+#define DS2_W_V(PFV, SCV) { static bool a_ = false; if (!a_) { DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_nt_w4_kernel<0, PFV, SCV>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS)); a_ = true; } \
+                            hipLaunchKernelGGL((gemm_bf16_nt_w4_kernel<0, PFV, SCV>), dim3(cus, 1, 1), dim3(256), W4_LDS, s, g, ntx, nty); }
+          if (wpf) { if (sc == '3') DS2_W_V(true, 3) else if (sc == '4') DS2_W_V(true, 4) else DS2_W_V(true, 1) }
+          else { if (sc == '3') DS2_W_V(false, 3) else if (sc == '4') DS2_W_V(false, 4) else DS2_W_V(false, 1) }
+#undef DS2_W_V
+        }
+      } else if (ring) {
         static bool rattr = false;
         if (!rattr) {
           DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_nt_ring_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, R_RING + G_PATCH));
