@@ -35,7 +35,7 @@ __device__ __forceinline__ void w4_dma(unsigned voff, const char* sbase, unsigne
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 
-template <int DBG = 0, bool PF = false, int SCHED = 1>
+template <int DBG = 0, bool PF = false, int SCHED = 1, int STAG = 0>
 __global__ __launch_bounds__(256) void gemm_bf16_nt_w4_kernel(BArgs g, int ntx, int nty) {
   extern __shared__ __attribute__((aligned(1024))) char ldsg[];
   constexpr int YM = SCHED == 1 ? 10 : SCHED == 3 ? 20 : 16;   // MFMA of phase B behind which the wait for tile kt + 1 sits (barrier Y behind the next)
@@ -212,6 +212,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_w4_kernel(BArgs g, int ntx, 
     for (int p = 0; p < 8; ++p) { dma_a(65536u, p); dma_b(65536u, p); }
     sA += 128; sB += 128;
   };
+  // STAG (experiment): the workgroups start in STAG phase groups a fraction of a tile period apart, so that their epilogues (256 KB of C per
+  // tile, all CUs at once when they run in lock-step: an HBM write burst with the matrix pipes idle) interleave with other groups' main loops
+  if constexpr (STAG > 1) {
+    const int phase = (blockIdx.x >> 3) % STAG;
+    const long long wait = (long long)phase * nkt * g.kchunk / STAG;     // clocks: nkt k-tiles of ~g.kchunk clocks each
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    while ((long long)__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+  }
   stage_first_two();
   set_prefetch(m0, n0);
   bool after_epilogue = false;
