@@ -1055,7 +1055,6 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
 
 #include "gemm_nt_ring.h"
 #include "gemm_nt_w4.h"
-#include "gemm_nt_w4b.h"
 #include "gemm_tn_group.h"
 
 }  // namespace
@@ -1138,44 +1137,18 @@ extern "C" int ds2_gemm_bf16_nt(int M, int N, int K, const void* A, int lda, lon
       static const char* ring_env = ds2_exp_getenv("DS2_GEMM_RING");
       const bool ring = ring_env && (ring_env[0] == '1' || ring_env[0] == 'q') && !(pe && pe[0] == '0') && batch == 1 && splitk == 1 && !accumulate &&
                         (K % 32) == 0 && K >= 128 && wide && !(g.nt_store & ~1) && ntx * nty > cus;
-      // four waves x 128 x 128 (gemm_nt_w4.h)
-      const bool w4 = ring_env && ring_env[0] == 'w' && !(pe && pe[0] == '0') && batch == 1 && splitk == 1 && !accumulate && (K % 64) == 0 && K >= 128 &&
-                      wide && !(g.nt_store & ~1) && ntx * nty > cus && (long long)lda * 512 < (1ll << 31) && (long long)ldb * 512 < (1ll << 31);
-      const bool w4b = ring_env && ring_env[0] == 'x' && !(pe && pe[0] == '0') && batch == 1 && splitk == 1 && !accumulate && (K % 64) == 0 && K >= 128 &&
-                       wide && !(g.nt_store & ~1) && ntx * nty > cus && (long long)lda * 512 < (1ll << 31) && (long long)ldb * 512 < (1ll << 31);
-      if (w4b) {
-        static const int xdbg = ds2_exp_getenv("DS2_W4_DBG") ? atoi(ds2_exp_getenv("DS2_W4_DBG")) : 0;   // timing ablations (WRONG RESULTS)
-#define DS2_X_V(n) { static bool a_ = false; if (!a_) { DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_nt_w4b_kernel<n>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS)); a_ = true; } \
-                     hipLaunchKernelGGL((gemm_bf16_nt_w4b_kernel<n>), dim3(cus, 1, 1), dim3(256), W4_LDS, s, g, ntx, nty); }
-        if (xdbg == 1) DS2_X_V(1) else if (xdbg == 2) DS2_X_V(2) else if (xdbg == 4) DS2_X_V(4) else if (xdbg == 6) DS2_X_V(6) else DS2_X_V(0)
-#undef DS2_X_V
-      } else if (w4) {
-        static bool wattr = false;
-        if (!wattr) { DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_nt_w4_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS)); wattr = true; }
-        static const int wdbg = ds2_exp_getenv("DS2_W4_DBG") ? atoi(ds2_exp_getenv("DS2_W4_DBG")) : 0;   // timing ablations (WRONG RESULTS)
-        if (wdbg) {
-#define DS2_W_DBG(n) if (wdbg == n) { DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_nt_w4_kernel<n>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS)); \
-                       hipLaunchKernelGGL((gemm_bf16_nt_w4_kernel<n>), dim3(cus, 1, 1), dim3(256), W4_LDS, s, g, ntx, nty); }
-          DS2_W_DBG(1) DS2_W_DBG(2) DS2_W_DBG(4) DS2_W_DBG(5) DS2_W_DBG(6) DS2_W_DBG(8) DS2_W_DBG(10)
-#undef DS2_W_DBG
-        } else {
-          // "w" / "wp" (L2 prefetch) + optional schedule digit: "w3", "wp4", ...
-          const bool wpf = ring_env[1] == 'p';
-          const char sc = ring_env[wpf ? 2 : 1];
-#define DS2_W_V(PFV, SCV) { static bool a_ = false; if (!a_) { DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_nt_w4_kernel<0, PFV, SCV>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS)); a_ = true; } \
-                            hipLaunchKernelGGL((gemm_bf16_nt_w4_kernel<0, PFV, SCV>), dim3(cus, 1, 1), dim3(256), W4_LDS, s, g, ntx, nty); }
-          if (ring_env[1] == 's') {                                  // "ws<n>": start phases staggered (n = 2 / 4 groups); DS2_W4_STAG_CLK clocks per k-tile
-            static const int sclk = ds2_exp_getenv("DS2_W4_STAG_CLK") ? atoi(ds2_exp_getenv("DS2_W4_STAG_CLK")) : 3600;
-            BArgs gs = g; gs.kchunk = sclk;
-#define DS2_W_S(NV) { static bool a_ = false; if (!a_) { DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_nt_w4_kernel<0, false, 1, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS)); a_ = true; } \
-                      hipLaunchKernelGGL((gemm_bf16_nt_w4_kernel<0, false, 1, NV>), dim3(cus, 1, 1), dim3(256), W4_LDS, s, gs, ntx, nty); }
-            if (ring_env[2] == '4') DS2_W_S(4) else DS2_W_S(2)
-#undef DS2_W_S
-          } else
-          if (wpf) { if (sc == '3') DS2_W_V(true, 3) else if (sc == '4') DS2_W_V(true, 4) else DS2_W_V(true, 1) }
-          else { if (sc == '3') DS2_W_V(false, 3) else if (sc == '4') DS2_W_V(false, 4) else DS2_W_V(false, 1) }
+      // four waves x 128 x 128 (gemm_nt_w4.h): the default wherever it applies — K a multiple of the 64-deep k-tile, more tiles than CUs, plain
+      // write-out, 32-bit lane offsets inside a tile (DS2_GEMM_W4=0: the 8-wave persistent kernel instead, A/B switch)
+      static const char* w4_env = ds2_exp_getenv("DS2_GEMM_W4");
+      const bool w4 = !(w4_env && w4_env[0] == '0') && !(ring_env && ring_env[0] != 'w') && !(pe && pe[0] == '0') && batch == 1 && splitk == 1 &&
+                      !accumulate && (K % 64) == 0 && K >= 128 && wide && !(g.nt_store & ~1) && ntx * nty > cus &&
+                      (long long)lda * 512 < (1ll << 31) && (long long)ldb * 512 < (1ll << 31);
+      if (w4) {
+        static const int wdbg = ds2_exp_getenv("DS2_W4_DBG") ? atoi(ds2_exp_getenv("DS2_W4_DBG")) : 0;   // timing ablations (WRONG RESULTS; scripts/r5_w4_dbg.sh)
+#define DS2_W_V(n) { static bool a_ = false; if (!a_) { DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_nt_w4_kernel<n>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS)); a_ = true; } \
+                     hipLaunchKernelGGL((gemm_bf16_nt_w4_kernel<n>), dim3(cus, 1, 1), dim3(256), W4_LDS, s, g, ntx, nty); }
+        if (wdbg == 1) DS2_W_V(1) else if (wdbg == 2) DS2_W_V(2) else if (wdbg == 4) DS2_W_V(4) else if (wdbg == 5) DS2_W_V(5) else if (wdbg == 6) DS2_W_V(6) else DS2_W_V(0)
 #undef DS2_W_V
-        }
       } else if (ring) {
         static bool rattr = false;
         if (!rattr) {

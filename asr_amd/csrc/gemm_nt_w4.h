@@ -15,18 +15,28 @@
 //               every hardware lane group of a ds_read_b128 ({0-3, 12-15, 20-27}, ...)
 //   DMA         wave w moves the 8-row pieces w, w + 4, ..., w + 28 of A and of B: 16 x global_load_lds_dwordx4 per wave and k-tile; source =
 //               SGPR base (advanced by 128 B per k-tile with scalar adds) + one 32-bit lane offset per piece (constant within a tile)
-//   k-tile kt   (buffer cur = kt & 1; fragments of its k-step 0 already in registers):
-//      phase A  64 MFMAs of k-step 0 | behind them: 8 reads A(k-step 1) | lgkmcnt(0), BARRIER 1: nobody reads cur.A any more |
-//               DMA A(kt + 2) -> cur.A interleaved with 8 reads B(k-step 1) | lgkmcnt(0), BARRIER 2: cur.B is free | DMA B(kt + 2) -> cur.B
-//      phase B  64 MFMAs of k-step 1 | rest of DMA B | vmcnt(16): own DMA of tile kt + 1 has landed, BARRIER 3: everybody's has |
-//               16 reads of tile kt + 1, k-step 0, from the other buffer | lgkmcnt(0)
+//   k-tile kt   (buffer cur = kt & 1; fragments of its k-step 0 already in registers); slot s = the issue shadow of MFMA s:
+//      phase A  64 MFMAs of k-step 0 | 8 reads A(k-step 1) behind MFMAs 0, 2 .. 14 | lgkmcnt(0), BARRIER X_A at 20: nobody reads cur.A any more |
+//               DMA A(kt + 2) -> cur.A at 21, 25 .. 49, the 8 reads B(k-step 1) between them at 23, 27 .. 51 | lgkmcnt(0), BARRIER X_B at 55: cur.B
+//               is free | DMA B(kt + 2) -> cur.B from 57 on
+//      phase B  64 MFMAs of k-step 1 | rest of DMA B at 0, 2 .. 8 | vmcnt(16) at 10: own DMA of tile kt + 1 has landed (tile kt + 2's 16
+//               instructions stay in flight), BARRIER Y at 11: everybody's has | 16 reads of tile kt + 1, k-step 0, from the other buffer at
+//               13, 16 .. 58 | lgkmcnt(0)
 //   Two tiles of DMA are in flight for most of a k-tile; a tile is read one whole k-tile (~1 us) after its DMA went out.
 // The product is formed TRANSPOSED (B fragment as the MFMA's first operand): a lane holds four consecutive columns of one C row and the
 // accumulators leave as 16-byte stores straight from the registers.
 //
 // Persistent: one workgroup per CU walks tiles orig, orig + grid, ... in the XCD-aware order of the 8-wave kernel; the DMA of the next tile's
-// first two k-tiles goes out before the epilogue's stores.  vmcnt is ONE in-order counter (loads, LDS-DMA, stores; at most 63): the waits of
-// the first k-tile after an epilogue are vmcnt(63), which retires the operand DMA issued before the 64 stores and at most 17 of the stores.
+// first two k-tiles goes out before the epilogue's stores.  vmcnt is ONE in-order counter (loads, LDS-DMA, stores; at most 63): the wait at the
+// top of a tile that follows an epilogue is vmcnt(63), which retires the 32 DMA instructions issued before the 64 stores and one store.
+//
+// Measured (profiles/r05_gemm_w4_ab.txt, same box, random operands): dX (K = 6144) 381 -> 342 us, forward projection (K = 1024) 534 -> 508,
+// c4's forward projection 646 -> 612; bit-identical to the 8-wave kernel on every shape.  Tried on the way and not kept (same record): the
+// same tile on v_mfma_f32_32x32x16_bf16 (slower: 364 us on dX — its MFMA + LDS part alone runs at 1.27 PF/s against 1.38 here), one or two
+// barriers per k-tile instead of three (the refill of cur then starts later: 361), an L2 prefetch of the operand stream two k-tiles ahead of its
+// DMA (no change), start phases of the workgroups staggered so that their epilogues interleave (slower).  Timing ablations: the MFMA + LDS part
+// alone takes 292 us on dX (one wave per SIMD issues 16x16x32 MFMAs at 1.50 PF/s at best: scripts/probe_mfma_power.hip), the operand stream alone
+// 270 us (148 from an L2-resident 64 KB), both together 342-383.
 constexpr int W4_LDS = 4 * G_TILE;
 
 // 1 KiB of an operand tile, global -> LDS: lane offset (bytes) from a uniform base; M0 = LDS destination of lane 0 (one wait state between the
@@ -35,10 +45,9 @@ __device__ __forceinline__ void w4_dma(unsigned voff, const char* sbase, unsigne
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 
-template <int DBG = 0, bool PF = false, int SCHED = 1, int STAG = 0>
+template <int DBG = 0>
 __global__ __launch_bounds__(256) void gemm_bf16_nt_w4_kernel(BArgs g, int ntx, int nty) {
   extern __shared__ __attribute__((aligned(1024))) char ldsg[];
-  constexpr int YM = SCHED == 1 ? 10 : SCHED == 3 ? 20 : 16;   // MFMA of phase B behind which the wait for tile kt + 1 sits (barrier Y behind the next)
   const int nt = ntx * nty;
   int orig = blockIdx.x;
   const int SR = g.super_rows > 0 ? g.super_rows : 1 << 20;
@@ -89,37 +98,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_w4_kernel(BArgs g, int ntx, 
   const unsigned raA0 = lds0 + (wm * 128 + frow) * 128 + swz0;           // k-step 0, buffer 0; k-step 1 = ^ 64; buffer 1 = ^ 65536
   const unsigned raB0 = lds0 + 32768 + (wn * 128 + frow) * 128 + swz0;
 
-  // ---- L2 prefetch (PF): the operand stream misses the L2 on the first touch of every line, and a miss holds up everything behind it in the
-  // in-order return path of the CU's vector memory pipe.  One plain dword load per wave and k-tile touches 16 lines of A and 16 of B of tile
-  // kt + 2 + W4_PD (lanes 0-15 / 16-31; the upper half-wave repeats them), its result is never waited for by itself: the line is (on its way)
-  // in the L2 when the DMA of that tile goes out W4_PD k-tiles later.  The 4 waves cover ONE quarter (64 rows) of each operand tile; which
-  // quarter follows from the tile's position among the CUs that share the operand tile inside the XCD (A: the column tiles, B: the row tiles of
-  // a super-row), so together they cover every line once.  Issued behind the k-tile's 16 DMA instructions: the sync point's wait is vmcnt(1).
-  constexpr int W4_PD = 2;
-  const char* pf = nullptr;                              // per lane
-  int pf_left = 0;                                       // k-tiles the prefetch pointer may still advance inside this tile (uniform)
-  auto set_prefetch = [&](int tm0, int tn0) {
-    if constexpr (PF) {
-      int rl = lane;
-      asm volatile("" : "+v"(rl));
-      const int l16 = rl & 15, isb = (rl >> 4) & 1;
-      const int qa = (tn0 >> 8) & 3, qb = (tm0 >> 8) & 3;
-      const int ra = min(qa * 64 + wave * 16 + l16, g.M - 1 - tm0), rb = min(qb * 64 + wave * 16 + l16, g.N - 1 - tn0);
-      const char* pa = reinterpret_cast<const char*>(g.A + (long long)(tm0 + ra) * g.lda);
-      const char* pb = reinterpret_cast<const char*>(g.B + (long long)(tn0 + rb) * g.ldb);
-      pf = (isb ? pb : pa) + min(2 + W4_PD, nkt - 1) * 128;   // the first prefetch (issued in k-tile 0) is for tile 2 + W4_PD
-    }
-  };
-  // (the loaded dword lands in ONE register that stays allocated for the whole kernel — "+v" here, a use behind the tile loop: a register the
-  // allocator considered free would be overwritten whenever the load returns)
-  float pf_dummy = 0.f;
-  auto prefetch = [&]() {
-    if constexpr (PF) {
-      asm volatile("global_load_dword %0, %1, off" : "+v"(pf_dummy) : "v"(pf) : "memory");
-      if (pf_left > 0) { pf += 128; --pf_left; }          // (never beyond the row: the last W4_PD k-tiles repeat the last line)
-    }
-  };
-
   f32x4 acc[8][8];
   f32x4 fa[2][8], fb[2][8];
 #define W4_BC(x) __builtin_bit_cast(bf16x8, x)
@@ -131,14 +109,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_w4_kernel(BArgs g, int ntx, 
                : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3]), "+v"(F[4]), "+v"(F[5]), "+v"(F[6]), "+v"(F[7])                       \
                :                                                                                                                      \
                : "memory")
-  // one k-tile.  DMA: stage tile kt + 2 (0 / 1); VMW: the vmcnt wait in front of the "landed" barrier as a string ("" = none); NEXT: read tile
-  // kt + 1's k-step 0.  Barriers: X — every wave has finished its reads of (a half of) buffer cur, which is refilled with tile kt + 2 behind it;
-  // Y — every wave has seen its own DMA of tile kt + 1 land (a COUNTED wait: tile kt + 2's 16 instructions stay in flight), so tile kt + 1 is
-  // read from the other buffer behind it.  SCHED picks where the pieces sit among the 2 x 64 MFMAs (s_ = slot behind MFMA m_ of phase A / B):
-  //   1: reads A1 at A0,2..14 | X_A at A20 | DMA A at A21,25..49 with reads B1 at A23,27..51 | X_B at A55 | DMA B at A57,59,61,B0..8 | Y at B10/11 |
-  //      next reads at B13,16..58
-  //   3: reads A1,B1 at A0..15 | X at A22 | DMA A,B at A23,25..53 | Y at B20/21 | next reads at B22,24..52
-  //   4: reads A1,B1 at A0..15 | X at A22 | DMA A at A23,27..51 | DMA B at B0,2..14 | Y at B16/17 | next reads at B18,20..48
+  // one k-tile.  DMA: stage tile kt + 2 (0 / 1); VMW: the vmcnt wait in front of barrier Y as a string ("" = none); NEXT: read tile kt + 1's
+  // k-step 0 (see the schedule at the top of the file)
 #define W4_KTILE(DMA, VMW, NEXT)                                                                                                      \
   do {                                                                                                                                \
     const unsigned cA1 = (raA0 ^ 64u) + boff, cB1 = (raB0 ^ 64u) + boff, nA0 = raA0 + (boff ^ 65536u), nB0 = raB0 + (boff ^ 65536u);   \
@@ -146,55 +118,28 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_w4_kernel(BArgs g, int ntx, 
     _Pragma("unroll") for (int m_ = 0; m_ < 64; ++m_) {                                                                               \
       if (!(DBG & 4)) acc[m_ & 7][m_ >> 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W4_BC(fb[0][m_ >> 3]), W4_BC(fa[0][m_ & 7]), acc[m_ & 7][m_ >> 3], 0, 0, 0); \
       W4_SB();                                                                                                                        \
-      if constexpr (SCHED == 1) {                                                                                                     \
-        if (m_ < 16 && !(m_ & 1)) W4_RD(fa[1][(m_ >> 1) & 7], cA1, ((m_ >> 1) & 7) * 2048);                                           \
-        if (m_ == 19) W4_LGKM0(fa[1]);                                                                                                \
-        if (m_ == 20) __builtin_amdgcn_s_barrier();                                                                                   \
-        if (m_ >= 21 && m_ <= 51 && (m_ & 1)) {                                                                                       \
-          if (((m_ - 21) >> 1) & 1) W4_RD(fb[1][((m_ - 21) >> 2) & 7], cB1, (((m_ - 21) >> 2) & 7) * 2048);                           \
-          else if (DMA) dma_a(boff, ((m_ - 21) >> 2) & 7);                                                                            \
-        }                                                                                                                             \
-        if (m_ == 54) W4_LGKM0(fb[1]);                                                                                                \
-        if (m_ == 55) __builtin_amdgcn_s_barrier();                                                                                   \
-        if ((DMA) && (m_ == 57 || m_ == 59 || m_ == 61)) dma_b(boff, (m_ - 57) >> 1);                                                 \
-      } else {                                                                                                                        \
-        if (m_ < 8) W4_RD(fa[1][m_ & 7], cA1, (m_ & 7) * 2048);                                                                       \
-        else if (m_ < 16) W4_RD(fb[1][m_ & 7], cB1, (m_ & 7) * 2048);                                                                 \
-        if (m_ == 21) { W4_LGKM0(fa[1]); W4_LGKM0(fb[1]); }                                                                           \
-        if (m_ == 22) __builtin_amdgcn_s_barrier();                                                                                   \
-        if (SCHED == 3 && (DMA) && m_ >= 23 && m_ <= 53 && (m_ & 1)) {                                                                \
-          if (((m_ - 23) >> 1) < 8) dma_a(boff, ((m_ - 23) >> 1) & 7);                                                                \
-          else dma_b(boff, (((m_ - 23) >> 1) - 8) & 7);                                                                               \
-        }                                                                                                                             \
-        if (SCHED == 4 && (DMA) && m_ >= 23 && m_ <= 51 && ((m_ - 23) & 3) == 0) dma_a(boff, ((m_ - 23) >> 2) & 7);                   \
-        if (SCHED == 3 && (DMA) && PF && m_ == 55) prefetch();                                                                        \
-        if (SCHED == 3 && (DMA) && m_ == 57 && !(DBG & 2)) { sA += 128; sB += 128; }                                                  \
+      if (m_ < 16 && !(m_ & 1)) W4_RD(fa[1][(m_ >> 1) & 7], cA1, ((m_ >> 1) & 7) * 2048);                                             \
+      if (m_ == 19) W4_LGKM0(fa[1]);                                                                                                  \
+      if (m_ == 20) __builtin_amdgcn_s_barrier();                                                                                     \
+      if (m_ >= 21 && m_ <= 51 && (m_ & 1)) {                                                                                         \
+        if (((m_ - 21) >> 1) & 1) W4_RD(fb[1][((m_ - 21) >> 2) & 7], cB1, (((m_ - 21) >> 2) & 7) * 2048);                             \
+        else if (DMA) dma_a(boff, ((m_ - 21) >> 2) & 7);                                                                              \
       }                                                                                                                               \
+      if (m_ == 54) W4_LGKM0(fb[1]);                                                                                                  \
+      if (m_ == 55) __builtin_amdgcn_s_barrier();                                                                                     \
+      if ((DMA) && (m_ == 57 || m_ == 59 || m_ == 61)) dma_b(boff, (m_ - 57) >> 1);                                                   \
       W4_SB();                                                                                                                        \
     }                                                                                                                                 \
     _Pragma("unroll") for (int m_ = 0; m_ < 64; ++m_) {                                                                               \
       if (!(DBG & 4)) acc[m_ & 7][m_ >> 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W4_BC(fb[1][m_ >> 3]), W4_BC(fa[1][m_ & 7]), acc[m_ & 7][m_ >> 3], 0, 0, 0); \
       W4_SB();                                                                                                                        \
-      if constexpr (SCHED == 1) {                                                                                                     \
-        if ((DMA) && m_ < 10 && !(m_ & 1)) dma_b(boff, 3 + (m_ >> 1));                                                                \
-        if ((DMA) && PF && m_ == 9) prefetch();                                                                                       \
-        if ((DMA) && m_ == 9 && !(DBG & 2)) { sA += 128; sB += 128; }                                                                 \
-      }                                                                                                                               \
-      if constexpr (SCHED == 4) {                                                                                                     \
-        if ((DMA) && m_ < 16 && !(m_ & 1)) dma_b(boff, (m_ >> 1) & 7);                                                                \
-        if ((DMA) && PF && m_ == 15) prefetch();                                                                                      \
-        if ((DMA) && m_ == 15 && !(DBG & 2)) { sA += 128; sB += 128; }                                                                \
-      }                                                                                                                               \
-      if ((NEXT) && m_ == YM) asm volatile(VMW ::: "memory");                                                                         \
-      if ((NEXT) && m_ == YM + 1) __builtin_amdgcn_s_barrier();                                                                       \
-      if (SCHED == 1) {                                                                                                               \
-        if ((NEXT) && m_ >= 13 && m_ <= 58 && (m_ - 13) % 3 == 0) {                                                                   \
-          if ((m_ - 13) / 3 < 8) W4_RD(fa[0][((m_ - 13) / 3) & 7], nA0, (((m_ - 13) / 3) & 7) * 2048);                                \
-          else W4_RD(fb[0][((m_ - 13) / 3 - 8) & 7], nB0, (((m_ - 13) / 3 - 8) & 7) * 2048);                                          \
-        }                                                                                                                             \
-      } else if ((NEXT) && m_ >= YM + 2 && m_ < YM + 34 && !((m_ - YM) & 1)) {                                                        \
-        if (((m_ - YM - 2) >> 1) < 8) W4_RD(fa[0][((m_ - YM - 2) >> 1) & 7], nA0, (((m_ - YM - 2) >> 1) & 7) * 2048);                 \
-        else W4_RD(fb[0][(((m_ - YM - 2) >> 1) - 8) & 7], nB0, ((((m_ - YM - 2) >> 1) - 8) & 7) * 2048);                              \
+      if ((DMA) && m_ < 10 && !(m_ & 1)) dma_b(boff, 3 + (m_ >> 1));                                                                  \
+      if ((DMA) && m_ == 9 && !(DBG & 2)) { sA += 128; sB += 128; }                                                                   \
+      if ((NEXT) && m_ == 10) asm volatile(VMW ::: "memory");                                                                         \
+      if ((NEXT) && m_ == 11) __builtin_amdgcn_s_barrier();                                                                           \
+      if ((NEXT) && m_ >= 13 && m_ <= 58 && (m_ - 13) % 3 == 0) {                                                                     \
+        if ((m_ - 13) / 3 < 8) W4_RD(fa[0][((m_ - 13) / 3) & 7], nA0, (((m_ - 13) / 3) & 7) * 2048);                                  \
+        else W4_RD(fb[0][((m_ - 13) / 3 - 8) & 7], nB0, (((m_ - 13) / 3 - 8) & 7) * 2048);                                            \
       }                                                                                                                               \
       W4_SB();                                                                                                                        \
     }                                                                                                                                 \
@@ -212,16 +157,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_w4_kernel(BArgs g, int ntx, 
     for (int p = 0; p < 8; ++p) { dma_a(65536u, p); dma_b(65536u, p); }
     sA += 128; sB += 128;
   };
-  // STAG (experiment): the workgroups start in STAG phase groups a fraction of a tile period apart, so that their epilogues (256 KB of C per
-  // tile, all CUs at once when they run in lock-step: an HBM write burst with the matrix pipes idle) interleave with other groups' main loops
-  if constexpr (STAG > 1) {
-    const int phase = (blockIdx.x >> 3) % STAG;
-    const long long wait = (long long)phase * nkt * g.kchunk / STAG;     // clocks: nkt k-tiles of ~g.kchunk clocks each
-    const long long t0 = __builtin_amdgcn_s_memtime();
-    while ((long long)__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
-  }
   stage_first_two();
-  set_prefetch(m0, n0);
   bool after_epilogue = false;
   for (;;) {
     // k-tiles 0 and 1 have landed (behind an epilogue its 64 stores are younger than that DMA: 63 = the counter's maximum retires the 32 DMA
@@ -243,14 +179,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_w4_kernel(BArgs g, int ntx, 
     unsigned boff = 0u;
     int kt = 0;
     if (nkt > 2) {                                       // k-tile 0: tile 1 is known to have landed
-      pf_left = max(0, nkt - 3 - W4_PD);
       W4_KTILE(1, "", 1);
       kt = 1;
     }
-    for (; kt < nkt - 2; ++kt) {
-      if constexpr (PF) W4_KTILE(1, "s_waitcnt vmcnt(18)", 1);    // (younger than tile kt + 1's DMA: its prefetch load, tile kt + 2's 16 DMA, its prefetch load)
-      else W4_KTILE(1, "s_waitcnt vmcnt(16)", 1);
-    }
+    for (; kt < nkt - 2; ++kt) W4_KTILE(1, "s_waitcnt vmcnt(16)", 1);
     if (kt < nkt - 1) W4_KTILE(0, "s_waitcnt vmcnt(0)", 1);
     // the last k-tile; behind its barrier nobody reads the operand buffers any more
     const bool more = orig + (int)gridDim.x < nt;
@@ -273,7 +205,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_w4_kernel(BArgs g, int ntx, 
                  : "+v"(pbv[0]), "+v"(pbv[1]), "+v"(pbv[2]), "+v"(pbv[3]), "+v"(pbv[4]), "+v"(pbv[5]), "+v"(pbv[6]), "+v"(pbv[7])
                  :
                  : "memory");
-    if (more) { stage_first_two(); set_prefetch(m0n, n0n); }
+    if (more) stage_first_two();
     // ---- epilogue: lane holds C[m0 + wm*128 + i*16 + (lane & 15)][n0 + wn*128 + j*16 + (lane >> 4)*4 .. + 3]
     {
       float* C = g.C;
@@ -300,7 +232,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_w4_kernel(BArgs g, int ntx, 
     orig += (int)gridDim.x; m0 = m0n; n0 = n0n;
     after_epilogue = true;
   }
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_dummy) : : "memory");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #undef W4_BC
 #undef W4_SB
 #undef W4_RD

@@ -116,12 +116,15 @@ def test_gemm_bf16_large_tiles(dev, M, N, K, splitk):
 
 
 @pytest.mark.parametrize("M,N,K,use_bias", [(4600, 3972, 1024, True), (4360, 4100, 128, False), (4100, 4360, 6144, False), (3072, 3800, 1312, True),
-                                            (4600, 3972, 1312, False), (32064, 6144, 1024, True)])
+                                            (4600, 3972, 1312, False), (32064, 6144, 1024, True), (2304, 7210, 192, True), (32064, 1024, 6144, False),
+                                            (5000, 3600, 320, True)])
 def test_gemm_bf16_persistent_tiles_bit_identical(dev, M, N, K, use_bias):
-    """The persistent form of the 256 x 256 NT kernel (one workgroup per CU walking several tiles, the next tile's operands staged from
-    inside the current one; taken for short reductions with more tiles than CUs — the forward input projection of every recurrent layer,
-    blocks.py:76-78 / 88) against the one-workgroup-per-tile form of the same kernel: an accumulating call into zeros never takes the
-    persistent form, and x + 0 is x — the two results must agree bit for bit, ragged edges included; fp64 check at the smaller sizes."""
+    """The persistent forms of the 256 x 256 NT product (one workgroup per CU walking several tiles, the next tile's operands staged from
+    inside the current one; taken with more tiles than CUs — the forward input projection and dX of every recurrent layer, blocks.py:76-78 /
+    88): the FOUR-wave kernel (gemm_nt_w4.h: 128 x 128 per wave on v_mfma_f32_16x16x32_bf16, K a multiple of 64: here K = 1024, 128, 192, 320,
+    6144 — two, three, five k-tiles and the step's own shapes) and the 8-wave kernel (K = 1312) against the one-workgroup-per-tile 8-wave
+    kernel: an accumulating call into zeros never takes a persistent form, and x + 0 is x — the two results must agree bit for bit, ragged
+    edges included, run after run; fp64 check at the smaller sizes."""
     from asr_amd import ops
     A, B, bias = T_(50, M, K), T_(51, N, K), T_(52, N)
     Ab, Bb = ops.cast_bf16(g(A, dev)), ops.cast_bf16(g(B, dev))
