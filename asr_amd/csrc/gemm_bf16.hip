@@ -1056,6 +1056,7 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
 #include "gemm_nt_ring.h"
 #include "gemm_nt_w4.h"
 #include "gemm_tn_group.h"
+#include "gemm_tn_w4.h"
 
 }  // namespace
 
@@ -1296,9 +1297,27 @@ extern "C" int ds2_gemm_bf16_tn_splitk_group(int nprob, const ds2_tn_problem* pr
     DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_tn_glds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
     attr_set = true;
   }
-  BArgs unused{};
-  hipLaunchKernelGGL(gemm_bf16_tn_glds_kernel<true>, dim3(items), dim3(512), G_LDS, (hipStream_t)stream, unused, 0, 0, g);
-  DS2_LAUNCH_CHECK("gemm_bf16_tn_glds_kernel<grouped>");
+  // four waves x 128 x 128 (gemm_tn_w4.h) when every k-tile of every slice is full; DS2_GEMM_W4=0: the 8-wave kernel (A/B switch)
+  static const char* w4_env = ds2_exp_getenv("DS2_GEMM_W4");
+  bool w4 = !(w4_env && w4_env[0] == '0');
+  for (int i = 0; i < nprob; ++i) {
+    const ds2_tn_problem& q = probs[i];
+    const int kc = g.p[i].kchunk, klast = q.K - (splitk - 1) * kc;
+    w4 = w4 && (q.K % 64) == 0 && kc >= 128 && klast >= 128 && (long long)q.lda * 128 < (1ll << 31) && (long long)q.ldb * 128 < (1ll << 31);
+  }
+  if (w4) {
+    static bool w4_attr = false;
+    if (!w4_attr) {
+      DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_tn_w4_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS));
+      w4_attr = true;
+    }
+    hipLaunchKernelGGL(gemm_bf16_tn_w4_kernel<0>, dim3(items), dim3(256), W4_LDS, (hipStream_t)stream, g);
+    DS2_LAUNCH_CHECK("gemm_bf16_tn_w4_kernel");
+  } else {
+    BArgs unused{};
+    hipLaunchKernelGGL(gemm_bf16_tn_glds_kernel<true>, dim3(items), dim3(512), G_LDS, (hipStream_t)stream, unused, 0, 0, g);
+    DS2_LAUNCH_CHECK("gemm_bf16_tn_glds_kernel<grouped>");
+  }
   if (any_slab) {
     int blocks = (int)((elems + 255) / 256);
     if (blocks > 8192) blocks = 8192;

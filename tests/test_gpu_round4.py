@@ -162,6 +162,19 @@ def test_grouped_splitk_weight_gradients_match_separate_launches():
     used = ops.gemm_bf16_tn_splitk_group([(A, Bm, one)], splitk=3)
     ops.gemm_bf16_tn(A, Bm, out=ref, splitk=used)
     assert torch.equal(one, ref)
+    # K a multiple of the 64-deep k-tile: the grouped launch takes the FOUR-wave kernel (gemm_tn_w4.h: 128 x 128 per wave, 16x16x32 MFMA,
+    # operands by two ds_read_b64_tr_b16 each); ds2_gemm_bf16_tn stays on the 8-wave kernel — same slices, same order: equal to the bit,
+    # ragged M / N edges and column-sliced operands included
+    for K, M, N, sk in ((4992, 768, 512, 3), (8192, 1048, 2056, 2), (640, 264, 8, 1)):
+        A = torch.randn(K, M + 16, device="cuda", generator=g).bfloat16()[:, 16:]
+        Bm = torch.randn(K, N + 8, device="cuda", generator=g).bfloat16()[:, :N]
+        one, ref = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+        used = ops.gemm_bf16_tn_splitk_group([(A, Bm, one)], splitk=sk)
+        ops.gemm_bf16_tn(A, Bm, out=ref, splitk=used)
+        assert torch.equal(one, ref), (K, M, N, float((one - ref).abs().max()))
+        again = torch.empty_like(one)
+        ops.gemm_bf16_tn_splitk_group([(A, Bm, again)], splitk=sk)
+        assert torch.equal(one, again)
 
 
 def test_side_stream_schedule_lstm_and_narrow_shapes_fall_back_cleanly():
