@@ -460,6 +460,9 @@ __global__ __launch_bounds__(256) void bn2d_act_collapse_kernel(const float* __r
       if (out_f32) out_f32[row * F + f] = a;
       if (out_bf) out_bf[row * ldb + f] = (nbf16)a;
     }
+    // the zero padding behind the last feature (ldb > F: the row pitch rounded up to the GEMM's 64-deep k-tile) is written by the last f-tile
+    if (out_bf && blockIdx.y == gridDim.y - 1 && t < T)
+      for (int fp = F + tx; fp < ldb; fp += 32) out_bf[((long long)t * Bn + b) * ldb + fp] = (nbf16)0.f;
   }
 }
 
@@ -808,8 +811,8 @@ extern "C" int ds2_bn2d_act_fwd_fused(const float* Y, int B, int D, int T, const
   return 0;
 }
 
-// x (T*B, 32*D) = collapse(mask(hardtanh(BN(Y)))) as fp32 (pitch 32*D; may be NULL) and / or bf16 (pitch ld_bf >= 32*D, ld_bf % 8 == 0, pad
-// columns zeroed by the caller's allocation: with D = 41, 32*D = 1312 is its own multiple of 8; may be NULL)
+// x (T*B, 32*D) = collapse(mask(hardtanh(BN(Y)))) as fp32 (pitch 32*D; may be NULL) and / or bf16 (pitch ld_bf >= 32*D, ld_bf % 8 == 0, the pad
+// columns behind 32*D are written as zeros: the engine rounds the pitch up to the GEMMs' 64-deep k-tile, 1312 -> 1344; may be NULL)
 extern "C" int ds2_bn2d_act_collapse(const float* Y, int B, int D, int T, const int* lens_dev, const float* mean, const float* var,
                                      const float* gamma, const float* beta, float eps, float* x_f32, void* x_bf16, int ld_bf, void* stream) {
   DS2_REQUIRE(Y && lens_dev && mean && var && gamma && beta && (x_f32 || x_bf16), "ds2_bn2d_act_collapse: null pointer");

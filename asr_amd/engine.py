@@ -295,7 +295,8 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
     xn0 = None
     if cfg.precision == "bf16":
         # BN + Hardtanh + mask + collapse + cast in one pass: layer 0 takes the bf16 operand; nobody needs the fp32 form
-        xin, xn0 = ops.bn2d_act_collapse(y2, lens_dev, m2, v2, W[cp + "4.weight"], W[cp + "4.bias"], want_f32=debug_acts)
+        # (row pitch rounded up to the GEMMs' 64-deep k-tile: 1312 -> 1344 zero-padded features put layer 0's projection on the four-wave kernel)
+        xin, xn0 = ops.bn2d_act_collapse(y2, lens_dev, m2, v2, W[cp + "4.weight"], W[cp + "4.bias"], want_f32=debug_acts, pad_to=64)
     else:
         a2 = ops.bn2d_act_fwd(y2, lens_dev, m2, v2, W[cp + "4.weight"], W[cp + "4.bias"])
         xin = ops.transpose_bft(a2, B, 32 * D2, T, to_tbf=True).view(M, 32 * D2)   # (T*B, 1312), feature = c*D2 + d
@@ -317,7 +318,7 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
         else:
             xn = xn0 if cfg.precision == "bf16" else xin
         if cfg.precision == "bf16":
-            gx = ops.gemm_bf16_nt(xn, ops.cast_bf16(W[f"rnns.{l}.wih_cat"]), bias=W[f"rnns.{l}.bih_cat"])
+            gx = ops.gemm_bf16_nt(xn, ops.cast_bf16(W[f"rnns.{l}.wih_cat"], ld=xn.shape[1]), bias=W[f"rnns.{l}.bih_cat"])
         elif _f32_split_ok(M, 2 * G * H, xn.shape[1], H):
             # three-term split-bf16 product as ONE NT GEMM over a reduction index 3 I long: [hi | hi | lo] x [hi | lo | hi]^T
             lc.xs = ops.split_bf16(xn, 0)

@@ -150,11 +150,13 @@ def _pad8(n: int) -> int:
     return (n + 7) // 8 * 8
 
 
-def cast_bf16(src: Tensor) -> Tensor:
-    """(R, C) fp32 row-major view -> (R, pad8(C)) bf16, pad columns zero."""
+def cast_bf16(src: Tensor, ld: Optional[int] = None) -> Tensor:
+    """(R, C) fp32 row-major view -> (R, ld or pad8(C)) bf16, pad columns zero."""
     _chk_f32(src)
     R, Cc = src.shape
-    dst = torch.empty(R, _pad8(Cc), dtype=torch.bfloat16, device=src.device)
+    ld = _pad8(Cc) if ld is None else ld
+    assert ld >= Cc and ld % 8 == 0
+    dst = torch.empty(R, ld, dtype=torch.bfloat16, device=src.device)
     _lib.check(_lib.load().ds2_cast_bf16(src.data_ptr(), _row_pitch(src), dst.data_ptr(), dst.size(1), R, Cc, _stream()), "ds2_cast_bf16")
     return dst
 
@@ -521,9 +523,9 @@ def bn2d_act_fwd_fused(Y: Tensor, lens_dev: Tensor, mean, var, gamma, beta, want
     return a32, apad, anh
 
 
-def bn2d_act_collapse(Y: Tensor, lens_dev: Tensor, mean, var, gamma, beta, want_f32=False, want_bf16=True):
+def bn2d_act_collapse(Y: Tensor, lens_dev: Tensor, mean, var, gamma, beta, want_f32=False, want_bf16=True, pad_to: int = 8):
     """bf16 mode: BatchNorm2d + Hardtanh + mask + (B,32*D,T) -> (T*B, 32*D) collapse (+ cast) in one pass over the conv output.
-    Returns (x fp32 (T*B, 32*D) | None, x bf16 (T*B, pad8(32*D)) | None)."""
+    Returns (x fp32 (T*B, 32*D) | None, x bf16 (T*B, 32*D rounded up to a multiple of pad_to, pad columns zero) | None)."""
     _chk_f32(Y, mean, var, gamma, beta)
     B, Cc, D, T = Y.shape
     assert Cc == 32 and Y.is_contiguous() and (want_f32 or want_bf16)
@@ -531,7 +533,7 @@ def bn2d_act_collapse(Y: Tensor, lens_dev: Tensor, mean, var, gamma, beta, want_
     x32 = torch.empty(T * B, F, dtype=torch.float32, device=Y.device) if want_f32 else None
     xbf = None
     if want_bf16:
-        xbf = (torch.empty if _pad8(F) == F else torch.zeros)(T * B, _pad8(F), dtype=torch.bfloat16, device=Y.device)
+        xbf = torch.empty(T * B, -(-F // pad_to) * pad_to, dtype=torch.bfloat16, device=Y.device)      # (the kernel writes the pad columns)
     _lib.check(_lib.load().ds2_bn2d_act_collapse(Y.data_ptr(), B, D, T, lens_dev.data_ptr(), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(),
                                                  beta.data_ptr(), BN_EPS, _ptr(x32), _ptr(xbf), xbf.size(1) if xbf is not None else 0, _stream()),
                "ds2_bn2d_act_collapse")

@@ -162,7 +162,8 @@ int ds2_bn2d_act_bwd_f32(const float* Y, const float* dA, float* dY, int B, int 
 int ds2_bn2d_act_fwd_fused(const float* Y, int B, int D, int T, const int* lens_dev, const float* mean, const float* var,
                            const float* gamma, const float* beta, float eps, float* a_f32, void* a_pad, void* a_nhwc, void* stream);
 /* second conv stage, bf16 mode: the same block fused with the (B,32*D,T) -> (T*B, 32*D) collapse (deepspeech.py:135-137) and the cast to
- * the first recurrent layer's bf16 GEMM operand; x_f32 (pitch 32*D) and x_bf16 (pitch ld_bf, multiple of 8) may each be NULL */
+ * the first recurrent layer's bf16 GEMM operand; x_f32 (pitch 32*D) and x_bf16 (pitch ld_bf >= 32*D, a multiple of 8; the columns behind
+ * 32*D are written as zeros) may each be NULL */
 int ds2_bn2d_act_collapse(const float* Y, int B, int D, int T, const int* lens_dev, const float* mean, const float* var,
                           const float* gamma, const float* beta, float eps, float* x_f32, void* x_bf16, int ld_bf, void* stream);
 size_t ds2_bn2d_act_bwd_fused_workspace_bytes(int B, int D, int T);

@@ -247,6 +247,11 @@ def test_bn2d_act(dev, B, D, T, lens):
     x32, xbf = ops.bn2d_act_collapse(Yd, ld, mean, var, gd, bd, want_f32=True)
     ref_x = ops.transpose_bft(a32, B, C * D, T, True).view(T * B, C * D)
     assert float((x32 - ref_x).abs().max()) <= 1e-5 and torch.equal(xbf[:, :C * D], x32.bfloat16()) and float(xbf[:, C * D:].float().abs().sum()) == 0
+    # row pitch rounded up to the GEMM's k-tile: the pad columns are written as zeros by the kernel (the buffer starts as NaN bit patterns)
+    for pad_to in (64, 8):
+        torch.full((T * B * (-(-C * D // pad_to) * pad_to),), float("nan"), device=dev).bfloat16()       # leave NaNs for the allocator to hand back
+        _, xp = ops.bn2d_act_collapse(Yd, ld, mean, var, gd, bd, pad_to=pad_to)
+        assert xp.shape[1] == -(-C * D // pad_to) * pad_to and torch.equal(xp[:, :C * D], xbf[:, :C * D]) and float(xp[:, C * D:].float().abs().sum()) == 0
     dg2, db2, dbias = torch.empty(C, device=dev), torch.empty(C, device=dev), torch.empty(C, device=dev)
     d32, dpad, dnh = ops.bn2d_act_bwd_fused(Yd, dAd, ld, mean, var, gd, bd, dg2, db2, dbias, want_f32=True, want_pad=True, want_nhwc=True)
     assert rel_l2(d32.cpu(), Yr.grad) < 3e-5 and torch.equal(dg2, dg_) and torch.equal(db2, db_)
