@@ -43,9 +43,10 @@ def _regs(tok: str):
 
 
 def check_tn_loop(asm: str):
-    """every kernel that gathers fragments with ds_read_b64_tr_b16 (both instances of the 256 x 256 TN kernel and the co-resident grouped one)"""
-    found = list(re.finditer(r"^(_ZN\S*gemm_bf16_tn_(?:glds|group)_kernel\w*):[^\n]*\n(.*?)s_endpgm", asm, re.S | re.M))
-    assert len(found) >= 3, "TN kernels not found"
+    """every kernel that gathers fragments with ds_read_b64_tr_b16 (both instances of the 256 x 256 TN kernel, the four-wave grouped one of
+    gemm_tn_w4.h and the co-resident grouped one)"""
+    found = list(re.finditer(r"^(_ZN\S*gemm_bf16_tn_(?:glds|group|w4)_kernel\w*):[^\n]*\n(.*?)s_endpgm", asm, re.S | re.M))
+    assert len(found) >= 4, "TN kernels not found"
     reads = violations = 0
     for m in found:
         r, v = _check_tn_body(m.group(1), m.group(2))
