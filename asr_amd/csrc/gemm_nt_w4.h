@@ -87,8 +87,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_w4_kernel(BArgs g, int ntx, 
   };
   retarget(m0, n0);
   const unsigned dstw = lds0 + wave * 1024;              // piece p of A -> + p * 4096, of B -> + 32768 + p * 4096; buffer -> + 65536
-  // DBG (timing experiments, WRONG RESULTS): 1 = no operand DMA in the steady state, 2 = the DMA re-reads one L2-resident 64 KB, 4 = no MFMA,
-  // 8 = no epilogue stores
+  // DBG (timing experiments, WRONG RESULTS): 1 = no operand DMA in the steady state, 2 = the DMA re-reads one L2-resident 64 KB, 4 = no MFMA
   auto dma_a = [&](unsigned boff, int p) { if (!(DBG & 1)) w4_dma(voffA[p], sA, dstw + boff + p * 4096); };
   auto dma_b = [&](unsigned boff, int p) { if (!(DBG & 1)) w4_dma(voffB[p], sB, dstw + boff + 32768 + p * 4096); };
 
@@ -222,7 +221,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_w4_kernel(BArgs g, int ntx, 
         for (int j = 0; j < 8; ++j) {
           const int col = n0 + wn * 128 + j * 16 + fseg * 4;
           const f32x4 v = acc[i][j] + pbv[j];
-          f32x4* pc = (row < g.M && col < g.N && !(DBG & 8)) ? reinterpret_cast<f32x4*>(C + (long long)row * ldc + col) : reinterpret_cast<f32x4*>(g_sink16);
+          f32x4* pc = (row < g.M && col < g.N) ? reinterpret_cast<f32x4*>(C + (long long)row * ldc + col) : reinterpret_cast<f32x4*>(g_sink16);
           if (stream_out) __builtin_nontemporal_store(v, pc);
           else *pc = v;
         }
