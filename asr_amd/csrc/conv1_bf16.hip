@@ -207,6 +207,7 @@ __global__ __launch_bounds__(512) void conv1_bf16_fwd_kernel(C1Args a, float* __
 
 // ---- weight gradient -------------------------------------------------------------------------------------------------
 constexpr int W_TT = 64;                       // time steps (K) per block
+constexpr int W_PF = 4;                        // output rows in flight between their HBM request and their LDS publish
 constexpr int W_PITCH = W_TT * 2 + 16;         // 144 bytes per (row, tap) / per co: conflict-free ds_read_b128
 constexpr int W_SLOT = NC * W_PITCH;           // 2304 bytes per input row
 constexpr int W_NR = 44;                       // ring slots (window 41 + 2 being written + 1)
@@ -275,8 +276,7 @@ __global__ __launch_bounds__(256) void conv1_bf16_wgrad_kernel(C1WArgs a) {
       dy_store(0, tid + 256, v1);
     }
     // Data of step o that is not in LDS yet = R(o): the two new rows f = 2o + 19, 2o + 20 (256 chunks, one per thread) and the
-    // dY tile of row o.  R(o + 2) is loaded into registers during step o and published at the end of step o + 1: two steps of
-    // MFMAs cover the HBM latency (one step's ~0.35 us of math does not).
+    // dY tile of row o.  R(o + 4) is loaded into registers during step o and published at the end of step o + 3 (see the loop).
     struct Regs { u32x4 nr; f32x4 d0, d1; };
     const int nrow = tid >> 7, nk = tid & 127;
     auto fetch = [&](int o, Regs& r) {                   // loads R(o): exactly 9 loads, no branches (o >= D1 reads zeros)
@@ -306,30 +306,40 @@ __global__ __launch_bounds__(256) void conv1_bf16_wgrad_kernel(C1WArgs a) {
         bp[i] = (kd < KD ? ring + slot * W_SLOT : zslot) + cl * W_PITCH + half * 16;
       }
       // k-step outer: the dY fragment is read once per k-step for all of the wave's tiles, and consecutive MFMAs go to different
-      // accumulators (no dependent-issue stalls)
+      // accumulators (no dependent-issue stalls).  The fragments of k-step ks + 1 are read BEFORE the MFMAs of k-step ks issue (two register
+      // sets): one wave per SIMD, so an LDS round trip in front of every k-step's MFMAs is fully exposed otherwise.
+      bf16x8 af[2], bf[2][W_TPW];
+      auto frags = [&](int ks, int set) {
+        af[set] = *reinterpret_cast<const bf16x8*>(ap + ks * 32);
+#pragma unroll
+        for (int i = 0; i < W_TPW; ++i) bf[set][i] = *reinterpret_cast<const bf16x8*>(bp[i] + ks * 32);   // (tile slots past the 21st read the zero slot)
+      };
+      frags(0, 0);
 #pragma unroll
       for (int ks = 0; ks < W_TT / 16; ++ks) {
-        const bf16x8 af = *reinterpret_cast<const bf16x8*>(ap + ks * 32);
+        if (ks + 1 < W_TT / 16) frags(ks + 1, (ks + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < W_TPW; ++i) {                  // no branch: the 3 tile slots past the 21st read the zero slot (kd >= 41)
-          const bf16x8 bf = *reinterpret_cast<const bf16x8*>(bp[i] + ks * 32);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[i], 0, 0, 0);
-        }
+        for (int i = 0; i < W_TPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1], bf[ks & 1][i], acc[i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     };
-    Regs ra, rb;
-    fetch(1, rb);
+    // W_PF register sets: R(o + W_PF) is requested during step o and published at the end of step o + W_PF - 1.  With two sets (round 4) a
+    // step could not be shorter than half an HBM round trip — one block per CU (113 KB of LDS), nothing else resident to hide it: 1.8 us per
+    // step against 0.35 us of MFMAs (four sets: 1.57, profiles/r05_conv1_wgrad.txt).
+    Regs rs[W_PF];
+#pragma unroll
+    for (int k = 1; k < W_PF; ++k) fetch(k, rs[k]);
     __syncthreads();
-    for (int o = 0; o < a.D1; o += 2) {
-      fetch(o + 2, ra);
-      compute(o);
-      publish(o + 1, rb);
-      __syncthreads();
-      if (o + 1 < a.D1) {
-        fetch(o + 3, rb);
-        compute(o + 1);
-        publish(o + 2, ra);
-        __syncthreads();
+    for (int o = 0; o < a.D1; o += W_PF) {
+#pragma unroll
+      for (int k = 0; k < W_PF; ++k) {
+        if (o + k < a.D1) {                              // (block-uniform)
+          fetch(o + k + W_PF, rs[k]);
+          compute(o + k);
+          publish(o + k + 1, rs[(k + 1) % W_PF]);
+          __syncthreads();
+        }
       }
     }
   }
