@@ -26,6 +26,18 @@ constexpr int KD = 41, KTAPS = 11, PD = 20, PT = 5, CO = 32, NC = 16;
 
 __device__ __attribute__((aligned(16))) float g_zero_c1[4] = {0.f, 0.f, 0.f, 0.f};
 
+// -DDS2_C1_TRACE (scripts/probe_conv1.hip only): wave 0 of every block sums the shader clocks it spends in the phases of its main loop
+#ifdef DS2_C1_TRACE
+__device__ unsigned long long g_c1_trace[8192 * 8];
+#define C1T_DECL unsigned long long c1t_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c1t_last_ = __builtin_amdgcn_s_memtime()
+#define C1T(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); c1t_[k] += n_ - c1t_last_; c1t_last_ = n_; } while (0)
+#define C1T_DUMP(blk) do { if (threadIdx.x == 0) for (int k_ = 0; k_ < 8; ++k_) g_c1_trace[(long long)(blk) * 8 + k_] = c1t_[k_]; } while (0)
+#else
+#define C1T_DECL
+#define C1T(k)
+#define C1T_DUMP(blk)
+#endif
+
 // ---- operand images --------------------------------------------------------------------------------------------------
 // thread = (b, f, 8 consecutive output steps): 25 input samples -> 8 X16 pixels (256 contiguous bytes) and one 16-byte run in
 // each of the 16 X16T rows
@@ -118,6 +130,8 @@ __global__ __launch_bounds__(512) void conv1_bf16_fwd_kernel(C1Args a, float* __
   const int o = o0 + wave;
 
   // DMA of one tile's window: wave w moves rows w, w + 8, ...; lane i lands at byte 16 i of the row = pixel i >> 1, slot i & 1
+  // (a form with wave-uniform row bases + one lane offset per tile cut the issue phase from 1250 to 380 clocks per tile in
+  // scripts/probe_conv1.hip and changed nothing in the step: not kept)
   const int pix = lane >> 1;
   const int ghalf = swz_half(pix, lane & 1);
   auto stage = [&](int buf, int t0) {
@@ -144,6 +158,8 @@ __global__ __launch_bounds__(512) void conv1_bf16_fwd_kernel(C1Args a, float* __
   float s1[16], s2[16];                                    // BatchNorm statistics of what this lane stores (stat_part != NULL)
 #pragma unroll
   for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+  C1T_DECL;
+  C1T(0);                                                    // prologue
   for (int tile = tile_beg; tile < tile_end; ++tile) {
     const int t0 = tile * F_TT, buf = (tile - tile_beg) & 1;
     const bool live = t0 < len;                                           // block-uniform; later tiles of a short utterance are all zero
@@ -166,11 +182,17 @@ __global__ __launch_bounds__(512) void conv1_bf16_fwd_kernel(C1Args a, float* __
     // The wait must be EXPLICIT: the compiler does not put a vmcnt wait in front of this loop's barrier (it emits a bare s_barrier:
     // the LDS-DMA issued one iteration ago is not something its fence lowering tracks across the back edge), and without it
     // the next tile's ds_reads could overtake a still-landing window row — measured as run-to-run differences in ~1 % of forward
-    // passes (scripts/det_check_fwd.py).  vmcnt(0) also covers the previous tile's stores, issued a whole tile ago.
+    // passes (scripts/det_check_fwd.py).  vmcnt(0) also covers the previous tile's stores, issued a whole tile ago (they have retired by
+    // then: 90 clocks per block in this wait, scripts/probe_conv1.hip).
+    C1T(1);                                                  // MFMAs issued (incl. their fragment reads)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    C1T(2);                                                  // DMA of the other window + this wave's earlier stores retired
     __syncthreads();            // everyone is done reading this window; the other window (DMA'd a whole tile ago) has landed
+    C1T(3);                                                  // barrier
     if (tile + 2 < tile_end && (tile + 2) * F_TT < len) stage(buf, (tile + 2) * F_TT);     // refill it two tiles ahead
-    // the stores of this tile drain under the next tile's MFMAs
+    C1T(4);                                                  // DMA issue
+    // the stores of this tile drain under the next tile's MFMAs.  (Issuing them INSIDE the next tile's MFMA loop — one behind every second
+    // MFMA, counted wait — was built and is slower: 250 against 222 us.)
     const int t = t0 + l31;
     if (t < a.T && o < a.D1) {
 #pragma unroll
@@ -182,7 +204,9 @@ __global__ __launch_bounds__(512) void conv1_bf16_fwd_kernel(C1Args a, float* __
         s2[r] += v * v;
       }
     }
+    C1T(5);                                                  // stores issued
   }
+  C1T_DUMP(((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
   if (stat_part) {
     // per-channel sums of the block: over the 32 lanes of a half-wave, then over the 8 waves (output rows) in order; the window
     // buffers are dead here (every wave has passed the last tile's barrier)
@@ -279,10 +303,31 @@ __global__ __launch_bounds__(256) void conv1_bf16_wgrad_kernel(C1WArgs a) {
     // dY tile of row o.  R(o + 4) is loaded into registers during step o and published at the end of step o + 3 (see the loop).
     struct Regs { u32x4 nr; f32x4 d0, d1; };
     const int nrow = tid >> 7, nk = tid & 127;
-    auto fetch = [&](int o, Regs& r) {                   // loads R(o): exactly 9 loads, no branches (o >= D1 reads zeros)
-      r.nr = *reinterpret_cast<const u32x4*>(row_src(o < a.D1 ? 2 * o - 1 + nrow + PD : -1000, nk >> 3, nk & 7));
-      dy_load(o, tid, r.d0);
-      dy_load(o, tid + 256, r.d1);
+    // R(o) by 9 loads whose addresses are a UNIFORM base (a scalar function of o) + a 32-bit lane offset fixed for the whole block: the
+    // per-step index arithmetic (64-bit multiplies, pointer selects: 1150 clocks per step with the matrix pipe idle, scripts/probe_conv1.hip)
+    // is gone.  Steps of a dY row beyond T are CLAMPED to the row's last step instead of read from a zero page (their X16T partners are
+    // zero and dY is finite), rows beyond D1 to the last row (never published); input rows beyond F read the zero page (wave-uniform).
+    unsigned dyoff[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k = tid + 256 * h, co = k >> 4, tq = t0 + (k & 15) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dyoff[h][j] = (unsigned)(((long long)co * a.D1 * a.T + min(tq + j, a.T - 1)) * 4);
+    }
+    const unsigned rowoff = (unsigned)((((long long)nrow * NC + (nk >> 3)) * a.Tp + t0 + (nk & 7) * 8) * 2);
+    const char* dy_b = reinterpret_cast<const char*>(a.dy + (long long)b * CO * a.D1 * a.T);
+    const char* x_b = reinterpret_cast<const char*>(a.X16T + (long long)b * a.F * NC * a.Tp);
+    const int nrow_u = __builtin_amdgcn_readfirstlane(nrow);
+    auto fetch = [&](int o, Regs& r) {
+      const int f = 2 * o - 1 + PD + nrow_u;                                       // wave-uniform (>= 0)
+      const bool ok = f < a.F;
+      const char* xs = ok ? x_b + (long long)f * NC * a.Tp * 2 - (long long)nrow_u * NC * a.Tp * 2 : reinterpret_cast<const char*>(g_zero_c1);
+      r.nr = *reinterpret_cast<const u32x4*>(xs + (ok ? rowoff : 0u));
+      const char* ds_ = dy_b + (long long)min(o, a.D1 - 1) * a.T * 4;
+      r.d0 = f32x4{*reinterpret_cast<const float*>(ds_ + dyoff[0][0]), *reinterpret_cast<const float*>(ds_ + dyoff[0][1]),
+                   *reinterpret_cast<const float*>(ds_ + dyoff[0][2]), *reinterpret_cast<const float*>(ds_ + dyoff[0][3])};
+      r.d1 = f32x4{*reinterpret_cast<const float*>(ds_ + dyoff[1][0]), *reinterpret_cast<const float*>(ds_ + dyoff[1][1]),
+                   *reinterpret_cast<const float*>(ds_ + dyoff[1][2]), *reinterpret_cast<const float*>(ds_ + dyoff[1][3])};
     };
     auto publish = [&](int o, const Regs& r) {           // R(o) -> ring slots outside the window of step o - 1, dY buffer o & 1
       if (o < a.D1) {
@@ -331,17 +376,24 @@ __global__ __launch_bounds__(256) void conv1_bf16_wgrad_kernel(C1WArgs a) {
 #pragma unroll
     for (int k = 1; k < W_PF; ++k) fetch(k, rs[k]);
     __syncthreads();
+    C1T_DECL;
+    C1T(0);
     for (int o = 0; o < a.D1; o += W_PF) {
 #pragma unroll
       for (int k = 0; k < W_PF; ++k) {
         if (o + k < a.D1) {                              // (block-uniform)
           fetch(o + k + W_PF, rs[k]);
+          C1T(1);
           compute(o + k);
+          C1T(2);
           publish(o + k + 1, rs[(k + 1) % W_PF]);
+          C1T(3);
           __syncthreads();
+          C1T(4);
         }
       }
     }
+    C1T_DUMP(4096 + (long long)blockIdx.y * gridDim.x + blockIdx.x);
   }
 #pragma unroll
   for (int i = 0; i < W_TPW; ++i) {

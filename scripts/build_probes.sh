@@ -13,3 +13,4 @@ mkdir -p build
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../include -I../asr_amd/csrc -DDS2_RNN_TRACE -mllvm -amdgpu-kernarg-preload-count=9 -x hip probe_persist_timeline.hip ../asr_amd/csrc/api.cpp -o build/probe_persist_timeline
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -std=c++17 -Wno-unused-result probe_tr_read.hip -o build/probe_tr_read
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 probe_ksplit_reduce.hip -o build/probe_ksplit_reduce
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../include -I../asr_amd/csrc -x hip probe_conv1.hip ../asr_amd/csrc/api.cpp -o build/probe_conv1

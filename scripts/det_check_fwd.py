@@ -24,7 +24,7 @@ out_lens = torch.tensor([max(1, (int(round(float(p) * tin)) + 1) // 2) for p in 
 def snap():
     with torch.no_grad():
         logits, ctx = engine.forward(W, model._cfg, x, out_lens, training=True, save=True)
-    d = {"y1": ctx.y1, "a1": ctx.a1, "y2": ctx.y2}
+    d = {k: v for k, v in (("y1", ctx.y1), ("a1", ctx.a1), ("a1p", ctx.a1p), ("y2", ctx.y2)) if v is not None}
     for l, lc in enumerate(ctx.layers):
         for nm in ("xin", "xn", "gx", "rec", "hbuf"):
             t = getattr(lc, nm, None)
