@@ -1420,7 +1420,7 @@ extern "C" size_t ds2_cast_bf16_both_workspace_bytes(int R, int Cc) { return (si
 extern "C" int ds2_cast_bf16_both(const float* src, int ld_src, void* dst_r, int ld_r, void* dst_t, int ld_t, int R, int Cc, float* colsum,
                                   void* ws, size_t ws_bytes, void* stream) {
   DS2_REQUIRE(src && dst_t && R > 0 && Cc > 0, "ds2_cast_bf16_both: bad args");
-  DS2_REQUIRE(ld_t >= R && (ld_t % 8) == 0 && (!dst_r || (ld_r >= Cc && ld_r < Cc + 8 && (ld_r % 8) == 0)),
+  DS2_REQUIRE(ld_t >= R && (ld_t % 8) == 0 && (!dst_r || (ld_r >= Cc && ld_r <= ceil_div(Cc, 64) * 64 && (ld_r % 8) == 0)),   // (the kernel's 64-column tiles write zeros up to there)
               "ds2_cast_bf16_both: bad pitches (ld_r=%d ld_t=%d)", ld_r, ld_t);
   if (colsum) DS2_REQUIRE(ws && ws_bytes >= ds2_cast_bf16_both_workspace_bytes(R, Cc), "ds2_cast_bf16_both: workspace too small");
   int rc = launch_cast_transpose(src, ld_src, dst_t, ld_t, dst_r, ld_r, R, Cc, colsum ? (float*)ws : nullptr, stream);

@@ -182,6 +182,7 @@ class LayerCtx:
     wpb: Optional[Tensor] = None     # W_hh^T in fragment order for the backward recurrence
     rec: Optional[Tensor] = None     # bf16 training: packed saved-gate records (M, 2H, 4) instead of gates in gx
     h_bf: Optional[Tensor] = None    # bf16 training, persistent forward recurrence: (M, 2H) bf16 copy of hbuf (operand of the TN-form dW_hh)
+    wihT: Optional[Tensor] = None    # bf16 training: bf16 W_ih^T (I, pad8(2GH)), the B operand of dX (cast with the forward projection's operand)
     xs: Optional[Tensor] = None      # fp32 mode, split-bf16 GEMMs: (M, 3 I) [hi | hi | lo] split copy of xn (xn itself is then not kept)
     gshape: tuple = ()               # (M, 2GH) when gx itself was released
 
@@ -318,7 +319,13 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
         else:
             xn = xn0 if cfg.precision == "bf16" else xin
         if cfg.precision == "bf16":
-            gx = ops.gemm_bf16_nt(xn, ops.cast_bf16(W[f"rnns.{l}.wih_cat"], ld=xn.shape[1]), bias=W[f"rnns.{l}.bih_cat"])
+            if save:
+                # training: ONE read of W_ih gives the row-major bf16 operand of this projection and the transposed one of dX (kept for backward)
+                w_bf, lc.wihT = ops.cast_bf16_both(W[f"rnns.{l}.wih_cat"], ld_r=xn.shape[1])
+            else:
+                w_bf = ops.cast_bf16(W[f"rnns.{l}.wih_cat"], ld=xn.shape[1])
+            gx = ops.gemm_bf16_nt(xn, w_bf, bias=W[f"rnns.{l}.bih_cat"])
+            del w_bf
         elif _f32_split_ok(M, 2 * G * H, xn.shape[1], H):
             # three-term split-bf16 product as ONE NT GEMM over a reduction index 3 I long: [hi | hi | lo] x [hi | lo | hi]^T
             lc.xs = ops.split_bf16(xn, 0)
@@ -551,7 +558,7 @@ def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy, done, private: bo
         else:
             queued = (l, (lc.aux, lc.hbuf, lc.xn), dgx_bf)
         # ---- critical path: dXn = dGx W_ih -> BatchNorm1d backward -> the next layer's dy
-        dxn = ops.gemm_bf16_nt(dgx_bf, ops.cast_transpose_bf16(W[f"rnns.{l}.wih_cat"]))
+        dxn = ops.gemm_bf16_nt(dgx_bf, (lc.wihT if lc.wihT is not None else ops.cast_transpose_bf16(W[f"rnns.{l}.wih_cat"])))
         if l > 0:
             bp = f"rnns.{l}.batch_norm.module."
             dy = _bn_backward(dxn, lc.xin, lc.mean, lc.var, W[bp + "weight"], Gr[bp + "weight"], Gr[bp + "bias"], FUSE_BN_BWD, private)
@@ -570,7 +577,7 @@ def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy, done, private: bo
         elif tn:
             weight_gradients_tn(*queued_tn)                      # nothing to prepare: straight behind the critical-path work of the layer
             queued_tn = None
-        lc.gx = lc.aux = lc.hbuf = lc.xn = lc.wpb = lc.h_bf = None
+        lc.gx = lc.aux = lc.hbuf = lc.xn = lc.wpb = lc.h_bf = lc.wihT = None
     if queued_side is not None:
         start = torch.cuda.Event()                               # layer 0: beside the conv-stack backward
         start.record(main)
@@ -651,12 +658,12 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
         # ---- critical path: dXn = dGx W_ih (feeds the next layer's backward) ---------------------------------------
         dgxT = dgs = dbih_sum = None
         if bfd:
-            dxn = ops.gemm_bf16_nt(dgx_bf, ops.cast_transpose_bf16(W[f"rnns.{l}.wih_cat"]))
+            dxn = ops.gemm_bf16_nt(dgx_bf, (lc.wihT if lc.wihT is not None else ops.cast_transpose_bf16(W[f"rnns.{l}.wih_cat"])))
             # dW = dGx^T [Xn | h] needs the transposed copy; the same read gives db_ih = column sums of dGx
             dgxT, dbih_sum = ops.transpose_bf16(dgx_bf, colsum=Gr[f"rnns.{l}.bih_cat"].view(-1))       # sums land in the gradient buffer
         elif bf:
             dgx_r, dgxT, dbih_sum = ops.cast_bf16_both(dgx, colsum=True)
-            dxn = ops.gemm_bf16_nt(dgx_r, ops.cast_transpose_bf16(W[f"rnns.{l}.wih_cat"]))
+            dxn = ops.gemm_bf16_nt(dgx_r, (lc.wihT if lc.wihT is not None else ops.cast_transpose_bf16(W[f"rnns.{l}.wih_cat"])))
             del dgx_r
         elif split:
             # dXn = dGx W_ih as [hi | hi | lo](dGx) x [hi | lo | hi](W_ih^T)^T; the split copy of dGx also feeds both weight-gradient products
@@ -764,7 +771,7 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
                     keep.append((dgs, lc.xs))
                 else:
                     ops.gemm(dgx, lc.xn, transA=True, out=Gr[f"rnns.{l}.wih_cat"])
-            lc.gx = lc.aux = lc.hbuf = lc.xn = lc.wpb = lc.xs = None
+            lc.gx = lc.aux = lc.hbuf = lc.xn = lc.wpb = lc.xs = lc.wihT = None
         if not defer:
             off_path()
         if l > 0:

@@ -180,12 +180,14 @@ def cast_transpose_bf16(src: Tensor, colsum: Optional[Tensor] = None) -> Tensor:
     return dst
 
 
-def cast_bf16_both(src: Tensor, colsum: bool = False):
-    """(R, C) fp32 -> (bf16 (R, pad8(C)), bf16 (C, pad8(R)) = src^T[, fp32 column sums (C)]) from one read of src; pads zero."""
+def cast_bf16_both(src: Tensor, colsum: bool = False, ld_r: Optional[int] = None):
+    """(R, C) fp32 -> (bf16 (R, ld_r or pad8(C)), bf16 (C, pad8(R)) = src^T[, fp32 column sums (C)]) from one read of src; pads zero."""
     _chk_f32(src)
     R, Cc = src.shape
     lib = _lib.load()
-    dst_r = torch.empty(R, _pad8(Cc), dtype=torch.bfloat16, device=src.device)
+    ld_r = _pad8(Cc) if ld_r is None else ld_r
+    assert ld_r >= Cc and ld_r % 8 == 0
+    dst_r = torch.empty(R, ld_r, dtype=torch.bfloat16, device=src.device)
     dst_t = torch.empty(Cc, _pad8(R), dtype=torch.bfloat16, device=src.device)
     cs, ws, wsb = None, None, 0
     if colsum:

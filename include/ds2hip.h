@@ -113,7 +113,7 @@ int ds2_cast_bf16(const float* src, int ld_src, void* dst, int ld_dst, int R, in
 int ds2_split_bf16(const float* src, int ld_src, void* dst, int ld_dst, int R, int Cc, int order, void* stream);
 int ds2_cast_transpose_bf16(const float* src, int ld_src, void* dst, int ld_dst, int R, int Cc, void* stream);
 /* both copies from ONE read of src: dst_r (R, ld_r) = bf16(src) (NULL: skipped), dst_t (C, ld_t) = bf16(src)^T, pads zero
- * (ld_r % 8 == 0, C <= ld_r < C + 8; ld_t % 8 == 0, ld_t >= R); colsum (C) optional: column sums of src from the same read
+ * (ld_r % 8 == 0, C <= ld_r <= C rounded up to a multiple of 64; ld_t % 8 == 0, ld_t >= R); colsum (C) optional: column sums of src from the same read
  * (the bias gradient db_ih = sum_rows dGx), then ws >= ds2_cast_bf16_both_workspace_bytes(R, C) */
 size_t ds2_cast_bf16_both_workspace_bytes(int R, int Cc);
 int ds2_cast_bf16_both(const float* src, int ld_src, void* dst_r, int ld_r, void* dst_t, int ld_t, int R, int Cc, float* colsum, void* ws,
