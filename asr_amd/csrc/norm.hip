@@ -375,53 +375,82 @@ __global__ __launch_bounds__(256) void bn2d_tile_kernel(const float* __restrict_
   constexpr int CH = 32;
   __shared__ float tile[CH][65];
   const int t0 = blockIdx.x * 64, d = blockIdx.y, b = blockIdx.z;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int t = t0 + lane;
   const int len = min(lens[b], T);
-  const bool in_t = t < T, live = t < len;
-  float res[8];
+  // thread = (channel tid >> 4 (+ 16), 4 consecutive frames): 16-byte lane accesses.  The rows are only 4-byte aligned (T = 501-style
+  // lengths); the hardware takes dword-aligned dwordx4 accesses and the vector types below say so.  (Rounds 2-4 streamed these rows with
+  // 4-byte lane accesses, eight per thread and tensor: the forward pass ran at 2.9 TB/s, 172 us; with the wide form 108 us.)
+  typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+  const int l16 = threadIdx.x & 15, tl4 = l16 * 4, tq0 = t0 + tl4;
+  const bool full4 = tq0 + 3 < T;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int c = wave + 4 * i;
+  for (int i = 0; i < 2; ++i) {
+    const int c = (threadIdx.x >> 4) + 16 * i;
     const long long row = ((long long)b * CH + c) * D + d;
     const float mu = mean[c], rs = rsqrtf(var[c] + eps), ga = gamma[c], be = beta[c];
-    float r = 0.f;
-    if (in_t) {
-      const float y = Yraw[row * T + t];
-      if (!BWD) {
-        r = live ? fminf(fmaxf((y - mu) * (rs * ga) + be, 0.f), 20.f) : 0.f;
-      } else {
-        const float da = dA[row * T + t];
-        const float xh = (y - mu) * rs;
-        const float z = xh * ga + be;
-        const float dz = (live && z > 0.f && z < 20.f) ? da : 0.f;
-        r = live ? ga * rs * (dz - s0[c] * inv_count - xh * (s1[c] * inv_count)) : 0.f;
+    float y[4] = {0.f, 0.f, 0.f, 0.f}, da[4] = {0.f, 0.f, 0.f, 0.f};
+    if (full4) {
+      const f32x4u q = *reinterpret_cast<const f32x4u*>(Yraw + row * T + tq0);
+      y[0] = q.x; y[1] = q.y; y[2] = q.z; y[3] = q.w;
+      if (BWD) {
+        const f32x4u g = *reinterpret_cast<const f32x4u*>(dA + row * T + tq0);
+        da[0] = g.x; da[1] = g.y; da[2] = g.z; da[3] = g.w;
       }
-      if (out_f32) out_f32[row * T + t] = r;
-      if (out_pad) out_pad[row * Tp + 8 + t] = (nbf16)r;
-    }
-    res[i] = r;
-    tile[c][lane] = r;
-    if (out_pad) {                                        // the row's zero frame: 8 leading zeros (first tile), tail (last tile)
-      if (blockIdx.x == 0 && lane < 8) out_pad[row * Tp + lane] = (nbf16)0.f;
-      if (blockIdx.x == gridDim.x - 1 && T + 8 + lane < Tp) out_pad[row * Tp + T + 8 + lane] = (nbf16)0.f;
-    }
-  }
-  if (BWD && chan_part) {
-    const long long blk = ((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    } else {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const float sum = wave_sum(res[i]);
-      if (lane == 0) chan_part[blk * CH + wave + 4 * i] = sum;
+      for (int j = 0; j < 4; ++j)
+        if (tq0 + j < T) {
+          y[j] = Yraw[row * T + tq0 + j];
+          if (BWD) da[j] = dA[row * T + tq0 + j];
+        }
+    }
+    float r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool live = tq0 + j < len;
+      if (!BWD) {
+        r[j] = live ? fminf(fmaxf((y[j] - mu) * (rs * ga) + be, 0.f), 20.f) : 0.f;
+      } else {
+        const float xh = (y[j] - mu) * rs;
+        const float z = xh * ga + be;
+        const float dz = (live && z > 0.f && z < 20.f) ? da[j] : 0.f;
+        r[j] = live ? ga * rs * (dz - s0[c] * inv_count - xh * (s1[c] * inv_count)) : 0.f;
+      }
+      tile[c][tl4 + j] = r[j];
+    }
+    if (out_f32) {
+      if (full4) *reinterpret_cast<f32x4u*>(out_f32 + row * T + tq0) = f32x4u{r[0], r[1], r[2], r[3]};
+      else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (tq0 + j < T) out_f32[row * T + tq0 + j] = r[j];
+      }
+    }
+    if (out_pad) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (tq0 + j < T) out_pad[row * Tp + 8 + tq0 + j] = (nbf16)r[j];
+      // the row's zero frame: 8 leading zeros (first tile), tail (last tile)
+      if (blockIdx.x == 0 && l16 < 8) out_pad[row * Tp + l16] = (nbf16)0.f;
+      if (blockIdx.x == gridDim.x - 1) for (int q = l16; T + 8 + q < Tp; q += 16) out_pad[row * Tp + T + 8 + q] = (nbf16)0.f;
+    }
+    if (BWD && chan_part) {
+      // the tile's sum of dY for this channel: 4 values per lane in order, then the 16 lanes of the channel by a fixed butterfly
+      float sum = ((r[0] + r[1]) + r[2]) + r[3];
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) sum += __shfl_xor(sum, m);
+      const long long blk = ((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      if (l16 == 0) chan_part[blk * CH + c] = sum;
     }
   }
   if (out_nhwc) {
     __syncthreads();
-    const int c = threadIdx.x & 31, tq = threadIdx.x >> 5;   // 8 frames per pass, 32 channels = 64 contiguous bytes per frame
+    // one 16-byte store per thread: 8 channels of one frame; a wave writes 16 consecutive frames = 1 KiB contiguous (2-byte lane stores —
+    // eight 128-byte wave-stores per thread — held the forward pass at 2.9 TB/s)
+    typedef nbf16 nbf16x8 __attribute__((ext_vector_type(8)));
+    const int c8 = (threadIdx.x & 3) * 8, tl = threadIdx.x >> 2, tt = t0 + tl;
+    if (tt < T) {
+      nbf16x8 o;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int tl = tq + 8 * i, tt = t0 + tl;
-      if (tt < T) out_nhwc[(((long long)b * D + d) * T + tt) * CH + c] = (nbf16)tile[c][tl];
+      for (int j = 0; j < 8; ++j) o[j] = (nbf16)tile[c8 + j][tl];
+      *reinterpret_cast<nbf16x8*>(out_nhwc + (((long long)b * D + d) * T + tt) * CH + c8) = o;
     }
   }
 }
@@ -433,36 +462,49 @@ __global__ __launch_bounds__(256) void bn2d_act_collapse_kernel(const float* __r
                                                                 const float* __restrict__ mean, const float* __restrict__ var,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                                 float* __restrict__ out_f32, nbf16* __restrict__ out_bf, int ldb) {
-  __shared__ float tile[32][33];
+  // 64 features x 32 frames per block; 16-byte lane accesses: reads = (feature tid >> 3 (+ 32), 4 consecutive frames: dword-aligned dwordx4,
+  // see bn2d_tile_kernel), bf16 writes = (frame tid >> 3, 8 consecutive features) = 128 contiguous bytes per frame
+  typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+  typedef nbf16 nbf16x8 __attribute__((ext_vector_type(8)));
+  __shared__ float tile[64][33];
   const int F = 32 * D;
   const int b = blockIdx.z;
-  const int f0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int f0 = blockIdx.y * 64, t0 = blockIdx.x * 32;
   const int len = min(lens[b], T);
+  {
+    const int q4 = (threadIdx.x & 7) * 4, t = t0 + q4;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int f = f0 + ty + 8 * i, t = t0 + tx;
-    float a = 0.f;
-    if (f < F && t < len) {
-      const int c = f / D;
-      const float y = Yraw[((long long)b * F + f) * T + t];
-      a = fminf(fmaxf((y - mean[c]) * (rsqrtf(var[c] + eps) * gamma[c]) + beta[c], 0.f), 20.f);
+    for (int i = 0; i < 2; ++i) {
+      const int fl = (threadIdx.x >> 3) + 32 * i, f = f0 + fl;
+      float a[4] = {0.f, 0.f, 0.f, 0.f};
+      if (f < F && t < len) {
+        const int c = f / D;
+        const float sc = rsqrtf(var[c] + eps) * gamma[c], mu = mean[c], be = beta[c];
+        const float* p = Yraw + ((long long)b * F + f) * T + t;
+        float y[4] = {0.f, 0.f, 0.f, 0.f};
+        if (t + 3 < T) { const f32x4u q = *reinterpret_cast<const f32x4u*>(p); y[0] = q.x; y[1] = q.y; y[2] = q.z; y[3] = q.w; }
+        else for (int j = 0; j < 4; ++j) if (t + j < T) y[j] = p[j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] = (t + j < len) ? fminf(fmaxf((y[j] - mu) * sc + be, 0.f), 20.f) : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tile[fl][q4 + j] = a[j];
     }
-    tile[ty + 8 * i][tx] = a;
   }
   __syncthreads();
+  const int tl = threadIdx.x >> 3, t = t0 + tl, f8 = (threadIdx.x & 7) * 8, f = f0 + f8;
+  if (t < T) {
+    const long long row = (long long)t * Bn + b;
+    if (out_f32) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int t = t0 + ty + 8 * i, f = f0 + tx;
-    if (f < F && t < T) {
-      const float a = tile[tx][ty + 8 * i];
-      const long long row = (long long)t * Bn + b;
-      if (out_f32) out_f32[row * F + f] = a;
-      if (out_bf) out_bf[row * ldb + f] = (nbf16)a;
+      for (int j = 0; j < 8; ++j) if (f + j < F) out_f32[row * F + f + j] = tile[f8 + j][tl];
     }
-    // the zero padding behind the last feature (ldb > F: the row pitch rounded up to the GEMM's 64-deep k-tile) is written by the last f-tile
-    if (out_bf && blockIdx.y == gridDim.y - 1 && t < T)
-      for (int fp = F + tx; fp < ldb; fp += 32) out_bf[((long long)t * Bn + b) * ldb + fp] = (nbf16)0.f;
+    if (out_bf && f < ldb) {                                 // (F and ldb are multiples of 8: an 8-run is either inside F, or all padding)
+      nbf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (f + j < F) ? (nbf16)tile[f8 + j][tl] : (nbf16)0.f;
+      *reinterpret_cast<nbf16x8*>(out_bf + row * ldb + f) = o;
+    }
   }
 }
 
@@ -499,33 +541,53 @@ __global__ __launch_bounds__(256) void chan_part_finalize_kernel(const float* __
 // (B, F, T) -> (T, B, F)  [dir 0]   or   (T, B, F) -> (B, F, T)  [dir 1] ; 32x32 LDS tiles
 __global__ __launch_bounds__(256) void transpose_bft_kernel(const float* __restrict__ src, float* __restrict__ dst, int Bn, int F, int T,
                                                             int dir) {
-  __shared__ float tile[32][33];
+  // 64 x 64 tiles, 16-byte lane accesses on both sides (rows of length T are only 4-byte aligned: dword-aligned dwordx4, see bn2d_tile_kernel);
+  // thread = (row tid >> 4 (+ 16 i), 4 consecutive elements).  (32 x 32 tiles with 4-byte lanes before: 103 us for the 336 MB of c3's backward.)
+  typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+  __shared__ float tile[64][65];
   const int b = blockIdx.z;
-  const int f0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // ty 0..7
-  if (dir == 0) {
+  const int f0 = blockIdx.y * 64, t0 = blockIdx.x * 64;
+  const int q4 = (threadIdx.x & 15) * 4, r16 = threadIdx.x >> 4;
+  // the (B,F,T) side: row = feature, run along t;  the (T,B,F) side: row = frame, run along f
+  auto bft = [&](int f, int t) { return ((long long)b * F + f) * T + t; };
+  auto tbf = [&](int t, int f) { return ((long long)t * Bn + b) * F + f; };
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int f = f0 + ty + 8 * i, t = t0 + tx;
-      tile[ty + 8 * i][tx] = (f < F && t < T) ? src[((long long)b * F + f) * T + t] : 0.f;
+  for (int i = 0; i < 4; ++i) {
+    const int r = r16 + 16 * i;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (dir == 0) {                                          // read (B,F,T): feature f0 + r, frames t0 + q4 ..
+      const int f = f0 + r, t = t0 + q4;
+      if (f < F) {
+        if (t + 3 < T) { const f32x4u q = *reinterpret_cast<const f32x4u*>(src + bft(f, t)); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+        else for (int j = 0; j < 4; ++j) if (t + j < T) v[j] = src[bft(f, t + j)];
+      }
+    } else {                                                 // read (T,B,F): frame t0 + r, features f0 + q4 ..
+      const int t = t0 + r, f = f0 + q4;
+      if (t < T) {
+        if (f + 3 < F) { const f32x4u q = *reinterpret_cast<const f32x4u*>(src + tbf(t, f)); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+        else for (int j = 0; j < 4; ++j) if (f + j < F) v[j] = src[tbf(t, f + j)];
+      }
     }
-    __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int t = t0 + ty + 8 * i, f = f0 + tx;
-      if (f < F && t < T) dst[((long long)t * Bn + b) * F + f] = tile[tx][ty + 8 * i];
-    }
-  } else {
+    for (int j = 0; j < 4; ++j) tile[r][q4 + j] = v[j];
+  }
+  __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int t = t0 + ty + 8 * i, f = f0 + tx;
-      tile[ty + 8 * i][tx] = (f < F && t < T) ? src[((long long)t * Bn + b) * F + f] : 0.f;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int f = f0 + ty + 8 * i, t = t0 + tx;
-      if (f < F && t < T) dst[((long long)b * F + f) * T + t] = tile[tx][ty + 8 * i];
+  for (int i = 0; i < 4; ++i) {
+    const int r = r16 + 16 * i;
+    const f32x4u o = {tile[q4][r], tile[q4 + 1][r], tile[q4 + 2][r], tile[q4 + 3][r]};
+    if (dir == 0) {                                          // write (T,B,F): frame t0 + r, features f0 + q4 ..
+      const int t = t0 + r, f = f0 + q4;
+      if (t < T) {
+        if (f + 3 < F) *reinterpret_cast<f32x4u*>(dst + tbf(t, f)) = o;
+        else for (int j = 0; j < 4; ++j) if (f + j < F) dst[tbf(t, f + j)] = o[j];
+      }
+    } else {                                                 // write (B,F,T): feature f0 + r, frames t0 + q4 ..
+      const int f = f0 + r, t = t0 + q4;
+      if (f < F) {
+        if (t + 3 < T) *reinterpret_cast<f32x4u*>(dst + bft(f, t)) = o;
+        else for (int j = 0; j < 4; ++j) if (t + j < T) dst[bft(f, t + j)] = o[j];
+      }
     }
   }
 }
@@ -817,7 +879,7 @@ extern "C" int ds2_bn2d_act_collapse(const float* Y, int B, int D, int T, const 
                                      const float* gamma, const float* beta, float eps, float* x_f32, void* x_bf16, int ld_bf, void* stream) {
   DS2_REQUIRE(Y && lens_dev && mean && var && gamma && beta && (x_f32 || x_bf16), "ds2_bn2d_act_collapse: null pointer");
   DS2_REQUIRE(!x_bf16 || (ld_bf >= 32 * D && (ld_bf % 8) == 0), "ds2_bn2d_act_collapse: bad bf16 pitch %d", ld_bf);
-  hipLaunchKernelGGL(bn2d_act_collapse_kernel, dim3(ceil_div(T, 32), D, B), dim3(256), 0, (hipStream_t)stream, Y, B, D, T, lens_dev, mean, var,
+  hipLaunchKernelGGL(bn2d_act_collapse_kernel, dim3(ceil_div(T, 32), ceil_div(ld_bf > 32 * D ? ld_bf : 32 * D, 64), B), dim3(256), 0, (hipStream_t)stream, Y, B, D, T, lens_dev, mean, var,
                      gamma, beta, eps, x_f32, (nbf16*)x_bf16, ld_bf);
   DS2_LAUNCH_CHECK("bn2d_act_collapse_kernel");
   return 0;
@@ -858,7 +920,7 @@ extern "C" int ds2_bn2d_act_bwd_fused(const float* Y, const float* dA, int B, in
 // dir 0: (B,F,T) -> (T,B,F)  (deepspeech.py:135-137 collapse) ; dir 1: inverse
 extern "C" int ds2_transpose_bft_f32(const float* src, float* dst, int B, int F, int T, int dir, void* stream) {
   DS2_REQUIRE(src && dst && B > 0 && F > 0 && T > 0, "ds2_transpose_bft_f32: bad args");
-  dim3 grid(ceil_div(T, 32), ceil_div(F, 32), B);
+  dim3 grid(ceil_div(T, 64), ceil_div(F, 64), B);
   hipLaunchKernelGGL(transpose_bft_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dst, B, F, T, dir);
   DS2_LAUNCH_CHECK("transpose_bft_kernel");
   return 0;
