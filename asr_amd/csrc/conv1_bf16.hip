@@ -150,14 +150,12 @@ __global__ __launch_bounds__(512) void conv1_bf16_fwd_kernel(C1Args a, float* __
   }
   __syncthreads();                                                        // vmcnt(0) + barrier: weights and the first two windows are in LDS
   const int rd = swz_half(l31, half) * 16;                                // this lane's 16-byte slot inside its 32-byte record
-  // biases of this lane's 16 output channels, loaded ONCE before any store is in flight: a load inside the store loop would make
-  // every s_waitcnt vmcnt(0) wait for all earlier stores (one memory counter), i.e. serialise the HBM write latency 16 times a tile
-  float bv[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) bv[r] = a.bias ? a.bias[(r & 3) + 8 * (r >> 2) + 4 * half] : 0.f;
-  float s1[16], s2[16];                                    // BatchNorm statistics of what this lane stores (stat_part != NULL)
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+  // The product is formed TRANSPOSED (input fragment as the MFMA's first operand): a lane then holds ONE output channel (lane & 31) at 4 x 4
+  // consecutive frames, so a tile leaves as four 16-byte stores per lane instead of sixteen 4-byte ones (the rows of y1 are only 4-byte
+  // aligned: dword-aligned dwordx4, see norm.hip) and bias / BatchNorm statistics are one register each.
+  typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+  const float bv = a.bias ? a.bias[l31] : 0.f;             // loaded ONCE before any store is in flight (one in-order memory counter)
+  float s1 = 0.f, s2 = 0.f;                                // BatchNorm statistics of what this lane stores (stat_part != NULL)
   C1T_DECL;
   C1T(0);                                                    // prologue
   for (int tile = tile_beg; tile < tile_end; ++tile) {
@@ -175,8 +173,8 @@ __global__ __launch_bounds__(512) void conv1_bf16_fwd_kernel(C1Args a, float* __
       for (int kd = 0; kd < KD; ++kd) {
         const bf16x8 wf = *reinterpret_cast<const bf16x8*>(ap + kd * (CO * NC * 2));
         const bf16x8 xb = *reinterpret_cast<const bf16x8*>(bp + kd * F_ROWB);
-        if (kd & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xb, acc1, 0, 0, 0);
-        else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xb, acc0, 0, 0, 0);
+        if (kd & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xb, wf, acc1, 0, 0, 0);
+        else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xb, wf, acc0, 0, 0, 0);
       }
     }
     // The wait must be EXPLICIT: the compiler does not put a vmcnt wait in front of this loop's barrier (it emits a bare s_barrier:
@@ -193,15 +191,22 @@ __global__ __launch_bounds__(512) void conv1_bf16_fwd_kernel(C1Args a, float* __
     C1T(4);                                                  // DMA issue
     // the stores of this tile drain under the next tile's MFMAs.  (Issuing them INSIDE the next tile's MFMA loop — one behind every second
     // MFMA, counted wait — was built and is slower: 250 against 222 us.)
-    const int t = t0 + l31;
-    if (t < a.T && o < a.D1) {
+    if (o < a.D1) {
+      float* yrow = a.y + (((long long)b * CO + l31) * a.D1 + o) * a.T;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
-        const float v = (t < len) ? acc0[r] + acc1[r] + bv[r] : 0.f;
-        a.y[(((long long)b * CO + co) * a.D1 + o) * a.T + t] = v;
-        s1[r] += v;
-        s2[r] += v * v;
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int t = t0 + 8 * g4 + 4 * half;              // frames t .. t + 3 = accumulator registers 4 g4 .. 4 g4 + 3
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] = (t + j < len) ? acc0[4 * g4 + j] + acc1[4 * g4 + j] + bv : 0.f;
+          if (t + j < a.T) { s1 += v[j]; s2 += v[j] * v[j]; }
+        }
+        if (t + 3 < a.T) *reinterpret_cast<f32x4u*>(yrow + t) = f32x4u{v[0], v[1], v[2], v[3]};
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (t + j < a.T) yrow[t + j] = v[j];
+        }
       }
     }
     C1T(5);                                                  // stores issued
@@ -212,12 +217,9 @@ __global__ __launch_bounds__(512) void conv1_bf16_fwd_kernel(C1Args a, float* __
     // buffers are dead here (every wave has passed the last tile's barrier)
     __syncthreads();
     float* red = reinterpret_cast<float*>(lds);            // [8 waves][32 co][2]
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-#pragma unroll
-      for (int m = 1; m < 32; m <<= 1) { s1[r] += __shfl_xor(s1[r], m); s2[r] += __shfl_xor(s2[r], m); }
-      if (l31 == 0) { const int co = (r & 3) + 8 * (r >> 2) + 4 * half; red[(wave * 32 + co) * 2 + 0] = s1[r]; red[(wave * 32 + co) * 2 + 1] = s2[r]; }
-    }
+    s1 += __shfl_xor(s1, 32);                              // the two half-waves hold the other frames of the same channel
+    s2 += __shfl_xor(s2, 32);
+    if (half == 0) { red[(wave * 32 + l31) * 2 + 0] = s1; red[(wave * 32 + l31) * 2 + 1] = s2; }
     __syncthreads();
     if (tid < 64) {
       float sum = 0.f;
