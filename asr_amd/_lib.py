@@ -106,6 +106,7 @@ SIGNATURES = {
     "ds2_softmax_rows_f32": (i32, [vp, i32, vp, i32, i32, i32, vp]),
     "ds2_greedy_decode_workspace_bytes": (sz, [i32, i32]),
     "ds2_greedy_decode_f32": (i32, [vp, i64, i64, i32, i32, i32, vp, i32, vp, vp, vp, vp, sz, vp]),
+    "ds2_conv1_bf16_row_pitch": (i32, [i32]),
     "ds2_conv1_bf16_bytes": (sz, [i32, i32, i32, i32]),
     "ds2_conv1_pack_bf16": (i32, [vp, vp, vp]),
     "ds2_conv1_gather_bf16": (i32, [vp, vp, vp, i32, i32, i32, vp]),

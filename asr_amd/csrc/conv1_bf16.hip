@@ -2,11 +2,15 @@
 // Conv2d(1, 32, (41, 11), stride (2, 2), padding (20, 5)), deepspeech.py:61:
 //     y1[b,co,o,t] = bias[co] + sum_{kd<41, kt<11} W[co,0,kd,kt] * x[b, 2o + kd - 20, 2t + kt - 5]
 //
-// One input channel gives the MFMA no channel axis to contract over, so the 11 time taps play that role: a gather pass builds,
-// from one read of the spectrogram, the two bf16 operand images
-//     X16 [b][f][t][16]   (tap-contiguous:  X16[..][t][c]  = x[b][f][2t + c - 5], c < 11, else 0)   -> forward  B operand
-//     X16T[b][f][16][Tp]  (time-contiguous: X16T[..][c][t] = same value)                              -> wgrad    B operand
-// (165 MB each at B = 64 x 10 s; the stride-2 / shift-by-tap addressing is paid once, here, instead of in every fragment read).
+// One input channel gives the MFMA no channel axis to contract over, so the 11 time taps play that role (padded to 16, the five extra
+// taps have zero weights).  Operand images, built from one read of the spectrogram:
+//     XB  [b][f][P]       bf16 ROWS: XB[..][7 + s] = x[b][f][s], zeros in front and behind (P = 2 pad32(T) + 72)      -> forward operand
+//     X16T[b][f][16][Tp]  (time-contiguous: X16T[..][c][t] = x[b][f][2t + c - 5], c < 11, else 0)                      -> wgrad operand
+// Forward (round 5): the 16 taps of output step t are the 16 CONSECUTIVE samples 2t - 5 .. 2t + 10 of a row, so the MFMA fragment of lane t
+// is a 16-byte run of the raw row at byte offset 4t (+ 16 for the upper half-wave) of a window that starts at sample 2 t0 - 5 = XB index
+// 2 t0 + 2: 4-byte aligned — two ds_read2_b32 per fragment.  Rounds 2-4 materialised the tap-expanded image X16[b][f][t][16] (165 MB, eight
+// times the rows) and re-read it 3.4-fold (55 input rows per 8 output rows): 900 MB of traffic bound the forward kernel at 256 us whatever
+// its stores or DMA issue cost (scripts/probe_conv1.hip).
 //   forward: GEMM M = co (32), N = t, K = (kd, c) = 41 x 16.  block = (b, 8 output rows, half of the time axis), persistent over
 //            32-step tiles: all 41 weight rows are staged once, the 55 input rows a tile touches are DMA'd (global_load_lds, one
 //            1 KiB instruction per row) into a double buffer while the previous tile is multiplied; 8 waves, one output row each (two
@@ -83,6 +87,27 @@ __global__ __launch_bounds__(256) void conv1_gather_kernel(const float* __restri
   }
 }
 
+// XB[b][f][7 + s] = bf16(x[b][f][s]), zeros elsewhere; thread = 8 consecutive elements of a row (16-byte stores; the source run starts one
+// float before an 8-element boundary, so it is read by scalar loads)
+constexpr int XB_LEFT = 7;
+inline __host__ __device__ int xb_pitch(int T) { return 2 * ((T + 31) / 32 * 32) + 72; }
+__global__ __launch_bounds__(256) void conv1_rows_kernel(const float* __restrict__ x, __bf16* __restrict__ XB, long long rows, int Tin, int P) {
+  const int oct = P / 8;
+  const long long total = rows * oct;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / oct;
+    const int k0 = (int)(i % oct) * 8;
+    const float* xr = x + row * Tin;
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int sidx = k0 + j - XB_LEFT;
+      o[j] = (sidx >= 0 && sidx < Tin) ? (__bf16)xr[sidx] : (__bf16)0.f;
+    }
+    *reinterpret_cast<bf16x8*>(XB + row * P + k0) = o;
+  }
+}
+
 // 32-byte records (one pixel / one output channel = 16 taps) read by 16-lane ds_read_b128 groups at record stride would hit
 // every bank row twice; swapping the two 16-byte halves of records 8..15 (mod 16) makes the 16 lanes of a group land on 16
 // distinct bank quads.  Applied to the packed weights here and, through the DMA source addresses, to the staged input rows.
@@ -100,14 +125,14 @@ __global__ void conv1_pack_kernel(const float* __restrict__ w, __bf16* __restric
 // ---- forward -----------------------------------------------------------------------------------------------------------
 constexpr int F_OG = 8, F_TT = 32, F_SPLIT = 2;
 constexpr int F_ROWS = 2 * (F_OG - 1) + KD;        // 55 input rows per block
-constexpr int F_ROWB = F_TT * NC * 2;              // 1024 bytes per staged row = ONE global_load_lds wave-instruction
-constexpr int F_BUF = F_ROWS * F_ROWB;             // 56320
+constexpr int F_ROWB = 256;                        // bytes per staged row: 128 samples from 2 t0 - 5 on (78 are read); four rows per global_load_lds wave-instruction
+constexpr int F_BUF = (F_ROWS + 3) / 4 * 1024;         // 14336: the row groups of one window
 constexpr int F_WB = KD * CO * NC * 2;             // 41984 bytes of weights
-constexpr int F_LDS = 2 * F_BUF + F_WB;            // 154624: two row windows (double buffer) + all weights
+constexpr int F_LDS = 2 * F_BUF + F_WB;            // 70656: two row windows (double buffer) + all weights -> two blocks per CU
 
 struct C1Args {
-  const __bf16* X16; const __bf16* wp; const float* bias; const int* lens; float* y;
-  int B, F, T, D1;
+  const __bf16* XB; const __bf16* wp; const float* bias; const int* lens; float* y;
+  int B, F, T, D1, P;
 };
 
 typedef __attribute__((address_space(3))) void c1_lds_void;
@@ -129,17 +154,14 @@ __global__ __launch_bounds__(512) void conv1_bf16_fwd_kernel(C1Args a, float* __
   const int f0 = 2 * o0 - PD;
   const int o = o0 + wave;
 
-  // DMA of one tile's window: wave w moves rows w, w + 8, ...; lane i lands at byte 16 i of the row = pixel i >> 1, slot i & 1
-  // (a form with wave-uniform row bases + one lane offset per tile cut the issue phase from 1250 to 380 clocks per tile in
-  // scripts/probe_conv1.hip and changed nothing in the step: not kept)
-  const int pix = lane >> 1;
-  const int ghalf = swz_half(pix, lane & 1);
+  // DMA of one tile's window: one wave-instruction lands FOUR rows (lane = row (lane >> 4), 16-byte chunk (lane & 15) of the 256 staged
+  // bytes); wave w moves the row groups w, w + 8.  Rows outside the spectrogram read the zero page.
   auto stage = [&](int buf, int t0) {
-    for (int r = wave; r < F_ROWS; r += 8) {
-      const int f = f0 + r, t = t0 + pix;
-      const bool ok = f >= 0 && f < a.F && t < a.T;
-      const void* src = ok ? (const void*)(a.X16 + (((long long)b * a.F + f) * a.T + t) * NC + ghalf * 8) : (const void*)g_zero_c1;
-      __builtin_amdgcn_global_load_lds((c1_gbl_void*)src, (c1_lds_void*)(lds + buf * F_BUF + r * F_ROWB), 16, 0, 0);
+    for (int gq = wave; gq < (F_ROWS + 3) / 4; gq += 8) {
+      const int r = gq * 4 + (lane >> 4), f = f0 + r;
+      const bool ok = r < F_ROWS && f >= 0 && f < a.F;
+      const void* src = ok ? (const void*)(a.XB + ((long long)b * a.F + f) * a.P + 2 * t0 + 2 + (lane & 15) * 8) : (const void*)g_zero_c1;
+      __builtin_amdgcn_global_load_lds((c1_gbl_void*)src, (c1_lds_void*)(lds + buf * F_BUF + gq * 1024), 16, 0, 0);
     }
   };
   const bool any = tile_beg < tile_end && tile_beg * F_TT < len;        // block-uniform
@@ -167,12 +189,14 @@ __global__ __launch_bounds__(512) void conv1_bf16_fwd_kernel(C1Args a, float* __
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
     if (live && o < a.D1) {
       // output row o0 + wave reads local input rows 2*wave + kd, kd = 0..40
-      const char* bp = lds + buf * F_BUF + (2 * wave) * F_ROWB + l31 * (NC * 2) + rd;
+      // this lane's 16 taps of output step t0 + l31 = 32 consecutive bytes of the raw row from byte 4 l31 on; the upper half-wave takes taps 8..15
+      typedef bf16x8 bf16x8u __attribute__((aligned(4)));
+      const char* bp = lds + buf * F_BUF + (2 * wave) * F_ROWB + l31 * 4 + half * 16;
       const char* ap = wl + l31 * (NC * 2) + rd;
 #pragma unroll
       for (int kd = 0; kd < KD; ++kd) {
         const bf16x8 wf = *reinterpret_cast<const bf16x8*>(ap + kd * (CO * NC * 2));
-        const bf16x8 xb = *reinterpret_cast<const bf16x8*>(bp + kd * F_ROWB);
+        const bf16x8 xb = *reinterpret_cast<const bf16x8u*>(bp + kd * F_ROWB);
         if (kd & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xb, wf, acc1, 0, 0, 0);
         else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xb, wf, acc0, 0, 0, 0);
       }
@@ -442,10 +466,11 @@ inline int pad64(int T) { return (T + 63) / 64 * 64; }
 
 }  // namespace
 
-// sizes (bytes): which = 0 packed weights, 1 X16 (forward operand image), 2 X16T (weight-gradient operand image)
+// sizes (bytes): which = 0 packed weights, 1 XB (forward operand: bf16 rows, pitch ds2_conv1_bf16_row_pitch), 2 X16T (weight-gradient operand image)
+extern "C" int ds2_conv1_bf16_row_pitch(int T) { return xb_pitch(T); }
 extern "C" size_t ds2_conv1_bf16_bytes(int which, int B, int F, int T) {
   if (which == 0) return (size_t)KD * CO * NC * 2;
-  if (which == 1) return (size_t)B * F * T * NC * 2;
+  if (which == 1) return (size_t)B * F * xb_pitch(T) * 2;
   return (size_t)B * F * NC * pad64(T) * 2;
 }
 
@@ -456,20 +481,31 @@ extern "C" int ds2_conv1_pack_bf16(const float* w1, void* wp, void* stream) {
   return 0;
 }
 
-// x (B,1,F,Tin) fp32 -> X16 and/or X16T (either may be NULL); T = output steps = (Tin + 2*5 - 11)/2 + 1
-extern "C" int ds2_conv1_gather_bf16(const float* x, void* X16, void* X16T, int B, int F, int Tin, void* stream) {
-  DS2_REQUIRE(x && (X16 || X16T) && B > 0 && F > 0 && Tin > 0, "ds2_conv1_gather_bf16: bad args");
+// x (B,1,F,Tin) fp32 -> XB (B,F,P) and/or X16T (either may be NULL); T = output steps = (Tin + 2*5 - 11)/2 + 1, P = ds2_conv1_bf16_row_pitch(T)
+extern "C" int ds2_conv1_gather_bf16(const float* x, void* XB, void* X16T, int B, int F, int Tin, void* stream) {
+  DS2_REQUIRE(x && (XB || X16T) && B > 0 && F > 0 && Tin > 0, "ds2_conv1_gather_bf16: bad args");
   const int T = (Tin + 2 * PT - KTAPS) / 2 + 1, Tp = pad64(T);
-  const long long total = (long long)B * F * (Tp / 8);
-  long long blocks = (total + 255) / 256;
-  if (blocks > 65535) blocks = 65535;
-  hipLaunchKernelGGL(conv1_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (__bf16*)X16, (__bf16*)X16T, (long long)B * F, Tin,
-                     T, Tp);
-  DS2_LAUNCH_CHECK("conv1_gather_kernel");
+  if (XB) {
+    const int P = xb_pitch(T);
+    DS2_REQUIRE(XB_LEFT + Tin + 8 <= P, "ds2_conv1_gather_bf16: row pitch %d too small for Tin=%d", P, Tin);
+    const long long total = (long long)B * F * (P / 8);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 65535) blocks = 65535;
+    hipLaunchKernelGGL(conv1_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (__bf16*)XB, (long long)B * F, Tin, P);
+    DS2_LAUNCH_CHECK("conv1_rows_kernel");
+  }
+  if (X16T) {
+    const long long total = (long long)B * F * (Tp / 8);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 65535) blocks = 65535;
+    hipLaunchKernelGGL(conv1_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (__bf16*)nullptr, (__bf16*)X16T, (long long)B * F, Tin,
+                       T, Tp);
+    DS2_LAUNCH_CHECK("conv1_gather_kernel");
+  }
   return 0;
 }
 
-// y1 (B,32,D1,T) fp32 = conv1(x) + bias, zero for t >= lens[b] (MaskConv).  X16 from ds2_conv1_gather_bf16, wp from ds2_conv1_pack_bf16.
+// y1 (B,32,D1,T) fp32 = conv1(x) + bias, zero for t >= lens[b] (MaskConv).  XB from ds2_conv1_gather_bf16, wp from ds2_conv1_pack_bf16.
 extern "C" int ds2_conv1_fwd_bf16_stat_blocks(int B, int F, int Tin) {
   (void)Tin;
   return F_SPLIT * ceil_div((F + 2 * PD - KD) / 2 + 1, F_OG) * B;
@@ -477,12 +513,12 @@ extern "C" int ds2_conv1_fwd_bf16_stat_blocks(int B, int F, int Tin) {
 
 // stat_part: NULL, or ds2_conv1_fwd_bf16_stat_blocks() x 32 x 2 floats: per-block (sum, sum of squares) of every output channel over what
 // the block stored (masked frames count as zeros: what BatchNorm2d sees) - finished by ds2_chanstats_from_partials
-extern "C" int ds2_conv1_fwd_bf16_stats(const void* X16, const void* wp, const float* bias, const int* lens_dev, float* y1, int B, int F, int Tin,
+extern "C" int ds2_conv1_fwd_bf16_stats(const void* XB, const void* wp, const float* bias, const int* lens_dev, float* y1, int B, int F, int Tin,
                                         float* stat_part, void* stream) {
-  DS2_REQUIRE(X16 && wp && y1, "ds2_conv1_fwd_bf16: null pointer");
+  DS2_REQUIRE(XB && wp && y1, "ds2_conv1_fwd_bf16: null pointer");
   C1Args a{};
-  a.X16 = (const __bf16*)X16; a.wp = (const __bf16*)wp; a.bias = bias; a.lens = lens_dev; a.y = y1;
-  a.B = B; a.F = F; a.T = (Tin + 2 * PT - KTAPS) / 2 + 1; a.D1 = (F + 2 * PD - KD) / 2 + 1;
+  a.XB = (const __bf16*)XB; a.wp = (const __bf16*)wp; a.bias = bias; a.lens = lens_dev; a.y = y1;
+  a.B = B; a.F = F; a.T = (Tin + 2 * PT - KTAPS) / 2 + 1; a.D1 = (F + 2 * PD - KD) / 2 + 1; a.P = xb_pitch(a.T);
   static bool attr_set = false;
   if (!attr_set) {
     DS2_HIP(hipFuncSetAttribute((const void*)conv1_bf16_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
@@ -493,9 +529,9 @@ extern "C" int ds2_conv1_fwd_bf16_stats(const void* X16, const void* wp, const f
   return 0;
 }
 
-extern "C" int ds2_conv1_fwd_bf16(const void* X16, const void* wp, const float* bias, const int* lens_dev, float* y1, int B, int F, int Tin,
+extern "C" int ds2_conv1_fwd_bf16(const void* XB, const void* wp, const float* bias, const int* lens_dev, float* y1, int B, int F, int Tin,
                                   void* stream) {
-  return ds2_conv1_fwd_bf16_stats(X16, wp, bias, lens_dev, y1, B, F, Tin, nullptr, stream);
+  return ds2_conv1_fwd_bf16_stats(XB, wp, bias, lens_dev, y1, B, F, Tin, nullptr, stream);
 }
 
 extern "C" size_t ds2_conv1_wgrad_bf16_workspace_bytes(int B, int Tin) {

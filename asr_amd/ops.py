@@ -659,27 +659,28 @@ def conv1_pack_bf16(w1: Tensor) -> Tensor:
 
 
 def conv1_gather_bf16(x: Tensor, want_fwd: bool = True, want_wgrad: bool = True):
-    """x (B,1,F,Tin) fp32 -> (X16 (B,F,T,16) bf16 | None, X16T (B,F,16,pad64(T)) bf16 | None): conv1's operand images."""
+    """x (B,1,F,Tin) fp32 -> (XB (B,F,P) bf16 rows, XB[..., 7 + s] = x[..., s], zero padded | None, X16T (B,F,16,pad64(T)) bf16 | None):
+    conv1's forward / weight-gradient operand images."""
     _chk_f32(x)
     assert x.is_contiguous()
     lib = _lib.load()
     B, _, F, Tin = x.shape
     _, _, T = _lib.conv_dims(F, Tin)
-    X16 = torch.empty(lib.ds2_conv1_bf16_bytes(1, B, F, T) // 2, dtype=torch.bfloat16, device=x.device).view(B, F, T, 16) if want_fwd else None
+    XB = torch.empty(lib.ds2_conv1_bf16_bytes(1, B, F, T) // 2, dtype=torch.bfloat16, device=x.device).view(B, F, lib.ds2_conv1_bf16_row_pitch(T)) if want_fwd else None
     X16T = torch.empty(lib.ds2_conv1_bf16_bytes(2, B, F, T) // 2, dtype=torch.bfloat16, device=x.device).view(B, F, 16, -1) if want_wgrad else None
-    _lib.check(lib.ds2_conv1_gather_bf16(x.data_ptr(), _ptr(X16), _ptr(X16T), B, F, Tin, _stream()), "ds2_conv1_gather_bf16")
-    return X16, X16T
+    _lib.check(lib.ds2_conv1_gather_bf16(x.data_ptr(), _ptr(XB), _ptr(X16T), B, F, Tin, _stream()), "ds2_conv1_gather_bf16")
+    return XB, X16T
 
 
-def conv1_fwd_bf16(X16: Tensor, wp: Tensor, bias: Tensor, lens_dev: Tensor, Tin: int, stats: bool = False):
+def conv1_fwd_bf16(XB: Tensor, wp: Tensor, bias: Tensor, lens_dev: Tensor, Tin: int, stats: bool = False):
     """stats=True: also returns the per-block (sum, sum of squares) partials of y1's channels, taken in the epilogue (chanstats_from_partials)."""
-    B, F, T, _ = X16.shape
-    D1, _, T2 = _lib.conv_dims(F, Tin)
-    assert T2 == T
+    B, F, P = XB.shape
+    D1, _, T = _lib.conv_dims(F, Tin)
     lib = _lib.load()
-    y1 = torch.empty(B, 32, D1, T, dtype=torch.float32, device=X16.device)
-    part = torch.empty(lib.ds2_conv1_fwd_bf16_stat_blocks(B, F, Tin), 32, 2, dtype=torch.float32, device=X16.device) if stats else None
-    _lib.check(lib.ds2_conv1_fwd_bf16_stats(X16.data_ptr(), wp.data_ptr(), bias.data_ptr(), lens_dev.data_ptr(), y1.data_ptr(), B, F, Tin,
+    assert P == lib.ds2_conv1_bf16_row_pitch(T) and XB.is_contiguous()
+    y1 = torch.empty(B, 32, D1, T, dtype=torch.float32, device=XB.device)
+    part = torch.empty(lib.ds2_conv1_fwd_bf16_stat_blocks(B, F, Tin), 32, 2, dtype=torch.float32, device=XB.device) if stats else None
+    _lib.check(lib.ds2_conv1_fwd_bf16_stats(XB.data_ptr(), wp.data_ptr(), bias.data_ptr(), lens_dev.data_ptr(), y1.data_ptr(), B, F, Tin,
                                             _ptr(part), _stream()), "ds2_conv1_fwd_bf16")
     return (y1, part) if stats else y1
 

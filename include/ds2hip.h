@@ -334,18 +334,20 @@ int ds2_greedy_decode_f32(const float* probs, long long ld_b, long long ld_t, in
                           int* ids, int* offs, int* out_len, void* ws, size_t ws_bytes, void* stream);
 
 /* conv1 in bf16 mode (Conv2d(1,32,(41,11),s=(2,2),p=(20,5)), deepspeech.py:61, forward + weight gradient; conv1 has no data
- * gradient).  ds2_conv1_gather_bf16 builds the two bf16 operand images from one read of the spectrogram batch:
- * X16 (B,F,T,16) tap-contiguous for the forward, X16T (B,F,16,pad64(T)) time-contiguous for the weight gradient (either may be
- * NULL).  ds2_conv1_bf16_bytes(which = 0 packed weights | 1 X16 | 2 X16T, B, F, T) sizes the buffers. */
+ * gradient).  ds2_conv1_gather_bf16 builds the two bf16 operand images from the spectrogram batch: XB (B,F,P) = the rows themselves as
+ * bf16, XB[..][7 + s] = x[..][s] with zeros in front and behind (P = ds2_conv1_bf16_row_pitch(T)) for the forward — the 16 taps of an output
+ * step are 16 consecutive samples of a row — and X16T (B,F,16,pad64(T)) time-contiguous per tap for the weight gradient (either may be NULL).
+ * ds2_conv1_bf16_bytes(which = 0 packed weights | 1 XB | 2 X16T, B, F, T) sizes the buffers. */
+int ds2_conv1_bf16_row_pitch(int T);
 size_t ds2_conv1_bf16_bytes(int which, int B, int F, int T);
 int ds2_conv1_pack_bf16(const float* w1, void* wp, void* stream);
-int ds2_conv1_gather_bf16(const float* x, void* X16, void* X16T, int B, int F, int Tin, void* stream);
-int ds2_conv1_fwd_bf16(const void* X16, const void* wp, const float* bias, const int* lens_dev, float* y1, int B, int F, int Tin,
+int ds2_conv1_gather_bf16(const float* x, void* XB, void* X16T, int B, int F, int Tin, void* stream);
+int ds2_conv1_fwd_bf16(const void* XB, const void* wp, const float* bias, const int* lens_dev, float* y1, int B, int F, int Tin,
                        void* stream);
 /* ... with the BatchNorm2d statistics of y1 taken in the epilogue: stat_part = ds2_conv1_fwd_bf16_stat_blocks() x 32 x 2 floats of per-block
  * (sum, sum of squares) per channel; ds2_chanstats_from_partials turns them into mean / biased var (+ running stats) - no pass over y1 */
 int ds2_conv1_fwd_bf16_stat_blocks(int B, int F, int Tin);
-int ds2_conv1_fwd_bf16_stats(const void* X16, const void* wp, const float* bias, const int* lens_dev, float* y1, int B, int F, int Tin,
+int ds2_conv1_fwd_bf16_stats(const void* XB, const void* wp, const float* bias, const int* lens_dev, float* y1, int B, int F, int Tin,
                              float* stat_part, void* stream);
 size_t ds2_conv1_wgrad_bf16_workspace_bytes(int B, int Tin);
 int ds2_conv1_wgrad_bf16(const void* X16T, const float* dy1, const int* lens_dev, float* dW1, int B, int F, int Tin, void* ws,
