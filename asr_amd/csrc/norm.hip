@@ -12,10 +12,16 @@
 
 namespace {
 
+// (rows that are only 4-byte aligned — T = 501-style lengths — still move as ONE dword-aligned dwordx4 per lane: the hardware takes it, the
+// aligned(4) vector type says so to the compiler; rounds 1-4 fell back to four scalar accesses there)
+typedef float f32x4_dw __attribute__((ext_vector_type(4), aligned(4)));
 __device__ __forceinline__ f32x4 ld4(const float* __restrict__ p, int valid, bool vec) {
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
   if (valid >= 4 && vec) {
     v = *reinterpret_cast<const f32x4*>(p);
+  } else if (valid >= 4) {
+    const f32x4_dw q = *reinterpret_cast<const f32x4_dw*>(p);
+    v.x = q.x; v.y = q.y; v.z = q.z; v.w = q.w;
   } else {
     if (valid > 0) v.x = p[0];
     if (valid > 1) v.y = p[1];
@@ -27,6 +33,8 @@ __device__ __forceinline__ f32x4 ld4(const float* __restrict__ p, int valid, boo
 __device__ __forceinline__ void st4(float* __restrict__ p, f32x4 v, int valid, bool vec) {
   if (valid >= 4 && vec) {
     *reinterpret_cast<f32x4*>(p) = v;
+  } else if (valid >= 4) {
+    *reinterpret_cast<f32x4_dw*>(p) = f32x4_dw{v.x, v.y, v.z, v.w};
   } else {
     if (valid > 0) p[0] = v.x;
     if (valid > 1) p[1] = v.y;
