@@ -20,11 +20,13 @@
 //            fp32 on the fly; 21 accumulator tiles of 32 columns (= 2 kernel rows x 16 taps) over 4 waves; ordered reduction
 //            of the per-block partials afterwards (deterministic).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4_c1 __attribute__((ext_vector_type(4), aligned(4)));     // a dword-aligned dwordx4 access
 
 constexpr int KD = 41, KTAPS = 11, PD = 20, PT = 5, CO = 32, NC = 16;
 
@@ -53,11 +55,23 @@ __global__ __launch_bounds__(256) void conv1_gather_kernel(const float* __restri
     const long long row = i / octs;
     const int t0 = (int)(i % octs) * 8;
     const float* xr = x + row * Tin;
+    // 25 consecutive samples from 2 t0 - 5 on: six dword-aligned dwordx4 loads + one (the run starts at an odd sample: 4-byte aligned
+    // only; round 2-4: 25 scalar loads per thread), element-wise at the row's ends
     float v[25];
+    const int s0 = 2 * t0 - PT;
+    if (s0 >= 0 && s0 + 25 <= Tin) {
 #pragma unroll
-    for (int j = 0; j < 25; ++j) {
-      const int ti = 2 * t0 - PT + j;
-      v[j] = (ti >= 0 && ti < Tin) ? xr[ti] : 0.f;
+      for (int q = 0; q < 6; ++q) {
+        const f32x4_c1 w = *reinterpret_cast<const f32x4_c1*>(xr + s0 + 4 * q);
+        v[4 * q] = w.x; v[4 * q + 1] = w.y; v[4 * q + 2] = w.z; v[4 * q + 3] = w.w;
+      }
+      v[24] = xr[s0 + 24];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 25; ++j) {
+        const int ti = s0 + j;
+        v[j] = (ti >= 0 && ti < Tin) ? xr[ti] : 0.f;
+      }
     }
     // pixel (t0 + e), tap c  <-  v[2e + c]
     if (X16) {
@@ -99,10 +113,16 @@ __global__ __launch_bounds__(256) void conv1_rows_kernel(const float* __restrict
     const int k0 = (int)(i % oct) * 8;
     const float* xr = x + row * Tin;
     bf16x8 o;
+    const int sb = k0 - XB_LEFT;
+    if (sb >= 0 && sb + 8 <= Tin) {                         // two dword-aligned dwordx4 loads
+      const f32x4_c1 w0 = *reinterpret_cast<const f32x4_c1*>(xr + sb), w1 = *reinterpret_cast<const f32x4_c1*>(xr + sb + 4);
+      o = bf16x8{(__bf16)w0.x, (__bf16)w0.y, (__bf16)w0.z, (__bf16)w0.w, (__bf16)w1.x, (__bf16)w1.y, (__bf16)w1.z, (__bf16)w1.w};
+    } else {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int sidx = k0 + j - XB_LEFT;
-      o[j] = (sidx >= 0 && sidx < Tin) ? (__bf16)xr[sidx] : (__bf16)0.f;
+      for (int j = 0; j < 8; ++j) {
+        const int sidx = sb + j;
+        o[j] = (sidx >= 0 && sidx < Tin) ? (__bf16)xr[sidx] : (__bf16)0.f;
+      }
     }
     *reinterpret_cast<bf16x8*>(XB + row * P + k0) = o;
   }
@@ -344,16 +364,24 @@ __global__ __launch_bounds__(256) void conv1_bf16_wgrad_kernel(C1WArgs a) {
     const char* dy_b = reinterpret_cast<const char*>(a.dy + (long long)b * CO * a.D1 * a.T);
     const char* x_b = reinterpret_cast<const char*>(a.X16T + (long long)b * a.F * NC * a.Tp);
     const int nrow_u = __builtin_amdgcn_readfirstlane(nrow);
-    auto fetch = [&](int o, Regs& r) {
+    // a time tile that lies completely inside T (all but the last one): a thread's four steps of a dY row are one dword-aligned dwordx4
+    const bool full_tile = t0 + W_TT <= a.T;                                         // block-uniform
+    auto fetch = [&](int o, Regs& r, auto full_c) {
       const int f = 2 * o - 1 + PD + nrow_u;                                       // wave-uniform (>= 0)
       const bool ok = f < a.F;
       const char* xs = ok ? x_b + (long long)f * NC * a.Tp * 2 - (long long)nrow_u * NC * a.Tp * 2 : reinterpret_cast<const char*>(g_zero_c1);
       r.nr = *reinterpret_cast<const u32x4*>(xs + (ok ? rowoff : 0u));
       const char* ds_ = dy_b + (long long)min(o, a.D1 - 1) * a.T * 4;
-      r.d0 = f32x4{*reinterpret_cast<const float*>(ds_ + dyoff[0][0]), *reinterpret_cast<const float*>(ds_ + dyoff[0][1]),
-                   *reinterpret_cast<const float*>(ds_ + dyoff[0][2]), *reinterpret_cast<const float*>(ds_ + dyoff[0][3])};
-      r.d1 = f32x4{*reinterpret_cast<const float*>(ds_ + dyoff[1][0]), *reinterpret_cast<const float*>(ds_ + dyoff[1][1]),
-                   *reinterpret_cast<const float*>(ds_ + dyoff[1][2]), *reinterpret_cast<const float*>(ds_ + dyoff[1][3])};
+      if constexpr (decltype(full_c)::value) {
+        const f32x4_c1 q0 = *reinterpret_cast<const f32x4_c1*>(ds_ + dyoff[0][0]), q1 = *reinterpret_cast<const f32x4_c1*>(ds_ + dyoff[1][0]);
+        r.d0 = f32x4{q0.x, q0.y, q0.z, q0.w};
+        r.d1 = f32x4{q1.x, q1.y, q1.z, q1.w};
+      } else {
+        r.d0 = f32x4{*reinterpret_cast<const float*>(ds_ + dyoff[0][0]), *reinterpret_cast<const float*>(ds_ + dyoff[0][1]),
+                     *reinterpret_cast<const float*>(ds_ + dyoff[0][2]), *reinterpret_cast<const float*>(ds_ + dyoff[0][3])};
+        r.d1 = f32x4{*reinterpret_cast<const float*>(ds_ + dyoff[1][0]), *reinterpret_cast<const float*>(ds_ + dyoff[1][1]),
+                     *reinterpret_cast<const float*>(ds_ + dyoff[1][2]), *reinterpret_cast<const float*>(ds_ + dyoff[1][3])};
+      }
     };
     auto publish = [&](int o, const Regs& r) {           // R(o) -> ring slots outside the window of step o - 1, dY buffer o & 1
       if (o < a.D1) {
@@ -398,28 +426,32 @@ __global__ __launch_bounds__(256) void conv1_bf16_wgrad_kernel(C1WArgs a) {
     // W_PF register sets: R(o + W_PF) is requested during step o and published at the end of step o + W_PF - 1.  With two sets (round 4) a
     // step could not be shorter than half an HBM round trip — one block per CU (113 KB of LDS), nothing else resident to hide it: 1.8 us per
     // step against 0.35 us of MFMAs (four sets: 1.57, profiles/r05_conv1_wgrad.txt).
-    Regs rs[W_PF];
+    auto run = [&](auto full_c) {                        // (two copies of the loop: the number of loads per step is static in each)
+      Regs rs[W_PF];
 #pragma unroll
-    for (int k = 1; k < W_PF; ++k) fetch(k, rs[k]);
-    __syncthreads();
-    C1T_DECL;
-    C1T(0);
-    for (int o = 0; o < a.D1; o += W_PF) {
+      for (int k = 1; k < W_PF; ++k) fetch(k, rs[k], full_c);
+      __syncthreads();
+      C1T_DECL;
+      C1T(0);
+      for (int o = 0; o < a.D1; o += W_PF) {
 #pragma unroll
-      for (int k = 0; k < W_PF; ++k) {
-        if (o + k < a.D1) {                              // (block-uniform)
-          fetch(o + k + W_PF, rs[k]);
-          C1T(1);
-          compute(o + k);
-          C1T(2);
-          publish(o + k + 1, rs[(k + 1) % W_PF]);
-          C1T(3);
-          __syncthreads();
-          C1T(4);
+        for (int k = 0; k < W_PF; ++k) {
+          if (o + k < a.D1) {                            // (block-uniform)
+            fetch(o + k + W_PF, rs[k], full_c);
+            C1T(1);
+            compute(o + k);
+            C1T(2);
+            publish(o + k + 1, rs[(k + 1) % W_PF]);
+            C1T(3);
+            __syncthreads();
+            C1T(4);
+          }
         }
       }
-    }
-    C1T_DUMP(4096 + (long long)blockIdx.y * gridDim.x + blockIdx.x);
+      C1T_DUMP(4096 + (long long)blockIdx.y * gridDim.x + blockIdx.x);
+    };
+    if (full_tile) run(std::true_type{});
+    else run(std::false_type{});
   }
 #pragma unroll
   for (int i = 0; i < W_TPW; ++i) {
