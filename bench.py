@@ -459,13 +459,24 @@ def dp_path_one_rank_worker(dev, steps=5, warmup=3):
     import socket
     if dist.is_initialized():
         return {"error": "a process group already exists"}
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    import random
     old = {k: os.environ.get(k) for k in ("MASTER_ADDR", "MASTER_PORT", "DS2_FORCE_ALLREDUCE", "DS2_DP_MODE")}
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DS2_FORCE_ALLREDUCE="1", DS2_DP_MODE="conv")
+    os.environ.update(MASTER_ADDR="127.0.0.1", DS2_FORCE_ALLREDUCE="1", DS2_DP_MODE="conv")
     try:
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        for attempt in range(4):                             # (a probed port can be taken before the store binds it: retry on another one)
+            port = random.randint(20000, 31999)
+            with socket.socket() as sk:
+                try:
+                    sk.bind(("127.0.0.1", port))
+                except OSError:
+                    continue
+            os.environ["MASTER_PORT"] = str(port)
+            try:
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+                break
+            except Exception as e:
+                if attempt == 3 or not ("EADDRINUSE" in str(e) or "address already in use" in str(e).lower()):
+                    raise
         tr, batches, (rnn, H, L, C, B, tin) = _make_trainer("c3", "bf16", dev)
         bx, bt, bp, bs = batches[0]
         for _ in range(warmup):
@@ -506,12 +517,33 @@ def spawn_ranks(n):
     have = torch.cuda.device_count()
     if have < n and "--ranks-on-one-gpu" not in sys.argv:
         sys.exit(f"bench.py: --gpus {n} requested but this node exposes {have} GPU(s); refusing to run (a scaling point must use {n} devices)")
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return sys.exit(subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")).returncode)
+    import random
+    rc = 1
+    for attempt in range(4):
+        # a port that binds NOW, taken from below the ephemeral range (a probe of port 0 hands out a port the kernel may give to any outgoing
+        # connection before the launcher's store binds it: seen once as EADDRINUSE); if the launcher still loses the race, try another port
+        port = None
+        for _ in range(64):
+            cand = random.randint(20000, 31999)
+            with socket.socket() as sk:
+                try:
+                    sk.bind(("127.0.0.1", cand))
+                    port = cand
+                    break
+                except OSError:
+                    continue
+        if port is None:
+            sys.exit("bench.py: no free rendezvous port found on 127.0.0.1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        r = subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), stderr=subprocess.PIPE, text=True)
+        rc = r.returncode
+        in_use = rc != 0 and ("EADDRINUSE" in r.stderr or "address already in use" in r.stderr.lower())
+        if not in_use or attempt == 3:
+            sys.stderr.write(r.stderr)
+            break
+        sys.stderr.write(f"bench.py: rendezvous port {port} was taken between probe and bind, retrying with another one\n")
+    return sys.exit(rc)
 
 
 def main():
