@@ -618,7 +618,7 @@ struct TnSProb {
 };
 struct TnSGroup {
   TnSProb p[TN_MAX_PROBLEMS];
-  int nprob, splitk, nitems;
+  int nprob, splitk, nitems, order;
 };
 
 template <bool GROUPED>
@@ -1291,6 +1291,8 @@ extern "C" int ds2_gemm_bf16_tn_splitk_group(int nprob, const ds2_tn_problem* pr
   }
   for (int i = nprob; i < TN_MAX_PROBLEMS; ++i) { g.p[i] = g.p[0]; g.p[i].nslab = 0; }
   g.nprob = nprob; g.splitk = splitk; g.nitems = items;
+  static const char* ord_env = ds2_exp_getenv("DS2_TN_ORDER");
+  g.order = !(ord_env && ord_env[0] == '0');
   if (any_slab) DS2_REQUIRE(workspace && workspace_bytes >= off, "ds2_gemm_bf16_tn_splitk_group: workspace too small");
   static bool attr_set = false;
   if (!attr_set) {

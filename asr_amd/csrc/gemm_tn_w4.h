@@ -1,7 +1,8 @@
 // Grouped split-K TN bf16 GEMM (the weight-gradient products of one recurrent layer in one launch), FOUR waves x 128 x 128 per 256 x 256 x 64
 // k-tile, accumulators in AGPRs: the four-wave schedule of gemm_nt_w4.h on the TN kernel's K-row-major LDS image.   (included by gemm_bf16.hip)
 //
-//   item        blockIdx.x = (problem, K slice, 256 x 256 tile) exactly as gemm_bf16_tn_glds_kernel<true>; every k-tile of every slice is full
+//   item        (problem, K slice, 256 x 256 tile, row-major) as gemm_bf16_tn_glds_kernel<true>, but handed to the workgroups in XCD-sized runs of
+//               32 consecutive items (below); every k-tile of every slice is full
 //               (the launcher takes this kernel only when every K is a multiple of 64)
 //   LDS         [2 buffers][A | B], an operand tile = 64 k-rows x 512 B (256 columns); one DMA instruction lands 2 k-rows (1 KiB): wave w moves
 //               pieces w, w + 4, ..., w + 28 of A and of B
@@ -22,7 +23,19 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_w4_kernel(TnSGroup grp) {
   float* Cfinal; float* Cslab; long long ldcf;
   bool partial;
   {
-    const int item = blockIdx.x;
+    // blockIdx.x -> item: workgroup ids go round the 8 XCDs, one workgroup per CU, so the 32 workgroups an XCD holds at a time are the ids
+    // 256 c + x + 8 j.  They take 32 CONSECUTIVE items = (with at most 8 column tiles) a few whole tile rows of one K slice, which share their
+    // A / B panels through that XCD's L2: 12 panels for 64 panel reads at 4 column tiles.
+    int item = blockIdx.x;
+    if (grp.order) {
+      const int full = grp.nitems & ~255;
+      if (item < full) {
+        item = (item & ~255) + ((item & 7) << 5) + ((item & 255) >> 3);
+      } else {
+        const int R = grp.nitems - full, o = item - full, x = o & 7, q8 = R >> 3, r8 = R & 7;
+        item = full + (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + (o >> 3);
+      }
+    }
     A = grp.p[0].A; B = grp.p[0].B; Cfinal = grp.p[0].C; Cslab = grp.p[0].partial;
     pM = grp.p[0].M; pN = grp.p[0].N; pK = grp.p[0].K; plda = grp.p[0].lda; pldb = grp.p[0].ldb; ldcf = grp.p[0].ldc; ntx = grp.p[0].ntx;
     nt = grp.p[0].ntiles; kchunk = grp.p[0].kchunk;
@@ -39,8 +52,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_w4_kernel(TnSGroup grp) {
     partial = to_slab != 0;
     Cslab += (long long)(slab0 + zs) * pM * pN;
   }
-  const int xcd = orig & 7, q8 = nt >> 3, r8 = nt & 7;
-  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  int tile = orig;
+  if (!grp.order) {                                      // DS2_TN_ORDER=0 (A/B): each XCD a contiguous run of every slice's tiles
+    const int xcd = orig & 7, q8 = nt >> 3, r8 = nt & 7;
+    tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  }
   const int m0 = (tile / ntx) * 256, n0 = (tile % ntx) * 256;
   const int kbeg = zs * kchunk;
   const int kend = min(pK, kbeg + kchunk);

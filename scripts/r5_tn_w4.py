@@ -52,27 +52,42 @@ def child(mode):
         del probs, dwih, dwhh
     print(repr(out))
 
-if len(sys.argv) > 2 and sys.argv[1] == "child":
-    child(sys.argv[2]); sys.exit(0)
-mode = sys.argv[1] if len(sys.argv) > 1 else "check"
-def run(w4):
-    env = dict(os.environ, DS2_GEMM_W4=w4, DS2_EXPERIMENTAL="1")
-    r = subprocess.run([sys.executable, __file__, "child", mode], env=env, capture_output=True, text=True)
-    if r.returncode != 0: print(r.stdout[-2000:], r.stderr[-3000:]); sys.exit(1)
-    return eval(r.stdout.strip().splitlines()[-1])
-if mode == "check":
-    a, b = run("0"), run("1")
-    ok = True
-    for k in a:
-        same = a[k][1] == b[k][1]
-        ok &= same and b[k][0] < 1e-5
-        print(f"{k:12s} 8-wave err {a[k][0]:.2e}  4-wave err {b[k][0]:.2e}  bit-identical checksums: {same}")
-    print("TN W4 CHECK", "PASS" if ok else "FAIL")
-else:
-    res = {"0": [], "1": []}
-    for rep in range(3):
-        for v in ("0", "1"): res[v].append(run(v))
-    for k in res["0"][0]:
-        t0 = sorted(r[k][0] for r in res["0"])[1]; t1 = sorted(r[k][0] for r in res["1"])[1]
-        f0 = sorted(r[k][1] for r in res["0"])[1]; f1 = sorted(r[k][1] for r in res["1"])[1]
-        print(f"{k:12s} 8-wave {t0:7.1f} us ({f0:5.0f} TF/s)   4-wave {t1:7.1f} us ({f1:5.0f} TF/s)  x{t1 / t0:.3f}   (GEMM + reduce launch)")
+def main():
+    global mode
+    if len(sys.argv) > 2 and sys.argv[1] == "child":
+        child(sys.argv[2]); sys.exit(0)
+    mode = sys.argv[1] if len(sys.argv) > 1 else "check"
+    def run(w4, order="1", child_mode=None):
+        env = dict(os.environ, DS2_GEMM_W4=w4, DS2_TN_ORDER=order, DS2_EXPERIMENTAL="1")
+        r = subprocess.run([sys.executable, __file__, "child", child_mode or mode], env=env, capture_output=True, text=True)
+        if r.returncode != 0: print(r.stdout[-2000:], r.stderr[-3000:]); sys.exit(1)
+        return eval(r.stdout.strip().splitlines()[-1])
+    if mode == "check":
+        a, b = run("0"), run("1")
+        ok = True
+        for k in a:
+            same = a[k][1] == b[k][1]
+            ok &= same and b[k][0] < 1e-5
+            print(f"{k:12s} 8-wave err {a[k][0]:.2e}  4-wave err {b[k][0]:.2e}  bit-identical checksums: {same}")
+        print("TN W4 CHECK", "PASS" if ok else "FAIL")
+    elif mode == "order":
+        # item order of the four-wave kernel: XCD runs of 32 consecutive items (default) against DS2_TN_ORDER=0 (a contiguous run of every slice per XCD)
+        a, b = run("1", "0", "check"), run("1", "1", "check")
+        print("bit-identical checksums across orders:", all(a[k][1] == b[k][1] for k in a))
+        res = {"0": [], "1": []}
+        for rep in range(3):
+            for v in ("0", "1"): res[v].append(run("1", v, "time"))
+        for k in res["0"][0]:
+            t0 = sorted(r[k][0] for r in res["0"])[1]; t1 = sorted(r[k][0] for r in res["1"])[1]
+            print(f"{k:12s} per-slice order {t0:7.1f} us   XCD runs of 32 {t1:7.1f} us  x{t1 / t0:.3f}   (GEMM + reduce launch)")
+    else:
+        res = {"0": [], "1": []}
+        for rep in range(3):
+            for v in ("0", "1"): res[v].append(run(v))
+        for k in res["0"][0]:
+            t0 = sorted(r[k][0] for r in res["0"])[1]; t1 = sorted(r[k][0] for r in res["1"])[1]
+            f0 = sorted(r[k][1] for r in res["0"])[1]; f1 = sorted(r[k][1] for r in res["1"])[1]
+            print(f"{k:12s} 8-wave {t0:7.1f} us ({f0:5.0f} TF/s)   4-wave {t1:7.1f} us ({f1:5.0f} TF/s)  x{t1 / t0:.3f}   (GEMM + reduce launch)")
+
+if __name__ == "__main__":
+    main()
