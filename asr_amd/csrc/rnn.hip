@@ -620,6 +620,7 @@ __device__ __forceinline__ PRole persist_role(const RnnArgs& a, unsigned* census
 // lo plane of every exchange buffer (4 bytes per element, as the fp32 exchange), and a chunk's product is hi.hi + lo.hi + hi.lo — three
 // 16x16x32 bf16 MFMAs (48 cycles) where the fp32 path issues eight 16x16x4 fp32 MFMAs (256 cycles) for the same 32 k.  Everything else
 // (state, gate math, outputs, protocol) is the BF = true data path; results are within ~1e-6 of the fp32 kernels', not bit-identical to them.
+typedef float f32x2r __attribute__((ext_vector_type(2)));
 template <int G, int MB, int NS, int NCW, bool BF, bool SP = false>
 __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, char* xbuf, unsigned* census, int spin_limit) {
   static_assert(MB * NS * 256 <= NW * 64, "one (row, unit) pair per thread");
@@ -669,6 +670,13 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
   const int b = b0 + mb * 16 + brow, j = j0 + ns * 16 + jl;
   const bool pact = (sub < MB * NS) && b < B && j < H;
   const int src_lane = (brow >> 2) * 16 + jl, reg = brow & 3;
+  // The gate math reads ONE dword of an accumulator vector: lane 16 r + jl of a wave wants dword 4 jl + r of its 64-vector row.  The LDS serves
+  // a dword read 32 lanes at a time from 32 banks, and 4 jl + r hits every bank twice (jl and jl + 8) — 2 of the 4 cycles of each of the 24 reads
+  // per thread and step were bank conflicts, 384 clocks per CU and step (SQ_LDS_BANK_CONFLICT, scripts/probe_lds_pair.hip).  Writer lanes with
+  // bit 3 set therefore store their vector rotated by two dwords: unit jl + 8 then sits in banks 4 jl + ((r + 2) & 3), which nobody else in its
+  // half-wave reads.
+  const int red_sw = (lane >> 3) & 1;
+  const int red_reg = (reg + 2 * ((jl >> 3) & 1)) & 3;
   const int plen = pact ? a.lens[b] : 0;
   float pb[G];
 #pragma unroll
@@ -839,7 +847,12 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
-      for (int g = 0; g < NS * G; ++g) red[s & 1][wave][i * NS * G + g][lane] = acc[i][g];
+      for (int g = 0; g < NS * G; ++g) {
+        // (two 8-byte halves, swapped in the lanes with bit 3 set: see red_reg below)
+        float* rp = reinterpret_cast<float*>(&red[s & 1][wave][i * NS * G + g][lane]);
+        *reinterpret_cast<f32x2r*>(rp + 2 * red_sw) = f32x2r{acc[i][g][0], acc[i][g][1]};
+        *reinterpret_cast<f32x2r*>(rp + 2 - 2 * red_sw) = f32x2r{acc[i][g][2], acc[i][g][3]};
+      }
     PTRACE(2);                                          // HBM section + MFMAs issued, partial sums written
     __syncthreads();
     PTRACE(3);                                          // barrier passed
@@ -853,7 +866,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
       for (int g = 0; g < G; ++g) {
         float sum = 0.f;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) sum += red[s & 1][w][sub * G + g][src_lane][reg];
+        for (int w = 0; w < NW; ++w) sum += red[s & 1][w][sub * G + g][src_lane][red_reg];
         gh[g] = sum + pb[g];
       }
       if constexpr (G == 3) {
@@ -1139,6 +1152,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_persistent_kernel(RnnArgs a, 
   const bool pair = sub < MB * NS;
   const bool pact = pair && b < B && j < H;
   const int src_lane = (brow >> 2) * 16 + jl, reg = brow & 3;
+  const int red_sw = (lane >> 3) & 1, red_reg = (reg + 2 * ((jl >> 3) & 1)) & 3;      // conflict-free dword reads of the partial sums (see forward)
   const int plen = pact ? a.lens[b] : 0;
   const __bf16* gates_bf = a.gates_bf;
   float dcar = 0.f;                                                           // GRU dh*z / LSTM dc*f of the step before (own pair)
@@ -1297,7 +1311,11 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_persistent_kernel(RnnArgs a, 
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
-      for (int n = 0; n < NS; ++n) red[s & 1][wave][i * NS + n][lane] = acc[i][n];
+      for (int n = 0; n < NS; ++n) {                      // (halves swapped in the lanes with bit 3 set: rnn_fwd_persistent_kernel's red_reg)
+        float* rp = reinterpret_cast<float*>(&red[s & 1][wave][i * NS + n][lane]);
+        *reinterpret_cast<f32x2r*>(rp + 2 * red_sw) = f32x2r{acc[i][n][0], acc[i][n][1]};
+        *reinterpret_cast<f32x2r*>(rp + 2 - 2 * red_sw) = f32x2r{acc[i][n][2], acc[i][n][3]};
+      }
     PTRACE(2);
     __syncthreads();
     PTRACE(3);
@@ -1308,7 +1326,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_persistent_kernel(RnnArgs a, 
     if (pact && t < plen) {
       float carry = 0.f;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) carry += red[s & 1][w][sub][src_lane][reg];
+      for (int w = 0; w < NW; ++w) carry += red[s & 1][w][sub][src_lane][red_reg];
       if constexpr (G == 3) {
         const float dh = cur.dy + carry + dcar;
         float dpn;

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char
   constexpr int NPL = SP ? 2 : 1;
   static_assert(NW == 8 && NT >= 2 && (NT % 2) == 0, "8 waves: wave w owns output columns [w*H/8, (w+1)*H/8) = NT 16-column tiles");
   constexpr int NL = NT / 2;                                  // 1 KB wave loads per gather = producers / 8 = tile pairs per wave
-  constexpr int AST = 40;                                     // bf16 per staged row (80 B pitch: conflict-free ds_read_b128)
+  constexpr int AST = 48;                                     // bf16 per staged row: 96 B pitch — the operand read (row = lane & 15, 16-byte chunk lane >> 4) is conflict-free under ds_read_b128's lane groups (80 B was not: 4 of its 8 cycles, scripts/probe_lds_pair.hip)
   // planes 0..G-1: dGh gate by gate (the MFMA operand); GRU plane 3: d(pre-activation of n) = the n column of dGx.  Double-buffered: ONE barrier per step
   __shared__ __attribute__((aligned(16))) __bf16 As[NPL][2][4][16][AST];
   const PRole role = persist_role(a, census, spin_limit, 2);
