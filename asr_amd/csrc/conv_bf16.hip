@@ -618,7 +618,7 @@ __global__ __launch_bounds__(256) void padcast_kernel(const float* __restrict__ 
 // read covers 4 consecutive rows = 256 contiguous bytes = every bank once, no swizzle.  K runs over the OUTPUT time of a 128-step segment
 // (no halo steps multiplied: 8 k-steps of 16, against 5 for 64 outputs above); the A1 rows are staged with 8 halo steps on either side.
 // block = (group of 3 kernel rows, chunk of (b,o) pairs) as above — but all 7 groups of a chunk on ONE XCD and the chunk walked segment-major
-// (L2 hit rate 10 -> 79 %, 1.1 GB -> 0.21 GB of fabric reads per launch): 4 waves split the 11 time taps, 9 accumulators per wave live in registers
+// (L2 hit rate 10 -> 79 %, 2.2 GB -> 0.43 GB of fabric reads per launch): 4 waves split the 11 time taps, 9 accumulators per wave live in registers
 // across the chunk; per k-step one dY fragment feeds all 9 MFMAs of the wave, each (kernel row, tap) has its own A1 fragment.
 // Segments are double-buffered: the DMA of segment i+1 is issued behind the barrier that ends segment i-1's reads.
 // Same partial layout as above (ordered reduction by conv2_wgrad_bf16_reduce_kernel: deterministic).

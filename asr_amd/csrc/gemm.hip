@@ -14,6 +14,7 @@
 // are unit-stride ds_read_b32 — conflict-free.  Global loads for tile kt+1 are in flight while
 // tile kt is multiplied (2 LDS buffers, one barrier per K-tile).
 #include "common.h"
+#include "permlane.h"
 
 namespace {
 
@@ -225,6 +226,89 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g, int vecA, int
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Skinny NT product C[M, N <= 32] = A[M, K] B[N, K]^T (+ bias): the fc layer's logits (nn.Linear 1024 -> 29 classes, deepspeech.py:105).
+// The 128 x 128 tile above runs it at one k-tile of 16 per ~1.45 us (a load -> LDS -> barrier chain with one tile in flight, two of the four
+// waves without a column to compute): 93 us for 131 MB of A.  Here a wave owns 32 rows for the whole K:
+//   B          all of it in LDS as Bs[k][32] (zero columns past N): lane (n, h) reads Bs[2 j + h][n] for MFMA j — one contiguous 256 B per wave
+//   A          straight from global into the MFMA layout: lane (m = lane & 31, h = lane >> 5) loads A[m][8 c + 4 h .. + 3]; two
+//              v_permlane32_swap turn the lower half's (k0 k1 k2 k3) and the upper half's (k4 .. k7) into the four operand registers
+//              [k0 | k1], [k2 | k3], [k4 | k5], [k6 | k7] (lower | upper lanes); 16 such loads in flight per lane
+//   arithmetic the same v_mfma_f32_32x32x2_f32 chain in the same k order as gemm_f32_kernel (one accumulator per element, k ascending, even k
+//              from the lower lanes): BIT-IDENTICAL results
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int SK_INFLIGHT = 16;
+__global__ __launch_bounds__(256) void gemm_f32_skinny_nt_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                                 float* __restrict__ C, int ldc, const float* __restrict__ bias, int M, int N,
+                                                                 int K) {
+  extern __shared__ __attribute__((aligned(16))) float Bs[];     // [K][32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r0 = blockIdx.x * 128 + wave * 32;
+  const bool rows = r0 < M;                                       // (wave-uniform; a wave without rows still helps to fill Bs)
+  const int m = lane & 31, h = lane >> 5;
+  const float* pa = A + (long long)min(r0 + m, M - 1) * lda + 4 * h;
+  const float* pb = Bs + h * 32 + m;
+  const int nc = K >> 3;                                          // K % 128 == 0: whole groups of SK_INFLIGHT chunks, no tail
+  // The A stream is issued and awaited by hand (left to itself the compiler rotates the registers and waits for each load right behind its
+  // issue): the loads return in order, so when chunk i is due at most SK_INFLIGHT - 1 younger loads are outstanding — vmcnt(15); the register
+  // set of a chunk is re-loaded (16 chunks ahead) behind its four MFMAs.  Behind the last group the re-loads repeat its chunks.  The first
+  // group goes out BEFORE the B fill: HBM latency and the fill's L2 round trips overlap.
+  f32x4 q[SK_INFLIGHT];
+#pragma unroll
+  for (int i = 0; i < SK_INFLIGHT; ++i) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(q[i]) : "v"(pa + 8 * i) : "memory");
+  {
+    const int n = tid & 31, kq = tid >> 5;                        // 8 k-quads per pass, 8 passes in flight
+    for (int k0 = kq * 4; k0 < K; k0 += 256) {
+      f32x4 w[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k4 = k0 + 32 * j;
+        w[j] = (n < N && k4 < K) ? *reinterpret_cast<const f32x4*>(B + (long long)n * ldb + k4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k4 = k0 + 32 * j;
+        if (k4 < K) { Bs[(k4 + 0) * 32 + n] = w[j].x; Bs[(k4 + 1) * 32 + n] = w[j].y; Bs[(k4 + 2) * 32 + n] = w[j].z; Bs[(k4 + 3) * 32 + n] = w[j].w; }
+      }
+    }
+  }
+  __syncthreads();
+  if (!rows) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float bc[4] = {pb[0], pb[64], pb[128], pb[192]};
+  for (int c0 = 0; c0 < nc; c0 += SK_INFLIGHT) {
+    const float* pn = pa + 8 * (c0 + SK_INFLIGHT < nc ? c0 + SK_INFLIGHT : c0);
+    const float* b = pb + c0 * 256;                               // 8 k-rows of 32 per chunk
+#pragma unroll
+    for (int i = 0; i < SK_INFLIGHT; ++i) {
+      // B values of the NEXT chunk (the last chunk of all re-reads itself): requested before this chunk's MFMAs
+      const float* bn = b + ((c0 + i + 1 < nc) ? (i + 1) * 256 : i * 256);
+      const float bn0 = bn[0], bn1 = bn[64], bn2 = bn[128], bn3 = bn[192];
+      asm volatile("s_waitcnt vmcnt(15)" : "+v"(q[i]) : : "memory");
+      const u32pair xy = permlane32_swap(q[i].x, q[i].y);         // a = [k0 | k1], b = [k4 | k5]
+      const u32pair zw = permlane32_swap(q[i].z, q[i].w);         // a = [k2 | k3], b = [k6 | k7]
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xy.a, bc[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(zw.a, bc[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xy.b, bc[2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(zw.b, bc[3], acc, 0, 0, 0);
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(q[i]) : "v"(pn + 8 * i) : "memory");
+      bc[0] = bn0; bc[1] = bn1; bc[2] = bn2; bc[3] = bn3;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // (the trailing re-loads: nothing may land in a register that has been re-used)
+  // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  if (m < N) {
+    const float bv = bias ? bias[m] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = r0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (row < M) C[(long long)row * ldc + m] = acc[r] + bv;
+    }
+  }
+}
+
 // ordered (deterministic) reduction of split-K partials
 __global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ C, const float* __restrict__ bias,
                                      int M, int N, int ldc, long long sC, int splitk, int accumulate) {
@@ -271,6 +355,19 @@ extern "C" int ds2_gemm_f32(int transA, int transB, int M, int N, int K, const f
   const int vecB = ((ldb % 4) == 0) && (((uintptr_t)B % 16) == 0) && ((strideB % 4) == 0);
   dim3 grid(ceil_div(N, BN), ceil_div(M, BM), batch * splitk), block(256);
   hipStream_t s = (hipStream_t)stream;
+  // skinny NT (the fc logits): gemm_f32_skinny_nt_kernel, bit-identical to the tile kernel.  DS2_GEMM_SKINNY=0: the tile kernel (A/B switch)
+  static const char* skinny_env = ds2_exp_getenv("DS2_GEMM_SKINNY");
+  if (!transA && transB && N <= 32 && M >= 1024 && K >= 128 && (K % 128) == 0 && (size_t)K * 128 <= 160 * 1024 && batch == 1 && splitk == 1 && !accumulate &&
+      vecA && vecB && !(skinny_env && skinny_env[0] == '0')) {
+    static bool attr = false;
+    if (!attr) {
+      DS2_HIP(hipFuncSetAttribute((const void*)gemm_f32_skinny_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr = true;
+    }
+    hipLaunchKernelGGL(gemm_f32_skinny_nt_kernel, dim3(ceil_div(M, 128)), dim3(256), (size_t)K * 128, s, A, lda, B, ldb, C, ldc, bias, M, N, K);
+    DS2_LAUNCH_CHECK("gemm_f32_skinny_nt_kernel");
+    return 0;
+  }
   if (!transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, s, g, vecA, vecB);
   else if (!transA && transB) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, s, g, vecA, vecB);
   else if (transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, s, g, vecA, vecB);

@@ -27,7 +27,7 @@ for tag in ("l2", "ea"):
         if tag == "l2":
             rows.append((c["TCC_MISS_sum"] * 128 / n[k] / 1e6, f"{k:54s} x{n[k]:3d}  req {c['TCC_REQ_sum'] / n[k]:10.3g}  hit {100 * c['TCC_HIT_sum'] / max(1, c['TCC_REQ_sum']):5.1f} %  miss MB/launch {c['TCC_MISS_sum'] * 128 / n[k] / 1e6:8.1f}"))
         else:
-            rd = (c["TCC_EA0_RDREQ_sum"] - c["TCC_EA0_RDREQ_32B_sum"]) * 64 + c["TCC_EA0_RDREQ_32B_sum"] * 32
+            rd = (c["TCC_EA0_RDREQ_sum"] - c["TCC_EA0_RDREQ_32B_sum"]) * 128 + c["TCC_EA0_RDREQ_32B_sum"] * 32   # gfx950: a full read request is 128 B (the x2 of FETCH_SIZE, MI355X_MICROARCH.md)
             wr = c["TCC_EA0_WRREQ_64B_sum"] * 64 + (c["TCC_EA0_WRREQ_sum"] - c["TCC_EA0_WRREQ_64B_sum"]) * 32
             rows.append((rd / n[k], f"{k:54s} x{n[k]:3d}  EA read MB/launch {rd / n[k] / 1e6:8.1f}  EA write MB/launch {wr / n[k] / 1e6:8.1f}"))
     print("==", tag)

@@ -1046,3 +1046,27 @@ def test_spectrogram_full_size_properties(dev):
         assert f == 1 + len(waves[i]) // 160
         v = x[i, 0, :, :f]
         assert abs(float(v.mean())) < 1e-3 and abs(float(v.std()) - 1.0) < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,with_bias", [(32064, 29, 1024, False), (4100, 29, 768, True), (2048, 32, 1280, False), (1027, 7, 128, True)])
+def test_skinny_nt_gemm_is_bit_identical_to_the_tile_kernel(M, N, K, with_bias):
+    """The fc logits kernel (gemm_f32_skinny_nt_kernel: a wave owns 32 rows for the whole K, B in LDS, A straight into the MFMA layout) runs the
+    same v_mfma_f32_32x32x2_f32 chain in the same k order as the 128 x 128 tile kernel: same bits.  The tile kernel is reached through
+    accumulate=True on a zeroed output (the skinny path does not take accumulating calls); an fp64 product bounds both."""
+    from asr_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev); g.manual_seed(M + N + K)
+    A = torch.randn(M, K, device=dev, generator=g)
+    W = torch.randn(N, K, device=dev, generator=g) * 0.05
+    bias = torch.randn(N, device=dev, generator=g) if with_bias else None
+    got = ops.gemm(A, W, transB=True, bias=bias)
+    ref = torch.zeros(M, N, device=dev)
+    ops.gemm(A, W, transB=True, out=ref, accumulate=True)
+    if bias is not None:
+        ref = ref + bias                                      # (the tile kernel adds the bias to the finished sum as well: one fp32 add)
+    assert torch.equal(got, ref)
+    exact = A.double() @ W.double().t() + (bias.double() if bias is not None else 0.0)
+    assert (got.double() - exact).abs().max().item() <= 2e-5 * exact.abs().max().item()
+    again = ops.gemm(A, W, transB=True, bias=bias)
+    assert torch.equal(got, again)
