@@ -13,6 +13,7 @@
 // ([k][m] / [k][n], row pitch 132 floats) so that MFMA fragment reads (lane = (m&31) + 32*(k&1))
 // are unit-stride ds_read_b32 — conflict-free.  Global loads for tile kt+1 are in flight while
 // tile kt is multiplied (2 LDS buffers, one barrier per K-tile).
+#include <type_traits>
 #include "common.h"
 #include "permlane.h"
 
@@ -309,6 +310,66 @@ __global__ __launch_bounds__(256) void gemm_f32_skinny_nt_kernel(const float* __
   }
 }
 
+// Skinny-K NN product C[M, N] = A[M, K <= 32] B[K, N]: the fc layer's input gradient dXn = dLogits W (K = 29 classes; autograd of nn.Linear,
+// deepspeech.py:105).  The tile kernel reaches 2.2 TB/s on the 131 MB it writes (A rows of 29 floats take its scalar edge-load path, and a
+// workgroup is two k-tiles of prologue for 64 stores per lane).  Here B sits in LDS as it lies in memory ([k][N]); a wave keeps the A fragments
+// of its 32 rows in 15 registers (lane (m, h): A[m][2 j + h]) and walks the N / 32 column tiles: 15 ds_read_b32 + 15 MFMAs + 16 row stores
+// (two full 128-byte lines each) per tile.  Same MFMA chain in the same k order (the tile kernel's sixteenth MFMA adds exact zeros): bit-identical.
+__global__ __launch_bounds__(256) void gemm_f32_skinny_k_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                                float* __restrict__ C, int ldc, const float* __restrict__ bias, int M, int N,
+                                                                int K) {
+  extern __shared__ __attribute__((aligned(16))) float Bk[];     // [32][N], rows K .. 31 zero
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int e0 = tid * 4; e0 < 32 * N; e0 += 8 * 1024) {           // 8 loads in flight per thread
+    f32x4 w[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u * 1024, k = e / N, n = e - k * N;
+      w[u] = (e < 32 * N && k < K) ? *reinterpret_cast<const f32x4*>(B + (long long)k * ldb + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (e0 + u * 1024 < 32 * N) *reinterpret_cast<f32x4*>(Bk + e0 + u * 1024) = w[u];
+  }
+  const int r0 = blockIdx.x * 128 + wave * 32;
+  const int m = lane & 31, h = lane >> 5;
+  float a[15];
+  {
+    const float* pa = A + (long long)min(r0 + m, M - 1) * lda;
+#pragma unroll
+    for (int j = 0; j < 15; ++j) a[j] = (2 * j + h < K) ? pa[2 * j + h] : 0.f;
+  }
+  __syncthreads();
+  if (r0 >= M) return;
+  const float* pb = Bk + h * N + m;
+  // (no bias in this kernel: a load inside the tile loop would make every tile wait for the previous tile's stores — one in-order vmcnt)
+  auto run = [&](auto full_c) {
+    constexpr bool FULL = decltype(full_c)::value;
+    float bc[15], bn[15];
+#pragma unroll
+    for (int j = 0; j < 15; ++j) bc[j] = pb[2 * j * N];
+    for (int n0 = 0; n0 < N; n0 += 32) {
+      const int nn = n0 + 32 < N ? n0 + 32 : n0;                  // the next tile's B values, requested before this tile's MFMAs
+#pragma unroll
+      for (int j = 0; j < 15; ++j) bn[j] = pb[2 * j * N + nn];
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 15; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bc[j], acc, 0, 0, 0);      // (k >= K: exact zeros on both sides)
+      float* pc = C + (long long)(r0 + 4 * h) * ldc + n0 + m;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int dr = (r & 3) + 8 * (r >> 2);
+        if (FULL || r0 + 4 * h + dr < M) pc[(long long)dr * ldc] = acc[r] + 0.f;     // (+ 0.f: the tile kernel's "+ bias" with no bias)
+      }
+#pragma unroll
+      for (int j = 0; j < 15; ++j) bc[j] = bn[j];
+    }
+  };
+  if (r0 + 32 <= M) run(std::true_type{}); else run(std::false_type{});
+}
+
 // ordered (deterministic) reduction of split-K partials
 __global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ C, const float* __restrict__ bias,
                                      int M, int N, int ldc, long long sC, int splitk, int accumulate) {
@@ -366,6 +427,19 @@ extern "C" int ds2_gemm_f32(int transA, int transB, int M, int N, int K, const f
     }
     hipLaunchKernelGGL(gemm_f32_skinny_nt_kernel, dim3(ceil_div(M, 128)), dim3(256), (size_t)K * 128, s, A, lda, B, ldb, C, ldc, bias, M, N, K);
     DS2_LAUNCH_CHECK("gemm_f32_skinny_nt_kernel");
+    return 0;
+  }
+  // skinny-K NN (the fc layer's input gradient): gemm_f32_skinny_k_kernel, bit-identical to the tile kernel
+  // (one workgroup per CU — W fills the LDS —, 128 rows each: worth it from ~3/4 of the chip's CUs upwards; c2's 16000 rows stay on the tile kernel)
+  if (!transA && !transB && K >= 1 && K <= 30 && (N % 32) == 0 && (size_t)N * 128 <= 160 * 1024 && M >= 20000 && batch == 1 && splitk == 1 && !accumulate &&
+      !bias && vecB && !(skinny_env && skinny_env[0] == '0')) {
+    static bool attr = false;
+    if (!attr) {
+      DS2_HIP(hipFuncSetAttribute((const void*)gemm_f32_skinny_k_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr = true;
+    }
+    hipLaunchKernelGGL(gemm_f32_skinny_k_kernel, dim3(ceil_div(M, 128)), dim3(256), (size_t)N * 128, s, A, lda, B, ldb, C, ldc, bias, M, N, K);
+    DS2_LAUNCH_CHECK("gemm_f32_skinny_k_kernel");
     return 0;
   }
   if (!transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, s, g, vecA, vecB);

@@ -13,6 +13,13 @@ def child():
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 50
         out[name] = (us, M * K * 4 / us / 1e6, C.double().sum().item())
+        dl = torch.randn(M, N, device="cuda") * 0.01; Wk = torch.randn(N, K, device="cuda")
+        D = ops.gemm(dl, Wk)
+        torch.cuda.synchronize(); e0.record()
+        for _ in range(20): ops.gemm(dl, Wk, out=D)
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 50
+        out[name + " dX"] = (us, M * K * 4 / us / 1e6, D.double().sum().item())
     print(repr(out))
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     child(); sys.exit(0)
@@ -25,4 +32,4 @@ for rep in range(2):
         res[v] = eval(r.stdout.strip().splitlines()[-1])
 for k in res["0"]:
     a, b = res["0"][k], res["1"][k]
-    print(f"{k:8s} tile kernel {a[0]:7.1f} us ({a[1]:5.2f} TB/s of A)   skinny {b[0]:7.1f} us ({b[1]:5.2f} TB/s)   same checksum: {a[2] == b[2]}")
+    print(f"{k:8s} tile kernel {a[0]:7.1f} us ({a[1]:5.2f} TB/s of A | C)   skinny {b[0]:7.1f} us ({b[1]:5.2f} TB/s)   same checksum: {a[2] == b[2]}")

@@ -1070,3 +1070,22 @@ def test_skinny_nt_gemm_is_bit_identical_to_the_tile_kernel(M, N, K, with_bias):
     assert (got.double() - exact).abs().max().item() <= 2e-5 * exact.abs().max().item()
     again = ops.gemm(A, W, transB=True, bias=bias)
     assert torch.equal(got, again)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(32064, 1024, 29), (24000, 1280, 29), (20001, 768, 30), (20480, 128, 5)])
+def test_skinny_k_gemm_is_bit_identical_to_the_tile_kernel(M, N, K):
+    """The fc layer's input gradient dXn = dLogits W (K = classes <= 30): gemm_f32_skinny_k_kernel (W in LDS, a wave's A fragments in registers,
+    full-line row stores) against the tile kernel (reached through accumulate=True on a zeroed output) — same MFMA chain, same bits."""
+    from asr_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev); g.manual_seed(M + N + K)
+    A = torch.randn(M, K, device=dev, generator=g) * 0.01
+    W = torch.randn(K, N, device=dev, generator=g)
+    got = ops.gemm(A, W)
+    ref = torch.zeros(M, N, device=dev)
+    ops.gemm(A, W, out=ref, accumulate=True)
+    assert torch.equal(got, ref)
+    exact = A.double() @ W.double()
+    assert (got.double() - exact).abs().max().item() <= 1e-5 * exact.abs().max().item()
+    assert torch.equal(got, ops.gemm(A, W))
