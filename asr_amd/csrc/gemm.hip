@@ -370,6 +370,58 @@ __global__ __launch_bounds__(256) void gemm_f32_skinny_k_kernel(const float* __r
   if (r0 + 32 <= M) run(std::true_type{}); else run(std::false_type{});
 }
 
+// Skinny-M TN product, split along K: partial[zs][M <= 32][N] = A[kbeg .. kend, M]^T B[kbeg .. kend, N] — the fc layer's weight gradient
+// dW = dLogits^T Xn (29 classes x H, K = T*B; autograd of nn.Linear, deepspeech.py:105).  The tile kernel takes the 29-float rows of dLogits
+// through its scalar edge loads, one 16-deep k-tile per HBM round trip.  Here one wave = (K slice, 32 columns): per MFMA one dword per lane of
+// each operand straight from global in the MFMA layout (A: lane (m, h) <- A[k0 + 2 j + h][m], 29 consecutive floats per half, L2-resident;
+// B: 128 contiguous bytes per half, streamed once), 16 MFMAs = 32 loads in flight per wave, counted by hand (vmcnt(30) at every MFMA).  Same
+// slices, same k order inside a slice, the same ordered reduction behind it: bit-identical to the tile kernel's split-K result.
+constexpr int SM_AHEAD = 16;
+__global__ __launch_bounds__(256) void gemm_f32_skinny_m_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                                float* __restrict__ part, int M, int N, int K, int kchunk) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int zs = blockIdx.y, n0 = blockIdx.x * 128 + wave * 32;
+  const int kbeg = zs * kchunk, kend = min(K, kbeg + kchunk);
+  const int m = lane & 31, h = lane >> 5;
+  const bool mok = m < M;
+  const int nj = (kend - kbeg + 1) >> 1;                          // MFMAs of this slice (wave-uniform), a multiple of SM_AHEAD is NOT required
+  // element addresses of MFMA j: k = kbeg + 2 j + h, clamped to the last row of the slice (the value is then replaced by zero)
+  const float* pa0 = A + (mok ? m : 0);
+  const float* pb0 = B + n0 + m;
+  auto ka = [&](int j) { const int k = kbeg + 2 * j + h; return k < kend ? k : kend - 1; };
+  float av[SM_AHEAD], bv[SM_AHEAD];
+#pragma unroll
+  for (int i = 0; i < SM_AHEAD; ++i) {
+    const long long k = ka(i < nj ? i : nj - 1);
+    asm volatile("global_load_dword %0, %1, off" : "=&v"(av[i]) : "v"(pa0 + k * lda) : "memory");
+    asm volatile("global_load_dword %0, %1, off" : "=&v"(bv[i]) : "v"(pb0 + k * ldb) : "memory");
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int j0 = 0; j0 < nj; j0 += SM_AHEAD) {
+#pragma unroll
+    for (int i = 0; i < SM_AHEAD; ++i) {
+      const int j = j0 + i;
+      asm volatile("s_waitcnt vmcnt(30)" : "+v"(av[i]), "+v"(bv[i]) : : "memory");
+      const bool real = j < nj && kbeg + 2 * j + h < kend;        // (past the slice: exact zeros, as the tile kernel's zero-filled k-tile)
+      const float a = (real && mok) ? av[i] : 0.f, b = real ? bv[i] : 0.f;
+      if (j < nj) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      const int jn = j + SM_AHEAD < nj ? j + SM_AHEAD : nj - 1;   // (behind the end: re-reads of the last pair, unused)
+      const long long k = ka(jn);
+      asm volatile("global_load_dword %0, %1, off" : "=&v"(av[i]) : "v"(pa0 + k * lda) : "memory");
+      asm volatile("global_load_dword %0, %1, off" : "=&v"(bv[i]) : "v"(pb0 + k * ldb) : "memory");
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  float* out = part + (long long)zs * M * N + n0 + m;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (row < M) out[(long long)row * N] = acc[r];
+  }
+}
+
 // ordered (deterministic) reduction of split-K partials
 __global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ C, const float* __restrict__ bias,
                                      int M, int N, int ldc, long long sC, int splitk, int accumulate) {
@@ -453,11 +505,16 @@ extern "C" int ds2_gemm_f32(int transA, int transB, int M, int N, int K, const f
     DS2_LAUNCH_CHECK("gemm_f32_skinny_k_kernel");
     return 0;
   }
-  if (!transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, s, g, vecA, vecB);
+  // skinny-M split-K TN (the fc layer's weight gradient): gemm_f32_skinny_m_kernel writes the same slabs as the tile kernel, bit for bit
+  const bool skinny_m = transA && !transB && M <= 32 && (N % 128) == 0 && splitk > 1 && batch == 1 && kchunk >= 64 && !(skinny_env && skinny_env[0] == '0');
+  if (skinny_m) {
+    hipLaunchKernelGGL(gemm_f32_skinny_m_kernel, dim3(N / 128, splitk), dim3(256), 0, s, A, lda, B, ldb, (float*)workspace, M, N, K, kchunk);
+    DS2_LAUNCH_CHECK("gemm_f32_skinny_m_kernel");
+  } else if (!transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, s, g, vecA, vecB);
   else if (!transA && transB) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, s, g, vecA, vecB);
   else if (transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, s, g, vecA, vecB);
   else hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, s, g, vecA, vecB);
-  DS2_LAUNCH_CHECK("gemm_f32_kernel");
+  if (!skinny_m) DS2_LAUNCH_CHECK("gemm_f32_kernel");
   if (splitk > 1) {
     dim3 rg(ceil_div(M * N, 256), batch);
     hipLaunchKernelGGL(splitk_reduce_kernel, rg, dim3(256), 0, s, (const float*)workspace, C, bias, M, N, ldc, strideC,

@@ -20,6 +20,12 @@ def child():
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 50
         out[name + " dX"] = (us, M * K * 4 / us / 1e6, D.double().sum().item())
+        G = ops.gemm(dl, A, transA=True)                       # dW = dLogits^T Xn (split-K + ordered reduce)
+        torch.cuda.synchronize(); e0.record()
+        for _ in range(20): ops.gemm(dl, A, transA=True, out=G)
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 50
+        out[name + " dW"] = (us, M * K * 4 / us / 1e6, G.double().sum().item())
     print(repr(out))
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     child(); sys.exit(0)
