@@ -1092,17 +1092,17 @@ def test_skinny_k_gemm_is_bit_identical_to_the_tile_kernel(M, N, K):
 
 
 @pytest.mark.gpu
-def test_splitk_reduce_adds_the_slabs_in_slice_order():
+@pytest.mark.parametrize("K,M,N", [(32064, 29, 1024), (5000, 29, 768), (4100, 7, 128), (4099, 32, 256)])
+def test_splitk_reduce_adds_the_slabs_in_slice_order(K, M, N):
     """The fc weight gradient (29 x 1024, K = T*B = 32064) runs as 118 K slices of 272 + an ordered reduction whose loads are batched 16 deep:
     the sum must be the slices' partial products added one after the other, starting from zero — reproduced here with one un-split call per slice."""
     from asr_amd import ops
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev); g.manual_seed(11)
-    K, M, N = 32064, 29, 1024
     dl = torch.randn(K, M, device=dev, generator=g) * 0.01
     xn = torch.randn(K, N, device=dev, generator=g)
     got = ops.gemm(dl, xn, transA=True)
-    tiles = 8
+    tiles = (N + 127) // 128                                  # (ops.gemm_raw's rule for a skinny weight gradient)
     sk = max(1, min((1024 + tiles - 1) // tiles, K // 256))
     kchunk = -(-(-(-K // sk)) // 16) * 16
     ref = torch.zeros(M, N, device=dev)
