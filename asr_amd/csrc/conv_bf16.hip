@@ -34,6 +34,7 @@ struct CArgs {
   float* out;         // (B, 32, Dtot, T) fp32
   const int* lens;    // (B) or null
   int B, Din, T, Dtot, KD, SD, PD, OS, OO;
+  int gx, gy, gz;     // conv2_bf16_rows_kernel: logical grid (time tiles, output-row groups, utterances) behind its 1-D launch
 };
 
 constexpr int IN_CHUNKS = NPIX * 4;                 // 16-byte chunks of one staged row (552)
@@ -145,7 +146,18 @@ __global__ __launch_bounds__(256) void conv2_bf16_rows_kernel(CArgs a, int n_out
   __shared__ __attribute__((aligned(16))) char w_lds[WROW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
-  const int t0 = blockIdx.x * TT, o0 = R * blockIdx.y, b = blockIdx.z;
+  // 1-D launch, workgroup ids go round the 8 XCDs: XCD x takes a contiguous eighth of the (utterance, time tile, row group) list, row group
+  // fastest — neighbouring row groups of one (utterance, time tile) read 19 of their 25 input rows in common and now meet in ONE L2 (the 3-D
+  // launch put them on different XCDs: every XCD fetched nearly the whole input, 4.4 x the operand bytes on the fabric)
+  int bx, by, bz;
+  {
+    const int total = a.gx * a.gy * a.gz, id = blockIdx.x;
+    const int lin = (total & 7) == 0 ? (id & 7) * (total >> 3) + (id >> 3) : id;
+    by = lin % a.gy;
+    const int pair = lin / a.gy;
+    bx = pair % a.gx; bz = pair / a.gx;
+  }
+  const int t0 = bx * TT, o0 = R * by, b = bz;
   const int len = a.lens ? min(a.lens[b], a.T) : a.T;
   const int t = t0 + wave * 32 + l31;
   auto out_ptr = [&](int o, int co) { return a.out + (((long long)b * CH + co) * a.Dtot + (a.OS * o + a.OO)) * a.T + t; };
@@ -277,7 +289,7 @@ __global__ __launch_bounds__(256) void conv2_bf16_rows_kernel(CArgs a, int n_out
     if (tid < 64) {
       const int co = tid >> 1, w = tid & 1;
       const float sum = ((red[0][co][w] + red[1][co][w]) + red[2][co][w]) + red[3][co][w];
-      const long long blk = ((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      const long long blk = ((long long)bz * a.gy + by) * a.gx + bx;
       stat_part[(blk * 32 + co) * 2 + w] = sum;
     }
   }
@@ -370,7 +382,10 @@ extern "C" int ds2_conv2_fwd_bf16_stats(const void* a1_nhwc, const void* wf, con
   // blocks of a fully masked tile return early: their slots must read as zeros
   if (stat_part) DS2_HIP(hipMemsetAsync(stat_part, 0, (size_t)ds2_conv2_fwd_bf16_stat_blocks(B, D1, T) * 64 * sizeof(float), (hipStream_t)stream));
   if (rows_env && rows_env[0] == '1') hipLaunchKernelGGL(conv2_bf16_kernel, dim3(ceil_div(T, TT), D2, B), dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((conv2_bf16_rows_kernel<2, 3>), dim3(ceil_div(T, TT), ceil_div(D2, 3), B), dim3(256), 0, (hipStream_t)stream, a, D2, stat_part);
+  else {
+    a.gx = ceil_div(T, TT); a.gy = ceil_div(D2, 3); a.gz = B;
+    hipLaunchKernelGGL((conv2_bf16_rows_kernel<2, 3>), dim3(a.gx * a.gy * a.gz), dim3(256), 0, (hipStream_t)stream, a, D2, stat_part);
+  }
   DS2_LAUNCH_CHECK("conv2_bf16_kernel fwd");
   return 0;
 }
@@ -393,7 +408,10 @@ extern "C" int ds2_conv2_dgrad_bf16(const void* dy2_nhwc, const void* wd0, const
     // four output rows per block here (rows one apart: 4 input-row slots): 2 x 347 -> 2 x 290 us
     static const char* rows_env = ds2_exp_getenv("DS2_CONV2_ROWS");
     if (rows_env && rows_env[0] == '1') hipLaunchKernelGGL(conv2_bf16_kernel, dim3(ceil_div(T, TT), n_o, B), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((conv2_bf16_rows_kernel<1, 4>), dim3(ceil_div(T, TT), ceil_div(n_o, 4), B), dim3(256), 0, (hipStream_t)stream, a, n_o, (float*)nullptr);
+    else {
+      a.gx = ceil_div(T, TT); a.gy = ceil_div(n_o, 4); a.gz = B;
+      hipLaunchKernelGGL((conv2_bf16_rows_kernel<1, 4>), dim3(a.gx * a.gy * a.gz), dim3(256), 0, (hipStream_t)stream, a, n_o, (float*)nullptr);
+    }
   }
   DS2_LAUNCH_CHECK("conv2_bf16_kernel dgrad");
   return 0;
