@@ -216,7 +216,8 @@ def test_bench_two_ranks_end_to_end_on_one_gpu():
     assert d["device_count"] >= 1 and isinstance(d["rccl_version"], str) and len(d["ranks"]) == 2
     assert [r["rank"] for r in d["ranks"]] == [0, 1] and all(r["device_index"] == 0 and r["pci_bus_id"] for r in d["ranks"])
     assert d["distinct_devices"] == 1                                           # test mode: both ranks on cuda:0 — a real run reports N
-    assert d["persistent_starved_steps_all_ranks"] == 0
+    # (summed over the ranks; NOT necessarily 0 here — see below: two processes time-share the one GPU in this test mode)
+    assert 0 <= d["persistent_starved_steps_all_ranks"] <= 2 * 4 and d["persistent_starved_steps_all_ranks"] >= out["persistent_starved_steps"]
     assert d["conv_backward_ms"] > 0 and d["big_collective_outlasts_conv_backward_ms"] >= 0
     # two PROCESSES time-share the one GPU here, so a persistent recurrence launch of one rank can find its CUs held by the other rank's kernels
     # for longer than the spin limit: that is the starvation path doing its job (every rank skips the step, restores the BatchNorm statistics,
