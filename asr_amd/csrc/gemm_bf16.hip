@@ -632,7 +632,17 @@ __global__ __launch_bounds__(512) void gemm_bf16_tn_glds_kernel(BArgs g, int ntx
   bool partial;
   if constexpr (GROUPED) {
     // the item's problem: field by field with wave-uniform compares (a dynamically indexed kernel-argument struct would go to scratch)
-    const int item = blockIdx.x;
+    // items handed to the workgroups in XCD-sized runs of 32 consecutive (slice, tile) pairs: see gemm_tn_w4.h (same order, same reason)
+    int item = blockIdx.x;
+    if (grp.order) {
+      const int full = grp.nitems & ~255;
+      if (item < full) {
+        item = (item & ~255) + ((item & 7) << 5) + ((item & 255) >> 3);
+      } else {
+        const int R = grp.nitems - full, o = item - full, x = o & 7, q8 = R >> 3, r8 = R & 7;
+        item = full + (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + (o >> 3);
+      }
+    }
     A = grp.p[0].A; B = grp.p[0].B; Cfinal = grp.p[0].C; Cslab = grp.p[0].partial;
     pM = grp.p[0].M; pN = grp.p[0].N; pK = grp.p[0].K; plda = grp.p[0].lda; pldb = grp.p[0].ldb; ldcf = grp.p[0].ldc; ntx = grp.p[0].ntx;
     nt = grp.p[0].ntiles; kchunk = grp.p[0].kchunk;
@@ -660,8 +670,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_tn_glds_kernel(BArgs g, int ntx
     Cfinal = g.C + (long long)zb * g.sC; ldcf = g.ldc;
     Cslab = g.partial + ((long long)zb * g.splitk + zs) * (long long)g.M * g.N;
   }
-  const int xcd = orig & 7, q8 = nt >> 3, r8 = nt & 7;
-  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  int tile = orig;
+  if (!(GROUPED && grp.order)) {
+    const int xcd = orig & 7, q8 = nt >> 3, r8 = nt & 7;
+    tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  }
   const int m0 = (tile / ntx) * 256, n0 = (tile % ntx) * 256;
   const int kbeg = zs * kchunk;
   const int kend = min(pK, kbeg + kchunk);

@@ -5,8 +5,8 @@ export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r5_step_l2; rm -rf $OUT; mkdir -p $OUT
 ROOT=$GRAFT_REPO_ROOT
 cd /tmp
-rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $OUT -o l2 -- python $ROOT/bench.py --workload c3 --steps 2 --warmup 1 --no-cpu-baseline --no-other-workloads > $OUT/log.txt 2>&1
-rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --output-format csv -d $OUT -o ea -- python $ROOT/bench.py --workload c3 --steps 2 --warmup 1 --no-cpu-baseline --no-other-workloads > $OUT/log_ea.txt 2>&1
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $OUT -o l2 -- python $ROOT/bench.py --workload ${WL:-c3} --steps 2 --warmup 1 --no-cpu-baseline --no-other-workloads > $OUT/log.txt 2>&1
+rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --output-format csv -d $OUT -o ea -- python $ROOT/bench.py --workload ${WL:-c3} --steps 2 --warmup 1 --no-cpu-baseline --no-other-workloads > $OUT/log_ea.txt 2>&1
 cd $ROOT
 python3 - $OUT <<'PY'
 import csv, sys, glob, collections, re

@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r5_step_sq; rm -rf $OUT; mkdir -p $OUT
 ROOT=$GRAFT_REPO_ROOT
 cd /tmp
-B="python $ROOT/bench.py --workload c3 --steps 2 --warmup 1 --no-cpu-baseline --no-other-workloads"
+B="python $ROOT/bench.py --workload ${WL:-c3} --steps 2 --warmup 1 --no-cpu-baseline --no-other-workloads"
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT -o a -- $B > $OUT/log_a.txt 2>&1
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU --output-format csv -d $OUT -o b -- $B > $OUT/log_b.txt 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $OUT -o c -- $B > $OUT/log_c.txt 2>&1
