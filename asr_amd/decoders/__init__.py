@@ -91,10 +91,10 @@ class GreedyDecoder(Decoder):
         ids, offs, lens = ops.greedy_decode(probs, sizes, self.blank_index)
         B, T = ids.shape
         host = torch.cat((ids.reshape(-1), offs.reshape(-1), lens)).cpu()
-        if ops.rnn_poison_seen():
+        if ops.rnn_poison_seen(ids.device):
             # the copy above synchronised with the stream: if the forward that produced `probs` was poisoned (a persistent recurrence
             # launch starved: NaN logits -> empty transcripts), say so here instead of returning garbage silently
-            ops.rnn_persistent_check()
+            ops.rnn_persistent_check(ids.device)
         ids_h, offs_h, lens_h = host[:B * T].view(B, T), host[B * T:2 * B * T].view(B, T), host[2 * B * T:].tolist()
         strings, offsets = [], []
         for b in range(B):

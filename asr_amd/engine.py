@@ -113,7 +113,7 @@ def _f32_split_ok(M: int, N: int, K: int, H: int = 8) -> bool:
     return F32_GEMM == "split" and M >= 512 and N >= 256 and K >= 256 and K % 8 == 0 and N % 8 == 0 and H % 8 == 0
 
 
-_BWD_PERSISTENT = {}      # (recurrence context of the calling thread, gates, H, B) -> did the last backward recurrence of this shape run as a persistent launch?
+_BWD_PERSISTENT = {}      # (id of the recurrence context in use, gates, H, B) -> did the last backward recurrence of this shape run as a persistent launch?
 _SIDE = {}
 
 
@@ -343,11 +343,11 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
         if pack:
             # (not for shapes whose backward recurrence is known to run one launch per step - LSTM H = 1280: nobody would read the copy)
             h_bf = (torch.empty(M, 2 * H, dtype=torch.bfloat16, device=x.device)
-                    if (WGRAD_TN and OVERLAP_MODE == "2" and T > 1 and _BWD_PERSISTENT.get((G, H, B), True)) else None)
+                    if (WGRAD_TN and OVERLAP_MODE == "2" and T > 1 and _BWD_PERSISTENT.get((ops.rnn_ctx_key(x.device), G, H, B), True)) else None)
             hbuf, aux, rec = ops.rnn_fwd(G, gx, wpf, W[f"rnns.{l}.bhh_cat"], lens_dev, T, B, H, bf16=True, packed_gates=True, h_bf16=h_bf)
             gx = None
             lc.rec, lc.gshape = rec, (M, 2 * G * H)
-            if h_bf is not None and (ops.rnn_last_path() & 1):
+            if h_bf is not None and (ops.rnn_last_path(x.device) & 1):
                 lc.h_bf = h_bf                                   # (only a persistent launch writes it)
         else:
             hbuf, aux = ops.rnn_fwd(G, gx, wpf, W[f"rnns.{l}.bhh_cat"], lens_dev, T, B, H, bf16=rmode)
@@ -543,7 +543,7 @@ def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy, done, private: bo
         else:
             ops.rnn_bwd(G, dy, lc.gx, lc.aux, lc.hbuf, lc.wpb, lens_dev, T, B, H, bf16=True, dgx_bf16=dgx_bf, gates_bf16=lc.rec, dhn_bf16=dhn_bf,
                         bias_part=bias_part)
-        _BWD_PERSISTENT[shape_key] = bool(ops.rnn_last_path() & 2)
+        _BWD_PERSISTENT[shape_key] = bool(ops.rnn_last_path(dev) & 2)
         if queued_idle is not None:
             # enqueued BEHIND the recurrence launch: the recurrence's workgroups are dispatched first, the GEMM's fill what is left
             weight_gradients_group(*queued_idle, _BWD_PERSISTENT[shape_key], start_idle)
@@ -646,7 +646,7 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
         rmode = 1 if bf else (2 if (F32_RNN == "split" and H % 32 == 0) else 0)          # (the mode lc.wpb was packed for in forward)
         ops.rnn_bwd(G, dy, lc.gx, lc.aux, lc.hbuf, lc.wpb, lens_dev, T, B, H, bf16=rmode, dgx_bf16=dgx_bf, gates_bf16=lc.rec)
         if not bf:
-            _BWD_PERSISTENT[f32_key] = bool(ops.rnn_last_path() & 2)
+            _BWD_PERSISTENT[f32_key] = bool(ops.rnn_last_path(dy.device) & 2)
         if pending_off is not None:
             fn, ev, pl = pending_off
             pending_off = None

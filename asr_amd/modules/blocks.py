@@ -3,7 +3,9 @@
 Inside `DeepSpeech` these classes are *parameter containers*: `DeepSpeech.forward` runs the fused
 MI355X kernel schedule (asr_amd/engine.py) over their parameters and never calls their `forward`.
 Stand-alone `forward` of a block is provided where a HIP kernel exists (MaskConv masking,
-SequenceWise reshape, InferenceBatchSoftmax, BatchRNN in no-grad mode); there is no CPU path.
+SequenceWise reshape, InferenceBatchSoftmax, BatchRNN in no-grad mode); there is no CPU path for the
+bidirectional model.  The unidirectional variant (`bidirectional=False` + `Lookahead`; no BASELINE
+config, SURVEY.md §2 row 1 "keep as PyTorch fallback, not a kernel target") runs on torch ops.
 """
 import torch
 import torch.nn as nn
@@ -113,11 +115,16 @@ class BatchRNN(nn.Module):
         pass  # parameters are already one flat buffer (asr_amd/params.py)
 
     def forward(self, x, output_lengths):
-        """Stand-alone inference/forward-only use: (T,N,I) -> (T,N,H) through the HIP kernels."""
+        """Stand-alone inference/forward-only use: (T,N,I) -> (T,N,H) through the HIP kernels (bidirectional); the unidirectional variant —
+        outside every BASELINE config, not a kernel target — runs the reference's op sequence on torch ops, autograd
+        included: BatchNorm1d over all rows, packed sequence through the cell, zero rows beyond each length (blocks.py:84-93)."""
+        if not self._bidirectional:
+            if self.batch_norm is not None:
+                x = self.batch_norm(x)
+            packed = nn.utils.rnn.pack_padded_sequence(x, torch.as_tensor(output_lengths).cpu())
+            return nn.utils.rnn.pad_packed_sequence(self.rnn(packed)[0])[0]
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise NotImplementedError("BatchRNN.forward stand-alone has no autograd; train through DeepSpeech.forward")
-        if not self._bidirectional:
-            raise NotImplementedError("unidirectional BatchRNN has no HIP kernel and asr_amd has no torch fallback by design: see INTEGRATION.md, \"Unidirectional models\" (use asr_deepspeech.modules for this variant)")
         if not x.is_cuda:
             raise _lib.DS2LibraryError("BatchRNN.forward: GPU tensor required (no CPU fallback)")
         T, N, I = x.shape
@@ -145,8 +152,9 @@ class BatchRNN(nn.Module):
 
 
 class Lookahead(nn.Module):
-    """blocks.py:96-132 (only built when bidirectional=False).  Parameter container only: the
-    unidirectional variant is outside every BASELINE config and has no HIP kernel."""
+    """blocks.py:96-132 (only built when bidirectional=False): y[t] = sum_{k < context} w[:, k] * x[t + k] per feature, zeros beyond the end
+    (Wang et al. 2016).  The unidirectional variant is outside every BASELINE config and is not a kernel target (SURVEY.md §2 row 1:
+    "keep as PyTorch fallback"): a depthwise torch convolution over time, as in the reference."""
 
     def __init__(self, n_features, context):
         super().__init__()
@@ -158,7 +166,9 @@ class Lookahead(nn.Module):
                               padding=0, bias=None)
 
     def forward(self, x):
-        raise NotImplementedError("Lookahead (unidirectional DeepSpeech) has no HIP kernel and asr_amd has no torch fallback by design: see INTEGRATION.md, \"Unidirectional models\" (use asr_deepspeech.modules for this variant)")
+        """(T, N, H) -> (T, N, H)"""
+        nht = torch.nn.functional.pad(x.permute(1, 2, 0), self.pad, value=0)          # (N, H, T + context - 1): future frames, zero-padded
+        return self.conv(nht).permute(2, 0, 1).contiguous()
 
     def __repr__(self):
         return f"{self.__class__.__name__}(n_features={self.n_features}, context={self.context})"

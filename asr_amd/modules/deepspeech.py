@@ -33,6 +33,9 @@ class _DS2Function(torch.autograd.Function):
         W = model._flat.tensors(model)
         logits, saved = engine.forward(W, model._cfg, x, lens_dev, training=model.training, save=True)
         ctx.model, ctx.saved = model, saved
+        # backward runs on autograd's worker thread: it must go through the recurrence context of THIS thread (whose enable switches the
+        # trainer set, and whose starvation record / cooldown the trainer reads), not through a fresh one of the worker's own
+        ctx.rnn_ctx, ctx.device = ops.rnn_ctx(x.device), x.device
         return logits
 
     @staticmethod
@@ -54,8 +57,9 @@ class _DS2Function(torch.autograd.Function):
             keep, flat.flat_grad = flat.flat_grad, torch.empty_like(flat.flat_grad)
         try:
             Gr = flat.tensors(model, grads=True)
-            engine.backward(W, Gr, model._cfg, ctx.saved, dlogits.contiguous(),
-                            on_bucket=None if accumulating else model._on_bucket)
+            with ops.use_rnn_ctx(ctx.rnn_ctx, ctx.device), torch.cuda.device(ctx.device):
+                engine.backward(W, Gr, model._cfg, ctx.saved, dlogits.contiguous(),
+                                on_bucket=None if accumulating else model._on_bucket)
         finally:
             if accumulating:
                 flat.flat_grad = keep
@@ -168,8 +172,11 @@ class DeepSpeech(nn.Module):
     def forward(self, x: torch.Tensor, lengths: torch.Tensor):
         lengths = torch.as_tensor(lengths).cpu().int()
         output_lengths = self.get_seq_lens(lengths)
-        if not self.bidirectional or self._cfg.rnn == "unsupported":
-            raise NotImplementedError("only bidirectional GRU/LSTM DeepSpeech has MI355X kernels, and asr_amd has no torch fallback by design: see INTEGRATION.md, \"Unidirectional models\" (use asr_deepspeech.modules.DeepSpeech for that variant)")
+        if not self.bidirectional:
+            return self._forward_unidirectional(x, output_lengths)
+        if self._cfg.rnn == "unsupported":
+            raise NotImplementedError("only GRU / LSTM cells have MI355X kernels (asr_deepspeech.vars.supported_rnns lists nn.RNN too: use "
+                                      "asr_deepspeech.modules.DeepSpeech for that cell)")
         if not x.is_cuda:
             raise _lib.DS2LibraryError(
                 "asr_amd.DeepSpeech.forward needs GPU input: the MI355X HIP kernels are the only implementation. "
@@ -182,11 +189,11 @@ class DeepSpeech(nn.Module):
             params = [p for _, p in self.named_parameters()]
             logits = _DS2Function.apply(self, x, lens_dev, *params)
         else:
-            if not self.training and ops.rnn_poison_seen():
+            if not self.training and ops.rnn_poison_seen(x.device):
                 # an EARLIER inference forward of this process was handed NaN logits (below) and nobody has settled the starvation since:
                 # settle it now — raises DS2LibraryError naming the launch, clears the record and moves the next recurrence calls onto the
                 # step kernels, so a caller that only ever calls forward() sees the failure once and then keeps working
-                ops.rnn_persistent_check()
+                ops.rnn_persistent_check(x.device)
             W = self._flat.tensors(self)
             logits, _ = engine.forward(W, self._cfg, x, lens_dev, training=self.training, save=False)
             if not self.training:
@@ -201,6 +208,32 @@ class DeepSpeech(nn.Module):
         out = logits.transpose(0, 1)            # (B,T,C) view, like the reference's x.transpose(0, 1)
         out = self.inference_softmax(out)       # identity in train, HIP softmax in eval
         return out, output_lengths
+
+    def _forward_unidirectional(self, x, output_lengths):
+        """`bidirectional=False` (+ Lookahead, deepspeech.py:83-101, :142-143): not on any BASELINE configuration and not a kernel target
+        ("keep as PyTorch fallback") — the reference's op sequence on torch ops with torch autograd, on whatever device
+        the module lives on, so that a unidirectional checkpoint of the reference loads, evaluates and fine-tunes behind the same class.
+        The MI355X kernels, the fused `trainer.step` and the data-parallel reducer are for the bidirectional model only."""
+        if not getattr(self, "_uni_note", False):
+            self._uni_note = True
+            print("[asr_amd] unidirectional DeepSpeech: this variant runs on torch ops (no MI355X kernels; SURVEY.md §2 row 1)", flush=True)
+        keep = (torch.arange(int(output_lengths.max()) if output_lengths.numel() else 0, device=x.device).view(1, 1, 1, -1)
+                < output_lengths.to(x.device).view(-1, 1, 1, 1))
+        h = x
+        for m in self.conv.seq_module:                       # MaskConv (blocks.py:42-56): every stage's output is zeroed beyond each utterance
+            h = m(h)
+            t = h.size(3)
+            live = keep[..., :t] if keep.size(3) >= t else torch.nn.functional.pad(keep, (0, t - keep.size(3)))
+            h = h * live
+        b, c, d, t = h.shape
+        h = h.reshape(b, c * d, t).permute(2, 0, 1).contiguous()                     # (T, N, c*D + d)
+        for rnn in self.rnns:
+            h = rnn(h, output_lengths)
+        h = self.lookahead(h)
+        h = self.fc(h).transpose(0, 1)
+        if not self.training:
+            h = torch.softmax(h, dim=-1)
+        return h, output_lengths
 
     def get_loader(self, manifest, batch_size, num_workers, caching=False):
         from ..data import get_loader
@@ -241,7 +274,7 @@ class DeepSpeech(nn.Module):
                     offset += size
                 out, output_sizes = self.forward(inputs, input_sizes)
                 decoded_output, _ = decoder.decode(out, output_sizes)   # (copies to the host: the device is idle behind it)
-                ops.rnn_persistent_check()                              # raise if a persistent recurrence of this batch starved (the logits are NaN then)
+                ops.rnn_persistent_check(inputs.device)                 # raise if a persistent recurrence of this batch starved (the logits are NaN then)
                 target_strings = decoder.convert_to_strings(split_targets)
                 if output_file is not None:
                     output_data.append((out.detach().cpu().numpy(), output_sizes.numpy(), target_strings))

@@ -51,6 +51,9 @@ class RnnCtx(C.Structure):
 
 
 _RNN_TLS = threading.local()
+_RNN_REGISTRY = []                      # every context ever created: (ctx, status tensor, pinned word, uid) — kept for the life of the process, so
+_RNN_REGISTRY_LOCK = threading.Lock()   # a kernel still queued on some stream can never write into memory the caching allocator has handed on
+_RNN_UID = {}                           # ctypes address of a context -> its monotonically increasing id (never reused, unlike thread idents)
 
 
 def _pinned_word():
@@ -66,11 +69,19 @@ def _pinned_word():
     return None, None, None
 
 
-def rnn_ctx(device=None) -> RnnCtx:
-    """The calling thread's recurrence context for `device` (default: the current CUDA device), created on first use: the struct itself, its
-    8-int device status record and its pinned poison word are allocated HERE, by the caller of the C ABI."""
+def _dev_key(device=None):
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    return dev, (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+
+
+def rnn_ctx(device=None) -> RnnCtx:
+    """The recurrence context the calling thread uses on `device` (default: the current CUDA device): the one bound with use_rnn_ctx() if any
+    (an autograd worker thread running the backward of a forward that another thread issued), else the thread's own, created on first use:
+    the struct itself, its 8-int device status record and its pinned poison word are allocated HERE, by the caller of the C ABI."""
+    dev, key = _dev_key(device)
+    bound = getattr(_RNN_TLS, "bound", None)
+    if bound and key in bound[-1]:
+        return bound[-1][key]
     table = getattr(_RNN_TLS, "ctx", None)
     if table is None:
         table = _RNN_TLS.ctx = {}
@@ -81,8 +92,35 @@ def rnn_ctx(device=None) -> RnnCtx:
         torch.cuda.synchronize(dev)                                   # the status record is zero before the first launch reads it
         _lib.check(_lib.load().ds2_rnn_ctx_init(C.addressof(ctx), status.data_ptr(), phost, pdev), "ds2_rnn_ctx_init")
         assert ctx.size == C.sizeof(RnnCtx), "ds2_rnn_ctx layout mismatch between include/ds2hip.h and asr_amd/ops.py"
-        table[key] = (ctx, status, pin)                               # (the tensors live as long as the context)
-    return table[key][0]
+        with _RNN_REGISTRY_LOCK:
+            uid = len(_RNN_REGISTRY)
+            _RNN_REGISTRY.append((ctx, status, pin, uid))
+            _RNN_UID[C.addressof(ctx)] = uid
+        table[key] = ctx
+    return table[key]
+
+
+class use_rnn_ctx:
+    """`with use_rnn_ctx(ctx, device):` — inside the block the CALLING thread's recurrence calls on `device` go through `ctx` instead of the
+    thread's own context.  asr_amd.modules.deepspeech binds the context of the thread that ran forward around engine.backward: `loss.backward()`
+    runs on PyTorch's autograd worker thread, and the enable switches, debug selectors, starvation record and cooldown that the forward thread
+    (the trainer) set and reads must be the ones the backward recurrences see and write."""
+
+    def __init__(self, ctx: RnnCtx, device=None):
+        self.ctx, self.key = ctx, _dev_key(device)[1]
+
+    def __enter__(self):
+        stack = getattr(_RNN_TLS, "bound", None)
+        if stack is None:
+            stack = _RNN_TLS.bound = []
+        top = dict(stack[-1]) if stack else {}
+        top[self.key] = self.ctx
+        stack.append(top)
+        return self.ctx
+
+    def __exit__(self, *exc):
+        _RNN_TLS.bound.pop()
+        return False
 
 
 def _ctxp(device=None) -> int:
@@ -90,8 +128,9 @@ def _ctxp(device=None) -> int:
 
 
 def rnn_ctx_key(device=None):
-    """hashable identity of the calling thread's context (host-side caches of "what did the last call of this shape do" are keyed with it)"""
-    return (threading.get_ident(), _ctxp(device))
+    """hashable identity of the context in use (host-side caches of "what did the last call of this shape do" are keyed with it): a
+    monotonically increasing id, never reused by a later thread or context"""
+    return _RNN_UID[_ctxp(device)]
 
 
 def debug_flags(flags: int, device=None) -> int:
@@ -813,19 +852,19 @@ def rnn_pack(gates: int, whh: Tensor, bf16=False):
     return wpf, wpb
 
 
-def rnn_persistent_enable(forward: bool = True, backward: bool = True) -> None:
+def rnn_persistent_enable(forward: bool = True, backward: bool = True, device=None) -> None:
     """Which bf16 recurrences may run as one persistent launch.  A persistent launch needs all of its workgroups resident at once, so
     the backward one must be off while collectives run on a communication stream during backward (data-parallel training)."""
-    _lib.check(_lib.load().ds2_rnn_persistent_enable(_ctxp(), int(bool(forward)), int(bool(backward))), "ds2_rnn_persistent_enable")
+    _lib.check(_lib.load().ds2_rnn_persistent_enable(_ctxp(device), int(bool(forward)), int(bool(backward))), "ds2_rnn_persistent_enable")
 
 
-def rnn_persistent_check() -> None:
+def rnn_persistent_check(device=None) -> None:
     """Raise if a persistent recurrence launch starved since the last call (a workgroup never saw its operand, or the launch never became
     resident: it needs every workgroup on the chip at once).  Call at a point where the device is idle anyway (the train step's loss sync)."""
     rec = (C.c_int * 8)()
-    _lib.check(_lib.load().ds2_rnn_persistent_status(_ctxp(), C.cast(rec, C.c_void_p)), "ds2_rnn_persistent_status")
+    _lib.check(_lib.load().ds2_rnn_persistent_status(_ctxp(device), C.cast(rec, C.c_void_p)), "ds2_rnn_persistent_status")
     if rec[0]:
-        starved, left = rnn_persistent_counters()
+        starved, left = rnn_persistent_counters(device)
         what = {1: "forward", 2: "backward", 3: "census (launch never resident)"}.get(rec[0], str(rec[0]))
         raise _lib.DS2LibraryError(
             f"persistent recurrence starved ({what}): ids ({rec[1]}, {rec[2]}, {rec[3]}) step {rec[4]} wave {rec[5]} pending chunks {rec[6] & 0xffffffff:08x} "
@@ -842,17 +881,17 @@ def rnn_poison_if_starved(buf: Tensor) -> None:
     _lib.check(_lib.load().ds2_rnn_poison_if_starved(_ctxp(buf.device), buf.data_ptr(), buf.numel(), _stream()), "ds2_rnn_poison_if_starved")
 
 
-def rnn_poison_seen() -> bool:
+def rnn_poison_seen(device=None) -> bool:
     """True once a rnn_poison_if_starved kernel has actually overwritten a buffer since the last rnn_persistent_check(): a host memory read
     (no synchronisation).  A caller that sees it should run rnn_persistent_check(), which raises, clears the record and moves the next
     recurrence calls onto the step kernels."""
-    return bool(_lib.load().ds2_rnn_poison_seen(_ctxp()))
+    return bool(_lib.load().ds2_rnn_poison_seen(_ctxp(device)))
 
 
-def rnn_persistent_counters():
+def rnn_persistent_counters(device=None):
     """(launches through the calling thread's context that starved, recurrence calls left on the step kernels before re-arming)."""
     out = (C.c_int * 2)()
-    _lib.check(_lib.load().ds2_rnn_persistent_counters(_ctxp(), C.cast(out, C.c_void_p)), "ds2_rnn_persistent_counters")
+    _lib.check(_lib.load().ds2_rnn_persistent_counters(_ctxp(device), C.cast(out, C.c_void_p)), "ds2_rnn_persistent_counters")
     return int(out[0]), int(out[1])
 
 
@@ -896,10 +935,10 @@ def wgrad_fits_beside_bwd_recurrence(gates: int, H: int) -> bool:
     return _CORESIDENT[key]
 
 
-def rnn_last_path() -> int:
+def rnn_last_path(device=None) -> int:
     """bit 0 / bit 1: the last rnn_fwd / rnn_bwd call ran as one persistent launch (and produced its optional outputs); bit 2: that
     backward launch was the K-split kernel (bf16 partial-dh exchange; results within a stated tolerance of the step kernels')"""
-    return _lib.load().ds2_rnn_last_path(_ctxp())
+    return _lib.load().ds2_rnn_last_path(_ctxp(device))
 
 
 def rnn_bwd(gates: int, dy: Tensor, gx: Optional[Tensor], aux: Tensor, hbuf: Tensor, wp_bwd: Tensor, lens_dev: Tensor, T: int, B: int, H: int,

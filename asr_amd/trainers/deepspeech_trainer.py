@@ -65,7 +65,10 @@ class DeepSpeechTrainer:
         self.overwrite_lr = overwrite_lr
         self._reducer = None
         self._rejected_losses = []          # loss values of steps the device gate rejected after step() had reported them (train() takes them back)
+        self._loss_corrections = []         # (reported - recomputed) loss of batches that were re-run after a starved launch
         self._unsettled = None
+        self._starved_report = None
+        self._last_prep = None
         self.load()
 
     # -- epoch loop (deepspeech_trainer.py:50-66) -------------------------------------------------
@@ -97,10 +100,23 @@ class DeepSpeechTrainer:
             if fused:
                 valid_loss, loss_value = self.step(data)
             else:
+                pct0 = data[2].clone()                            # fit() multiplies the percentages in place (A.5): a re-run needs the originals
                 valid_loss, loss, loss_value = self.fit(data)
-                if valid_loss:
+                for _attempt in range(3):
+                    if not valid_loss:
+                        break
                     self._optimizer.zero_grad()
                     loss.backward()
+                    if getattr(self._model, "_flat", None) is None:
+                        break                                     # (not an asr_amd model: nothing to check)
+                    torch.cuda.synchronize(self._device)
+                    if not self._persistent_starved():            # a starved BACKWARD recurrence left invalid gradients: never apply them
+                        break
+                    self._restore_bn_stats(self._step_index)      # the re-run's forward repeats this batch's running-statistics update
+                    valid_loss, loss, loss_value = self.fit((data[0], data[1], pct0.clone(), data[3]))
+                else:
+                    valid_loss = False
+                if valid_loss:
                     self._optimizer.step()
             if valid_loss:
                 current.loss += loss_value
@@ -120,32 +136,44 @@ class DeepSpeechTrainer:
         inputs, targets, input_percentages, target_sizes = data
         input_sizes = input_percentages.mul_(int(inputs.size(3))).int()      # in place + fp32 truncation (A.5)
         inputs = inputs.to(self._device)
-        out, output_sizes = self._model.forward(inputs, input_sizes)
-        out = out.transpose(0, 1)                                            # TxNxC
-        float_out = out.float()
-        if not isinstance(self.criterion, CTCLoss):
-            float_out = float_out.log_softmax(2)        # torch criterion: keep the reference's op sequence
-        # (asr_amd.CTCLoss fuses the row log-softmax into the CTC kernels)
-        loss = self.criterion(float_out, targets, output_sizes, target_sizes).to(self._device)
-        loss = loss / inputs.size(0)
-        loss_value = loss.item()
-        starved = self._persistent_starved()
+        hip_model = getattr(self._model, "_ensure_flat", None) is not None and getattr(self._model, "bidirectional", True) and inputs.is_cuda
+        for _attempt in range(3):
+            if hip_model:
+                self._model._ensure_flat(inputs.device)
+                self._step_index = getattr(self, "_step_index", -1) + 1
+                self._snapshot_bn_stats(self._step_index)                    # (put back if this forward has to be repeated)
+            out, output_sizes = self._model.forward(inputs, input_sizes)
+            out = out.transpose(0, 1)                                        # TxNxC
+            float_out = out.float()
+            if not isinstance(self.criterion, CTCLoss):
+                float_out = float_out.log_softmax(2)    # torch criterion: keep the reference's op sequence
+            # (asr_amd.CTCLoss fuses the row log-softmax into the CTC kernels)
+            loss = self.criterion(float_out, targets, output_sizes, target_sizes).to(self._device)
+            loss = loss / inputs.size(0)
+            loss_value = loss.item()
+            starved = hip_model and self._persistent_starved()
+            if not starved:
+                break
+            # The reference never skips a VALID batch (deepspeech_trainer.py:86-97: only check_loss decides).  A starved persistent launch is
+            # this library's own failure, so the same batch is computed again: the library is in its cooldown now (one-launch-per-step
+            # kernels, which cannot starve) and the running statistics the invalid forward wrote are put back first.
+            self._restore_bn_stats(self._step_index)
         valid_loss, _ = check_loss(loss, loss_value)
         return valid_loss and not starved, loss, loss_value
 
     # -- fused step ---------------------------------------------------------------------------------
-    @staticmethod
-    def _persistent_starved() -> bool:
+    def _persistent_starved(self) -> bool:
         """True if a persistent recurrence launch starved during this step (not every workgroup could be resident: something else held CUs).
-        The step's results are then invalid: it is reported, skipped like a non-finite loss, and the library has already switched to
-        the one-launch-per-step kernels for the rest of the process."""
+        The step's results are then invalid: it is reported and counted, the library has switched to the one-launch-per-step kernels for its
+        cooldown, and the caller computes the SAME batch again on those (fit / train / _recover) — no batch is dropped, the sequence of
+        optimizer updates is the one an un-starved run makes."""
         try:
-            ops.rnn_persistent_check()
+            ops.rnn_persistent_check(self._device)
             return False
         except Exception as e:                                               # DS2LibraryError
             import sys
             DeepSpeechTrainer.starved_steps += 1
-            print(f"[asr_amd] step skipped: {e}", file=sys.stderr, flush=True)
+            print(f"[asr_amd] step re-run on the one-launch-per-step kernels: {e}", file=sys.stderr, flush=True)
             return True
 
     def _get_reducer(self):
@@ -156,7 +184,7 @@ class DeepSpeechTrainer:
             # recurrence (which needs every workgroup resident at once) must be off; "conv" (default: collectives only under the conv-stack
             # backward) and "serial" keep it.  The forward recurrence never overlaps a collective in any schedule.
             single = self._reducer.world == 1 and not self._reducer.force          # (a forced 1-rank run behaves like a multi-rank one)
-            ops.rnn_persistent_enable(True, single or not self._reducer.overlaps_recurrence)
+            ops.rnn_persistent_enable(True, single or not self._reducer.overlaps_recurrence, device=self._device)
         return self._reducer
 
     def step(self, data):
@@ -170,6 +198,9 @@ class DeepSpeechTrainer:
         rejected for another reason (a starved launch, another rank's loss) is reported — and the optimizer's step count corrected — when
         the next call (or `synchronize()`) reads the flag back."""
         model = self._model
+        if not getattr(model, "bidirectional", True):
+            raise NotImplementedError("DeepSpeechTrainer.step is the fused MI355X train step of the bidirectional model; a unidirectional model "
+                                      "(torch ops) trains through the reference's own loop: fit(data) -> loss.backward() -> optimizer.step()")
         if not isinstance(self._optimizer, FusedAdamW):
             return self._step_host_gated(data)
         inputs, targets, input_percentages, target_sizes = data
@@ -182,7 +213,8 @@ class DeepSpeechTrainer:
         # asynchronous copy from pinned memory: a pageable `.to(device)` is stream-ordered AND blocks the host, i.e. it would make the host
         # wait for the previous step's backward after all
         t_h, off_h, tl_h, max_u = _prep_targets_host(targets, target_sizes)
-        lens_dev, tg, off, tl = self._stage_ints(inputs.device, output_sizes.to(torch.int32), t_h, off_h, tl_h)
+        prep = (inputs, output_sizes.to(torch.int32), t_h, off_h, tl_h, max_u)      # everything a re-run of this batch needs (_recover)
+        lens_dev, tg, off, tl = self._stage_ints(inputs.device, *prep[1:5])
         main = torch.cuda.current_stream()
         with torch.no_grad():
             W = model._flat.tensors(model)
@@ -207,13 +239,14 @@ class DeepSpeechTrainer:
             pin["loss_done"].synchronize()                                   # the step's single host wait: CTC done (backward is running)
             loss_value = float(pin["loss"][0])
             prev_starved = self._settle()                                    # the PREVIOUS step's (rank-reduced) verdict is long available
+            if prev_starved:
+                # The previous step did not update the weights (device gate), and this step's recurrences were launched before that was
+                # known (the record they would have left has just been cleared with the other): neither is trusted, NEITHER IS DROPPED —
+                # both batches are computed again, in order, synchronously, on the step kernels of the cooldown (every rank takes this
+                # branch: the verdict is the reduced one).
+                return self._recover(prep)
             valid_loss, _ = check_loss(None, loss_value)
             gate = ops.step_gate(loss)                                       # device verdict of THIS step, behind backward in stream order
-            if prev_starved:
-                # this step's recurrences were launched before the starvation of the previous one was known (and the record it would have
-                # left has just been cleared with the other): do not trust them either
-                gate.zero_()
-                valid_loss = False
             gate = red.all_valid_device(gate)                                # MIN over ranks (no-op for one rank)
             self._optimizer.grad_scale = 1.0 / red.world
             self._optimizer.step(apply_flag=gate)
@@ -225,7 +258,66 @@ class DeepSpeechTrainer:
                 pin["gate_done"].record(pin["stream"])
             gate.record_stream(pin["stream"])
             self._unsettled, self._unsettled_loss, self._unsettled_index = valid_loss, loss_value, self._step_index
+            self._last_prep = prep
         return valid_loss, loss_value
+
+    def _run_sync(self, prep):
+        """One train step on a prepared batch, host-gated (one full synchronisation): forward, CTC, backward, all-reduce, starvation check,
+        optimizer.  A starved launch (impossible during a cooldown, possible in the host-gated path of a torch optimizer) repeats the batch.
+        Returns (valid_loss, loss_value)."""
+        model = self._model
+        inputs, output_sizes, t_h, off_h, tl_h, max_u = prep
+        B = inputs.size(0)
+        valid_loss, loss_value = False, float("nan")
+        for _attempt in range(3):
+            lens_dev, tg, off, tl = self._stage_ints(inputs.device, output_sizes, t_h, off_h, tl_h)
+            with torch.no_grad():
+                W = model._flat.tensors(model)
+                Gr = model._flat.tensors(model, grads=True)
+                self._step_index = getattr(self, "_step_index", -1) + 1
+                self._snapshot_bn_stats(self._step_index)
+                logits, ctx = engine.forward(W, model._cfg, inputs, lens_dev, training=True, save=True)
+                nll, dlogits = ops.ctc_loss(logits, tg, off, lens_dev, tl, max_u, 1.0 / B, want_grad=True)
+                loss = ops.ctc_batch_mean(nll)[0]
+                red = self._get_reducer()
+                engine.backward(W, Gr, model._cfg, ctx, dlogits, on_bucket=red.on_bucket if red.active else None)
+                red.finish()
+                loss_value = loss.item()
+                torch.cuda.synchronize(inputs.device)
+                starved = self._persistent_starved()                         # the device is idle here
+                if not red.all_valid(not starved, inputs.device):            # starved on ANY rank: every rank repeats the batch
+                    self._restore_bn_stats(self._step_index)
+                    continue
+                valid_loss, _ = check_loss(loss, loss_value)
+                valid_loss = red.all_valid(valid_loss, inputs.device)
+                if valid_loss and isinstance(self._optimizer, FusedAdamW):
+                    self._optimizer.grad_scale = 1.0 / red.world
+                    self._optimizer.step()
+                elif valid_loss:
+                    for n, p in model.named_parameters():                    # torch AdamW skips parameters without a gradient: frozen ones get none
+                        p.grad = (Gr[n] if red.world == 1 else Gr[n] / red.world) if p.requires_grad else None
+                    self._optimizer.step()
+                return valid_loss, loss_value
+        print("[asr_amd] a persistent recurrence starved three times in a row on the same batch: batch skipped", flush=True)
+        return False, loss_value
+
+    def _recover(self, prep_cur):
+        """After _settle() reported the previous step starved: compute that batch again (the weights did not move, the BatchNorm statistics
+        are back to what they were before it), then the current one.  The epoch-loss bookkeeping is corrected for what step() had
+        reported for the previous batch.  prep_cur None: only the previous batch (synchronize() at the end of an epoch)."""
+        torch.cuda.synchronize(self._device)
+        reported_valid, reported_loss = self._starved_report
+        self._starved_report = None
+        valid_p, loss_p = self._run_sync(self._last_prep)
+        if valid_p:
+            self._loss_corrections.append((reported_loss if reported_valid else 0.0) - loss_p)   # train() added `reported_loss` (or nothing)
+        elif reported_valid:
+            self._rejected_losses.append(reported_loss)
+        if prep_cur is None:
+            return None
+        out = self._run_sync(prep_cur)
+        self._last_prep = prep_cur
+        return out
 
     def _stage_ints(self, device, *cpu_int32):
         """One pinned staging buffer, one non-blocking H2D copy; returns device views (16-byte aligned starts).  The buffer is reused
@@ -263,11 +355,12 @@ class DeepSpeechTrainer:
         if not applied:
             self._optimizer.undo_step_count()
             own = self._persistent_starved() if starved_any else False       # this rank's own record (counted, printed, cleared, cooldown)
-            if pending:                                                      # not explained by this rank's own loss
-                if starved_any and not own:
-                    print("[asr_amd] step skipped on every rank: a persistent recurrence launch starved on another rank", flush=True)
-                elif not starved_any:
-                    print("[asr_amd] step skipped on every rank: another rank's loss was not valid", flush=True)
+            if starved_any and not own:
+                print("[asr_amd] step re-run on every rank: a persistent recurrence launch starved on another rank", flush=True)
+            if starved_any:
+                self._starved_report = (bool(pending), self._unsettled_loss)   # _recover() re-runs the batch and settles the bookkeeping
+            elif pending:                                                    # not explained by this rank's own loss
+                print("[asr_amd] step skipped on every rank: another rank's loss was not valid", flush=True)
                 # the step's loss was reported as valid (and train() has added it to the epoch loss) before this verdict existed:
                 # hand it back so that the bookkeeping matches the updates that were really applied
                 self._rejected_losses.append(self._unsettled_loss)
@@ -281,7 +374,8 @@ class DeepSpeechTrainer:
 
     def _take_back_rejected(self) -> float:
         """Sum of the loss values of steps that step() reported as valid but the device gate rejected afterwards (and forget them)."""
-        total = sum(self._rejected_losses)
+        total = sum(self._rejected_losses) + sum(self._loss_corrections)     # (corrections: a re-run batch's loss against what was reported)
+        self._loss_corrections = []
         if self._rejected_losses:
             print("Loss non valid, skipped")                                 # the reference's message, for the step it belongs to
             self._rejected_losses = []
@@ -307,7 +401,8 @@ class DeepSpeechTrainer:
 
     def synchronize(self):
         """Wait for everything enqueued by step() and settle the last step's device verdict (call before reading weights / counters)."""
-        self._settle()
+        if self._settle():
+            self._recover(None)
         torch.cuda.synchronize(self._device)
 
     def _step_host_gated(self, data):
@@ -316,35 +411,10 @@ class DeepSpeechTrainer:
         inputs, targets, input_percentages, target_sizes = data
         input_sizes = input_percentages.mul_(int(inputs.size(3))).int()
         inputs = inputs.to(self._device, non_blocking=True)
-        B = inputs.size(0)
         output_sizes = model.get_seq_lens(input_sizes.cpu().int())
         model._ensure_flat(inputs.device)
-        lens_dev = output_sizes.to(inputs.device, non_blocking=True)
-        tg, off, tl, max_u = _prep_targets(targets, target_sizes, inputs.device)
-        with torch.no_grad():
-            W = model._flat.tensors(model)
-            Gr = model._flat.tensors(model, grads=True)
-            self._step_index = getattr(self, "_step_index", -1) + 1
-            self._snapshot_bn_stats(self._step_index)
-            logits, ctx = engine.forward(W, model._cfg, inputs, lens_dev, training=True, save=True)
-            nll, dlogits = ops.ctc_loss(logits, tg, off, lens_dev, tl, max_u, 1.0 / B, want_grad=True)
-            loss = ops.ctc_batch_mean(nll)[0]
-            red = self._get_reducer()
-            engine.backward(W, Gr, model._cfg, ctx, dlogits, on_bucket=red.on_bucket if red.active else None)
-            red.finish()
-            loss_value = loss.item()
-            starved = self._persistent_starved()                             # the device is idle here
-            if not red.all_valid(not starved, inputs.device):                # starved on ANY rank: every rank drops this forward's BatchNorm update
-                self._restore_bn_stats(self._step_index)
-                starved = True
-            valid_loss, _ = check_loss(loss, loss_value)
-            valid_loss = valid_loss and not starved                          # a starved step is skipped like a non-finite loss (on every rank)
-            valid_loss = red.all_valid(valid_loss, inputs.device)
-            if valid_loss:
-                for n, p in model.named_parameters():                        # torch AdamW skips parameters without a gradient: frozen ones get none
-                    p.grad = (Gr[n] if red.world == 1 else Gr[n] / red.world) if p.requires_grad else None
-                self._optimizer.step()
-        return valid_loss, loss_value
+        t_h, off_h, tl_h, max_u = _prep_targets_host(targets, target_sizes)
+        return self._run_sync((inputs, output_sizes.to(torch.int32), t_h, off_h, tl_h, max_u))
 
     # -- eval / bookkeeping (deepspeech_trainer.py:119-137) ----------------------------------------
     def test(self, test_loader):

@@ -40,6 +40,17 @@ F32_NOTE = ("fp32 storage, state, accumulation, BatchNorm, CTC, optimizer, conv 
             "recurrences (where the shape fits) and conv2's backward take each fp32 operand as TWO bf16 terms (hi + lo) and form a product as "
             "hi.hi + hi.lo + lo.hi on the bf16 matrix cores with fp32 accumulation: 4e-6 / 1e-6 / 2e-5 of the fp64 result "
             "(DS2_F32_GEMM=f32 DS2_F32_RNN=f32 DS2_F32_CONV=f32: the fp32-input MFMA kernels)")
+
+
+def dtype_label(dtype):
+    """What "f32" means in THIS process: "fp32-grade (bf16x3)" when any of the three product families runs as three-term split-bf16 products
+    (the default), "f32" only when DS2_F32_GEMM = DS2_F32_RNN = DS2_F32_CONV = f32 select the fp32-input MFMA kernels throughout."""
+    if dtype != "f32":
+        return dtype
+    from asr_amd import engine as _eng
+    return "f32" if (_eng.F32_GEMM, _eng.F32_RNN, _eng.F32_CONV) == ("f32", "f32", "f32") else "fp32-grade (bf16x3)"
+
+
 FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, dense f32-input matrix rate
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # same guide: dense bf16 MFMA (the 5 PF marketing figure is 2:1 sparse)
 # fp32 mode, split kernels: an fp32-grade product is THREE bf16 MFMA products (hi.hi + hi.lo + lo.hi), so the roof of such a kernel, in
@@ -424,7 +435,7 @@ def quick_workload(workload, dtype, dev, steps, warmup):
     from asr_amd import engine as _eng
     step_peak = SPLIT_BF16_PEAK_TFLOPS if (dtype != "bf16" and _eng.F32_GEMM == "split") else peak      # the GEMMs' roof in this mode
     out = {"workload": f"{workload}: DS2 {L}x{H} bi-{rnn.upper()} {dtype}, T_in {tin}, batch {B}" + (", length-bucketed bins" if len(batches) > 1 else ""),
-           **({"dtype_note": F32_NOTE} if dtype == "f32" else {}),
+           "dtype": dtype_label(dtype), **({"dtype_note": F32_NOTE} if dtype_label(dtype).startswith("fp32-grade") else {}),
            "steps": steps, "ms_per_step": ms, "utterances_per_sec": B * steps / dt, "loss": lv, "valid_last_step": bool(valid),
            "step_tflops": flops / (ms * 1e-3) / 1e12, "step_frac_of_matrix_peak": flops / (ms * 1e-3) / 1e12 / step_peak, "matrix_peak_tflops": step_peak,
            **({"matrix_peak_note": SPLIT_PEAK_NOTE, "step_vs_fp32_mfma_peak": flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS} if step_peak != peak else {}),
@@ -435,6 +446,23 @@ def quick_workload(workload, dtype, dev, steps, warmup):
     del tr, batches
     torch.cuda.empty_cache()
     return out
+
+
+def quick_workload_true_f32(workload, steps, limit_s=120):
+    """quick_workload(workload, "f32") in a child process with DS2_F32_GEMM / _RNN / _CONV = f32: the fp32-INPUT MFMA kernels for every product
+    (the reference's own arithmetic, `v_mfma_f32_32x32x2_f32` / `16x16x4_f32`) instead of the default three-term split-bf16 products — the
+    selectors are read once per process, hence the child."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--quick-worker", workload, "f32", str(steps)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=limit_s,
+                           env=dict(os.environ, DS2_F32_GEMM="f32", DS2_F32_RNN="f32", DS2_F32_CONV="f32", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+        for line in r.stdout.splitlines():
+            if line.startswith("QUICK_JSON "):
+                return json.loads(line[len("QUICK_JSON "):])
+        return {"error": "worker failed: " + (r.stderr or r.stdout)[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"error": f"worker exceeded {limit_s}s"}
 
 
 def dp_path_one_rank(limit_s=120):
@@ -547,6 +575,11 @@ def spawn_ranks(n):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--quick-worker":      # `bench.py --quick-worker c2 f32 6`: quick_workload in a child (its own DS2_F32_* env)
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        print("QUICK_JSON " + json.dumps(quick_workload(sys.argv[2], sys.argv[3], dev, int(sys.argv[4]), 2)), flush=True)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "--dp-one-rank-worker":
         torch.cuda.set_device(0)
         print("DP1_JSON " + json.dumps(dp_path_one_rank_worker(torch.device("cuda", 0))), flush=True)
@@ -840,8 +873,8 @@ def main():
             "metric": "utterances/sec (10 s, 161-bin) DS2 5x1024 BiGRU CTC train step" if args.workload == "c3"
                       else f"utterances/sec DS2 {L}x{H} bi-{rnn} CTC train step",
             "value": utts, "unit": "utterances/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
-            **({"dtype_note": F32_NOTE} if dtype == "f32" else {}),
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype_label(dtype),
+            **({"dtype_note": F32_NOTE} if dtype_label(dtype).startswith("fp32-grade") else {}),
             "data": "synthetic N(0,1) 161-bin spectrograms, random-init weights, random labels U=T_in/20",
             "config": {"workload": f"{args.workload}: DS2 {L}x{H} bi-{rnn.upper()} {dtype}, {tin} input frames ({tin // 100} s), "
                                    f"batch {B}/GPU, {C} classes", "global_batch": B * world, "parallelism": f"dp{world}",
@@ -869,6 +902,8 @@ def main():
                     other[name] = quick_workload(wl, dt_, dev, st, 2) if time.time() - t_other < 40 else {"skipped": "time box"}
                 except Exception as e:
                     other[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            # BASELINE configs[1] (1 x MI355X, fp32) on the reference's own arithmetic, next to the emulated one: fp32-input MFMA kernels throughout
+            other["c2_true_f32"] = quick_workload_true_f32("c2", 5) if time.time() - t_other < 60 else {"skipped": "time box"}
             out["other_workloads"] = other
             out["dp_path_1rank"] = dp_path_one_rank() if time.time() - t_other < 60 else {"skipped": "time box"}
             model = tr = opt = batches = None

@@ -78,6 +78,9 @@ def model_state(shapes: dict, base_seed: int = 0) -> dict:
             hidden = shapes[hh_key][1]
             k = 1.0 / hidden ** 0.5
             out[key] = uniform(shape, s, -k, k)
+        elif key.startswith("lookahead."):                      # unidirectional variant: depthwise Conv1d (H, 1, context)
+            k = 1.0 / shape[-1] ** 0.5
+            out[key] = uniform(shape, s, -k, k)
         elif key == "fc.0.module.1.weight":
             k = 1.0 / shape[1] ** 0.5
             out[key] = uniform(shape, s, -k, k)

@@ -16,6 +16,10 @@ Outputs (committed, data only — expected outputs, never reference source):
     tests/golden/model_<name>.npz   whole model: logits, loss, grads (sub-sampled), BN running
                                     stats, 3 AdamW steps — reference statement sequence of
                                     DeepSpeechTrainer.fit + backward + AdamW.step
+    tests/golden/model_c3_full.npz, model_c2_full.npz   BASELINE configs[2] / [1] at FULL size (5x1024 B=64, 5x768 B=32, T_in 1001, ragged): one step
+                                    of the imported reference AND of the fp64 oracle — loss, per-utterance logit checksums, sub-sampled gradients
+                                    (`--only-full c3_full`, tens of minutes each; not part of the default run)
+    tests/golden/model_uni_gru_h16_l2.npz   the unidirectional variant (bidirectional=False + Lookahead), one step (`--only-uni`)
     tests/golden/ref_checkpoint_gru_16x2_c7.pth (+ _eval.npz)   a checkpoint in the reference trainer's wire format written from the
                                     reference's own model / torch AdamW / StepLR after one optimizer step, the reference model's eval
                                     probabilities and train-mode loss at those weights (`--only-checkpoint` regenerates it, byte-identical)
@@ -235,6 +239,163 @@ def gen_model(out, name, DeepSpeech, tmp):
     print(name, "losses", losses)
 
 
+def _full_t_ins(seed, b, lo):
+    rng = np.random.default_rng(seed)
+    t = sorted((int(v) for v in rng.integers(lo, 1002, size=b)), reverse=True)
+    t[0] = 1001
+    return t
+
+
+FULL = {
+    # BASELINE.json configs at their FULL size, ragged batch (one 10 s utterance, the rest lo/100 .. 10 s).
+    # name: (rnn, hidden, layers, classes, t_ins, data seed)
+    "c3_full": ("gru", 1024, 5, 29, _full_t_ins(5, 64, 701), 1),    # configs[2]: the metric configuration, per-GPU batch
+    "c2_full": ("gru", 768, 5, 29, _full_t_ins(6, 32, 801), 1),     # configs[1]
+    "dbg_full": ("gru", 32, 2, 7, [40, 33, 21], 1),                 # seconds: checks this generator itself (not committed)
+}
+FULL_MAX = 2048            # elements kept per tensor
+LOGIT_STRIDE = 97
+
+
+def sub_full(a: np.ndarray) -> np.ndarray:
+    f = np.asarray(a).reshape(-1)
+    return f if f.size <= FULL_MAX else f[::-(-f.size // FULL_MAX)]
+
+
+def _logit_record(rec, tag, logits, out_lens):
+    """per-utterance checksums over the valid frames + a strided sub-sample of them (logits beyond a length are garbage by contract, A.3)"""
+    lg = np.asarray(logits, dtype=np.float64)
+    rec[f"logitsum_{tag}"] = np.array([lg[b, :int(n)].sum() for b, n in enumerate(out_lens)])
+    rec[f"logitnorm_{tag}"] = np.array([np.sqrt((lg[b, :int(n)] ** 2).sum()) for b, n in enumerate(out_lens)])
+    rec[f"logits_{tag}"] = np.concatenate([lg[b, :int(n)].reshape(-1)[::LOGIT_STRIDE] for b, n in enumerate(out_lens)])
+
+
+def gen_model_full(out, name, DeepSpeech, tmp):
+    """ONE train step (fit + backward, deepspeech_trainer.py:102-117, :86-87) of the imported reference at a BASELINE configuration's full
+    size, and the same step by the fp64 oracle (oracle/ds2_oracle.py with dtype=float64 - the padded + masked restatement that the small
+    fixtures pin): loss, per-utterance logit checksums + sub-sample, every parameter gradient sub-sampled (<= FULL_MAX elements each) with
+    its full-tensor norm and sum, and the full-tensor distance between the reference's fp32 gradient and the fp64 one - the round-off the
+    reference itself carries, which is what a tolerance for ill-conditioned gradients (the conv biases in front of a BatchNorm) has to be
+    measured against.  Tens of minutes on 8 cores."""
+    import time
+    from torch.utils.checkpoint import checkpoint
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import ds2_oracle as O
+    rnn, hidden, layers, classes, t_ins, seed = FULL[name]
+    torch.set_num_threads(os.cpu_count() or 1)
+    model = DeepSpeech(audio_conf=audio_conf(), decoder=None, label_path=label_csv(tmp, classes),
+                       rnn_type={"gru": "nn.GRU", "lstm": "nn.LSTM"}[rnn], rnn_hidden_size=hidden,
+                       rnn_hidden_layers=layers, bidirectional=True)
+    shapes = det.state_shapes(rnn, hidden, layers, classes)
+    weights = det.model_state(shapes, base_seed=0)
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in weights.items()}
+    model.load_state_dict(sd)
+    model.train()
+    x, targets, pct, tsz = det.batch(len(t_ins), t_ins, classes, seed=seed)
+    inputs, targets, tsz = torch.from_numpy(x), torch.from_numpy(targets), torch.from_numpy(tsz)
+    criterion = torch.nn.CTCLoss(reduction="sum")
+    rec = {}
+    t0 = time.time()
+    cache = os.path.join(os.path.dirname(os.path.dirname(HERE)), "gpurun_out", "gold", f"ref_part_{name}.npz")   # (scratch: the reference half alone is minutes)
+    if os.path.exists(cache):
+        zc = np.load(cache)
+        rec = {k: zc[k] for k in zc.files if not k.startswith("fullgrad_")}
+        gref = {k[len("fullgrad_"):]: zc[k] for k in zc.files if k.startswith("fullgrad_")}
+        print(name, "reference step: loaded from", cache, flush=True)
+    else:
+        # ---- reference statement sequence: deepspeech_trainer.py:102-117 (fit), :86-87 (zero_grad, backward) ----
+        input_percentages = torch.from_numpy(pct.copy())
+        input_sizes = input_percentages.mul_(int(inputs.size(3))).int()
+        o, output_sizes = model.forward(inputs, input_sizes)
+        o = o.transpose(0, 1)
+        float_out = o.float().log_softmax(2)
+        loss = criterion(float_out, targets, output_sizes, tsz)
+        loss = loss / inputs.size(0)
+        rec["loss_ref"] = np.array(loss.item(), dtype=np.float64)
+        model.zero_grad()
+        loss.backward()
+        print(name, "reference step", f"{time.time() - t0:.0f} s", "loss", float(rec["loss_ref"]), flush=True)
+        rec["input_sizes"] = input_sizes.numpy()
+        rec["output_sizes"] = output_sizes.numpy()
+        _logit_record(rec, "ref", o.detach().transpose(0, 1).numpy(), output_sizes.numpy())
+        gref = {k: p.grad.detach().numpy().copy() for k, p in model.named_parameters()}
+        for k, v in model.state_dict().items():
+            if "running_" in k:
+                rec["buf_" + k] = v.numpy().copy()
+        os.makedirs(os.path.dirname(cache), exist_ok=True)
+        np.savez(cache, **rec, **{"fullgrad_" + k: v for k, v in gref.items()})
+        del o, float_out, loss
+    del model
+
+    # ---- the same step by the fp64 oracle; the recurrences are re-run in backward (checkpoint) so that the graph of one direction at a
+    # time is alive (40 GB otherwise)
+    t0 = time.time()
+    saved = (O.gru_direction, O.lstm_direction)
+    O.gru_direction = lambda *a, _f=saved[0]: checkpoint(_f, *a, use_reentrant=False)
+    O.lstm_direction = lambda *a, _f=saved[1]: checkpoint(_f, *a, use_reentrant=False)
+    # (ATen has no blocked fp64 convolution on the CPU: it unfolds the whole batch, 78 GB for conv2 at B = 64 - a few utterances at a time instead,
+    # the same sums)
+    conv2d = torch.nn.functional.conv2d
+    torch.nn.functional.conv2d = lambda a, w, b=None, **kw: (conv2d(a, w, b, **kw) if a.size(0) <= 2 else
+                                                             torch.cat([conv2d(a[i:i + 2], w, b, **kw) for i in range(0, a.size(0), 2)]))
+    try:
+        r64 = O.fit_and_grads(sd, inputs, targets, torch.from_numpy(pct.copy()), tsz, dtype=torch.float64)
+    finally:
+        O.gru_direction, O.lstm_direction = saved
+        torch.nn.functional.conv2d = conv2d
+    print(name, "fp64 oracle step", f"{time.time() - t0:.0f} s", "loss", r64["loss"], flush=True)
+    rec["loss_f64"] = np.array(r64["loss"], dtype=np.float64)
+    assert np.array_equal(r64["out_lens"].numpy(), rec["output_sizes"])
+    _logit_record(rec, "f64", r64["logits"].numpy(), rec["output_sizes"])
+    for k, g in gref.items():
+        g64 = r64["grads"][k].numpy()
+        rec["grad_ref_" + k] = sub_full(g)
+        rec["grad_f64_" + k] = sub_full(g64)
+        rec["gradnorm_ref_" + k] = np.array(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        rec["gradnorm_f64_" + k] = np.array(np.sqrt((g64 ** 2).sum()))
+        rec["gradsum_ref_" + k] = np.array(g.astype(np.float64).sum())
+        rec["gradsum_f64_" + k] = np.array(g64.sum())
+        rec["graddist_ref_f64_" + k] = np.array(np.sqrt(((g.astype(np.float64) - g64) ** 2).sum()))
+    worst = max(gref, key=lambda k: float(rec["graddist_ref_f64_" + k] / max(float(rec["gradnorm_f64_" + k]), 1e-30)))
+    print(name, "reference fp32 vs fp64: loss", abs(float(rec["loss_ref"]) - float(rec["loss_f64"])) / float(rec["loss_f64"]),
+          "worst gradient", worst, float(rec["graddist_ref_f64_" + worst] / rec["gradnorm_f64_" + worst]), flush=True)
+    rec["cfg"] = np.array(json.dumps(dict(rnn=rnn, hidden=hidden, layers=layers, classes=classes, t_ins=t_ins, seed=seed,
+                                          full_max=FULL_MAX, logit_stride=LOGIT_STRIDE)))
+    np.savez_compressed(os.path.join(out, f"model_{name}.npz"), **rec)
+    print(name, os.path.getsize(os.path.join(out, f"model_{name}.npz")), "bytes", flush=True)
+
+
+def gen_model_uni(out, DeepSpeech, tmp):
+    """The unidirectional variant (bidirectional=False + Lookahead, deepspeech.py:83-101, blocks.py:96-132): one step of the reference's
+    statement sequence -> logits, loss, every gradient, eval-mode probabilities.  Small (it pins asr_amd's torch-op branch for this variant)."""
+    rnn, hidden, layers, classes, context, t_ins, seed = "gru", 16, 2, 7, 5, [40, 33, 21], 3
+    model = DeepSpeech(audio_conf=audio_conf(), decoder=None, label_path=label_csv(tmp, classes), rnn_type="nn.GRU", rnn_hidden_size=hidden,
+                       rnn_hidden_layers=layers, bidirectional=False, context=context)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    weights = det.model_state(shapes, base_seed=0)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in weights.items()})
+    model.train()
+    x, targets, pct, tsz = det.batch(len(t_ins), t_ins, classes, seed=seed)
+    inputs = torch.from_numpy(x)
+    input_sizes = torch.from_numpy(pct.copy()).mul_(int(inputs.size(3))).int()
+    o, output_sizes = model.forward(inputs, input_sizes)
+    loss = torch.nn.CTCLoss(reduction="sum")(o.transpose(0, 1).float().log_softmax(2), torch.from_numpy(targets), output_sizes, torch.from_numpy(tsz))
+    loss = loss / inputs.size(0)
+    model.zero_grad()
+    loss.backward()
+    rec = {"logits": o.detach().numpy(), "loss": np.array(loss.item()), "output_sizes": output_sizes.numpy()}
+    for k, p in model.named_parameters():
+        rec["grad_" + k] = subsample(p.grad.detach().numpy())
+        rec["gradnorm_" + k] = np.array(float(p.grad.detach().double().norm()))
+    model.eval()
+    with torch.no_grad():
+        rec["eval_probs"] = model.forward(inputs, torch.from_numpy(pct.copy()).mul_(int(inputs.size(3))).int())[0].numpy()
+    rec["cfg"] = np.array(json.dumps(dict(rnn=rnn, hidden=hidden, layers=layers, classes=classes, context=context, t_ins=t_ins, seed=seed,
+                                          shapes={k: list(v) for k, v in shapes.items()})))
+    np.savez_compressed(os.path.join(out, "model_uni_gru_h16_l2.npz"), **rec)
+    print("uni", float(rec["loss"]), os.path.getsize(os.path.join(out, "model_uni_gru_h16_l2.npz")), "bytes")
+
+
 def gen_manifest(out, DeepSpeech, tmp):
     man = {}
     for rnn, hidden, layers, classes in (("gru", 32, 2, 7), ("lstm", 24, 2, 7), ("gru", 768, 5, 29)):
@@ -434,6 +595,14 @@ def main():
         with tempfile.TemporaryDirectory() as tmp:
             gen_checkpoint(out, DeepSpeech, tmp)
         return
+    if "--only-uni" in sys.argv:
+        with tempfile.TemporaryDirectory() as tmp:
+            gen_model_uni(out, DeepSpeech, tmp)
+        return
+    if "--only-full" in sys.argv:                      # model_c3_full.npz / model_c2_full.npz: tens of minutes each, not part of the default run
+        with tempfile.TemporaryDirectory() as tmp:
+            gen_model_full(out, sys.argv[sys.argv.index("--only-full") + 1], DeepSpeech, tmp)
+        return
     if "--only-model" in sys.argv:                     # regenerate one model fixture without touching the others
         with tempfile.TemporaryDirectory() as tmp:
             gen_model(out, sys.argv[sys.argv.index("--only-model") + 1], DeepSpeech, tmp)
@@ -447,6 +616,7 @@ def main():
             gen_model(out, name, DeepSpeech, tmp)
         gen_checkpoint(out, DeepSpeech, tmp)
         gen_data_formats(out, tmp)
+        gen_model_uni(out, DeepSpeech, tmp)
     for f in sorted(os.listdir(out)):
         if f.endswith((".npz", ".json")):
             print(f, os.path.getsize(os.path.join(out, f)))

@@ -188,33 +188,42 @@ from test_gpu_model import make_model
 from asr_amd import CTCLoss, FusedAdamW, ops, _lib
 from asr_amd.trainers import DeepSpeechTrainer
 B, tin, C = 16, 101, 29
-torch.manual_seed(0)
-model = make_model(dict(rnn="gru", hidden=256, layers=2, classes=C))
-model.precision = "bf16"
-opt = FusedAdamW(model, lr=1.5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5)
 dev = torch.device("cuda", 0)
-tr = DeepSpeechTrainer(model, CTCLoss(reduction="sum"), 1, None, opt, None, None, dev, dev, False, None)
-x, targets, pct, tsz = bench.synthetic_batch(B, tin, C, 1)
-x = x.cuda()
-model._ensure_flat(dev)
-tr._get_reducer()                                         # (creates the reducer: it arms both persistent kernels)
-ops.rnn_persistent_enable(False, True)                    # forward on the step kernels (a valid loss), backward persistent: that one starves
-flat, _ = model.flat_parameters()
-w0 = flat.detach().clone()
-st0, ct0 = model._flat.stats.detach().clone(), model._flat.counters.detach().clone()
-# DS2_RNN_SPIN_LIMIT=0: the persistent launches of step 0 give up at their first failed poll -> the device gate rejects the step
-v0, l0 = tr.step((x, targets, pct.clone(), tsz))
-v1, l1 = tr.step((x, targets, pct.clone(), tsz))          # discovers the starvation of step 0 (settle), is itself not trusted
-tr.synchronize()
-taken_back = tr._take_back_rejected()
-res = {"v0": bool(v0), "v1": bool(v1), "weights_unchanged": bool(torch.equal(flat, w0)), "stats_restored": bool(torch.equal(model._flat.stats, st0)),
-       "counters_restored": bool(torch.equal(model._flat.counters, ct0)), "taken_back": taken_back, "l0": l0, "starved_steps": DeepSpeechTrainer.starved_steps,
-       "opt_steps": int(opt.state["step"])}
-# the library now runs the one-launch-per-step kernels for DS2_RNN_REARM_CALLS calls: a normal step goes through and updates everything
-v2, l2 = tr.step((x, targets, pct.clone(), tsz))
-tr.synchronize()
-res.update({"v2": bool(v2), "weights_moved": bool(not torch.equal(flat, w0)), "stats_moved": bool(not torch.equal(model._flat.stats, st0)),
-            "counters_after": model._flat.counters.tolist(), "rejected_after": tr._take_back_rejected()})
+batches = [bench.synthetic_batch(B, tin, C, 1 + 2 * k, ragged=False) for k in range(3)]
+batches = [(x.cuda(), t, p, z) for x, t, p, z in batches]
+
+def run(persistent_bwd):
+    torch.manual_seed(0)
+    model = make_model(dict(rnn="gru", hidden=256, layers=2, classes=C))
+    model.precision = "bf16"
+    opt = FusedAdamW(model, lr=1.5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5)
+    tr = DeepSpeechTrainer(model, CTCLoss(reduction="sum"), 1, None, opt, None, None, dev, dev, False, None)
+    model._ensure_flat(dev)
+    tr._get_reducer()                                     # (creates the reducer: it arms both persistent kernels)
+    ops.rnn_persistent_enable(False, persistent_bwd)      # forward on the step kernels (a valid loss); the persistent backward starves
+    flat, _ = model.flat_parameters()
+    w0 = flat.detach().clone()
+    out = []
+    for x, t, p, z in batches:
+        out.append(tr.step((x, t, p.clone(), z)))
+    tr.synchronize()
+    return model, opt, tr, flat, w0, out
+
+# reference run: every recurrence on the one-launch-per-step kernels, nothing can starve
+mA, oA, tA, fA, w0, outA = run(False)
+wA, stA, ctA = fA.detach().clone(), mA._flat.stats.detach().clone(), mA._flat.counters.detach().clone()
+starved_before = DeepSpeechTrainer.starved_steps
+# DS2_RNN_SPIN_LIMIT=0: the persistent backward launches of step 0 give up at their first failed poll -> the device gate rejects the step;
+# step 1 discovers it (settle) and BOTH batches are computed again on the step kernels of the cooldown (DS2_RNN_REARM_CALLS=8 = two steps
+# of this 2-layer model); step 2 runs persistent again, starves, and is re-run by synchronize()
+model, opt, tr, flat, w0b, outB = run(True)
+reported = sum(l for v, l in outB if v) - tr._take_back_rejected()
+res = {"same_start": bool(torch.equal(w0, w0b)), "weights_moved": bool(not torch.equal(flat, w0b)),
+       "weights_equal_step_kernel_run": bool(torch.equal(flat, wA)), "stats_equal": bool(torch.equal(model._flat.stats, stA)),
+       "counters_equal": bool(torch.equal(model._flat.counters, ctA)), "counters_after": model._flat.counters.tolist(),
+       "starved_steps": DeepSpeechTrainer.starved_steps - starved_before, "opt_steps": int(opt.state["step"]), "opt_steps_ref": int(oA.state["step"]),
+       "epoch_loss": reported, "epoch_loss_ref": sum(l for v, l in outA if v), "valid": [bool(v) for v, _ in outB], "valid_ref": [bool(v) for v, _ in outA]}
+x, targets, pct, tsz = batches[0]
 # inference while the persistent kernels are armed again and starve: NaN logits without a host sync, then the check raises
 ops.rnn_persistent_enable(True, True)
 model.eval()
@@ -236,21 +245,166 @@ print("STARVE_JSON " + json.dumps(res))
 '''
 
 
-def test_starved_step_bookkeeping_and_inference_poison(tmp_path):
-    """a train step whose persistent recurrence starved (forced: DS2_RNN_SPIN_LIMIT=0) is rejected by the device gate one step
-    late.  The weights stay untouched, the BatchNorm running statistics and counters written by the two un-trusted forwards are put back,
-    the loss that step() had already reported as valid is handed back to train()'s bookkeeping; after the cooldown on the step kernels a
-    normal step updates everything.  Inference never synchronises the device per forward: a starved launch turns the logits into NaN in
-    stream order and the next check raises."""
+def test_starved_step_is_recomputed_not_dropped_and_inference_poison(tmp_path):
+    """a train step whose persistent recurrence starved (forced: DS2_RNN_SPIN_LIMIT=0) is rejected by the device gate
+    one step late — and then COMPUTED AGAIN on the one-launch-per-step kernels, together with the step that was launched before the starvation
+    was known.  The reference never skips a valid batch (deepspeech_trainer.py:86-97): after three batches the weights, the BatchNorm running
+    statistics / counters and the optimizer's step count are bit-identical to a run that used the step kernels throughout, the starved
+    launches are counted, the epoch-loss bookkeeping equals the clean run's.  Inference never synchronises the device per forward: a starved
+    launch turns the logits into NaN in stream order and the next check raises."""
     script = str(tmp_path / "starve_step.py")
     open(script, "w").write(STARVE_STEP_WORKER)
     env = dict(os.environ, DS2_RNN_SPIN_LIMIT="0", DS2_RNN_REARM_CALLS="8")
     r = subprocess.run([sys.executable, script, ROOT], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     res = json.loads([l for l in r.stdout.splitlines() if l.startswith("STARVE_JSON ")][-1][len("STARVE_JSON "):])
-    assert res["v0"] and not res["v1"], res                     # step 0 looked valid when it returned; step 1 was not trusted
-    assert res["weights_unchanged"] and res["stats_restored"] and res["counters_restored"], res
-    assert res["starved_steps"] >= 1 and abs(res["taken_back"] - res["l0"]) < 1e-6 * abs(res["l0"]) and res["opt_steps"] == 0, res
-    assert res["v2"] and res["weights_moved"] and res["stats_moved"] and res["rejected_after"] == 0.0, res
-    assert set(res["counters_after"]) == {1}, res               # exactly one accepted training forward
+    assert res["same_start"] and res["weights_moved"], res
+    assert res["weights_equal_step_kernel_run"] and res["stats_equal"] and res["counters_equal"], res      # no batch lost, none applied twice
+    assert res["starved_steps"] >= 2 and res["opt_steps"] == res["opt_steps_ref"] == 3 and set(res["counters_after"]) == {3}, res
+    assert all(res["valid_ref"]) and abs(res["epoch_loss"] - res["epoch_loss_ref"]) <= 1e-6 * abs(res["epoch_loss_ref"]), res
     assert res.get("eval_finite_on_step_kernels", True) and res["eval_path_persistent"] and res["eval_nan"] and res["eval_check_raised"], res
+
+
+DP_STARVE_WORKER = r'''
+import os, sys, json
+import numpy as np, torch, torch.distributed as dist
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests")); sys.path.insert(0, os.path.join(root, "tests", "golden"))
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)             # two ranks share the one GPU: gloo moves the CUDA buckets
+import bench
+from test_gpu_model import make_model
+from asr_amd import CTCLoss, FusedAdamW, ops
+from asr_amd.trainers import DeepSpeechTrainer
+B, tin, C = 16, 101, 29
+dev = torch.device("cuda", 0)
+torch.manual_seed(0)
+model = make_model(dict(rnn="gru", hidden=128, layers=2, classes=C))      # H % 256 != 0: the all-gather backward kernel, bit-identical to the step kernels
+model.precision = "bf16"
+opt = FusedAdamW(model, lr=1.5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5)
+tr = DeepSpeechTrainer(model, CTCLoss(reduction="sum"), 1, None, opt, None, None, dev, dev, False, None)
+out = []
+for k in range(3):
+    x, t, p, z = bench.synthetic_batch(B, tin, C, 100 * rank + 1 + 2 * k)  # each rank its own shard
+    out.append(tr.step((x.cuda(), t, p.clone(), z)))
+tr.synchronize()
+reported = sum(l for v, l in out if v) - tr._take_back_rejected()
+flat, _ = model.flat_parameters()
+np.save(sys.argv[2] + f".rank{rank}.npy", flat.detach().cpu().numpy())
+print("DPSTARVE_JSON " + json.dumps({"rank": rank, "starved_steps": DeepSpeechTrainer.starved_steps, "opt_steps": int(opt.state["step"]),
+                                     "counters": model._flat.counters.tolist(), "epoch_loss": reported,
+                                     "persistent_seen": bool(ops.rnn_persistent_counters()[0] > 0 or ops.rnn_last_path() & 3)}))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_starved_rank_makes_every_rank_recompute_two_ranks_gloo(tmp_path):
+    """The data-parallel form of the test above: rank 1's persistent launches starve (DS2_RNN_SPIN_LIMIT=0 in that process only), rank 0's do
+    not.  The device verdict is the MIN over ranks, so BOTH ranks compute the starved batch (and the one launched behind it) again, in step,
+    with matching collectives: after three batches both replicas hold the same weights, bit-identical to those of a two-rank run that used
+    the one-launch-per-step kernels throughout (DS2_RNN_PERSISTENT=0); three optimizer updates, no batch lost, same epoch loss."""
+    script = str(tmp_path / "w.py")
+    open(script, "w").write(DP_STARVE_WORKER)
+    results = {}
+    for tag, envs in (("starve", ({}, {"DS2_RNN_SPIN_LIMIT": "0", "DS2_RNN_REARM_CALLS": "8"})),
+                      ("steps", ({"DS2_RNN_PERSISTENT": "0"}, {"DS2_RNN_PERSISTENT": "0"}))):
+        out = str(tmp_path / tag)
+        procs = []
+        for r in range(2):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29611 + (tag == "steps")),
+                       HSA_ENABLE_IPC_MODE_LEGACY="0", **envs[r])
+            procs.append(subprocess.Popen([sys.executable, script, ROOT, out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+        outs = [p.communicate(timeout=600)[0] for p in procs]
+        assert all(p.returncode == 0 for p in procs), outs
+        recs = [json.loads([l for l in o.splitlines() if l.startswith("DPSTARVE_JSON ")][-1][len("DPSTARVE_JSON "):]) for o in outs]
+        results[tag] = (sorted(recs, key=lambda d: d["rank"]), [np.load(out + f".rank{r}.npy") for r in range(2)])
+    (rs, ws), (rc, wc) = results["starve"], results["steps"]
+    assert np.array_equal(ws[0], ws[1]) and np.array_equal(wc[0], wc[1])                  # replicas stay bit-identical
+    assert np.array_equal(ws[0], wc[0])                                                  # ... and equal the run that could not starve
+    assert rs[1]["starved_steps"] >= 1 and rs[0]["starved_steps"] == 0 and rc[0]["starved_steps"] == rc[1]["starved_steps"] == 0, (rs, rc)
+    for r in range(2):
+        assert rs[r]["opt_steps"] == rc[r]["opt_steps"] == 3 and set(rs[r]["counters"]) == {3}, (rs, rc)
+        assert abs(rs[r]["epoch_loss"] - rc[r]["epoch_loss"]) <= 1e-6 * abs(rc[r]["epoch_loss"]), (rs, rc)
+
+
+AUTOGRAD_STARVE_WORKER = r'''
+import os, sys, json
+import numpy as np, torch
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests")); sys.path.insert(0, os.path.join(root, "tests", "golden"))
+import bench
+from test_gpu_model import make_model
+from asr_amd import CTCLoss, ops, _lib
+from asr_amd.trainers import DeepSpeechTrainer
+B, tin, C = 16, 101, 29
+dev = torch.device("cuda", 0)
+batches = [bench.synthetic_batch(B, tin, C, 1 + 2 * k) for k in range(3)]
+res = {}
+# ---- (a) a backward recurrence launched by loss.backward() runs on autograd's worker thread: it must use (and leave its starvation record
+# in) the context of the thread that ran forward, where the enable switches were set and where the check is made
+torch.manual_seed(0)
+model = make_model(dict(rnn="gru", hidden=256, layers=2, classes=C))
+model.precision = "bf16"
+model._ensure_flat(dev)
+ops.rnn_persistent_enable(False, True)                    # forward on the step kernels; the persistent backward starves (DS2_RNN_SPIN_LIMIT=0)
+x, t, p, z = batches[0]
+out, ol = model.forward(x.cuda(), (p * x.size(3)).int())
+loss = CTCLoss(reduction="sum")(out.transpose(0, 1), t, ol, z) / B
+torch.cuda.synchronize()
+ops.rnn_persistent_check()                                # nothing starved so far
+loss.backward()
+torch.cuda.synchronize()
+res["backward_path_persistent"] = bool(ops.rnn_last_path() & 2)       # the main thread's context saw the worker thread's launch
+try:
+    ops.rnn_persistent_check()
+    res["check_raised"] = False
+except _lib.DS2LibraryError:
+    res["check_raised"] = True
+ops.rnn_persistent_enable(False, False)
+loss2 = CTCLoss(reduction="sum")(model.forward(x.cuda(), (p * x.size(3)).int())[0].transpose(0, 1), t, ol, z) / B
+model.zero_grad(); loss2.backward(); torch.cuda.synchronize()
+res["switch_reaches_autograd_backward"] = not bool(ops.rnn_last_path() & 2)
+while ops.rnn_persistent_counters()[1] > 0:               # burn the cooldown
+    model.zero_grad()
+    l3 = CTCLoss(reduction="sum")(model.forward(x.cuda(), (p * x.size(3)).int())[0].transpose(0, 1), t, ol, z) / B
+    l3.backward()
+torch.cuda.synchronize()
+del model
+
+# ---- (b) the reference-API loop (fit + loss.backward() + torch AdamW): a starved backward is computed again, never applied, never dropped
+def run(persistent_bwd):
+    torch.manual_seed(0)
+    model = make_model(dict(rnn="gru", hidden=256, layers=2, classes=C))
+    model.precision = "bf16"
+    opt = torch.optim.AdamW(model.parameters(), lr=1.5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5)
+    tr = DeepSpeechTrainer(model, CTCLoss(reduction="sum"), 1, None, opt, None, None, dev, dev, False, None)
+    model._ensure_flat(dev)
+    ops.rnn_persistent_enable(False, persistent_bwd)
+    tr.train([(x, t, p.clone(), z) for x, t, p, z in batches])
+    torch.cuda.synchronize()
+    return model.flat_parameters()[0].detach().clone(), model._flat.counters.tolist(), tr._metrics.train.current.loss
+wA, cA, lA = run(False)
+s0 = DeepSpeechTrainer.starved_steps
+wB, cB, lB = run(True)
+res.update({"fit_weights_equal": bool(torch.equal(wA, wB)), "fit_counters": cB, "fit_counters_ref": cA, "fit_starved": DeepSpeechTrainer.starved_steps - s0,
+            "fit_loss": lB, "fit_loss_ref": lA})
+print("AG_JSON " + json.dumps(res))
+'''
+
+
+def test_autograd_backward_uses_the_forward_threads_recurrence_context(tmp_path):
+    """ADVICE round 5 (medium): `loss.backward()` runs `_DS2Function.backward` on PyTorch's autograd worker thread.  The recurrence context
+    (enable switches, debug selectors, starvation record, cooldown) is captured in forward and bound around engine.backward, so (a) a backward
+    launch that starves is seen by `rnn_persistent_check()` on the calling thread and the persistent switches set there reach it, and (b) the
+    reference-API loop `fit` + `loss.backward()` + torch AdamW recomputes a batch whose backward starved: same weights, bit for bit, as a run on
+    the step kernels, no batch dropped."""
+    script = str(tmp_path / "ag.py")
+    open(script, "w").write(AUTOGRAD_STARVE_WORKER)
+    env = dict(os.environ, DS2_RNN_SPIN_LIMIT="0", DS2_RNN_REARM_CALLS="4")
+    r = subprocess.run([sys.executable, script, ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("AG_JSON ")][-1][len("AG_JSON "):])
+    assert res["backward_path_persistent"] and res["check_raised"] and res["switch_reaches_autograd_backward"], res
+    assert res["fit_weights_equal"] and res["fit_starved"] >= 1 and res["fit_counters"] == res["fit_counters_ref"], res
+    assert abs(res["fit_loss"] - res["fit_loss_ref"]) <= 1e-6 * abs(res["fit_loss_ref"]), res
