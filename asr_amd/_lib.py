@@ -48,6 +48,9 @@ SIGNATURES = {
     "ds2_gemm_bf16_tn_splitk_group": (i32, [i32, vp, i32, vp, sz, vp]),
     "ds2_gemm_bf16_nt": (i32, [i32, i32, i32, vp, i32, i64, vp, i32, i64, vp, i32, i64, vp, i32, i32, i32, vp, sz, vp]),
     "ds2_cast_bf16": (i32, [vp, i32, vp, i32, i32, i32, vp]),
+    "ds2_gemm_bf16_nt_obf16": (i32, [i32, i32, i32, vp, i32, vp, i32, vp, i32, vp, vp]),
+    "ds2_cast_f32_from_bf16": (i32, [vp, vp, i64, vp]),
+    "ds2_rnn_fwd_gxbf16": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, sz, vp]),
     "ds2_split_bf16": (i32, [vp, i32, vp, i32, i32, i32, i32, vp]),
     "ds2_cast_transpose_bf16": (i32, [vp, i32, vp, i32, i32, i32, vp]),
     "ds2_cast_bf16_both_workspace_bytes": (sz, [i32, i32]),

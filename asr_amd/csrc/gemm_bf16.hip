@@ -1067,6 +1067,7 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
 }
 
 #include "gemm_nt_ring.h"
+#include "permlane.h"
 #include "gemm_nt_w4.h"
 #include "gemm_tn_group.h"
 #include "gemm_tn_w4.h"
@@ -1207,6 +1208,51 @@ extern "C" int ds2_gemm_bf16_nt(int M, int N, int K, const void* A, int lda, lon
                        ldc, strideC, splitk, accumulate);
     DS2_LAUNCH_CHECK("splitk_reduce_bf_kernel");
   }
+  return 0;
+}
+
+// CU count of the CURRENT device and "has this per-function attribute been set on the current device" — per device id, so that a process
+// that drives two GPUs (device_test != device, two threads on two devices) never launches with the other device's grid size or without the
+// dynamic-LDS attribute
+static int ds2_cus_current() {
+  static int cus[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!cus[dev]) {
+    hipDeviceProp_t prop;
+    cus[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 1;
+  }
+  return cus[dev];
+}
+
+// C[M,N] **bf16** = A[M,K] bf16 * B[N,K]^T bf16 + bias (fp32 accumulation and bias add, one rounding at the store): the x-projections of a
+// recurrent layer in the bf16 training mode (aten::addmm inside aten::gru / lstm, blocks.py:76-78, 88), consumed once by ds2_rnn_fwd_gxbf16.
+// Four-wave 256 x 256 x 64 kernel only (gemm_nt_w4.h, OBF): returns 1 — nothing launched, call ds2_gemm_bf16_nt — where that kernel does not
+// apply (K % 64, fewer tiles than CUs, N % 8, alignment), 0 when launched, < 0 on error.
+extern "C" int ds2_gemm_bf16_nt_obf16(int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias, void* stream) {
+  DS2_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C, "ds2_gemm_bf16_nt_obf16: bad arguments M=%d N=%d K=%d", M, N, K);
+  DS2_REQUIRE((K % 8) == 0 && (lda % 8) == 0 && (ldb % 8) == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0,
+              "ds2_gemm_bf16_nt_obf16: K, lda, ldb must be multiples of 8 and the operands 16-byte aligned");
+  const int cus = ds2_cus_current();
+  const int ntx = ceil_div(N, 256), nty = ceil_div(M, 256);
+  const bool ok = (K % 64) == 0 && K >= 128 && (N % 8) == 0 && (ldc % 8) == 0 && ((uintptr_t)C % 16) == 0 && (!bias || ((uintptr_t)bias % 16) == 0) &&
+                  ntx * nty > cus && (long long)lda * 512 < (1ll << 31) && (long long)ldb * 512 < (1ll << 31);
+  if (!ok) return 1;
+  BArgs g;
+  g.A = (const __bf16*)A; g.B = (const __bf16*)B; g.C = (float*)C; g.bias = bias;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.sA = g.sB = g.sC = 0;
+  g.splitk = 1; g.kchunk = K; g.accumulate = 0; g.partial = nullptr;
+  g.nt_store = 1; g.super_rows = 4;
+  static bool attr[64] = {false};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!attr[dev]) {
+    DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_nt_w4_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS));
+    attr[dev] = true;
+  }
+  hipLaunchKernelGGL((gemm_bf16_nt_w4_kernel<0, true>), dim3(cus, 1, 1), dim3(256), W4_LDS, (hipStream_t)stream, g, ntx, nty);
+  DS2_LAUNCH_CHECK("gemm_bf16_nt_w4_kernel<obf16>");
   return 0;
 }
 
@@ -1384,6 +1430,24 @@ extern "C" int ds2_gemm_bf16_tn_group(int nprob, const ds2_tn_problem* probs, in
 }
 
 // dst (R, ldd) bf16 = cast(src (R, C) fp32, pitch lds); ldd % 8 == 0, ldd >= C, pad columns zero.
+// n contiguous bf16 -> fp32 (n % 8 == 0, 16-byte aligned): the widening of bf16 x-projections for a forward recurrence that cannot run as a
+// persistent launch (ds2_rnn_fwd_gxbf16 returned 1: cooldown after a starved launch, or a shape without a persistent kernel)
+__global__ __launch_bounds__(256) void widen_bf16_kernel(const bf16x8* __restrict__ src, f32x4* __restrict__ dst, long long n8) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+    const bf16x8 v = __builtin_nontemporal_load(src + i);
+    __builtin_nontemporal_store(f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]}, dst + 2 * i);
+    __builtin_nontemporal_store(f32x4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]}, dst + 2 * i + 1);
+  }
+}
+extern "C" int ds2_cast_f32_from_bf16(const void* src, float* dst, long long n, void* stream) {
+  DS2_REQUIRE(src && dst && n > 0 && (n % 8) == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0, "ds2_cast_f32_from_bf16: bad args");
+  const long long n8 = n / 8;
+  const int blocks = (int)std::min<long long>((n8 + 255) / 256, 8192);
+  hipLaunchKernelGGL(widen_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)src, (f32x4*)dst, n8);
+  DS2_LAUNCH_CHECK("widen_bf16_kernel");
+  return 0;
+}
+
 extern "C" int ds2_cast_bf16(const float* src, int ld_src, void* dst, int ld_dst, int R, int Cc, void* stream) {
   DS2_REQUIRE(src && dst && R > 0 && Cc > 0 && ld_dst >= Cc && (ld_dst % 8) == 0, "ds2_cast_bf16: bad args");
   const long long total = (long long)R * (ld_dst / 4);

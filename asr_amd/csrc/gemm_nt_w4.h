@@ -38,6 +38,8 @@
 // alone takes 292 us on dX (one wave per SIMD issues 16x16x32 MFMAs at 1.50 PF/s at best: scripts/probe_mfma_power.hip), the operand stream alone
 // 270 us (148 from an L2-resident 64 KB), both together 342-383.
 constexpr int W4_LDS = 4 * G_TILE;
+typedef __bf16 bf16x4w __attribute__((ext_vector_type(4)));
+typedef float f32x2w __attribute__((ext_vector_type(2)));
 
 // 1 KiB of an operand tile, global -> LDS: lane offset (bytes) from a uniform base; M0 = LDS destination of lane 0 (one wait state between the
 // scalar write of M0 and the LDS-DMA instruction that reads it: inside an asm statement the compiler's hazard recogniser does not see the pair)
@@ -45,7 +47,12 @@ __device__ __forceinline__ void w4_dma(unsigned voff, const char* sbase, unsigne
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 
-template <int DBG = 0>
+// OBF: C leaves as bf16 (g.C is a __bf16*, ldc in bf16 elements, N % 8 == 0): the x-projections of a recurrent layer in the bf16 training mode,
+// which the forward recurrence reads once (394 MB written + read per c3 layer instead of 788).  A lane's four columns of the 16-column blocks
+// j, j + 1 are packed to two dwords each; two v_permlane16_swap hand the odd 16-lane rows' block-j halves to the even rows and the even rows'
+// block-(j + 1) halves to the odd rows, so that every lane owns EIGHT consecutive columns of one block: 32 sixteen-byte stores per wave and
+// tile (64 B contiguous per row and store instruction, as in the fp32 form) instead of 64.
+template <int DBG = 0, bool OBF = false>
 __global__ __launch_bounds__(256) void gemm_bf16_nt_w4_kernel(BArgs g, int ntx, int nty) {
   extern __shared__ __attribute__((aligned(1024))) char ldsg[];
   const int nt = ntx * nty;
@@ -214,6 +221,26 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_w4_kernel(BArgs g, int ntx, 
       int el = lane;
       asm volatile("" : "+v"(el));
       const int frow = el & 15, fseg = el >> 4;
+      if constexpr (OBF) {
+        __bf16* Cb = reinterpret_cast<__bf16*>(C);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int row = m0 + wm * 128 + i * 16 + frow;
+#pragma unroll
+          for (int j = 0; j < 8; j += 2) {
+            const f32x4 va = acc[i][j] + pbv[j], vb = acc[i][j + 1] + pbv[j + 1];
+            const bf16x4w pa = {(__bf16)va[0], (__bf16)va[1], (__bf16)va[2], (__bf16)va[3]};
+            const bf16x4w pb = {(__bf16)vb[0], (__bf16)vb[1], (__bf16)vb[2], (__bf16)vb[3]};
+            const f32x2w a2 = __builtin_bit_cast(f32x2w, pa), b2 = __builtin_bit_cast(f32x2w, pb);
+            const u32pair s0 = permlane16_swap(a2[0], b2[0]), s1 = permlane16_swap(a2[1], b2[1]);
+            const int col = n0 + wn * 128 + (j + (fseg & 1)) * 16 + (fseg >> 1) * 8;
+            const f32x4 v = {s0.a, s1.a, s0.b, s1.b};
+            f32x4* pc = (row < g.M && col < g.N) ? reinterpret_cast<f32x4*>(Cb + (long long)row * ldc + col) : reinterpret_cast<f32x4*>(g_sink16);
+            if (stream_out) __builtin_nontemporal_store(v, pc);
+            else *pc = v;
+          }
+        }
+      } else
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int row = m0 + wm * 128 + i * 16 + frow;

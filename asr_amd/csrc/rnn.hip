@@ -54,6 +54,9 @@ constexpr int NW = DS2_RNN_NW;          // waves per block
 // not evict the per-XCD working set that IS re-read every step (W_hh slices 3.1 MB + packed h at H=1024) from the 4 MB L2.
 __device__ __forceinline__ float ldnt(const float* p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ void stnt(float* p, float v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ float ldnt_bf(const __bf16* p) {
+  return __uint_as_float((unsigned)__builtin_nontemporal_load(reinterpret_cast<const unsigned short*>(p)) << 16);
+}
 
 struct RnnArgs {
   float* gx;          // (T,B,2,G*H)  fwd: in x-proj / out gates ; bwd: in gates / out d(pre-activations wrt x-proj)
@@ -88,6 +91,9 @@ struct RnnArgs {
   // first wave that gave up polling; and (host side only, never dereferenced on the device) the context itself
   int* status;
   ds2_rnn_ctx* hctx;
+  // forward, persistent kernels of the bf16 training mode only (ds2_rnn_fwd_gxbf16): the x-projections as the bf16 tensor the projection GEMM
+  // wrote (ds2_gemm_bf16_nt_obf16), same (T,B,2,G*H) layout; `gx` is then NULL and never written (the gates go to gates_bf)
+  const __bf16* gxb;
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -700,9 +706,10 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
   float pgx[G], pgx_next[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) { pgx[g] = 0.f; pgx_next[g] = 0.f; }
+  const bool gx_is_bf = a.gxb != nullptr;                                    // (wave-uniform; BF training launches only)
   if (pact) {
 #pragma unroll
-    for (int g = 0; g < G; ++g) pgx[g] = ldnt(a.gx + eG + g * H);
+    for (int g = 0; g < G; ++g) pgx[g] = gx_is_bf ? ldnt_bf(a.gxb + eG + g * H) : ldnt(a.gx + eG + g * H);
   }
 
   // saved-for-backward outputs of one time step
@@ -841,8 +848,13 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
     // results go out at its end, behind the publish: nothing of the next step depends on them.)
     const bool more = s + 1 < T;
     if (more && pact) {
+      if (gx_is_bf) {
 #pragma unroll
-      for (int g = 0; g < G; ++g) pgx_next[g] = ldnt(a.gx + eG + dG + g * H);
+        for (int g = 0; g < G; ++g) pgx_next[g] = ldnt_bf(a.gxb + eG + dG + g * H);
+      } else {
+#pragma unroll
+        for (int g = 0; g < G; ++g) pgx_next[g] = ldnt(a.gx + eG + dG + g * H);
+      }
     }
 #pragma unroll
     for (int i = 0; i < MB; ++i)
@@ -1831,6 +1843,29 @@ extern "C" int ds2_rnn_fwd_ex(ds2_rnn_ctx* ctx, int gates, float* gx, const void
   // step kernels: zero padding rows / columns of the ping-pong buffers (the persistent path has filled its own with the sentinel)
   DS2_HIP(hipMemsetAsync(ws, 0, ds2_rnn_fwd_workspace_bytes(B, H, bf16), (hipStream_t)stream));
   return bf16 == 1 ? dispatch<true>(gates, false, a, (hipStream_t)stream) : dispatch<false>(gates, false, a, (hipStream_t)stream);
+}
+
+// The forward recurrence of the bf16 training mode from bf16 x-projections (ds2_gemm_bf16_nt_obf16's output): persistent kernels only.
+// Returns 0 = launched (ds2_rnn_last_path bit 0 set), 1 = not taken — the shape has no persistent kernel, or the context is in its cooldown /
+// has the forward kernel switched off; nothing was launched or counted: widen the x-projections (ds2_cast_f32_from_bf16) and call
+// ds2_rnn_fwd_ex —, < 0 error.  gates_bf16 (the packed saved-gate records) is required: there is no fp32 gx to overwrite with the gates.
+extern "C" int ds2_rnn_fwd_gxbf16(ds2_rnn_ctx* ctx, int gates, const void* gx_bf16, const void* wp_fwd, const float* bhh, float* hbuf, float* aux,
+                                  const int* lens_dev, int T, int B, int H, void* gates_bf16, void* h_bf16, void* ws, size_t ws_bytes, void* stream) {
+  DS2_REQUIRE(gates == 3 || gates == 4, "ds2_rnn_fwd_gxbf16: gates must be 3 (GRU) or 4 (LSTM)");
+  DS2_REQUIRE(gx_bf16 && wp_fwd && bhh && hbuf && aux && lens_dev && gates_bf16, "ds2_rnn_fwd_gxbf16: null pointer");
+  DS2_REQUIRE(T > 0 && B > 0 && H > 0 && (H % 4) == 0, "ds2_rnn_fwd_gxbf16: need H %% 4 == 0 (H=%d)", H);
+  DS2_REQUIRE(ws && ws_bytes >= ds2_rnn_fwd_workspace_bytes(B, H, 1), "ds2_rnn_fwd_gxbf16: workspace too small");
+  if (!persist_idle(ctx, false)) return 1;
+  RnnArgs a{};
+  a.gx = nullptr; a.gxb = (const __bf16*)gx_bf16; a.aux = aux; a.hbuf = hbuf; a.wp = (const float*)wp_fwd; a.bhh = bhh; a.pk = (float*)ws; a.lens = lens_dev;
+  a.T = T; a.B = B; a.H = H; a.gates_bf = (__bf16*)gates_bf16; a.h_bf = (__bf16*)h_bf16;
+  a.hctx = ctx; a.status = ctx->status_dev;
+  a.dbg = ctx->debug_flags;
+  const int rc = gates == 3 ? try_launch_persistent_fwd<3, true>(a, (hipStream_t)stream) : try_launch_persistent_fwd<4, true>(a, (hipStream_t)stream);
+  if (rc < 0) return rc;
+  if (rc == 0) return 1;
+  ctx->last_path = (ctx->last_path & ~(1 | 32 | 256)) | 1;
+  return 0;
 }
 
 extern "C" int ds2_rnn_fwd(ds2_rnn_ctx* ctx, int gates, float* gx, const void* wp_fwd, const float* bhh, float* hbuf, float* aux, const int* lens_dev, int T,

@@ -104,6 +104,10 @@ F32_CONV_FWD = _tune("DS2_F32_CONV_FWD", "f32")
 # gradient already take (time-major LDS images filled by DMA; no padded copies of a1 / dY2 are written any more); "pad" = the round-2 kernel
 # on zero-padded (B,32,D,Tp) copies (eight pre-shifted dY copies in LDS).  A/B: profiles/r05_conv_ab.txt.
 CONV2_WGRAD = _tune("DS2_CONV2_WGRAD", "nhwc")
+# bf16 training, the x-projections of a recurrent layer (DS2_GX_BF16, default 1): the projection GEMM rounds its fp32 accumulators (+ bias) to
+# bf16 at the store and the forward recurrence reads that — 394 MB written + read per c3 layer instead of 788 (ops.gemm_bf16_nt_obf16; the gates
+# are saved as bf16 records anyway).  0: fp32 x-projections as rounds 1-5.  A/B and parity deltas: profiles/r06_gx_bf16_ab.txt.
+GX_BF16 = _tune("DS2_GX_BF16", "1") != "0"
 
 
 def _f32_split_ok(M: int, N: int, K: int, H: int = 8) -> bool:
@@ -324,7 +328,11 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
                 w_bf, lc.wihT = ops.cast_bf16_both(W[f"rnns.{l}.wih_cat"], ld_r=xn.shape[1])
             else:
                 w_bf = ops.cast_bf16(W[f"rnns.{l}.wih_cat"], ld=xn.shape[1])
-            gx = ops.gemm_bf16_nt(xn, w_bf, bias=W[f"rnns.{l}.bih_cat"])
+            gx = None
+            if GX_BF16 and save and B % 8 == 0:                  # (the conditions of `pack` below: the only consumer of a bf16 gx)
+                gx = ops.gemm_bf16_nt_obf16(xn, w_bf, bias=W[f"rnns.{l}.bih_cat"])
+            if gx is None:
+                gx = ops.gemm_bf16_nt(xn, w_bf, bias=W[f"rnns.{l}.bih_cat"])
             del w_bf
         elif _f32_split_ok(M, 2 * G * H, xn.shape[1], H):
             # three-term split-bf16 product as ONE NT GEMM over a reduction index 3 I long: [hi | hi | lo] x [hi | lo | hi]^T

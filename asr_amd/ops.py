@@ -278,6 +278,31 @@ def _pick_splitk(M: int, N: int, K: int) -> int:
     return 1
 
 
+def gemm_bf16_nt_obf16(A: Tensor, B: Tensor, bias: Optional[Tensor] = None) -> Optional[Tensor]:
+    """bf16 (M, N) = A[M,K] @ B[N,K]^T + bias with fp32 accumulation, ONE rounding at the store — or None where the four-wave kernel does not
+    apply (the caller then takes gemm_bf16_nt's fp32 result)."""
+    assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and A.is_cuda and B.is_cuda and A.stride(1) == 1 and B.stride(1) == 1
+    M, K = A.shape
+    N, Kb = B.shape
+    assert K == Kb and K % 8 == 0, (A.shape, B.shape)
+    if N % 8:
+        return None
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=A.device)
+    rc = _lib.load().ds2_gemm_bf16_nt_obf16(M, N, K, A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), out.data_ptr(), N, _ptr(bias), _stream())
+    if rc == 1:
+        return None
+    _lib.check(rc, "ds2_gemm_bf16_nt_obf16")
+    return out
+
+
+def widen_bf16(x: Tensor) -> Tensor:
+    """contiguous bf16 -> fp32 (numel % 8 == 0)"""
+    assert x.dtype == torch.bfloat16 and x.is_cuda and x.is_contiguous() and x.numel() % 8 == 0
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().ds2_cast_f32_from_bf16(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "ds2_cast_f32_from_bf16")
+    return out
+
+
 def gemm_bf16_nt(A: Tensor, B: Tensor, bias: Optional[Tensor] = None, out: Optional[Tensor] = None, accumulate: bool = False,
                  splitk: int = 0) -> Tensor:
     """out[M,N] fp32 (+)= A[M,K] @ B[N,K]^T, A/B bf16 with K (incl. zero padding) a multiple of 8."""
@@ -903,7 +928,7 @@ def rnn_fwd(gates: int, gx: Tensor, wp_fwd: Tensor, bhh: Tensor, lens_dev: Tenso
     packed_gates: the saved-for-backward gates go to one 8-byte bf16 record per hidden unit (gx keeps the x-projections; GRU aux
     is not written) — pass the returned buffer to rnn_bwd.
     h_bf16: optional (T*B, 2H) bf16 buffer that receives a bf16 copy of hbuf — by a persistent launch only (rnn_last_path() & 1)."""
-    _chk_f32(gx, bhh)
+    _chk_f32(bhh)
     assert gx.is_contiguous() and bhh.is_contiguous()
     if h_bf16 is not None:
         assert h_bf16.dtype == torch.bfloat16 and h_bf16.is_contiguous() and h_bf16.numel() == T * B * 2 * H
@@ -913,6 +938,18 @@ def rnn_fwd(gates: int, gx: Tensor, wp_fwd: Tensor, bhh: Tensor, lens_dev: Tenso
     rec = torch.empty(T * B, 2 * H, 4, dtype=torch.bfloat16, device=gx.device) if packed_gates else None
     wsb = lib.ds2_rnn_fwd_workspace_bytes(B, H, int(bf16))
     ws = _ws(wsb, gx.device)
+    if gx.dtype == torch.bfloat16:
+        # bf16 x-projections (gemm_bf16_nt_obf16): persistent launches of the bf16 training mode take them as they are; anything else (a
+        # cooldown after a starved launch, a shape without a persistent kernel) gets them widened and runs as before
+        assert int(bf16) == 1 and packed_gates, "bf16 x-projections: bf16 training mode with packed gate records only"
+        rc = lib.ds2_rnn_fwd_gxbf16(_ctxp(gx.device), gates, gx.data_ptr(), wp_fwd.data_ptr(), bhh.data_ptr(), hbuf.data_ptr(), aux.data_ptr(),
+                                    lens_dev.data_ptr(), T, B, H, _ptr(rec), _ptr(h_bf16), ws.data_ptr(), wsb, _stream())
+        if rc == 0:
+            return hbuf, aux, rec
+        if rc != 1:
+            _lib.check(rc, "ds2_rnn_fwd_gxbf16")
+        gx = widen_bf16(gx)
+    _chk_f32(gx)
     _lib.check(lib.ds2_rnn_fwd_ex(_ctxp(gx.device), gates, gx.data_ptr(), wp_fwd.data_ptr(), bhh.data_ptr(), hbuf.data_ptr(), aux.data_ptr(),
                                   lens_dev.data_ptr(), T, B, H, int(bf16), _ptr(rec), _ptr(h_bf16), ws.data_ptr(), wsb, _stream()),
                "ds2_rnn_fwd")

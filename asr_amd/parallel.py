@@ -9,6 +9,16 @@ Three schedules (DS2_DP_MODE):
   * "serial": every bucket's all-reduce is ordered INTO the compute stream right where its gradients become final.  Nothing overlaps.
   * "overlap": buckets are reduced on a side stream while the rest of backward runs; the trainer then switches the persistent BACKWARD
     recurrence off (ds2_rnn_persistent_enable(1, 0)), which costs more than the communication it hides.
+  * "auto": MEASURE, then choose between "conv" and "serial".  Overlap is not free on this part: the collective's channel kernels take CUs
+    and memory bandwidth from the conv-stack backward they hide under (scripts/r6_dp_window.py prices that on one GPU).  Steps 1-2 run
+    "conv", steps 3-4 "serial", each with an event at the first bucket of backward and one after the last collective; the MAX over ranks of
+    the two spans decides (the same number on every rank, so every rank switches alike), and `auto_report` says what was chosen and why.
+    Costs two device synchronisations and one 2-float all-reduce, once, inside the warm-up (>= 5 warm-up steps).
+
+RCCL channels: the schedules assume RCCL's defaults (it sizes its channel count to the topology: on an 8-GPU xGMI mesh up to 32 channels of
+one workgroup each for a 260 MB all-reduce).  A collective NEVER runs beside a persistent recurrence in "conv" / "serial" / "auto", so
+the channel count only prices the conv-stack window; cap it with NCCL_MAX_NCHANNELS (e.g. 16) if `dist.conv_backward_ms` of a multi-GPU line
+grows by more than the collective's own duration.
 
 The reference has no live distributed code; semantics defined in SURVEY §8(e):
 per-rank BatchNorm statistics (plain DDP), gradients = mean over ranks of each rank's
@@ -34,8 +44,14 @@ class BucketedAllReducer:
         # path on a 1-GPU box; a 1-rank SUM is the identity)
         self.force = dist.is_initialized() and os.environ.get("DS2_FORCE_ALLREDUCE") == "1"
         self.mode = os.environ.get("DS2_DP_MODE", "conv")
-        if self.mode not in ("conv", "serial", "overlap"):
-            raise ValueError(f"DS2_DP_MODE={self.mode!r}: expected conv, serial or overlap")
+        if self.mode not in ("conv", "serial", "overlap", "auto"):
+            raise ValueError(f"DS2_DP_MODE={self.mode!r}: expected conv, serial, overlap or auto")
+        # "auto": starts as "conv", measures both, settles on one (see _auto_step); auto_report: None until then
+        self.auto = self.mode == "auto" and flat_grad.is_cuda
+        self.auto_report: Optional[dict] = None
+        self._auto_steps, self._auto_ev, self._auto_spans = 0, None, {}
+        if self.mode == "auto":
+            self.mode = "conv"
         self.use_stream = flat_grad.is_cuda and self.mode in ("overlap", "conv")
         # does a collective ever run while backward's recurrences are still being executed?  (only then must the persistent backward go)
         self.overlaps_recurrence = flat_grad.is_cuda and self.mode == "overlap"
@@ -59,6 +75,9 @@ class BucketedAllReducer:
         """Called by engine.backward when bucket `name`'s gradient kernels are enqueued."""
         if self.world == 1 and not self.force:
             return
+        if self.auto and self._auto_ev is None and self._auto_steps in (1, 2, 3, 4):
+            self._auto_ev = torch.cuda.Event(enable_timing=True)      # first bucket of this backward (fc): where communication could start
+            self._auto_ev.record(torch.cuda.current_stream())
         if self.mode == "conv" and name != "conv" and self._release_on is not None:
             # fc / recurrent layers: hold until the last of them is final, then ONE all-reduce over their (contiguous) span
             self._held.append(name)
@@ -119,6 +138,14 @@ class BucketedAllReducer:
             tail = [max(0.0, b["mark"].elapsed_time(b["end"]) - sp) for b, sp in zip(bigs, span)]
             out["conv_backward_ms"] = sum(span) / len(span)
             out["big_collective_outlasts_conv_backward_ms"] = sum(tail) / len(tail)
+            # what the compute stream waits for at the end of backward: the big collective's tail + the (serialised) conv bucket
+            out["exposed_comm_ms"] = out["big_collective_outlasts_conv_backward_ms"] + sum(c["start"].elapsed_time(c["end"]) for c in convs) / len(convs)
+        elif self.mode == "serial":
+            steps = max(len(convs), 1)
+            out["exposed_comm_ms"] = sum(r["start"].elapsed_time(r["end"]) for r in recs) / steps      # nothing overlaps: every collective is exposed
+        out["schedule_chosen"] = self.mode
+        if self.auto_report:
+            out["auto"] = self.auto_report
         return out
 
     def finish(self):
@@ -131,6 +158,40 @@ class BucketedAllReducer:
         self._pending = []
         self.launched = []
         assert not self._held, f"buckets never released: {self._held}"
+        if self.auto:
+            self._auto_step()
+
+    def _auto_step(self):
+        """DS2_DP_MODE=auto, called at the end of every step until the choice is made: steps 1-2 in "conv", 3-4 in "serial", the span from
+        backward's first bucket to the compute stream having all reduced gradients is timed in both, the MAX over ranks decides."""
+        k = self._auto_steps
+        self._auto_steps += 1
+        if self._auto_ev is not None:
+            end = torch.cuda.Event(enable_timing=True)
+            end.record(torch.cuda.current_stream())
+            self._auto_spans.setdefault(self.mode, []).append((self._auto_ev, end))
+            self._auto_ev = None
+        if k == 2:                                       # two "conv" steps timed: now two "serial" ones
+            self._set_mode("serial")
+        elif k == 4:
+            torch.cuda.synchronize(self.flat_grad.device)
+            span = {m: sum(a.elapsed_time(b) for a, b in v) / len(v) for m, v in self._auto_spans.items()}
+            t = torch.tensor([span.get("conv", 0.0), span.get("serial", 0.0)], dtype=torch.float64, device=self.flat_grad.device)
+            if self.world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            conv_ms, serial_ms = float(t[0]), float(t[1])
+            chosen = "conv" if conv_ms <= serial_ms else "serial"
+            self._set_mode(chosen)
+            self.auto_report = {"schedule_chosen": chosen, "backward_with_comm_ms": {"conv": conv_ms, "serial": serial_ms},
+                                "measured_over_steps": {m: len(v) for m, v in self._auto_spans.items()}}
+            self.auto = False
+            self._auto_spans = {}
+
+    def _set_mode(self, mode: str):
+        self.mode = mode
+        self.use_stream = self.flat_grad.is_cuda and mode in ("overlap", "conv")
+        if self.use_stream and self.comm_stream is None:
+            self.comm_stream = torch.cuda.Stream(device=self.flat_grad.device)
 
     def all_valid_device(self, flag: torch.Tensor) -> torch.Tensor:
         """Device-side agreement: `flag` (int32 GPU tensor, 1 = this rank's step is valid) becomes the MIN over ranks, in stream order,

@@ -81,6 +81,13 @@ size_t ds2_gemm_bf16_workspace_bytes(int M, int N, int batch, int splitk);
 int ds2_gemm_bf16_nt(int M, int N, int K, const void* A, int lda, long long strideA, const void* B, int ldb, long long strideB, float* C,
                      int ldc, long long strideC, const float* bias, int accumulate, int batch, int splitk, void* workspace,
                      size_t workspace_bytes, void* stream);
+/* C[M,N] **bf16** = A[M,K] B[N,K]^T + bias (fp32 accumulation and bias add, ONE rounding at the store; ldc in bf16 elements, N, ldc % 8 == 0):
+ * the x-projections of a recurrent layer in the bf16 training mode (aten::addmm inside aten::gru / lstm, blocks.py:76-78, 88), read once by
+ * ds2_rnn_fwd_gxbf16.  Returns 1 — nothing launched, call ds2_gemm_bf16_nt — where the four-wave kernel does not apply (K % 64 != 0, fewer
+ * 256 x 256 tiles than CUs, alignment); 0 = launched; < 0 = error. */
+int ds2_gemm_bf16_nt_obf16(int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias, void* stream);
+/* n contiguous bf16 -> fp32 (n % 8 == 0, 16-byte aligned bases). */
+int ds2_cast_f32_from_bf16(const void* src, float* dst, long long n, void* stream);
 /* "TN" form: C[M,N] (+)= A[K,M]^T B[K,N], both operands bf16 row-major with the reduction index on the rows (pitches lda / ldb).
  * The weight-gradient product of the recurrent layers (dW = dGx^T [Xn | h], K = T*B) without a transposed copy of any operand.
  * M, N, lda, ldb, strides multiples of 8; batch > 1: independent products at the given element strides (may be negative). */
@@ -274,6 +281,13 @@ int ds2_rnn_fwd(ds2_rnn_ctx* ctx, int gates, float* gx, const void* wp_fwd, cons
  * dW_hh GEMM).  Written by a PERSISTENT launch only: check ds2_rnn_last_path() & 1 after the call. */
 int ds2_rnn_fwd_ex(ds2_rnn_ctx* ctx, int gates, float* gx, const void* wp_fwd, const float* bhh, float* hbuf, float* aux, const int* lens_dev, int T, int B,
                    int H, int bf16, void* gates_bf16, void* h_bf16, void* ws, size_t ws_bytes, void* stream);
+/* The forward recurrence of the bf16 training mode reading its x-projections as the **bf16** tensor ds2_gemm_bf16_nt_obf16 wrote (same
+ * (T,B,2,G*H) layout; half the bytes written by the projection and read here: aten::gru / aten::lstm of blocks.py:87-89 take them from
+ * aten::addmm at full precision — the rounding is part of the stated bf16-mode tolerance).  Persistent kernels only; gates_bf16 is required.
+ * Returns 0 = launched (ds2_rnn_last_path() & 1), 1 = not taken and nothing launched or counted (cooldown, forward kernel switched off, no
+ * persistent kernel for the shape): widen with ds2_cast_f32_from_bf16 and call ds2_rnn_fwd_ex; < 0 = error. */
+int ds2_rnn_fwd_gxbf16(ds2_rnn_ctx* ctx, int gates, const void* gx_bf16, const void* wp_fwd, const float* bhh, float* hbuf, float* aux,
+                       const int* lens_dev, int T, int B, int H, void* gates_bf16, void* h_bf16, void* ws, size_t ws_bytes, void* stream);
 size_t ds2_rnn_bwd_workspace_bytes(int gates, int B, int H, int bf16);
 /* dgx_bf16: NULL, or a (T,B,2,G*H) bf16 buffer that receives the gradient wrt the x-projections instead of gx (which then keeps
  * the gates): the bf16-mode GEMMs consume it directly.  gates_bf16: NULL, or the packed records written by ds2_rnn_fwd — read

@@ -302,13 +302,15 @@ dist.destroy_process_group()
 def test_starved_rank_makes_every_rank_recompute_two_ranks_gloo(tmp_path):
     """The data-parallel form of the test above: rank 1's persistent launches starve (DS2_RNN_SPIN_LIMIT=0 in that process only), rank 0's do
     not.  The device verdict is the MIN over ranks, so BOTH ranks compute the starved batch (and the one launched behind it) again, in step,
-    with matching collectives: after three batches both replicas hold the same weights, bit-identical to those of a two-rank run that used
-    the one-launch-per-step kernels throughout (DS2_RNN_PERSISTENT=0); three optimizer updates, no batch lost, same epoch loss."""
+    with matching collectives: after three batches both replicas hold the same weights, bit-identical to those of a two-rank run in which rank 1
+    used the one-launch-per-step kernels throughout (DS2_RNN_PERSISTENT=0: nothing can starve) and rank 0 the same kernels as here — the two
+    kernel families are not bit-identical at the step level (bias gradients: fp32 per-row sums in the persistent kernels, column sums of the
+    bf16 dGx behind the step kernels), so each rank is compared with itself; three optimizer updates, no batch lost, same epoch loss."""
     script = str(tmp_path / "w.py")
     open(script, "w").write(DP_STARVE_WORKER)
     results = {}
     for tag, envs in (("starve", ({}, {"DS2_RNN_SPIN_LIMIT": "0", "DS2_RNN_REARM_CALLS": "8"})),
-                      ("steps", ({"DS2_RNN_PERSISTENT": "0"}, {"DS2_RNN_PERSISTENT": "0"}))):
+                      ("steps", ({}, {"DS2_RNN_PERSISTENT": "0"}))):       # rank 1 on kernels that cannot starve, rank 0 as in the other run
         out = str(tmp_path / tag)
         procs = []
         for r in range(2):
@@ -408,3 +410,58 @@ def test_autograd_backward_uses_the_forward_threads_recurrence_context(tmp_path)
     assert res["backward_path_persistent"] and res["check_raised"] and res["switch_reaches_autograd_backward"], res
     assert res["fit_weights_equal"] and res["fit_starved"] >= 1 and res["fit_counters"] == res["fit_counters_ref"], res
     assert abs(res["fit_loss"] - res["fit_loss_ref"]) <= 1e-6 * abs(res["fit_loss_ref"]), res
+
+
+AUTO_WORKER = r'''
+import os, sys, json, hashlib
+import numpy as np, torch, torch.distributed as dist
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests")); sys.path.insert(0, os.path.join(root, "tests", "golden"))
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+import bench
+from test_gpu_model import make_model
+from asr_amd import CTCLoss, FusedAdamW
+from asr_amd.trainers import DeepSpeechTrainer
+B, tin, C = 64, 201, 29
+torch.manual_seed(0)
+model = make_model(dict(rnn="gru", hidden=1024, layers=2, classes=C))
+model.precision = "bf16"
+opt = FusedAdamW(model, lr=1.5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5)
+dev = torch.device("cuda", 0)
+tr = DeepSpeechTrainer(model, CTCLoss(reduction="sum"), 1, None, opt, None, None, dev, dev, False, None)
+x, targets, pct, tsz = bench.synthetic_batch(B, tin, C, 1)
+x = x.cuda()
+modes, losses = [], []
+for it in range(7):
+    valid, lv = tr.step((x, targets, pct.clone(), tsz))
+    modes.append(tr._get_reducer().mode)
+    losses.append(lv)
+tr.synchronize()
+red = tr._get_reducer()
+flat, _ = model.flat_parameters()
+print("AUTO_JSON " + json.dumps({"modes": modes, "losses": losses, "report": red.auto_report, "still_auto": red.auto, "starved": DeepSpeechTrainer.starved_steps,
+                                 "weights_sha": hashlib.sha256(flat.detach().cpu().numpy().tobytes()).hexdigest()}))
+dist.destroy_process_group()
+'''
+
+
+def test_dp_mode_auto_measures_both_schedules_and_settles(tmp_path):
+    """DS2_DP_MODE=auto (VERDICT round 5 item 5b): steps 1-2 run the "conv" schedule, steps 3-4 "serial", both timed from backward's first
+    bucket to the compute stream holding all reduced gradients; the faster one is kept and reported.  One forced RCCL rank: the two schedules
+    give bit-identical weights, so the mixed run ends exactly where a pure "conv" run of the same seven steps ends."""
+    res = {}
+    for i, mode in enumerate(("auto", "conv")):
+        script = str(tmp_path / f"auto_{mode}.py")
+        open(script, "w").write(AUTO_WORKER)
+        env = dict(os.environ, RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29641 + i), DS2_FORCE_ALLREDUCE="1", DS2_DP_MODE=mode,
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        r = subprocess.run([sys.executable, script, ROOT], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        res[mode] = json.loads([l for l in r.stdout.splitlines() if l.startswith("AUTO_JSON ")][-1][len("AUTO_JSON "):])
+    a = res["auto"]
+    assert a["modes"][:3] == ["conv", "conv", "serial"] and a["modes"][3] == "serial" and not a["still_auto"], a
+    rep = a["report"]
+    assert rep["schedule_chosen"] in ("conv", "serial") and a["modes"][-1] == rep["schedule_chosen"], a
+    assert rep["measured_over_steps"] == {"conv": 2, "serial": 2} and min(rep["backward_with_comm_ms"].values()) > 0, rep
+    assert a["starved"] == 0 and a["losses"] == res["conv"]["losses"] and a["weights_sha"] == res["conv"]["weights_sha"]

@@ -1,0 +1,154 @@
+"""Round-6 GPU tests: bf16 x-projections (projection GEMM -> forward recurrence), the full-size reference / fp64 fixtures of the BASELINE
+configurations (tests/golden/model_c3_full.npz, model_c2_full.npz), and what else the round added on the device side."""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+from helpers import GOLDEN, model_inputs, rel_l2  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda", 0)
+
+
+@pytest.mark.parametrize("M,N,K", [(32064, 6144, 1024), (16032, 4608, 768), (32064, 6144, 1344), (24032, 10240, 1280), (8000, 2056, 256)])
+def test_projection_gemm_with_bf16_output_is_the_rounded_fp32_result(dev, M, N, K):
+    """ds2_gemm_bf16_nt_obf16 (gemm_nt_w4.h, OBF): the same accumulators + bias as the fp32-output kernel, rounded once to bf16 at the store —
+    bit-identical to rounding the fp32 kernel's result, at the recurrent layers' shapes (c3, c2, c3 layer 0, c4) and a ragged one."""
+    from asr_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(dev).bfloat16()
+    Bm = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).bfloat16()
+    bias = torch.randn(N, generator=g).to(dev)
+    ref = ops.gemm_bf16_nt(A, Bm, bias=bias)
+    got = ops.gemm_bf16_nt_obf16(A, Bm, bias=bias)
+    assert got is not None, "the four-wave kernel applies to this shape"
+    assert got.dtype == torch.bfloat16 and got.shape == (M, N)
+    assert torch.equal(got.view(torch.int16), ref.bfloat16().view(torch.int16))
+    assert ops.gemm_bf16_nt_obf16(A[:256], Bm[:256], bias=None) is None                 # fewer tiles than CUs: the caller keeps the fp32 form
+    assert torch.equal(ops.widen_bf16(got), got.float())
+
+
+@pytest.mark.parametrize("G,H,B,T", [(3, 1024, 64, 40), (3, 768, 32, 33), (4, 1280, 32, 21), (3, 256, 16, 50)])
+def test_forward_recurrence_from_bf16_x_projections_is_bit_identical_to_the_widened_input(dev, G, H, B, T):
+    """ds2_rnn_fwd_gxbf16: the persistent forward kernel reading bf16 x-projections gives exactly what it gives for the same values widened
+    to fp32 (h, the packed gate records, the bf16 h copy); in a cooldown (the persistent kernels off) the binding widens and falls back."""
+    from asr_amd import ops
+    torch.manual_seed(G * H + B + T)
+    gxb = (torch.randn(T * B, 2 * G * H, device=dev) * 0.7).bfloat16()
+    whh = (torch.rand(2, G * H, H, device=dev) * 2 - 1) / H ** 0.5
+    bhh = torch.randn(2, G * H, device=dev) * 0.1
+    lens = torch.randint(T // 2, T + 1, (B,), dtype=torch.int32, device=dev).sort(descending=True).values
+    lens[0] = T
+    wpf, _ = ops.rnn_pack(G, whh, bf16=True)
+
+    def run(gx):
+        hb16 = torch.empty(T * B, 2 * H, dtype=torch.bfloat16, device=dev)
+        hbuf, aux, rec = ops.rnn_fwd(G, gx, wpf, bhh, lens, T, B, H, bf16=True, packed_gates=True, h_bf16=hb16)
+        path = ops.rnn_last_path()
+        torch.cuda.synchronize()
+        ops.rnn_persistent_check()
+        return hbuf, aux, rec, hb16, path
+    a = run(gxb)
+    b = run(gxb.float())
+    assert (a[4] & 1) == (b[4] & 1)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[2].view(torch.int16), b[2].view(torch.int16))
+    if G == 4:
+        assert torch.equal(a[1], b[1])
+    if a[4] & 1:
+        assert torch.equal(a[3].view(torch.int16), b[3].view(torch.int16))
+    ops.rnn_persistent_enable(False, True)
+    try:
+        c = run(gxb)                                           # step kernels: widened by the binding
+        assert not (c[4] & 1) and torch.equal(c[0], a[0]) and torch.equal(c[2].view(torch.int16), a[2].view(torch.int16))
+    finally:
+        ops.rnn_persistent_enable(True, True)
+
+
+def _full_fixture(name):
+    path = os.path.join(GOLDEN, f"model_{name}.npz")
+    if not os.path.exists(path):
+        pytest.skip(f"{path} not generated (tests/golden/make_golden.py --only-full {name})")
+    z = np.load(path)
+    return z, json.loads(str(z["cfg"]))
+
+
+def _sub_full(a, full_max):
+    f = np.asarray(a).reshape(-1)
+    return f if f.size <= full_max else f[::-(-f.size // full_max)]
+
+
+@pytest.mark.parametrize("name", ["c3_full", "c2_full"])
+def test_full_size_step_vs_reference_and_fp64_goldens(name):
+    """BASELINE configs[2] (5 x 1024 BiGRU, B = 64, T_in = 1001, ragged) and configs[1] (5 x 768, B = 32) at FULL size.
+    The fixture holds one train step of the IMPORTED REFERENCE (fp32, CPU) and of the fp64 oracle on the same weights and batch: loss,
+    per-utterance logit checksums + sub-sample, every parameter gradient sub-sampled, and the full-tensor distance between the reference's fp32
+    gradient and the fp64 one.  The HIP path in fp32 mode is held to north_star's 1e-3 against BOTH — and for the two conv biases, which sit
+    in front of a BatchNorm (a near-cancelling sum over 1.3 - 2.6 M positions per channel: ill-conditioned in any fp32 arithmetic), to
+    |g_hip - g_fp64| <= max(1e-3 |g_fp64|, |g_ref_fp32 - g_fp64|): no further from the exact gradient than the reference itself is."""
+    from test_gpu_model import make_model
+    from asr_amd import CTCLoss
+    from oracle import ds2_oracle as O
+    z, cfg = _full_fixture(name)
+    fm, ls = int(cfg["full_max"]), int(cfg["logit_stride"])
+    sd, x, targets, pct, tsz = model_inputs(cfg, well_conditioned=False)
+    B = x.size(0)
+    lens = O.lengths_from_percentages(pct, x.size(3))
+    assert np.array_equal(lens.numpy(), z["input_sizes"])
+    model = make_model(cfg, sd)
+    model.precision = "fp32"
+    out, out_lens = model.forward(x.cuda(), lens)
+    assert np.array_equal(out_lens.cpu().numpy(), z["output_sizes"])
+    loss = CTCLoss(reduction="sum")(out.transpose(0, 1), targets, out_lens, tsz) / B
+    loss.backward()
+    torch.cuda.synchronize()
+    lv = float(loss.detach())
+    l64, lref = float(z["loss_f64"]), float(z["loss_ref"])
+    assert abs(lv - l64) <= 1e-3 * abs(l64) and abs(lv - lref) <= 1e-3 * abs(lref), (lv, l64, lref)
+    lg = out.detach().cpu().numpy().astype(np.float64)
+    ol = z["output_sizes"]
+    sub = np.concatenate([lg[b, :int(n)].reshape(-1)[::ls] for b, n in enumerate(ol)])
+    norms = np.array([np.sqrt((lg[b, :int(n)] ** 2).sum()) for b, n in enumerate(ol)])
+    sums = np.array([lg[b, :int(n)].sum() for b, n in enumerate(ol)])
+    report = {"loss": (lv, l64, lref), "logits_vs_f64": rel_l2(sub, z["logits_f64"]), "logits_vs_ref": rel_l2(sub, z["logits_ref"])}
+    assert report["logits_vs_f64"] <= 1e-3 and report["logits_vs_ref"] <= 1e-3, report
+    assert np.all(np.abs(norms - z["logitnorm_f64"]) <= 1e-3 * z["logitnorm_f64"]), "per-utterance logit norms"
+    assert np.all(np.abs(sums - z["logitsum_f64"]) <= 1e-3 * z["logitnorm_f64"] * np.sqrt(np.maximum(ol, 1) * lg.shape[2])), "per-utterance logit sums"
+    gmax = max(float(z["gradnorm_f64_" + k]) for k, _ in model.named_parameters())
+    worst = ("", 0.0)
+    for k, p in model.named_parameters():
+        g = p.grad.detach().cpu().numpy().astype(np.float64)
+        n64, nref = float(z["gradnorm_f64_" + k]), float(z["gradnorm_ref_" + k])
+        ref_dist = float(z["graddist_ref_f64_" + k])                           # |g_ref_fp32 - g_fp64|, full tensor
+        gs = _sub_full(g, fm)
+        frac = np.sqrt(gs.size / g.size)                                       # a strided sub-sample carries this share of a tensor's norm
+        e64 = np.linalg.norm(gs - z["grad_f64_" + k])
+        eref = np.linalg.norm(gs - z["grad_ref_" + k].astype(np.float64))
+        conv_bias = k in ("conv.seq_module.0.bias", "conv.seq_module.3.bias")
+        # floor: a tensor whose gradient is tiny beside the model's largest is compared on that scale (as tests/test_gpu_configs.py does)
+        tol64 = max(1e-3 * max(n64, 1e-4 * gmax), ref_dist if conv_bias else 0.0) * frac
+        tolref = 1e-3 * max(nref, 1e-4 * gmax) * frac + (2.0 * ref_dist * frac if conv_bias else 0.0)
+        assert abs(np.sqrt((g ** 2).sum()) - n64) <= 2e-3 * max(n64, 1e-4 * gmax) + (ref_dist if conv_bias else 0.0), (k, "norm")
+        assert e64 <= tol64, (k, "vs fp64", e64 / frac / max(n64, 1e-30), ref_dist / max(n64, 1e-30))
+        assert eref <= tolref, (k, "vs reference", eref / frac / max(nref, 1e-30))
+        if not conv_bias and e64 / frac / max(n64, 1e-4 * gmax) > worst[1]:
+            worst = (k, e64 / frac / max(n64, 1e-4 * gmax))
+    report["worst_gradient_vs_f64"] = worst
+    for k in ("conv.seq_module.0.bias", "conv.seq_module.3.bias"):
+        g = model.get_parameter(k).grad.detach().cpu().numpy().astype(np.float64)
+        report[k] = {"hip_vs_f64": float(np.linalg.norm(g - z["grad_f64_" + k]) / z["gradnorm_f64_" + k]),
+                     "ref_vs_f64": float(z["graddist_ref_f64_" + k] / z["gradnorm_f64_" + k])}
+    print(name, json.dumps(report))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", f"full_size_{name}.json"), "w") as f:
+        json.dump(report, f, indent=1)
