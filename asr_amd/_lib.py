@@ -24,6 +24,7 @@ SIGNATURES = {
     "ds2_device_info": (i32, [C.POINTER(i32), C.POINTER(i32), C.c_char_p, i32]),
     "ds2_debug_flags": (i32, [vp, i32]),
     "ds2_rnn_ctx_init": (i32, [vp, vp, vp, vp]),
+    "ds2_memset_async": (i32, [vp, i32, sz, vp]),
     "ds2_ablation_build": (i32, []),
     "ds2_rnn_persistent_status": (i32, [vp, vp]),
     "ds2_rnn_persistent_counters": (i32, [vp, vp]),
@@ -50,7 +51,7 @@ SIGNATURES = {
     "ds2_cast_bf16": (i32, [vp, i32, vp, i32, i32, i32, vp]),
     "ds2_gemm_bf16_nt_obf16": (i32, [i32, i32, i32, vp, i32, vp, i32, vp, i32, vp, vp]),
     "ds2_cast_f32_from_bf16": (i32, [vp, vp, i64, vp]),
-    "ds2_rnn_fwd_gxbf16": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, sz, vp]),
+    "ds2_rnn_fwd_x": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, sz, vp]),
     "ds2_split_bf16": (i32, [vp, i32, vp, i32, i32, i32, i32, vp]),
     "ds2_cast_transpose_bf16": (i32, [vp, i32, vp, i32, i32, i32, vp]),
     "ds2_cast_bf16_both_workspace_bytes": (sz, [i32, i32]),

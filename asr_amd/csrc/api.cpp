@@ -54,6 +54,11 @@ extern "C" int ds2_rnn_ctx_init(ds2_rnn_ctx* ctx, int* status_dev, int* poison_h
   ctx->status_dev = status_dev; ctx->poison_host = poison_host; ctx->poison_dev = poison_dev;
   return 0;
 }
+extern "C" int ds2_memset_async(void* dst, int value, size_t bytes, void* stream) {
+  if (!dst || bytes == 0) return ds2_set_error("ds2_memset_async: bad arguments");
+  hipError_t e = hipMemsetAsync(dst, value, bytes, (hipStream_t)stream);
+  return e == hipSuccess ? 0 : ds2_set_error("ds2_memset_async: %s", hipGetErrorString(e));
+}
 extern "C" int ds2_ablation_build(void) {
 #ifdef DS2_ABLATE
   return 1;

@@ -615,6 +615,9 @@ struct TnSProb {
   const __bf16* A; const __bf16* B; float* C; float* partial;       // partial: the product's slabs [nslab][M][N] (unused when it has one slab)
   int M, N, K, lda, ldb, ldc, ntx, ntiles, kchunk, first_item;
   int slab0, nslab, to_slab;                                        // this entry's first slab; slabs to reduce (first term only, else 0); write a slab?
+  // fused reduce (gemm_tn_w4.h): the product's arrival counters, one per tile (zeroed by the launcher), and how many slabs a tile waits for —
+  // the workgroup that stores the LAST slab of a tile adds all of them in slab order and writes C; tick == NULL: the separate reduce launch
+  int* tick; int nslab_all;
 };
 struct TnSGroup {
   TnSProb p[TN_MAX_PROBLEMS];
@@ -1226,7 +1229,7 @@ static int ds2_cus_current() {
 }
 
 // C[M,N] **bf16** = A[M,K] bf16 * B[N,K]^T bf16 + bias (fp32 accumulation and bias add, one rounding at the store): the x-projections of a
-// recurrent layer in the bf16 training mode (aten::addmm inside aten::gru / lstm, blocks.py:76-78, 88), consumed once by ds2_rnn_fwd_gxbf16.
+// recurrent layer in the bf16 training mode (aten::addmm inside aten::gru / lstm, blocks.py:76-78, 88), consumed once by ds2_rnn_fwd_x.
 // Four-wave 256 x 256 x 64 kernel only (gemm_nt_w4.h, OBF): returns 1 — nothing launched, call ds2_gemm_bf16_nt — where that kernel does not
 // apply (K % 64, fewer tiles than CUs, N % 8, alignment), 0 when launched, < 0 on error.
 extern "C" int ds2_gemm_bf16_nt_obf16(int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias, void* stream) {
@@ -1300,7 +1303,8 @@ extern "C" size_t ds2_gemm_bf16_tn_splitk_group_workspace_bytes(int nprob, const
   if (splitk < 1) splitk = 1;
   size_t n = 0;
   for (int i = 0; i < nprob; ++i) n += (size_t)splitk * probs[i].M * probs[i].N * sizeof(float);   // (an upper bound: one-slab products use none)
-  return n;
+  for (int i = 0; i < nprob; ++i) n += (size_t)ceil_div(probs[i].M, 256) * ceil_div(probs[i].N, 256) * sizeof(int);   // arrival counters of the fused reduce
+  return n + 256;
 }
 
 extern "C" int ds2_gemm_bf16_tn_splitk_group(int nprob, const ds2_tn_problem* probs, int splitk, void* workspace, size_t workspace_bytes,
@@ -1341,11 +1345,22 @@ extern "C" int ds2_gemm_bf16_tn_splitk_group(int nprob, const ds2_tn_problem* pr
     p.to_slab = nslab > 1;
     p.slab0 = term * splitk;
     p.nslab = (term == 0 && nslab > 1) ? nslab : 0;
+    p.tick = nullptr; p.nslab_all = nslab;
     if (term == 0) {
       p.partial = (float*)((char*)workspace + off);
       if (nslab > 1) { off += (size_t)nslab * q.M * q.N * sizeof(float); elems += (long long)q.M * q.N / 4; any_slab = true; }
     } else {
       p.partial = g.p[i - term].partial;
+    }
+  }
+  // arrival counters behind the slabs (256-byte aligned), one int per tile of every product that has slabs
+  const size_t tick_off = (off + 255) & ~(size_t)255;
+  size_t tick_bytes = 0;
+  for (int i = 0; i < nprob; ++i) {
+    if (g.p[i].nslab > 0) { g.p[i].tick = (int*)((char*)workspace + tick_off + tick_bytes); tick_bytes += (size_t)g.p[i].ntiles * sizeof(int); }
+    else if (g.p[i].to_slab) {                           // a further term of a product: its first term's counters
+      int t0 = i; while (t0 > 0 && probs[t0 - 1].C == probs[i].C) --t0;
+      g.p[i].tick = g.p[t0].tick;
     }
   }
   for (int i = nprob; i < TN_MAX_PROBLEMS; ++i) { g.p[i] = g.p[0]; g.p[i].nslab = 0; }
@@ -1366,6 +1381,16 @@ extern "C" int ds2_gemm_bf16_tn_splitk_group(int nprob, const ds2_tn_problem* pr
     const int kc = g.p[i].kchunk, klast = q.K - (splitk - 1) * kc;
     w4 = w4 && (q.K % 64) == 0 && kc >= 128 && klast >= 128 && (long long)q.lda * 128 < (1ll << 31) && (long long)q.ldb * 128 < (1ll << 31);
   }
+  // EXPERIMENT of round 6, measured and NOT the default (DS2_TN_FUSED_REDUCE=1 with DS2_EXPERIMENTAL=1 selects it; profiles/r06_experiments.txt):
+  // fused reduce in the four-wave kernel — the last workgroup to deliver a slab of a tile sums the tile's slabs in slab order and writes C, the
+  // same additions in the same order as splitk_reduce_group_kernel, without that launch.  Bit-identical, and SLOWER: c3 step +1.1 ms with a
+  // full device-scope fence per workgroup (768 cache write-back + invalidate operations per launch drop the operand panels the XCD's L2 holds
+  // for the workgroups that are still multiplying), +0.6 ms with release-only fences (the last arrivers' 768 KB of slab reads at a single
+  // CU's HBM rate sit on the launch's tail, and the write-backs remain) — against 4 x 53 us of reduce launches saved.
+  static const char* fr_env = ds2_exp_getenv("DS2_TN_FUSED_REDUCE");
+  const bool fused = w4 && any_slab && (fr_env && fr_env[0] == '1') && workspace_bytes >= tick_off + tick_bytes;
+  if (!fused) for (int i = 0; i < TN_MAX_PROBLEMS; ++i) g.p[i].tick = nullptr;
+  else DS2_HIP(hipMemsetAsync((char*)workspace + tick_off, 0, tick_bytes, (hipStream_t)stream));
   if (w4) {
     static bool w4_attr = false;
     if (!w4_attr) {
@@ -1379,7 +1404,7 @@ extern "C" int ds2_gemm_bf16_tn_splitk_group(int nprob, const ds2_tn_problem* pr
     hipLaunchKernelGGL(gemm_bf16_tn_glds_kernel<true>, dim3(items), dim3(512), G_LDS, (hipStream_t)stream, unused, 0, 0, g);
     DS2_LAUNCH_CHECK("gemm_bf16_tn_glds_kernel<grouped>");
   }
-  if (any_slab) {
+  if (any_slab && !fused) {
     int blocks = (int)((elems + 255) / 256);
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, elems);
@@ -1431,7 +1456,7 @@ extern "C" int ds2_gemm_bf16_tn_group(int nprob, const ds2_tn_problem* probs, in
 
 // dst (R, ldd) bf16 = cast(src (R, C) fp32, pitch lds); ldd % 8 == 0, ldd >= C, pad columns zero.
 // n contiguous bf16 -> fp32 (n % 8 == 0, 16-byte aligned): the widening of bf16 x-projections for a forward recurrence that cannot run as a
-// persistent launch (ds2_rnn_fwd_gxbf16 returned 1: cooldown after a starved launch, or a shape without a persistent kernel)
+// persistent launch (ds2_rnn_fwd_x returned 1: cooldown after a starved launch, or a shape without a persistent kernel)
 __global__ __launch_bounds__(256) void widen_bf16_kernel(const bf16x8* __restrict__ src, f32x4* __restrict__ dst, long long n8) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
     const bf16x8 v = __builtin_nontemporal_load(src + i);

@@ -22,6 +22,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_w4_kernel(TnSGroup grp) {
   int pM, pN, plda, pldb, zs, orig, nt, kchunk, ntx, pK;
   float* Cfinal; float* Cslab; long long ldcf;
   bool partial;
+  int* tick; int nslab_all; const float* slabs;          // fused reduce (TnSProb::tick): this tile's arrival counter, slabs per tile, slab 0
   {
     // blockIdx.x -> item: workgroup ids go round the 8 XCDs, one workgroup per CU, so the 32 workgroups an XCD holds at a time are the ids
     // 256 c + x + 8 j.  They take 32 CONSECUTIVE items = (with at most 8 column tiles) a few whole tile rows of one K slice, which share their
@@ -36,20 +37,21 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_w4_kernel(TnSGroup grp) {
         item = full + (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + (o >> 3);
       }
     }
-    A = grp.p[0].A; B = grp.p[0].B; Cfinal = grp.p[0].C; Cslab = grp.p[0].partial;
+    A = grp.p[0].A; B = grp.p[0].B; Cfinal = grp.p[0].C; Cslab = grp.p[0].partial; tick = grp.p[0].tick; nslab_all = grp.p[0].nslab_all;
     pM = grp.p[0].M; pN = grp.p[0].N; pK = grp.p[0].K; plda = grp.p[0].lda; pldb = grp.p[0].ldb; ldcf = grp.p[0].ldc; ntx = grp.p[0].ntx;
     nt = grp.p[0].ntiles; kchunk = grp.p[0].kchunk;
     int first = 0, slab0 = grp.p[0].slab0, to_slab = grp.p[0].to_slab;
 #pragma unroll
     for (int k = 1; k < TN_MAX_PROBLEMS; ++k)
       if (k < grp.nprob && item >= grp.p[k].first_item) {
-        A = grp.p[k].A; B = grp.p[k].B; Cfinal = grp.p[k].C; Cslab = grp.p[k].partial;
+        A = grp.p[k].A; B = grp.p[k].B; Cfinal = grp.p[k].C; Cslab = grp.p[k].partial; tick = grp.p[k].tick; nslab_all = grp.p[k].nslab_all;
         pM = grp.p[k].M; pN = grp.p[k].N; pK = grp.p[k].K; plda = grp.p[k].lda; pldb = grp.p[k].ldb; ldcf = grp.p[k].ldc; ntx = grp.p[k].ntx;
         nt = grp.p[k].ntiles; kchunk = grp.p[k].kchunk; first = grp.p[k].first_item; slab0 = grp.p[k].slab0; to_slab = grp.p[k].to_slab;
       }
     const int local = item - first;
     zs = local / nt; orig = local % nt;
     partial = to_slab != 0;
+    slabs = Cslab;
     Cslab += (long long)(slab0 + zs) * pM * pN;
   }
   int tile = orig;
@@ -201,6 +203,36 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_w4_kernel(TnSGroup grp) {
       for (int j = 0; j < 8; ++j) {
         const int col = n0 + wn * 128 + j * 16 + fseg * 4;
         if (row < pM && col < pN) *reinterpret_cast<f32x4*>(C + (long long)row * ldc + col) = acc[i][j];
+      }
+    }
+    // ---- fused reduce: whoever delivers the LAST slab of this tile adds all of them (slab 0 first, as splitk_reduce_group_kernel does) and
+    // writes C.  Release: every thread's slab stores are made visible at device scope before the workgroup's arrival is counted; acquire: the
+    // last arriver invalidates its view before it reads the other workgroups' slabs (they may sit on another XCD).
+    if (partial && tick) {
+      __shared__ int s_last;
+      // (release ONLY here — write back, no invalidate: a full fence by each of the 768 workgroups drops the operand panels its XCD's L2
+      // holds for the neighbours that are still multiplying, measured +0.22 ms per launch; the acquire is the last arriver's alone)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __syncthreads();
+      if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(tick + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nslab_all - 1;
+      __syncthreads();
+      if (s_last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const long long slab = (long long)pM * pN;
+#pragma unroll 1
+        for (int i = 0; i < 8; ++i) {
+          const int row = m0 + wm * 128 + i * 16 + frow;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int col = n0 + wn * 128 + j * 16 + fseg * 4;
+            if (row < pM && col < pN) {
+              const float* sp = slabs + (long long)row * pN + col;
+              f32x4 sum = *reinterpret_cast<const f32x4*>(sp);
+              for (int k = 1; k < nslab_all; ++k) sum += *reinterpret_cast<const f32x4*>(sp + k * slab);
+              *reinterpret_cast<f32x4*>(Cfinal + (long long)row * ldcf + col) = sum;
+            }
+          }
+        }
       }
     }
   }

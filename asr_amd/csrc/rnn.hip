@@ -91,9 +91,13 @@ struct RnnArgs {
   // first wave that gave up polling; and (host side only, never dereferenced on the device) the context itself
   int* status;
   ds2_rnn_ctx* hctx;
-  // forward, persistent kernels of the bf16 training mode only (ds2_rnn_fwd_gxbf16): the x-projections as the bf16 tensor the projection GEMM
+  // forward, persistent kernels of the bf16 training mode only (ds2_rnn_fwd_x): the x-projections as the bf16 tensor the projection GEMM
   // wrote (ds2_gemm_bf16_nt_obf16), same (T,B,2,G*H) layout; `gx` is then NULL and never written (the gates go to gates_bf)
   const __bf16* gxb;
+  // forward, persistent kernels, optional (NULL: not produced): (2, ceil(B/16), H) sums of h over time and over the 16 batch rows of a tile,
+  // per direction — the column sums of this layer's output y = h_fwd + h_bwd without a pass over it (ds2_center_colstats)
+  float* hsum;
+  int prearmed;       // host side only: the caller has filled the whole workspace with 0xff (ds2_rnn_ctx.ws_prearmed): persistent launchers skip their own fill
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -688,6 +692,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
 #pragma unroll
   for (int g = 0; g < G; ++g) pb[g] = pact ? a.bhh[(dir * G + g) * H + j] : 0.f;
   float pprev = 0.f;                                                         // h_{t-1} (GRU) / c_{t-1} (LSTM)
+  float psum = 0.f;                                                          // sum over time of this pair's h (a.hsum)
   // A wave's 64 threads are 4 batch rows x 16 units = 64 / EPL complete 16-byte chunks of the packed buffer (chunk = one row, EPL units), so
   // every wave publishes (and resets) its own chunks — no workgroup-wide staging.  Lane p < 64 / EPL handles row (wave & 3) * 4 + (p & 3) and
   // unit group p >> 2 of this slice.
@@ -703,10 +708,18 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
   const int t0 = dir == 0 ? 0 : T - 1;
   const long long dH = (dir == 0 ? 1LL : -1LL) * B * 2 * H, dG = dH * G;
   long long eH = (((long long)t0 * B + b) * 2 + dir) * H + j, eG = (((long long)t0 * B + b) * 2 + dir) * G * H + j;
-  float pgx[G], pgx_next[G];
+  // x-projections: fp32 (a.gx) or the bf16 tensor of ds2_gemm_bf16_nt_obf16 (a.gxb).  The NEXT step's values are requested one step ahead and
+  // kept RAW (the loaded bits, untouched) until they are used: widening a bf16 right behind its load would put the load's full latency — a wait
+  // for the vector-memory counter — into every time step (measured: +0.48 us per step)
+  float pgx[G];
+  unsigned pgx_raw[G];
 #pragma unroll
-  for (int g = 0; g < G; ++g) { pgx[g] = 0.f; pgx_next[g] = 0.f; }
+  for (int g = 0; g < G; ++g) { pgx[g] = 0.f; pgx_raw[g] = 0u; }
   const bool gx_is_bf = a.gxb != nullptr;                                    // (wave-uniform; BF training launches only)
+  // bf16: the lane loads the aligned DWORD that holds its unit and its neighbour's (the same load instruction as the fp32 form) and keeps its
+  // half: even units the low one (<< 16), odd units the high one (& 0xffff0000)
+  const unsigned gx_shift = (gx_is_bf && !(j & 1)) ? 16u : 0u, gx_mask = gx_is_bf ? 0xffff0000u : 0xffffffffu;
+  const unsigned* gxw = reinterpret_cast<const unsigned*>(a.gxb);           // dword view: element index e -> word e >> 1
   if (pact) {
 #pragma unroll
     for (int g = 0; g < G; ++g) pgx[g] = gx_is_bf ? ldnt_bf(a.gxb + eG + g * H) : ldnt(a.gx + eG + g * H);
@@ -746,6 +759,12 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
   for (int s = 0; s < T; ++s) {
     const int t = dir == 0 ? s : T - 1 - s;
     PTRACE(0);
+    if (s > 0) {
+      // x-projections of THIS step: requested one step ago, landed; widened HERE, in front of the poll (idle time), not behind it on the
+      // dependent chain gather -> MFMA -> gate math
+#pragma unroll
+      for (int g = 0; g < G; ++g) pgx[g] = __uint_as_float((pgx_raw[g] << gx_shift) & gx_mask);
+    }
     f32x4 acc[MB][NS * G];
 #pragma unroll
     for (int i = 0; i < MB; ++i)
@@ -839,10 +858,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
       PTRACE(6);
     }
 #endif
-    if (s > 0) {
-#pragma unroll
-      for (int g = 0; g < G; ++g) pgx[g] = pgx_next[g];  // x-projections of THIS step: loaded one step ago, landed
-    }
+
     // ---- the x-projections of the NEXT step are requested HERE: the vector-memory counter retires in order, so whatever is outstanding when the
     // next poll pass is issued delays it by its full latency; right behind the gather these loads have the whole step to land.  (The step's own
     // results go out at its end, behind the publish: nothing of the next step depends on them.)
@@ -850,10 +866,10 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
     if (more && pact) {
       if (gx_is_bf) {
 #pragma unroll
-        for (int g = 0; g < G; ++g) pgx_next[g] = ldnt_bf(a.gxb + eG + dG + g * H);
+        for (int g = 0; g < G; ++g) pgx_raw[g] = __builtin_nontemporal_load(gxw + ((eG + dG + g * H) >> 1));
       } else {
 #pragma unroll
-        for (int g = 0; g < G; ++g) pgx_next[g] = ldnt(a.gx + eG + dG + g * H);
+        for (int g = 0; g < G; ++g) pgx_raw[g] = __float_as_uint(ldnt(a.gx + eG + dG + g * H));
       }
     }
 #pragma unroll
@@ -922,7 +938,25 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
     PTRACE(5);                                          // publish issued
     // ---- the step's saved-for-backward outputs: last, in the shadow of the exchange
     store_outputs(eH, eG, out_g, out_aux, hnew, live);
+    psum += hnew;                                       // (0 beyond the sample's length, exactly what hbuf holds there)
     eH += dH; eG += dG;
+  }
+  if (a.hsum) {
+    // column sums of h over this tile's 16 batch rows: over the 4 rows of a wave by two xor-shuffles, over the 4 waves of a sub-tile through
+    // LDS in wave order (fixed order: run-to-run identical)
+    float v = psum;
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    __syncthreads();                                    // (every wave is past its last read of `red`)
+    float* rs = reinterpret_cast<float*>(&red[0][0][0][0]);
+    if (lane < 16) rs[wave * 16 + lane] = v;
+    __syncthreads();
+    if ((wave & 3) == 0 && lane < 16 && (wave >> 2) < MB * NS) {
+      const int sb = wave >> 2, mb_ = sb / NS, ns_ = sb % NS;
+      const float tot = ((rs[wave * 16 + lane] + rs[(wave + 1) * 16 + lane]) + rs[(wave + 2) * 16 + lane]) + rs[(wave + 3) * 16 + lane];
+      const int jj = j0 + ns_ * 16 + lane, tile = bt * MB + mb_;
+      if (jj < H && tile < (B + 15) / 16) a.hsum[((long long)dir * ((B + 15) / 16) + tile) * H + jj] = tot;
+    }
   }
   PTRACE_DUMP(0);
 }
@@ -1493,6 +1527,13 @@ inline int pick_mb(int B, int H) {
 // transient (another process or stream holding CUs for a moment) costs a few slow steps, not the rest of the run.  The backward kernel must
 // be switched off (ds2_rnn_persistent_enable) by a caller that runs collectives on another stream during backward, because a persistent
 // launch needs every one of its workgroups resident at once.  No context: no persistent launch.
+// ds2_rnn_ctx.ws_prearmed is a one-shot promise about the workspace of the NEXT recurrence call through the context: read and cleared at entry
+int take_prearmed(ds2_rnn_ctx* c) {
+  if (!c) return 0;
+  const int v = c->ws_prearmed;
+  c->ws_prearmed = 0;
+  return v;
+}
 bool persist_allowed(ds2_rnn_ctx* c, bool bwd) {
   if (!c || !c->status_dev) return false;
   if (c->cooldown != 0) {
@@ -1566,7 +1607,7 @@ int try_launch_persistent_fwd(RnnArgs a, hipStream_t st) {
   a.p_census = xcd_local_fits(a.p_gs, 2 * nbt) ? 1 : 0;
   char* xbuf = reinterpret_cast<char*>(a.pk);
   const size_t xbytes = 4 * NPL * fwd_xbuf_bytes(a.B, a.H, BF ? 1 : 0);
-  DS2_HIP(hipMemsetAsync(xbuf, 0xff, xbytes + CENSUS_BYTES, st));      // every 16-byte chunk = the "not yet published" sentinel; census words = -1
+  if (!a.prearmed) DS2_HIP(hipMemsetAsync(xbuf, 0xff, xbytes + CENSUS_BYTES, st));      // every 16-byte chunk = the "not yet published" sentinel; census words = -1
   unsigned* census = reinterpret_cast<unsigned*>(xbuf + xbytes);
   // 1-D grid.  Census mode: one workgroup per CU of the whole chip, roles by real XCD id (surplus workgroups exit); else exactly the workgroups needed
   dim3 grid(a.p_census ? cu_count() : a.p_gs * nbt * 2), block(NW * 64);
@@ -1629,7 +1670,7 @@ int try_launch_persistent_bwd(RnnArgs a, hipStream_t st) {
   a.p_census = xcd_local_fits(a.p_gs, 2 * nbt) ? 1 : 0;
   char* xbuf = reinterpret_cast<char*>(a.pk);
   const size_t xbytes = 4 * NPL * bwd_xbuf_bytes(G, a.B, a.H, BF ? 1 : 0);
-  DS2_HIP(hipMemsetAsync(xbuf, 0xff, xbytes + CENSUS_BYTES, st));
+  if (!a.prearmed) DS2_HIP(hipMemsetAsync(xbuf, 0xff, xbytes + CENSUS_BYTES, st));
   unsigned* census = reinterpret_cast<unsigned*>(xbuf + xbytes);
   dim3 grid(a.p_census ? cu_count() : a.p_gs * nbt * 2), block(NW * 64);   // see the forward launcher
   static const char* sl = getenv("DS2_RNN_SPIN_LIMIT");
@@ -1805,6 +1846,7 @@ extern "C" int ds2_rnn_fwd_ex(ds2_rnn_ctx* ctx, int gates, float* gx, const void
   a.gx = gx; a.aux = aux; a.hbuf = hbuf; a.wp = (const float*)wp_fwd; a.bhh = bhh; a.pk = (float*)ws; a.lens = lens_dev;
   a.T = T; a.B = B; a.H = H; a.gates_bf = (__bf16*)gates_bf16; a.h_bf = (__bf16*)h_bf16;
   a.hctx = ctx; a.status = ctx ? ctx->status_dev : nullptr;
+  a.prearmed = take_prearmed(ctx);
   int scratch_path = 0;
   int& last_path = ctx ? ctx->last_path : scratch_path;
   {
@@ -1845,27 +1887,36 @@ extern "C" int ds2_rnn_fwd_ex(ds2_rnn_ctx* ctx, int gates, float* gx, const void
   return bf16 == 1 ? dispatch<true>(gates, false, a, (hipStream_t)stream) : dispatch<false>(gates, false, a, (hipStream_t)stream);
 }
 
-// The forward recurrence of the bf16 training mode from bf16 x-projections (ds2_gemm_bf16_nt_obf16's output): persistent kernels only.
-// Returns 0 = launched (ds2_rnn_last_path bit 0 set), 1 = not taken — the shape has no persistent kernel, or the context is in its cooldown /
-// has the forward kernel switched off; nothing was launched or counted: widen the x-projections (ds2_cast_f32_from_bf16) and call
-// ds2_rnn_fwd_ex —, < 0 error.  gates_bf16 (the packed saved-gate records) is required: there is no fp32 gx to overwrite with the gates.
-extern "C" int ds2_rnn_fwd_gxbf16(ds2_rnn_ctx* ctx, int gates, const void* gx_bf16, const void* wp_fwd, const float* bhh, float* hbuf, float* aux,
-                                  const int* lens_dev, int T, int B, int H, void* gates_bf16, void* h_bf16, void* ws, size_t ws_bytes, void* stream) {
-  DS2_REQUIRE(gates == 3 || gates == 4, "ds2_rnn_fwd_gxbf16: gates must be 3 (GRU) or 4 (LSTM)");
-  DS2_REQUIRE(gx_bf16 && wp_fwd && bhh && hbuf && aux && lens_dev && gates_bf16, "ds2_rnn_fwd_gxbf16: null pointer");
-  DS2_REQUIRE(T > 0 && B > 0 && H > 0 && (H % 4) == 0, "ds2_rnn_fwd_gxbf16: need H %% 4 == 0 (H=%d)", H);
-  DS2_REQUIRE(ws && ws_bytes >= ds2_rnn_fwd_workspace_bytes(B, H, 1), "ds2_rnn_fwd_gxbf16: workspace too small");
-  if (!persist_idle(ctx, false)) return 1;
+// ds2_rnn_fwd_ex for the bf16 TRAINING mode (bf16 == 1, packed gate records), with two more optional operands:
+//   gx_bf16  the x-projections as the bf16 tensor ds2_gemm_bf16_nt_obf16 wrote (then gx may be NULL).  Persistent kernels only: returns 1 —
+//            nothing launched, nothing counted — when the call cannot run as a persistent launch (cooldown, forward kernel switched off, no
+//            persistent kernel for the shape); the caller widens (ds2_cast_f32_from_bf16) and calls again with gx.
+//   hsum     (2, ceil(B/16), H) fp32: per direction and 16-row batch tile the sums of h over time — written by a persistent launch only
+//            (ds2_rnn_last_path() & 1), the input of ds2_center_colstats.
+// Returns 0 = done, 1 = see gx_bf16, < 0 error.
+extern "C" int ds2_rnn_fwd_x(ds2_rnn_ctx* ctx, int gates, float* gx, const void* gx_bf16, const void* wp_fwd, const float* bhh, float* hbuf, float* aux,
+                             const int* lens_dev, int T, int B, int H, void* gates_bf16, void* h_bf16, float* hsum, void* ws, size_t ws_bytes, void* stream) {
+  DS2_REQUIRE(gates == 3 || gates == 4, "ds2_rnn_fwd_x: gates must be 3 (GRU) or 4 (LSTM)");
+  DS2_REQUIRE((gx || gx_bf16) && wp_fwd && bhh && hbuf && aux && lens_dev && gates_bf16, "ds2_rnn_fwd_x: null pointer");
+  DS2_REQUIRE(T > 0 && B > 0 && H > 0 && (H % 4) == 0, "ds2_rnn_fwd_x: need H %% 4 == 0 (H=%d)", H);
+  DS2_REQUIRE(ws && ws_bytes >= ds2_rnn_fwd_workspace_bytes(B, H, 1), "ds2_rnn_fwd_x: workspace too small");
+  if (!gx && !persist_idle(ctx, false)) return 1;
   RnnArgs a{};
-  a.gx = nullptr; a.gxb = (const __bf16*)gx_bf16; a.aux = aux; a.hbuf = hbuf; a.wp = (const float*)wp_fwd; a.bhh = bhh; a.pk = (float*)ws; a.lens = lens_dev;
-  a.T = T; a.B = B; a.H = H; a.gates_bf = (__bf16*)gates_bf16; a.h_bf = (__bf16*)h_bf16;
-  a.hctx = ctx; a.status = ctx->status_dev;
-  a.dbg = ctx->debug_flags;
+  a.gx = gx_bf16 ? nullptr : gx; a.gxb = (const __bf16*)gx_bf16; a.aux = aux; a.hbuf = hbuf; a.wp = (const float*)wp_fwd; a.bhh = bhh; a.pk = (float*)ws;
+  a.lens = lens_dev; a.T = T; a.B = B; a.H = H; a.gates_bf = (__bf16*)gates_bf16; a.h_bf = (__bf16*)h_bf16; a.hsum = hsum;
+  a.hctx = ctx; a.status = ctx ? ctx->status_dev : nullptr;
+  a.prearmed = take_prearmed(ctx);
+  a.dbg = ctx ? ctx->debug_flags : 0;
+  int scratch_path = 0;
+  int& last_path = ctx ? ctx->last_path : scratch_path;
   const int rc = gates == 3 ? try_launch_persistent_fwd<3, true>(a, (hipStream_t)stream) : try_launch_persistent_fwd<4, true>(a, (hipStream_t)stream);
   if (rc < 0) return rc;
-  if (rc == 0) return 1;
-  ctx->last_path = (ctx->last_path & ~(1 | 32 | 256)) | 1;
-  return 0;
+  last_path = (last_path & ~(1 | 32 | 256)) | (rc == 1 ? 1 : 0);
+  if (rc == 1) return 0;
+  if (!gx) return 1;
+  a.gx = gx; a.gxb = nullptr; a.hsum = nullptr;
+  DS2_HIP(hipMemsetAsync(ws, 0, ds2_rnn_fwd_workspace_bytes(B, H, 1), (hipStream_t)stream));
+  return dispatch<true>(gates, false, a, (hipStream_t)stream);
 }
 
 extern "C" int ds2_rnn_fwd(ds2_rnn_ctx* ctx, int gates, float* gx, const void* wp_fwd, const float* bhh, float* hbuf, float* aux, const int* lens_dev, int T,
@@ -2027,6 +2078,7 @@ extern "C" int ds2_rnn_bwd_ex(ds2_rnn_ctx* ctx, int gates, const float* dy, int 
   a.dhn_bf = (__bf16*)dhn_bf16; a.bsum = bias_part;
   a.lens = lens_dev; a.T = T; a.B = B; a.H = H;
   a.hctx = ctx; a.status = ctx ? ctx->status_dev : nullptr;
+  a.prearmed = take_prearmed(ctx);
   int scratch_path = 0, scratch_kind = 0;
   int& last_path = ctx ? ctx->last_path : scratch_path;
   int& last_bwd_kind = ctx ? ctx->last_bwd_kind : scratch_kind;
@@ -2103,6 +2155,7 @@ extern "C" int ds2_rnn_bwd_bn(ds2_rnn_ctx* ctx, int gates, const float* dyn, int
     a.lens = lens_dev; a.T = T; a.B = B; a.H = H;
     a.bn_x = bn_x; a.ldbnx = ldx; a.bn_mean = bn_mean; a.bn_var = bn_var; a.bn_gamma = bn_gamma; a.bn_s0 = bn_s0; a.bn_s1 = bn_s1; a.bn_eps = bn_eps;
     a.hctx = ctx; a.status = ctx ? ctx->status_dev : nullptr;
+    a.prearmed = take_prearmed(ctx);
     a.dbg = ctx ? ctx->debug_flags : 0;
     // (only when the persistent backward is armed: a cool-down call is counted once, by the un-fused call below)
     const int rc = persist_idle(ctx, true) ? (gates == 3 ? try_launch_ksplit_bwd<3>(a, st) : try_launch_ksplit_bwd<4>(a, st)) : 0;

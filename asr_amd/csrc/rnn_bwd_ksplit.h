@@ -526,7 +526,7 @@ int try_launch_ksplit_bwd(RnnArgs a, hipStream_t st) {
   a.p_census = xcd_local_fits(gs, 2 * nbt) ? 1 : 0;
   char* xbuf = reinterpret_cast<char*>(a.pk);
   const size_t xbytes = NPL * ksplit_xbuf_bytes(a.B, a.H);
-  DS2_HIP(hipMemsetAsync(xbuf, 0xff, xbytes + CENSUS_BYTES, st));     // both slots: tag 1 = "not the data of steps 0 / 1"; census words = -1
+  if (!a.prearmed) DS2_HIP(hipMemsetAsync(xbuf, 0xff, xbytes + CENSUS_BYTES, st));     // both slots: tag 1 = "not the data of steps 0 / 1"; census words = -1
   unsigned* census = reinterpret_cast<unsigned*>(xbuf + xbytes);
   dim3 grid(a.p_census ? cu_count() : gs * nbt * 2), block(NW * 64);
   static const char* sl = getenv("DS2_RNN_SPIN_LIMIT");

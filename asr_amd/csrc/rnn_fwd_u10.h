@@ -277,7 +277,7 @@ int try_launch_fwd_u10(RnnArgs a, hipStream_t st) {
   a.p_nbt = nbt; a.p_gs = gs; a.p_cux = CUS_PER_XCD; a.p_census = 0;         // 128 slices never fit one XCD: placement-independent protocol
   char* xbuf = reinterpret_cast<char*>(a.pk);
   const size_t xbytes = 4 * 2 * fwd_xbuf_bytes(a.B, a.H, 1);
-  DS2_HIP(hipMemsetAsync(xbuf, 0xff, xbytes + CENSUS_BYTES, st));
+  if (!a.prearmed) DS2_HIP(hipMemsetAsync(xbuf, 0xff, xbytes + CENSUS_BYTES, st));
   unsigned* census = reinterpret_cast<unsigned*>(xbuf + xbytes);
   dim3 grid(gs * nbt * 2), block(NW * 64);
   static const char* sl = getenv("DS2_RNN_SPIN_LIMIT");

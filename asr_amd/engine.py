@@ -107,7 +107,10 @@ CONV2_WGRAD = _tune("DS2_CONV2_WGRAD", "nhwc")
 # bf16 training, the x-projections of a recurrent layer (DS2_GX_BF16, default 1): the projection GEMM rounds its fp32 accumulators (+ bias) to
 # bf16 at the store and the forward recurrence reads that — 394 MB written + read per c3 layer instead of 788 (ops.gemm_bf16_nt_obf16; the gates
 # are saved as bf16 records anyway).  0: fp32 x-projections as rounds 1-5.  A/B and parity deltas: profiles/r06_gx_bf16_ab.txt.
-GX_BF16 = _tune("DS2_GX_BF16", "1") != "0"
+GX_BF16 = _tune("DS2_GX_BF16", "0") != "0"
+# the workspace of a recurrence call (exchange buffers of a persistent launch: every byte 0xff) is armed AHEAD of the GEMM in front of the
+# recurrence (ops.rnn_ws) instead of by a fill launched between that GEMM and the recurrence (DS2_WS_PREARM=0: as rounds 1-5)
+WS_PREARM = _tune("DS2_WS_PREARM", "1") != "0"
 
 
 def _f32_split_ok(M: int, N: int, K: int, H: int = 8) -> bool:
@@ -313,6 +316,9 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
     mean = var = None
     for l in range(L):
         lc = LayerCtx()
+        bf = cfg.precision == "bf16"
+        rmode = 1 if bf else (2 if (F32_RNN == "split" and H % 32 == 0) else 0)
+        ws_f = ops.rnn_ws("fwd", G, B, H, rmode, x.device) if WS_PREARM else None
         if l > 0:
             bp = f"rnns.{l}.batch_norm.module."
             if not training:
@@ -342,8 +348,6 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
                 xn = None                                        # backward takes dW_ih from the split copy (6 bytes per element instead of 4 + 6)
         else:
             gx = ops.gemm(xn, W[f"rnns.{l}.wih_cat"], transB=True, bias=W[f"rnns.{l}.bih_cat"])  # (M, 2GH)
-        bf = cfg.precision == "bf16"
-        rmode = 1 if bf else (2 if (F32_RNN == "split" and H % 32 == 0) else 0)
         wpf, wpb = ops.rnn_pack(G, W[f"rnns.{l}.whh_cat"], bf16=rmode)
         # bf16 training (B % 8 == 0, the condition of the bf16 dGx path in backward): the saved gates are ONE packed bf16 record per
         # hidden unit; the fp32 x-projection buffer is then dead after the recurrence
@@ -352,13 +356,13 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
             # (not for shapes whose backward recurrence is known to run one launch per step - LSTM H = 1280: nobody would read the copy)
             h_bf = (torch.empty(M, 2 * H, dtype=torch.bfloat16, device=x.device)
                     if (WGRAD_TN and OVERLAP_MODE == "2" and T > 1 and _BWD_PERSISTENT.get((ops.rnn_ctx_key(x.device), G, H, B), True)) else None)
-            hbuf, aux, rec = ops.rnn_fwd(G, gx, wpf, W[f"rnns.{l}.bhh_cat"], lens_dev, T, B, H, bf16=True, packed_gates=True, h_bf16=h_bf)
+            hbuf, aux, rec = ops.rnn_fwd(G, gx, wpf, W[f"rnns.{l}.bhh_cat"], lens_dev, T, B, H, bf16=True, packed_gates=True, h_bf16=h_bf, ws=ws_f)
             gx = None
             lc.rec, lc.gshape = rec, (M, 2 * G * H)
             if h_bf is not None and (ops.rnn_last_path(x.device) & 1):
                 lc.h_bf = h_bf                                   # (only a persistent launch writes it)
         else:
-            hbuf, aux = ops.rnn_fwd(G, gx, wpf, W[f"rnns.{l}.bhh_cat"], lens_dev, T, B, H, bf16=rmode)
+            hbuf, aux = ops.rnn_fwd(G, gx, wpf, W[f"rnns.{l}.bhh_cat"], lens_dev, T, B, H, bf16=rmode, ws=ws_f)
         lc.wpb = wpb
         nxt = f"rnns.{l + 1}.batch_norm.module" if l + 1 < L else "fc.0.module.0"
         y, mean, var = ops.add_colstats(hbuf[:, :H], hbuf[:, H:], *run(nxt))
@@ -523,6 +527,7 @@ def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy, done, private: bo
     n_idle = _idle_cus_beside_bwd_recurrence(dev, B, H)
     idle_ok = (group_ok and WGRAD_SIDE == "sk" and WGRAD_IDLE and T > 1
                and WGRAD_IDLE_MIN_CUS <= n_idle < torch.cuda.get_device_properties(dev).multi_processor_count // 2)
+    ws_b = ops.rnn_ws("bwd", G, B, H, 1, dev) if WS_PREARM else None      # (the top layer's: behind the fc block's backward, which is short)
     for l in range(L - 1, -1, -1):
         lc = ctx.layers[l]
         if queued_side is not None:
@@ -547,10 +552,10 @@ def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy, done, private: bo
         bias_part = torch.empty(B, 2, 4, H, dtype=torch.float32, device=dev) if want_tn else None
         if isinstance(dy, BnGrad):
             ops.rnn_bwd_bn(G, dy.dyn, dy.x, dy.mean, dy.var, dy.gamma, dy.sums, lc.gx, lc.aux, lc.hbuf, lc.wpb, lens_dev, T, B, H, bf16=True,
-                           dgx_bf16=dgx_bf, gates_bf16=lc.rec, dhn_bf16=dhn_bf, bias_part=bias_part)
+                           dgx_bf16=dgx_bf, gates_bf16=lc.rec, dhn_bf16=dhn_bf, bias_part=bias_part, ws=ws_b)
         else:
             ops.rnn_bwd(G, dy, lc.gx, lc.aux, lc.hbuf, lc.wpb, lens_dev, T, B, H, bf16=True, dgx_bf16=dgx_bf, gates_bf16=lc.rec, dhn_bf16=dhn_bf,
-                        bias_part=bias_part)
+                        bias_part=bias_part, ws=ws_b)
         _BWD_PERSISTENT[shape_key] = bool(ops.rnn_last_path(dev) & 2)
         if queued_idle is not None:
             # enqueued BEHIND the recurrence launch: the recurrence's workgroups are dispatched first, the GEMM's fill what is left
@@ -566,6 +571,7 @@ def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy, done, private: bo
         else:
             queued = (l, (lc.aux, lc.hbuf, lc.xn), dgx_bf)
         # ---- critical path: dXn = dGx W_ih -> BatchNorm1d backward -> the next layer's dy
+        ws_b = ops.rnn_ws("bwd", G, B, H, 1, dev) if (WS_PREARM and l > 0) else None     # the layer below's recurrence workspace, armed ahead of this GEMM
         dxn = ops.gemm_bf16_nt(dgx_bf, (lc.wihT if lc.wihT is not None else ops.cast_transpose_bf16(W[f"rnns.{l}.wih_cat"])))
         if l > 0:
             bp = f"rnns.{l}.batch_norm.module."

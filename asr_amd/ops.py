@@ -47,7 +47,7 @@ class RnnCtx(C.Structure):
     bits, cooldown, enable switches or starvation record."""
     _fields_ = [("size", C.c_int), ("persist_fwd", C.c_int), ("persist_bwd", C.c_int), ("cooldown", C.c_int), ("rearm_calls", C.c_int),
                 ("starved_total", C.c_int), ("last_path", C.c_int), ("last_bwd_kind", C.c_int), ("debug_flags", C.c_int),
-                ("reserved", C.c_int * 7), ("status_dev", C.c_void_p), ("poison_host", C.c_void_p), ("poison_dev", C.c_void_p)]
+                ("ws_prearmed", C.c_int), ("reserved", C.c_int * 6), ("status_dev", C.c_void_p), ("poison_host", C.c_void_p), ("poison_dev", C.c_void_p)]
 
 
 _RNN_TLS = threading.local()
@@ -877,6 +877,26 @@ def rnn_pack(gates: int, whh: Tensor, bf16=False):
     return wpf, wpb
 
 
+def rnn_ws(kind: str, gates: int, B: int, H: int, bf16, device) -> Tensor:
+    """The workspace of ONE rnn_fwd ("fwd") / rnn_bwd / rnn_bwd_bn ("bwd") call, filled with 0xff bytes NOW, in stream order: pass it as `ws=` to
+    the call.  A persistent launch needs its exchange buffers armed with that pattern; armed here — ahead of the GEMM in front of the recurrence —
+    the fill is no longer a launch of its own between that GEMM and the launch that waits for every CU (ds2_rnn_ctx.ws_prearmed)."""
+    lib = _lib.load()
+    n = lib.ds2_rnn_fwd_workspace_bytes(B, H, int(bf16)) if kind == "fwd" else lib.ds2_rnn_bwd_workspace_bytes(gates, B, H, int(bf16))
+    ws = _ws(n, device)
+    _lib.check(lib.ds2_memset_async(ws.data_ptr(), 0xff, ws.numel(), _stream()), "ds2_memset_async")
+    return ws
+
+
+def _take_ws(ws: Optional[Tensor], need: int, device) -> Tensor:
+    """`ws` from rnn_ws (promised to the library through the context's one-shot flag) or a fresh, un-armed workspace"""
+    if ws is None:
+        return _ws(need, device)
+    assert ws.numel() >= need and ws.device == torch.device(device)
+    rnn_ctx(device).ws_prearmed = 1
+    return ws
+
+
 def rnn_persistent_enable(forward: bool = True, backward: bool = True, device=None) -> None:
     """Which bf16 recurrences may run as one persistent launch.  A persistent launch needs all of its workgroups resident at once, so
     the backward one must be off while collectives run on a communication stream during backward (data-parallel training)."""
@@ -921,14 +941,16 @@ def rnn_persistent_counters(device=None):
 
 
 def rnn_fwd(gates: int, gx: Tensor, wp_fwd: Tensor, bhh: Tensor, lens_dev: Tensor, T: int, B: int, H: int, bf16=False,
-            packed_gates: bool = False, h_bf16: Optional[Tensor] = None):
+            packed_gates: bool = False, h_bf16: Optional[Tensor] = None, hsum: Optional[Tensor] = None, ws: Optional[Tensor] = None):
     """gx (T*B, 2*G*H) in/out; returns (hbuf (T*B, 2H), aux (T*B, 2H)[, gates_bf (T*B, 2H, 4) bf16]).
     bf16: False / 0 fp32, True / 1 bf16 operands, 2 = fp32 mode with the split persistent kernel (h and W_hh as hi + lo bf16 planes, three MFMAs
     per product: fp32-grade results at the bf16 matrix rate; wp_fwd from rnn_pack(bf16=2); rnn_last_path() & 32 when it took the call).
     packed_gates: the saved-for-backward gates go to one 8-byte bf16 record per hidden unit (gx keeps the x-projections; GRU aux
     is not written) — pass the returned buffer to rnn_bwd.
-    h_bf16: optional (T*B, 2H) bf16 buffer that receives a bf16 copy of hbuf — by a persistent launch only (rnn_last_path() & 1)."""
-    _chk_f32(bhh)
+    h_bf16: optional (T*B, 2H) bf16 buffer that receives a bf16 copy of hbuf — by a persistent launch only (rnn_last_path() & 1).
+    hsum: optional (2, ceil(B/16), H) fp32 buffer that receives, per direction and 16-row batch tile, the sums of h over time — by a persistent
+    launch only (rnn_last_path() & 1); bf16 training mode (bf16 = 1, packed_gates)."""
+    _chk_f32(bhh, hsum)
     assert gx.is_contiguous() and bhh.is_contiguous()
     if h_bf16 is not None:
         assert h_bf16.dtype == torch.bfloat16 and h_bf16.is_contiguous() and h_bf16.numel() == T * B * 2 * H
@@ -937,18 +959,22 @@ def rnn_fwd(gates: int, gx: Tensor, wp_fwd: Tensor, bhh: Tensor, lens_dev: Tenso
     aux = torch.empty_like(hbuf)
     rec = torch.empty(T * B, 2 * H, 4, dtype=torch.bfloat16, device=gx.device) if packed_gates else None
     wsb = lib.ds2_rnn_fwd_workspace_bytes(B, H, int(bf16))
-    ws = _ws(wsb, gx.device)
-    if gx.dtype == torch.bfloat16:
-        # bf16 x-projections (gemm_bf16_nt_obf16): persistent launches of the bf16 training mode take them as they are; anything else (a
-        # cooldown after a starved launch, a shape without a persistent kernel) gets them widened and runs as before
-        assert int(bf16) == 1 and packed_gates, "bf16 x-projections: bf16 training mode with packed gate records only"
-        rc = lib.ds2_rnn_fwd_gxbf16(_ctxp(gx.device), gates, gx.data_ptr(), wp_fwd.data_ptr(), bhh.data_ptr(), hbuf.data_ptr(), aux.data_ptr(),
-                                    lens_dev.data_ptr(), T, B, H, _ptr(rec), _ptr(h_bf16), ws.data_ptr(), wsb, _stream())
-        if rc == 0:
-            return hbuf, aux, rec
-        if rc != 1:
-            _lib.check(rc, "ds2_rnn_fwd_gxbf16")
-        gx = widen_bf16(gx)
+    ws = _take_ws(ws, wsb, gx.device)
+    if gx.dtype == torch.bfloat16 or hsum is not None:
+        # the bf16 training mode's entry point: bf16 x-projections (gemm_bf16_nt_obf16) and / or the per-tile column sums of h.  Persistent
+        # launches take bf16 x-projections as they are; anything else (a cooldown after a starved launch, a shape without a persistent
+        # kernel) gets them widened and runs as before
+        assert int(bf16) == 1 and packed_gates, "rnn_fwd: bf16 x-projections / hsum belong to the bf16 training mode with packed gate records"
+        gxb = gx if gx.dtype == torch.bfloat16 else None
+        gxf = None if gxb is not None else gx
+        for _attempt in (0, 1):
+            rc = lib.ds2_rnn_fwd_x(_ctxp(gx.device), gates, _ptr(gxf), _ptr(gxb), wp_fwd.data_ptr(), bhh.data_ptr(), hbuf.data_ptr(), aux.data_ptr(),
+                                   lens_dev.data_ptr(), T, B, H, _ptr(rec), _ptr(h_bf16), _ptr(hsum), ws.data_ptr(), wsb, _stream())
+            if rc != 1:
+                break
+            gxf, gxb = widen_bf16(gxb), None
+        _lib.check(rc, "ds2_rnn_fwd_x")
+        return hbuf, aux, rec
     _chk_f32(gx)
     _lib.check(lib.ds2_rnn_fwd_ex(_ctxp(gx.device), gates, gx.data_ptr(), wp_fwd.data_ptr(), bhh.data_ptr(), hbuf.data_ptr(), aux.data_ptr(),
                                   lens_dev.data_ptr(), T, B, H, int(bf16), _ptr(rec), _ptr(h_bf16), ws.data_ptr(), wsb, _stream()),
@@ -980,7 +1006,7 @@ def rnn_last_path(device=None) -> int:
 
 def rnn_bwd(gates: int, dy: Tensor, gx: Optional[Tensor], aux: Tensor, hbuf: Tensor, wp_bwd: Tensor, lens_dev: Tensor, T: int, B: int, H: int,
             bf16: bool = False, dgx_bf16: Optional[Tensor] = None, gates_bf16: Optional[Tensor] = None, dhn_bf16: Optional[Tensor] = None,
-            bias_part: Optional[Tensor] = None):
+            bias_part: Optional[Tensor] = None, ws: Optional[Tensor] = None):
     """dgx_bf16: optional (T*B, 2*G*H) bf16 buffer that receives dGx (then `gx` keeps the gates).
     gates_bf16: the packed records of rnn_fwd(packed_gates=True), read instead of gx / GRU aux (gx may then be None).
     dhn_bf16 (GRU, (T*B, 2H) bf16 copy of d(hn)) and bias_part ((B, 2, 4, H) fp32 per-batch-row sums over time of the gate gradients):
@@ -997,7 +1023,7 @@ def rnn_bwd(gates: int, dy: Tensor, gx: Optional[Tensor], aux: Tensor, hbuf: Ten
     assert gx is not None or (dgx_bf16 is not None and gates_bf16 is not None)
     lib = _lib.load()
     wsb = lib.ds2_rnn_bwd_workspace_bytes(gates, B, H, int(bf16))
-    ws = _ws(wsb, dy.device)
+    ws = _take_ws(ws, wsb, dy.device)
     _lib.check(lib.ds2_rnn_bwd_ex(_ctxp(dy.device), gates, dy.data_ptr(), _row_pitch(dy), _ptr(gx), aux.data_ptr(), hbuf.data_ptr(), wp_bwd.data_ptr(),
                                   lens_dev.data_ptr(), T, B, H, int(bf16), _ptr(dgx_bf16), _ptr(gates_bf16), _ptr(dhn_bf16), _ptr(bias_part),
                                   ws.data_ptr(), wsb, _stream()), "ds2_rnn_bwd")
@@ -1024,7 +1050,7 @@ def bn1d_bwd_sums(dY: Tensor, X: Tensor, mean: Tensor, var: Tensor, gamma: Tenso
 
 def rnn_bwd_bn(gates: int, dyn: Tensor, bn_x: Tensor, mean: Tensor, var: Tensor, gamma: Tensor, sums: Tensor, gx: Optional[Tensor], aux: Tensor,
                hbuf: Tensor, wp_bwd: Tensor, lens_dev: Tensor, T: int, B: int, H: int, bf16: bool = False, dgx_bf16: Optional[Tensor] = None,
-               gates_bf16: Optional[Tensor] = None, dhn_bf16: Optional[Tensor] = None, bias_part: Optional[Tensor] = None):
+               gates_bf16: Optional[Tensor] = None, dhn_bf16: Optional[Tensor] = None, bias_part: Optional[Tensor] = None, ws: Optional[Tensor] = None):
     """rnn_bwd for a layer whose output feeds a BatchNorm1d: `dyn` is the gradient wrt the BatchNorm's OUTPUT, `bn_x` its input, `sums` the
     (s0, s1) result of bn1d_bwd_sums.  The K-split kernel applies the elementwise BatchNorm backward on the fly (rnn_last_path() & 16);
     any other kernel family gets it materialised first."""
@@ -1033,7 +1059,7 @@ def rnn_bwd_bn(gates: int, dyn: Tensor, bn_x: Tensor, mean: Tensor, var: Tensor,
     assert s0.is_contiguous() and s1.is_contiguous() and s0.numel() == H == s1.numel() and bn_x.shape == (T * B, H) and dyn.shape == (T * B, H)
     lib = _lib.load()
     wsb = lib.ds2_rnn_bwd_workspace_bytes(gates, B, H, int(bf16))
-    ws = _ws(wsb, dyn.device)
+    ws = _take_ws(ws, wsb, dyn.device)
     def call(scratch):
         return lib.ds2_rnn_bwd_bn(_ctxp(dyn.device), gates, dyn.data_ptr(), _row_pitch(dyn), bn_x.data_ptr(), _row_pitch(bn_x), mean.data_ptr(), var.data_ptr(),
                                   gamma.data_ptr(), s0.data_ptr(), s1.data_ptr(), BN_EPS, _ptr(scratch), _ptr(gx), aux.data_ptr(),

@@ -51,12 +51,17 @@ typedef struct ds2_rnn_ctx {
   int last_path;            /* out: bits describing what the last forward / backward call launched (ds2_rnn_last_path) */
   int last_bwd_kind;        /* out: 0 step kernels, 1 all-gather persistent, 2 K-split persistent */
   int debug_flags;          /* kernel-family selectors (ds2_debug_flags) */
-  int reserved[7];
+  int ws_prearmed;          /* in, one-shot (cleared by the next recurrence call through this context): the caller has filled that call's whole
+                             * workspace with 0xff bytes (ds2_memset_async) EARLIER in the stream — a persistent launch then skips its own
+                             * fill of the exchange buffers, which otherwise sits between the projection GEMM and the launch that needs every CU */
+  int reserved[6];
   int* status_dev;
   int* poison_host;
   int* poison_dev;
 } ds2_rnn_ctx;
 int ds2_rnn_ctx_init(ds2_rnn_ctx* ctx, int* status_dev, int* poison_host, int* poison_dev);
+/* hipMemsetAsync through the C ABI (workspace pre-arming, see ws_prearmed). */
+int ds2_memset_async(void* dst, int value, size_t bytes, void* stream);
 /* Kernel-family selectors of the recurrence (every selection computes the full result; used by the parity tests and A/B scripts):
  * 8 / 16 alternative tile shapes of the wide step kernels, 64 one launch per time step instead of the persistent kernels, 128 the
  * all-gather persistent backward kernel instead of the K-split one.  Returns the previous value; 0 = production.  Bits 1 / 2 (skip the
@@ -83,7 +88,7 @@ int ds2_gemm_bf16_nt(int M, int N, int K, const void* A, int lda, long long stri
                      size_t workspace_bytes, void* stream);
 /* C[M,N] **bf16** = A[M,K] B[N,K]^T + bias (fp32 accumulation and bias add, ONE rounding at the store; ldc in bf16 elements, N, ldc % 8 == 0):
  * the x-projections of a recurrent layer in the bf16 training mode (aten::addmm inside aten::gru / lstm, blocks.py:76-78, 88), read once by
- * ds2_rnn_fwd_gxbf16.  Returns 1 — nothing launched, call ds2_gemm_bf16_nt — where the four-wave kernel does not apply (K % 64 != 0, fewer
+ * ds2_rnn_fwd_x.  Returns 1 — nothing launched, call ds2_gemm_bf16_nt — where the four-wave kernel does not apply (K % 64 != 0, fewer
  * 256 x 256 tiles than CUs, alignment); 0 = launched; < 0 = error. */
 int ds2_gemm_bf16_nt_obf16(int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias, void* stream);
 /* n contiguous bf16 -> fp32 (n % 8 == 0, 16-byte aligned bases). */
@@ -281,13 +286,18 @@ int ds2_rnn_fwd(ds2_rnn_ctx* ctx, int gates, float* gx, const void* wp_fwd, cons
  * dW_hh GEMM).  Written by a PERSISTENT launch only: check ds2_rnn_last_path() & 1 after the call. */
 int ds2_rnn_fwd_ex(ds2_rnn_ctx* ctx, int gates, float* gx, const void* wp_fwd, const float* bhh, float* hbuf, float* aux, const int* lens_dev, int T, int B,
                    int H, int bf16, void* gates_bf16, void* h_bf16, void* ws, size_t ws_bytes, void* stream);
-/* The forward recurrence of the bf16 training mode reading its x-projections as the **bf16** tensor ds2_gemm_bf16_nt_obf16 wrote (same
- * (T,B,2,G*H) layout; half the bytes written by the projection and read here: aten::gru / aten::lstm of blocks.py:87-89 take them from
- * aten::addmm at full precision — the rounding is part of the stated bf16-mode tolerance).  Persistent kernels only; gates_bf16 is required.
- * Returns 0 = launched (ds2_rnn_last_path() & 1), 1 = not taken and nothing launched or counted (cooldown, forward kernel switched off, no
- * persistent kernel for the shape): widen with ds2_cast_f32_from_bf16 and call ds2_rnn_fwd_ex; < 0 = error. */
-int ds2_rnn_fwd_gxbf16(ds2_rnn_ctx* ctx, int gates, const void* gx_bf16, const void* wp_fwd, const float* bhh, float* hbuf, float* aux,
-                       const int* lens_dev, int T, int B, int H, void* gates_bf16, void* h_bf16, void* ws, size_t ws_bytes, void* stream);
+/* ds2_rnn_fwd_ex for the bf16 TRAINING mode (bf16 operands, packed gate records required) with two more optional operands.
+ * gx_bf16: the x-projections as the **bf16** tensor ds2_gemm_bf16_nt_obf16 wrote (same (T,B,2,G*H) layout; half the bytes written by the
+ *   projection and read here: aten::gru / aten::lstm of blocks.py:87-89 take them from aten::addmm at full precision — the rounding is part of
+ *   the stated bf16-mode tolerance); gx may then be NULL.  Persistent kernels only: the call returns 1 — nothing launched, nothing counted —
+ *   when it cannot run as a persistent launch (cooldown, forward kernel switched off, no persistent kernel for the shape); widen with
+ *   ds2_cast_f32_from_bf16 and call again with gx.
+ * hsum: (2, ceil(B/16), H) fp32, per direction and 16-row batch tile the sums over time of h — the column sums of the layer's output
+ *   y = h_fwd + h_bwd (blocks.py:92) without a pass over it; written by a PERSISTENT launch only (ds2_rnn_last_path() & 1); input of
+ *   ds2_center_colstats.
+ * Returns 0 = done, 1 = see gx_bf16, < 0 = error. */
+int ds2_rnn_fwd_x(ds2_rnn_ctx* ctx, int gates, float* gx, const void* gx_bf16, const void* wp_fwd, const float* bhh, float* hbuf, float* aux,
+                  const int* lens_dev, int T, int B, int H, void* gates_bf16, void* h_bf16, float* hsum, void* ws, size_t ws_bytes, void* stream);
 size_t ds2_rnn_bwd_workspace_bytes(int gates, int B, int H, int bf16);
 /* dgx_bf16: NULL, or a (T,B,2,G*H) bf16 buffer that receives the gradient wrt the x-projections instead of gx (which then keeps
  * the gates): the bf16-mode GEMMs consume it directly.  gates_bf16: NULL, or the packed records written by ds2_rnn_fwd — read

@@ -41,7 +41,7 @@ def test_projection_gemm_with_bf16_output_is_the_rounded_fp32_result(dev, M, N, 
 
 @pytest.mark.parametrize("G,H,B,T", [(3, 1024, 64, 40), (3, 768, 32, 33), (4, 1280, 32, 21), (3, 256, 16, 50)])
 def test_forward_recurrence_from_bf16_x_projections_is_bit_identical_to_the_widened_input(dev, G, H, B, T):
-    """ds2_rnn_fwd_gxbf16: the persistent forward kernel reading bf16 x-projections gives exactly what it gives for the same values widened
+    """ds2_rnn_fwd_x: the persistent forward kernel reading bf16 x-projections gives exactly what it gives for the same values widened
     to fp32 (h, the packed gate records, the bf16 h copy); in a cooldown (the persistent kernels off) the binding widens and falls back."""
     from asr_amd import ops
     torch.manual_seed(G * H + B + T)
