@@ -715,7 +715,9 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
   unsigned pgx_raw[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) { pgx[g] = 0.f; pgx_raw[g] = 0u; }
-  const bool gx_is_bf = a.gxb != nullptr;                                    // (wave-uniform; BF training launches only)
+  // (compiled out of the split form of the fp32 mode: its instances sit at the register limit, and neither operand exists in that mode)
+  constexpr bool TRAIN_OPS = BF && !SP;
+  const bool gx_is_bf = TRAIN_OPS && a.gxb != nullptr;                       // (wave-uniform; BF training launches only)
   // bf16: the lane loads the aligned DWORD that holds its unit and its neighbour's (the same load instruction as the fp32 form) and keeps its
   // half: even units the low one (<< 16), odd units the high one (& 0xffff0000)
   const unsigned gx_shift = (gx_is_bf && !(j & 1)) ? 16u : 0u, gx_mask = gx_is_bf ? 0xffff0000u : 0xffffffffu;
@@ -759,11 +761,13 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
   for (int s = 0; s < T; ++s) {
     const int t = dir == 0 ? s : T - 1 - s;
     PTRACE(0);
-    if (s > 0) {
-      // x-projections of THIS step: requested one step ago, landed; widened HERE, in front of the poll (idle time), not behind it on the
-      // dependent chain gather -> MFMA -> gate math
+    if constexpr (TRAIN_OPS) {
+      if (s > 0) {
+        // x-projections of THIS step: requested one step ago, landed; widened HERE, in front of the poll (idle time), not behind it on the
+        // dependent chain gather -> MFMA -> gate math
 #pragma unroll
-      for (int g = 0; g < G; ++g) pgx[g] = __uint_as_float((pgx_raw[g] << gx_shift) & gx_mask);
+        for (int g = 0; g < G; ++g) pgx[g] = __uint_as_float((pgx_raw[g] << gx_shift) & gx_mask);
+      }
     }
     f32x4 acc[MB][NS * G];
 #pragma unroll
@@ -859,6 +863,12 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
     }
 #endif
 
+    if constexpr (!TRAIN_OPS) {
+      if (s > 0) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) pgx[g] = __uint_as_float(pgx_raw[g]);  // x-projections of THIS step: loaded one step ago, landed
+      }
+    }
     // ---- the x-projections of the NEXT step are requested HERE: the vector-memory counter retires in order, so whatever is outstanding when the
     // next poll pass is issued delays it by its full latency; right behind the gather these loads have the whole step to land.  (The step's own
     // results go out at its end, behind the publish: nothing of the next step depends on them.)
@@ -938,10 +948,10 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_persistent_kernel(RnnArgs a, 
     PTRACE(5);                                          // publish issued
     // ---- the step's saved-for-backward outputs: last, in the shadow of the exchange
     store_outputs(eH, eG, out_g, out_aux, hnew, live);
-    psum += hnew;                                       // (0 beyond the sample's length, exactly what hbuf holds there)
+    if constexpr (TRAIN_OPS) psum += hnew;              // (0 beyond the sample's length, exactly what hbuf holds there)
     eH += dH; eG += dG;
   }
-  if (a.hsum) {
+  if (TRAIN_OPS && a.hsum) {
     // column sums of h over this tile's 16 batch rows: over the 4 rows of a wave by two xor-shuffles, over the 4 waves of a sub-tile through
     // LDS in wave order (fixed order: run-to-run identical)
     float v = psum;

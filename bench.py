@@ -80,7 +80,7 @@ def kernel_source_sha256():
     return h.hexdigest()
 
 
-PMC_SUMMARY = "r05_pmc_persistent.json"
+PMC_SUMMARY = "r06_pmc_persistent.json"
 
 
 def expected_ksplit_instance(G, H):
@@ -855,6 +855,24 @@ def main():
                     **({"fused": "BatchNorm1d backward (elementwise half) of the layer above"} if (ksplit and bn_fused) else {}),
                     "us_per_launch": bwd_layer_us / bl,
                     "us_per_time_step": bwd_layer_us / T, "launches_per_step": bl * L}
+    # The recurrences are serial chains of T dependent steps: beside the MFMA fraction each carries the LATENCY FLOOR of a time step — the
+    # phases in which its waves wait (exchange publish -> visible -> gathered, the workgroup barrier, the loop-top drain), measured on the
+    # product's own kernels built with phase stamps (scripts/probe_persist_timeline.hip -> profiles/r06_persist_phases.json) — and, where the
+    # PMC summary applies, counted HBM traffic over algorithmic bytes (> 1: the exchange's write-through, not operand re-reads: traffic_note)
+    try:
+        with open(os.path.join(ROOT, "profiles", "r06_persist_phases.json")) as f:
+            phases = json.load(f)
+    except (OSError, ValueError):
+        phases = None
+    for rl, key, pers_ in ((roofline, "fwd", persistent and not (path_bits & 256)), (roofline_bwd, "bwd", ksplit)):
+        if phases and same_shape and pers_ and key in phases.get("kernels", {}):
+            k_ = phases["kernels"][key]
+            rl["latency_floor_us_per_time_step"] = k_["latency_floor_us"]
+            rl["latency_floor_frac_of_time_step"] = k_["latency_floor_us"] / k_["us_per_time_step_traced_build"]
+            rl["phases_us_per_time_step"] = k_["phases_us"]
+            rl["phases_source"] = phases["source"] + " (phase-stamped build of the same kernel sources: " + str(k_["us_per_time_step_traced_build"]) + " us per time step)"
+        if rl.get("traffic"):
+            rl["wasted_traffic_ratio"] = rl["traffic"] / rl["algorithmic_hbm_bytes_per_launch"]
     if bwd_layer_us > layer_us:
         roofline, roofline_bwd = roofline_bwd, roofline
     if roofline["traffic"] is None and pmc_why_not:

@@ -39,19 +39,23 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1, e2;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
   float msf = 0, msb = 0;
+  ds2_rnn_ctx ctx;                                       // caller-owned recurrence context (round 5's C ABI)
+  int* status_dev;
+  CK(hipMalloc(&status_dev, 8 * sizeof(int))); CK(hipMemset(status_dev, 0, 8 * sizeof(int)));
+  if (ds2_rnn_ctx_init(&ctx, status_dev, nullptr, nullptr)) { printf("ctx init failed: %s\n", ds2_last_error()); return 1; }
   for (int rep = 0; rep < 3; ++rep) {
     CK(hipMemset(trace, 0, 2 * NW * 8 * 8));
     CK(hipEventRecord(e0));
-    if (ds2_rnn_fwd(G, gx, wpf, bhh, hbuf, aux, lens, T, B, H, bf, rec, ws, wsf, nullptr)) { printf("fwd failed: %s\n", ds2_last_error()); return 1; }
+    if (ds2_rnn_fwd(&ctx, G, gx, wpf, bhh, hbuf, aux, lens, T, B, H, bf, rec, ws, wsf, nullptr)) { printf("fwd failed: %s\n", ds2_last_error()); return 1; }
     CK(hipEventRecord(e1));
-    if (ds2_rnn_bwd(G, dy, H, nullptr, aux, hbuf, wpb, lens, T, B, H, bf, dgx, rec, wsb_, wsb, nullptr)) { printf("bwd failed: %s\n", ds2_last_error()); return 1; }
+    if (ds2_rnn_bwd(&ctx, G, dy, H, nullptr, aux, hbuf, wpb, lens, T, B, H, bf, dgx, rec, wsb_, wsb, nullptr)) { printf("bwd failed: %s\n", ds2_last_error()); return 1; }
     CK(hipEventRecord(e2));
     CK(hipDeviceSynchronize());
     CK(hipEventElapsedTime(&msf, e0, e1)); CK(hipEventElapsedTime(&msb, e1, e2));
   }
   int st[8];
-  ds2_rnn_persistent_status(st);
-  printf("paths taken: %d (3 = both persistent, 7 = K-split backward), starved %d\n", ds2_rnn_last_path(), st[0]);
+  ds2_rnn_persistent_status(&ctx, st);
+  printf("paths taken: %d (3 = both persistent, 7 = K-split backward), starved %d\n", ds2_rnn_last_path(&ctx), st[0]);
   std::vector<unsigned long long> tr(2 * NW * 8);
   CK(hipMemcpy(tr.data(), trace, tr.size() * 8, hipMemcpyDeviceToHost));
   const char* names_ag[7] = {"publish -> loop top", "gather (poll)", "HBM issue + MFMA + partials", "barrier", "LDS sums + gate math", "stage + publish", "-"};
@@ -59,7 +63,7 @@ int main(int argc, char** argv) {
   const char* names_ks[7] = {"store issue -> loop top", "gather (poll) + reduce-scatter", "next fetch issued + gate math", "dGh -> LDS + barrier", "LDS read + MFMA issue",
                              "MFMA drain + pack + publish", "result stores + offset step"};
   for (int kind = 0; kind < 2; ++kind) {
-    const char** names = (kind == 1 && (ds2_rnn_last_path() & 4)) ? names_ks : names_ag;
+    const char** names = (kind == 1 && (ds2_rnn_last_path(&ctx) & 4)) ? names_ks : names_ag;
     const double us_step = (kind ? msb : msf) * 1e3 / T;
     double tot = 0;
     for (int k = 0; k < 7; ++k) tot += (double)tr[(kind * NW + 0) * 8 + k];

@@ -42,6 +42,7 @@ dst = torch.empty_like(src)
 moved = torch.zeros(1, dtype=torch.int64, device=dev)
 setting = {"wgs": 0, "usec": 0.0}
 real_all_reduce = dist.all_reduce
+GRAD_ELEMS = 1
 
 
 class _Done:
@@ -52,7 +53,9 @@ class _Done:
 def all_reduce(t, *a, **k):
     """the big gradient bucket -> the stand-in kernel on the stream the reducer issues its collective on; everything else: RCCL (one rank)"""
     if t.numel() > (1 << 20) and setting["wgs"] > 0:
-        rc = hog.hog_launch(setting["wgs"], setting["usec"], src.data_ptr(), dst.data_ptr(), PER_WG, moved.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        # (the "serial" schedule reduces bucket by bucket: each bucket's stand-in runs for its share of the collective's duration)
+        usec = setting["usec"] * min(1.0, t.numel() / float(GRAD_ELEMS))
+        rc = hog.hog_launch(setting["wgs"], usec, src.data_ptr(), dst.data_ptr(), PER_WG, moved.data_ptr(), torch.cuda.current_stream().cuda_stream)
         assert rc == 0, rc
         return _Done()
     return real_all_reduce(t, *a, **k)
@@ -65,6 +68,7 @@ for _ in range(3):
     tr.step((bx, bt, bp.clone(), bs))
 tr.synchronize()
 red = tr._get_reducer()
+GRAD_ELEMS = red.flat_grad.numel()
 rows = []
 print(f"# c3 bf16 (5 x 1024 BiGRU, B = 64, T_in = 1001), schedule {red.mode}, one forced RCCL rank; the big bucket's all-reduce replaced by N x 512-thread")
 print("# HBM-streaming workgroups for D us (scripts/probe_hog.hip).  ms per step, conv-stack backward span, exposed communication, GB moved by the stand-in")
