@@ -64,6 +64,10 @@ SIGNATURES = {
     "ds2_bn1d_apply_f32": (i32, [vp, i32, vp, i32, i32, i32, vp, vp, vp, vp, f32, vp]),
     "ds2_bn1d_apply_bf16": (i32, [vp, i32, vp, i32, i32, i32, vp, vp, vp, vp, f32, vp]),
     "ds2_bn1d_bwd_f32": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, vp, vp, vp, f32, vp, vp, vp, sz, vp]),
+    "ds2_bn1d_bwd_xbf16": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, vp, vp, vp, f32, vp, vp, vp, sz, vp]),
+    "ds2_center_colstats": (i32, [vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, vp, vp, vp, vp, vp, f32, vp, sz, vp]),
+    "ds2_wih_fold_bf16": (i32, [vp, i32, vp, i32, i32, vp, vp, vp, vp, f32, vp, i32, vp, vp, vp, vp]),
+    "ds2_scale_rank1_f32": (i32, [vp, i32, i32, i32, vp, vp, vp, vp]),
     "ds2_chanreduce_workspace_bytes": (sz, [i32]),
     "ds2_bn2d_stats_f32": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp, f32, vp, sz, vp]),
     "ds2_bn2d_act_fwd_f32": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, f32, vp]),
@@ -101,6 +105,7 @@ SIGNATURES = {
     "ds2_rnn_bwd_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "ds2_rnn_bwd_ex": (i32, [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, sz, vp]),
     "ds2_rnn_bwd_bn": (i32, [vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, sz, vp]),
+    "ds2_rnn_bwd_bn_xbf16": (i32, [vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, sz, vp]),
     "ds2_rnn_bias_grads": (i32, [i32, vp, i32, i32, vp, vp, vp]),
     "ds2_rnn_bwd": (i32, [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
     "ds2_ctc_workspace_bytes": (sz, [i32, i32, i32]),

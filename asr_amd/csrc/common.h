@@ -72,3 +72,5 @@ int ds2i_col_finalize_sums(const float* part, int chunks, int H, float* out0, fl
 // norm.hip: the elementwise half of BatchNorm1d backward, dX = gamma rstd (dY - s0/M - xhat s1/M), from already reduced column sums s0 / s1
 int ds2i_bn1d_bwd_apply(const float* dY, int lddy, const float* X, int ldx, float* dX, int lddx, int M, int H, const float* mean, const float* var,
                         const float* gamma, const float* s0, const float* s1, float eps, hipStream_t s);
+int ds2i_bn1d_bwd_apply_xbf(const float* dY, int lddy, const void* X_bf16, int ldx, float* dX, int lddx, int M, int H, const float* mean, const float* var,
+                            const float* gamma, const float* s0, const float* s1, float eps, hipStream_t stream);

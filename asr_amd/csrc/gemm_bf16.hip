@@ -1455,6 +1455,54 @@ extern "C" int ds2_gemm_bf16_tn_group(int nprob, const ds2_tn_problem* probs, in
 }
 
 // dst (R, ldd) bf16 = cast(src (R, C) fp32, pitch lds); ldd % 8 == 0, ldd >= C, pad columns zero.
+// The BatchNorm1d in front of a recurrent layer folded into the layer's input projection (round 6): with the centred operand yc = y - m0
+// (ds2_center_colstats) the projection  BN(y) W^T + b  is  yc (W diag(s))^T + (b + W c),  s = gamma rsqrt(var + eps),  c = beta - delta s.
+// One block per weight row: W'[g][i] = bf16(W[g][i] s[i]) (row pitch ldw2, pad columns zero) and bias'[g] = b[g] + sum_i W[g][i] c[i] (fp32
+// weights, thread-strided partial sums combined by xor-shuffles and across the four waves in wave order: run-to-run identical); block 0
+// also writes s and c (the epilogue of the weight gradient needs them: ds2_scale_rank1_f32).
+__global__ __launch_bounds__(256) void wih_fold_kernel(const float* __restrict__ W, int ldw, const float* __restrict__ bias, const float* __restrict__ var,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ delta,
+                                                       float eps, __bf16* __restrict__ W2, int ldw2, float* __restrict__ bias2,
+                                                       float* __restrict__ colscale, float* __restrict__ colshift, int I) {
+  __shared__ float red[4];
+  const int g = blockIdx.x;
+  const float* wrow = W + (long long)g * ldw;
+  __bf16* orow = W2 + (long long)g * ldw2;
+  float dot = 0.f;
+  for (int c0 = threadIdx.x * 4; c0 < ldw2; c0 += 1024) {
+    bf16x4 o = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+    if (c0 < I) {                                          // (I % 4 == 0)
+      const f32x4 w = *reinterpret_cast<const f32x4*>(wrow + c0);
+      const f32x4 vv = *reinterpret_cast<const f32x4*>(var + c0), ga = *reinterpret_cast<const f32x4*>(gamma + c0);
+      const f32x4 be = *reinterpret_cast<const f32x4*>(beta + c0), de = *reinterpret_cast<const f32x4*>(delta + c0);
+      f32x4 sc;
+      sc.x = ga.x * rsqrtf(vv.x + eps); sc.y = ga.y * rsqrtf(vv.y + eps); sc.z = ga.z * rsqrtf(vv.z + eps); sc.w = ga.w * rsqrtf(vv.w + eps);
+      const f32x4 sh = be - de * sc;
+      const f32x4 ws = w * sc;
+      o = bf16x4{(__bf16)ws.x, (__bf16)ws.y, (__bf16)ws.z, (__bf16)ws.w};
+      dot += (w.x * sh.x + w.y * sh.y) + (w.z * sh.z + w.w * sh.w);
+      if (g == 0) { *reinterpret_cast<f32x4*>(colscale + c0) = sc; *reinterpret_cast<f32x4*>(colshift + c0) = sh; }
+    }
+    *reinterpret_cast<bf16x4*>(orow + c0) = o;
+  }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) dot += __shfl_xor(dot, m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+  __syncthreads();
+  if (threadIdx.x == 0) bias2[g] = (bias ? bias[g] : 0.f) + (((red[0] + red[1]) + red[2]) + red[3]);
+}
+extern "C" int ds2_wih_fold_bf16(const float* W, int ldw, const float* bias, int R, int I, const float* var, const float* gamma, const float* beta,
+                                 const float* delta, float eps, void* W2_bf16, int ldw2, float* bias2, float* colscale, float* colshift, void* stream) {
+  DS2_REQUIRE(W && var && gamma && beta && delta && W2_bf16 && bias2 && colscale && colshift && R > 0 && I > 0, "ds2_wih_fold_bf16: null pointer");
+  DS2_REQUIRE((I % 4) == 0 && (ldw % 4) == 0 && ldw2 >= I && (ldw2 % 8) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)W2_bf16 % 16) == 0 &&
+              ((uintptr_t)var % 16) == 0 && ((uintptr_t)gamma % 16) == 0 && ((uintptr_t)beta % 16) == 0 && ((uintptr_t)delta % 16) == 0 &&
+              ((uintptr_t)colscale % 16) == 0 && ((uintptr_t)colshift % 16) == 0, "ds2_wih_fold_bf16: I %% 4, pitches and 16-byte alignment");
+  hipLaunchKernelGGL(wih_fold_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, W, ldw, bias, var, gamma, beta, delta, eps, (__bf16*)W2_bf16, ldw2, bias2,
+                     colscale, colshift, I);
+  DS2_LAUNCH_CHECK("wih_fold_kernel");
+  return 0;
+}
+
 // n contiguous bf16 -> fp32 (n % 8 == 0, 16-byte aligned): the widening of bf16 x-projections for a forward recurrence that cannot run as a
 // persistent launch (ds2_rnn_fwd_x returned 1: cooldown after a starved launch, or a shape without a persistent kernel)
 __global__ __launch_bounds__(256) void widen_bf16_kernel(const bf16x8* __restrict__ src, f32x4* __restrict__ dst, long long n8) {

@@ -9,12 +9,15 @@
 // are bit-reproducible run to run, no float atomics.  Every kernel is a coalesced stream:
 // 16-byte loads along the contiguous axis, wavefront shuffles + LDS for the in-block reduction.
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
 // (rows that are only 4-byte aligned — T = 501-style lengths — still move as ONE dword-aligned dwordx4 per lane: the hardware takes it, the
 // aligned(4) vector type says so to the compiler; rounds 1-4 fell back to four scalar accesses there)
 typedef float f32x4_dw __attribute__((ext_vector_type(4), aligned(4)));
+typedef __bf16 nbf16x4 __attribute__((ext_vector_type(4)));
+constexpr int BN_ROWS_PER_BLOCK = 32;
 __device__ __forceinline__ f32x4 ld4(const float* __restrict__ p, int valid, bool vec) {
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
   if (valid >= 4 && vec) {
@@ -165,8 +168,6 @@ __global__ __launch_bounds__(256) void col_finalize_kernel(const float* __restri
 // into (scale, shift) ONCE, then the thread streams rows with one 16-byte load and one store each — the earlier form re-loaded
 // four parameter vectors per element quad and ran at a third of the HBM rate.  OUT_BF16: write the bf16 GEMM operand directly
 // (row pitch ldy % 8 == 0, pad columns H..ldy zero).
-typedef __bf16 nbf16x4 __attribute__((ext_vector_type(4)));
-constexpr int BN_ROWS_PER_BLOCK = 32;
 template <bool OUT_BF16>
 __global__ __launch_bounds__(256) void bn1d_apply_kernel(const float* __restrict__ X, int ldx, void* __restrict__ Yv, int ldy, int M, int H,
                                                          const float* __restrict__ mean, const float* __restrict__ var,
@@ -621,6 +622,184 @@ __global__ __launch_bounds__(256) void transpose2d_kernel(const float* __restric
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// BatchNorm1d folded into the projection (round 6, DS2_BN_FOLD): the direction sum + statistics pass writes the CENTRED sum as the bf16 GEMM
+// operand and nothing else.
+//   y = Xa + Xb (blocks.py:92);  m0 = column mean of y from the per-tile sums of h the forward recurrence emitted (hsum: no pass over y);
+//   yc = y - m0 -> bf16 (M, ldy);  partials of sum yc and sum yc^2 (fp32 values, before the rounding)
+// finalize: delta = sum yc / M (round-off of m0: ~1e-7), mean = m0 + delta, var = sum yc^2 / M - delta^2 — statistics of y itself, exact to
+// fp32 round-off, from ONE pass (the centring is what lets a single pass be as accurate as the two-pass form).
+// grid = (ceil(H/64), chunks), block = 16 column-quads x 16 row groups, as col_reduce_kernel.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void center_colstats_kernel(const float* __restrict__ Xa, int lda, const float* __restrict__ Xb, int ldb,
+                                                              const float* __restrict__ hsum, int ntiles, __bf16* __restrict__ Yc, int ldy,
+                                                              int M, int H, int rows_per_chunk, float inv_m, float* __restrict__ m0_out,
+                                                              float* __restrict__ part, int vec) {
+  __shared__ float red[16][64][2];
+  const int cq = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int c0 = blockIdx.x * 64 + cq * 4;
+  const int valid = H - c0;
+  const int rbeg = blockIdx.y * rows_per_chunk;
+  const int rend = min(M, rbeg + rows_per_chunk);
+  f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, m0 = {0, 0, 0, 0};
+  if (valid > 0) {
+    // forward tiles first, then reverse tiles, in tile order: every block computes the same bits
+    for (int d = 0; d < 2; ++d)
+      for (int t = 0; t < ntiles; ++t) m0 += ld4(hsum + ((long long)d * ntiles + t) * H + c0, valid, false);
+    m0 *= inv_m;
+    if (blockIdx.y == 0 && rg == 0) st4(m0_out + c0, m0, valid, false);
+    for (int r = rbeg + rg; r < rend; r += 16) {
+      const f32x4 x = ld4(Xa + (long long)r * lda + c0, valid, vec) + ld4(Xb + (long long)r * ldb + c0, valid, vec);
+      const f32x4 xc = x - m0;
+      s0 += xc;
+      s1 += xc * xc;
+      if (valid >= 4) {
+        *reinterpret_cast<nbf16x4*>(Yc + (long long)r * ldy + c0) = nbf16x4{(__bf16)xc.x, (__bf16)xc.y, (__bf16)xc.z, (__bf16)xc.w};
+      } else {
+        const float v[4] = {xc.x, xc.y, xc.z, xc.w};
+        for (int e = 0; e < 4; ++e) Yc[(long long)r * ldy + c0 + e] = (__bf16)(e < valid ? v[e] : 0.f);
+      }
+    }
+  } else if (c0 < ldy) {                                   // pad columns H .. ldy of the GEMM operand: zeros
+    for (int r = rbeg + rg; r < rend; r += 16)
+      for (int e = 0; e < 4 && c0 + e < ldy; ++e) Yc[(long long)r * ldy + c0 + e] = (__bf16)0.f;
+  }
+  red[rg][cq * 4 + 0][0] = s0.x; red[rg][cq * 4 + 0][1] = s1.x;
+  red[rg][cq * 4 + 1][0] = s0.y; red[rg][cq * 4 + 1][1] = s1.y;
+  red[rg][cq * 4 + 2][0] = s0.z; red[rg][cq * 4 + 2][1] = s1.z;
+  red[rg][cq * 4 + 3][0] = s0.w; red[rg][cq * 4 + 3][1] = s1.w;
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int c = threadIdx.x >> 1, w = threadIdx.x & 1;
+    float sacc = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) sacc += red[g][c][w];
+    const int col = blockIdx.x * 64 + c;
+    if (col < H) part[((long long)blockIdx.y * H + col) * 2 + w] = sacc;
+  }
+}
+
+// partials [chunks][H][2] of (sum yc, sum yc^2) + m0 -> delta, mean, biased var (+ running statistics: momentum, unbiased var); fp64 combine
+__global__ __launch_bounds__(256) void center_finalize_kernel(const float* __restrict__ part, int chunks, int H, double count,
+                                                              const float* __restrict__ m0, float* __restrict__ mean, float* __restrict__ var,
+                                                              float* __restrict__ delta, float* __restrict__ run_mean,
+                                                              float* __restrict__ run_var, float momentum) {
+  __shared__ double red[8][32][2];
+  const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double a = 0.0, b = 0.0;
+  if (c < H)
+    for (int k = grp; k < chunks; k += 8) {
+      a += (double)part[((long long)k * H + c) * 2 + 0];
+      b += (double)part[((long long)k * H + c) * 2 + 1];
+    }
+  red[grp][cl][0] = a;
+  red[grp][cl][1] = b;
+  __syncthreads();
+  if (grp != 0 || c >= H) return;
+  a = 0.0; b = 0.0;
+#pragma unroll
+  for (int g = 0; g < 8; ++g) { a += red[g][cl][0]; b += red[g][cl][1]; }
+  const double d = a / count;
+  double v = b / count - d * d;
+  if (v < 0.0) v = 0.0;
+  const double m = (double)m0[c] + d;
+  delta[c] = (float)d;
+  mean[c] = (float)m;
+  var[c] = (float)v;
+  if (run_mean) {
+    const double unb = count > 1.0 ? v * count / (count - 1.0) : v;
+    run_mean[c] = (float)((1.0 - momentum) * (double)run_mean[c] + momentum * m);
+    run_var[c] = (float)((1.0 - momentum) * (double)run_var[c] + momentum * unb);
+  }
+}
+
+// BatchNorm1d backward sums with the BatchNorm INPUT given as bf16 (the centred operand above; `mean` is then its delta):
+//   s0 = sum dY, s1 = sum dY * (x - mean) * rstd.   Same grid / reduction order as col_reduce_kernel<2>.
+__global__ __launch_bounds__(256) void col_reduce_bwd_xbf_kernel(const __bf16* __restrict__ X, int ldx, const float* __restrict__ dY, int lddy, int M, int H,
+                                                                 int rows_per_chunk, const float* __restrict__ mean, const float* __restrict__ var,
+                                                                 float eps, float* __restrict__ part, int vec) {
+  __shared__ float red[16][64][2];
+  const int cq = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int c0 = blockIdx.x * 64 + cq * 4;
+  const int valid = H - c0;
+  const int rbeg = blockIdx.y * rows_per_chunk;
+  const int rend = min(M, rbeg + rows_per_chunk);
+  f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
+  if (valid > 0) {
+    const f32x4 mu = ld4(mean + c0, valid, false), vv = ld4(var + c0, valid, false);
+    f32x4 rs;
+    rs.x = rsqrtf(vv.x + eps); rs.y = rsqrtf(vv.y + eps); rs.z = rsqrtf(vv.z + eps); rs.w = rsqrtf(vv.w + eps);
+    for (int r = rbeg + rg; r < rend; r += 16) {
+      f32x4 x = {0.f, 0.f, 0.f, 0.f};
+      if (valid >= 4) {
+        const nbf16x4 q = *reinterpret_cast<const nbf16x4*>(X + (long long)r * ldx + c0);
+        x = f32x4{(float)q[0], (float)q[1], (float)q[2], (float)q[3]};
+      } else {
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int e = 0; e < valid; ++e) v[e] = (float)X[(long long)r * ldx + c0 + e];
+        x = f32x4{v[0], v[1], v[2], v[3]};
+      }
+      const f32x4 dy = ld4(dY + (long long)r * lddy + c0, valid, vec);
+      s0 += dy;
+      s1 += dy * ((x - mu) * rs);
+    }
+  }
+  red[rg][cq * 4 + 0][0] = s0.x; red[rg][cq * 4 + 0][1] = s1.x;
+  red[rg][cq * 4 + 1][0] = s0.y; red[rg][cq * 4 + 1][1] = s1.y;
+  red[rg][cq * 4 + 2][0] = s0.z; red[rg][cq * 4 + 2][1] = s1.z;
+  red[rg][cq * 4 + 3][0] = s0.w; red[rg][cq * 4 + 3][1] = s1.w;
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int c = threadIdx.x >> 1, w = threadIdx.x & 1;
+    float sacc = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) sacc += red[g][c][w];
+    const int col = blockIdx.x * 64 + c;
+    if (col < H) part[((long long)blockIdx.y * H + col) * 2 + w] = sacc;
+  }
+}
+
+// dX = k1 dY - k2 - k3 (x - mu) with the BatchNorm input x as bf16 (H % 4 == 0): the materialised form for recurrences that cannot fuse it
+__global__ __launch_bounds__(256) void bn1d_bwd_apply_xbf_kernel(const float* __restrict__ dY, int lddy, const __bf16* __restrict__ X, int ldx,
+                                                                 float* __restrict__ dX, int lddx, int M, int H, const float* __restrict__ mean,
+                                                                 const float* __restrict__ var, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ s0, const float* __restrict__ s1, float eps,
+                                                                 float inv_count, int vec) {
+  const int c0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (c0 >= H) return;
+  const f32x4 mu = ld4(mean + c0, 4, false), vv = ld4(var + c0, 4, false), g = ld4(gamma + c0, 4, false);
+  const f32x4 a = ld4(s0 + c0, 4, false), b = ld4(s1 + c0, 4, false);
+  f32x4 rs, k1, k2, k3;
+  rs.x = rsqrtf(vv.x + eps); rs.y = rsqrtf(vv.y + eps); rs.z = rsqrtf(vv.z + eps); rs.w = rsqrtf(vv.w + eps);
+  k1 = g * rs;
+  k2 = k1 * a * inv_count;
+  k3 = k1 * rs * b * inv_count;
+  const int rend = min(M, (int)(blockIdx.y + 1) * BN_ROWS_PER_BLOCK);
+#pragma unroll 8
+  for (int r = blockIdx.y * BN_ROWS_PER_BLOCK; r < rend; ++r) {
+    const f32x4 dy = ld4(dY + (long long)r * lddy + c0, 4, vec);
+    const nbf16x4 q = *reinterpret_cast<const nbf16x4*>(X + (long long)r * ldx + c0);
+    const f32x4 x = {(float)q[0], (float)q[1], (float)q[2], (float)q[3]};
+    st4(dX + (long long)r * lddx + c0, k1 * dy - k2 - k3 * (x - mu), 4, vec);
+  }
+}
+
+// C[r][c] = C[r][c] * scale[c] + rowv[r] * shift[c]     (R, N) fp32, N % 4 == 0: the weight gradient of a projection whose BatchNorm was
+// folded into it — dW_ih = (dGx^T yc) diag(s) + db_ih (x) (beta - delta s)
+__global__ __launch_bounds__(256) void scale_rank1_kernel(float* __restrict__ C, int ldc, int R, int N, const float* __restrict__ scale,
+                                                          const float* __restrict__ rowv, const float* __restrict__ shift) {
+  const int cq = N / 4;
+  const long long total = (long long)R * cq;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cq), c0 = (int)(i % cq) * 4;
+    f32x4* p = reinterpret_cast<f32x4*>(C + (long long)r * ldc + c0);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c0), sh = *reinterpret_cast<const f32x4*>(shift + c0);
+    *p = *p * sc + sh * rowv[r];
+  }
+}
+
 int pick_chunks(int M, int colblocks, int min_rows) {
   int chunks = 2048 / (colblocks > 0 ? colblocks : 1);
   if (chunks < 1) chunks = 1;
@@ -735,6 +914,79 @@ extern "C" int ds2_bn1d_bwd_f32(const float* dY, int lddy, const float* X, int l
                              ws_bytes, (hipStream_t)stream);
   if (rc || !dX) return rc;
   return ds2i_bn1d_bwd_apply(dY, lddy, X, ldx, dX, lddx, M, H, mean, var, gamma, dbeta, dgamma, eps, (hipStream_t)stream);
+}
+
+
+int ds2i_bn1d_bwd_apply_xbf(const float* dY, int lddy, const void* X, int ldx, float* dX, int lddx, int M, int H, const float* mean, const float* var,
+                            const float* gamma, const float* s0, const float* s1, float eps, hipStream_t stream) {
+  DS2_REQUIRE((H % 4) == 0 && (ldx % 4) == 0, "bn1d_bwd_apply (bf16 input): H and its pitch must be multiples of 4");
+  const int vec = (lddy % 4 == 0) && (lddx % 4 == 0) && ((uintptr_t)dY % 16 == 0) && ((uintptr_t)dX % 16 == 0);
+  dim3 grid(ceil_div(ceil_div(H, 4), 256), ceil_div(M, BN_ROWS_PER_BLOCK));
+  hipLaunchKernelGGL(bn1d_bwd_apply_xbf_kernel, grid, dim3(256), 0, stream, dY, lddy, (const __bf16*)X, ldx, dX, lddx, M, H, mean, var, gamma, s0, s1, eps,
+                     1.0f / (float)M, vec);
+  DS2_LAUNCH_CHECK("bn1d_bwd_apply_xbf_kernel");
+  return 0;
+}
+
+// ---- BatchNorm1d folded into the following projection (round 6): see center_colstats_kernel -------------------------------------------------
+// Y = Xa + Xb is never written: Yc = bf16(Y - m0) (M, ldyc: pad columns zero) with m0 the column means from hsum (2, ntiles, H) — the
+// per-direction, per-16-row-tile sums of h over time that ds2_rnn_fwd_x emits; mean / var = the batch statistics of Y (what nn.BatchNorm1d
+// computes, blocks.py:75, 85-86), delta = mean - m0 (the mean of the centred operand: the "mean" that BatchNorm formulas written on Yc use);
+// running statistics updated like ds2_add_colstats_f32.  workspace: ds2_colreduce_workspace_bytes(M, H) + H floats.
+extern "C" int ds2_center_colstats(const float* Xa, int lda, const float* Xb, int ldb, const float* hsum, int ntiles, void* Yc_bf16, int ldyc, int M,
+                                   int H, float* mean, float* var, float* delta, float* run_mean, float* run_var, float momentum, void* ws,
+                                   size_t ws_bytes, void* stream) {
+  DS2_REQUIRE(Xa && Xb && hsum && Yc_bf16 && mean && var && delta && M > 0 && H > 0 && ntiles > 0, "ds2_center_colstats: bad args");
+  DS2_REQUIRE(ldyc >= H && (ldyc % 8) == 0 && ((uintptr_t)Yc_bf16 % 16) == 0, "ds2_center_colstats: bad operand pitch %d", ldyc);
+  const int colblocks = ceil_div(ldyc, 64);
+  const int chunks = pick_chunks(M, colblocks, 64);
+  const int rpc = ceil_div(M, chunks);
+  const int nch = ceil_div(M, rpc);
+  DS2_REQUIRE(ws && ws_bytes >= ((size_t)nch * H * 2 + H) * sizeof(float), "ds2_center_colstats: workspace too small");
+  const int vec = (lda % 4 == 0) && (ldb % 4 == 0) && ((uintptr_t)Xa % 16 == 0) && ((uintptr_t)Xb % 16 == 0);
+  float* part = (float*)ws;
+  float* m0 = part + (size_t)nch * H * 2;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(center_colstats_kernel, dim3(colblocks, nch), dim3(256), 0, s, Xa, lda, Xb, ldb, hsum, ntiles, (__bf16*)Yc_bf16, ldyc, M, H, rpc,
+                     1.0f / (float)M, m0, part, vec);
+  DS2_LAUNCH_CHECK("center_colstats_kernel");
+  hipLaunchKernelGGL(center_finalize_kernel, dim3(ceil_div(H, 32)), dim3(256), 0, s, (const float*)part, nch, H, (double)M, (const float*)m0, mean, var,
+                     delta, run_mean, run_var, momentum);
+  DS2_LAUNCH_CHECK("center_finalize_kernel");
+  return 0;
+}
+
+// ds2_bn1d_bwd_f32 with the BatchNorm input X given as bf16 (pitch ldx): the column sums dbeta = sum dY, dgamma = sum dY xhat and, when dX is
+// given (H % 4 == 0), the materialised gradient.  `mean` is the mean OF X (for the centred operand of ds2_center_colstats: its delta).
+extern "C" int ds2_bn1d_bwd_xbf16(const float* dY, int lddy, const void* X_bf16, int ldx, float* dX, int lddx, int M, int H, const float* mean,
+                                  const float* var, const float* gamma, float eps, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream) {
+  DS2_REQUIRE(dY && X_bf16 && mean && var && gamma && dgamma && dbeta && M > 0 && H > 0 && (ldx % 4) == 0, "ds2_bn1d_bwd_xbf16: bad args");
+  const int colblocks = ceil_div(H, 64);
+  const int chunks = pick_chunks(M, colblocks, 64);
+  const int rpc = ceil_div(M, chunks);
+  const int nch = ceil_div(M, rpc);
+  DS2_REQUIRE(ws && ws_bytes >= (size_t)nch * H * 2 * sizeof(float), "ds2_bn1d_bwd_xbf16: workspace too small");
+  const int vec = (lddy % 4 == 0) && ((uintptr_t)dY % 16 == 0);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(col_reduce_bwd_xbf_kernel, dim3(colblocks, nch), dim3(256), 0, s, (const __bf16*)X_bf16, ldx, dY, lddy, M, H, rpc, mean, var, eps,
+                     (float*)ws, vec);
+  DS2_LAUNCH_CHECK("col_reduce_bwd_xbf_kernel");
+  hipLaunchKernelGGL(col_finalize_kernel, dim3(ceil_div(H, 32)), dim3(256), 0, s, (const float*)ws, nch, H, (double)M, 1, dbeta, dgamma, (float*)nullptr,
+                     (float*)nullptr, 0.f);
+  DS2_LAUNCH_CHECK("col_finalize_kernel");
+  if (!dX) return 0;
+  return ds2i_bn1d_bwd_apply_xbf(dY, lddy, X_bf16, ldx, dX, lddx, M, H, mean, var, gamma, dbeta, dgamma, eps, s);
+}
+
+// C[r][c] = C[r][c] * scale[c] + rowv[r] * shift[c], (R, N) fp32 in place, N % 4 == 0, 16-byte aligned rows
+extern "C" int ds2_scale_rank1_f32(float* C, int ldc, int R, int N, const float* scale, const float* rowv, const float* shift, void* stream) {
+  DS2_REQUIRE(C && scale && rowv && shift && R > 0 && N > 0 && (N % 4) == 0 && (ldc % 4) == 0 && ((uintptr_t)C % 16) == 0 &&
+              ((uintptr_t)scale % 16) == 0 && ((uintptr_t)shift % 16) == 0, "ds2_scale_rank1_f32: bad args");
+  const long long total = (long long)R * (N / 4);
+  const int blocks = (int)std::min<long long>((total + 255) / 256, 8192);
+  hipLaunchKernelGGL(scale_rank1_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, C, ldc, R, N, scale, rowv, shift);
+  DS2_LAUNCH_CHECK("scale_rank1_kernel");
+  return 0;
 }
 
 extern "C" size_t ds2_chanreduce_workspace_bytes(int C) { return (size_t)2048 * 2 * sizeof(float) * (size_t)(C > 1 ? C : 1); }

@@ -97,6 +97,7 @@ struct RnnArgs {
   // forward, persistent kernels, optional (NULL: not produced): (2, ceil(B/16), H) sums of h over time and over the 16 batch rows of a tile,
   // per direction — the column sums of this layer's output y = h_fwd + h_bwd without a pass over it (ds2_center_colstats)
   float* hsum;
+  int bn_x_bf16;      // bwd, K-split kernel: bn_x is really a bf16 tensor (the centred operand of ds2_center_colstats; bn_mean is then its delta), ldbnx even
   int prearmed;       // host side only: the caller has filled the whole workspace with 0xff (ds2_rnn_ctx.ws_prearmed): persistent launchers skip their own fill
 };
 
@@ -2144,7 +2145,7 @@ extern "C" int ds2_rnn_bwd_ex(ds2_rnn_ctx* ctx, int gates, const float* dy, int 
 // elementwise half of the BatchNorm backward is applied on the fly to the one value a (row, unit) pair needs per step (bit 16 of
 // ds2_rnn_last_path()) — no pass over (T*B, H); otherwise it is materialised into dy_scratch (T*B, H) first and the call proceeds as
 // ds2_rnn_bwd_ex(dy = dy_scratch).
-extern "C" int ds2_rnn_bwd_bn(ds2_rnn_ctx* ctx, int gates, const float* dyn, int lddyn, const float* bn_x, int ldx, const float* bn_mean, const float* bn_var,
+static int rnn_bwd_bn_impl(ds2_rnn_ctx* ctx, int gates, const float* dyn, int lddyn, const float* bn_x, int bn_x_bf16, int ldx, const float* bn_mean, const float* bn_var,
                               const float* bn_gamma, const float* bn_s0, const float* bn_s1, float bn_eps, float* dy_scratch, float* gx,
                               float* aux, const float* hbuf, const void* wp_bwd, const int* lens_dev, int T, int B, int H, int bf16,
                               void* dgx_bf16, const void* gates_bf16, void* dhn_bf16, float* bias_part, void* ws, size_t ws_bytes,
@@ -2163,7 +2164,7 @@ extern "C" int ds2_rnn_bwd_bn(ds2_rnn_ctx* ctx, int gates, const float* dyn, int
     a.dgx_bf = (__bf16*)dgx_bf16; a.gates_bf = (__bf16*)const_cast<void*>(gates_bf16);
     a.dhn_bf = (__bf16*)dhn_bf16; a.bsum = bias_part;
     a.lens = lens_dev; a.T = T; a.B = B; a.H = H;
-    a.bn_x = bn_x; a.ldbnx = ldx; a.bn_mean = bn_mean; a.bn_var = bn_var; a.bn_gamma = bn_gamma; a.bn_s0 = bn_s0; a.bn_s1 = bn_s1; a.bn_eps = bn_eps;
+    a.bn_x = bn_x; a.bn_x_bf16 = bn_x_bf16; a.ldbnx = ldx; a.bn_mean = bn_mean; a.bn_var = bn_var; a.bn_gamma = bn_gamma; a.bn_s0 = bn_s0; a.bn_s1 = bn_s1; a.bn_eps = bn_eps;
     a.hctx = ctx; a.status = ctx ? ctx->status_dev : nullptr;
     a.prearmed = take_prearmed(ctx);
     a.dbg = ctx ? ctx->debug_flags : 0;
@@ -2179,12 +2180,33 @@ extern "C" int ds2_rnn_bwd_bn(ds2_rnn_ctx* ctx, int gates, const float* dyn, int
   // not taken by the K-split kernel: materialise dy, then the ordinary path.  dy_scratch == NULL: nothing has been launched or counted
   // yet — return 1 so that the caller allocates the (T*B, H) buffer only when it is really needed, and calls again
   if (!dy_scratch) return 1;
-  int rc = ds2i_bn1d_bwd_apply(dyn, lddyn, bn_x, ldx, dy_scratch, H, T * B, H, bn_mean, bn_var, bn_gamma, bn_s0, bn_s1, bn_eps, st);
+  int rc = bn_x_bf16 ? ds2i_bn1d_bwd_apply_xbf(dyn, lddyn, bn_x, ldx, dy_scratch, H, T * B, H, bn_mean, bn_var, bn_gamma, bn_s0, bn_s1, bn_eps, st)
+                     : ds2i_bn1d_bwd_apply(dyn, lddyn, bn_x, ldx, dy_scratch, H, T * B, H, bn_mean, bn_var, bn_gamma, bn_s0, bn_s1, bn_eps, st);
   if (rc) return rc;
   rc = ds2_rnn_bwd_ex(ctx, gates, dy_scratch, H, gx, aux, hbuf, wp_bwd, lens_dev, T, B, H, bf16, dgx_bf16, gates_bf16, dhn_bf16, bias_part, ws, ws_bytes,
                       stream);
   if (ctx) ctx->last_path &= ~16;
   return rc;
+}
+
+extern "C" int ds2_rnn_bwd_bn(ds2_rnn_ctx* ctx, int gates, const float* dyn, int lddyn, const float* bn_x, int ldx, const float* bn_mean, const float* bn_var,
+                              const float* bn_gamma, const float* bn_s0, const float* bn_s1, float bn_eps, float* dy_scratch, float* gx,
+                              float* aux, const float* hbuf, const void* wp_bwd, const int* lens_dev, int T, int B, int H, int bf16,
+                              void* dgx_bf16, const void* gates_bf16, void* dhn_bf16, float* bias_part, void* ws, size_t ws_bytes,
+                              void* stream) {
+  return rnn_bwd_bn_impl(ctx, gates, dyn, lddyn, bn_x, 0, ldx, bn_mean, bn_var, bn_gamma, bn_s0, bn_s1, bn_eps, dy_scratch, gx, aux, hbuf, wp_bwd, lens_dev,
+                         T, B, H, bf16, dgx_bf16, gates_bf16, dhn_bf16, bias_part, ws, ws_bytes, stream);
+}
+
+// ds2_rnn_bwd_bn with the BatchNorm's input given as bf16 (pitch ldx, even; H % 4 == 0): the centred operand of ds2_center_colstats, bn_mean its
+// delta.  Everything else as ds2_rnn_bwd_bn.
+extern "C" int ds2_rnn_bwd_bn_xbf16(ds2_rnn_ctx* ctx, int gates, const float* dyn, int lddyn, const void* bn_x_bf16, int ldx, const float* bn_mean,
+                                    const float* bn_var, const float* bn_gamma, const float* bn_s0, const float* bn_s1, float bn_eps, float* dy_scratch,
+                                    float* gx, float* aux, const float* hbuf, const void* wp_bwd, const int* lens_dev, int T, int B, int H, int bf16,
+                                    void* dgx_bf16, const void* gates_bf16, void* dhn_bf16, float* bias_part, void* ws, size_t ws_bytes, void* stream) {
+  DS2_REQUIRE((ldx % 2) == 0 && (H % 4) == 0 && ((uintptr_t)bn_x_bf16 % 4) == 0, "ds2_rnn_bwd_bn_xbf16: even pitch, H %% 4 == 0, 4-byte aligned base");
+  return rnn_bwd_bn_impl(ctx, gates, dyn, lddyn, (const float*)bn_x_bf16, 1, ldx, bn_mean, bn_var, bn_gamma, bn_s0, bn_s1, bn_eps, dy_scratch, gx, aux, hbuf,
+                         wp_bwd, lens_dev, T, B, H, bf16, dgx_bf16, gates_bf16, dhn_bf16, bias_part, ws, ws_bytes, stream);
 }
 
 extern "C" int ds2_rnn_bwd(ds2_rnn_ctx* ctx, int gates, const float* dy, int lddy, float* gx, float* aux, const float* hbuf, const void* wp_bwd,

@@ -101,6 +101,11 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char
   // BatchNorm1d backward of the layer above, applied on the fly (ds2_rnn_bwd_bn): dy_used = bn1 dy + bnx x + bn0 with this unit's constants
   //   k1 = gamma rstd, k2 = k1 s0 / M, k3 = k1 rstd s1 / M  ->  bn1 = k1, bnx = -k3, bn0 = k3 mean - k2     (norm.hip: bn1d_bwd_apply_kernel)
   const bool bn = a.bn_x != nullptr;
+  // bn_x as bf16 (a.bn_x_bf16): the lane loads the aligned DWORD that holds its element and its neighbour's — the same load instruction as the
+  // fp32 form — and keeps its half (even elements << 16, odd ones & 0xffff0000); the widening happens where the value is consumed, in the
+  // coefficient math at the END of a step (not on the dependent chain)
+  const bool bxbf = bn && a.bn_x_bf16 != 0;
+  const unsigned bx_sh = (bxbf && !(j & 1)) ? 16u : 0u, bx_mask = bxbf ? 0xffff0000u : 0xffffffffu;
   const long long dX = (dir == 0 ? -1LL : 1LL) * B * a.ldbnx;
   long long eX = ((long long)t0 * B + b) * a.ldbnx + j;
   float bn1 = 1.f, bnx = 0.f, bn0 = 0.f;
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char
     const bool on = pact && asm_fetch;
     const void* prec = on ? (const void*)(gates_bf + 4 * fH) : (const void*)a.dy;
     const float* pdy = on ? a.dy + fY : a.dy;
-    const float* pbx = (on && bn) ? a.bn_x + fX : a.dy;
+    const float* pbx = (on && bn) ? (bxbf ? a.bn_x + (fX >> 1) : a.bn_x + fX) : a.dy;
     const float* ppv = (on && has_prev) ? a.hbuf + fH + dH : a.hbuf;
     asm volatile("global_load_dwordx2 %0, %4, off nt\n\tglobal_load_dword %1, %5, off nt\n\tglobal_load_dword %2, %6, off nt\n\t"
                  "global_load_dword %3, %7, off"
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char
   // that many were issued behind them); the record is used in place — same registers from the load to the last use
 #define DS2_KS_FETCH_WAIT(r, YOUNGER) asm volatile("s_waitcnt vmcnt(%4)" : "+v"((r).rec), "+v"((r).dy), "+v"((r).bx), "+v"((r).prev) : "n"(YOUNGER) : "memory")
   auto raw_ops = [&](const Raw& r, bool has_prev) {
-    return Ops{__builtin_bit_cast(bf16x4_, r.rec), 0.f, 0.f, 0.f, 0.f, 0.f, r.dy, has_prev ? r.prev : 0.f, r.bx};
+    return Ops{__builtin_bit_cast(bf16x4_, r.rec), 0.f, 0.f, 0.f, 0.f, 0.f, r.dy, has_prev ? r.prev : 0.f, __uint_as_float((__float_as_uint(r.bx) << bx_sh) & bx_mask)};
   };
   // operands of the step whose offsets are (fH, fG, fY); has_prev: that step has a predecessor in FORWARD order (= the step processed after it)
   auto fetch = [&](long long fH, long long fG, long long fY, long long fX, bool has_prev) {
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char
       else o.g3 = ldnt(a.aux + fH);
     }
     o.dy = ldnt(a.dy + fY);
-    if (bn) o.bx = ldnt(a.bn_x + fX);
+    if (bn) o.bx = bxbf ? __uint_as_float((__float_as_uint(ldnt(a.bn_x + (fX >> 1))) << bx_sh) & bx_mask) : ldnt(a.bn_x + fX);
     if (has_prev) o.prev = (G == 3) ? a.hbuf[fH + dH] : a.aux[fH + dH];     // h / c of the previous frame in forward order = the NEXT step's row
     return o;
   };

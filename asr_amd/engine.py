@@ -111,6 +111,12 @@ GX_BF16 = _tune("DS2_GX_BF16", "0") != "0"
 # the workspace of a recurrence call (exchange buffers of a persistent launch: every byte 0xff) is armed AHEAD of the GEMM in front of the
 # recurrence (ops.rnn_ws) instead of by a fill launched between that GEMM and the recurrence (DS2_WS_PREARM=0: as rounds 1-5)
 WS_PREARM = _tune("DS2_WS_PREARM", "1") != "0"
+# bf16 training, BatchNorm1d of the recurrent layers 1 .. L-1 folded into their input projections (DS2_BN_FOLD): the direction sum + statistics
+# pass of the layer in front writes ONLY the centred bf16 operand yc = y - m0 (ops.center_colstats: column means from the per-tile sums of h the
+# forward recurrence emits, statistics of the centred values) and the normalisation goes into the weights, gx = yc (W_ih diag(s))^T + (b + W_ih c)
+# (ops.wih_fold); backward: dW_ih = (dGx^T yc) diag(s) + db (x) c, BatchNorm backward on (yc, delta, var).  Neither y (fp32) nor BN(y) exists
+# any more: 327 MB moved per layer in forward instead of 589, 196 instead of 262 for the backward sums.  0: the separate passes of rounds 1-5.
+BN_FOLD = _tune("DS2_BN_FOLD", "1") != "0"
 
 
 def _f32_split_ok(M: int, N: int, K: int, H: int = 8) -> bool:
@@ -152,14 +158,16 @@ class BnGrad:
 def _bn_backward(dxn: Tensor, x: Tensor, mean, var, gamma, dgamma, dbeta, fuse: bool, private_sums: bool):
     """BatchNorm1d backward in front of a recurrent layer's backward: the materialised gradient, or (fuse) the column sums only + a BnGrad.
     private_sums: the gradient buffers may be all-reduced (asynchronously, in place) before the recurrence below has read the sums."""
+    xbf = x.dtype == torch.bfloat16                      # BN_FOLD: x = the centred bf16 operand, mean = its delta
     if not fuse:
-        return ops.bn1d_bwd(dxn, x, mean, var, gamma, dgamma, dbeta)
+        return (ops.bn1d_bwd_xbf if xbf else ops.bn1d_bwd)(dxn, x, mean, var, gamma, dgamma, dbeta)
+    sums_fn = ops.bn1d_bwd_sums_xbf if xbf else ops.bn1d_bwd_sums
     if private_sums:
-        sums = ops.bn1d_bwd_sums(dxn, x, mean, var, gamma)
+        sums = sums_fn(dxn, x, mean, var, gamma)
         dbeta.copy_(sums[0])
         dgamma.copy_(sums[1])
     else:
-        sums = ops.bn1d_bwd_sums(dxn, x, mean, var, gamma, out=(dbeta, dgamma))
+        sums = sums_fn(dxn, x, mean, var, gamma, out=(dbeta, dgamma))
     return BnGrad(dxn, x, mean, var, gamma, sums)
 
 
@@ -192,6 +200,7 @@ class LayerCtx:
     wihT: Optional[Tensor] = None    # bf16 training: bf16 W_ih^T (I, pad8(2GH)), the B operand of dX (cast with the forward projection's operand)
     xs: Optional[Tensor] = None      # fp32 mode, split-bf16 GEMMs: (M, 3 I) [hi | hi | lo] split copy of xn (xn itself is then not kept)
     gshape: tuple = ()               # (M, 2GH) when gx itself was released
+    fold: tuple = ()                 # BN_FOLD: (colscale s, colshift c) of this layer's folded BatchNorm; xin / xn are then the centred bf16 operand
 
 
 @dataclass
@@ -313,13 +322,23 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
         ctx.y1, ctx.a1, ctx.a1p, ctx.y2, ctx.st1, ctx.st2 = y1, a1, a1p, y2, (m1, v1), (m2, v2)
 
     # ---- recurrent stack ------------------------------------------------------------------------
-    mean = var = None
+    mean = var = delta = None
     for l in range(L):
         lc = LayerCtx()
         bf = cfg.precision == "bf16"
         rmode = 1 if bf else (2 if (F32_RNN == "split" and H % 32 == 0) else 0)
         ws_f = ops.rnn_ws("fwd", G, B, H, rmode, x.device) if WS_PREARM else None
-        if l > 0:
+        folded = l > 0 and xin.dtype == torch.bfloat16       # BN_FOLD: the layer in front left the centred bf16 operand (+ mean, var, delta)
+        if folded:
+            bp = f"rnns.{l}.batch_norm.module."
+            xn = xin
+            w_bf, bias_eff, colscale, colshift = ops.wih_fold(W[f"rnns.{l}.wih_cat"], W[f"rnns.{l}.bih_cat"], var, W[bp + "weight"], W[bp + "bias"], delta,
+                                                              ld=xn.shape[1])
+            lc.wihT = ops.cast_transpose_bf16(W[f"rnns.{l}.wih_cat"])          # (un-scaled: dX is the gradient wrt BN's OUTPUT, as before)
+            lc.mean, lc.var, lc.fold = delta, var, (colscale, colshift)        # (the mean OF xin)
+            gx = ops.gemm_bf16_nt(xn, w_bf, bias=bias_eff)
+            del w_bf
+        elif l > 0:
             bp = f"rnns.{l}.batch_norm.module."
             if not training:
                 mean, var = W[bp + "running_mean"], W[bp + "running_var"]
@@ -328,7 +347,9 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
             lc.mean, lc.var = mean, var
         else:
             xn = xn0 if cfg.precision == "bf16" else xin
-        if cfg.precision == "bf16":
+        if folded:
+            pass
+        elif cfg.precision == "bf16":
             if save:
                 # training: ONE read of W_ih gives the row-major bf16 operand of this projection and the transposed one of dX (kept for backward)
                 w_bf, lc.wihT = ops.cast_bf16_both(W[f"rnns.{l}.wih_cat"], ld_r=xn.shape[1])
@@ -356,16 +377,25 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
             # (not for shapes whose backward recurrence is known to run one launch per step - LSTM H = 1280: nobody would read the copy)
             h_bf = (torch.empty(M, 2 * H, dtype=torch.bfloat16, device=x.device)
                     if (WGRAD_TN and OVERLAP_MODE == "2" and T > 1 and _BWD_PERSISTENT.get((ops.rnn_ctx_key(x.device), G, H, B), True)) else None)
-            hbuf, aux, rec = ops.rnn_fwd(G, gx, wpf, W[f"rnns.{l}.bhh_cat"], lens_dev, T, B, H, bf16=True, packed_gates=True, h_bf16=h_bf, ws=ws_f)
+            # BN_FOLD: the layer behind this one folds its BatchNorm — this recurrence emits the per-tile column sums of h it needs
+            hsum = (torch.empty(2, (B + 15) // 16, H, dtype=torch.float32, device=x.device)
+                    if (BN_FOLD and training and l + 1 < L and H % 8 == 0 and OVERLAP_MODE == "2" and T > 1) else None)
+            hbuf, aux, rec = ops.rnn_fwd(G, gx, wpf, W[f"rnns.{l}.bhh_cat"], lens_dev, T, B, H, bf16=True, packed_gates=True, h_bf16=h_bf, ws=ws_f, hsum=hsum)
+            if hsum is not None and not (ops.rnn_last_path(x.device) & 1):
+                hsum = None                                      # (only a persistent launch writes it)
             gx = None
             lc.rec, lc.gshape = rec, (M, 2 * G * H)
             if h_bf is not None and (ops.rnn_last_path(x.device) & 1):
                 lc.h_bf = h_bf                                   # (only a persistent launch writes it)
         else:
+            hsum = None
             hbuf, aux = ops.rnn_fwd(G, gx, wpf, W[f"rnns.{l}.bhh_cat"], lens_dev, T, B, H, bf16=rmode, ws=ws_f)
         lc.wpb = wpb
         nxt = f"rnns.{l + 1}.batch_norm.module" if l + 1 < L else "fc.0.module.0"
-        y, mean, var = ops.add_colstats(hbuf[:, :H], hbuf[:, H:], *run(nxt))
+        if hsum is not None:
+            y, mean, var, delta = ops.center_colstats(hbuf[:, :H], hbuf[:, H:], hsum, *run(nxt))     # y: the CENTRED bf16 operand
+        else:
+            y, mean, var = ops.add_colstats(hbuf[:, :H], hbuf[:, H:], *run(nxt))
         if save:
             lc.xin, lc.xn, lc.gx, lc.hbuf, lc.aux = xin, xn, gx, hbuf, aux
             ctx.layers.append(lc)
@@ -414,6 +444,13 @@ def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy, done, private: bo
             torch.cuda.current_stream().wait_stream(side)
         report(name)
 
+    def fold_epilogue(l):
+        """BN_FOLD: the projection's operand was the centred yc, not BN(y): dW_ih = (dGx^T yc) diag(s) + db_ih (x) c, applied to the product in
+        place on the stream that formed it (db_ih is final before any weight-gradient product of its layer is launched)"""
+        f = fold_of.get(l)
+        if f:
+            ops.scale_rank1_(Gr[f"rnns.{l}.wih_cat"], f[0], Gr[f"rnns.{l}.bih_cat"].view(-1), f[1])
+
     def weight_gradients(p):
         """layer p's dW_hh / dW_ih GEMMs on the compute stream, behind the event of its operand passes"""
         l, dgxT, hT, auxT, xnT, ready, hold = p
@@ -427,6 +464,7 @@ def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy, done, private: bo
         if G == 3:
             ops.gemm_bf16_nt_pair(auxT[0:H, ka[0]], auxT[H:2 * H, ka[1]], hT[0:H, kb[0]], hT[H:2 * H, kb[1]], dwhh[:, 2 * H:])
         ops.gemm_bf16_nt(dgxT, xnT, out=Gr[f"rnns.{l}.wih_cat"])
+        fold_epilogue(l)
         for t in (dgxT, hT, auxT, xnT) + hold:                   # allocated / last used on the other stream: tell the caching allocator
             if t is not None:
                 t.record_stream(main)
@@ -449,6 +487,7 @@ def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy, done, private: bo
             ops.gemm_bf16_tn(dgx_bf, xn[:, :I], out=dwih)
         else:                                                    # xn is zero-padded to a multiple of 8 columns
             dwih.copy_(ops.gemm_bf16_tn(dgx_bf, xn)[:, :I])
+        fold_epilogue(l)
         done(f"rnns.{l}")
 
     def weight_gradients_group(l, dgx_bf, dhn_bf, h_bf, xn, on_side, start):
@@ -464,11 +503,13 @@ def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy, done, private: bo
         launch = ops.gemm_bf16_tn_splitk_group if WGRAD_SIDE == "sk" else ops.gemm_bf16_tn_group
         if not on_side:
             launch(probs)
+            fold_epilogue(l)
             done(f"rnns.{l}")
             return
         with torch.cuda.stream(side):
             side.wait_event(start)
             launch(probs)
+            fold_epilogue(l)
             if not serial_buckets:
                 done(f"rnns.{l}")                                # (a reducer records its "gradients final" event on the current = side stream)
         if serial_buckets:                                       # the "serial" data-parallel schedule orders every collective INTO the compute stream
@@ -527,6 +568,7 @@ def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy, done, private: bo
     n_idle = _idle_cus_beside_bwd_recurrence(dev, B, H)
     idle_ok = (group_ok and WGRAD_SIDE == "sk" and WGRAD_IDLE and T > 1
                and WGRAD_IDLE_MIN_CUS <= n_idle < torch.cuda.get_device_properties(dev).multi_processor_count // 2)
+    fold_of = {l: ctx.layers[l].fold for l in range(L)}          # (kept apart: the layer contexts are cleared as backward moves down)
     ws_b = ops.rnn_ws("bwd", G, B, H, 1, dev) if WS_PREARM else None      # (the top layer's: behind the fc block's backward, which is short)
     for l in range(L - 1, -1, -1):
         lc = ctx.layers[l]

@@ -488,6 +488,81 @@ def add_colstats(Xa: Tensor, Xb: Tensor, run_mean: Optional[Tensor] = None, run_
     return Y, mean, var
 
 
+def center_colstats(Xa: Tensor, Xb: Tensor, hsum: Tensor, run_mean: Optional[Tensor] = None, run_var: Optional[Tensor] = None):
+    """(yc bf16 (M, pad8(H)) = (Xa + Xb) - m0 with m0 the column means from `hsum` (2, tiles, H; rnn_fwd), mean, var, delta): the direction
+    sum and the BatchNorm1d statistics of a recurrent layer's output in ONE pass that writes only the centred bf16 GEMM operand."""
+    _chk_f32(Xa, Xb, hsum, run_mean, run_var)
+    lib = _lib.load()
+    M, H = Xa.shape
+    assert hsum.is_contiguous() and hsum.dim() == 3 and hsum.size(0) == 2 and hsum.size(2) == H
+    yc = torch.empty(M, _pad8(H), dtype=torch.bfloat16, device=Xa.device)
+    stats = torch.empty(3, H, dtype=torch.float32, device=Xa.device)
+    wsb = lib.ds2_colreduce_workspace_bytes(M, H) + 4 * H
+    ws = _ws(wsb, Xa.device)
+    _lib.check(lib.ds2_center_colstats(Xa.data_ptr(), _row_pitch(Xa), Xb.data_ptr(), _row_pitch(Xb), hsum.data_ptr(), hsum.size(1), yc.data_ptr(), yc.size(1),
+                                       M, H, stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), _ptr(run_mean), _ptr(run_var), BN_MOMENTUM,
+                                       ws.data_ptr(), wsb, _stream()), "ds2_center_colstats")
+    return yc, stats[0], stats[1], stats[2]
+
+
+def wih_fold(W: Tensor, bias: Tensor, var: Tensor, gamma: Tensor, beta: Tensor, delta: Tensor, ld: int):
+    """BatchNorm1d folded into the projection behind it: (W2 bf16 (R, ld) = W diag(s), bias2 fp32 = bias + W c, s, c) with
+    s = gamma rsqrt(var + eps), c = beta - delta s  (ds2_wih_fold_bf16)."""
+    _chk_f32(W, bias, var, gamma, beta, delta)
+    R, I = W.shape
+    assert ld >= I and ld % 8 == 0 and I % 4 == 0 and W.stride(1) == 1
+    W2 = torch.empty(R, ld, dtype=torch.bfloat16, device=W.device)
+    bias2 = torch.empty(R, dtype=torch.float32, device=W.device)
+    sc = torch.empty(2, I, dtype=torch.float32, device=W.device)
+    _lib.check(_lib.load().ds2_wih_fold_bf16(W.data_ptr(), _row_pitch(W), bias.data_ptr(), R, I, var.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                             delta.data_ptr(), BN_EPS, W2.data_ptr(), ld, bias2.data_ptr(), sc[0].data_ptr(), sc[1].data_ptr(), _stream()),
+               "ds2_wih_fold_bf16")
+    return W2, bias2, sc[0], sc[1]
+
+
+def scale_rank1_(Cm: Tensor, scale: Tensor, rowv: Tensor, shift: Tensor) -> Tensor:
+    """in place: C[r][c] = C[r][c] * scale[c] + rowv[r] * shift[c]"""
+    _chk_f32(Cm, scale, rowv, shift)
+    R, N = Cm.shape
+    assert Cm.stride(1) == 1 and scale.numel() == N == shift.numel() and rowv.numel() == R and rowv.is_contiguous()
+    _lib.check(_lib.load().ds2_scale_rank1_f32(Cm.data_ptr(), _row_pitch(Cm), R, N, scale.data_ptr(), rowv.data_ptr(), shift.data_ptr(), _stream()),
+               "ds2_scale_rank1_f32")
+    return Cm
+
+
+def bn1d_bwd_sums_xbf(dY: Tensor, X: Tensor, mean: Tensor, var: Tensor, gamma: Tensor, out: Optional[Tuple[Tensor, Tensor]] = None) -> Tuple[Tensor, Tensor]:
+    """bn1d_bwd_sums with the BatchNorm input X as bf16 (M, >= H): (sum dY, sum dY * xhat) with xhat = (X - mean) rsqrt(var + eps)."""
+    _chk_f32(dY, mean, var, gamma)
+    assert X.dtype == torch.bfloat16 and X.is_cuda and X.stride(1) == 1
+    lib = _lib.load()
+    M, H = dY.shape
+    if out is None:
+        both = torch.empty(2, H, dtype=torch.float32, device=dY.device)
+        out = (both[0], both[1])
+    s0, s1 = out
+    _chk_f32(s0, s1)
+    assert s0.is_contiguous() and s1.is_contiguous() and s0.numel() == H == s1.numel()
+    wsb = lib.ds2_colreduce_workspace_bytes(M, H)
+    ws = _ws(wsb, dY.device)
+    _lib.check(lib.ds2_bn1d_bwd_xbf16(dY.data_ptr(), _row_pitch(dY), X.data_ptr(), X.stride(0), None, 0, M, H, mean.data_ptr(), var.data_ptr(),
+                                      gamma.data_ptr(), BN_EPS, s1.data_ptr(), s0.data_ptr(), ws.data_ptr(), wsb, _stream()), "ds2_bn1d_bwd_xbf16")
+    return s0, s1
+
+
+def bn1d_bwd_xbf(dY: Tensor, X: Tensor, mean: Tensor, var: Tensor, gamma: Tensor, dgamma: Tensor, dbeta: Tensor) -> Tensor:
+    """materialised BatchNorm1d backward with the input as bf16 (the fallback of layers whose recurrence cannot fuse it)"""
+    _chk_f32(dY, mean, var, gamma, dgamma, dbeta)
+    assert X.dtype == torch.bfloat16 and X.is_cuda and X.stride(1) == 1
+    lib = _lib.load()
+    M, H = dY.shape
+    dX = torch.empty(M, H, dtype=torch.float32, device=dY.device)
+    wsb = lib.ds2_colreduce_workspace_bytes(M, H)
+    ws = _ws(wsb, dY.device)
+    _lib.check(lib.ds2_bn1d_bwd_xbf16(dY.data_ptr(), _row_pitch(dY), X.data_ptr(), X.stride(0), dX.data_ptr(), H, M, H, mean.data_ptr(), var.data_ptr(),
+                                      gamma.data_ptr(), BN_EPS, dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), wsb, _stream()), "ds2_bn1d_bwd_xbf16")
+    return dX
+
+
 def colsum(X: Tensor) -> Tensor:
     _chk_f32(X)
     lib = _lib.load()
@@ -1055,13 +1130,15 @@ def rnn_bwd_bn(gates: int, dyn: Tensor, bn_x: Tensor, mean: Tensor, var: Tensor,
     (s0, s1) result of bn1d_bwd_sums.  The K-split kernel applies the elementwise BatchNorm backward on the fly (rnn_last_path() & 16);
     any other kernel family gets it materialised first."""
     s0, s1 = sums
-    _chk_f32(dyn, bn_x, mean, var, gamma, s0, s1, gx, aux, hbuf, bias_part)
-    assert s0.is_contiguous() and s1.is_contiguous() and s0.numel() == H == s1.numel() and bn_x.shape == (T * B, H) and dyn.shape == (T * B, H)
+    xbf = bn_x.dtype == torch.bfloat16                  # the centred bf16 operand of center_colstats (mean = its delta): ds2_rnn_bwd_bn_xbf16
+    _chk_f32(dyn, None if xbf else bn_x, mean, var, gamma, s0, s1, gx, aux, hbuf, bias_part)
+    assert s0.is_contiguous() and s1.is_contiguous() and s0.numel() == H == s1.numel() and bn_x.shape[0] == T * B and bn_x.shape[1] >= H and dyn.shape == (T * B, H)
+    assert bn_x.stride(1) == 1 and (not xbf or bn_x.shape[1] == H or bn_x.stride(0) % 2 == 0)
     lib = _lib.load()
     wsb = lib.ds2_rnn_bwd_workspace_bytes(gates, B, H, int(bf16))
     ws = _take_ws(ws, wsb, dyn.device)
     def call(scratch):
-        return lib.ds2_rnn_bwd_bn(_ctxp(dyn.device), gates, dyn.data_ptr(), _row_pitch(dyn), bn_x.data_ptr(), _row_pitch(bn_x), mean.data_ptr(), var.data_ptr(),
+        return (lib.ds2_rnn_bwd_bn_xbf16 if xbf else lib.ds2_rnn_bwd_bn)(_ctxp(dyn.device), gates, dyn.data_ptr(), _row_pitch(dyn), bn_x.data_ptr(), bn_x.stride(0), mean.data_ptr(), var.data_ptr(),
                                   gamma.data_ptr(), s0.data_ptr(), s1.data_ptr(), BN_EPS, _ptr(scratch), _ptr(gx), aux.data_ptr(),
                                   hbuf.data_ptr(), wp_bwd.data_ptr(), lens_dev.data_ptr(), T, B, H, int(bf16), _ptr(dgx_bf16), _ptr(gates_bf16),
                                   _ptr(dhn_bf16), _ptr(bias_part), ws.data_ptr(), wsb, _stream())

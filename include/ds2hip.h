@@ -156,6 +156,27 @@ int ds2_bn1d_bwd_f32(const float* dY, int lddy, const float* X, int ldx, float* 
                      const float* var, const float* gamma, float eps, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
                      void* stream);
 
+/* ---- BatchNorm1d folded into the input projection of the recurrent layer behind it (bf16 training mode, round 6) --------------------------
+ * blocks.py:85-86 (SequenceWise(BatchNorm1d)) + :92 (direction sum of the layer in front) + aten::addmm inside aten::gru / lstm (:88).
+ * y = Xa + Xb is never written.  ds2_center_colstats writes the CENTRED sum yc = y - m0 as the bf16 GEMM operand (M, ldyc; pad columns
+ * zero), m0 = the column means of y taken from hsum (2, ntiles, H: ds2_rnn_fwd_x), and returns the batch statistics of y (mean, biased var:
+ * what nn.BatchNorm1d computes; running statistics updated with momentum and the unbiased variance) plus delta = mean - m0, the mean of yc.
+ * ds2_wih_fold_bf16 then folds the normalisation into the projection:  BN(y) W^T + b = yc (W diag(s))^T + (b + W c),
+ * s = gamma rsqrt(var + eps), c = beta - delta s: W2 = bf16(W diag(s)) (R rows, pitch ldw2), bias2 = b + W c in fp32, colscale = s, colshift = c.
+ * Backward: the weight gradient of the folded projection is dW = (dGx^T yc) diag(s) + db (x) c (ds2_scale_rank1_f32 on the TN product);
+ * the BatchNorm backward formulas hold on (yc, delta, var) unchanged — ds2_bn1d_bwd_xbf16 / ds2_rnn_bwd_bn_xbf16 take the bf16 operand.
+ * workspace of ds2_center_colstats: ds2_colreduce_workspace_bytes(M, H) + H * sizeof(float). */
+int ds2_center_colstats(const float* Xa, int lda, const float* Xb, int ldb, const float* hsum, int ntiles, void* Yc_bf16, int ldyc, int M, int H,
+                        float* mean, float* var, float* delta, float* run_mean, float* run_var, float momentum, void* ws, size_t ws_bytes,
+                        void* stream);
+int ds2_wih_fold_bf16(const float* W, int ldw, const float* bias, int R, int I, const float* var, const float* gamma, const float* beta,
+                      const float* delta, float eps, void* W2_bf16, int ldw2, float* bias2, float* colscale, float* colshift, void* stream);
+/* C[r][c] = C[r][c] * scale[c] + rowv[r] * shift[c], (R, N) fp32 in place (N, ldc % 4 == 0, 16-byte aligned) */
+int ds2_scale_rank1_f32(float* C, int ldc, int R, int N, const float* scale, const float* rowv, const float* shift, void* stream);
+/* ds2_bn1d_bwd_f32 with the BatchNorm input as bf16 (pitch ldx % 4 == 0; dX, when given, needs H % 4 == 0); `mean` = the mean of X itself */
+int ds2_bn1d_bwd_xbf16(const float* dY, int lddy, const void* X_bf16, int ldx, float* dX, int lddx, int M, int H, const float* mean, const float* var,
+                       const float* gamma, float eps, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- BatchNorm2d + Hardtanh(0,20) + MaskConv time mask on (B,C,D,T) ----------------------------
  * modules/deepspeech.py:62-63,65-66 under modules/blocks.py:48-55 (mask after EVERY sub-module). */
 size_t ds2_chanreduce_workspace_bytes(int C);
@@ -328,6 +349,12 @@ int ds2_rnn_bwd_bn(ds2_rnn_ctx* ctx, int gates, const float* dyn, int lddyn, con
                    const float* bn_gamma, const float* bn_s0, const float* bn_s1, float bn_eps, float* dy_scratch, float* gx, float* aux,
                    const float* hbuf, const void* wp_bwd, const int* lens_dev, int T, int B, int H, int bf16, void* dgx_bf16,
                    const void* gates_bf16, void* dhn_bf16, float* bias_part, void* ws, size_t ws_bytes, void* stream);
+
+/* ds2_rnn_bwd_bn with the BatchNorm's input given as bf16 (the centred operand of ds2_center_colstats; bn_mean = its delta; even pitch, H % 4 == 0) */
+int ds2_rnn_bwd_bn_xbf16(ds2_rnn_ctx* ctx, int gates, const float* dyn, int lddyn, const void* bn_x_bf16, int ldx, const float* bn_mean,
+                         const float* bn_var, const float* bn_gamma, const float* bn_s0, const float* bn_s1, float bn_eps, float* dy_scratch, float* gx,
+                         float* aux, const float* hbuf, const void* wp_bwd, const int* lens_dev, int T, int B, int H, int bf16, void* dgx_bf16,
+                         const void* gates_bf16, void* dhn_bf16, float* bias_part, void* ws, size_t ws_bytes, void* stream);
 
 /* bias gradients of one recurrent layer from ds2_rnn_bwd_ex's bias_part (B,2,4,H): db_ih (2,G*H) [bias_ih_l0 | bias_ih_l0_reverse] and
  * db_hh (2,G*H); GRU: db_ih = [d r, d z, d n], db_hh = [d r, d z, d(hn)]; LSTM: both = [d i, d f, d g, d o]. */
