@@ -8,6 +8,8 @@
 // (rnn.hip's ds2_rnn_bwd_bn falls back to this norm.hip entry; the probe links rnn.hip alone and never calls it)
 int ds2i_bn1d_bwd_apply(const float*, int, const float*, int, float*, int, int, int, const float*, const float*, const float*, const float*, const float*,
                         float, hipStream_t) { return -1; }
+int ds2i_bn1d_bwd_apply_xbf(const float*, int, const void*, int, float*, int, int, int, const float*, const float*, const float*, const float*, const float*,
+                            float, hipStream_t) { return -1; }
 #include <vector>
 #include <cstdlib>
 
