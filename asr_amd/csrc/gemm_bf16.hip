@@ -20,6 +20,7 @@
 #include <type_traits>
 #include <cstdint>
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -1077,6 +1078,40 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
 
 }  // namespace
 
+// CU count of the CURRENT device, and "set this function's dynamic-LDS attribute once per DEVICE": per device id, so that a process that
+// drives two GPUs (device_test != device, two threads on two devices) never launches with the other device's grid size or without the
+// attribute.  The four-wave kernels (gemm_nt_w4.h / gemm_tn_w4.h: v_mfma_f32_16x16x32_bf16, 128 KB of LDS, one in-order
+// vmcnt shared by loads and stores) are gfx950 code: ds2_is_gfx950() gates them in the launchers.
+static int ds2_dev_index() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  return dev;
+}
+static int ds2_cus_current() {
+  static int cus[64] = {0};
+  const int dev = ds2_dev_index();
+  if (!cus[dev]) {
+    hipDeviceProp_t prop;
+    cus[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 1;
+  }
+  return cus[dev];
+}
+static bool ds2_is_gfx950() {
+  static int known[64] = {0};                            // 0 unknown, 1 yes, 2 no
+  const int dev = ds2_dev_index();
+  if (!known[dev]) {
+    hipDeviceProp_t prop;
+    known[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) ? 1 : 2;
+  }
+  return known[dev] == 1;
+}
+#define DS2_ATTR_ONCE(func, bytes)                                                                                          \
+  do {                                                                                                                      \
+    static bool done_[64] = {false};                                                                                        \
+    const int d_ = ds2_dev_index();                                                                                         \
+    if (!done_[d_]) { DS2_HIP(hipFuncSetAttribute((const void*)func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); done_[d_] = true; } \
+  } while (0)
+
 extern "C" size_t ds2_gemm_bf16_workspace_bytes(int M, int N, int batch, int splitk) {
   if (splitk <= 1) return 0;
   return (size_t)batch * splitk * (size_t)M * N * sizeof(float);
@@ -1117,33 +1152,19 @@ extern "C" int ds2_gemm_bf16_nt(int M, int N, int K, const void* A, int lda, lon
   static const char* force = ds2_exp_getenv("DS2_GEMM_TILE");      // "128" | "glds": tuning override (scripts/bench_gemm.py)
   const bool use_glds = force ? (force[0] == 'g') : (M >= 256 && N >= 256 && tiles256 >= 128);
   if (use_glds) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_nt_glds_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
-      attr_set = true;
-    }
+    DS2_ATTR_ONCE((gemm_bf16_nt_glds_kernel<2, 4>), G_LDS);
     const int ntx = ceil_div(N, 256), nty = ceil_div(M, 256);
     // 8 waves (128 x 64 per wave) for every shape (a 16-wave 64 x 64 variant lost to it in round 2 once the epilogue went through LDS and is no
     // longer built).
     static const char* wv = ds2_exp_getenv("DS2_GEMM_WAVES");      // "pp": the ping-pong schedule of the one-tile kernel (tuning override)
     const bool pp = wv && wv[0] == 'p';
     if (pp) {
-      static bool pp_attr = false;
-      if (!pp_attr) {
-        DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_nt_glds_kernel<2, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
-        pp_attr = true;
-      }
+      DS2_ATTR_ONCE((gemm_bf16_nt_glds_kernel<2, 4, true>), G_LDS);
       hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<2, 4, true>), dim3(ntx * nty, 1, batch * splitk), dim3(512), G_LDS, s, g, ntx, nty);
     } else {
       // persistent form (one workgroup per CU walking several tiles; see the kernel): short reductions with more tiles than CUs, plain write-out
       static const char* pe = ds2_exp_getenv("DS2_GEMM_PERS");     // "0": one workgroup per tile for every shape (A/B switch)
-      static int cus = 0;
-      if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                  ? prop.multiProcessorCount : 1;
-      }
+      const int cus = ds2_cus_current();
       const int nkt = K / BK;
       const bool wide = (N % 4) == 0 && (ldc % 4) == 0 && ((uintptr_t)C % 16) == 0 && (!bias || ((uintptr_t)bias % 16) == 0);
       const bool pers = !(pe && pe[0] == '0') && batch == 1 && splitk == 1 && !accumulate && (K % BK) == 0 && nkt >= 2 && (nkt % 2) == 0 &&
@@ -1158,22 +1179,18 @@ extern "C" int ds2_gemm_bf16_nt(int M, int N, int K, const void* A, int lda, lon
       // four waves x 128 x 128 (gemm_nt_w4.h): the default wherever it applies — K a multiple of the 64-deep k-tile, more tiles than CUs, plain
       // write-out, 32-bit lane offsets inside a tile (DS2_GEMM_W4=0: the 8-wave persistent kernel instead, A/B switch)
       static const char* w4_env = ds2_exp_getenv("DS2_GEMM_W4");
-      const bool w4 = !(w4_env && w4_env[0] == '0') && !(ring_env && ring_env[0] != 'w') && !(pe && pe[0] == '0') && batch == 1 && splitk == 1 &&
+      const bool w4 = ds2_is_gfx950() && !(w4_env && w4_env[0] == '0') && !(ring_env && ring_env[0] != 'w') && !(pe && pe[0] == '0') && batch == 1 && splitk == 1 &&
                       !accumulate && (K % 64) == 0 && K >= 128 && wide && !(g.nt_store & ~1) && ntx * nty > cus &&
                       (long long)lda * 512 < (1ll << 31) && (long long)ldb * 512 < (1ll << 31);
       if (w4) {
         static const int wdbg = ds2_exp_getenv("DS2_W4_DBG") ? atoi(ds2_exp_getenv("DS2_W4_DBG")) : 0;   // timing ablations (WRONG RESULTS; scripts/r5_w4_dbg.sh)
-#define DS2_W_V(n) { static bool a_ = false; if (!a_) { DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_nt_w4_kernel<n>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS)); a_ = true; } \
+#define DS2_W_V(n) { DS2_ATTR_ONCE((gemm_bf16_nt_w4_kernel<n>), W4_LDS); \
                      hipLaunchKernelGGL((gemm_bf16_nt_w4_kernel<n>), dim3(cus, 1, 1), dim3(256), W4_LDS, s, g, ntx, nty); }
         if (wdbg == 1) DS2_W_V(1) else if (wdbg == 2) DS2_W_V(2) else if (wdbg == 4) DS2_W_V(4) else if (wdbg == 5) DS2_W_V(5) else if (wdbg == 6) DS2_W_V(6) else DS2_W_V(0)
 #undef DS2_W_V
       } else if (ring) {
-        static bool rattr = false;
-        if (!rattr) {
-          DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_nt_ring_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, R_RING + G_PATCH));
-          DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_nt_pp16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, R_RING));
-          rattr = true;
-        }
+        DS2_ATTR_ONCE((gemm_bf16_nt_ring_kernel<false>), R_RING + G_PATCH);
+        DS2_ATTR_ONCE((gemm_bf16_nt_pp16_kernel<false>), R_RING);
         static const int rdbg = ds2_exp_getenv("DS2_RING_DBG") ? atoi(ds2_exp_getenv("DS2_RING_DBG")) : 0;   // timing ablations of the pp16 kernel (WRONG RESULTS)
         if (ring_env[0] == 'q' && rdbg) {
 #define DS2_Q_DBG(n) if (rdbg == n) { DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_nt_pp16_kernel<false, n>, hipFuncAttributeMaxDynamicSharedMemorySize, R_RING)); \
@@ -1181,20 +1198,14 @@ extern "C" int ds2_gemm_bf16_nt(int M, int N, int K, const void* A, int lda, lon
           DS2_Q_DBG(1) DS2_Q_DBG(2) DS2_Q_DBG(3) DS2_Q_DBG(8) DS2_Q_DBG(18) DS2_Q_DBG(22) DS2_Q_DBG(26) DS2_Q_DBG(82) DS2_Q_DBG(146)
 #undef DS2_Q_DBG
         } else if (ring_env[0] == 'q' && ring_env[1] == '5') {       // five slots: the whole LDS
-          static bool a5 = false;
-          if (!a5) { DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_nt_pp16_kernel<false, 0, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * R_SLICE)); a5 = true; }
+          DS2_ATTR_ONCE((gemm_bf16_nt_pp16_kernel<false, 0, 5>), 5 * R_SLICE);
           hipLaunchKernelGGL((gemm_bf16_nt_pp16_kernel<false, 0, 5>), dim3(cus, 1, 1), dim3(512), 5 * R_SLICE, s, g, ntx, nty);
         } else if (ring_env[0] == 'q')
           hipLaunchKernelGGL((gemm_bf16_nt_pp16_kernel<false>), dim3(cus, 1, 1), dim3(512), R_RING, s, g, ntx, nty);
         else
           hipLaunchKernelGGL((gemm_bf16_nt_ring_kernel<false>), dim3(cus, 1, 1), dim3(512), R_RING + G_PATCH, s, g, ntx, nty);
       } else if (pers) {
-        static bool pattr = false;
-        if (!pattr) {
-          DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_nt_glds_kernel<2, 4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      G_LDS + G_PATCH));
-          pattr = true;
-        }
+        DS2_ATTR_ONCE((gemm_bf16_nt_glds_kernel<2, 4, false, true>), G_LDS + G_PATCH);
         hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<2, 4, false, true>), dim3(cus, 1, 1), dim3(512), G_LDS + G_PATCH, s, g, ntx, nty);
       } else {
         hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<2, 4>), dim3(ntx * nty, 1, batch * splitk), dim3(512), G_LDS, s, g, ntx, nty);
@@ -1214,20 +1225,6 @@ extern "C" int ds2_gemm_bf16_nt(int M, int N, int K, const void* A, int lda, lon
   return 0;
 }
 
-// CU count of the CURRENT device and "has this per-function attribute been set on the current device" — per device id, so that a process
-// that drives two GPUs (device_test != device, two threads on two devices) never launches with the other device's grid size or without the
-// dynamic-LDS attribute
-static int ds2_cus_current() {
-  static int cus[64] = {0};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  if (!cus[dev]) {
-    hipDeviceProp_t prop;
-    cus[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 1;
-  }
-  return cus[dev];
-}
-
 // C[M,N] **bf16** = A[M,K] bf16 * B[N,K]^T bf16 + bias (fp32 accumulation and bias add, one rounding at the store): the x-projections of a
 // recurrent layer in the bf16 training mode (aten::addmm inside aten::gru / lstm, blocks.py:76-78, 88), consumed once by ds2_rnn_fwd_x.
 // Four-wave 256 x 256 x 64 kernel only (gemm_nt_w4.h, OBF): returns 1 — nothing launched, call ds2_gemm_bf16_nt — where that kernel does not
@@ -1238,7 +1235,7 @@ extern "C" int ds2_gemm_bf16_nt_obf16(int M, int N, int K, const void* A, int ld
               "ds2_gemm_bf16_nt_obf16: K, lda, ldb must be multiples of 8 and the operands 16-byte aligned");
   const int cus = ds2_cus_current();
   const int ntx = ceil_div(N, 256), nty = ceil_div(M, 256);
-  const bool ok = (K % 64) == 0 && K >= 128 && (N % 8) == 0 && (ldc % 8) == 0 && ((uintptr_t)C % 16) == 0 && (!bias || ((uintptr_t)bias % 16) == 0) &&
+  const bool ok = ds2_is_gfx950() && (K % 64) == 0 && K >= 128 && (N % 8) == 0 && (ldc % 8) == 0 && ((uintptr_t)C % 16) == 0 && (!bias || ((uintptr_t)bias % 16) == 0) &&
                   ntx * nty > cus && (long long)lda * 512 < (1ll << 31) && (long long)ldb * 512 < (1ll << 31);
   if (!ok) return 1;
   BArgs g;
@@ -1247,13 +1244,7 @@ extern "C" int ds2_gemm_bf16_nt_obf16(int M, int N, int K, const void* A, int ld
   g.sA = g.sB = g.sC = 0;
   g.splitk = 1; g.kchunk = K; g.accumulate = 0; g.partial = nullptr;
   g.nt_store = 1; g.super_rows = 4;
-  static bool attr[64] = {false};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  if (!attr[dev]) {
-    DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_nt_w4_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS));
-    attr[dev] = true;
-  }
+  DS2_ATTR_ONCE((gemm_bf16_nt_w4_kernel<0, true>), W4_LDS);
   hipLaunchKernelGGL((gemm_bf16_nt_w4_kernel<0, true>), dim3(cus, 1, 1), dim3(256), W4_LDS, (hipStream_t)stream, g, ntx, nty);
   DS2_LAUNCH_CHECK("gemm_bf16_nt_w4_kernel<obf16>");
   return 0;
@@ -1281,11 +1272,7 @@ extern "C" int ds2_gemm_bf16_tn(int M, int N, int K, const void* A, int lda, lon
   g.splitk = splitk; g.kchunk = kchunk; g.accumulate = accumulate; g.partial = (float*)workspace; g.nt_store = 0; g.super_rows = 0;
   { static const char* wide_env = ds2_exp_getenv("DS2_GEMM_WIDE"); if (wide_env && wide_env[0] == '0') g.nt_store |= 128; }
   hipStream_t s = (hipStream_t)stream;
-  static bool attr_set = false;
-  if (!attr_set) {
-    DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_tn_glds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
-    attr_set = true;
-  }
+  DS2_ATTR_ONCE((gemm_bf16_tn_glds_kernel<false>), G_LDS);
   const int ntx = ceil_div(N, 256), nty = ceil_div(M, 256);
   hipLaunchKernelGGL(gemm_bf16_tn_glds_kernel<false>, dim3(ntx * nty, 1, batch * splitk), dim3(512), G_LDS, s, g, ntx, nty, TnSGroup{});
   DS2_LAUNCH_CHECK("gemm_bf16_tn_glds_kernel");
@@ -1368,14 +1355,10 @@ extern "C" int ds2_gemm_bf16_tn_splitk_group(int nprob, const ds2_tn_problem* pr
   static const char* ord_env = ds2_exp_getenv("DS2_TN_ORDER");
   g.order = !(ord_env && ord_env[0] == '0');
   if (any_slab) DS2_REQUIRE(workspace && workspace_bytes >= off, "ds2_gemm_bf16_tn_splitk_group: workspace too small");
-  static bool attr_set = false;
-  if (!attr_set) {
-    DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_tn_glds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
-    attr_set = true;
-  }
+  DS2_ATTR_ONCE((gemm_bf16_tn_glds_kernel<true>), G_LDS);
   // four waves x 128 x 128 (gemm_tn_w4.h) when every k-tile of every slice is full; DS2_GEMM_W4=0: the 8-wave kernel (A/B switch)
   static const char* w4_env = ds2_exp_getenv("DS2_GEMM_W4");
-  bool w4 = !(w4_env && w4_env[0] == '0');
+  bool w4 = ds2_is_gfx950() && !(w4_env && w4_env[0] == '0');
   for (int i = 0; i < nprob; ++i) {
     const ds2_tn_problem& q = probs[i];
     const int kc = g.p[i].kchunk, klast = q.K - (splitk - 1) * kc;
@@ -1392,11 +1375,7 @@ extern "C" int ds2_gemm_bf16_tn_splitk_group(int nprob, const ds2_tn_problem* pr
   if (!fused) for (int i = 0; i < TN_MAX_PROBLEMS; ++i) g.p[i].tick = nullptr;
   else DS2_HIP(hipMemsetAsync((char*)workspace + tick_off, 0, tick_bytes, (hipStream_t)stream));
   if (w4) {
-    static bool w4_attr = false;
-    if (!w4_attr) {
-      DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_tn_w4_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS));
-      w4_attr = true;
-    }
+    DS2_ATTR_ONCE((gemm_bf16_tn_w4_kernel<0>), W4_LDS);
     hipLaunchKernelGGL(gemm_bf16_tn_w4_kernel<0>, dim3(items), dim3(256), W4_LDS, (hipStream_t)stream, g);
     DS2_LAUNCH_CHECK("gemm_bf16_tn_w4_kernel");
   } else {
@@ -1434,21 +1413,11 @@ extern "C" int ds2_gemm_bf16_tn_group(int nprob, const ds2_tn_problem* probs, in
   }
   for (int i = nprob; i < TNG_MAX_PROBLEMS; ++i) g.p[i] = g.p[0];
   g.nprob = nprob; g.ntiles = tiles;
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-              ? prop.multiProcessorCount : 8;
-  }
+  const int cus = ds2_cus_current() < 8 ? 8 : ds2_cus_current();
   int grid = max_workgroups > 0 ? (max_workgroups < cus ? max_workgroups : cus) : cus;
   if (grid > tiles) grid = tiles;
   grid = grid < 8 ? 8 : grid / 8 * 8;                  // the tile walk deals whole runs to the 8 XCDs
-  static bool attr_set = false;
-  if (!attr_set) {
-    DS2_HIP(hipFuncSetAttribute((const void*)gemm_bf16_tn_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, L_LDS_REQ));
-    attr_set = true;
-  }
+  DS2_ATTR_ONCE((gemm_bf16_tn_group_kernel), L_LDS_REQ);
   hipLaunchKernelGGL(gemm_bf16_tn_group_kernel, dim3(grid), dim3(256), L_LDS_REQ, (hipStream_t)stream, g);
   DS2_LAUNCH_CHECK("gemm_bf16_tn_group_kernel");
   return 0;

@@ -1558,15 +1558,16 @@ bool persist_idle(const ds2_rnn_ctx* c, bool bwd) { return c && c->status_dev &&
 // bytes of ONE packed h buffer of the forward recurrence ([2 dirs][tiles][chunks][1 KiB]); the persistent kernel uses four
 size_t fwd_xbuf_bytes(int B, int H, int bf16) { return (size_t)2 * (ceil_div(B, 32) * 2) * ceil_div(H, bf16 ? 32 : 16) * 1024; }
 
-int cu_count() {
-  static int n = 0;
-  if (!n) {
-    int dev = 0;
+int cu_count() {                                          // of the CURRENT device (cached per device id: a process may drive two GPUs)
+  static int n[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!n[dev]) {
     hipDeviceProp_t p;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
-    if (n <= 0) n = 1;
+    if (hipGetDeviceProperties(&p, dev) == hipSuccess) n[dev] = p.multiProcessorCount;
+    if (n[dev] <= 0) n[dev] = 1;
   }
-  return n;
+  return n[dev];
 }
 
 // XCD-local exchange (persist_role's census mode): possible when every exchange group (gs workgroups) fits one XCD and the groups fit the
