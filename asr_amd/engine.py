@@ -136,6 +136,13 @@ def _idle_cus_beside_bwd_recurrence(device, B: int, H: int) -> int:
     return torch.cuda.get_device_properties(device).multi_processor_count - 2 * ((B + 15) // 16) * ((H + 31) // 32)
 
 
+def _wgrad_idle_schedule(device, B: int, H: int) -> bool:
+    """does backward launch a layer's weight-gradient GEMMs on the side stream beside the NEXT layer's recurrence (the idle-CU schedule of
+    _backward_rnn_deferred: B = 32 shapes whose recurrence leaves 64 ... 127 CUs without a workgroup — c4)?"""
+    n_idle = _idle_cus_beside_bwd_recurrence(device, B, H)
+    return (WGRAD_SIDE == "sk" and WGRAD_IDLE and WGRAD_IDLE_MIN_CUS <= n_idle < torch.cuda.get_device_properties(device).multi_processor_count // 2)
+
+
 def _side_stream(device):
     import threading
     key = (device.type, device.index, threading.get_ident())      # one side stream per driving thread: two threads never share one
@@ -379,7 +386,10 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
                     if (WGRAD_TN and OVERLAP_MODE == "2" and T > 1 and _BWD_PERSISTENT.get((ops.rnn_ctx_key(x.device), G, H, B), True)) else None)
             # BN_FOLD: the layer behind this one folds its BatchNorm — this recurrence emits the per-tile column sums of h it needs
             hsum = (torch.empty(2, (B + 15) // 16, H, dtype=torch.float32, device=x.device)
-                    if (BN_FOLD and training and l + 1 < L and H % 8 == 0 and OVERLAP_MODE == "2" and T > 1) else None)
+                    if (BN_FOLD and training and l + 1 < L and H % 8 == 0 and OVERLAP_MODE == "2" and T > 1
+                        # (not under the idle-CU schedule: the fold's weight-gradient epilogue — 52 MB read + written at c4 — would run on
+                        #  the side stream beside the next layer's latency-bound recurrence: c4 bf16 49.3 -> 50.4 ms, profiles/r06_experiments.txt)
+                        and not _wgrad_idle_schedule(x.device, B, H)) else None)
             hbuf, aux, rec = ops.rnn_fwd(G, gx, wpf, W[f"rnns.{l}.bhh_cat"], lens_dev, T, B, H, bf16=True, packed_gates=True, h_bf16=h_bf, ws=ws_f, hsum=hsum)
             if hsum is not None and not (ops.rnn_last_path(x.device) & 1):
                 hsum = None                                      # (only a persistent launch writes it)
