@@ -47,6 +47,7 @@ SIGNATURES = {
     "ds2_gemm_bf16_tn_group": (i32, [i32, vp, i32, vp]),
     "ds2_gemm_bf16_tn_splitk_group_workspace_bytes": (sz, [i32, vp, i32]),
     "ds2_gemm_bf16_tn_splitk_group": (i32, [i32, vp, i32, vp, sz, vp]),
+    "ds2_gemm_bf16_tn_splitk_group_ep": (i32, [i32, vp, i32, i32, vp, vp, vp, vp, sz, vp]),
     "ds2_gemm_bf16_nt": (i32, [i32, i32, i32, vp, i32, i64, vp, i32, i64, vp, i32, i64, vp, i32, i32, i32, vp, sz, vp]),
     "ds2_cast_bf16": (i32, [vp, i32, vp, i32, i32, i32, vp]),
     "ds2_gemm_bf16_nt_obf16": (i32, [i32, i32, i32, vp, i32, vp, i32, vp, i32, vp, vp]),

@@ -623,6 +623,10 @@ struct TnSProb {
 struct TnSGroup {
   TnSProb p[TN_MAX_PROBLEMS];
   int nprob, splitk, nitems, order;
+  // epilogue of ONE product in the reduce launch (ds2_gemm_bf16_tn_splitk_group_ep; ep_prob < 0: none):
+  //   C[r][c] = (sum of slabs)[r][c] * ep_scale[c] + ep_rowv[r] * ep_shift[c]   — the weight gradient of a projection with a folded BatchNorm
+  int ep_prob;
+  const float* ep_scale; const float* ep_rowv; const float* ep_shift;
 };
 
 template <bool GROUPED>
@@ -895,13 +899,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_group_kernel(TnSGroup grp, 
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     long long local = idx;
     const float* part = nullptr; float* C = nullptr; int M = 0, N = 1, ldc = 0, nslab = 0;
-    bool found = false;
+    bool found = false, ep = false;
 #pragma unroll
     for (int q = 0; q < TN_MAX_PROBLEMS; ++q) {
       const long long mn = (q < grp.nprob && grp.p[q].nslab > 0) ? (long long)grp.p[q].M * grp.p[q].N / 4 : 0;
       if (!found && local < mn) {
         part = grp.p[q].partial; C = grp.p[q].C; M = grp.p[q].M; N = grp.p[q].N; ldc = grp.p[q].ldc; nslab = grp.p[q].nslab;
-        found = true;
+        found = true; ep = q == grp.ep_prob;
       }
       if (!found) local -= mn;
     }
@@ -909,6 +913,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_group_kernel(TnSGroup grp, 
     const int row = (int)(e / N), col = (int)(e % N);
     f32x4 sum = *reinterpret_cast<const f32x4*>(part + e);
     for (int sidx = 1; sidx < nslab; ++sidx) sum += *reinterpret_cast<const f32x4*>(part + (long long)sidx * M * N + e);
+    if (ep) sum = sum * *reinterpret_cast<const f32x4*>(grp.ep_scale + col) + *reinterpret_cast<const f32x4*>(grp.ep_shift + col) * grp.ep_rowv[row];
     *reinterpret_cast<f32x4*>(C + (long long)row * ldc + col) = sum;
   }
 }
@@ -1294,8 +1299,24 @@ extern "C" size_t ds2_gemm_bf16_tn_splitk_group_workspace_bytes(int nprob, const
   return n + 256;
 }
 
+static int tn_splitk_group_impl(int nprob, const ds2_tn_problem* probs, int splitk, int ep_index, const float* ep_scale, const float* ep_rowv,
+                                const float* ep_shift, void* workspace, size_t workspace_bytes, void* stream);
 extern "C" int ds2_gemm_bf16_tn_splitk_group(int nprob, const ds2_tn_problem* probs, int splitk, void* workspace, size_t workspace_bytes,
                                              void* stream) {
+  return tn_splitk_group_impl(nprob, probs, splitk, -1, nullptr, nullptr, nullptr, workspace, workspace_bytes, stream);
+}
+// ... with an epilogue on product `ep_index`, applied by the reduce launch:  C = (A^T B) diag(scale) + rowv (x) shift  (scale / shift: N floats,
+// 16-byte aligned; rowv: M floats) — the weight gradient of a projection whose BatchNorm was folded into it (ds2_wih_fold_bf16).  Returns 1,
+// nothing launched, when that product would have a single slab (split factor 1: no reduce launch to carry the epilogue): call the plain entry
+// and ds2_scale_rank1_f32.
+extern "C" int ds2_gemm_bf16_tn_splitk_group_ep(int nprob, const ds2_tn_problem* probs, int splitk, int ep_index, const float* ep_scale,
+                                                const float* ep_rowv, const float* ep_shift, void* workspace, size_t workspace_bytes, void* stream) {
+  DS2_REQUIRE(ep_index >= 0 && ep_index < nprob && ep_scale && ep_rowv && ep_shift && ((uintptr_t)ep_scale % 16) == 0 && ((uintptr_t)ep_shift % 16) == 0,
+              "ds2_gemm_bf16_tn_splitk_group_ep: bad epilogue arguments");
+  return tn_splitk_group_impl(nprob, probs, splitk, ep_index, ep_scale, ep_rowv, ep_shift, workspace, workspace_bytes, stream);
+}
+static int tn_splitk_group_impl(int nprob, const ds2_tn_problem* probs, int splitk, int ep_index, const float* ep_scale, const float* ep_rowv,
+                                const float* ep_shift, void* workspace, size_t workspace_bytes, void* stream) {
   DS2_REQUIRE(nprob >= 1 && nprob <= TN_MAX_PROBLEMS && probs, "ds2_gemm_bf16_tn_splitk_group: 1..%d problems", TN_MAX_PROBLEMS);
   if (splitk < 1) splitk = 1;
   int kmin = probs[0].K;
@@ -1352,6 +1373,8 @@ extern "C" int ds2_gemm_bf16_tn_splitk_group(int nprob, const ds2_tn_problem* pr
   }
   for (int i = nprob; i < TN_MAX_PROBLEMS; ++i) { g.p[i] = g.p[0]; g.p[i].nslab = 0; }
   g.nprob = nprob; g.splitk = splitk; g.nitems = items;
+  g.ep_prob = ep_index; g.ep_scale = ep_scale; g.ep_rowv = ep_rowv; g.ep_shift = ep_shift;
+  if (ep_index >= 0 && g.p[ep_index].nslab == 0) return 1;       // (single slab, or a further term of a product: nothing reduces it)
   static const char* ord_env = ds2_exp_getenv("DS2_TN_ORDER");
   g.order = !(ord_env && ord_env[0] == '0');
   if (any_slab) DS2_REQUIRE(workspace && workspace_bytes >= off, "ds2_gemm_bf16_tn_splitk_group: workspace too small");

@@ -117,6 +117,7 @@ WS_PREARM = _tune("DS2_WS_PREARM", "1") != "0"
 # (ops.wih_fold); backward: dW_ih = (dGx^T yc) diag(s) + db (x) c, BatchNorm backward on (yc, delta, var).  Neither y (fp32) nor BN(y) exists
 # any more: 327 MB moved per layer in forward instead of 589, 196 instead of 262 for the backward sums.  0: the separate passes of rounds 1-5.
 BN_FOLD = _tune("DS2_BN_FOLD", "1") != "0"
+BN_FOLD_IDLE = _tune("DS2_BN_FOLD_IDLE", "0") != "0"      # (A/B: the fold also under the idle-CU weight-gradient schedule, see forward())
 
 
 def _f32_split_ok(M: int, N: int, K: int, H: int = 8) -> bool:
@@ -389,7 +390,7 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
                     if (BN_FOLD and training and l + 1 < L and H % 8 == 0 and OVERLAP_MODE == "2" and T > 1
                         # (not under the idle-CU schedule: the fold's weight-gradient epilogue — 52 MB read + written at c4 — would run on
                         #  the side stream beside the next layer's latency-bound recurrence: c4 bf16 49.3 -> 50.4 ms, profiles/r06_experiments.txt)
-                        and not _wgrad_idle_schedule(x.device, B, H)) else None)
+                        and (BN_FOLD_IDLE or not _wgrad_idle_schedule(x.device, B, H))) else None)
             hbuf, aux, rec = ops.rnn_fwd(G, gx, wpf, W[f"rnns.{l}.bhh_cat"], lens_dev, T, B, H, bf16=True, packed_gates=True, h_bf16=h_bf, ws=ws_f, hsum=hsum)
             if hsum is not None and not (ops.rnn_last_path(x.device) & 1):
                 hsum = None                                      # (only a persistent launch writes it)
@@ -510,16 +511,24 @@ def _backward_rnn_deferred(W, Gr, cfg: ModelCfg, ctx: Ctx, dy, done, private: bo
                  (dgx_bf[0:M - B, G * H:G * H + rows], h_bf[B:M, H:2 * H], dwhh[1, :rows])]
         if G == 3:
             probs += [(dhn_bf[B:M, 0:H], h_bf[0:M - B, 0:H], dwhh[0, 2 * H:]), (dhn_bf[0:M - B, H:2 * H], h_bf[B:M, H:2 * H], dwhh[1, 2 * H:])]
-        launch = ops.gemm_bf16_tn_splitk_group if WGRAD_SIDE == "sk" else ops.gemm_bf16_tn_group
+        f = fold_of.get(l)
+        if WGRAD_SIDE == "sk" and f:
+            # BN_FOLD: the epilogue of dW_ih (problem 0) rides in the reduce launch of the grouped split-K product
+            def launch(pr):
+                ops.gemm_bf16_tn_splitk_group(pr, epilogue=(0, f[0], Gr[f"rnns.{l}.bih_cat"].view(-1), f[1]))
+        elif WGRAD_SIDE == "sk":
+            launch = ops.gemm_bf16_tn_splitk_group
+        else:
+            def launch(pr):
+                ops.gemm_bf16_tn_group(pr)
+                fold_epilogue(l)
         if not on_side:
             launch(probs)
-            fold_epilogue(l)
             done(f"rnns.{l}")
             return
         with torch.cuda.stream(side):
             side.wait_event(start)
             launch(probs)
-            fold_epilogue(l)
             if not serial_buckets:
                 done(f"rnns.{l}")                                # (a reducer records its "gradients final" event on the current = side stream)
         if serial_buckets:                                       # the "serial" data-parallel schedule orders every collective INTO the compute stream

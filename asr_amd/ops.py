@@ -413,7 +413,7 @@ def _tn_problem_array(problems):
     return arr
 
 
-def gemm_bf16_tn_splitk_group(problems, splitk: int = 0):
+def gemm_bf16_tn_splitk_group(problems, splitk: int = 0, epilogue=None):
     """Several TN products `[(A (K, M), B (K, N), out (M, N))]` in ONE launch of the 256 x 256 kernel with a common split-K factor and one reduce
     launch (ds2_gemm_bf16_tn_splitk_group).  splitk 0: chosen so that tiles x splitk fills whole rounds of the chip (the cost model of
     _pick_splitk over the tiles of all products together)."""
@@ -436,6 +436,18 @@ def gemm_bf16_tn_splitk_group(problems, splitk: int = 0):
     ap = C.cast(arr, C.c_void_p)
     wsb = lib.ds2_gemm_bf16_tn_splitk_group_workspace_bytes(len(problems), ap, splitk)
     ws = _ws(wsb, problems[0][0].device) if wsb else None
+    if epilogue is not None:
+        # epilogue = (index, scale (N), rowv (M), shift (N)): out[index] = (A^T B) diag(scale) + rowv (x) shift, applied by the reduce launch
+        idx, scale, rowv, shift = epilogue
+        _chk_f32(scale, rowv, shift)
+        rc = lib.ds2_gemm_bf16_tn_splitk_group_ep(len(problems), ap, splitk, int(idx), scale.data_ptr(), rowv.data_ptr(), shift.data_ptr(), _ptr(ws), wsb, _stream())
+        if rc == 0:
+            return splitk
+        if rc != 1:
+            _lib.check(rc, "ds2_gemm_bf16_tn_splitk_group_ep")
+        _lib.check(lib.ds2_gemm_bf16_tn_splitk_group(len(problems), ap, splitk, _ptr(ws), wsb, _stream()), "ds2_gemm_bf16_tn_splitk_group")
+        scale_rank1_(problems[idx][2], scale, rowv, shift)       # (single slab: nothing reduces that product)
+        return splitk
     _lib.check(lib.ds2_gemm_bf16_tn_splitk_group(len(problems), ap, splitk, _ptr(ws), wsb, _stream()), "ds2_gemm_bf16_tn_splitk_group")
     return splitk
 

@@ -115,6 +115,11 @@ int ds2_gemm_bf16_tn_group(int nprob, const ds2_tn_problem* problems, int max_wo
  * split operands, ds2_split_bf16): up to 16 entries per launch. */
 size_t ds2_gemm_bf16_tn_splitk_group_workspace_bytes(int nprob, const ds2_tn_problem* problems, int splitk);
 int ds2_gemm_bf16_tn_splitk_group(int nprob, const ds2_tn_problem* problems, int splitk, void* workspace, size_t workspace_bytes, void* stream);
+/* ds2_gemm_bf16_tn_splitk_group with an epilogue on product ep_index, applied by the reduce launch: C = (A^T B) diag(scale) + rowv (x) shift
+ * (scale / shift: N floats, 16-byte aligned; rowv: M floats) — dW_ih of a projection whose BatchNorm1d was folded into it (ds2_wih_fold_bf16).
+ * Returns 1, nothing launched, when that product would have a single slab: use the plain entry + ds2_scale_rank1_f32. */
+int ds2_gemm_bf16_tn_splitk_group_ep(int nprob, const ds2_tn_problem* probs, int splitk, int ep_index, const float* ep_scale, const float* ep_rowv,
+                                     const float* ep_shift, void* workspace, size_t workspace_bytes, void* stream);
 int ds2_cast_bf16(const float* src, int ld_src, void* dst, int ld_dst, int R, int Cc, void* stream);
 /* fp32 mode (precision="fp32", BASELINE configs[1],[3]), large GEMMs: every fp32 operand is SPLIT into two bf16 terms, x = hi + lo with
  * hi = bf16(x), lo = bf16(x - hi) (x is represented to 2^-18 relative), and a product is taken as a_hi b_hi + a_hi b_lo + a_lo b_hi on the bf16

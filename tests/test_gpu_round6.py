@@ -259,3 +259,23 @@ def test_forward_recurrence_emits_the_column_sums_of_h(dev, G, H, B, T):
         outs.append((dgx.float(), ops.rnn_last_path()))
     assert outs[0][1] == outs[1][1]
     assert rel_l2(outs[1][0].cpu(), outs[0][0].cpu()) < 1e-2, "bf16 BatchNorm input: within bf16 rounding of the fp32 form"
+
+
+def test_grouped_splitk_reduce_carries_the_fold_epilogue(dev):
+    """ds2_gemm_bf16_tn_splitk_group_ep: product 0's reduce applies C = (A^T B) diag(scale) + rowv (x) shift — the same numbers as the plain grouped
+    launch followed by ops.scale_rank1_ (to a contraction difference), the other products untouched; a single-slab launch falls back."""
+    from asr_amd import ops
+    torch.manual_seed(3)
+    K, M, N = 8192, 768, 512
+    A = (torch.randn(K, M, device=dev) * 0.1).bfloat16()
+    B1 = (torch.randn(K, N, device=dev) * 0.1).bfloat16()
+    B2 = (torch.randn(K, 256, device=dev) * 0.1).bfloat16()
+    scale, shift, rowv = torch.rand(N, device=dev) + 0.5, torch.randn(N, device=dev), torch.randn(M, device=dev)
+    for splitk in (4, 1):
+        o1, o2 = torch.empty(M, N, device=dev), torch.empty(M, 256, device=dev)
+        ops.gemm_bf16_tn_splitk_group([(A, B1, o1), (A, B2, o2)], splitk=splitk)
+        want = ops.scale_rank1_(o1.clone(), scale, rowv, shift)
+        e1, e2 = torch.empty(M, N, device=dev), torch.empty(M, 256, device=dev)
+        ops.gemm_bf16_tn_splitk_group([(A, B1, e1), (A, B2, e2)], splitk=splitk, epilogue=(0, scale, rowv, shift))
+        assert torch.equal(e2, o2)
+        assert rel_l2(e1.cpu(), want.cpu()) < 1e-6, splitk
