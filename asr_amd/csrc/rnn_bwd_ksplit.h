@@ -161,7 +161,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_ksplit_kernel(RnnArgs a, char
       else o.g3 = ldnt(a.aux + fH);
     }
     o.dy = ldnt(a.dy + fY);
-    if (bn) o.bx = bxbf ? __uint_as_float((__float_as_uint(ldnt(a.bn_x + (fX >> 1))) << bx_sh) & bx_mask) : ldnt(a.bn_x + fX);
+    if (bn) o.bx = __uint_as_float((__float_as_uint(ldnt(a.bn_x + (bxbf ? (fX >> 1) : fX))) << bx_sh) & bx_mask);   // ONE load either way (no branch in the step)
     if (has_prev) o.prev = (G == 3) ? a.hbuf[fH + dH] : a.aux[fH + dH];     // h / c of the previous frame in forward order = the NEXT step's row
     return o;
   };

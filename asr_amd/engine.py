@@ -117,7 +117,7 @@ WS_PREARM = _tune("DS2_WS_PREARM", "1") != "0"
 # (ops.wih_fold); backward: dW_ih = (dGx^T yc) diag(s) + db (x) c, BatchNorm backward on (yc, delta, var).  Neither y (fp32) nor BN(y) exists
 # any more: 327 MB moved per layer in forward instead of 589, 196 instead of 262 for the backward sums.  0: the separate passes of rounds 1-5.
 BN_FOLD = _tune("DS2_BN_FOLD", "1") != "0"
-BN_FOLD_IDLE = _tune("DS2_BN_FOLD_IDLE", "0") != "0"      # (A/B: the fold also under the idle-CU weight-gradient schedule, see forward())
+BN_FOLD_IDLE = _tune("DS2_BN_FOLD_IDLE", "1") != "0"      # (A/B: 0 = no fold for shapes under the idle-CU weight-gradient schedule, see forward())
 
 
 def _f32_split_ok(M: int, N: int, K: int, H: int = 8) -> bool:
@@ -141,7 +141,7 @@ def _wgrad_idle_schedule(device, B: int, H: int) -> bool:
     """does backward launch a layer's weight-gradient GEMMs on the side stream beside the NEXT layer's recurrence (the idle-CU schedule of
     _backward_rnn_deferred: B = 32 shapes whose recurrence leaves 64 ... 127 CUs without a workgroup — c4)?"""
     n_idle = _idle_cus_beside_bwd_recurrence(device, B, H)
-    return (WGRAD_SIDE == "sk" and WGRAD_IDLE and WGRAD_IDLE_MIN_CUS <= n_idle < torch.cuda.get_device_properties(device).multi_processor_count // 2)
+    return WGRAD_IDLE_MIN_CUS <= n_idle < torch.cuda.get_device_properties(device).multi_processor_count // 2      # (the shape alone decides)
 
 
 def _side_stream(device):
@@ -388,8 +388,9 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
             # BN_FOLD: the layer behind this one folds its BatchNorm — this recurrence emits the per-tile column sums of h it needs
             hsum = (torch.empty(2, (B + 15) // 16, H, dtype=torch.float32, device=x.device)
                     if (BN_FOLD and training and l + 1 < L and H % 8 == 0 and OVERLAP_MODE == "2" and T > 1
-                        # (not under the idle-CU schedule: the fold's weight-gradient epilogue — 52 MB read + written at c4 — would run on
-                        #  the side stream beside the next layer's latency-bound recurrence: c4 bf16 49.3 -> 50.4 ms, profiles/r06_experiments.txt)
+                        # (c4 — LSTM 1280 under the idle-CU schedule — first LOST 1.1 ms with the fold: not the epilogue beside the recurrence,
+                        #  but a branch the bf16 BatchNorm input had put into the LSTM instance's per-step operand fetch; with ONE load either
+                        #  way the fold is worth -0.2 ms there too, profiles/r06_experiments.txt)
                         and (BN_FOLD_IDLE or not _wgrad_idle_schedule(x.device, B, H))) else None)
             hbuf, aux, rec = ops.rnn_fwd(G, gx, wpf, W[f"rnns.{l}.bhh_cat"], lens_dev, T, B, H, bf16=True, packed_gates=True, h_bf16=h_bf, ws=ws_f, hsum=hsum)
             if hsum is not None and not (ops.rnn_last_path(x.device) & 1):
