@@ -975,13 +975,23 @@ def rnn_ws(kind: str, gates: int, B: int, H: int, bf16, device) -> Tensor:
     return ws
 
 
-def _take_ws(ws: Optional[Tensor], need: int, device) -> Tensor:
-    """`ws` from rnn_ws (promised to the library through the context's one-shot flag) or a fresh, un-armed workspace"""
+def _take_ws(ws: Optional[Tensor], need: int, device):
+    """(workspace, armed): `ws` from rnn_ws (armed: every byte 0xff) or a fresh, un-armed one"""
     if ws is None:
-        return _ws(need, device)
+        return _ws(need, device), False
     assert ws.numel() >= need and ws.device == torch.device(device)
-    rnn_ctx(device).ws_prearmed = 1
-    return ws
+    return ws, True
+
+
+def _rnn_call(device, armed: bool, thunk):
+    """Run one recurrence entry point with the context's one-shot `ws_prearmed` promise set iff the workspace was armed by rnn_ws — and never
+    left standing: the library clears it when it reads it; an argument check that fails before that must not hand it to the NEXT call."""
+    ctx = rnn_ctx(device)
+    ctx.ws_prearmed = 1 if armed else 0
+    try:
+        return thunk()
+    finally:
+        ctx.ws_prearmed = 0
 
 
 def rnn_persistent_enable(forward: bool = True, backward: bool = True, device=None) -> None:
@@ -1046,7 +1056,7 @@ def rnn_fwd(gates: int, gx: Tensor, wp_fwd: Tensor, bhh: Tensor, lens_dev: Tenso
     aux = torch.empty_like(hbuf)
     rec = torch.empty(T * B, 2 * H, 4, dtype=torch.bfloat16, device=gx.device) if packed_gates else None
     wsb = lib.ds2_rnn_fwd_workspace_bytes(B, H, int(bf16))
-    ws = _take_ws(ws, wsb, gx.device)
+    ws, armed = _take_ws(ws, wsb, gx.device)
     if gx.dtype == torch.bfloat16 or hsum is not None:
         # the bf16 training mode's entry point: bf16 x-projections (gemm_bf16_nt_obf16) and / or the per-tile column sums of h.  Persistent
         # launches take bf16 x-projections as they are; anything else (a cooldown after a starved launch, a shape without a persistent
@@ -1055,17 +1065,18 @@ def rnn_fwd(gates: int, gx: Tensor, wp_fwd: Tensor, bhh: Tensor, lens_dev: Tenso
         gxb = gx if gx.dtype == torch.bfloat16 else None
         gxf = None if gxb is not None else gx
         for _attempt in (0, 1):
-            rc = lib.ds2_rnn_fwd_x(_ctxp(gx.device), gates, _ptr(gxf), _ptr(gxb), wp_fwd.data_ptr(), bhh.data_ptr(), hbuf.data_ptr(), aux.data_ptr(),
-                                   lens_dev.data_ptr(), T, B, H, _ptr(rec), _ptr(h_bf16), _ptr(hsum), ws.data_ptr(), wsb, _stream())
+            rc = _rnn_call(gx.device, armed and _attempt == 0, lambda: lib.ds2_rnn_fwd_x(
+                _ctxp(gx.device), gates, _ptr(gxf), _ptr(gxb), wp_fwd.data_ptr(), bhh.data_ptr(), hbuf.data_ptr(), aux.data_ptr(),
+                lens_dev.data_ptr(), T, B, H, _ptr(rec), _ptr(h_bf16), _ptr(hsum), ws.data_ptr(), wsb, _stream()))
             if rc != 1:
                 break
             gxf, gxb = widen_bf16(gxb), None
         _lib.check(rc, "ds2_rnn_fwd_x")
         return hbuf, aux, rec
     _chk_f32(gx)
-    _lib.check(lib.ds2_rnn_fwd_ex(_ctxp(gx.device), gates, gx.data_ptr(), wp_fwd.data_ptr(), bhh.data_ptr(), hbuf.data_ptr(), aux.data_ptr(),
-                                  lens_dev.data_ptr(), T, B, H, int(bf16), _ptr(rec), _ptr(h_bf16), ws.data_ptr(), wsb, _stream()),
-               "ds2_rnn_fwd")
+    _lib.check(_rnn_call(gx.device, armed, lambda: lib.ds2_rnn_fwd_ex(
+        _ctxp(gx.device), gates, gx.data_ptr(), wp_fwd.data_ptr(), bhh.data_ptr(), hbuf.data_ptr(), aux.data_ptr(),
+        lens_dev.data_ptr(), T, B, H, int(bf16), _ptr(rec), _ptr(h_bf16), ws.data_ptr(), wsb, _stream())), "ds2_rnn_fwd")
     return (hbuf, aux, rec) if packed_gates else (hbuf, aux)
 
 
@@ -1110,10 +1121,11 @@ def rnn_bwd(gates: int, dy: Tensor, gx: Optional[Tensor], aux: Tensor, hbuf: Ten
     assert gx is not None or (dgx_bf16 is not None and gates_bf16 is not None)
     lib = _lib.load()
     wsb = lib.ds2_rnn_bwd_workspace_bytes(gates, B, H, int(bf16))
-    ws = _take_ws(ws, wsb, dy.device)
-    _lib.check(lib.ds2_rnn_bwd_ex(_ctxp(dy.device), gates, dy.data_ptr(), _row_pitch(dy), _ptr(gx), aux.data_ptr(), hbuf.data_ptr(), wp_bwd.data_ptr(),
-                                  lens_dev.data_ptr(), T, B, H, int(bf16), _ptr(dgx_bf16), _ptr(gates_bf16), _ptr(dhn_bf16), _ptr(bias_part),
-                                  ws.data_ptr(), wsb, _stream()), "ds2_rnn_bwd")
+    ws, armed = _take_ws(ws, wsb, dy.device)
+    _lib.check(_rnn_call(dy.device, armed, lambda: lib.ds2_rnn_bwd_ex(
+        _ctxp(dy.device), gates, dy.data_ptr(), _row_pitch(dy), _ptr(gx), aux.data_ptr(), hbuf.data_ptr(), wp_bwd.data_ptr(),
+        lens_dev.data_ptr(), T, B, H, int(bf16), _ptr(dgx_bf16), _ptr(gates_bf16), _ptr(dhn_bf16), _ptr(bias_part),
+        ws.data_ptr(), wsb, _stream())), "ds2_rnn_bwd")
 
 
 def bn1d_bwd_sums(dY: Tensor, X: Tensor, mean: Tensor, var: Tensor, gamma: Tensor, out: Optional[Tuple[Tensor, Tensor]] = None) -> Tuple[Tensor, Tensor]:
@@ -1148,12 +1160,12 @@ def rnn_bwd_bn(gates: int, dyn: Tensor, bn_x: Tensor, mean: Tensor, var: Tensor,
     assert bn_x.stride(1) == 1 and (not xbf or bn_x.shape[1] == H or bn_x.stride(0) % 2 == 0)
     lib = _lib.load()
     wsb = lib.ds2_rnn_bwd_workspace_bytes(gates, B, H, int(bf16))
-    ws = _take_ws(ws, wsb, dyn.device)
+    ws, armed = _take_ws(ws, wsb, dyn.device)
     def call(scratch):
-        return (lib.ds2_rnn_bwd_bn_xbf16 if xbf else lib.ds2_rnn_bwd_bn)(_ctxp(dyn.device), gates, dyn.data_ptr(), _row_pitch(dyn), bn_x.data_ptr(), bn_x.stride(0), mean.data_ptr(), var.data_ptr(),
+        return _rnn_call(dyn.device, armed and scratch is None, lambda: (lib.ds2_rnn_bwd_bn_xbf16 if xbf else lib.ds2_rnn_bwd_bn)(_ctxp(dyn.device), gates, dyn.data_ptr(), _row_pitch(dyn), bn_x.data_ptr(), bn_x.stride(0), mean.data_ptr(), var.data_ptr(),
                                   gamma.data_ptr(), s0.data_ptr(), s1.data_ptr(), BN_EPS, _ptr(scratch), _ptr(gx), aux.data_ptr(),
                                   hbuf.data_ptr(), wp_bwd.data_ptr(), lens_dev.data_ptr(), T, B, H, int(bf16), _ptr(dgx_bf16), _ptr(gates_bf16),
-                                  _ptr(dhn_bf16), _ptr(bias_part), ws.data_ptr(), wsb, _stream())
+                                  _ptr(dhn_bf16), _ptr(bias_part), ws.data_ptr(), wsb, _stream()))
     rc = call(None)                  # the fused K-split launch needs no scratch: the (T*B, H) fp32 buffer is allocated only on the fallback (rc 1)
     if rc == 1:
         rc = call(torch.empty(T * B, H, dtype=torch.float32, device=dyn.device))
