@@ -465,3 +465,54 @@ def test_dp_mode_auto_measures_both_schedules_and_settles(tmp_path):
     assert rep["schedule_chosen"] in ("conv", "serial") and a["modes"][-1] == rep["schedule_chosen"], a
     assert rep["measured_over_steps"] == {"conv": 2, "serial": 2} and min(rep["backward_with_comm_ms"].values()) > 0, rep
     assert a["starved"] == 0 and a["losses"] == res["conv"]["losses"] and a["weights_sha"] == res["conv"]["weights_sha"]
+
+
+DP_AUTO_WORKER = r'''
+import os, sys, json, hashlib
+import numpy as np, torch, torch.distributed as dist
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests")); sys.path.insert(0, os.path.join(root, "tests", "golden"))
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)             # two ranks share the one GPU: gloo moves the CUDA buckets
+import bench
+from test_gpu_model import make_model
+from asr_amd import CTCLoss, FusedAdamW
+from asr_amd.trainers import DeepSpeechTrainer
+B, tin, C = 16, 101, 29
+dev = torch.device("cuda", 0)
+torch.manual_seed(0)
+model = make_model(dict(rnn="gru", hidden=128, layers=2, classes=C))
+model.precision = "bf16"
+opt = FusedAdamW(model, lr=1.5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5)
+tr = DeepSpeechTrainer(model, CTCLoss(reduction="sum"), 1, None, opt, None, None, dev, dev, False, None)
+modes = []
+for k in range(7):
+    x, t, p, z = bench.synthetic_batch(B, tin, C, 100 * rank + 1 + 2 * k)
+    v, lv = tr.step((x.cuda(), t, p.clone(), z))
+    assert v
+    modes.append(tr._get_reducer().mode)
+tr.synchronize()
+red = tr._get_reducer()
+flat, _ = model.flat_parameters()
+print("DPAUTO_JSON " + json.dumps({"rank": rank, "modes": modes, "report": red.auto_report, "still_auto": red.auto,
+                                   "sha": hashlib.sha256(flat.detach().cpu().numpy().tobytes()).hexdigest()}))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_dp_mode_auto_two_ranks_agree(tmp_path):
+    """DS2_DP_MODE=auto with two ranks (gloo, one GPU): the measured spans are MAX-reduced, so both ranks switch schedules at the same steps and
+    settle on the same one; the replicas stay bit-identical through the schedule changes."""
+    script = str(tmp_path / "w.py")
+    open(script, "w").write(DP_AUTO_WORKER)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29655", HSA_ENABLE_IPC_MODE_LEGACY="0", DS2_DP_MODE="auto")
+        procs.append(subprocess.Popen([sys.executable, script, ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    recs = sorted((json.loads([l for l in o.splitlines() if l.startswith("DPAUTO_JSON ")][-1][len("DPAUTO_JSON "):]) for o in outs), key=lambda d: d["rank"])
+    assert recs[0]["modes"] == recs[1]["modes"] and recs[0]["modes"][:4] == ["conv", "conv", "serial", "serial"], recs
+    assert recs[0]["report"] == recs[1]["report"] and recs[0]["report"]["schedule_chosen"] == recs[0]["modes"][-1] and not recs[0]["still_auto"], recs
+    assert recs[0]["sha"] == recs[1]["sha"]
