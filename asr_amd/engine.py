@@ -104,9 +104,10 @@ F32_CONV_FWD = _tune("DS2_F32_CONV_FWD", "f32")
 # gradient already take (time-major LDS images filled by DMA; no padded copies of a1 / dY2 are written any more); "pad" = the round-2 kernel
 # on zero-padded (B,32,D,Tp) copies (eight pre-shifted dY copies in LDS).  A/B: profiles/r05_conv_ab.txt.
 CONV2_WGRAD = _tune("DS2_CONV2_WGRAD", "nhwc")
-# bf16 training, the x-projections of a recurrent layer (DS2_GX_BF16, default 1): the projection GEMM rounds its fp32 accumulators (+ bias) to
-# bf16 at the store and the forward recurrence reads that — 394 MB written + read per c3 layer instead of 788 (ops.gemm_bf16_nt_obf16; the gates
-# are saved as bf16 records anyway).  0: fp32 x-projections as rounds 1-5.  A/B and parity deltas: profiles/r06_gx_bf16_ab.txt.
+# bf16 training, the x-projections of a recurrent layer (DS2_GX_BF16, default 0 — an experiment of round 6 that was measured and NOT taken): =1
+# makes the projection GEMM round its fp32 accumulators (+ bias) to bf16 at the store and the forward recurrence read that — 394 MB written + read
+# per c3 layer instead of 788 (ops.gemm_bf16_nt_obf16).  The projection gets as fast as dX (395 -> 367 us) but the recurrence pays +0.05 us per time
+# step for the 2-byte operand: net -0.06 ms per step for one more rounding of every gate pre-activation (profiles/r06_experiments.txt).
 GX_BF16 = _tune("DS2_GX_BF16", "0") != "0"
 # the workspace of a recurrence call (exchange buffers of a persistent launch: every byte 0xff) is armed AHEAD of the GEMM in front of the
 # recurrence (ops.rnn_ws) instead of by a fill launched between that GEMM and the recurrence (DS2_WS_PREARM=0: as rounds 1-5)
