@@ -372,8 +372,10 @@ def forward(W: Dict[str, Tensor], cfg: ModelCfg, x: Tensor, lens_dev: Tensor, tr
             del w_bf
         elif _f32_split_ok(M, 2 * G * H, xn.shape[1], H):
             # three-term split-bf16 product as ONE NT GEMM over a reduction index 3 I long: [hi | hi | lo] x [hi | lo | hi]^T
-            lc.xs = ops.split_bf16(xn, 0)
-            gx = ops.gemm_bf16_nt(lc.xs, ops.split_bf16(W[f"rnns.{l}.wih_cat"], 1), bias=W[f"rnns.{l}.bih_cat"])
+            # (rows padded with zeros to a multiple of the TN kernels' 64-deep k-tile: as the K-row-major operand of dW_ih in backward the split
+            #  copy then has a reduction length the four-wave kernel takes — T * B = 16032 at c2, 24032 at c4)
+            lc.xs = ops.split_bf16(xn, 0, pad_rows=64 if save else 0)
+            gx = ops.gemm_bf16_nt(lc.xs[:M], ops.split_bf16(W[f"rnns.{l}.wih_cat"], 1), bias=W[f"rnns.{l}.bih_cat"])
             if save:
                 xn = None                                        # backward takes dW_ih from the split copy (6 bytes per element instead of 4 + 6)
         else:
@@ -744,9 +746,9 @@ def backward(W: Dict[str, Tensor], Gr: Dict[str, Tensor], cfg: ModelCfg, ctx: Ct
             del dgx_r
         elif split:
             # dXn = dGx W_ih as [hi | hi | lo](dGx) x [hi | lo | hi](W_ih^T)^T; the split copy of dGx also feeds both weight-gradient products
-            dgs = ops.split_bf16(dgx, 0)                                                          # (M, 3 * 2GH)
+            dgs = ops.split_bf16(dgx, 0, pad_rows=64)                                             # (M rounded up to 64 like lc.xs, 3 * 2GH)
             wT = ops.transpose_batched(W[f"rnns.{l}.wih_cat"].unsqueeze(0))[0]                    # (I, 2GH)
-            dxn = ops.gemm_bf16_nt(dgs, ops.split_bf16(wT, 1))
+            dxn = ops.gemm_bf16_nt(dgs[:M], ops.split_bf16(wT, 1))
             del wT
         else:
             dxn = ops.gemm(dgx, W[f"rnns.{l}.wih_cat"])                                           # (M, I)

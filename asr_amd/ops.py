@@ -389,15 +389,21 @@ def gemm_bf16_tn_pair(A0: Tensor, A1: Tensor, B0: Tensor, B1: Tensor, out: Tenso
     return out
 
 
-def split_bf16(X: Tensor, order: int) -> Tensor:
+def split_bf16(X: Tensor, order: int, pad_rows: int = 0) -> Tensor:
     """fp32 (R, C) row-major view -> its split bf16 operand (R, n * pad8(C)): x = hi + lo, hi = bf16(x), lo = bf16(x - hi); order 0 = [hi | hi | lo]
-    (A operand of the fp32 mode's three-term product), 1 = [hi | lo | hi] (B operand), 2 = [hi | lo] (TN products).  See ds2_split_bf16."""
+    (A operand of the fp32 mode's three-term product), 1 = [hi | lo | hi] (B operand), 2 = [hi | lo] (TN products).  See ds2_split_bf16.
+    pad_rows: the result has its row count rounded up to a multiple of it, the extra rows ZERO — as the K-row-major operand of a TN product
+    (reduction index = rows) it then has a reduction length the four-wave kernel takes (K % 64 == 0), and the zero rows add nothing."""
     _chk_f32(X)
     assert X.dim() == 2 and X.stride(1) == 1 and order in (0, 1, 2)
     R, Cc = X.shape
     Cp = (Cc + 7) // 8 * 8
-    out = torch.empty(R, (2 if order == 2 else 3) * Cp, dtype=torch.bfloat16, device=X.device)
-    _lib.check(_lib.load().ds2_split_bf16(X.data_ptr(), _row_pitch(X), out.data_ptr(), out.stride(0), R, Cc, order, _stream()), "ds2_split_bf16")
+    Rp = -(-R // pad_rows) * pad_rows if pad_rows else R
+    out = torch.empty(Rp, (2 if order == 2 else 3) * Cp, dtype=torch.bfloat16, device=X.device)
+    lib = _lib.load()
+    if Rp > R:
+        _lib.check(lib.ds2_memset_async(out[R:].data_ptr(), 0, (Rp - R) * out.stride(0) * 2, _stream()), "ds2_memset_async")
+    _lib.check(lib.ds2_split_bf16(X.data_ptr(), _row_pitch(X), out.data_ptr(), out.stride(0), R, Cc, order, _stream()), "ds2_split_bf16")
     return out
 
 
